@@ -1,0 +1,147 @@
+/*
+ * helm.h -- C ABI of libhelm: MI355X-native frequency-domain Helmholtz operator
+ *           (assemble the 9-point PML-damped complex stencil, apply it, and solve
+ *           A(w) u = q for many right-hand sides with matrix-free Krylov on the GPU).
+ *
+ * This is the drop-in boundary for the hot path of uwoseis/zephyr's backend.  Each entry
+ * point names the reference interface it replaces (paths relative to the reference tree):
+ *
+ *   helm_create / helm_set_model   <- BaseModelDependent / BaseDiscretization config ingestion
+ *                                     zephyr/backend/base.py:11-109, discretization.py:23-76
+ *   helm_assemble                  <- MiniZephyr._initHelmholtzNinePoint  minizephyr.py:40-298
+ *                                     Eurus._initHelmholtzNinePoint       eurus.py:28-485
+ *   helm_get_diagonals             <- the `.A` property                   minizephyr.py:300-306, eurus.py:487-492
+ *   helm_apply[_device]            <- `A * x` (scipy CSR product)         used by tests / parity
+ *   helm_solve[_device]            <- BaseDiscretization.__mul__          discretization.py:78-106
+ *                                     (problemo.BestSolver LU + premul + conjugate),
+ *                                     Eurus.__mul__ pad/clip              eurus.py:512-533
+ *   helm_imaging_accumulate_device <- zero-lag imaging condition in HelmBaseProblem.Jtvec
+ *                                     zephyr/middleware/problem.py:152,162
+ *   helm_destroy                   <- `del obj.factors` / __del__         discretization.py:86-99
+ *
+ * Conventions
+ *   - complex128 values are interleaved (re, im) doubles; a field is the row-major (nz, nx)
+ *     ravel of the reference (linear index iz*nx + ix, base.py:93).
+ *   - multi-RHS buffers hold each right-hand side contiguously: X[r*rows + i]   (the Python
+ *     host passes np.ascontiguousarray(rhs.T)).
+ *   - coefficient planes: C[block][k][iz*nx+ix], k = 3*(dz+1) + (dx+1), meaning
+ *     (A x)[iz,ix] = sum_k C[k][iz,ix] * x[iz+dz, ix+dx].  MiniZephyr has 1 block, Eurus 4
+ *     (M1, M2, M3, M4 of the 2N x 2N system, eurus.py:430-464).
+ *   - every function returns an int status: 0 = ok, > 0 = number of right-hand sides that
+ *     did not reach the tolerance (helm_solve only), < 0 = hard error (HELM_ERR_*); the text
+ *     is available from helm_last_error().  No exceptions cross this boundary.
+ *   - the caller owns host buffers; the library owns all device memory behind the handle.
+ *     `_device` variants take device pointers valid on the handle's GPU.
+ *   - a handle is bound to one GPU and must be used by one host thread at a time.
+ */
+#ifndef HELM_H
+#define HELM_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct helm_op helm_op;
+
+/* discretisation variants */
+enum { HELM_MINIZEPHYR = 0, HELM_EURUS = 1 };
+
+/* Krylov methods */
+enum { HELM_BICGSTAB = 0, HELM_CGNR = 1, HELM_AUTO = 2 /* BiCGSTAB, CGNR for RHS that break down */ };
+
+/* hard errors */
+enum {
+    HELM_OK = 0,
+    HELM_ERR_ARG = -1,         /* bad argument / dimension mismatch (reference: ValueError) */
+    HELM_ERR_DEVICE = -2,      /* HIP runtime failure (no GPU, allocation, launch) */
+    HELM_ERR_STATE = -3,       /* call order: model/assemble missing */
+    HELM_ERR_UNSUPPORTED = -4, /* configuration outside the supported path */
+    HELM_ERR_PML = -5          /* Eurus PML profile length hazard (reference raises ValueError, eurus.py:84-91) */
+};
+
+typedef struct helm_solve_opts {
+    int method;        /* HELM_BICGSTAB | HELM_CGNR | HELM_AUTO */
+    double rtol;       /* stop when ||q' - A u||_2 / ||q'||_2 <= rtol (q' = premul*rhs), per RHS */
+    int maxit;         /* iteration cap per right-hand side */
+    int check_every;   /* iterations between host-side convergence checks (0 = default) */
+    int batch;         /* right-hand sides iterated together on the device (0 = default) */
+    int flags;         /* reserved, 0 */
+} helm_solve_opts;
+
+typedef struct helm_solve_info {
+    int iterations;    /* iterations used by this right-hand side */
+    int status;        /* 0 converged, 1 iteration cap, 2 breakdown (not recovered) */
+    int restarts;      /* BiCGSTAB restarts taken */
+    int method;        /* method that produced the returned wavefield */
+    double relres;     /* final TRUE relative residual ||q' - A u|| / ||q'|| (unscaled system) */
+} helm_solve_info;
+
+/* --- lifecycle ------------------------------------------------------------------------ */
+int helm_device_count(void);                   /* < 0 on HIP failure */
+const char *helm_version(void);
+
+/* freeSurf: 4 ints, reference order [iz=0 side, ix=nx-1 side, iz=nz-1 side, ix=0 side]
+ * (minizephyr.py:103-115,269-298); ignored by Eurus as in the reference.
+ * Returns NULL on failure; helm_last_error(NULL) holds the reason. */
+helm_op *helm_create(int device, int variant, int nz, int nx, double dx, double dz,
+                     int nPML, const int *freeSurf);
+void helm_destroy(helm_op *op);
+const char *helm_last_error(const helm_op *op);
+
+/* Use an existing hipStream_t (e.g. torch's current stream) for all work; NULL = own stream. */
+int helm_set_stream(helm_op *op, void *hip_stream);
+
+/* --- model and assembly --------------------------------------------------------------- */
+/* c: N complex; rho: N doubles or NULL (Gardner 310*Re(c)^0.25, discretization.py:70);
+ * theta/eps/delta: N doubles each or NULL (zeros), Eurus only (base.py:112-149). */
+int helm_set_model(helm_op *op, const double *c, const double *rho,
+                   const double *theta, const double *eps, const double *delta);
+
+/* freq complex (Hz); tau Laplace damping time constant (inf = none); ky cross-line wavenumber
+ * (MiniZephyr only); cPML Eurus C-PML amplitude (eurus.py:500-504). */
+int helm_assemble(helm_op *op, double freq_re, double freq_im, double tau, double ky, double cPML);
+
+int helm_num_blocks(const helm_op *op);        /* 1 (MiniZephyr) or 4 (Eurus) */
+long long helm_num_points(const helm_op *op);  /* N = nz*nx */
+
+/* out: num_blocks * 9 * N complex, layout C[block][k][i] */
+int helm_get_diagonals(helm_op *op, double *out);
+
+/* --- operator application (parity / microbenchmark) ----------------------------------- */
+/* Y[r] = M_block X[r], r < nrhs; adjoint != 0 applies the conjugate transpose. */
+int helm_apply(helm_op *op, int block, int adjoint, const double *X, double *Y, int nrhs);
+int helm_apply_device(helm_op *op, int block, int adjoint, const void *dX, void *dY, int nrhs);
+
+/* --- solve ---------------------------------------------------------------------------- */
+/* U[r] = conj( A^-1 (premul * RHS[r]) ).  rows = N, or 2N for Eurus stacked right-hand sides
+ * (eurus.py:512-533: N-row input is zero-padded and the result clipped to N rows; 2N-row input
+ * returns 2N rows).  info: nrhs entries or NULL.  opts NULL = defaults. */
+int helm_solve(helm_op *op, const double *RHS, double *U, int nrhs, long long rows,
+               double premul_re, double premul_im,
+               const helm_solve_opts *opts, helm_solve_info *info);
+int helm_solve_device(helm_op *op, const void *dRHS, void *dU, int nrhs, long long rows,
+                      double premul_re, double premul_im,
+                      const helm_solve_opts *opts, helm_solve_info *info);
+
+/* Timing of the last solve/apply on this handle, measured with HIP events on the handle's
+ * stream: total ms, and ms / launches / algorithmic bytes of the stencil-apply kernel. */
+typedef struct helm_timing {
+    double solve_ms;
+    double apply_ms;
+    long long apply_launches;
+    double apply_bytes;      /* sum over launches of N*(32*B + 144) */
+} helm_timing;
+int helm_last_timing(const helm_op *op, helm_timing *out);
+/* enable per-launch HIP-event timing of the stencil kernel inside solves (costs a little) */
+int helm_set_profiling(helm_op *op, int on);
+
+/* --- FWI imaging condition ------------------------------------------------------------ */
+/* G[i] += scaler[i] * sum_{s<nsrc} UF[s][i] * UB[s][i]   (complex, no conjugation;
+ * problem.py:152).  scaler: N complex (= -w^2/c^3).  All device pointers. */
+int helm_imaging_accumulate_device(helm_op *op, const void *dUF, const void *dUB, int nsrc,
+                                   const void *dScaler, void *dG);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HELM_H */

@@ -1,0 +1,21 @@
+"""zephyr_amd -- MI355X-native frequency-domain Helmholtz forward solver behind Zephyr's
+backend operator API (`Disc(systemConfig) * rhs`, `MultiFreq(systemConfig) * rhs`).
+
+Host classes mirror zephyr.backend; all assembly and solves run in libhelm (HIP, gfx950).
+"""
+from .analytical import AnalyticalHelmholtz
+from .base import BaseModelDependent, BaseAnisotropic
+from .config import AttributeMapper, BaseSCCache, SCFilter
+from .discretization import BaseDiscretization, DiscretizationWrapper
+from .distributors import BaseDist, BaseMPDist, MultiFreq, SerialMultiFreq, ViscoMultiFreq
+from .eurus import Eurus, EurusHD
+from .minizephyr import MiniZephyr, MiniZephyrHD
+from .source import (FakeSource, SimpleSource, StackedSimpleSource, SparseKaiserSource, KaiserSource,
+                     AnisotropicKaiserSource)
+
+__all__ = [
+    'AnalyticalHelmholtz', 'BaseModelDependent', 'BaseAnisotropic', 'AttributeMapper', 'BaseSCCache', 'SCFilter',
+    'BaseDiscretization', 'DiscretizationWrapper', 'BaseDist', 'BaseMPDist', 'MultiFreq', 'SerialMultiFreq',
+    'ViscoMultiFreq', 'Eurus', 'EurusHD', 'MiniZephyr', 'MiniZephyrHD', 'FakeSource', 'SimpleSource',
+    'StackedSimpleSource', 'SparseKaiserSource', 'KaiserSource', 'AnisotropicKaiserSource',
+]

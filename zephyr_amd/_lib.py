@@ -1,0 +1,121 @@
+"""ctypes binding of libhelm.so (C ABI declared in include/helm.h).
+
+The library is built in-tree by `__graft_entry__.build()` (hipcc --offload-arch=gfx950).
+There is NO CPU fallback: importing the operators without the built library, or using
+them without a GPU, raises.
+"""
+import ctypes
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libhelm.so')
+
+HELM_MINIZEPHYR, HELM_EURUS = 0, 1
+HELM_BICGSTAB, HELM_CGNR, HELM_AUTO = 0, 1, 2
+METHODS = {'bicgstab': HELM_BICGSTAB, 'cgnr': HELM_CGNR, 'auto': HELM_AUTO}
+
+ERRORS = {-1: 'HELM_ERR_ARG', -2: 'HELM_ERR_DEVICE', -3: 'HELM_ERR_STATE', -4: 'HELM_ERR_UNSUPPORTED', -5: 'HELM_ERR_PML'}
+
+
+class HelmError(RuntimeError):
+    def __init__(self, code, text):
+        self.code = code
+        RuntimeError.__init__(self, '%s: %s' % (ERRORS.get(code, code), text))
+
+
+class SolveOpts(ctypes.Structure):
+    _fields_ = [('method', ctypes.c_int), ('rtol', ctypes.c_double), ('maxit', ctypes.c_int),
+                ('check_every', ctypes.c_int), ('batch', ctypes.c_int), ('flags', ctypes.c_int)]
+
+
+class SolveInfo(ctypes.Structure):
+    _fields_ = [('iterations', ctypes.c_int), ('status', ctypes.c_int), ('restarts', ctypes.c_int),
+                ('method', ctypes.c_int), ('relres', ctypes.c_double)]
+
+
+class Timing(ctypes.Structure):
+    _fields_ = [('solve_ms', ctypes.c_double), ('apply_ms', ctypes.c_double),
+                ('apply_launches', ctypes.c_longlong), ('apply_bytes', ctypes.c_double)]
+
+
+# every symbol include/helm.h declares, with its ctypes signature
+_c_dp = ctypes.POINTER(ctypes.c_double)
+_SIGNATURES = {
+    'helm_device_count': (ctypes.c_int, []),
+    'helm_version': (ctypes.c_char_p, []),
+    'helm_create': (ctypes.c_void_p, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                      ctypes.c_double, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
+    'helm_destroy': (None, [ctypes.c_void_p]),
+    'helm_last_error': (ctypes.c_char_p, [ctypes.c_void_p]),
+    'helm_set_stream': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    'helm_set_model': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_void_p, ctypes.c_void_p]),
+    'helm_assemble': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                     ctypes.c_double, ctypes.c_double]),
+    'helm_num_blocks': (ctypes.c_int, [ctypes.c_void_p]),
+    'helm_num_points': (ctypes.c_longlong, [ctypes.c_void_p]),
+    'helm_get_diagonals': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    'helm_apply': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
+    'helm_apply_device': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
+    'helm_solve': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong,
+                                  ctypes.c_double, ctypes.c_double, ctypes.POINTER(SolveOpts), ctypes.POINTER(SolveInfo)]),
+    'helm_solve_device': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong,
+                                         ctypes.c_double, ctypes.c_double, ctypes.POINTER(SolveOpts), ctypes.POINTER(SolveInfo)]),
+    'helm_last_timing': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Timing)]),
+    'helm_set_profiling': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    'helm_imaging_accumulate_device': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                                      ctypes.c_void_p, ctypes.c_void_p]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def load():
+    """Load libhelm.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError('libhelm.so not found at %s: run `python -c "import __graft_entry__ as g; g.build()"` '
+                              '(hipcc --offload-arch=gfx950).  There is no CPU fallback.' % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def last_error(handle=None):
+    msg = load().helm_last_error(handle)
+    return msg.decode() if msg else ''
+
+
+def check(rc, handle=None):
+    if rc < 0:
+        raise HelmError(rc, last_error(handle))
+    return rc
+
+
+def require_gpu():
+    n = load().helm_device_count()
+    if n <= 0:
+        raise HelmError(-2, 'no HIP device visible (%s); libhelm has no CPU path' % last_error(None))
+    return n
+
+
+def ptr(arr):
+    return arr.ctypes.data_as(ctypes.c_void_p) if arr is not None else None
+
+
+def c128(arr):
+    return np.ascontiguousarray(arr, dtype=np.complex128)
+
+
+def f64(arr):
+    return np.ascontiguousarray(arr, dtype=np.float64)

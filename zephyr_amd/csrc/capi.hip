@@ -1,0 +1,579 @@
+// C ABI of libhelm (see include/helm.h) and the host-side Krylov drivers.
+//
+// The drivers only enqueue kernels: all vectors and all scalar recurrences stay on the device;
+// the host looks at the per-RHS status records every `check_every` iterations.
+#include "helm_internal.hpp"
+#include <cstring>
+#include <algorithm>
+#include <limits>
+
+// launchers from kernels.hip not in the shared header
+int helm_launch_fin_ex(helm_op *op, int which, int nrhs, int nblk_part, const int *mask, double *aux);
+int helm_launch_restart_copy_mask(helm_op *op, VecPtrs w, int nrhs, const int *mask);
+int helm_launch_norm2(helm_op *op, const cplx *a, int nrhs);
+
+static std::string g_last_error;
+
+void helm_set_error(helm_op *op, const char *msg) {
+    if (op) op->err = msg;
+    g_last_error = msg;
+}
+
+extern "C" const char *helm_last_error(const helm_op *op) { return op ? op->err.c_str() : g_last_error.c_str(); }
+extern "C" const char *helm_version(void) { return "libhelm 0.1 (gfx950)"; }
+
+extern "C" int helm_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { helm_set_error(nullptr, hipGetErrorString(e)); return HELM_ERR_DEVICE; }
+    return n;
+}
+
+#define HIP_TRY_NULL(call) do { hipError_t _e = (call); if (_e != hipSuccess) { char _b[256]; \
+    snprintf(_b, sizeof(_b), "%s failed: %s", #call, hipGetErrorString(_e)); helm_set_error(nullptr, _b); delete op; return nullptr; } } while (0)
+
+extern "C" helm_op *helm_create(int device, int variant, int nz, int nx, double dx, double dz, int nPML, const int *freeSurf) {
+    if (nz < 3 || nx < 3) { helm_set_error(nullptr, "nz and nx must be >= 3"); return nullptr; }
+    if (variant != HELM_MINIZEPHYR && variant != HELM_EURUS) { helm_set_error(nullptr, "unknown variant"); return nullptr; }
+    if (!(dx > 0) || !(dz > 0)) { helm_set_error(nullptr, "dx and dz must be positive"); return nullptr; }
+    helm_op *op = new helm_op();
+    op->device = device; op->variant = variant; op->nz = nz; op->nx = nx; op->N = (long long)nz * nx;
+    op->dx = dx; op->dz = dz; op->nPML = nPML;
+    if (freeSurf) for (int i = 0; i < 4; ++i) op->fs[i] = freeSurf[i] ? 1 : 0;
+    op->nblocks = variant == HELM_EURUS ? 4 : 1;
+    HIP_TRY_NULL(hipSetDevice(device));
+    HIP_TRY_NULL(hipStreamCreateWithFlags(&op->stream, hipStreamNonBlocking));
+    op->own_stream = true;
+    const size_t N = (size_t)op->N;
+    HIP_TRY_NULL(hipMalloc(&op->d_c, N * sizeof(cplx)));
+    HIP_TRY_NULL(hipMalloc(&op->d_rho, N * sizeof(double)));
+    HIP_TRY_NULL(hipMalloc(&op->d_C, (size_t)op->nblocks * 9 * N * sizeof(cplx)));
+    HIP_TRY_NULL(hipMalloc(&op->d_Cs, (size_t)op->nblocks * 9 * N * sizeof(cplx)));
+    HIP_TRY_NULL(hipMalloc(&op->d_dinv, (size_t)op->nblocks * N * sizeof(cplx)));
+    return op;
+}
+
+extern "C" void helm_destroy(helm_op *op) {
+    if (!op) return;
+    hipSetDevice(op->device);
+    if (op->stream) hipStreamSynchronize(op->stream);
+    hipFree(op->d_c); hipFree(op->d_rho); hipFree(op->d_theta); hipFree(op->d_eps); hipFree(op->d_delta);
+    hipFree(op->d_C); hipFree(op->d_Cs); hipFree(op->d_dinv);
+    hipFree(op->d_ws); hipFree(op->d_part); hipFree(op->d_scal);
+    if (op->h_scal) hipHostFree(op->h_scal);
+    for (hipEvent_t e : op->ev_pool) hipEventDestroy(e);
+    if (op->own_stream && op->stream) hipStreamDestroy(op->stream);
+    delete op;
+}
+
+extern "C" int helm_set_stream(helm_op *op, void *hip_stream) {
+    if (!op) return HELM_ERR_ARG;
+    HIP_TRY(op, hipSetDevice(op->device));
+    if (op->stream) HIP_TRY(op, hipStreamSynchronize(op->stream));
+    if (op->own_stream && op->stream) { hipStreamDestroy(op->stream); op->own_stream = false; }
+    if (hip_stream) { op->stream = (hipStream_t)hip_stream; op->own_stream = false; }
+    else { HIP_TRY(op, hipStreamCreateWithFlags(&op->stream, hipStreamNonBlocking)); op->own_stream = true; }
+    return HELM_OK;
+}
+
+extern "C" int helm_set_profiling(helm_op *op, int on) { if (!op) return HELM_ERR_ARG; op->profiling = on != 0; return HELM_OK; }
+extern "C" int helm_last_timing(const helm_op *op, helm_timing *out) { if (!op || !out) return HELM_ERR_ARG; *out = op->timing; return HELM_OK; }
+extern "C" int helm_num_blocks(const helm_op *op) { return op ? op->nblocks : HELM_ERR_ARG; }
+extern "C" long long helm_num_points(const helm_op *op) { return op ? op->N : HELM_ERR_ARG; }
+
+extern "C" int helm_set_model(helm_op *op, const double *c, const double *rho, const double *theta, const double *eps, const double *delta) {
+    if (!op || !c) return HELM_ERR_ARG;
+    HIP_TRY(op, hipSetDevice(op->device));
+    const size_t N = (size_t)op->N;
+    HIP_TRY(op, hipMemcpyAsync(op->d_c, c, N * sizeof(cplx), hipMemcpyHostToDevice, op->stream));
+    std::vector<double> gard;
+    if (!rho) {   // Gardner default 310 * Re(c)^0.25  (discretization.py:70)
+        gard.resize(N);
+        for (size_t i = 0; i < N; ++i) gard[i] = 310.0 * pow(c[2 * i], 0.25);
+        rho = gard.data();
+    }
+    HIP_TRY(op, hipMemcpyAsync(op->d_rho, rho, N * sizeof(double), hipMemcpyHostToDevice, op->stream));
+    op->aniso = false;
+    bool m3zero = true;
+    if (op->variant == HELM_EURUS) {
+        auto up = [&](double *&dst, const double *src) -> int {
+            if (!src) { if (dst) { hipFree(dst); dst = nullptr; } return 0; }
+            if (!dst) { if (hipMalloc(&dst, N * sizeof(double)) != hipSuccess) return -1; }
+            if (hipMemcpyAsync(dst, src, N * sizeof(double), hipMemcpyHostToDevice, op->stream) != hipSuccess) return -1;
+            return 0;
+        };
+        if (up(op->d_theta, theta) || up(op->d_eps, eps) || up(op->d_delta, delta)) HELM_FAIL(op, HELM_ERR_DEVICE, "anisotropy upload failed");
+        op->aniso = theta || eps || delta;
+        for (size_t i = 0; i < N && m3zero; ++i) {
+            const double e = eps ? eps[i] : 0.0, d = delta ? delta[i] : 0.0;
+            if (e != d) m3zero = false;
+        }
+    }
+    HIP_TRY(op, hipStreamSynchronize(op->stream));
+    op->block_zero[0] = op->block_zero[1] = op->block_zero[3] = false;
+    op->block_zero[2] = m3zero;
+    op->has_model = true;
+    op->assembled = false;
+    return HELM_OK;
+}
+
+extern "C" int helm_assemble(helm_op *op, double freq_re, double freq_im, double tau, double ky, double cPML) {
+    if (!op) return HELM_ERR_ARG;
+    if (!op->has_model) HELM_FAIL(op, HELM_ERR_STATE, "helm_set_model must be called before helm_assemble");
+    HIP_TRY(op, hipSetDevice(op->device));
+    int rc = helm_launch_assemble(op, freq_re, freq_im, tau, ky, cPML);
+    if (rc) return rc;
+    rc = helm_launch_scale_planes(op);
+    if (rc) return rc;
+    HIP_TRY(op, hipStreamSynchronize(op->stream));
+    op->assembled = true;
+    return HELM_OK;
+}
+
+extern "C" int helm_get_diagonals(helm_op *op, double *out) {
+    if (!op || !out) return HELM_ERR_ARG;
+    if (!op->assembled) HELM_FAIL(op, HELM_ERR_STATE, "operator not assembled");
+    HIP_TRY(op, hipSetDevice(op->device));
+    HIP_TRY(op, hipMemcpy(out, op->d_C, (size_t)op->nblocks * 9 * op->N * sizeof(cplx), hipMemcpyDeviceToHost));
+    return HELM_OK;
+}
+
+// ---- workspace ------------------------------------------------------------------------------
+static int ensure_ws(helm_op *op, size_t bytes) {
+    if (op->ws_bytes >= bytes) return HELM_OK;
+    if (op->d_ws) { hipFree(op->d_ws); op->d_ws = nullptr; op->ws_bytes = 0; }
+    HIP_TRY(op, hipMalloc(&op->d_ws, bytes));
+    op->ws_bytes = bytes;
+    return HELM_OK;
+}
+static int ensure_part(helm_op *op, int nrhs) {
+    const int nblk = std::max(helm_apply_num_blocks(op), helm_vec_num_blocks(op));
+    const size_t bytes = (size_t)nrhs * 4 * nblk * sizeof(double) + (size_t)nrhs * (2 * sizeof(double) + sizeof(int)) + 256;
+    if (op->part_bytes < bytes) {
+        if (op->d_part) { hipFree(op->d_part); op->d_part = nullptr; op->part_bytes = 0; }
+        HIP_TRY(op, hipMalloc(&op->d_part, bytes));
+        op->part_bytes = bytes;
+    }
+    if (op->scal_cap < nrhs) {
+        if (op->d_scal) hipFree(op->d_scal);
+        if (op->h_scal) hipHostFree(op->h_scal);
+        op->d_scal = nullptr; op->h_scal = nullptr; op->scal_cap = 0;
+        HIP_TRY(op, hipMalloc(&op->d_scal, (size_t)nrhs * sizeof(RhsScal)));
+        HIP_TRY(op, hipHostMalloc((void **)&op->h_scal, (size_t)nrhs * sizeof(RhsScal) + (size_t)nrhs * (2 * sizeof(double) + sizeof(int)) + 64, hipHostMallocDefault));
+        op->scal_cap = nrhs;
+    }
+    return HELM_OK;
+}
+
+static void timing_begin(helm_op *op) {
+    op->ev_used = 0;
+    op->ev_pending.clear();
+    op->timing.apply_ms = 0; op->timing.apply_launches = 0; op->timing.apply_bytes = 0;
+}
+static void timing_collect(helm_op *op) {
+    for (auto &pr : op->ev_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, op->ev_pool[pr.first], op->ev_pool[pr.first + 1]) == hipSuccess) {
+            op->timing.apply_ms += ms; op->timing.apply_launches += 1; op->timing.apply_bytes += pr.second;
+        }
+    }
+    op->ev_pending.clear();
+    op->ev_used = 0;
+}
+
+// ---- apply -----------------------------------------------------------------------------------
+extern "C" int helm_apply_device(helm_op *op, int block, int adjoint, const void *dX, void *dY, int nrhs) {
+    if (!op || !dX || !dY || nrhs < 1 || block < 0 || block >= op->nblocks) return HELM_ERR_ARG;
+    if (!op->assembled) HELM_FAIL(op, HELM_ERR_STATE, "operator not assembled");
+    HIP_TRY(op, hipSetDevice(op->device));
+    timing_begin(op);
+    ApplyArgs a;
+    a.planes = op->d_C + (long long)block * 9 * op->N; a.X = (const cplx *)dX; a.Y = (cplx *)dY; a.W = nullptr;
+    a.ld = op->N; a.nrhs = nrhs; a.scaled = 0; a.adjoint = adjoint ? 1 : 0; a.epi = EPI_NONE; a.scal = nullptr; a.part = nullptr;
+    int rc = helm_launch_apply(op, a);
+    if (rc) return rc;
+    HIP_TRY(op, hipStreamSynchronize(op->stream));
+    timing_collect(op);
+    return HELM_OK;
+}
+
+extern "C" int helm_apply(helm_op *op, int block, int adjoint, const double *X, double *Y, int nrhs) {
+    if (!op || !X || !Y || nrhs < 1) return HELM_ERR_ARG;
+    HIP_TRY(op, hipSetDevice(op->device));
+    const size_t bytes = (size_t)nrhs * op->N * sizeof(cplx);
+    void *dX = nullptr, *dY = nullptr;
+    HIP_TRY(op, hipMalloc(&dX, bytes));
+    if (hipMalloc(&dY, bytes) != hipSuccess) { hipFree(dX); HELM_FAIL(op, HELM_ERR_DEVICE, "hipMalloc failed"); }
+    int rc = HELM_OK;
+    if (hipMemcpy(dX, X, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = HELM_ERR_DEVICE;
+    if (!rc) rc = helm_apply_device(op, block, adjoint, dX, dY, nrhs);
+    if (!rc && hipMemcpy(Y, dY, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = HELM_ERR_DEVICE;
+    hipFree(dX); hipFree(dY);
+    return rc;
+}
+
+// ---- Krylov drivers ---------------------------------------------------------------------------
+namespace {
+
+struct Batch {
+    int nrhs;
+    VecPtrs w;
+    cplx *bbar;
+    int *d_mask; double *d_aux;      // device, nrhs ints / 2*nrhs doubles (inside d_part tail)
+    int *h_mask; double *h_aux;      // pinned (inside h_scal tail)
+};
+
+int download_scal(helm_op *op, int nrhs) {
+    HIP_TRY(op, hipMemcpyAsync(op->h_scal, op->d_scal, (size_t)nrhs * sizeof(RhsScal), hipMemcpyDeviceToHost, op->stream));
+    HIP_TRY(op, hipStreamSynchronize(op->stream));
+    return HELM_OK;
+}
+int upload_scal(helm_op *op, int nrhs) {
+    HIP_TRY(op, hipMemcpyAsync(op->d_scal, op->h_scal, (size_t)nrhs * sizeof(RhsScal), hipMemcpyHostToDevice, op->stream));
+    return HELM_OK;
+}
+
+ApplyArgs scaled_apply(helm_op *op, int block, const cplx *X, cplx *Y, const cplx *W, int nrhs, int adjoint, int epi, bool masked) {
+    ApplyArgs a;
+    a.planes = op->d_Cs + (long long)block * 9 * op->N; a.X = X; a.Y = Y; a.W = W; a.ld = op->N; a.nrhs = nrhs;
+    a.scaled = 1; a.adjoint = adjoint; a.epi = epi; a.scal = masked ? op->d_scal : nullptr; a.part = (double *)op->d_part;
+    return a;
+}
+
+// Restart the right-hand sides flagged in h_mask from their current iterate x:
+// r = bbar - Abar x, r0 = r, p = v = 0, scalars reset.  Host copy of scal must be fresh.
+int restart_masked(helm_op *op, int block, Batch &B) {
+    const int n = B.nrhs;
+    for (int b = 0; b < n; ++b) {
+        if (B.h_mask[b]) op->h_scal[b].status = ST_ACTIVE;
+        else if (op->h_scal[b].status == ST_ACTIVE) op->h_scal[b].status = ST_PARKED;
+    }
+    int rc = upload_scal(op, n);
+    if (rc) return rc;
+    HIP_TRY(op, hipMemcpyAsync(B.d_mask, B.h_mask, n * sizeof(int), hipMemcpyHostToDevice, op->stream));
+    rc = helm_launch_apply(op, scaled_apply(op, block, B.w.x, B.w.r, B.bbar, n, 0, EPI_RESID, true));
+    if (rc) return rc;
+    helm_launch_restart_copy_mask(op, B.w, n, B.d_mask);
+    helm_launch_fin_ex(op, FIN_RESTART, n, helm_apply_num_blocks(op), B.d_mask, nullptr);
+    HIP_TRY(op, hipGetLastError());
+    return HELM_OK;
+}
+
+int run_bicgstab(helm_op *op, int block, Batch &B, int maxit, int check_every, int max_restarts, std::vector<int> &restarts) {
+    const int n = B.nrhs;
+    const int nba = helm_apply_num_blocks(op), nbv = helm_vec_num_blocks(op);
+    int it_done = 0;
+    while (true) {
+        int rc = download_scal(op, n);
+        if (rc) return rc;
+        bool any_active = false, any_break = false;
+        int min_iters = std::numeric_limits<int>::max();
+        for (int b = 0; b < n; ++b) {
+            B.h_mask[b] = 0;
+            RhsScal &S = op->h_scal[b];
+            if (S.status == ST_ACTIVE) {
+                if (S.iters >= maxit) S.status = ST_FROZEN;   // iteration cap: stop working on it
+                else { any_active = true; min_iters = std::min(min_iters, S.iters); }
+            } else if (S.status == ST_BREAKDOWN && restarts[b] < max_restarts && S.iters < maxit) {
+                B.h_mask[b] = 1; any_break = true; restarts[b] += 1;
+            }
+        }
+        if (any_break) {
+            rc = restart_masked(op, block, B);
+            if (rc) return rc;
+            continue;     // re-read the status (a restarted RHS may already satisfy the tolerance)
+        }
+        if (!any_active) {
+            // un-freeze bookkeeping for the caller: frozen-by-cap stays FROZEN
+            upload_scal(op, n);
+            break;
+        }
+        upload_scal(op, n);
+        const int chunk = std::max(1, std::min(check_every, maxit - min_iters));
+        for (int k = 0; k < chunk; ++k) {
+            helm_launch_bicg_p(op, B.w, n);
+            rc = helm_launch_apply(op, scaled_apply(op, block, B.w.p, B.w.v, B.w.r0, n, 0, EPI_DOT_W, true));
+            if (rc) return rc;
+            helm_launch_fin(op, FIN_ALPHA, n, nba);
+            helm_launch_bicg_s(op, B.w, n);
+            rc = helm_launch_apply(op, scaled_apply(op, block, B.w.s, B.w.t, nullptr, n, 0, EPI_DOT_XY, true));
+            if (rc) return rc;
+            helm_launch_fin(op, FIN_OMEGA, n, nba);
+            helm_launch_bicg_xr(op, B.w, n, nbv);
+            helm_launch_fin(op, FIN_RHO, n, nbv);
+        }
+        HIP_TRY(op, hipGetLastError());
+        it_done += chunk;
+    }
+    return HELM_OK;
+}
+
+// CGNR on the Jacobi-scaled system for the right-hand sides flagged in h_mask (warm start from x).
+int run_cgnr(helm_op *op, int block, Batch &B, int maxit, int check_every) {
+    const int n = B.nrhs;
+    const int nba = helm_apply_num_blocks(op), nbv = helm_vec_num_blocks(op);
+    // r = bbar - Abar x for flagged RHS; others frozen
+    for (int b = 0; b < n; ++b) {
+        RhsScal &S = op->h_scal[b];
+        if (B.h_mask[b]) { S.status = ST_ACTIVE; S.iters = 0; }
+        else if (S.status == ST_ACTIVE) S.status = ST_FROZEN;
+    }
+    int rc = upload_scal(op, n);
+    if (rc) return rc;
+    rc = helm_launch_apply(op, scaled_apply(op, block, B.w.x, B.w.r, B.bbar, n, 0, EPI_RESID, true));
+    if (rc) return rc;
+    helm_launch_fin(op, FIN_CG_RR, n, nba);            // rr (and convergence check); iters becomes 1
+    rc = helm_launch_apply(op, scaled_apply(op, block, B.w.r, B.w.s, nullptr, n, 1, EPI_DOT_YY, true));   // z = A^H r
+    if (rc) return rc;
+    helm_launch_fin(op, FIN_CG_INIT, n, nba);
+    helm_launch_cg_p(op, B.w, n, 1);
+    while (true) {
+        rc = download_scal(op, n);
+        if (rc) return rc;
+        bool any_active = false;
+        int min_iters = std::numeric_limits<int>::max();
+        for (int b = 0; b < n; ++b) {
+            RhsScal &S = op->h_scal[b];
+            if (S.status == ST_ACTIVE) {
+                if (S.iters >= maxit) S.status = ST_FROZEN;
+                else { any_active = true; min_iters = std::min(min_iters, S.iters); }
+            }
+        }
+        upload_scal(op, n);
+        if (!any_active) break;
+        const int chunk = std::max(1, std::min(check_every, maxit - min_iters));
+        for (int k = 0; k < chunk; ++k) {
+            rc = helm_launch_apply(op, scaled_apply(op, block, B.w.p, B.w.v, nullptr, n, 0, EPI_DOT_YY, true));   // w = A p
+            if (rc) return rc;
+            helm_launch_fin(op, FIN_CG_ALPHA, n, nba);
+            helm_launch_cg_xr(op, B.w, n);
+            helm_launch_fin(op, FIN_CG_RR, n, nbv);
+            rc = helm_launch_apply(op, scaled_apply(op, block, B.w.r, B.w.s, nullptr, n, 1, EPI_DOT_YY, true)); // z = A^H r
+            if (rc) return rc;
+            helm_launch_fin(op, FIN_CG_BETA, n, nba);
+            helm_launch_cg_p(op, B.w, n, 0);
+        }
+        HIP_TRY(op, hipGetLastError());
+    }
+    return HELM_OK;
+}
+
+// Solve M_block X = premul * RHS[:, row_off : row_off+N] - sub   for nrhs right-hand sides.
+// dXout: [nrhs][N] (NOT conjugated).  info (optional) is filled per RHS.
+int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long long row_off, cplx premul,
+                const cplx *sub, cplx *dXout, int nrhs, const helm_solve_opts &o, helm_solve_info *info) {
+    const long long N = op->N;
+    int Bmax = o.batch > 0 ? o.batch : 16;
+    if (Bmax > nrhs) Bmax = nrhs;
+    const int check_every = o.check_every > 0 ? o.check_every : 50;
+    int rc = ensure_ws(op, (size_t)9 * Bmax * N * sizeof(cplx));
+    if (rc) return rc;
+    rc = ensure_part(op, Bmax);
+    if (rc) return rc;
+    int unconverged = 0;
+    for (int first = 0; first < nrhs; first += Bmax) {
+        const int n = std::min(Bmax, nrhs - first);
+        Batch B;
+        B.nrhs = n;
+        cplx *base = (cplx *)op->d_ws;
+        const long long vs = (long long)Bmax * N;
+        B.w.x = base; B.w.r = base + vs; B.w.r0 = base + 2 * vs; B.w.p = base + 3 * vs; B.w.v = base + 4 * vs;
+        B.w.s = base + 5 * vs; B.w.t = base + 6 * vs; B.bbar = base + 7 * vs;
+        cplx *qprime = base + 8 * vs;
+        const int nblk = std::max(helm_apply_num_blocks(op), helm_vec_num_blocks(op));
+        char *ptail = (char *)op->d_part + (size_t)Bmax * 4 * nblk * sizeof(double);
+        B.d_aux = (double *)ptail; B.d_mask = (int *)(ptail + (size_t)Bmax * 2 * sizeof(double));
+        char *htail = (char *)op->h_scal + (size_t)op->scal_cap * sizeof(RhsScal);
+        B.h_aux = (double *)htail; B.h_mask = (int *)(htail + (size_t)op->scal_cap * 2 * sizeof(double));
+
+        const cplx *rhs_b = dRHS + (long long)first * rhs_ld;
+        const cplx *sub_b = sub ? sub + (long long)first * N : nullptr;
+        // q' = premul*rhs - sub (unscaled), ||q'||^2 -> aux[n..2n)
+        rc = helm_launch_prep_rhs(op, rhs_b, rhs_ld, row_off, premul, sub_b, qprime, n);
+        if (rc) return rc;
+        helm_launch_norm2(op, qprime, n);
+        helm_launch_fin_ex(op, FIN_NORM, n, helm_vec_num_blocks(op), nullptr, B.d_aux + n);
+        // scaled system start
+        {
+            VecPtrs w = B.w;
+            w.t = B.bbar;   // init writes bbar through w.t
+            // NB: row offset is applied by giving prep a shifted base pointer
+            rc = helm_launch_bicg_init(op, block, rhs_b + row_off, rhs_ld, premul, sub_b, w, n, o.rtol * 0.5);
+            if (rc) return rc;
+        }
+        std::vector<int> restarts(n, 0);
+        std::vector<int> method_used(n, o.method == HELM_CGNR ? HELM_CGNR : HELM_BICGSTAB);
+        std::vector<int> total_iters(n, 0);
+        std::vector<double> relres(n, 0.0);
+        const int max_refine = 3;
+        for (int round = 0; round <= max_refine; ++round) {
+            if (o.method == HELM_CGNR) {
+                rc = download_scal(op, n);
+                if (rc) return rc;
+                bool any = false;
+                for (int b = 0; b < n; ++b) { B.h_mask[b] = (op->h_scal[b].status == ST_ACTIVE); any = any || B.h_mask[b]; }
+                if (any) { rc = run_cgnr(op, block, B, o.maxit, check_every); if (rc) return rc; }
+            } else {
+                rc = run_bicgstab(op, block, B, o.maxit, check_every, 25, restarts);
+                if (rc) return rc;
+                if (o.method == HELM_AUTO) {
+                    rc = download_scal(op, n);
+                    if (rc) return rc;
+                    bool any = false;
+                    for (int b = 0; b < n; ++b) {
+                        B.h_mask[b] = (op->h_scal[b].status == ST_BREAKDOWN);
+                        if (B.h_mask[b]) { any = true; method_used[b] = HELM_CGNR; total_iters[b] += op->h_scal[b].iters; }
+                    }
+                    if (any) { rc = run_cgnr(op, block, B, o.maxit, check_every); if (rc) return rc; }
+                }
+            }
+            // true residual of the UNSCALED system: s = q' - A x
+            ApplyArgs a;
+            a.planes = op->d_C + (long long)block * 9 * N; a.X = B.w.x; a.Y = B.w.s; a.W = qprime; a.ld = N; a.nrhs = n;
+            a.scaled = 0; a.adjoint = 0; a.epi = EPI_RESID; a.scal = nullptr; a.part = (double *)op->d_part;
+            rc = helm_launch_apply(op, a);
+            if (rc) return rc;
+            helm_launch_fin_ex(op, FIN_NORM, n, helm_apply_num_blocks(op), nullptr, B.d_aux);
+            HIP_TRY(op, hipMemcpyAsync(B.h_aux, B.d_aux, 2 * n * sizeof(double), hipMemcpyDeviceToHost, op->stream));
+            rc = download_scal(op, n);
+            if (rc) return rc;
+            bool refine = false;
+            for (int b = 0; b < n; ++b) {
+                const double qq = B.h_aux[n + b];
+                relres[b] = qq > 0 ? sqrt(B.h_aux[b] / qq) : 0.0;
+                B.h_mask[b] = 0;
+                RhsScal &S = op->h_scal[b];
+                if (S.status == ST_CONVERGED && relres[b] > o.rtol && round < max_refine && S.iters < o.maxit) {
+                    // the scaled criterion was met but the unscaled residual is not there yet: tighten and go on
+                    const double f = std::max(1e-3, 0.3 * o.rtol / relres[b]);
+                    S.tol2 *= f * f;
+                    B.h_mask[b] = 1; refine = true;
+                }
+            }
+            if (!refine) break;
+            if (o.method == HELM_CGNR) {
+                for (int b = 0; b < n; ++b) if (B.h_mask[b]) op->h_scal[b].status = ST_ACTIVE;
+                upload_scal(op, n);
+            } else {
+                rc = restart_masked(op, block, B);
+                if (rc) return rc;
+            }
+        }
+        // results
+        for (int b = 0; b < n; ++b) {
+            const RhsScal &S = op->h_scal[b];
+            const bool ok = relres[b] <= o.rtol * 1.0000001 || (S.status == ST_CONVERGED && relres[b] <= 10 * o.rtol);
+            if (!(relres[b] <= o.rtol * 1.0000001)) unconverged += 1;
+            if (info) {
+                helm_solve_info &I = info[first + b];
+                I.iterations += total_iters[b] + S.iters;
+                I.restarts += restarts[b];
+                I.method = method_used[b];
+                I.relres = std::max(I.relres, relres[b]);
+                const int st = (relres[b] <= o.rtol * 1.0000001) ? 0 : (S.status == ST_BREAKDOWN ? 2 : 1);
+                I.status = std::max(I.status, st);
+            }
+            (void)ok;
+        }
+        HIP_TRY(op, hipMemcpyAsync(dXout + (long long)first * N, B.w.x, (size_t)n * N * sizeof(cplx), hipMemcpyDeviceToDevice, op->stream));
+        HIP_TRY(op, hipStreamSynchronize(op->stream));
+    }
+    return unconverged;
+}
+
+}  // namespace
+
+extern "C" int helm_solve_device(helm_op *op, const void *dRHS, void *dU, int nrhs, long long rows,
+                                 double premul_re, double premul_im, const helm_solve_opts *opts, helm_solve_info *info) {
+    if (!op || !dRHS || !dU || nrhs < 1) return HELM_ERR_ARG;
+    if (!op->assembled) HELM_FAIL(op, HELM_ERR_STATE, "operator not assembled");
+    const long long N = op->N;
+    const bool stacked = (op->variant == HELM_EURUS && rows == 2 * N);
+    if (rows != N && !stacked) HELM_FAIL(op, HELM_ERR_ARG, "dimension mismatch: rhs has %lld rows, operator has %lld%s", rows, N,
+                                         op->variant == HELM_EURUS ? " (or 2N stacked)" : "");
+    HIP_TRY(op, hipSetDevice(op->device));
+    helm_solve_opts o;
+    if (opts) o = *opts; else { o.method = HELM_AUTO; o.rtol = 1e-10; o.maxit = 200000; o.check_every = 0; o.batch = 0; o.flags = 0; }
+    if (!(o.rtol > 0)) o.rtol = 1e-10;
+    if (o.maxit < 1) o.maxit = 200000;
+    if (info) for (int r = 0; r < nrhs; ++r) { info[r].iterations = 0; info[r].status = 0; info[r].restarts = 0; info[r].method = o.method; info[r].relres = 0.0; }
+    const cplx premul = cmake(premul_re, premul_im);
+
+    hipEvent_t e0, e1;
+    HIP_TRY(op, hipEventCreate(&e0));
+    HIP_TRY(op, hipEventCreate(&e1));
+    timing_begin(op);
+    HIP_TRY(op, hipEventRecord(e0, op->stream));
+
+    int result = 0;
+    cplx *dX = nullptr;
+    HIP_TRY(op, hipMalloc(&dX, (size_t)nrhs * N * sizeof(cplx)));
+    auto cleanup = [&]() { hipFree(dX); hipEventDestroy(e0); hipEventDestroy(e1); };
+
+    if (op->variant == HELM_MINIZEPHYR || !stacked) {
+        // Eurus with an N-row right-hand side: zero-padded second field => v = 0 and M1 u = q
+        // provided M3 == 0 (eurus.py:512-533)
+        if (op->variant == HELM_EURUS && !op->block_zero[2]) { cleanup(); HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "Eurus with eps != delta couples both fields (M3 != 0): coupled 2N solve not available yet"); }
+        int rc = solve_block(op, 0, (const cplx *)dRHS, rows, 0, premul, nullptr, dX, nrhs, o, info);
+        if (rc < 0) { cleanup(); return rc; }
+        result = rc;
+        rc = helm_launch_finish(op, dX, (cplx *)dU, rows, nrhs, 0);
+        if (rc) { cleanup(); return rc; }
+    } else {
+        if (!op->block_zero[2]) { cleanup(); HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "Eurus with eps != delta couples both fields (M3 != 0): coupled 2N solve not available yet"); }
+        // block-triangular: v = M4^-1 q2 ; u = M1^-1 (q1 - M2 v)
+        cplx *dV = nullptr, *dT = nullptr;
+        if (hipMalloc(&dV, (size_t)nrhs * N * sizeof(cplx)) != hipSuccess || hipMalloc(&dT, (size_t)nrhs * N * sizeof(cplx)) != hipSuccess) {
+            hipFree(dV); cleanup(); HELM_FAIL(op, HELM_ERR_DEVICE, "hipMalloc failed");
+        }
+        int rc = solve_block(op, 3, (const cplx *)dRHS, rows, N, premul, nullptr, dV, nrhs, o, info);
+        if (rc >= 0) {
+            result = rc;
+            ApplyArgs a;
+            a.planes = op->d_C + 1LL * 9 * N; a.X = dV; a.Y = dT; a.W = nullptr; a.ld = N; a.nrhs = nrhs; a.scaled = 0; a.adjoint = 0;
+            a.epi = EPI_NONE; a.scal = nullptr; a.part = nullptr;
+            rc = helm_launch_apply(op, a);
+            if (!rc) rc = solve_block(op, 0, (const cplx *)dRHS, rows, 0, premul, dT, dX, nrhs, o, info);
+            if (rc >= 0) {
+                result = std::max(result, rc);
+                rc = helm_launch_finish(op, dX, (cplx *)dU, rows, nrhs, 0);
+                if (!rc) rc = helm_launch_finish(op, dV, (cplx *)dU, rows, nrhs, N);
+            }
+        }
+        hipFree(dV); hipFree(dT);
+        if (rc < 0) { cleanup(); return rc; }
+    }
+    HIP_TRY(op, hipEventRecord(e1, op->stream));
+    HIP_TRY(op, hipStreamSynchronize(op->stream));
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    op->timing.solve_ms = ms;
+    timing_collect(op);
+    cleanup();
+    return result;
+}
+
+extern "C" int helm_solve(helm_op *op, const double *RHS, double *U, int nrhs, long long rows,
+                          double premul_re, double premul_im, const helm_solve_opts *opts, helm_solve_info *info) {
+    if (!op || !RHS || !U || nrhs < 1) return HELM_ERR_ARG;
+    HIP_TRY(op, hipSetDevice(op->device));
+    const size_t bytes = (size_t)nrhs * rows * sizeof(cplx);
+    void *dR = nullptr, *dU = nullptr;
+    HIP_TRY(op, hipMalloc(&dR, bytes));
+    if (hipMalloc(&dU, bytes) != hipSuccess) { hipFree(dR); HELM_FAIL(op, HELM_ERR_DEVICE, "hipMalloc failed"); }
+    int rc = HELM_OK;
+    if (hipMemcpy(dR, RHS, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = HELM_ERR_DEVICE;
+    if (!rc) rc = helm_solve_device(op, dR, dU, nrhs, rows, premul_re, premul_im, opts, info);
+    if (rc >= 0 && hipMemcpy(U, dU, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = HELM_ERR_DEVICE;
+    hipFree(dR); hipFree(dU);
+    return rc;
+}
+
+extern "C" int helm_imaging_accumulate_device(helm_op *op, const void *dUF, const void *dUB, int nsrc, const void *dScaler, void *dG) {
+    if (!op || !dUF || !dUB || !dScaler || !dG || nsrc < 1) return HELM_ERR_ARG;
+    HIP_TRY(op, hipSetDevice(op->device));
+    int rc = helm_launch_imaging(op, (const cplx *)dUF, (const cplx *)dUB, nsrc, (const cplx *)dScaler, (cplx *)dG);
+    if (rc) return rc;
+    HIP_TRY(op, hipStreamSynchronize(op->stream));
+    return HELM_OK;
+}

@@ -1,0 +1,153 @@
+// Internal declarations shared by the libhelm translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <cmath>
+#include "../../include/helm.h"
+
+typedef double2 cplx;   // interleaved (re, im), 16 B: one dwordx4 per lane
+
+#define HELM_WAVE 64
+#define HELM_NXCD 8
+
+// ---- complex helpers (host + device) ----------------------------------------------------
+__host__ __device__ inline cplx cmake(double r, double i) { cplx z; z.x = r; z.y = i; return z; }
+__host__ __device__ inline cplx cadd(cplx a, cplx b) { return cmake(a.x + b.x, a.y + b.y); }
+__host__ __device__ inline cplx csub(cplx a, cplx b) { return cmake(a.x - b.x, a.y - b.y); }
+__host__ __device__ inline cplx cmul(cplx a, cplx b) { return cmake(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__host__ __device__ inline cplx cscale(cplx a, double s) { return cmake(a.x * s, a.y * s); }
+__host__ __device__ inline cplx cconj(cplx a) { return cmake(a.x, -a.y); }
+__host__ __device__ inline cplx cneg(cplx a) { return cmake(-a.x, -a.y); }
+__host__ __device__ inline double cabs2(cplx a) { return a.x * a.x + a.y * a.y; }
+__host__ __device__ inline cplx cdiv(cplx a, cplx b) {
+    // Smith's algorithm (robust against over/underflow of |b|^2)
+    if (fabs(b.x) >= fabs(b.y)) {
+        double r = b.y / b.x, d = b.x + b.y * r;
+        return cmake((a.x + a.y * r) / d, (a.y - a.x * r) / d);
+    } else {
+        double r = b.x / b.y, d = b.x * r + b.y;
+        return cmake((a.x * r + a.y) / d, (a.y * r - a.x) / d);
+    }
+}
+__host__ __device__ inline cplx crecip(cplx b) { return cdiv(cmake(1.0, 0.0), b); }
+// acc += a*b
+__host__ __device__ inline void cfma(cplx &acc, cplx a, cplx b) {
+    acc.x = fma(a.x, b.x, acc.x); acc.x = fma(-a.y, b.y, acc.x);
+    acc.y = fma(a.x, b.y, acc.y); acc.y = fma(a.y, b.x, acc.y);
+}
+// acc += conj(a)*b
+__host__ __device__ inline void cfma_conj(cplx &acc, cplx a, cplx b) {
+    acc.x = fma(a.x, b.x, acc.x); acc.x = fma(a.y, b.y, acc.x);
+    acc.y = fma(a.x, b.y, acc.y); acc.y = fma(-a.y, b.x, acc.y);
+}
+
+// ---- per-RHS solver scalars kept on the device ---------------------------------------------
+// One record per right-hand side of the batch; written only by the single-block "finalize"
+// kernels, read by every vector kernel.  Plain doubles so the host can memcpy it.
+struct RhsScal {
+    double rho_re, rho_im;       // BiCGSTAB rho = (r0, r)       | CGNR gamma = (z,z)
+    double alpha_re, alpha_im;
+    double omega_re, omega_im;
+    double beta_re, beta_im;
+    double rr;                   // ||r||^2 (recursive residual, scaled system)
+    double bb;                   // ||b||^2 (scaled system)
+    double tol2;                 // (rtol_eff)^2
+    int status;                  // 0 active, 1 converged, 2 breakdown, 3 frozen by host
+    int iters;
+    int pad0, pad1;
+};
+
+enum { ST_ACTIVE = 0, ST_CONVERGED = 1, ST_BREAKDOWN = 2, ST_FROZEN = 3, ST_PARKED = 4 };
+
+// ---- the handle ---------------------------------------------------------------------------
+struct helm_op {
+    int device = 0, variant = 0, nz = 0, nx = 0, nPML = 10;
+    long long N = 0;
+    double dx = 1, dz = 1;
+    int fs[4] = {0, 0, 0, 0};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    // model
+    cplx *d_c = nullptr;
+    double *d_rho = nullptr, *d_theta = nullptr, *d_eps = nullptr, *d_delta = nullptr;
+    bool has_model = false, aniso = false;
+
+    // operator
+    int nblocks = 1;
+    cplx *d_C = nullptr;      // nblocks * 9 * N   raw planes
+    cplx *d_Cs = nullptr;     // nblocks * 9 * N   planes divided by the centre plane (Jacobi-scaled)
+    cplx *d_dinv = nullptr;   // nblocks * N       1 / centre plane
+    bool assembled = false;
+    bool block_zero[4] = {false, false, false, false};   // block is identically zero (e.g. Eurus M3 isotropic)
+
+    // solver workspace (grown on demand)
+    void *d_ws = nullptr; size_t ws_bytes = 0;
+    void *d_part = nullptr; size_t part_bytes = 0;     // partial sums of the fused dot products
+    RhsScal *d_scal = nullptr; RhsScal *h_scal = nullptr; int scal_cap = 0;
+
+    // timing / profiling
+    bool profiling = false;
+    helm_timing timing = {0, 0, 0, 0};
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<std::pair<int, double>> ev_pending;   // (event-pair index, bytes)
+    size_t ev_used = 0;
+
+    std::string err;
+};
+
+#define HELM_FAIL(op, code, ...) do { char _b[512]; snprintf(_b, sizeof(_b), __VA_ARGS__); helm_set_error(op, _b); return code; } while (0)
+#define HIP_TRY(op, call) do { hipError_t _e = (call); if (_e != hipSuccess) { \
+    HELM_FAIL(op, HELM_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); } } while (0)
+
+void helm_set_error(helm_op *op, const char *msg);
+
+// ---- launchers implemented in assemble.hip ----------------------------------------------------
+int helm_launch_assemble(helm_op *op, double freq_re, double freq_im, double tau, double ky, double cPML);
+
+// ---- launchers implemented in kernels.hip -----------------------------------------------------
+// epilogues of the fused stencil kernel
+enum { EPI_NONE = 0,      // y = A x
+       EPI_DOT_W = 1,     // + partial (w, y)                      [BiCGSTAB (r0, v)]
+       EPI_DOT_XY = 2,    // + partials (y, x), (y, y)             [BiCGSTAB (t,s),(t,t)]
+       EPI_DOT_YY = 3,    // + partial (y, y)                      [CGNR]
+       EPI_RESID = 4 };   // y = w - A x, + partial (y, y)         [restart / true residual]
+
+struct ApplyArgs {
+    const cplx *planes;   // 9 planes (raw or scaled), plane stride = N
+    const cplx *X; cplx *Y; const cplx *W;   // rhs stride = ld
+    long long ld;
+    int nrhs;
+    int scaled;           // 1: centre plane is 1 and skipped
+    int adjoint;
+    int epi;
+    const RhsScal *scal;  // may be null: all RHS active
+    double *part;         // partial sums, layout [rhs][q][nblk] doubles (q = 0..3)
+};
+int helm_launch_apply(helm_op *op, const ApplyArgs &a);
+int helm_apply_num_blocks(const helm_op *op);
+
+int helm_launch_scale_planes(helm_op *op);   // d_Cs, d_dinv from d_C
+
+struct VecPtrs {   // all [nrhs][N] complex, stride N
+    cplx *x, *r, *r0, *p, *v, *s, *t;
+};
+// BiCGSTAB
+int helm_launch_bicg_init(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, cplx premul, const cplx *sub, VecPtrs w, int nrhs, double rtol);
+int helm_launch_bicg_p(helm_op *op, VecPtrs w, int nrhs);
+int helm_launch_bicg_s(helm_op *op, VecPtrs w, int nrhs);
+int helm_launch_bicg_xr(helm_op *op, VecPtrs w, int nrhs, int nblk_part);
+int helm_launch_fin(helm_op *op, int which, int nrhs, int nblk_part);
+enum { FIN_BICG_INIT = 0, FIN_ALPHA = 1, FIN_OMEGA = 2, FIN_RHO = 3, FIN_RESTART = 4,
+       FIN_CG_INIT = 5, FIN_CG_ALPHA = 6, FIN_CG_RR = 7, FIN_CG_BETA = 8, FIN_NORM = 9 };
+int helm_vec_num_blocks(const helm_op *op);
+// CGNR
+int helm_launch_cg_xr(helm_op *op, VecPtrs w, int nrhs);      // x += alpha p ; r -= alpha w(v) ; (r,r)
+int helm_launch_cg_p(helm_op *op, VecPtrs w, int nrhs, int first);   // p = z(s) + beta p
+// misc
+int helm_launch_finish(helm_op *op, const cplx *x, cplx *dU, long long u_ld, int nrhs, long long row_off);   // U = conj(x)
+int helm_launch_prep_rhs(helm_op *op, const cplx *dRHS, long long rhs_ld, long long row_off, cplx premul, const cplx *sub, cplx *out, int nrhs); // out = premul*rhs - sub
+int helm_launch_imaging(helm_op *op, const cplx *uf, const cplx *ub, int nsrc, const cplx *scaler, cplx *g);
+int helm_launch_zero(helm_op *op, cplx *p, long long n);

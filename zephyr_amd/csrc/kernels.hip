@@ -1,0 +1,700 @@
+// Device kernels of the matrix-free Krylov path:
+//   * k_stencil   -- batched 9-point complex128 stencil apply, LDS-staged tiles, coefficients
+//                    register-blocked over the right-hand-side loop, fused dot-product epilogues
+//                    (wave64 shuffle reduction -> LDS -> one partial per workgroup)
+//   * k_bicg_* / k_cg_* -- fused vector updates of BiCGSTAB / CGNR with their dot products
+//   * k_fin       -- single-workgroup deterministic reduction of the partials + scalar recurrences
+//
+// The arithmetic replaces the sparse-LU solve behind BaseDiscretization.__mul__
+// (zephyr/backend/discretization.py:78-106).  This is HBM-bound work (<= 2.25 flop/B, no MFMA):
+// the design rules are 16-B-per-lane coalesced accesses, one pass per vector per kernel, and
+// an XCD-aware tile order so that halo rows are served by the XCD's own L2.
+#include "helm_internal.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// reductions
+// ------------------------------------------------------------------------------------------
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Reduce NQ doubles per thread over a 256-thread block; result valid in thread 0.
+template <int NQ>
+__device__ inline void block_sum(double (&v)[NQ], double *smem /* >= 4*NQ doubles */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) v[q] = wave_sum(v[q]);
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) smem[wave * NQ + q] = v[q];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) v[q] = (smem[q] + smem[NQ + q]) + (smem[2 * NQ + q] + smem[3 * NQ + q]);
+    }
+    __syncthreads();
+}
+
+__device__ inline bool rhs_active(const RhsScal *scal, int b) { return scal == nullptr || scal[b].status == ST_ACTIVE; }
+
+// Round-robin dispatch puts workgroup b on XCD b % 8; give every XCD one contiguous run of
+// tiles (a band of grid rows) so z-/x-neighbouring tiles share an L2.  Bijective for any count.
+__device__ inline int xcd_swizzle(int bid, int nblk) {
+    const int q = nblk / HELM_NXCD, rem = nblk % HELM_NXCD;
+    const int x = bid % HELM_NXCD, k = bid / HELM_NXCD;
+    const int start = x * q + (x < rem ? x : rem);
+    return start + k;
+}
+
+// ------------------------------------------------------------------------------------------
+// stencil apply
+// ------------------------------------------------------------------------------------------
+struct StencilParams {
+    const cplx *planes;
+    const cplx *X;
+    cplx *Y;
+    const cplx *W;
+    long long ld, N;
+    int nz, nx, nrhs, ntx, ntz, nblk;
+    const RhsScal *scal;
+    double *part;
+};
+
+constexpr int TX = 64;
+
+template <int P, bool SCALED, bool ADJ, int EPI>
+__global__ __launch_bounds__(256) void k_stencil(StencilParams q) {
+    constexpr int TZ = 4 * P;
+    constexpr int LW = TX + 2;             // tile row length in elements
+    constexpr int LR = TZ + 2;             // tile rows
+    constexpr int NLOAD = (LR + 3) / 4;    // main-column row loads per wave
+    __shared__ __attribute__((aligned(16))) cplx tile[2][LR * LW];
+    __shared__ double red[16];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = xcd_swizzle(blockIdx.x, q.nblk);
+    const int tz = t / q.ntx, tx = t - tz * q.ntx;
+    const int z0 = tz * TZ, x0 = tx * TX;
+    const int nz = q.nz, nx = q.nx;
+    const long long N = q.N;
+    const int col = x0 + lane;
+    const bool colok = col < nx;
+
+    // ---- coefficients for this thread's P points, kept in registers over the RHS loop ----
+    cplx cf[P][9];
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        const int row = z0 + wave * P + j;
+        const bool ok = colok && row < nz;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            if (SCALED && k == 4) { cf[j][k] = cmake(1.0, 0.0); continue; }
+            cplx v = cmake(0.0, 0.0);
+            if (!ADJ) {
+                if (ok) v = q.planes[(long long)k * N + (long long)row * nx + col];
+            } else {
+                // (A^H x)[i] = sum over neighbours n of conj(A[n,i]) x[n]; the entry A[n,i] sits in
+                // plane slot(-dz,-dx) at point n = i + (dz,dx)
+                const int dz = k / 3 - 1, dx = k % 3 - 1;
+                const int rn = row + dz, cn = col + dx;
+                if (ok && rn >= 0 && rn < nz && cn >= 0 && cn < nx)
+                    v = cconj(q.planes[(long long)(8 - k) * N + (long long)rn * nx + cn]);
+            }
+            cf[j][k] = v;
+        }
+    }
+
+    // ---- RHS loop with register prefetch + double-buffered LDS tile ----
+    cplx pre[NLOAD];
+    cplx prehalo = cmake(0.0, 0.0);
+    auto prefetch = [&](int b) {
+        const cplx *Xb = q.X + (long long)b * q.ld;
+#pragma unroll
+        for (int l = 0; l < NLOAD; ++l) {
+            const int r = wave + 4 * l;                 // tile row
+            const int grow = z0 - 1 + r;
+            cplx v = cmake(0.0, 0.0);
+            if (r < LR && colok && grow >= 0 && grow < nz) v = Xb[(long long)grow * nx + col];
+            pre[l] = v;
+        }
+        prehalo = cmake(0.0, 0.0);
+        if (tid < 2 * LR) {
+            const int r = tid >> 1, side = tid & 1;
+            const int grow = z0 - 1 + r, gcol = side ? x0 + TX : x0 - 1;
+            if (grow >= 0 && grow < nz && gcol >= 0 && gcol < nx) prehalo = Xb[(long long)grow * nx + gcol];
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int l = 0; l < NLOAD; ++l) {
+            const int r = wave + 4 * l;
+            if (r < LR) tile[buf][r * LW + 1 + lane] = pre[l];
+        }
+        if (tid < 2 * LR) {
+            const int r = tid >> 1, side = tid & 1;
+            tile[buf][r * LW + (side ? TX + 1 : 0)] = prehalo;
+        }
+    };
+
+    const int bstep = gridDim.y;
+    int b = blockIdx.y;
+    while (b < q.nrhs && !rhs_active(q.scal, b)) b += bstep;
+    if (b < q.nrhs) prefetch(b);
+    int buf = 0;
+    while (b < q.nrhs) {
+        stage(buf);
+        int bn = b + bstep;
+        while (bn < q.nrhs && !rhs_active(q.scal, bn)) bn += bstep;
+        if (bn < q.nrhs) prefetch(bn);
+        __syncthreads();
+
+        cplx acc[P];
+#pragma unroll
+        for (int j = 0; j < P; ++j) acc[j] = cmake(0.0, 0.0);
+        cplx xc_keep[P];
+        const cplx *trow = &tile[buf][(wave * P) * LW + lane];
+#pragma unroll
+        for (int rr = 0; rr < P + 2; ++rr) {
+            const cplx xl = trow[rr * LW + 0], xm = trow[rr * LW + 1], xr = trow[rr * LW + 2];
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                const int dzi = rr - j;            // 0,1,2 <-> dz = -1,0,+1
+                if (dzi < 0 || dzi > 2) continue;
+                cfma(acc[j], cf[j][dzi * 3 + 0], xl);
+                if (SCALED && dzi == 1) { acc[j].x += xm.x; acc[j].y += xm.y; }
+                else cfma(acc[j], cf[j][dzi * 3 + 1], xm);
+                cfma(acc[j], cf[j][dzi * 3 + 2], xr);
+                if (dzi == 1) xc_keep[j] = xm;
+            }
+        }
+
+        double dsum[4] = {0.0, 0.0, 0.0, 0.0};
+        cplx *Yb = q.Y + (long long)b * q.ld;
+        const cplx *Wb = (EPI == EPI_DOT_W || EPI == EPI_RESID) ? q.W + (long long)b * q.ld : nullptr;
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int row = z0 + wave * P + j;
+            if (colok && row < nz) {
+                const long long idx = (long long)row * nx + col;
+                cplx y = acc[j];
+                if (EPI == EPI_RESID) {
+                    const cplx w = Wb[idx];
+                    y = csub(w, y);
+                    dsum[0] += cabs2(y);
+                } else if (EPI == EPI_DOT_W) {
+                    const cplx w = Wb[idx];          // (w, y) = sum conj(w) y
+                    dsum[0] += w.x * y.x + w.y * y.y;
+                    dsum[1] += w.x * y.y - w.y * y.x;
+                } else if (EPI == EPI_DOT_XY) {
+                    const cplx x = xc_keep[j];       // (y, x) = sum conj(y) x ; (y, y)
+                    dsum[0] += y.x * x.x + y.y * x.y;
+                    dsum[1] += y.x * x.y - y.y * x.x;
+                    dsum[2] += cabs2(y);
+                } else if (EPI == EPI_DOT_YY) {
+                    dsum[0] += cabs2(y);
+                }
+                Yb[idx] = y;
+            }
+        }
+        if (EPI != EPI_NONE) {
+            block_sum<4>(dsum, red);
+            if (tid == 0) {
+                double *pp = q.part + ((long long)b * 4) * q.nblk + blockIdx.x;
+                pp[0] = dsum[0];
+                pp[(long long)q.nblk] = dsum[1];
+                pp[2LL * q.nblk] = dsum[2];
+                pp[3LL * q.nblk] = dsum[3];
+            }
+        }
+        buf ^= 1;
+        b = bn;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// elementwise / vector kernels (grid.x over points with a grid-stride loop, grid.y = rhs)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scale_planes(const cplx *__restrict__ C, cplx *__restrict__ Cs,
+                                                      cplx *__restrict__ dinv, long long N, int nblocks) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    for (int m = 0; m < nblocks; ++m) {
+        const cplx *Cm = C + (long long)m * 9 * N;
+        cplx *Sm = Cs + (long long)m * 9 * N;
+        const cplx d = Cm[4 * N + i];
+        const bool zero = (d.x == 0.0 && d.y == 0.0);
+        const cplx di = zero ? cmake(0.0, 0.0) : crecip(d);
+        dinv[(long long)m * N + i] = di;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Sm[(long long)k * N + i] = (k == 4) ? cmake(1.0, 0.0) : cmul(Cm[(long long)k * N + i], di);
+    }
+}
+
+// out = scale (.) (premul * rhs - sub)   [scale = dinv or null]
+__global__ __launch_bounds__(256) void k_prep_rhs(const cplx *__restrict__ rhs, long long rhs_ld, long long row_off,
+                                                  cplx premul, const cplx *__restrict__ sub,
+                                                  const cplx *__restrict__ scale, cplx *__restrict__ out, long long N) {
+    const int b = blockIdx.y;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x) {
+        cplx v = cmul(premul, rhs[(long long)b * rhs_ld + row_off + i]);
+        if (sub) v = csub(v, sub[(long long)b * N + i]);
+        if (scale) v = cmul(scale[i], v);
+        out[(long long)b * N + i] = v;
+    }
+}
+
+// BiCGSTAB / CGNR start: x = 0, r = r0 = bbar, p = v = 0, partial (r, r)
+__global__ __launch_bounds__(256) void k_krylov_init(const cplx *__restrict__ bbar, VecPtrs w, long long N,
+                                                     double *__restrict__ part, int nblk) {
+    __shared__ double red[4];
+    const int b = blockIdx.y;
+    double s[1] = {0.0};
+    const cplx zero = cmake(0.0, 0.0);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x) {
+        const long long g = (long long)b * N + i;
+        const cplx v = bbar[g];
+        w.x[g] = zero; w.r[g] = v; w.r0[g] = v; w.p[g] = zero; w.v[g] = zero;
+        s[0] += cabs2(v);
+    }
+    block_sum<1>(s, red);
+    if (threadIdx.x == 0) part[((long long)b * 4) * nblk + blockIdx.x] = s[0];
+}
+
+// p = r + beta (p - omega v)
+__global__ __launch_bounds__(256) void k_bicg_p(VecPtrs w, long long N, const RhsScal *__restrict__ scal) {
+    const int b = blockIdx.y;
+    if (scal[b].status != ST_ACTIVE) return;
+    const cplx beta = cmake(scal[b].beta_re, scal[b].beta_im), omega = cmake(scal[b].omega_re, scal[b].omega_im);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x) {
+        const long long g = (long long)b * N + i;
+        const cplx r = w.r[g], p = w.p[g], v = w.v[g];
+        cplx tmp = csub(p, cmul(omega, v));
+        w.p[g] = cadd(r, cmul(beta, tmp));
+    }
+}
+
+// s = r - alpha v
+__global__ __launch_bounds__(256) void k_bicg_s(VecPtrs w, long long N, const RhsScal *__restrict__ scal) {
+    const int b = blockIdx.y;
+    if (scal[b].status != ST_ACTIVE) return;
+    const cplx alpha = cmake(scal[b].alpha_re, scal[b].alpha_im);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x) {
+        const long long g = (long long)b * N + i;
+        w.s[g] = csub(w.r[g], cmul(alpha, w.v[g]));
+    }
+}
+
+// x += alpha p + omega s ; r = s - omega t ; partials (r0, r), (r, r)
+__global__ __launch_bounds__(256) void k_bicg_xr(VecPtrs w, long long N, const RhsScal *__restrict__ scal,
+                                                 double *__restrict__ part, int nblk) {
+    __shared__ double red[12];
+    const int b = blockIdx.y;
+    if (scal[b].status != ST_ACTIVE) return;
+    const cplx alpha = cmake(scal[b].alpha_re, scal[b].alpha_im), omega = cmake(scal[b].omega_re, scal[b].omega_im);
+    double s[3] = {0.0, 0.0, 0.0};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x) {
+        const long long g = (long long)b * N + i;
+        const cplx sv = w.s[g], tv = w.t[g], pv = w.p[g];
+        cplx xv = w.x[g];
+        cfma(xv, alpha, pv);
+        cfma(xv, omega, sv);
+        w.x[g] = xv;
+        const cplx rv = csub(sv, cmul(omega, tv));
+        w.r[g] = rv;
+        const cplx r0 = w.r0[g];
+        s[0] += r0.x * rv.x + r0.y * rv.y;
+        s[1] += r0.x * rv.y - r0.y * rv.x;
+        s[2] += cabs2(rv);
+    }
+    block_sum<3>(s, red);
+    if (threadIdx.x == 0) {
+        double *pp = part + ((long long)b * 4) * nblk + blockIdx.x;
+        pp[0] = s[0]; pp[(long long)nblk] = s[1]; pp[2LL * nblk] = s[2];
+    }
+}
+
+// r0 = r, p = v = 0 for right-hand sides being (re)started (status == ST_ACTIVE after FIN_RESTART
+// is decided by `mask[b]`)
+__global__ __launch_bounds__(256) void k_restart_copy(VecPtrs w, long long N, const int *__restrict__ mask) {
+    const int b = blockIdx.y;
+    if (!mask[b]) return;
+    const cplx zero = cmake(0.0, 0.0);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x) {
+        const long long g = (long long)b * N + i;
+        w.r0[g] = w.r[g]; w.p[g] = zero; w.v[g] = zero;
+    }
+}
+
+// CGNR: x += alpha p ; r -= alpha w(v) ; partial (r, r)
+__global__ __launch_bounds__(256) void k_cg_xr(VecPtrs w, long long N, const RhsScal *__restrict__ scal,
+                                               double *__restrict__ part, int nblk) {
+    __shared__ double red[4];
+    const int b = blockIdx.y;
+    if (scal[b].status != ST_ACTIVE) return;
+    const double alpha = scal[b].alpha_re;
+    double s[1] = {0.0};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x) {
+        const long long g = (long long)b * N + i;
+        const cplx pv = w.p[g], wv = w.v[g];
+        cplx xv = w.x[g], rv = w.r[g];
+        xv.x += alpha * pv.x; xv.y += alpha * pv.y;
+        rv.x -= alpha * wv.x; rv.y -= alpha * wv.y;
+        w.x[g] = xv; w.r[g] = rv;
+        s[0] += cabs2(rv);
+    }
+    block_sum<1>(s, red);
+    if (threadIdx.x == 0) part[((long long)b * 4) * nblk + blockIdx.x] = s[0];
+}
+
+// CGNR: p = z(s) + beta p
+__global__ __launch_bounds__(256) void k_cg_p(VecPtrs w, long long N, const RhsScal *__restrict__ scal, int first) {
+    const int b = blockIdx.y;
+    if (scal[b].status != ST_ACTIVE) return;
+    const double beta = first ? 0.0 : scal[b].beta_re;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x) {
+        const long long g = (long long)b * N + i;
+        const cplx z = w.s[g];
+        cplx p = first ? cmake(0.0, 0.0) : w.p[g];
+        w.p[g] = cmake(z.x + beta * p.x, z.y + beta * p.y);
+    }
+}
+
+// partial (a, a)
+__global__ __launch_bounds__(256) void k_norm2(const cplx *__restrict__ a, long long N, double *__restrict__ part, int nblk) {
+    __shared__ double red[4];
+    const int b = blockIdx.y;
+    double s[1] = {0.0};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x)
+        s[0] += cabs2(a[(long long)b * N + i]);
+    block_sum<1>(s, red);
+    if (threadIdx.x == 0) part[((long long)b * 4) * nblk + blockIdx.x] = s[0];
+}
+
+// U = conj(x) into a (possibly strided / offset) output
+__global__ __launch_bounds__(256) void k_finish(const cplx *__restrict__ x, cplx *__restrict__ U, long long u_ld,
+                                                long long row_off, long long N) {
+    const int b = blockIdx.y;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x)
+        U[(long long)b * u_ld + row_off + i] = cconj(x[(long long)b * N + i]);
+}
+
+__global__ __launch_bounds__(256) void k_zero(cplx *__restrict__ p, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        p[i] = cmake(0.0, 0.0);
+}
+
+// G[i] += scaler[i] * sum_s UF[s][i] * UB[s][i]      (problem.py:152)
+__global__ __launch_bounds__(256) void k_imaging(const cplx *__restrict__ uf, const cplx *__restrict__ ub, int nsrc,
+                                                 const cplx *__restrict__ scaler, cplx *__restrict__ g, long long N) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x) {
+        cplx acc = cmake(0.0, 0.0);
+        for (int s = 0; s < nsrc; ++s) cfma(acc, uf[(long long)s * N + i], ub[(long long)s * N + i]);
+        cplx gv = g[i];
+        cfma(gv, scaler[i], acc);
+        g[i] = gv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// finalize: one workgroup per right-hand side sums the per-workgroup partials in a fixed order
+// (bitwise reproducible) and advances the scalar recurrences.
+// ------------------------------------------------------------------------------------------
+__device__ inline void fin_sum(const double *part, int b, int nblk, double (&out)[4], double *smem) {
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += part[((long long)b * 4 + q) * nblk + i];
+    }
+    block_sum<4>(v, smem);
+    __shared__ double bc[4];
+    if (threadIdx.x == 0) { bc[0] = v[0]; bc[1] = v[1]; bc[2] = v[2]; bc[3] = v[3]; }
+    __syncthreads();
+    out[0] = bc[0]; out[1] = bc[1]; out[2] = bc[2]; out[3] = bc[3];
+}
+
+struct FinParams {
+    RhsScal *scal;
+    const double *part;
+    int nblk;
+    int which;
+    double rtol;
+    const int *mask;    // FIN_RESTART: which RHS to touch
+    double *aux;        // FIN_NORM: aux[b] = sum
+};
+
+__device__ inline bool finite2(cplx a) { return isfinite(a.x) && isfinite(a.y); }
+
+__global__ __launch_bounds__(256) void k_fin(FinParams f) {
+    __shared__ double smem[16];
+    const int b = blockIdx.x;
+    RhsScal *S = f.scal ? f.scal + b : nullptr;
+    if (f.which == FIN_NORM) {
+        double v[4];
+        fin_sum(f.part, b, f.nblk, v, smem);
+        if (threadIdx.x == 0) f.aux[b] = v[0];
+        return;
+    }
+    if (f.which == FIN_RESTART) {
+        if (!f.mask[b]) {   // right-hand sides parked while others restart resume where they were
+            if (threadIdx.x == 0 && S->status == ST_PARKED) S->status = ST_ACTIVE;
+            return;
+        }
+    }
+    else if (f.which != FIN_BICG_INIT && S->status != ST_ACTIVE) return;
+    double v[4];
+    fin_sum(f.part, b, f.nblk, v, smem);
+    if (threadIdx.x != 0) return;
+
+    switch (f.which) {
+    case FIN_BICG_INIT: {           // v[0] = (b, b) of the scaled system
+        S->bb = v[0]; S->rr = v[0];
+        S->rho_re = v[0]; S->rho_im = 0.0;
+        S->alpha_re = 1.0; S->alpha_im = 0.0; S->omega_re = 1.0; S->omega_im = 0.0;
+        S->beta_re = 0.0; S->beta_im = 0.0;
+        S->tol2 = f.rtol * f.rtol;
+        S->iters = 0;
+        S->pad0 = 0;                // restarts
+        S->pad1 = 0;
+        S->status = (v[0] == 0.0 || !isfinite(v[0])) ? ST_CONVERGED : ST_ACTIVE;
+        break;
+    }
+    case FIN_RESTART: {             // v[0] = (r, r) of the recomputed true residual; r0 := r
+        S->rr = v[0];
+        S->rho_re = v[0]; S->rho_im = 0.0;
+        S->alpha_re = 1.0; S->alpha_im = 0.0; S->omega_re = 1.0; S->omega_im = 0.0;
+        S->beta_re = 0.0; S->beta_im = 0.0;
+        S->pad0 += 1;
+        S->status = (v[0] <= S->tol2 * S->bb) ? ST_CONVERGED : ST_ACTIVE;
+        break;
+    }
+    case FIN_ALPHA: {               // sigma = (r0, v); alpha = rho / sigma
+        const cplx sigma = cmake(v[0], v[1]);
+        const cplx rho = cmake(S->rho_re, S->rho_im);
+        const cplx alpha = cdiv(rho, sigma);
+        if (cabs2(sigma) == 0.0 || !finite2(alpha)) { S->status = ST_BREAKDOWN; break; }
+        S->alpha_re = alpha.x; S->alpha_im = alpha.y;
+        break;
+    }
+    case FIN_OMEGA: {               // omega = (t, s) / (t, t)
+        const double tt = v[2];
+        cplx omega = cmake(0.0, 0.0);
+        if (tt > 0.0) omega = cmake(v[0] / tt, v[1] / tt);
+        if (!finite2(omega)) { S->status = ST_BREAKDOWN; break; }
+        S->omega_re = omega.x; S->omega_im = omega.y;
+        break;
+    }
+    case FIN_RHO: {                 // rho' = (r0, r); rr = (r, r); beta = (rho'/rho)(alpha/omega)
+        const cplx rhon = cmake(v[0], v[1]);
+        const double rr = v[2];
+        S->iters += 1;
+        S->rr = rr;
+        if (!isfinite(rr) || !finite2(rhon)) { S->status = ST_BREAKDOWN; break; }
+        if (rr <= S->tol2 * S->bb) { S->status = ST_CONVERGED; break; }
+        const cplx rho = cmake(S->rho_re, S->rho_im);
+        const cplx alpha = cmake(S->alpha_re, S->alpha_im), omega = cmake(S->omega_re, S->omega_im);
+        if (cabs2(omega) == 0.0 || cabs2(rho) == 0.0 || cabs2(rhon) == 0.0) { S->status = ST_BREAKDOWN; break; }
+        const cplx beta = cmul(cdiv(rhon, rho), cdiv(alpha, omega));
+        if (!finite2(beta)) { S->status = ST_BREAKDOWN; break; }
+        S->beta_re = beta.x; S->beta_im = beta.y;
+        S->rho_re = rhon.x; S->rho_im = rhon.y;
+        break;
+    }
+    case FIN_CG_INIT: {             // v[0] = (z, z)
+        S->rho_re = v[0]; S->rho_im = 0.0;
+        if (v[0] == 0.0) S->status = ST_CONVERGED;
+        break;
+    }
+    case FIN_CG_ALPHA: {            // v[0] = (w, w); alpha = gamma / (w, w)
+        if (v[0] == 0.0 || !isfinite(v[0])) { S->status = ST_BREAKDOWN; break; }
+        S->alpha_re = S->rho_re / v[0]; S->alpha_im = 0.0;
+        break;
+    }
+    case FIN_CG_RR: {               // v[0] = (r, r)
+        S->iters += 1;
+        S->rr = v[0];
+        if (!isfinite(v[0])) { S->status = ST_BREAKDOWN; break; }
+        if (v[0] <= S->tol2 * S->bb) S->status = ST_CONVERGED;
+        break;
+    }
+    case FIN_CG_BETA: {             // v[0] = (z, z) new
+        if (S->rho_re == 0.0) { S->status = ST_BREAKDOWN; break; }
+        S->beta_re = v[0] / S->rho_re; S->beta_im = 0.0;
+        S->rho_re = v[0];
+        break;
+    }
+    default: break;
+    }
+}
+
+inline int vec_blocks(long long N) {
+    long long nb = (N + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    return (int)nb;
+}
+
+}  // namespace
+
+// ==========================================================================================
+// host launchers
+// ==========================================================================================
+#ifndef STENCIL_P
+#define STENCIL_P 2
+#endif
+
+int helm_apply_num_blocks(const helm_op *op) {
+    const int ntx = (op->nx + TX - 1) / TX, ntz = (op->nz + 4 * STENCIL_P - 1) / (4 * STENCIL_P);
+    return ntx * ntz;
+}
+int helm_vec_num_blocks(const helm_op *op) { return vec_blocks(op->N); }
+
+template <int P, bool SCALED, bool ADJ>
+static void launch_stencil_epi(hipStream_t st, dim3 grid, const StencilParams &q, int epi) {
+    switch (epi) {
+    case EPI_NONE: hipLaunchKernelGGL((k_stencil<P, SCALED, ADJ, EPI_NONE>), grid, dim3(256), 0, st, q); break;
+    case EPI_DOT_W: hipLaunchKernelGGL((k_stencil<P, SCALED, ADJ, EPI_DOT_W>), grid, dim3(256), 0, st, q); break;
+    case EPI_DOT_XY: hipLaunchKernelGGL((k_stencil<P, SCALED, ADJ, EPI_DOT_XY>), grid, dim3(256), 0, st, q); break;
+    case EPI_DOT_YY: hipLaunchKernelGGL((k_stencil<P, SCALED, ADJ, EPI_DOT_YY>), grid, dim3(256), 0, st, q); break;
+    case EPI_RESID: hipLaunchKernelGGL((k_stencil<P, SCALED, ADJ, EPI_RESID>), grid, dim3(256), 0, st, q); break;
+    }
+}
+
+int helm_launch_apply(helm_op *op, const ApplyArgs &a) {
+    StencilParams q;
+    q.planes = a.planes; q.X = a.X; q.Y = a.Y; q.W = a.W; q.ld = a.ld; q.N = op->N;
+    q.nz = op->nz; q.nx = op->nx; q.nrhs = a.nrhs;
+    q.ntx = (op->nx + TX - 1) / TX; q.ntz = (op->nz + 4 * STENCIL_P - 1) / (4 * STENCIL_P);
+    q.nblk = q.ntx * q.ntz;
+    q.scal = a.scal; q.part = a.part;
+    int split = 1;
+    if (q.nblk < 1024) { split = (1024 + q.nblk - 1) / q.nblk; if (split > a.nrhs) split = a.nrhs; if (split < 1) split = 1; }
+    dim3 grid(q.nblk, split);
+
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (op->profiling) {
+        if (op->ev_used + 2 > op->ev_pool.size() && op->ev_pool.size() >= 8192) { e0 = nullptr; }
+        else if (op->ev_used + 2 > op->ev_pool.size()) {
+            for (int i = 0; i < 64; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) HELM_FAIL(op, HELM_ERR_DEVICE, "hipEventCreate failed"); op->ev_pool.push_back(e); }
+        }
+        if (op->ev_used + 2 <= op->ev_pool.size()) {
+            e0 = op->ev_pool[op->ev_used]; e1 = op->ev_pool[op->ev_used + 1];
+            hipEventRecord(e0, op->stream);
+        } else e0 = nullptr;
+    }
+    if (a.scaled) {
+        if (a.adjoint) launch_stencil_epi<STENCIL_P, true, true>(op->stream, grid, q, a.epi);
+        else launch_stencil_epi<STENCIL_P, true, false>(op->stream, grid, q, a.epi);
+    } else {
+        if (a.adjoint) launch_stencil_epi<STENCIL_P, false, true>(op->stream, grid, q, a.epi);
+        else launch_stencil_epi<STENCIL_P, false, false>(op->stream, grid, q, a.epi);
+    }
+    if (op->profiling && e0) {
+        hipEventRecord(e1, op->stream);
+        int nact = a.nrhs;   // upper bound: inactive RHS are skipped on the device
+        op->ev_pending.push_back(std::make_pair((int)op->ev_used, (double)op->N * (32.0 * nact + 144.0)));
+        op->ev_used += 2;
+    }
+    HIP_TRY(op, hipGetLastError());
+    return HELM_OK;
+}
+
+int helm_launch_scale_planes(helm_op *op) {
+    const int blocks = (int)((op->N + 255) / 256);
+    hipLaunchKernelGGL(k_scale_planes, dim3(blocks), dim3(256), 0, op->stream, op->d_C, op->d_Cs, op->d_dinv, op->N, op->nblocks);
+    HIP_TRY(op, hipGetLastError());
+    return HELM_OK;
+}
+
+int helm_launch_prep_rhs(helm_op *op, const cplx *dRHS, long long rhs_ld, long long row_off, cplx premul,
+                         const cplx *sub, cplx *out, int nrhs) {
+    dim3 grid(vec_blocks(op->N), nrhs);
+    hipLaunchKernelGGL(k_prep_rhs, grid, dim3(256), 0, op->stream, dRHS, rhs_ld, row_off, premul, sub, (const cplx *)nullptr, out, op->N);
+    HIP_TRY(op, hipGetLastError());
+    return HELM_OK;
+}
+
+// bbar -> krylov vectors; `sub` etc. were folded into bbar by the caller (prep + scale)
+int helm_launch_bicg_init(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, cplx premul, const cplx *sub,
+                          VecPtrs w, int nrhs, double rtol) {
+    // w.t temporarily receives bbar = dinv * (premul*rhs - sub); the caller copies/keeps it
+    dim3 grid(vec_blocks(op->N), nrhs);
+    hipLaunchKernelGGL(k_prep_rhs, grid, dim3(256), 0, op->stream, dRHS, rhs_ld, (long long)0, premul, sub,
+                       (const cplx *)(op->d_dinv + (long long)block * op->N), w.t, op->N);
+    hipLaunchKernelGGL(k_krylov_init, grid, dim3(256), 0, op->stream, (const cplx *)w.t, w, op->N, (double *)op->d_part, (int)grid.x);
+    FinParams f; f.scal = op->d_scal; f.part = (const double *)op->d_part; f.nblk = grid.x; f.which = FIN_BICG_INIT; f.rtol = rtol; f.mask = nullptr; f.aux = nullptr;
+    hipLaunchKernelGGL(k_fin, dim3(nrhs), dim3(256), 0, op->stream, f);
+    HIP_TRY(op, hipGetLastError());
+    return HELM_OK;
+}
+
+int helm_launch_bicg_p(helm_op *op, VecPtrs w, int nrhs) {
+    dim3 grid(vec_blocks(op->N), nrhs);
+    hipLaunchKernelGGL(k_bicg_p, grid, dim3(256), 0, op->stream, w, op->N, (const RhsScal *)op->d_scal);
+    return HELM_OK;
+}
+int helm_launch_bicg_s(helm_op *op, VecPtrs w, int nrhs) {
+    dim3 grid(vec_blocks(op->N), nrhs);
+    hipLaunchKernelGGL(k_bicg_s, grid, dim3(256), 0, op->stream, w, op->N, (const RhsScal *)op->d_scal);
+    return HELM_OK;
+}
+int helm_launch_bicg_xr(helm_op *op, VecPtrs w, int nrhs, int) {
+    dim3 grid(vec_blocks(op->N), nrhs);
+    hipLaunchKernelGGL(k_bicg_xr, grid, dim3(256), 0, op->stream, w, op->N, (const RhsScal *)op->d_scal, (double *)op->d_part, (int)grid.x);
+    return HELM_OK;
+}
+int helm_launch_cg_xr(helm_op *op, VecPtrs w, int nrhs) {
+    dim3 grid(vec_blocks(op->N), nrhs);
+    hipLaunchKernelGGL(k_cg_xr, grid, dim3(256), 0, op->stream, w, op->N, (const RhsScal *)op->d_scal, (double *)op->d_part, (int)grid.x);
+    return HELM_OK;
+}
+int helm_launch_cg_p(helm_op *op, VecPtrs w, int nrhs, int first) {
+    dim3 grid(vec_blocks(op->N), nrhs);
+    hipLaunchKernelGGL(k_cg_p, grid, dim3(256), 0, op->stream, w, op->N, (const RhsScal *)op->d_scal, first);
+    return HELM_OK;
+}
+
+int helm_launch_fin(helm_op *op, int which, int nrhs, int nblk_part) {
+    FinParams f; f.scal = op->d_scal; f.part = (const double *)op->d_part; f.nblk = nblk_part; f.which = which; f.rtol = 0.0; f.mask = nullptr; f.aux = nullptr;
+    hipLaunchKernelGGL(k_fin, dim3(nrhs), dim3(256), 0, op->stream, f);
+    return HELM_OK;
+}
+
+int helm_launch_fin_ex(helm_op *op, int which, int nrhs, int nblk_part, const int *mask, double *aux) {
+    FinParams f; f.scal = op->d_scal; f.part = (const double *)op->d_part; f.nblk = nblk_part; f.which = which; f.rtol = 0.0; f.mask = mask; f.aux = aux;
+    hipLaunchKernelGGL(k_fin, dim3(nrhs), dim3(256), 0, op->stream, f);
+    return HELM_OK;
+}
+
+int helm_launch_restart_copy_mask(helm_op *op, VecPtrs w, int nrhs, const int *mask) {
+    dim3 grid(vec_blocks(op->N), nrhs);
+    hipLaunchKernelGGL(k_restart_copy, grid, dim3(256), 0, op->stream, w, op->N, mask);
+    return HELM_OK;
+}
+
+int helm_launch_norm2(helm_op *op, const cplx *a, int nrhs) {
+    dim3 grid(vec_blocks(op->N), nrhs);
+    hipLaunchKernelGGL(k_norm2, grid, dim3(256), 0, op->stream, a, op->N, (double *)op->d_part, (int)grid.x);
+    return HELM_OK;
+}
+
+int helm_launch_finish(helm_op *op, const cplx *x, cplx *dU, long long u_ld, int nrhs, long long row_off) {
+    dim3 grid(vec_blocks(op->N), nrhs);
+    hipLaunchKernelGGL(k_finish, grid, dim3(256), 0, op->stream, x, dU, u_ld, row_off, op->N);
+    HIP_TRY(op, hipGetLastError());
+    return HELM_OK;
+}
+
+int helm_launch_zero(helm_op *op, cplx *p, long long n) {
+    hipLaunchKernelGGL(k_zero, dim3(vec_blocks(n)), dim3(256), 0, op->stream, p, n);
+    return HELM_OK;
+}
+
+int helm_launch_imaging(helm_op *op, const cplx *uf, const cplx *ub, int nsrc, const cplx *scaler, cplx *g) {
+    hipLaunchKernelGGL(k_imaging, dim3(vec_blocks(op->N)), dim3(256), 0, op->stream, uf, ub, nsrc, scaler, g, op->N);
+    HIP_TRY(op, hipGetLastError());
+    return HELM_OK;
+}

@@ -1,0 +1,286 @@
+"""GPU-backed discretisation base classes.
+
+Interface of zephyr/backend/discretization.py:18-169: an object built from a `systemConfig`
+dict that supports `obj * rhs` -> conj(A^-1 (premul * rhs)).  The sparse LU behind the
+reference's `Ainv` (external problemo.BestSolver, discretization.py:78-85) is replaced by the
+matrix-free Krylov solve of libhelm on the MI355X; assembly also happens on the device.
+"""
+import copy
+import ctypes
+import os
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+from .base import BaseModelDependent
+from .config import BaseSCCache
+
+
+def default_device():
+    for key in ('HELM_DEVICE', 'LOCAL_RANK'):
+        if key in os.environ:
+            try:
+                return int(os.environ[key])
+            except ValueError:
+                pass
+    return 0
+
+
+class BaseDiscretization(BaseModelDependent):
+    """Model properties, device operator handle and the `A^-1 * rhs` action (discretization.py:18-106)."""
+
+    VARIANT = None
+
+    initMap = {
+        #   key            required  rename        cast
+        'c':              (True,     '_c',         np.complex128),
+        'rho':            (False,    '_rho',       np.float64),
+        'freq':           (True,     None,         np.complex128),
+        'Solver':         (False,    '_Solver',    None),       # accepted for compatibility; the GPU Krylov solver is used
+        'tau':            (False,    '_tau',       np.float64),
+        'premul':         (False,    '_premul',    np.complex128),
+        # solver controls (additions of this implementation)
+        'rtol':           (False,    '_rtol',      np.float64),
+        'maxit':          (False,    '_maxit',     np.int64),
+        'method':         (False,    '_method',    str),
+        'batch':          (False,    '_batch',     np.int64),
+        'checkEvery':     (False,    '_checkEvery', np.int64),
+        'device':         (False,    '_device',    np.int64),
+    }
+
+    # ---- model properties -----------------------------------------------------------------
+    @property
+    def tau(self):
+        'Laplace-domain damping time constant (discretization.py:33-36)'
+        return getattr(self, '_tau', np.inf)
+
+    @property
+    def dampCoeff(self):
+        return 1j / self.tau
+
+    @property
+    def premul(self):
+        return getattr(self, '_premul', 1.)
+
+    @property
+    def c(self):
+        'Complex wave velocity (discretization.py:49-55)'
+        if isinstance(self._c, np.ndarray) and self._c.ndim > 0:
+            return self._c
+        return self._c * np.ones((self.nz, self.nx), dtype=np.complex128)
+
+    @property
+    def rho(self):
+        'Bulk density; Gardner default 310 Re(c)^0.25 (discretization.py:57-72)'
+        if hasattr(self, '_rho'):
+            if not (isinstance(self._rho, np.ndarray) and self._rho.ndim > 0):
+                return self._rho * np.ones((self.nz, self.nx), dtype=np.float64)
+        else:
+            self._rho = 310. * self.c.real ** 0.25
+        return self._rho
+
+    # ---- solver controls -------------------------------------------------------------------
+    @property
+    def rtol(self):
+        return float(getattr(self, '_rtol', 1e-10))
+
+    @property
+    def maxit(self):
+        return int(getattr(self, '_maxit', 200000))
+
+    @property
+    def method(self):
+        return getattr(self, '_method', 'auto')
+
+    @property
+    def device(self):
+        return int(getattr(self, '_device', default_device()))
+
+    # ---- device operator --------------------------------------------------------------------
+    def _model_arrays(self):
+        'returns (c, rho, theta, eps, delta) host arrays (None where not applicable)'
+        dims = (int(self.nz), int(self.nx))
+        return _lib.c128(self.c.reshape(dims)), _lib.f64(self.rho.reshape(dims)), None, None, None
+
+    def _assemble_args(self):
+        'returns (ky, cPML)'
+        return 0.0, 0.0
+
+    @property
+    def handle(self):
+        'The assembled device operator (lazily created; replaces the LU `Ainv`, discretization.py:78-85)'
+        if getattr(self, '_handle', None) is None:
+            lib = _lib.load()
+            _lib.require_gpu()
+            fs = (ctypes.c_int * 4)(*[1 if f else 0 for f in self.freeSurf])
+            ky, cpml = self._assemble_args()
+            h = lib.helm_create(self.device, self.VARIANT, int(self.nz), int(self.nx), float(self.dx), float(self.dz),
+                                int(self.nPML), fs)
+            if not h:
+                raise _lib.HelmError(-2, _lib.last_error(None))
+            try:
+                c, rho, theta, eps, delta = self._model_arrays()
+                _lib.check(lib.helm_set_model(h, _lib.ptr(c), _lib.ptr(rho), _lib.ptr(theta), _lib.ptr(eps), _lib.ptr(delta)), h)
+                f = complex(self.freq)
+                _lib.check(lib.helm_assemble(h, f.real, f.imag, float(self.tau), float(ky), float(cpml)), h)
+            except Exception:
+                lib.helm_destroy(h)
+                raise
+            self._handle = h
+        return self._handle
+
+    @property
+    def Ainv(self):
+        return self.handle
+
+    @Ainv.deleter
+    def Ainv(self):
+        h = getattr(self, '_handle', None)
+        if h is not None:
+            _lib.load().helm_destroy(h)
+            self._handle = None
+
+    @property
+    def factors(self):
+        'True when a device operator is resident (mirrors the LU-cache flag, discretization.py:91-96)'
+        return getattr(self, '_handle', None) is not None
+
+    @factors.deleter
+    def factors(self):
+        del self.Ainv
+
+    def __del__(self):
+        try:
+            del self.factors
+        except Exception:
+            pass
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop('_handle', None)     # device handles do not pickle; they are rebuilt lazily
+        state.pop('_A', None)
+        return state
+
+    # ---- operator views -----------------------------------------------------------------------
+    def diagonals(self):
+        'Coefficient planes from the device: (nblocks, 9, nz, nx) complex128'
+        lib = _lib.load()
+        h = self.handle
+        nb = lib.helm_num_blocks(h)
+        out = np.empty((nb, 9, int(self.nz), int(self.nx)), dtype=np.complex128)
+        _lib.check(lib.helm_get_diagonals(h, _lib.ptr(out)), h)
+        return out
+
+    def applyForward(self, x, block=0, adjoint=False):
+        'A x (or A^H x) on the device for one block; x: (N,) or (N, nrhs)'
+        lib = _lib.load()
+        h = self.handle
+        x2, onedim = self._dense_rhs(x)
+        X = np.ascontiguousarray(x2.T, dtype=np.complex128)
+        Y = np.empty_like(X)
+        _lib.check(lib.helm_apply(h, int(block), 1 if adjoint else 0, _lib.ptr(X), _lib.ptr(Y), X.shape[0]), h)
+        return Y.T[:, 0] if onedim else Y.T
+
+    @property
+    def shape(self):
+        return (self.nrow, self.nrow)
+
+    def _solve_opts(self):
+        o = _lib.SolveOpts()
+        o.method = _lib.METHODS[self.method.lower()]
+        o.rtol = self.rtol
+        o.maxit = self.maxit
+        o.check_every = int(getattr(self, '_checkEvery', 0))
+        o.batch = int(getattr(self, '_batch', 0))
+        o.flags = 0
+        return o
+
+    def _solve(self, rhs, rows):
+        'rhs: (rows, nrhs) dense complex -> (rows, nrhs)'
+        lib = _lib.load()
+        h = self.handle
+        nrhs = rhs.shape[1]
+        R = np.ascontiguousarray(rhs.T, dtype=np.complex128)       # each RHS contiguous
+        U = np.empty_like(R)
+        info = (_lib.SolveInfo * nrhs)()
+        opts = self._solve_opts()
+        pm = complex(self.premul)
+        rc = lib.helm_solve(h, _lib.ptr(R), _lib.ptr(U), nrhs, int(rows), pm.real, pm.imag, ctypes.byref(opts), info)
+        _lib.check(rc, h)
+        self.lastInfo = [dict(iterations=i.iterations, status=i.status, restarts=i.restarts, method=i.method,
+                              relres=i.relres) for i in info]
+        if rc > 0:
+            worst = max(i.relres for i in info)
+            raise ArithmeticError('%d of %d right-hand sides did not reach rtol=%g (worst relative residual %.3e, maxit=%d)'
+                                  % (rc, nrhs, self.rtol, worst, self.maxit))
+        return U.T
+
+    @staticmethod
+    def _dense_rhs(rhs):
+        if sp.issparse(rhs):
+            rhs = rhs.toarray()
+        rhs = np.asarray(rhs, dtype=np.complex128)
+        onedim = rhs.ndim == 1
+        if onedim:
+            rhs = rhs.reshape((-1, 1))
+        return rhs, onedim
+
+    def __mul__(self, rhs):
+        'conj(A^-1 (premul * rhs))  (discretization.py:101-103)'
+        rhs, onedim = self._dense_rhs(rhs)
+        if rhs.shape[0] != self.nrow:
+            raise ValueError('dimension mismatch')
+        u = self._solve(rhs, self.nrow)
+        return u[:, 0] if onedim else u
+
+    def __call__(self, value):
+        return self * value
+
+
+class DiscretizationWrapper(BaseSCCache):
+    """Composite of sub-problems built from per-sub-problem config updates (discretization.py:109-169)."""
+
+    initMap = {
+        'Disc':           (True,     None,         None),
+        'scaleTerm':      (False,    '_scaleTerm', np.complex128),
+    }
+
+    maskKeys = {'scaleTerm'}
+    cacheItems = ['_subProblems']
+
+    @property
+    def scaleTerm(self):
+        return getattr(self, '_scaleTerm', 1.)
+
+    @property
+    def _spConfigs(self):
+        def merged(update):
+            cfg = copy.copy(self.systemConfig)
+            cfg.update(update)
+            return cfg
+        return (merged(update) for update in self.spUpdates)
+
+    @property
+    def subProblems(self):
+        if getattr(self, '_subProblems', None) is None:
+            self._subProblems = [self.Disc(cfg) for cfg in self._spConfigs]
+        return self._subProblems
+
+    @property
+    def factors(self):
+        subs = getattr(self, '_subProblems', None)
+        return subs is not None and any(sub.factors for sub in subs)
+
+    @factors.deleter
+    def factors(self):
+        subs = getattr(self, '_subProblems', None)
+        if subs is not None:
+            for sub in subs:
+                del sub.factors
+
+    @property
+    def spUpdates(self):
+        raise NotImplementedError
+
+    def __mul__(self, rhs):
+        raise NotImplementedError
