@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- wavefields/s of the Helmholtz hot path on MI355X (BASELINE.json metric).
+
+Workload (BASELINE.json configs[2] / SURVEY.md 8(d) cfg3): Eurus, isotropic, 1024 x 1024 synthetic
+Marmousi-scale model (seed 20240512), dx = dz = 9 m, 16 frequencies linspace(2, 9.5, 16) Hz, 256
+Kaiser-windowed-sinc sources at z = 20 m, fp64 complex.  One "step" = one work item of that job:
+assemble A(w) for one frequency on the GPU and solve it for one batch of sources (default 8) to
+a true relative residual <= 1e-10, right-hand sides and wavefields resident in HBM.  Work items are
+dealt round-robin over ranks (weak scaling: every rank does `steps` items; no data-path collective).
+
+Prints ONE JSON line (rank 0).  `value` = wavefields completed by all ranks / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+NFREQ, NSRC = 16, 256
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def build_config(n, dx):
+    from zephyr_amd.models import marmousi_like
+    c = marmousi_like(n, n, dx)
+    return dict(nx=n, nz=n, dx=dx, dz=dx, c=c, nPML=10, cPML=1e3, freeSurf=(False, False, False, False))
+
+
+def source_locations(n, dx, nsrc):
+    xs = np.linspace(0.04 * n * dx, 0.96 * n * dx, nsrc)
+    return np.stack([xs, np.full(nsrc, 20.0)], axis=1)
+
+
+def work_item(w, nbatch_per_freq):
+    """global work-item index -> (frequency index, source-batch index).  Consecutive items walk the
+    frequency list with stride 5 (co-prime with 16) so short runs sample low and high frequencies."""
+    return (w * 5) % NFREQ, (w // NFREQ) % nbatch_per_freq
+
+
+def cpu_baseline(cfg, freqs, q_host, sample_rhs=8):
+    """Reference-equivalent CPU path (oracle: numpy assembly + SciPy SuperLU + back-substitution) on a
+    bounded sample: ONE frequency of the same 1024^2 model, LU of the isotropic-equivalent M1 block
+    (identical result to the reference's 2N system), `sample_rhs` back-substitutions.
+    Throughput is quoted for the job's 256 sources per frequency: 256 / (assemble + factor + 256*t_rhs)."""
+    from oracle import helm_oracle as ho
+    n = cfg['nx']
+    f = float(freqs[len(freqs) // 2])
+    t0 = time.perf_counter()
+    rho = ho.gardner_rho(cfg['c'])
+    C4 = ho.eurus_coefficients(n, n, cfg['c'], rho, f, dx=cfg['dx'], dz=cfg['dz'], nPML=cfg['nPML'], cPML=cfg['cPML'])
+    op = ho.DirectOperator(C4[0])
+    t1 = time.perf_counter()
+    op.factor()
+    t2 = time.perf_counter()
+    u = op * q_host[:, :sample_rhs]
+    t3 = time.perf_counter()
+    t_rhs = (t3 - t2) / sample_rhs
+    wps = NSRC / ((t1 - t0) + (t2 - t1) + NSRC * t_rhs)
+    return dict(value=wps, unit='wavefields/s', cores=1, kind='port',
+                sample='1 of 16 freqs (%.2f Hz) of the 1024^2 job: numpy assembly %.1fs + SciPy SuperLU factor %.1fs + %d back-substitutions %.3fs each, '
+                       'extrapolated to 256 sources/frequency; single thread; host has %d logical CPUs'
+                       % (f, t1 - t0, t2 - t1, sample_rhs, t_rhs, os.cpu_count())), u
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--n', type=int, default=1024, help='grid side (1024 = BASELINE workload)')
+    ap.add_argument('--dx', type=float, default=9.0)
+    ap.add_argument('--batch', type=int, default=8, help='sources per work item')
+    ap.add_argument('--rtol', type=float, default=1e-10)
+    ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
+    ap.add_argument('--method', default='auto')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    import __graft_entry__ as g
+    g.build()
+    from zephyr_amd import Eurus, SparseKaiserSource
+
+    n, dx = args.n, args.dx
+    cfg = build_config(n, dx)
+    freqs = np.linspace(2.0, 9.5, NFREQ)
+    B = args.batch
+    nb = NSRC // B
+    src = SparseKaiserSource(cfg)
+    locs = source_locations(n, dx, NSRC)
+    N = n * n
+
+    # all right-hand sides of the job are staged in HBM before the timed region
+    q_all = src(locs).toarray()                              # (N, 256) complex
+    d_rhs = torch.from_numpy(np.ascontiguousarray(q_all.T)).to(dev)      # [256][N]
+    d_u = torch.empty((B, N), dtype=torch.complex128, device=dev)
+
+    ops = {}
+
+    def run_item(w, profile):
+        fi, bi = work_item(w, nb)
+        sc = dict(cfg)
+        sc.update(freq=float(freqs[fi]), rtol=args.rtol, maxit=400000, method=args.method, batch=B, device=local)
+        op = Eurus(sc)                   # assembly on the GPU happens inside the timed region
+        op.setProfiling(profile)
+        rhs_ptr = d_rhs.data_ptr() + bi * B * N * 16
+        info = op.solveDevice(rhs_ptr, d_u.data_ptr(), B, N)
+        t = op.lastTiming()
+        del op.factors
+        return fi, info, t
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        run_item(rank + world * k, False)
+
+    barrier()
+    t0 = time.perf_counter()
+    iters, apply_ms, apply_launches, apply_bytes, solve_ms = [], 0.0, 0, 0.0, 0.0
+    freq_used = []
+    for k in range(args.steps):
+        fi, info, t = run_item(rank + world * (args.warmup + k), True)
+        iters += [i['iterations'] for i in info]
+        freq_used.append(float(freqs[fi]))
+        apply_ms += t['apply_ms']; apply_launches += t['apply_launches']; apply_bytes += t['apply_bytes']
+        solve_ms += t['solve_ms']
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    wavefields = world * args.steps * B
+    value = wavefields / elapsed
+
+    out = None
+    if rank == 0:
+        achieved = (apply_bytes / (apply_ms * 1e-3)) / 1e9 if apply_ms > 0 else 0.0
+        out = {
+            'metric': 'wavefields/sec (freq x source solves/s) on 1024^2 grid',
+            'value': value, 'unit': 'wavefields/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'Eurus 2D isotropic %dx%d synthetic-Marmousi (seed 20240512, dx=%g m), 16 freqs 2-9.5 Hz x 256 Kaiser sources; '
+                                   'step = assemble 1 frequency + solve %d sources to true relres<=%g (Jacobi-BiCGSTAB, CGNR fallback)' % (n, n, dx, B, args.rtol),
+                       'grid': [n, n], 'sources_per_step': B, 'freqs_hz_this_run': freq_used, 'sharding': 'work items (freq, source batch) round-robin over ranks',
+                       'iterations_per_rhs_mean': float(np.mean(iters)) if iters else None,
+                       'iterations_per_rhs_max': int(np.max(iters)) if iters else None},
+            'roofline': {'bound': 'hbm', 'kernel': 'k_stencil (batched 9-pt complex128 apply + fused dots)',
+                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': None, 'launches_timed': int(apply_launches),
+                         'avg_launch_us': 1e3 * apply_ms / apply_launches if apply_launches else None,
+                         'bytes_per_launch_algorithmic': apply_bytes / apply_launches if apply_launches else None,
+                         'apply_share_of_solve_time': apply_ms / solve_ms if solve_ms > 0 else None},
+        }
+        if world == 1 and not args.no_cpu:
+            cb, _ = cpu_baseline(cfg, freqs, q_all)
+            out['cpu_baseline'] = cb
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REAL reference (dev container only)  --  test infrastructure.
+
+Imports /root/reference/zephyr (read-only) through the stand-in packages in oracle/refshim and
+(1) checks oracle/helm_oracle.py entry-by-entry against it, (2) writes small golden input/output
+vectors that travel with the repo.  Only data is written: inputs and the reference's outputs.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+
+Nothing here runs on the GPU box and the product package never imports it.
+"""
+import os
+import sys
+import warnings
+
+os.environ.setdefault('PYTHONDONTWRITEBYTECODE', '1')
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = '/root/reference'
+sys.path[:0] = [os.path.join(HERE, 'refshim'), REF, ROOT]
+warnings.simplefilter('ignore')
+
+import numpy as np                                      # noqa: E402
+import scipy.sparse as sp                               # noqa: E402
+import zephyr.backend as zb                             # noqa: E402  (the reference)
+from oracle import helm_oracle as ho                    # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+os.makedirs(OUT, exist_ok=True)
+
+
+def planes_from_matrix(A, nz, nx):
+    """Reference sparse matrix (N x N) -> C[k, iz, ix]; asserts nothing non-zero is left over."""
+    A = sp.csr_matrix(A)
+    N = nz * nx
+    iz, ix = np.mgrid[0:nz, 0:nx]
+    C = np.zeros((9, nz, nx), dtype=np.complex128)
+    for k, (dz, dx) in enumerate(ho.SLOT_OFFSETS):
+        jz, jx = iz + dz, ix + dx
+        ok = (jz >= 0) & (jz < nz) & (jx >= 0) & (jx < nx)
+        rows = (iz * nx + ix)[ok]
+        cols = (jz * nx + jx)[ok]
+        C[k][ok] = np.asarray(A[rows, cols]).ravel()
+    left = A - ho.coefficients_to_csr(C)
+    assert left.nnz == 0 or abs(left).max() == 0.0, 'reference matrix has entries outside the 9-point pattern'
+    return C
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / np.abs(b).max()
+
+
+def hetero(nz, nx, seed, complex_c=True):
+    rng = np.random.default_rng(seed)
+    c = 1800. + 2200. * rng.random((nz, nx))
+    if complex_c:
+        c = c * (1 + 0.5j / (40. + 60. * rng.random((nz, nx))))     # c + 0.5j c / Q
+    rho = 1000. + 600. * rng.random((nz, nx))
+    return c, rho
+
+
+def g1_minizephyr_planes():
+    nz, nx = 24, 28
+    c, rho = hetero(nz, nx, 11)
+    base = dict(nx=nx, nz=nz, dx=7., dz=9., c=c, rho=rho, freq=13., tau=0.4, ky=0.001, nPML=5)
+    out = dict(nz=nz, nx=nx, c=c, rho=rho, dx=7., dz=9., freq=13., tau=0.4, ky=0.001, nPML=5)
+    sums = []
+    for code in range(16):
+        fs = tuple(bool(code >> b & 1) for b in range(4))
+        sc = dict(base, freeSurf=fs)
+        C = planes_from_matrix(zb.MiniZephyr(sc).A, nz, nx)
+        mine = ho.minizephyr_coefficients(nz, nx, c, rho, 13., dx=7., dz=9., tau=0.4, ky=0.001, nPML=5, freeSurf=fs)
+        assert rel(mine, C) <= 1e-13, ('MiniZephyr planes', fs, rel(mine, C))
+        sums.append([C.sum(), np.abs(C).sum(), (C * np.arange(C.size).reshape(C.shape)).sum()])
+        if code in (0, 9, 6):
+            out['planes_fs%d' % code] = C
+    out['checksums'] = np.array(sums)
+    # defaults: scalar c, default rho (Gardner), dx default, nPML default
+    sc = dict(nx=30, nz=26, c=2500., freq=40.)
+    out['planes_defaults'] = planes_from_matrix(zb.MiniZephyr(sc).A, 26, 30)
+    mine = ho.minizephyr_coefficients(26, 30, 2500., ho.gardner_rho(ho.as_field(2500., 26, 30, np.complex128)), 40.)
+    assert rel(mine, out['planes_defaults']) <= 1e-13
+    np.savez_compressed(os.path.join(OUT, 'g1_minizephyr_planes.npz'), **out)
+
+
+def g2_eurus_planes():
+    nz, nx = 22, 26
+    c, rho = hetero(nz, nx, 12)
+    rng = np.random.default_rng(13)
+    theta = 0.6 * rng.random((nz, nx)) - 0.3
+    eps = 0.25 * rng.random((nz, nx))
+    delta = 0.15 * rng.random((nz, nx))
+    out = dict(nz=nz, nx=nx, c=c, rho=rho, dx=7., dz=9., freq=13., tau=0.4, nPML=6, cPML=800., theta=theta, eps=eps, delta=delta)
+    for name, kw in (('iso', {}), ('tti', dict(theta=theta, eps=eps, delta=delta)), ('ell', dict(eps=eps, delta=eps))):
+        sc = dict(nx=nx, nz=nz, dx=7., dz=9., c=c, rho=rho, freq=13., tau=0.4, nPML=6, cPML=800.)
+        sc.update(kw)
+        A = sp.csr_matrix(zb.Eurus(sc).A)
+        N = nz * nx
+        C4 = np.stack([planes_from_matrix(A[r * N:(r + 1) * N, cc * N:(cc + 1) * N], nz, nx) for r in (0, 1) for cc in (0, 1)])
+        mine = ho.eurus_coefficients(nz, nx, c, rho, 13., dx=7., dz=9., tau=0.4, nPML=6, cPML=800., **kw)
+        for m in range(4):
+            scale = np.abs(C4[m]).max()
+            assert scale == 0 and np.abs(mine[m]).max() == 0 or rel(mine[m], C4[m]) <= 1e-13, ('Eurus planes', name, m)
+        out['planes_' + name] = C4
+    np.savez_compressed(os.path.join(OUT, 'g2_eurus_planes.npz'), **out)
+
+
+def g3_wavefields():
+    out = {}
+    # the reference's own test configuration (test_MiniZephyr.py:81-114, test_Eurus.py:39-94)
+    nx, nz = 100, 200
+    sloc = np.array([[25., 25.]])
+    rec = (np.arange(5, 196, 10), 60)          # receiver line: iz = 5..195 step 10 at ix = 60
+    for name, cls, sc in (
+        ('mz', zb.MiniZephyr, dict(c=2500., rho=1., nx=nx, nz=nz, freq=2e2)),
+        ('mzhd', zb.MiniZephyrHD, dict(c=2500., rho=1., nx=nx, nz=nz, freq=2e2)),
+        ('eu', zb.Eurus, dict(c=2000. * np.ones((nz, nx)), rho=np.ones((nz, nx)), nx=nx, nz=nz, dx=1, dz=1, freq=2e2, nPML=10, cPML=1e3)),
+        ('euhd', zb.EurusHD, dict(c=2000. * np.ones((nz, nx)), rho=np.ones((nz, nx)), nx=nx, nz=nz, dx=1, dz=1, freq=2e2, nPML=10, cPML=1e3)),
+        ('euell', zb.Eurus, dict(c=2000. * np.ones((nz, nx)), rho=np.ones((nz, nx)), nx=nx, nz=nz, dx=1, dz=1, freq=2e2, nPML=10, cPML=1e3,
+                                 theta=np.zeros((nz, nx)), eps=0.2 * np.ones((nz, nx)), delta=0.2 * np.ones((nz, nx)))),
+    ):
+        op = cls(sc)
+        q = (zb.StackedSimpleSource if name.startswith('eu') else zb.SimpleSource)(sc)(sloc)
+        u = op * q
+        ur = u[:nx * nz, 0].reshape((nz, nx))
+        out[name + '_line'] = ur[rec[0], rec[1]]
+        # the analytic comparison the reference's tests assert on
+        scA = dict(sc)
+        if name == 'euell':
+            scA.update(eps=0.2, theta=0.)
+        scA['c'] = float(np.ravel(sc['c'])[0]); scA['rho'] = 1.
+        uA = zb.AnalyticalHelmholtz(scA)(sloc).reshape((nz, nx))
+        seg = (uA[40:180, 40:80] - ur[40:180, 40:80]) / abs(uA[40:180, 40:80])
+        out[name + '_analytic_err'] = np.sqrt((seg.conj() * seg).sum()) / seg.size
+        # oracle check
+        if name.startswith('mz'):
+            C = ho.minizephyr_coefficients(nz, nx, sc['c'], sc['rho'], 2e2)
+            mine = ho.DirectOperator(C, premul=ho.premul_hd(2e2) if name == 'mzhd' else 1.) * q
+        else:
+            kw = dict(theta=sc['theta'], eps=sc['eps'], delta=sc['delta']) if name == 'euell' else {}
+            C = ho.eurus_coefficients(nz, nx, sc['c'], sc['rho'], 2e2, dx=1, dz=1, nPML=10, cPML=1e3, **kw)
+            mine = ho.DirectOperator(C, premul=ho.premul_hd(2e2) if name == 'euhd' else 1., eurus=True) * q
+        assert np.linalg.norm(mine - u) / np.linalg.norm(u) <= 1e-10, (name, np.linalg.norm(mine - u) / np.linalg.norm(u))
+    out['rec_iz'] = rec[0]
+    out['rec_ix'] = rec[1]
+    # heterogeneous full fields at 64 x 64 (exercises the Eurus z-flip)
+    nz = nx = 64
+    c, rho = hetero(nz, nx, 21)
+    sc = dict(nx=nx, nz=nz, dx=10., dz=10., c=c, rho=rho, freq=12., nPML=8)
+    locs = np.array([[300., 320.], [150., 400.]])
+    q = zb.SimpleSource(sc)(locs)
+    out['het_c'], out['het_rho'], out['het_locs'], out['het_q'] = c, rho, locs, q
+    out['het_mz'] = zb.MiniZephyr(sc) * q
+    out['het_eu'] = zb.Eurus(sc) * q
+    out['het_eu_stacked'] = zb.Eurus(sc) * zb.StackedSimpleSource(sc)(locs)
+    C = ho.minizephyr_coefficients(nz, nx, c, rho, 12., dx=10., dz=10., nPML=8)
+    assert np.linalg.norm(ho.DirectOperator(C) * q - out['het_mz']) / np.linalg.norm(out['het_mz']) <= 1e-10
+    C4 = ho.eurus_coefficients(nz, nx, c, rho, 12., dx=10., dz=10., nPML=8)
+    assert np.linalg.norm(ho.DirectOperator(C4, eurus=True) * q - out['het_eu']) / np.linalg.norm(out['het_eu']) <= 1e-10
+    # config 1 of BASELINE.json: MiniZephyr 128^2, c=2000, 5 Hz, 1 source at (640, 640) m
+    sc1 = dict(nx=128, nz=128, dx=10., dz=10., c=2000., rho=1., nPML=10, freq=5.)
+    q1 = zb.SimpleSource(sc1)(np.array([[640., 640.]]))
+    u1 = zb.MiniZephyr(sc1) * q1
+    out['cfg1_u'] = u1[:, 0]
+    C = ho.minizephyr_coefficients(128, 128, 2000., 1., 5., dx=10., dz=10.)
+    assert np.linalg.norm((ho.DirectOperator(C) * q1)[:, 0] - u1[:, 0]) / np.linalg.norm(u1) <= 1e-12
+    np.savez_compressed(os.path.join(OUT, 'g3_wavefields.npz'), **out)
+
+
+def g4_multifreq():
+    nz, nx = 40, 50
+    c, rho = hetero(nz, nx, 31, complex_c=False)
+    freqs = [8., 12., 20.]
+    sc = dict(nx=nx, nz=nz, dx=10., dz=10., c=c, rho=rho, nPML=6, freqs=freqs, Disc=zb.MiniZephyr, parallel=False, scaleTerm=0.5 - 0.25j)
+    locs = np.array([[200., 150.], [310., 220.]])
+    q = zb.SimpleSource(sc)(locs)
+    out = dict(c=c, rho=rho, freqs=np.array(freqs), q=q, locs=locs)
+    mf = zb.MultiFreq(sc)
+    out['shared'] = np.stack(list(mf * q))
+    qlist = [q * (1 + i) for i in range(3)]
+    out['list'] = np.stack(list(mf * qlist))
+    out['gen'] = np.stack(list(mf * (qq for qq in qlist)))
+    out['onedim'] = np.stack(list(mf * q[:, 0]))
+    # ViscoMultiFreq (complex c from Q, dispersion)
+    Q = 50. + 100. * np.random.default_rng(32).random((nz, nx))
+    scv = dict(sc, c=c, Q=Q, freqBase=10., Disc=zb.MiniZephyr)
+    scv.pop('scaleTerm')
+    vm = zb.ViscoMultiFreq(scv)
+    out['Q'] = Q
+    out['visco'] = np.stack(list(vm * q))
+    out['visco_c'] = np.stack([np.asarray(s.c).reshape((nz, nx)) for s in vm.subProblems])
+    np.savez_compressed(os.path.join(OUT, 'g4_multifreq.npz'), **out)
+
+
+def g5_sources():
+    out = {}
+    sc = dict(nx=100, nz=100, dx=1., dz=1.)
+    locs = np.array([[50., 50.], [25.5, 30.25], [2.2, 50.1], [97.6, 96.3], [50.3, 1.4]])
+    out['locs'] = locs
+    for name, cfg in (('nofs', dict(sc)), ('ireg2', dict(sc, ireg=2)), ('ireg0', dict(sc, ireg=0)),
+                      ('scaled', dict(nx=100, nz=100, dx=12.5, dz=10., xorig=-100., zorig=50.))):
+        use = locs if name != 'scaled' else locs * np.array([12.5, 10.]) + np.array([-100., 50.])
+        q = zb.SparseKaiserSource(cfg)(use).tocoo()
+        order = np.lexsort((q.row, q.col))
+        out[name + '_row'], out[name + '_col'], out[name + '_val'] = q.row[order], q.col[order], q.data[order]
+        out[name + '_locs'] = use
+    # free-surface mirroring: a location near the top edge with freeSurf[2] (only case that is shape-consistent in the reference)
+    cfgfs = dict(sc, freeSurf=(False, False, True, False))
+    lfs = np.array([[50.3, 1.4], [20.2, 2.6]])
+    q = zb.SparseKaiserSource(cfgfs)(lfs).tocoo()
+    order = np.lexsort((q.row, q.col))
+    out['fs_row'], out['fs_col'], out['fs_val'], out['fs_locs'] = q.row[order], q.col[order], q.data[order], lfs
+    out['simple_idx'] = zb.SimpleSource(sc).linIndexOf(locs)
+    out['simple_q_nz'] = np.argwhere(zb.SimpleSource(sc)(locs) != 0)
+    out['stacked_shape'] = np.array(zb.StackedSimpleSource(sc)(locs).shape)
+    np.savez_compressed(os.path.join(OUT, 'g5_sources.npz'), **out)
+
+
+def g7_analytic():
+    sc = dict(c=2500., rho=1., nx=100, nz=200, freq=2e2)
+    out = {}
+    for name, s in (('green2d', sc), ('green3d', dict(sc, **{'3D': True})), ('stretch', dict(sc, eps=0.2, theta=0.3, dx=2., dz=1.5))):
+        out[name] = zb.AnalyticalHelmholtz(s)(np.array([[25., 25.]]))
+    np.savez_compressed(os.path.join(OUT, 'g7_analytic.npz'), **out)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g7']
+    table = dict(g1=g1_minizephyr_planes, g2=g2_eurus_planes, g3=g3_wavefields, g4=g4_multifreq, g5=g5_sources, g7=g7_analytic)
+    for name in which:
+        table[name]()
+        print('wrote', name, flush=True)
+    for f in sorted(os.listdir(OUT)):
+        print('%8.1f KB  %s' % (os.path.getsize(os.path.join(OUT, f)) / 1024., f))

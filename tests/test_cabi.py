@@ -1,0 +1,63 @@
+"""CPU: the C-ABI shared library builds for gfx950, loads, and exports every symbol include/helm.h
+declares.  No compute calls (there is no GPU here); the product path must fail loudly without one."""
+import os
+import re
+import ctypes
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, 'include', 'helm.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(helm_[a-z_0-9]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol(helm_lib):
+    from zephyr_amd import _lib
+    names = header_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(helm_lib, n), 'libhelm.so does not export %s' % n
+    assert sorted(_lib.exported_symbols()) == names           # the ctypes table covers the header exactly
+    assert b'gfx950' in helm_lib.helm_version()
+
+
+def test_struct_layouts_match_header():
+    from zephyr_amd import _lib
+    assert ctypes.sizeof(_lib.SolveOpts) == 32
+    assert ctypes.sizeof(_lib.SolveInfo) == 24
+    assert ctypes.sizeof(_lib.Timing) == 32
+
+
+def test_code_object_is_gfx950():
+    so = os.path.join(ROOT, 'zephyr_amd', 'libhelm.so')
+    import __graft_entry__ as g
+    g.build()
+    blob = open(so, 'rb').read()
+    assert b'gfx950' in blob and b'k_stencil' in blob
+
+
+def gpu_present(lib):
+    return lib.helm_device_count() > 0
+
+
+def test_fails_loudly_without_gpu(helm_lib):
+    import zephyr_amd as za
+    if gpu_present(helm_lib):
+        pytest.skip('a GPU is present')
+    op = za.MiniZephyr(dict(nx=16, nz=16, c=2000., freq=5.))
+    with pytest.raises(Exception) as ei:
+        op * np.ones(256, complex)
+    assert 'no CPU' in str(ei.value) or 'HELM_ERR_DEVICE' in str(ei.value)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'zephyr_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.hpp', '.cpp', '.h')):
+                text = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in text.replace('test oracle', '').replace('as a test oracle', ''), '%s mentions the oracle' % f

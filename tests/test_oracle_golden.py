@@ -1,0 +1,139 @@
+"""CPU: the oracle (oracle/helm_oracle.py) against golden vectors produced by the real reference
+(tests/golden/*.npz, written by oracle/make_golden.py).  Pins the oracle without the reference."""
+import os
+import numpy as np
+import pytest
+
+from oracle import helm_oracle as ho
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / np.abs(b).max()
+
+
+def test_minizephyr_planes_all_free_surface_combos():
+    g = load('g1_minizephyr_planes.npz')
+    nz, nx = int(g['nz']), int(g['nx'])
+    kw = dict(dx=float(g['dx']), dz=float(g['dz']), tau=float(g['tau']), ky=float(g['ky']), nPML=int(g['nPML']))
+    for code in range(16):
+        fs = tuple(bool(code >> b & 1) for b in range(4))
+        C = ho.minizephyr_coefficients(nz, nx, g['c'], g['rho'], float(g['freq']), freeSurf=fs, **kw)
+        cs = np.array([C.sum(), np.abs(C).sum(), (C * np.arange(C.size).reshape(C.shape)).sum()])
+        assert np.allclose(cs, g['checksums'][code], rtol=1e-12, atol=0)
+        if code in (0, 9, 6):
+            assert rel(C, g['planes_fs%d' % code]) <= 1e-13
+    Cd = ho.minizephyr_coefficients(26, 30, 2500., ho.gardner_rho(np.full((26, 30), 2500.)), 40.)
+    assert rel(Cd, g['planes_defaults']) <= 1e-13
+
+
+@pytest.mark.parametrize('name', ['iso', 'tti', 'ell'])
+def test_eurus_planes(name):
+    g = load('g2_eurus_planes.npz')
+    nz, nx = int(g['nz']), int(g['nx'])
+    kw = {}
+    if name == 'tti':
+        kw = dict(theta=g['theta'], eps=g['eps'], delta=g['delta'])
+    elif name == 'ell':
+        kw = dict(eps=g['eps'], delta=g['eps'])
+    C4 = ho.eurus_coefficients(nz, nx, g['c'], g['rho'], float(g['freq']), dx=float(g['dx']), dz=float(g['dz']),
+                               tau=float(g['tau']), nPML=int(g['nPML']), cPML=float(g['cPML']), **kw)
+    ref = g['planes_' + name]
+    for m in range(4):
+        if np.abs(ref[m]).max() == 0:
+            assert np.abs(C4[m]).max() == 0          # M3 vanishes identically when eps == delta
+        else:
+            assert rel(C4[m], ref[m]) <= 1e-13
+    if name in ('iso', 'ell'):
+        assert np.abs(ref[2]).max() == 0
+
+
+def test_eurus_zflip_quirk_is_reproduced():
+    """One-cell velocity perturbation: the coefficient multiplying u(z-1,x) in row (z,x) is built
+    from the properties of cell (z+1,x) (eurus.py:117-127 with :171-179)."""
+    nz = nx = 30
+    c = np.full((nz, nx), 2000.)
+    base = ho.eurus_coefficients(nz, nx, c, 1000., 10., dx=10.)[0]
+    c2 = c.copy(); c2[15, 12] = 2600.
+    pert = ho.eurus_coefficients(nz, nx, c2, 1000., 10., dx=10.)[0]
+    changed = np.argwhere(np.abs(pert - base).max(axis=0) > 0)
+    # row (14, 12): the plane for dz=-1 (slots 0..2) changed, i.e. it couples to u(13, .) using cell (15, .)
+    k_changed_row14 = np.flatnonzero(np.abs(pert[:, 14, 12] - base[:, 14, 12]) > 0)
+    assert set(k_changed_row14) <= {0, 1, 2} and 1 in k_changed_row14
+    k_changed_row16 = np.flatnonzero(np.abs(pert[:, 16, 12] - base[:, 16, 12]) > 0)
+    assert set(k_changed_row16) <= {6, 7, 8} and 7 in k_changed_row16
+    assert len(changed) == 9
+
+
+def test_wavefields_reference_test_configs():
+    g = load('g3_wavefields.npz')
+    nx, nz = 100, 200
+    iz, ix = g['rec_iz'], int(g['rec_ix'])
+    q = np.zeros((nz * nx, 1), complex); q[25 * nx + 25, 0] = 1.
+    C = ho.minizephyr_coefficients(nz, nx, 2500., 1., 2e2)
+    u = (ho.DirectOperator(C) * q)[:, 0].reshape((nz, nx))
+    assert rel(u[iz, ix], g['mz_line']) <= 1e-10
+    uhd = (ho.DirectOperator(C, premul=ho.premul_hd(2e2)) * q)[:, 0].reshape((nz, nx))
+    assert rel(uhd[iz, ix], g['mzhd_line']) <= 1e-10
+    C4 = ho.eurus_coefficients(nz, nx, 2000., 1., 2e2, dx=1, dz=1)
+    ue = (ho.DirectOperator(C4, eurus=True) * q)[:, 0].reshape((nz, nx))
+    assert rel(ue[iz, ix], g['eu_line']) <= 1e-10
+    # accuracy thresholds the reference's own tests assert (test_MiniZephyr.py:114, test_Eurus.py:94,151)
+    assert abs(g['mz_analytic_err']) < 1e-2
+    assert abs(g['eu_analytic_err']) < 3e-2
+    assert abs(g['euell_analytic_err']) < 3e-2
+
+
+def test_wavefields_heterogeneous_and_cfg1():
+    g = load('g3_wavefields.npz')
+    nz = nx = 64
+    C = ho.minizephyr_coefficients(nz, nx, g['het_c'], g['het_rho'], 12., dx=10., dz=10., nPML=8)
+    assert np.linalg.norm(ho.DirectOperator(C) * g['het_q'] - g['het_mz']) / np.linalg.norm(g['het_mz']) <= 1e-10
+    C4 = ho.eurus_coefficients(nz, nx, g['het_c'], g['het_rho'], 12., dx=10., dz=10., nPML=8)
+    op = ho.DirectOperator(C4, eurus=True)
+    assert np.linalg.norm(op * g['het_q'] - g['het_eu']) / np.linalg.norm(g['het_eu']) <= 1e-10
+    q2 = np.vstack([g['het_q'], np.zeros_like(g['het_q'])])
+    assert np.linalg.norm(op * q2 - g['het_eu_stacked']) / np.linalg.norm(g['het_eu_stacked']) <= 1e-10
+    # the isotropic N x N M1 solve equals the 2N solve
+    m1 = ho.DirectOperator(C4[0]) * g['het_q']
+    assert np.linalg.norm(m1 - g['het_eu']) / np.linalg.norm(g['het_eu']) <= 1e-10
+    # BASELINE config 1 (plumbing): rtol 1e-12
+    C1 = ho.minizephyr_coefficients(128, 128, 2000., 1., 5., dx=10., dz=10.)
+    q1 = np.zeros((128 * 128, 1), complex); q1[64 * 128 + 64, 0] = 1.
+    u1 = (ho.DirectOperator(C1) * q1)[:, 0]
+    assert np.linalg.norm(u1 - g['cfg1_u']) / np.linalg.norm(g['cfg1_u']) <= 1e-12
+
+
+def test_result_is_conjugate_of_solve():
+    """||A conj(u) - q|| ~ 0: the reference returns the complex conjugate (discretization.py:101-103)."""
+    g = load('g3_wavefields.npz')
+    C = ho.minizephyr_coefficients(64, 64, g['het_c'], g['het_rho'], 12., dx=10., dz=10., nPML=8)
+    A = ho.coefficients_to_csr(C)
+    r = A @ g['het_mz'].conj() - g['het_q']
+    assert np.abs(r).max() < 1e-10
+
+
+def test_stencil_apply_equals_sparse_matvec():
+    rng = np.random.default_rng(0)
+    nz, nx = 33, 47
+    c = 2000 + 1000 * rng.random((nz, nx)); rho = 1000 + 100 * rng.random((nz, nx))
+    C = ho.minizephyr_coefficients(nz, nx, c, rho, 15., dx=8., dz=8., nPML=5)
+    X = rng.standard_normal((nz * nx, 3)) + 1j * rng.standard_normal((nz * nx, 3))
+    assert rel(ho.stencil_apply(C, X), ho.coefficients_to_csr(C) @ X) <= 1e-14
+
+
+def test_oracle_bicgstab_converges_to_lu():
+    nz = nx = 48
+    rng = np.random.default_rng(2)
+    c = 2000 + 1000 * rng.random((nz, nx))
+    C = ho.minizephyr_coefficients(nz, nx, c, 1000., 12., dx=10., dz=10., nPML=6)
+    q = np.zeros(nz * nx, complex); q[20 * nx + 22] = 1.
+    x, its = ho.jacobi_bicgstab(C, q, rtol=1e-10, maxit=20000)
+    ref = (ho.DirectOperator(C) * q).conj()
+    assert its < 20000
+    assert np.linalg.norm(x - ref) / np.linalg.norm(ref) < 1e-7

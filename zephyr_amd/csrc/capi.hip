@@ -268,12 +268,13 @@ int run_bicgstab(helm_op *op, int block, Batch &B, int maxit, int check_every, i
         if (rc) return rc;
         bool any_active = false, any_break = false;
         int min_iters = std::numeric_limits<int>::max();
+        int nactive = 0;
         for (int b = 0; b < n; ++b) {
             B.h_mask[b] = 0;
             RhsScal &S = op->h_scal[b];
             if (S.status == ST_ACTIVE) {
                 if (S.iters >= maxit) S.status = ST_FROZEN;   // iteration cap: stop working on it
-                else { any_active = true; min_iters = std::min(min_iters, S.iters); }
+                else { any_active = true; nactive += 1; min_iters = std::min(min_iters, S.iters); }
             } else if (S.status == ST_BREAKDOWN && restarts[b] < max_restarts && S.iters < maxit) {
                 B.h_mask[b] = 1; any_break = true; restarts[b] += 1;
             }
@@ -289,6 +290,7 @@ int run_bicgstab(helm_op *op, int block, Batch &B, int maxit, int check_every, i
             break;
         }
         upload_scal(op, n);
+        op->active_hint = nactive;
         const int chunk = std::max(1, std::min(check_every, maxit - min_iters));
         for (int k = 0; k < chunk; ++k) {
             helm_launch_bicg_p(op, B.w, n);
@@ -305,6 +307,7 @@ int run_bicgstab(helm_op *op, int block, Batch &B, int maxit, int check_every, i
         HIP_TRY(op, hipGetLastError());
         it_done += chunk;
     }
+    op->active_hint = -1;
     return HELM_OK;
 }
 

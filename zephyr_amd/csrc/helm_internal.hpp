@@ -94,6 +94,7 @@ struct helm_op {
     std::vector<hipEvent_t> ev_pool;
     std::vector<std::pair<int, double>> ev_pending;   // (event-pair index, bytes)
     size_t ev_used = 0;
+    int active_hint = -1;        // right-hand sides currently iterating (for the byte count of profiled launches)
 
     std::string err;
 };

@@ -594,7 +594,7 @@ int helm_launch_apply(helm_op *op, const ApplyArgs &a) {
     }
     if (op->profiling && e0) {
         hipEventRecord(e1, op->stream);
-        int nact = a.nrhs;   // upper bound: inactive RHS are skipped on the device
+        int nact = (a.scal && op->active_hint >= 0 && op->active_hint < a.nrhs) ? op->active_hint : a.nrhs;   // inactive RHS are skipped on the device
         op->ev_pending.push_back(std::make_pair((int)op->ev_used, (double)op->N * (32.0 * nact + 144.0)));
         op->ev_used += 2;
     }

@@ -215,6 +215,35 @@ class BaseDiscretization(BaseModelDependent):
                                   % (rc, nrhs, self.rtol, worst, self.maxit))
         return U.T
 
+    def solveDevice(self, d_rhs, d_u, nrhs, rows=None):
+        '''Solve with right-hand sides and wavefields already resident in HBM.
+
+        d_rhs / d_u: device pointers (ints) to [nrhs][rows] complex128, each RHS contiguous.
+        Returns the per-RHS info list; raises if a right-hand side misses the tolerance.'''
+        lib = _lib.load()
+        h = self.handle
+        rows = int(self.nrow if rows is None else rows)
+        info = (_lib.SolveInfo * nrhs)()
+        opts = self._solve_opts()
+        pm = complex(self.premul)
+        rc = lib.helm_solve_device(h, ctypes.c_void_p(d_rhs), ctypes.c_void_p(d_u), int(nrhs), rows, pm.real, pm.imag,
+                                   ctypes.byref(opts), info)
+        _lib.check(rc, h)
+        self.lastInfo = [dict(iterations=i.iterations, status=i.status, restarts=i.restarts, method=i.method,
+                              relres=i.relres) for i in info]
+        if rc > 0:
+            raise ArithmeticError('%d of %d right-hand sides did not reach rtol=%g' % (rc, nrhs, self.rtol))
+        return self.lastInfo
+
+    def setProfiling(self, on=True):
+        'time every stencil-apply launch of subsequent solves with HIP events on the solver stream'
+        _lib.check(_lib.load().helm_set_profiling(self.handle, 1 if on else 0), self.handle)
+
+    def lastTiming(self):
+        t = _lib.Timing()
+        _lib.check(_lib.load().helm_last_timing(self.handle, ctypes.byref(t)), self.handle)
+        return dict(solve_ms=t.solve_ms, apply_ms=t.apply_ms, apply_launches=t.apply_launches, apply_bytes=t.apply_bytes)
+
     @staticmethod
     def _dense_rhs(rhs):
         if sp.issparse(rhs):
