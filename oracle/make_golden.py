@@ -217,6 +217,35 @@ def g5_sources():
     np.savez_compressed(os.path.join(OUT, 'g5_sources.npz'), **out)
 
 
+def g6_survey():
+    from zephyr.middleware import Helm2DProblem, Helm2DSurvey
+    nz, nx = 60, 80
+    rng = np.random.default_rng(41)
+    c = 2000. + 1500. * rng.random((nz, nx))
+    rho = 1000. + 200. * rng.random((nz, nx))
+    src = np.stack([np.linspace(100, 700, 13), np.full(13, 80.)], 1)
+    rec = np.stack([np.linspace(60, 740, 11), np.full(11, 520.)], 1)
+    sterms = np.array([1.0 + 0.5j, 0.7 - 0.2j, 1.3 + 0.1j])
+    sc = dict(nx=nx, nz=nz, dx=10., dz=10., c=c, rho=rho, nPML=6, freqs=[6., 9., 14.], Disc=zb.MiniZephyrHD, parallel=False,
+              sterms=sterms, geom=dict(src=src, rec=rec, mode='fixed'))
+    prob, surv = Helm2DProblem(sc), Helm2DSurvey(sc)
+    prob.pair(surv)
+    d = surv.dpred()
+    resid = (rng.standard_normal(d.shape) + 1j * rng.standard_normal(d.shape)) * np.abs(d).mean()
+    g_mux = prob.Jtvec(None, resid)
+    uF = [np.asarray(x) for x in prob.lazyFields()]
+    g_u = prob.Jtvec(None, resid, u=uF)
+    out = dict(c=c, rho=rho, src=src, rec=rec, sterms=sterms, freqs=np.array([6., 9., 14.]), dpred=d, resid=resid, g_mux=g_mux, g_u=g_u,
+               uF_f1_src3=uF[1][:, 3])
+    # relative-geometry survey (receivers move with the source)
+    sc2 = dict(sc, geom=dict(src=src, rec=np.stack([np.linspace(-40, 40, 5), np.full(5, 300.)], 1), mode='relative'))
+    prob2, surv2 = Helm2DProblem(sc2), Helm2DSurvey(sc2)
+    prob2.pair(surv2)
+    out['dpred_relative'] = surv2.dpred()
+    out['rec_relative'] = sc2['geom']['rec']
+    np.savez_compressed(os.path.join(OUT, 'g6_survey.npz'), **out)
+
+
 def g7_analytic():
     sc = dict(c=2500., rho=1., nx=100, nz=200, freq=2e2)
     out = {}
@@ -226,8 +255,8 @@ def g7_analytic():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g7']
-    table = dict(g1=g1_minizephyr_planes, g2=g2_eurus_planes, g3=g3_wavefields, g4=g4_multifreq, g5=g5_sources, g7=g7_analytic)
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7']
+    table = dict(g1=g1_minizephyr_planes, g2=g2_eurus_planes, g3=g3_wavefields, g4=g4_multifreq, g5=g5_sources, g6=g6_survey, g7=g7_analytic)
     for name in which:
         table[name]()
         print('wrote', name, flush=True)

@@ -1,0 +1,179 @@
+"""Forward problem and FWI gradient on top of the frequency dispatcher.
+
+Interface of zephyr/middleware/problem.py:17-212 (HelmBaseProblem / Helm2DProblem) without SimPEG:
+`lazyFields` (forward wavefields per frequency), `Jtvec` (gradient by the zero-lag imaging
+condition; both the "mux" branch that solves forward and back-propagated sources together and the
+branch that re-uses given forward fields) and `updateModel`.
+
+Multi-GPU: frequencies are sharded over ranks (`shardFreqs`, default on when torch.distributed is
+initialised); the only collective is one all-reduce of the gradient (problem.py:152,162 sum over
+frequencies) or of the receiver data.
+"""
+import numpy as np
+import scipy.sparse as sp
+
+from .base import BaseModelDependent
+from .config import BaseSCCache
+from .distributors import MultiFreq, ViscoMultiFreq
+from .survey import HelmBaseSurvey, Helm2DSurvey
+from . import parallel
+
+EPS = 1e-15
+
+
+class HelmBaseProblem(BaseModelDependent, BaseSCCache):
+
+    initMap = {
+        #   key              required  rename       cast
+        'SystemWrapper':    (True,     None,        None),
+        'shardFreqs':       (False,    '_shard',    bool),
+    }
+
+    surveyPair = HelmBaseSurvey
+    cacheItems = ['_system']
+
+    def __init__(self, systemConfig, *args, **kwargs):
+        BaseSCCache.__init__(self, systemConfig, *args, **kwargs)
+        self.survey = None
+
+    # ---- pairing (SimPEG's BaseProblem.pair) -----------------------------------------------------------
+    def pair(self, survey):
+        if not isinstance(survey, self.surveyPair):
+            raise TypeError('%s must be paired with a %s' % (self.__class__.__name__, self.surveyPair.__name__))
+        self.survey = survey
+        survey.prob = self
+
+    @property
+    def ispaired(self):
+        return self.survey is not None
+
+    # ---- model -----------------------------------------------------------------------------------------
+    def updateModel(self, m, loneKey='c'):
+        'problem.py:51-66'
+        if m is None:
+            return
+        if isinstance(m, dict):
+            self.systemConfig.update(m)
+            self.clearCache()
+        elif isinstance(m, (np.ndarray, np.inexact, complex, float)):
+            m = np.asarray(m)
+            old = np.asarray(self.systemConfig.get(loneKey, 0.))
+            if old.size != m.size or not np.linalg.norm(m.ravel() - old.ravel()) < EPS:
+                self.systemConfig[loneKey] = m
+                self.clearCache()
+        else:
+            raise Exception('Class %s doesn\'t know how to update with model of type %s' % (self.__class__.__name__, type(m)))
+
+    def clearCache(self):
+        sysw = self.__dict__.get('_system', None)
+        if sysw is not None:
+            del sysw.factors
+        BaseSCCache.clearCache(self)
+
+    @property
+    def system(self):
+        if getattr(self, '_system', None) is None:
+            self._system = self.SystemWrapper(self.systemConfig)
+        return self._system
+
+    # ---- sharding --------------------------------------------------------------------------------------
+    @property
+    def ownedFreqs(self):
+        'frequency indices this rank solves'
+        nf = self.survey.nfreq
+        if getattr(self, '_shard', True):
+            return parallel.owned_indices(nf)
+        return list(range(nf))
+
+    def _solveOwned(self, rhs_list):
+        'generator of (ifreq, scaleTerm * sub * rhs) over the owned frequencies'
+        subs = self.system.subProblems
+        scale = self.system.scaleTerm
+        for ifreq in self.ownedFreqs:
+            r = rhs_list[ifreq] if isinstance(rhs_list, (list, tuple)) else rhs_list
+            yield ifreq, scale * (subs[ifreq] * r)
+
+    # ---- gradient scalers (problem.py:74-85) --------------------------------------------------------------
+    def scaledTerms(self, ifreq):
+        omega = 2 * np.pi * self.survey.freqs[ifreq]
+        c = self.system.subProblems[ifreq].c
+        return omega, c
+
+    def gradientScaler(self, ifreq):
+        omega, c = self.scaledTerms(ifreq)
+        return self.survey.postProcessors[ifreq](-(omega ** 2 / c ** 3).ravel())
+
+    # ---- forward -----------------------------------------------------------------------------------------
+    def lazyFields(self, m=None):
+        'generator of forward wavefields (N, nsrc) for the owned frequencies, in frequency order (problem.py:166-179)'
+        if not self.ispaired:
+            raise Exception('%s instance is not paired to a survey' % (self.__class__.__name__,))
+        self.updateModel(m)
+        qf = self.survey.getSources()
+        return (u for _, u in self._solveOwned(qf))
+
+    def fields(self, m=None):
+        'list of forward wavefields for ALL frequencies on this rank (no sharding)'
+        if not self.ispaired:
+            raise Exception('%s instance is not paired to a survey' % (self.__class__.__name__,))
+        self.updateModel(m)
+        qf = self.survey.getSources()
+        return list(self.system * qf)
+
+    # ---- gradient ----------------------------------------------------------------------------------------
+    def Jtvec(self, m=None, v=None, u=None):
+        """FWI gradient g = sum_f scaler_f sum_s uF (.) uB  (problem.py:124-164).
+
+        u is None: "mux" branch -- forward and back-propagated sources are stacked column-wise and
+        solved together per frequency; the result is complex (no .real), as in the reference.
+        u given (list of forward fields per frequency): only the back-propagation is solved and
+        the real part is returned.
+        """
+        if not self.ispaired:
+            raise Exception('%s instance is not paired to a survey' % (self.__class__.__name__,))
+        if v is None:
+            raise Exception('Actually, Jtvec requires a residual vector')
+        self.updateModel(m)
+        sv = self.survey
+        nsrc = sv.nsrc
+        resid = np.asarray(v).reshape((sv.nrec, sv.nsrc, sv.nfreq))
+        qb = sv.getResidualSources(resid)
+        owned = self.ownedFreqs
+        g = np.zeros(self.nrow, dtype=np.complex128)
+        if u is None:
+            qf = sv.getSources()
+            qm = [sp.hstack((qf[i], qb[i])) if i in owned else None for i in range(sv.nfreq)]
+            for ifreq, uMux in self._solveOwned(qm):
+                pp = sv.postProcessors[ifreq]
+                g += self.gradientScaler(ifreq) * pp((uMux[:, :nsrc] * uMux[:, nsrc:]).sum(axis=1))
+        else:
+            uF = list(u)
+            for ifreq, uB in self._solveOwned(qb):
+                pp = sv.postProcessors[ifreq]
+                g += self.gradientScaler(ifreq) * (np.asarray(uF[ifreq]) * pp(uB)).sum(axis=1)
+        if len(owned) != sv.nfreq:
+            g = parallel.allreduce_sum(g)
+        return g if u is None else g.real
+
+    @property
+    def factors(self):
+        return self.system.factors
+
+    @factors.deleter
+    def factors(self):
+        del self.system.factors
+
+
+class Helm2DProblem(HelmBaseProblem):
+
+    initMap = {
+        'SystemWrapper':    (False,    None,        None),
+    }
+
+    surveyPair = Helm2DSurvey
+    SystemWrapper = MultiFreq
+
+
+class Helm2DViscoProblem(Helm2DProblem):
+
+    SystemWrapper = ViscoMultiFreq
