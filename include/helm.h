@@ -47,7 +47,13 @@ typedef struct helm_op helm_op;
 enum { HELM_MINIZEPHYR = 0, HELM_EURUS = 1 };
 
 /* Krylov methods */
-enum { HELM_BICGSTAB = 0, HELM_CGNR = 1, HELM_AUTO = 2 /* BiCGSTAB, CGNR for RHS that break down */ };
+enum {
+    HELM_BICGSTAB = 0,   /* Jacobi-preconditioned BiCGSTAB */
+    HELM_CGNR = 1,       /* Jacobi-scaled CGNR */
+    HELM_AUTO = 2,       /* HELM_MG where available, else BiCGSTAB; CGNR for right-hand sides that break down */
+    HELM_MG = 3          /* BiCGSTAB right-preconditioned by shifted-Laplacian multigrid (damped-Jacobi smoothing)
+                            + PML strip line relaxation */
+};
 
 /* hard errors */
 enum {

@@ -12,8 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libhelm.so')
 
 HELM_MINIZEPHYR, HELM_EURUS = 0, 1
-HELM_BICGSTAB, HELM_CGNR, HELM_AUTO = 0, 1, 2
-METHODS = {'bicgstab': HELM_BICGSTAB, 'cgnr': HELM_CGNR, 'auto': HELM_AUTO}
+HELM_BICGSTAB, HELM_CGNR, HELM_AUTO, HELM_MG = 0, 1, 2, 3
+METHODS = {'bicgstab': HELM_BICGSTAB, 'cgnr': HELM_CGNR, 'auto': HELM_AUTO, 'mg': HELM_MG}
 
 ERRORS = {-1: 'HELM_ERR_ARG', -2: 'HELM_ERR_DEVICE', -3: 'HELM_ERR_STATE', -4: 'HELM_ERR_UNSUPPORTED', -5: 'HELM_ERR_PML'}
 

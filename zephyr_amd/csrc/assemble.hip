@@ -133,6 +133,7 @@ struct EuParams {
     double dx, dz;
     cplx om;
     int aniso;
+    int nblk_out;     // 4, or 1 to build only M1
 };
 
 // Eurus: eurus.py:140-168 (PML averages), :170-226 (buoyancy squares/lines), :229-269 (mass),
@@ -206,6 +207,7 @@ __global__ __launch_bounds__(256) void k_assemble_eurus(EuParams P, const cplx *
 
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
+        if (m >= P.nblk_out) break;
         const double mass = massv[m], c1x = c1xv[m], c1z = c1zv[m], c2x = c2xv[m], c2z = c2zv[m];
         const cplx ax = cscale(Lx4, c1x), bx = cscale(Lx4, c2x), az = cscale(Lz4, c1z), bz = cscale(Lz4, c2z);
         const cplx axf = cscale(Lx, c1x), bzf = cscale(Lz, c2z);
@@ -313,8 +315,8 @@ int helm_launch_assemble(helm_op *op, double freq_re, double freq_im, double tau
         MzParams P;
         P.nz = nz; P.nx = nx; P.dx = op->dx; P.dz = op->dz; P.aky = twopi * ky; P.om = om;
         const double lx = op->dx * (op->nPML - 1), lz = op->dz * (op->nPML - 1);
-        P.fx = 3.0 * log(1.0 / 1e-3) / (2.0 * lx * lx * lx);
-        P.fz = 3.0 * log(1.0 / 1e-3) / (2.0 * lz * lz * lz);
+        P.fx = op->pml_scale * 3.0 * log(1.0 / 1e-3) / (2.0 * lx * lx * lx);
+        P.fz = op->pml_scale * 3.0 * log(1.0 / 1e-3) / (2.0 * lz * lz * lz);
         P.fs0 = op->fs[0]; P.fs1 = op->fs[1]; P.fs2 = op->fs[2]; P.fs3 = op->fs[3];
         hipLaunchKernelGGL(k_assemble_mz, dim3(blocks), dim3(threads), 0, op->stream, P, op->d_c, op->d_rho,
                            d_prof, d_prof + nx, d_prof + 2 * nx, d_prof + 2 * nx + nz, op->d_C);
@@ -330,7 +332,7 @@ int helm_launch_assemble(helm_op *op, double freq_re, double freq_im, double tau
         auto build = [&](int n, double h, std::vector<cplx> &xi) -> int {
             const double L = h * (op->nPML - 1);
             const int len = (int)ceil((L + h) / h);
-            if (len != op->nPML) return HELM_ERR_PML;
+            if (len != op->nPML && !op->block0_only) return HELM_ERR_PML;   // preconditioner levels are free of the hazard
             std::vector<double> g(n, 0.0);
             for (int k = 0; k < op->nPML; ++k) g[k] = cPML * cos((M_PI / 2) * ((0.0 + k * h) / L));
             for (int k = 0; k < op->nPML; ++k) g[n - op->nPML + k] = cPML * cos((M_PI / 2) * ((0.0 + (op->nPML - 1 - k) * h) / L));
@@ -354,6 +356,7 @@ int helm_launch_assemble(helm_op *op, double freq_re, double freq_im, double tau
         HIP_TRY(op, hipMemcpyAsync(d_xi, h.data(), bytes, hipMemcpyHostToDevice, op->stream));
         EuParams P;
         P.nz = nz; P.nx = nx; P.dx = op->dx; P.dz = op->dz; P.om = om; P.aniso = op->aniso ? 1 : 0;
+        P.nblk_out = op->block0_only ? 1 : 4;
         hipLaunchKernelGGL(k_assemble_eurus, dim3(blocks), dim3(threads), 0, op->stream, P, op->d_c, op->d_rho,
                            op->d_theta, op->d_eps, op->d_delta, d_xi, d_xi + nx + 2, op->d_C);
         HIP_TRY(op, hipGetLastError());

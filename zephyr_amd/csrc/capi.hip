@@ -11,6 +11,7 @@
 int helm_launch_fin_ex(helm_op *op, int which, int nrhs, int nblk_part, const int *mask, double *aux);
 int helm_launch_restart_copy_mask(helm_op *op, VecPtrs w, int nrhs, const int *mask);
 int helm_launch_norm2(helm_op *op, const cplx *a, int nrhs);
+int helm_launch_krylov_init(helm_op *op, const cplx *bvec, VecPtrs w, int nrhs, double rtol);
 
 static std::string g_last_error;
 
@@ -41,6 +42,7 @@ extern "C" helm_op *helm_create(int device, int variant, int nz, int nx, double 
     op->dx = dx; op->dz = dz; op->nPML = nPML;
     if (freeSurf) for (int i = 0; i < 4; ++i) op->fs[i] = freeSurf[i] ? 1 : 0;
     op->nblocks = variant == HELM_EURUS ? 4 : 1;
+    if (nPML < 0) { op->block0_only = true; op->nPML = -nPML; op->nblocks = 1; }   // internal: preconditioner level
     HIP_TRY_NULL(hipSetDevice(device));
     HIP_TRY_NULL(hipStreamCreateWithFlags(&op->stream, hipStreamNonBlocking));
     op->own_stream = true;
@@ -59,6 +61,7 @@ extern "C" void helm_destroy(helm_op *op) {
     if (op->stream) hipStreamSynchronize(op->stream);
     hipFree(op->d_c); hipFree(op->d_rho); hipFree(op->d_theta); hipFree(op->d_eps); hipFree(op->d_delta);
     hipFree(op->d_C); hipFree(op->d_Cs); hipFree(op->d_dinv);
+    if (op->mg) mg_destroy(op);
     hipFree(op->d_ws); hipFree(op->d_part); hipFree(op->d_scal);
     if (op->h_scal) hipHostFree(op->h_scal);
     for (hipEvent_t e : op->ev_pool) hipEventDestroy(e);
@@ -110,6 +113,14 @@ extern "C" int helm_set_model(helm_op *op, const double *c, const double *rho, c
         }
     }
     HIP_TRY(op, hipStreamSynchronize(op->stream));
+    op->h_c.assign((const cplx *)c, (const cplx *)c + N);
+    op->h_rho.assign(rho, rho + N);
+    op->h_theta.clear(); op->h_eps.clear(); op->h_delta.clear();
+    if (op->variant == HELM_EURUS) {
+        if (theta) op->h_theta.assign(theta, theta + N);
+        if (eps) op->h_eps.assign(eps, eps + N);
+        if (delta) op->h_delta.assign(delta, delta + N);
+    }
     op->block_zero[0] = op->block_zero[1] = op->block_zero[3] = false;
     op->block_zero[2] = m3zero;
     op->has_model = true;
@@ -127,6 +138,8 @@ extern "C" int helm_assemble(helm_op *op, double freq_re, double freq_im, double
     if (rc) return rc;
     HIP_TRY(op, hipStreamSynchronize(op->stream));
     op->assembled = true;
+    op->a_freq_re = freq_re; op->a_freq_im = freq_im; op->a_tau = tau; op->a_ky = ky; op->a_cpml = cPML;
+    if (op->mg) mg_destroy(op);      // preconditioner belongs to the previous frequency
     return HELM_OK;
 }
 
@@ -187,7 +200,7 @@ extern "C" int helm_apply_device(helm_op *op, int block, int adjoint, const void
     if (!op->assembled) HELM_FAIL(op, HELM_ERR_STATE, "operator not assembled");
     HIP_TRY(op, hipSetDevice(op->device));
     timing_begin(op);
-    ApplyArgs a;
+    ApplyArgs a = ApplyArgs();
     a.planes = op->d_C + (long long)block * 9 * op->N; a.X = (const cplx *)dX; a.Y = (cplx *)dY; a.W = nullptr;
     a.ld = op->N; a.nrhs = nrhs; a.scaled = 0; a.adjoint = adjoint ? 1 : 0; a.epi = EPI_NONE; a.scal = nullptr; a.part = nullptr;
     int rc = helm_launch_apply(op, a);
@@ -218,7 +231,11 @@ namespace {
 struct Batch {
     int nrhs;
     VecPtrs w;
-    cplx *bbar;
+    cplx *bbar;          // right-hand side of the system being iterated (scaled q' or, with the MG preconditioner, q')
+    cplx *bscaled = nullptr;                 // D^-1 q' (right-hand side of the Jacobi-scaled system; CGNR fallback)
+    cplx *phat = nullptr, *shat = nullptr;   // preconditioned directions (MG mode)
+    bool pre = false;    // true: BiCGSTAB on A right-preconditioned by multigrid; false: Jacobi-scaled system
+    const cplx *planes = nullptr;            // planes of the iterated operator (raw for pre, scaled otherwise)
     int *d_mask; double *d_aux;      // device, nrhs ints / 2*nrhs doubles (inside d_part tail)
     int *h_mask; double *h_aux;      // pinned (inside h_scal tail)
 };
@@ -234,9 +251,17 @@ int upload_scal(helm_op *op, int nrhs) {
 }
 
 ApplyArgs scaled_apply(helm_op *op, int block, const cplx *X, cplx *Y, const cplx *W, int nrhs, int adjoint, int epi, bool masked) {
-    ApplyArgs a;
+    ApplyArgs a = ApplyArgs();
     a.planes = op->d_Cs + (long long)block * 9 * op->N; a.X = X; a.Y = Y; a.W = W; a.ld = op->N; a.nrhs = nrhs;
     a.scaled = 1; a.adjoint = adjoint; a.epi = epi; a.scal = masked ? op->d_scal : nullptr; a.part = (double *)op->d_part;
+    return a;
+}
+
+// apply of the operator the BiCGSTAB batch iterates on (Jacobi-scaled planes, or raw planes in MG mode)
+ApplyArgs batch_apply(helm_op *op, const Batch &B, const cplx *X, cplx *Y, const cplx *W, int epi) {
+    ApplyArgs a = ApplyArgs();
+    a.planes = B.planes; a.X = X; a.Y = Y; a.W = W; a.ld = op->N; a.nrhs = B.nrhs;
+    a.scaled = B.pre ? 0 : 1; a.adjoint = 0; a.epi = epi; a.scal = op->d_scal; a.part = (double *)op->d_part;
     return a;
 }
 
@@ -251,7 +276,7 @@ int restart_masked(helm_op *op, int block, Batch &B) {
     int rc = upload_scal(op, n);
     if (rc) return rc;
     HIP_TRY(op, hipMemcpyAsync(B.d_mask, B.h_mask, n * sizeof(int), hipMemcpyHostToDevice, op->stream));
-    rc = helm_launch_apply(op, scaled_apply(op, block, B.w.x, B.w.r, B.bbar, n, 0, EPI_RESID, true));
+    rc = helm_launch_apply(op, batch_apply(op, B, B.w.x, B.w.r, B.bbar, EPI_RESID));
     if (rc) return rc;
     helm_launch_restart_copy_mask(op, B.w, n, B.d_mask);
     helm_launch_fin_ex(op, FIN_RESTART, n, helm_apply_num_blocks(op), B.d_mask, nullptr);
@@ -294,14 +319,21 @@ int run_bicgstab(helm_op *op, int block, Batch &B, int maxit, int check_every, i
         const int chunk = std::max(1, std::min(check_every, maxit - min_iters));
         for (int k = 0; k < chunk; ++k) {
             helm_launch_bicg_p(op, B.w, n);
-            rc = helm_launch_apply(op, scaled_apply(op, block, B.w.p, B.w.v, B.w.r0, n, 0, EPI_DOT_W, true));
+            const cplx *pin = B.w.p, *sin = B.w.s;
+            if (B.pre) { rc = mg_apply(op, B.w.p, B.phat, n, op->d_scal); if (rc) return rc; pin = B.phat; }
+            rc = helm_launch_apply(op, batch_apply(op, B, pin, B.w.v, B.w.r0, EPI_DOT_W));
             if (rc) return rc;
             helm_launch_fin(op, FIN_ALPHA, n, nba);
             helm_launch_bicg_s(op, B.w, n);
-            rc = helm_launch_apply(op, scaled_apply(op, block, B.w.s, B.w.t, nullptr, n, 0, EPI_DOT_XY, true));
+            if (B.pre) {
+                rc = mg_apply(op, B.w.s, B.shat, n, op->d_scal); if (rc) return rc; sin = B.shat;
+                rc = helm_launch_apply(op, batch_apply(op, B, sin, B.w.t, B.w.s, EPI_DOT_WY));
+            } else {
+                rc = helm_launch_apply(op, batch_apply(op, B, sin, B.w.t, nullptr, EPI_DOT_XY));
+            }
             if (rc) return rc;
             helm_launch_fin(op, FIN_OMEGA, n, nba);
-            helm_launch_bicg_xr(op, B.w, n, nbv);
+            helm_launch_bicg_xr(op, B.w, pin, sin, n);
             helm_launch_fin(op, FIN_RHO, n, nbv);
         }
         HIP_TRY(op, hipGetLastError());
@@ -323,7 +355,7 @@ int run_cgnr(helm_op *op, int block, Batch &B, int maxit, int check_every) {
     }
     int rc = upload_scal(op, n);
     if (rc) return rc;
-    rc = helm_launch_apply(op, scaled_apply(op, block, B.w.x, B.w.r, B.bbar, n, 0, EPI_RESID, true));
+    rc = helm_launch_apply(op, scaled_apply(op, block, B.w.x, B.w.r, B.bscaled, n, 0, EPI_RESID, true));
     if (rc) return rc;
     helm_launch_fin(op, FIN_CG_RR, n, nba);            // rr (and convergence check); iters becomes 1
     rc = helm_launch_apply(op, scaled_apply(op, block, B.w.r, B.w.s, nullptr, n, 1, EPI_DOT_YY, true));   // z = A^H r
@@ -368,11 +400,18 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
     const long long N = op->N;
     int Bmax = o.batch > 0 ? o.batch : 16;
     if (Bmax > nrhs) Bmax = nrhs;
-    const int check_every = o.check_every > 0 ? o.check_every : 50;
-    int rc = ensure_ws(op, (size_t)9 * Bmax * N * sizeof(cplx));
+    int rc = ensure_ws(op, (size_t)11 * Bmax * N * sizeof(cplx));
     if (rc) return rc;
     rc = ensure_part(op, Bmax);
     if (rc) return rc;
+    // preconditioner choice: multigrid for the main block when asked for (or AUTO on Eurus, where it is validated)
+    bool use_mg = false;
+    if (block == 0 && (o.method == HELM_MG || (o.method == HELM_AUTO && op->variant == HELM_EURUS && std::min(op->nz, op->nx) >= 32))) {
+        rc = mg_setup(op, Bmax);
+        if (rc == HELM_OK) use_mg = true;
+        else if (o.method == HELM_MG) return rc;
+    }
+    const int check_every = o.check_every > 0 ? o.check_every : (use_mg ? 10 : 50);
     int unconverged = 0;
     for (int first = 0; first < nrhs; first += Bmax) {
         const int n = std::min(Bmax, nrhs - first);
@@ -381,8 +420,12 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
         cplx *base = (cplx *)op->d_ws;
         const long long vs = (long long)Bmax * N;
         B.w.x = base; B.w.r = base + vs; B.w.r0 = base + 2 * vs; B.w.p = base + 3 * vs; B.w.v = base + 4 * vs;
-        B.w.s = base + 5 * vs; B.w.t = base + 6 * vs; B.bbar = base + 7 * vs;
+        B.w.s = base + 5 * vs; B.w.t = base + 6 * vs; B.bscaled = base + 7 * vs;
         cplx *qprime = base + 8 * vs;
+        B.phat = base + 9 * vs; B.shat = base + 10 * vs;
+        B.pre = use_mg;
+        B.bbar = use_mg ? qprime : B.bscaled;
+        B.planes = use_mg ? op->d_C + (long long)block * 9 * N : op->d_Cs + (long long)block * 9 * N;
         const int nblk = std::max(helm_apply_num_blocks(op), helm_vec_num_blocks(op));
         char *ptail = (char *)op->d_part + (size_t)Bmax * 4 * nblk * sizeof(double);
         B.d_aux = (double *)ptail; B.d_mask = (int *)(ptail + (size_t)Bmax * 2 * sizeof(double));
@@ -399,13 +442,17 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
         // scaled system start
         {
             VecPtrs w = B.w;
-            w.t = B.bbar;   // init writes bbar through w.t
+            w.t = B.bscaled;   // init writes the scaled right-hand side through w.t
             // NB: row offset is applied by giving prep a shifted base pointer
             rc = helm_launch_bicg_init(op, block, rhs_b + row_off, rhs_ld, premul, sub_b, w, n, o.rtol * 0.5);
             if (rc) return rc;
+            if (use_mg) {      // iterate on the unscaled system A (M^-1 y) = q'
+                rc = helm_launch_krylov_init(op, qprime, B.w, n, o.rtol * 0.9);
+                if (rc) return rc;
+            }
         }
         std::vector<int> restarts(n, 0);
-        std::vector<int> method_used(n, o.method == HELM_CGNR ? HELM_CGNR : HELM_BICGSTAB);
+        std::vector<int> method_used(n, o.method == HELM_CGNR ? HELM_CGNR : (use_mg ? HELM_MG : HELM_BICGSTAB));
         std::vector<int> total_iters(n, 0);
         std::vector<double> relres(n, 0.0);
         const int max_refine = 3;
@@ -419,7 +466,7 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
             } else {
                 rc = run_bicgstab(op, block, B, o.maxit, check_every, 25, restarts);
                 if (rc) return rc;
-                if (o.method == HELM_AUTO) {
+                if (o.method == HELM_AUTO && !use_mg) {
                     rc = download_scal(op, n);
                     if (rc) return rc;
                     bool any = false;
@@ -431,7 +478,7 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
                 }
             }
             // true residual of the UNSCALED system: s = q' - A x
-            ApplyArgs a;
+            ApplyArgs a = ApplyArgs();
             a.planes = op->d_C + (long long)block * 9 * N; a.X = B.w.x; a.Y = B.w.s; a.W = qprime; a.ld = N; a.nrhs = n;
             a.scaled = 0; a.adjoint = 0; a.epi = EPI_RESID; a.scal = nullptr; a.part = (double *)op->d_part;
             rc = helm_launch_apply(op, a);
@@ -532,7 +579,7 @@ extern "C" int helm_solve_device(helm_op *op, const void *dRHS, void *dU, int nr
         int rc = solve_block(op, 3, (const cplx *)dRHS, rows, N, premul, nullptr, dV, nrhs, o, info);
         if (rc >= 0) {
             result = rc;
-            ApplyArgs a;
+            ApplyArgs a = ApplyArgs();
             a.planes = op->d_C + 1LL * 9 * N; a.X = dV; a.Y = dT; a.W = nullptr; a.ld = N; a.nrhs = nrhs; a.scaled = 0; a.adjoint = 0;
             a.epi = EPI_NONE; a.scal = nullptr; a.part = nullptr;
             rc = helm_launch_apply(op, a);

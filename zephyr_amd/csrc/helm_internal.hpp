@@ -75,7 +75,14 @@ struct helm_op {
     double *d_rho = nullptr, *d_theta = nullptr, *d_eps = nullptr, *d_delta = nullptr;
     bool has_model = false, aniso = false;
 
+    // host copies of the model (coarse levels of the multigrid preconditioner are built from them)
+    std::vector<cplx> h_c; std::vector<double> h_rho, h_theta, h_eps, h_delta;
+
     // operator
+    bool block0_only = false;     // Eurus preconditioner levels: assemble/keep only M1
+    double pml_scale = 1.0;       // MiniZephyr preconditioner levels: scales the PML factors (1 = reference)
+    double a_freq_re = 0, a_freq_im = 0, a_tau = 0, a_ky = 0, a_cpml = 0;   // parameters of the last assemble
+    struct MgPrecond *mg = nullptr;
     int nblocks = 1;
     cplx *d_C = nullptr;      // nblocks * 9 * N   raw planes
     cplx *d_Cs = nullptr;     // nblocks * 9 * N   planes divided by the centre plane (Jacobi-scaled)
@@ -105,6 +112,13 @@ struct helm_op {
 
 void helm_set_error(helm_op *op, const char *msg);
 
+// ---- multigrid preconditioner (mg.hip) ---------------------------------------------------------
+struct MgPrecond;
+int mg_setup(helm_op *op, int batch);                       // (re)build for the operator's current frequency
+void mg_destroy(helm_op *op);
+// out[b] = M^-1 in[b] for the active right-hand sides (scal may be null = all)
+int mg_apply(helm_op *op, const cplx *in, cplx *out, int nrhs, const RhsScal *scal);
+
 // ---- launchers implemented in assemble.hip ----------------------------------------------------
 int helm_launch_assemble(helm_op *op, double freq_re, double freq_im, double tau, double ky, double cPML);
 
@@ -114,18 +128,25 @@ enum { EPI_NONE = 0,      // y = A x
        EPI_DOT_W = 1,     // + partial (w, y)                      [BiCGSTAB (r0, v)]
        EPI_DOT_XY = 2,    // + partials (y, x), (y, y)             [BiCGSTAB (t,s),(t,t)]
        EPI_DOT_YY = 3,    // + partial (y, y)                      [CGNR]
-       EPI_RESID = 4 };   // y = w - A x, + partial (y, y)         [restart / true residual]
+       EPI_RESID = 4,     // y = w - A x, + partial (y, y)         [restart / true residual / MG residual]
+       EPI_JACOBI = 5,    // y = x + omega_j * dinv * (w - A x)    [MG smoother sweep]
+       EPI_DOT_WY = 6 };  // y = A x, + partials (y, w), (y, y)    [right-preconditioned BiCGSTAB (t,s),(t,t)]
 
 struct ApplyArgs {
-    const cplx *planes;   // 9 planes (raw or scaled), plane stride = N
-    const cplx *X; cplx *Y; const cplx *W;   // rhs stride = ld
-    long long ld;
-    int nrhs;
-    int scaled;           // 1: centre plane is 1 and skipped
-    int adjoint;
-    int epi;
-    const RhsScal *scal;  // may be null: all RHS active
-    double *part;         // partial sums, layout [rhs][q][nblk] doubles (q = 0..3)
+    const cplx *planes = nullptr;   // 9 planes (raw or scaled), plane stride = N
+    const cplx *X = nullptr; cplx *Y = nullptr; const cplx *W = nullptr;   // rhs stride = ld
+    long long ld = 0;
+    int nrhs = 0;
+    int scaled = 0;           // 1: centre plane is 1 and skipped
+    int adjoint = 0;
+    int epi = 0;
+    const RhsScal *scal = nullptr;  // may be null: all RHS active
+    double *part = nullptr;         // partial sums, layout [rhs][q][nblk] doubles (q = 0..3)
+    const cplx *dinv = nullptr;     // EPI_JACOBI: 1/diag
+    double omega_j = 0.0;           // EPI_JACOBI: damping
+    const int *tiles = nullptr;     // optional list of tile ids to process (frame tiles of the strip relaxation)
+    int ntiles = 0;
+    int profile = 1;                // count this launch in the roofline timing of the handle that owns the solve
 };
 int helm_launch_apply(helm_op *op, const ApplyArgs &a);
 int helm_apply_num_blocks(const helm_op *op);
@@ -139,7 +160,7 @@ struct VecPtrs {   // all [nrhs][N] complex, stride N
 int helm_launch_bicg_init(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, cplx premul, const cplx *sub, VecPtrs w, int nrhs, double rtol);
 int helm_launch_bicg_p(helm_op *op, VecPtrs w, int nrhs);
 int helm_launch_bicg_s(helm_op *op, VecPtrs w, int nrhs);
-int helm_launch_bicg_xr(helm_op *op, VecPtrs w, int nrhs, int nblk_part);
+int helm_launch_bicg_xr(helm_op *op, VecPtrs w, const cplx *xp, const cplx *xs, int nrhs);   // x += alpha xp + omega xs ; r = s - omega t
 int helm_launch_fin(helm_op *op, int which, int nrhs, int nblk_part);
 enum { FIN_BICG_INIT = 0, FIN_ALPHA = 1, FIN_OMEGA = 2, FIN_RHO = 3, FIN_RESTART = 4,
        FIN_CG_INIT = 5, FIN_CG_ALPHA = 6, FIN_CG_RR = 7, FIN_CG_BETA = 8, FIN_NORM = 9 };

@@ -63,6 +63,9 @@ struct StencilParams {
     int nz, nx, nrhs, ntx, ntz, nblk;
     const RhsScal *scal;
     double *part;
+    const cplx *dinv;
+    double omega_j;
+    const int *tiles;
 };
 
 constexpr int TX = 64;
@@ -77,7 +80,8 @@ __global__ __launch_bounds__(256) void k_stencil(StencilParams q) {
     __shared__ double red[16];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t = xcd_swizzle(blockIdx.x, q.nblk);
+    int t = xcd_swizzle(blockIdx.x, q.nblk);
+    if (q.tiles) t = q.tiles[t];
     const int tz = t / q.ntx, tx = t - tz * q.ntx;
     const int z0 = tz * TZ, x0 = tx * TX;
     const int nz = q.nz, nx = q.nx;
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(256) void k_stencil(StencilParams q) {
 
         double dsum[4] = {0.0, 0.0, 0.0, 0.0};
         cplx *Yb = q.Y + (long long)b * q.ld;
-        const cplx *Wb = (EPI == EPI_DOT_W || EPI == EPI_RESID) ? q.W + (long long)b * q.ld : nullptr;
+        const cplx *Wb = (EPI == EPI_DOT_W || EPI == EPI_RESID || EPI == EPI_JACOBI || EPI == EPI_DOT_WY) ? q.W + (long long)b * q.ld : nullptr;
 #pragma unroll
         for (int j = 0; j < P; ++j) {
             const int row = z0 + wave * P + j;
@@ -197,11 +201,21 @@ __global__ __launch_bounds__(256) void k_stencil(StencilParams q) {
                     dsum[2] += cabs2(y);
                 } else if (EPI == EPI_DOT_YY) {
                     dsum[0] += cabs2(y);
+                } else if (EPI == EPI_DOT_WY) {
+                    const cplx w = Wb[idx];          // (y, w) = sum conj(y) w ; (y, y)
+                    dsum[0] += y.x * w.x + y.y * w.y;
+                    dsum[1] += y.x * w.y - y.y * w.x;
+                    dsum[2] += cabs2(y);
+                } else if (EPI == EPI_JACOBI) {
+                    const cplx res = csub(Wb[idx], y);
+                    const cplx d = q.dinv[idx];
+                    y = xc_keep[j];
+                    cfma(y, cscale(d, q.omega_j), res);
                 }
                 Yb[idx] = y;
             }
         }
-        if (EPI != EPI_NONE) {
+        if (EPI != EPI_NONE && EPI != EPI_JACOBI) {
             block_sum<4>(dsum, red);
             if (tid == 0) {
                 double *pp = q.part + ((long long)b * 4) * q.nblk + blockIdx.x;
@@ -290,8 +304,8 @@ __global__ __launch_bounds__(256) void k_bicg_s(VecPtrs w, long long N, const Rh
 }
 
 // x += alpha p + omega s ; r = s - omega t ; partials (r0, r), (r, r)
-__global__ __launch_bounds__(256) void k_bicg_xr(VecPtrs w, long long N, const RhsScal *__restrict__ scal,
-                                                 double *__restrict__ part, int nblk) {
+__global__ __launch_bounds__(256) void k_bicg_xr(VecPtrs w, const cplx *__restrict__ xp, const cplx *__restrict__ xs, long long N,
+                                                 const RhsScal *__restrict__ scal, double *__restrict__ part, int nblk) {
     __shared__ double red[12];
     const int b = blockIdx.y;
     if (scal[b].status != ST_ACTIVE) return;
@@ -299,10 +313,11 @@ __global__ __launch_bounds__(256) void k_bicg_xr(VecPtrs w, long long N, const R
     double s[3] = {0.0, 0.0, 0.0};
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x) {
         const long long g = (long long)b * N + i;
-        const cplx sv = w.s[g], tv = w.t[g], pv = w.p[g];
+        const cplx sv = w.s[g], tv = w.t[g], pv = xp[g];
+        const cplx sx = (xs == w.s) ? sv : xs[g];
         cplx xv = w.x[g];
         cfma(xv, alpha, pv);
-        cfma(xv, omega, sv);
+        cfma(xv, omega, sx);
         w.x[g] = xv;
         const cplx rv = csub(sv, cmul(omega, tv));
         w.r[g] = rv;
@@ -560,6 +575,8 @@ static void launch_stencil_epi(hipStream_t st, dim3 grid, const StencilParams &q
     case EPI_DOT_XY: hipLaunchKernelGGL((k_stencil<P, SCALED, ADJ, EPI_DOT_XY>), grid, dim3(256), 0, st, q); break;
     case EPI_DOT_YY: hipLaunchKernelGGL((k_stencil<P, SCALED, ADJ, EPI_DOT_YY>), grid, dim3(256), 0, st, q); break;
     case EPI_RESID: hipLaunchKernelGGL((k_stencil<P, SCALED, ADJ, EPI_RESID>), grid, dim3(256), 0, st, q); break;
+    case EPI_JACOBI: hipLaunchKernelGGL((k_stencil<P, SCALED, ADJ, EPI_JACOBI>), grid, dim3(256), 0, st, q); break;
+    case EPI_DOT_WY: hipLaunchKernelGGL((k_stencil<P, SCALED, ADJ, EPI_DOT_WY>), grid, dim3(256), 0, st, q); break;
     }
 }
 
@@ -568,14 +585,16 @@ int helm_launch_apply(helm_op *op, const ApplyArgs &a) {
     q.planes = a.planes; q.X = a.X; q.Y = a.Y; q.W = a.W; q.ld = a.ld; q.N = op->N;
     q.nz = op->nz; q.nx = op->nx; q.nrhs = a.nrhs;
     q.ntx = (op->nx + TX - 1) / TX; q.ntz = (op->nz + 4 * STENCIL_P - 1) / (4 * STENCIL_P);
-    q.nblk = q.ntx * q.ntz;
-    q.scal = a.scal; q.part = a.part;
+    q.nblk = a.tiles ? a.ntiles : q.ntx * q.ntz;
+    q.scal = a.scal; q.part = a.part; q.dinv = a.dinv; q.omega_j = a.omega_j; q.tiles = a.tiles;
+    if (q.nblk < 1) return HELM_OK;
     int split = 1;
     if (q.nblk < 1024) { split = (1024 + q.nblk - 1) / q.nblk; if (split > a.nrhs) split = a.nrhs; if (split < 1) split = 1; }
     dim3 grid(q.nblk, split);
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (op->profiling) {
+    const bool prof = op->profiling && a.profile;
+    if (prof) {
         if (op->ev_used + 2 > op->ev_pool.size() && op->ev_pool.size() >= 8192) { e0 = nullptr; }
         else if (op->ev_used + 2 > op->ev_pool.size()) {
             for (int i = 0; i < 64; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) HELM_FAIL(op, HELM_ERR_DEVICE, "hipEventCreate failed"); op->ev_pool.push_back(e); }
@@ -592,7 +611,7 @@ int helm_launch_apply(helm_op *op, const ApplyArgs &a) {
         if (a.adjoint) launch_stencil_epi<STENCIL_P, false, true>(op->stream, grid, q, a.epi);
         else launch_stencil_epi<STENCIL_P, false, false>(op->stream, grid, q, a.epi);
     }
-    if (op->profiling && e0) {
+    if (prof && e0) {
         hipEventRecord(e1, op->stream);
         int nact = (a.scal && op->active_hint >= 0 && op->active_hint < a.nrhs) ? op->active_hint : a.nrhs;   // inactive RHS are skipped on the device
         op->ev_pending.push_back(std::make_pair((int)op->ev_used, (double)op->N * (32.0 * nact + 144.0)));
@@ -631,6 +650,16 @@ int helm_launch_bicg_init(helm_op *op, int block, const cplx *dRHS, long long rh
     return HELM_OK;
 }
 
+// x = 0, r = r0 = bvec, p = v = 0 and the scalar records, for a system whose right-hand side is already formed
+int helm_launch_krylov_init(helm_op *op, const cplx *bvec, VecPtrs w, int nrhs, double rtol) {
+    dim3 grid(vec_blocks(op->N), nrhs);
+    hipLaunchKernelGGL(k_krylov_init, grid, dim3(256), 0, op->stream, bvec, w, op->N, (double *)op->d_part, (int)grid.x);
+    FinParams f; f.scal = op->d_scal; f.part = (const double *)op->d_part; f.nblk = grid.x; f.which = FIN_BICG_INIT; f.rtol = rtol; f.mask = nullptr; f.aux = nullptr;
+    hipLaunchKernelGGL(k_fin, dim3(nrhs), dim3(256), 0, op->stream, f);
+    HIP_TRY(op, hipGetLastError());
+    return HELM_OK;
+}
+
 int helm_launch_bicg_p(helm_op *op, VecPtrs w, int nrhs) {
     dim3 grid(vec_blocks(op->N), nrhs);
     hipLaunchKernelGGL(k_bicg_p, grid, dim3(256), 0, op->stream, w, op->N, (const RhsScal *)op->d_scal);
@@ -641,9 +670,9 @@ int helm_launch_bicg_s(helm_op *op, VecPtrs w, int nrhs) {
     hipLaunchKernelGGL(k_bicg_s, grid, dim3(256), 0, op->stream, w, op->N, (const RhsScal *)op->d_scal);
     return HELM_OK;
 }
-int helm_launch_bicg_xr(helm_op *op, VecPtrs w, int nrhs, int) {
+int helm_launch_bicg_xr(helm_op *op, VecPtrs w, const cplx *xp, const cplx *xs, int nrhs) {
     dim3 grid(vec_blocks(op->N), nrhs);
-    hipLaunchKernelGGL(k_bicg_xr, grid, dim3(256), 0, op->stream, w, op->N, (const RhsScal *)op->d_scal, (double *)op->d_part, (int)grid.x);
+    hipLaunchKernelGGL(k_bicg_xr, grid, dim3(256), 0, op->stream, w, xp, xs, op->N, (const RhsScal *)op->d_scal, (double *)op->d_part, (int)grid.x);
     return HELM_OK;
 }
 int helm_launch_cg_xr(helm_op *op, VecPtrs w, int nrhs) {
