@@ -234,14 +234,23 @@ __global__ __launch_bounds__(256) void k_stencil(StencilParams q) {
 // elementwise / vector kernels (grid.x over points with a grid-stride loop, grid.y = rhs)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_scale_planes(const cplx *__restrict__ C, cplx *__restrict__ Cs,
-                                                      cplx *__restrict__ dinv, long long N, int nblocks) {
+                                                      cplx *__restrict__ dinv, long long N, int nblocks, double floor_frac) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     for (int m = 0; m < nblocks; ++m) {
         const cplx *Cm = C + (long long)m * 9 * N;
         cplx *Sm = Cs + (long long)m * 9 * N;
-        const cplx d = Cm[4 * N + i];
+        cplx d = Cm[4 * N + i];
         const bool zero = (d.x == 0.0 && d.y == 0.0);
+        if (floor_frac > 0.0 && !zero) {
+            // smoother safeguard on multigrid levels: where the diagonal nearly cancels (k h ~ 2: mass term
+            // against the Laplacian) keep its phase but not less than floor_frac of the row's absolute sum
+            double rows = 0.0;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) rows += sqrt(cabs2(Cm[(long long)k * N + i]));
+            const double ad = sqrt(cabs2(d));
+            if (ad < floor_frac * rows) d = cscale(d, floor_frac * rows / ad);
+        }
         const cplx di = zero ? cmake(0.0, 0.0) : crecip(d);
         dinv[(long long)m * N + i] = di;
 #pragma unroll
@@ -623,7 +632,7 @@ int helm_launch_apply(helm_op *op, const ApplyArgs &a) {
 
 int helm_launch_scale_planes(helm_op *op) {
     const int blocks = (int)((op->N + 255) / 256);
-    hipLaunchKernelGGL(k_scale_planes, dim3(blocks), dim3(256), 0, op->stream, op->d_C, op->d_Cs, op->d_dinv, op->N, op->nblocks);
+    hipLaunchKernelGGL(k_scale_planes, dim3(blocks), dim3(256), 0, op->stream, op->d_C, op->d_Cs, op->d_dinv, op->N, op->nblocks, op->diag_floor);
     HIP_TRY(op, hipGetLastError());
     return HELM_OK;
 }

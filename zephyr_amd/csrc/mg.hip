@@ -39,8 +39,8 @@ struct MgPrecond {
     helm_op *sop = nullptr;                     // fine grid, true PML, shifted: strip relaxation operator
     int W = 12;
     int *d_tiles = nullptr; int ntiles = 0;
-    cplx *zl_m = nullptr, *zl_c = nullptr;      // z-line factors [2W][nz]
-    cplx *xl_m = nullptr, *xl_c = nullptr;      // x-line factors [2W][nx-2W]
+    cplx *zl_m = nullptr, *zl_c = nullptr, *zl_a = nullptr;      // z-line factors [2W][nz]
+    cplx *xl_m = nullptr, *xl_c = nullptr, *xl_a = nullptr;      // x-line factors [2W][nx-2W]
     cplx *strip_r = nullptr;                    // [batch][N]
     int batch = 0;
     double omega_j = 0.8, beta = 0.5, cpml_m = 30.0, wstrip = 1.0;
@@ -134,7 +134,7 @@ __device__ inline int zline_ix(int li, int W, int nx) { return li < W ? li : nx 
 __device__ inline int xline_iz(int li, int W, int nz) { return li < W ? li : nz - 2 * W + li; }
 
 // Thomas factors of every line: m_i = 1/(b_i - a_i c'_{i-1}), c'_i = c_i m_i
-__global__ void k_line_factor(const cplx *__restrict__ C, int nz, int nx, int W, int zdir, cplx *__restrict__ m, cplx *__restrict__ cp) {
+__global__ void k_line_factor(const cplx *__restrict__ C, int nz, int nx, int W, int zdir, cplx *__restrict__ m, cplx *__restrict__ cp, cplx *__restrict__ af) {
     const int li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= 2 * W) return;
     const long long N = (long long)nz * nx;
@@ -152,40 +152,118 @@ __global__ void k_line_factor(const cplx *__restrict__ C, int nz, int nx, int W,
         cprev = cmul(c, mi);
         m[(long long)li * len + i] = mi;
         cp[(long long)li * len + i] = cprev;
+        af[(long long)li * len + i] = cneg(cmul(a, mi));
     }
 }
 
-// solve every line for the strip residual r (overwritten with the forward sweep), u += wstrip * x
-__global__ void k_line_solve(const cplx *__restrict__ C, int nz, int nx, int W, int zdir, const cplx *__restrict__ m,
-                             const cplx *__restrict__ cp, cplx *__restrict__ r, cplx *__restrict__ u, double wstrip,
-                             const RhsScal *scal) {
+// Solve every strip line for the residual r and add the correction: u += wstrip * T^-1 r.
+// One wave per (line, right-hand side).  Both Thomas sweeps are first-order linear recurrences
+//     forward : y_i = af_i y_{i-1} + m_i r_i          (af_i = -a_i m_i)
+//     backward: x_i = y_i - cp_i x_{i+1}
+// evaluated as segmented scans of affine maps: every lane owns SEG consecutive points (local
+// sequential pass), the 64 segment maps are combined with a shuffle scan, and a second local pass
+// applies the incoming value -- ~2*SEG + 6 dependent steps instead of 2*len.
+constexpr int LSEG = 16;
+
+struct Affine { cplx A, B; };     // x_out = A x_in + B
+__device__ inline Affine compose(const Affine &second, const Affine &first) {   // second after first
+    Affine r; r.A = cmul(second.A, first.A); r.B = cadd(cmul(second.A, first.B), second.B); return r;
+}
+__device__ inline cplx shfl_c(cplx v, int src) { cplx r; r.x = __shfl(v.x, src, 64); r.y = __shfl(v.y, src, 64); return r; }
+
+__global__ __launch_bounds__(64) void k_line_solve(int nz, int nx, int W, int zdir, const cplx *__restrict__ m,
+                                                   const cplx *__restrict__ cp, const cplx *__restrict__ af,
+                                                   const cplx *__restrict__ r, cplx *__restrict__ u, double wstrip,
+                                                   const RhsScal *scal) {
     const int b = blockIdx.y;
     if (!active(scal, b)) return;
-    const int li = blockIdx.x * blockDim.x + threadIdx.x;
-    if (li >= 2 * W) return;
+    const int li = blockIdx.x, lane = threadIdx.x;
     const long long N = (long long)nz * nx;
     const int len = zdir ? nz : nx - 2 * W;
-    const cplx *Ca = C + (long long)(zdir ? 1 : 3) * N;
-    cplx *rb = r + (long long)b * N;
+    const cplx *rb = r + (long long)b * N;
     cplx *ub = u + (long long)b * N;
     const long long base = zdir ? (long long)zline_ix(li, W, nx) : (long long)xline_iz(li, W, nz) * nx + W;
     const long long stride = zdir ? nx : 1;
-    const cplx *mm = m + (long long)li * len, *cc = cp + (long long)li * len;
-    cplx prev = cmake(0.0, 0.0);
-    for (int i = 0; i < len; ++i) {
-        const long long idx = base + (long long)i * stride;
-        cplx d = rb[idx];
-        if (i > 0) d = csub(d, cmul(Ca[idx], prev));
-        prev = cmul(d, mm[i]);
-        rb[idx] = prev;
+    const cplx *mm = m + (long long)li * len, *cc = cp + (long long)li * len, *aa = af + (long long)li * len;
+    const cplx zero = cmake(0.0, 0.0), one = cmake(1.0, 0.0);
+
+    const int chunk = 64 * LSEG;
+    const int nchunk = (len + chunk - 1) / chunk;
+    // ---- forward sweep, chunk by chunk; y kept in registers only for the last chunk, so it is staged through u's
+    //      companion buffer r (each point is read and written by the same lane) ----
+    cplx carry = zero;
+    cplx *rw = const_cast<cplx *>(rb);
+    for (int c = 0; c < nchunk; ++c) {
+        const int i0 = c * chunk + lane * LSEG;
+        cplx y[LSEG], a_[LSEG];
+        Affine seg; seg.A = one; seg.B = zero;
+#pragma unroll
+        for (int k = 0; k < LSEG; ++k) {
+            const int i = i0 + k;
+            cplx d = zero, mi = zero, ai = zero;
+            if (i < len) { d = rb[base + (long long)i * stride]; mi = mm[i]; ai = aa[i]; }
+            else { ai = one; }                       // identity map beyond the end
+            a_[k] = ai;
+            y[k] = (i < len) ? cmul(d, mi) : zero;   // beta_i
+        }
+#pragma unroll
+        for (int k = 0; k < LSEG; ++k) { seg.B = cadd(cmul(a_[k], seg.B), y[k]); seg.A = cmul(a_[k], seg.A); }
+        // inclusive scan of the segment maps over the wave
+        Affine inc = seg;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            Affine prev; prev.A = shfl_c(inc.A, lane - off < 0 ? 0 : lane - off); prev.B = shfl_c(inc.B, lane - off < 0 ? 0 : lane - off);
+            if (lane >= off) inc = compose(inc, prev);
+        }
+        // incoming value of this lane's segment: exclusive prefix applied to the carry
+        Affine exc; exc.A = shfl_c(inc.A, lane == 0 ? 0 : lane - 1); exc.B = shfl_c(inc.B, lane == 0 ? 0 : lane - 1);
+        cplx xin = (lane == 0) ? carry : cadd(cmul(exc.A, carry), exc.B);
+#pragma unroll
+        for (int k = 0; k < LSEG; ++k) {
+            xin = cadd(cmul(a_[k], xin), y[k]);
+            const int i = i0 + k;
+            if (i < len) rw[base + (long long)i * stride] = xin;
+        }
+        // carry for the next chunk = value after the whole chunk
+        const cplx lastA = shfl_c(inc.A, 63), lastB = shfl_c(inc.B, 63);
+        carry = cadd(cmul(lastA, carry), lastB);
     }
-    cplx x = cmake(0.0, 0.0);
-    for (int i = len - 1; i >= 0; --i) {
-        const long long idx = base + (long long)i * stride;
-        x = csub(rb[idx], cmul(cc[i], x));
-        cplx uv = ub[idx];
-        uv.x += wstrip * x.x; uv.y += wstrip * x.y;
-        ub[idx] = uv;
+    // ---- backward sweep: x_i = y_i - cp_i x_{i+1}, lanes own the same segments, scanned from the high end ----
+    carry = zero;
+    for (int c = nchunk - 1; c >= 0; --c) {
+        const int i0 = c * chunk + lane * LSEG;
+        cplx y[LSEG], a_[LSEG];
+#pragma unroll
+        for (int k = 0; k < LSEG; ++k) {
+            const int i = i0 + k;
+            if (i < len) { y[k] = rw[base + (long long)i * stride]; a_[k] = cneg(cc[i]); }
+            else { y[k] = zero; a_[k] = one; }
+        }
+        Affine seg; seg.A = one; seg.B = zero;
+#pragma unroll
+        for (int k = LSEG - 1; k >= 0; --k) { seg.B = cadd(cmul(a_[k], seg.B), y[k]); seg.A = cmul(a_[k], seg.A); }
+        Affine inc = seg;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int src = lane + off > 63 ? 63 : lane + off;
+            Affine nxt; nxt.A = shfl_c(inc.A, src); nxt.B = shfl_c(inc.B, src);
+            if (lane + off <= 63) inc = compose(inc, nxt);
+        }
+        const int srcx = lane == 63 ? 63 : lane + 1;
+        Affine exc; exc.A = shfl_c(inc.A, srcx); exc.B = shfl_c(inc.B, srcx);
+        cplx xin = (lane == 63) ? carry : cadd(cmul(exc.A, carry), exc.B);
+#pragma unroll
+        for (int k = LSEG - 1; k >= 0; --k) {
+            xin = cadd(cmul(a_[k], xin), y[k]);
+            const int i = i0 + k;
+            if (i < len) {
+                cplx uv = ub[base + (long long)i * stride];
+                uv.x += wstrip * xin.x; uv.y += wstrip * xin.y;
+                ub[base + (long long)i * stride] = uv;
+            }
+        }
+        const cplx firstA = shfl_c(inc.A, 0), firstB = shfl_c(inc.B, 0);
+        carry = cadd(cmul(firstA, carry), firstB);
     }
 }
 
@@ -245,7 +323,7 @@ void mg_destroy(helm_op *op) {
         hipFree(L.u); hipFree(L.f); hipFree(L.r); hipFree(L.t);
     }
     if (P->sop) { P->sop->own_stream = false; P->sop->stream = nullptr; helm_destroy(P->sop); }
-    hipFree(P->d_cinvT); hipFree(P->d_tiles); hipFree(P->zl_m); hipFree(P->zl_c); hipFree(P->xl_m); hipFree(P->xl_c); hipFree(P->strip_r);
+    hipFree(P->d_cinvT); hipFree(P->d_tiles); hipFree(P->zl_m); hipFree(P->zl_c); hipFree(P->xl_m); hipFree(P->xl_c); hipFree(P->zl_a); hipFree(P->xl_a); hipFree(P->strip_r);
     delete P;
     op->mg = nullptr;
 }
@@ -291,6 +369,7 @@ int mg_setup(helm_op *op, int batch) {
         if (!L.op) { helm_set_error(op, helm_last_error(nullptr)); mg_destroy(op); return HELM_ERR_DEVICE; }
         P->lv.push_back(L);
         if (op->variant == HELM_MINIZEPHYR) L.op->pml_scale = mz_weak;
+        L.op->diag_floor = env_double("HELM_MG_DIAGFLOOR", 0.5);
         P->lv.back().op = L.op;
         int rc = assemble_child(op, L.op, c, rho, th, ep, de, tauM, cpml_weak);
         if (rc) { helm_set_error(op, helm_last_error(L.op)); mg_destroy(op); return rc; }
@@ -351,10 +430,11 @@ int mg_setup(helm_op *op, int batch) {
         const size_t zl = (size_t)2 * W * op->nz, xl = (size_t)2 * W * (op->nx - 2 * W);
         MG_HIP(hipMalloc(&P->zl_m, zl * sizeof(cplx))); MG_HIP(hipMalloc(&P->zl_c, zl * sizeof(cplx)));
         MG_HIP(hipMalloc(&P->xl_m, xl * sizeof(cplx))); MG_HIP(hipMalloc(&P->xl_c, xl * sizeof(cplx)));
+        MG_HIP(hipMalloc(&P->zl_a, zl * sizeof(cplx))); MG_HIP(hipMalloc(&P->xl_a, xl * sizeof(cplx)));
         MG_HIP(hipMalloc(&P->strip_r, (size_t)batch * op->N * sizeof(cplx)));
         MG_HIP(hipMemsetAsync(P->strip_r, 0, (size_t)batch * op->N * sizeof(cplx), op->stream));
-        hipLaunchKernelGGL(k_line_factor, dim3((2 * W + 63) / 64), dim3(64), 0, op->stream, (const cplx *)P->sop->d_C, op->nz, op->nx, W, 1, P->zl_m, P->zl_c);
-        hipLaunchKernelGGL(k_line_factor, dim3((2 * W + 63) / 64), dim3(64), 0, op->stream, (const cplx *)P->sop->d_C, op->nz, op->nx, W, 0, P->xl_m, P->xl_c);
+        hipLaunchKernelGGL(k_line_factor, dim3((2 * W + 63) / 64), dim3(64), 0, op->stream, (const cplx *)P->sop->d_C, op->nz, op->nx, W, 1, P->zl_m, P->zl_c, P->zl_a);
+        hipLaunchKernelGGL(k_line_factor, dim3((2 * W + 63) / 64), dim3(64), 0, op->stream, (const cplx *)P->sop->d_C, op->nz, op->nx, W, 0, P->xl_m, P->xl_c, P->xl_a);
         MG_HIP(hipGetLastError());
     }
     MG_HIP(hipStreamSynchronize(op->stream));
@@ -429,11 +509,11 @@ int mg_apply(helm_op *op, const cplx *in, cplx *out, int nrhs, const RhsScal *sc
         a.tiles = P->d_tiles; a.ntiles = P->ntiles; a.profile = 0; a.part = (double *)op->d_part;
         rc = helm_launch_apply(P->sop, a);
         if (rc) return rc;
-        dim3 lg((2 * W + 63) / 64, nrhs);
-        hipLaunchKernelGGL(k_line_solve, lg, dim3(64), 0, op->stream, (const cplx *)P->sop->d_C, op->nz, op->nx, W, 1,
-                           (const cplx *)P->zl_m, (const cplx *)P->zl_c, P->strip_r, out, P->wstrip, scal);
-        hipLaunchKernelGGL(k_line_solve, lg, dim3(64), 0, op->stream, (const cplx *)P->sop->d_C, op->nz, op->nx, W, 0,
-                           (const cplx *)P->xl_m, (const cplx *)P->xl_c, P->strip_r, out, P->wstrip, scal);
+        dim3 lg(2 * W, nrhs);
+        hipLaunchKernelGGL(k_line_solve, lg, dim3(64), 0, op->stream, op->nz, op->nx, W, 1,
+                           (const cplx *)P->zl_m, (const cplx *)P->zl_c, (const cplx *)P->zl_a, (const cplx *)P->strip_r, out, P->wstrip, scal);
+        hipLaunchKernelGGL(k_line_solve, lg, dim3(64), 0, op->stream, op->nz, op->nx, W, 0,
+                           (const cplx *)P->xl_m, (const cplx *)P->xl_c, (const cplx *)P->xl_a, (const cplx *)P->strip_r, out, P->wstrip, scal);
     }
     HIP_TRY(op, hipGetLastError());
     return HELM_OK;
