@@ -28,7 +28,7 @@ namespace {
 
 struct MgLevel {
     helm_op *op = nullptr;
-    cplx *u = nullptr, *f = nullptr, *r = nullptr, *t = nullptr;   // [batch][N_l]
+    cplx *u = nullptr, *f = nullptr, *r = nullptr, *t = nullptr, *f2 = nullptr, *g = nullptr;   // [batch][N_l]
 };
 
 }  // namespace
@@ -45,6 +45,7 @@ struct MgPrecond {
     int batch = 0;
     double omega_j = 0.8, beta = 0.5, cpml_m = 30.0, wstrip = 1.0;
     int nu1 = 1, nu2 = 1, sweeps = 4, min_n = 16;
+    int fdepth = 0;          // levels < fdepth revisit their coarse level a second time (truncated F-cycle); 0 = V-cycle
 };
 
 namespace {
@@ -61,6 +62,16 @@ __global__ __launch_bounds__(256) void k_jac0(const cplx *__restrict__ dinv, con
     if (!active(scal, b)) return;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x)
         u[(long long)b * N + i] = cmul(cscale(dinv[i], omega_j), f[(long long)b * N + i]);
+}
+
+// u += e
+__global__ __launch_bounds__(256) void k_axpy1(const cplx *__restrict__ e, cplx *__restrict__ u, long long N, const RhsScal *scal) {
+    const int b = blockIdx.y;
+    if (!active(scal, b)) return;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x) {
+        const long long g = (long long)b * N + i;
+        u[g] = cadd(u[g], e[g]);
+    }
 }
 
 // full weighting: fc[I,J] = (1/16) sum_{di,dj} w(di) w(dj) r[2I+di, 2J+dj], w = (1,2,1), fine points outside skipped
@@ -171,13 +182,16 @@ __device__ inline Affine compose(const Affine &second, const Affine &first) {   
 }
 __device__ inline cplx shfl_c(cplx v, int src) { cplx r; r.x = __shfl(v.x, src, 64); r.y = __shfl(v.y, src, 64); return r; }
 
-__global__ __launch_bounds__(64) void k_line_solve(int nz, int nx, int W, int zdir, const cplx *__restrict__ m,
-                                                   const cplx *__restrict__ cp, const cplx *__restrict__ af,
+struct LineFactors { const cplx *m, *cp, *af; };
+
+__global__ __launch_bounds__(64) void k_line_solve(int nz, int nx, int W, LineFactors zf, LineFactors xf,
                                                    const cplx *__restrict__ r, cplx *__restrict__ u, double wstrip,
                                                    const RhsScal *scal) {
     const int b = blockIdx.y;
     if (!active(scal, b)) return;
-    const int li = blockIdx.x, lane = threadIdx.x;
+    const int zdir = blockIdx.x < 2 * W ? 1 : 0;          // first 2W workgroups: z-lines, next 2W: x-lines
+    const int li = zdir ? blockIdx.x : blockIdx.x - 2 * W, lane = threadIdx.x;
+    const cplx *m = zdir ? zf.m : xf.m, *cp = zdir ? zf.cp : xf.cp, *af = zdir ? zf.af : xf.af;
     const long long N = (long long)nz * nx;
     const int len = zdir ? nz : nx - 2 * W;
     const cplx *rb = r + (long long)b * N;
@@ -320,7 +334,7 @@ void mg_destroy(helm_op *op) {
     if (op->stream) hipStreamSynchronize(op->stream);
     for (MgLevel &L : P->lv) {
         if (L.op) { L.op->own_stream = false; L.op->stream = nullptr; helm_destroy(L.op); }
-        hipFree(L.u); hipFree(L.f); hipFree(L.r); hipFree(L.t);
+        hipFree(L.u); hipFree(L.f); hipFree(L.r); hipFree(L.t); hipFree(L.f2); hipFree(L.g);
     }
     if (P->sop) { P->sop->own_stream = false; P->sop->stream = nullptr; helm_destroy(P->sop); }
     hipFree(P->d_cinvT); hipFree(P->d_tiles); hipFree(P->zl_m); hipFree(P->zl_c); hipFree(P->xl_m); hipFree(P->xl_c); hipFree(P->zl_a); hipFree(P->xl_a); hipFree(P->strip_r);
@@ -347,6 +361,7 @@ int mg_setup(helm_op *op, int batch) {
     P->nu1 = env_int("HELM_MG_NU1", 1);
     P->nu2 = env_int("HELM_MG_NU2", 1);
     P->min_n = env_int("HELM_MG_MIN_N", 16);
+    P->fdepth = env_int("HELM_MG_FDEPTH", 3);
     P->W = op->nPML + 2;
     if (2 * P->W + 2 > op->nx || 2 * P->W + 2 > op->nz) P->sweeps = 0;      // grid too small for a frame: plain cycle
 
@@ -375,7 +390,7 @@ int mg_setup(helm_op *op, int batch) {
         if (rc) { helm_set_error(op, helm_last_error(L.op)); mg_destroy(op); return rc; }
         const size_t bytes = (size_t)batch * nz * nx * sizeof(cplx);
         MgLevel &R = P->lv.back();
-        if (P->lv.size() > 1) { MG_HIP(hipMalloc(&R.u, bytes)); MG_HIP(hipMalloc(&R.f, bytes)); }
+        if (P->lv.size() > 1) { MG_HIP(hipMalloc(&R.u, bytes)); MG_HIP(hipMalloc(&R.f, bytes)); MG_HIP(hipMalloc(&R.f2, bytes)); MG_HIP(hipMalloc(&R.g, bytes)); }
         MG_HIP(hipMalloc(&R.r, bytes)); MG_HIP(hipMalloc(&R.t, bytes));
         const int nzc = (nz + 1) / 2, nxc = (nx + 1) / 2;
         const int npmlc = std::max((npml - 1) / 2 + 1, 2);
@@ -455,7 +470,9 @@ int smooth_sweeps(helm_op *op, MgLevel &L, cplx *&u, cplx *&alt, const cplx *f, 
     return HELM_OK;
 }
 
-int vcycle(helm_op *op, MgPrecond *P, int l, const cplx *f, cplx *u_out, int nrhs, const RhsScal *scal) {
+// One multigrid cycle on level l: u_out = approx M_l^-1 f.  fmode: levels < P->fdepth visit their coarse
+// level a second time (with the coarse residual), the second visit being a plain V-cycle (truncated F-cycle).
+int vcycle(helm_op *op, MgPrecond *P, int l, const cplx *f, cplx *u_out, int nrhs, const RhsScal *scal, bool fmode) {
     MgLevel &L = P->lv[l];
     helm_op *lo = L.op;
     const long long N = lo->N;
@@ -465,32 +482,38 @@ int vcycle(helm_op *op, MgPrecond *P, int l, const cplx *f, cplx *u_out, int nrh
         hipLaunchKernelGGL(k_coarse_dense, grid, dim3(256), (size_t)P->nc * sizeof(cplx), st, (const cplx *)P->d_cinvT, f, u_out, P->nc, scal);
         return HELM_OK;
     }
-    // pre-smoothing from zero: u = w D^-1 f, then nu1-1 further sweeps (ping-pong u_out <-> L.t)
-    cplx *u = u_out, *alt = L.t;
+    // Jacobi sweeps ping-pong between two buffers; start so that the last sweep lands in u_out
+    const int pingpongs = (P->nu1 - 1) + P->nu2;
+    cplx *u = (pingpongs & 1) ? L.t : u_out, *alt = (pingpongs & 1) ? u_out : L.t;
     dim3 vg(vblocks(N), nrhs);
     hipLaunchKernelGGL(k_jac0, vg, dim3(256), 0, st, (const cplx *)lo->d_dinv, f, u, N, P->omega_j, scal);
     int rc = smooth_sweeps(op, L, u, alt, f, P->nu1 - 1, nrhs, P->omega_j, scal);
     if (rc) return rc;
-    // residual and restriction
-    {
+    auto residual = [&](helm_op *o, const cplx *x, const cplx *rhs, cplx *out) -> int {
         ApplyArgs a;
-        a.planes = lo->d_C; a.X = u; a.Y = L.r; a.W = f; a.ld = N; a.nrhs = nrhs; a.epi = EPI_RESID; a.scal = scal; a.profile = 0;
+        a.planes = o->d_C; a.X = x; a.Y = out; a.W = rhs; a.ld = o->N; a.nrhs = nrhs; a.epi = EPI_RESID; a.scal = scal; a.profile = 0;
         a.part = (double *)op->d_part;
-        rc = helm_launch_apply(lo, a);
-        if (rc) return rc;
-    }
+        return helm_launch_apply(o, a);
+    };
+    rc = residual(lo, u, f, L.r);
+    if (rc) return rc;
     MgLevel &C = P->lv[l + 1];
     dim3 cg(vblocks(C.op->N), nrhs);
     hipLaunchKernelGGL(k_restrict, cg, dim3(256), 0, st, (const cplx *)L.r, C.f, lo->nz, lo->nx, C.op->nz, C.op->nx, scal);
-    rc = vcycle(op, P, l + 1, C.f, C.u, nrhs, scal);
+    rc = vcycle(op, P, l + 1, C.f, C.u, nrhs, scal, fmode);
     if (rc) return rc;
+    if (fmode && l < P->fdepth && l + 1 < (int)P->lv.size() - 1) {
+        // second visit of the coarse level: e += V(f_c - M_c e), with its own right-hand-side / result buffers
+        rc = residual(C.op, C.u, C.f, C.g);
+        if (rc) return rc;
+        rc = vcycle(op, P, l + 1, C.g, C.f2, nrhs, scal, false);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_axpy1, cg, dim3(256), 0, st, (const cplx *)C.f2, C.u, C.op->N, scal);
+    }
     hipLaunchKernelGGL(k_prolong_add, vg, dim3(256), 0, st, (const cplx *)C.u, u, lo->nz, lo->nx, C.op->nz, C.op->nx, scal);
-    // post-smoothing
     rc = smooth_sweeps(op, L, u, alt, f, P->nu2, nrhs, P->omega_j, scal);
     if (rc) return rc;
-    if (u != u_out) {   // odd number of ping-pongs: result sits in L.t
-        hipMemcpyAsync(u_out, u, (size_t)nrhs * N * sizeof(cplx), hipMemcpyDeviceToDevice, st);
-    }
+    if (u != u_out) HELM_FAIL(op, HELM_ERR_STATE, "multigrid ping-pong parity error");
     return HELM_OK;
 }
 
@@ -500,7 +523,7 @@ int mg_apply(helm_op *op, const cplx *in, cplx *out, int nrhs, const RhsScal *sc
     MgPrecond *P = op->mg;
     if (!P) HELM_FAIL(op, HELM_ERR_STATE, "preconditioner not built");
     if (nrhs > P->batch) HELM_FAIL(op, HELM_ERR_ARG, "preconditioner batch too small");
-    int rc = vcycle(op, P, 0, in, out, nrhs, scal);
+    int rc = vcycle(op, P, 0, in, out, nrhs, scal, P->fdepth > 0);
     if (rc) return rc;
     const int W = P->W;
     for (int k = 0; k < P->sweeps; ++k) {
@@ -509,11 +532,10 @@ int mg_apply(helm_op *op, const cplx *in, cplx *out, int nrhs, const RhsScal *sc
         a.tiles = P->d_tiles; a.ntiles = P->ntiles; a.profile = 0; a.part = (double *)op->d_part;
         rc = helm_launch_apply(P->sop, a);
         if (rc) return rc;
-        dim3 lg(2 * W, nrhs);
-        hipLaunchKernelGGL(k_line_solve, lg, dim3(64), 0, op->stream, op->nz, op->nx, W, 1,
-                           (const cplx *)P->zl_m, (const cplx *)P->zl_c, (const cplx *)P->zl_a, (const cplx *)P->strip_r, out, P->wstrip, scal);
-        hipLaunchKernelGGL(k_line_solve, lg, dim3(64), 0, op->stream, op->nz, op->nx, W, 0,
-                           (const cplx *)P->xl_m, (const cplx *)P->xl_c, (const cplx *)P->xl_a, (const cplx *)P->strip_r, out, P->wstrip, scal);
+        dim3 lg(4 * W, nrhs);
+        LineFactors zf = {P->zl_m, P->zl_c, P->zl_a}, xf = {P->xl_m, P->xl_c, P->xl_a};
+        hipLaunchKernelGGL(k_line_solve, lg, dim3(64), 0, op->stream, op->nz, op->nx, W, zf, xf,
+                           (const cplx *)P->strip_r, out, P->wstrip, scal);
     }
     HIP_TRY(op, hipGetLastError());
     return HELM_OK;
