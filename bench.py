@@ -174,7 +174,8 @@ def main():
                        'grid': [n, n], 'sources_per_step': B, 'freqs_hz_this_run': freq_used, 'sharding': 'work items (freq, source batch) round-robin over ranks',
                        'iterations_per_rhs_mean': float(np.mean(iters)) if iters else None,
                        'iterations_per_rhs_max': int(np.max(iters)) if iters else None},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_stencil (batched 9-pt complex128 apply + fused dots)',
+            'roofline': {'bound': 'hbm', 'kernel': 'k_stencil (batched 9-pt complex128 apply with fused dot-product epilogue), outer-iteration launches',
+                         'bytes_formula': 'N*(32*B_active + 144) for the apply + N*16*B_active for the epilogue operand (r0 or s) it must read',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': None, 'launches_timed': int(apply_launches),
                          'avg_launch_us': 1e3 * apply_ms / apply_launches if apply_launches else None,

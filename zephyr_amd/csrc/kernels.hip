@@ -623,7 +623,10 @@ int helm_launch_apply(helm_op *op, const ApplyArgs &a) {
     if (prof && e0) {
         hipEventRecord(e1, op->stream);
         int nact = (a.scal && op->active_hint >= 0 && op->active_hint < a.nrhs) ? op->active_hint : a.nrhs;   // inactive RHS are skipped on the device
-        op->ev_pending.push_back(std::make_pair((int)op->ev_used, (double)op->N * (32.0 * nact + 144.0)));
+        // algorithmic bytes of the launch: the stencil apply N*(32*B + 144) plus, for the fused
+        // epilogues that take an operand vector (dot with r0 / s, residual w - Ax), that operand's one read
+        const bool operand = (a.epi == EPI_DOT_W || a.epi == EPI_DOT_WY || a.epi == EPI_RESID || a.epi == EPI_JACOBI);
+        op->ev_pending.push_back(std::make_pair((int)op->ev_used, (double)op->N * (32.0 * nact + 144.0 + (operand ? 16.0 * nact : 0.0))));
         op->ev_used += 2;
     }
     HIP_TRY(op, hipGetLastError());
