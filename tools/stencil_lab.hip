@@ -131,7 +131,7 @@ void run_tile(const char *name, const cplx *dC, const cplx *dX, cplx *dY, int n,
     if (q.nblk < 1024) { split = (1024 + q.nblk - 1) / q.nblk; if (split > B) split = B; }
     dim3 grid(q.nblk, split);
     CK(hipMemset(dY, 0, (size_t)B * N * sizeof(cplx)));
-    double ms = time_it([&] { hipLaunchKernelGGL((k_stencil<P, false, false, EPI_NONE>), grid, dim3(256), 0, 0, q); });
+    double ms = time_it([&] { hipLaunchKernelGGL((k_stencil_t<cplx, P, false, false, EPI_NONE>), grid, dim3(256), 0, 0, q); });
     std::vector<cplx> out((size_t)B * N);
     CK(hipMemcpy(out.data(), dY, out.size() * sizeof(cplx), hipMemcpyDeviceToHost));
     printf("%-28s %8.1f us  %7.1f GB/s alg  err %.1e\n", name, ms * 1e3, bytes / (ms * 1e-3) / 1e9, max_err(out, ref));

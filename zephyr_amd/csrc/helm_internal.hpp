@@ -43,6 +43,32 @@ __host__ __device__ inline void cfma_conj(cplx &acc, cplx a, cplx b) {
     acc.y = fma(a.x, b.y, acc.y); acc.y = fma(-a.y, b.x, acc.y);
 }
 
+// ---- single-precision complex (multigrid preconditioner storage) -------------------------------
+typedef float2 cplxf;
+__host__ __device__ inline cplxf cmakef(float r, float i) { cplxf z; z.x = r; z.y = i; return z; }
+__host__ __device__ inline cplxf cadd(cplxf a, cplxf b) { return cmakef(a.x + b.x, a.y + b.y); }
+__host__ __device__ inline cplxf csub(cplxf a, cplxf b) { return cmakef(a.x - b.x, a.y - b.y); }
+__host__ __device__ inline cplxf cmul(cplxf a, cplxf b) { return cmakef(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__host__ __device__ inline cplxf cscale(cplxf a, double s) { return cmakef(a.x * (float)s, a.y * (float)s); }
+__host__ __device__ inline cplxf cconj(cplxf a) { return cmakef(a.x, -a.y); }
+__host__ __device__ inline cplxf cneg(cplxf a) { return cmakef(-a.x, -a.y); }
+__host__ __device__ inline double cabs2(cplxf a) { return (double)a.x * a.x + (double)a.y * a.y; }
+__host__ __device__ inline void cfma(cplxf &acc, cplxf a, cplxf b) {
+    acc.x = fmaf(a.x, b.x, acc.x); acc.x = fmaf(-a.y, b.y, acc.x);
+    acc.y = fmaf(a.x, b.y, acc.y); acc.y = fmaf(a.y, b.x, acc.y);
+}
+__host__ __device__ inline cplxf to_f32(cplx a) { return cmakef((float)a.x, (float)a.y); }
+__host__ __device__ inline cplx to_f64(cplxf a) { return cmake((double)a.x, (double)a.y); }
+template <class V> __host__ __device__ inline V vzero();
+template <> __host__ __device__ inline cplx vzero<cplx>() { return cmake(0.0, 0.0); }
+template <> __host__ __device__ inline cplxf vzero<cplxf>() { return cmakef(0.f, 0.f); }
+template <class V> __host__ __device__ inline V vone();
+template <> __host__ __device__ inline cplx vone<cplx>() { return cmake(1.0, 0.0); }
+template <> __host__ __device__ inline cplxf vone<cplxf>() { return cmakef(1.f, 0.f); }
+template <class V> __host__ __device__ inline V vfrom(cplx a);
+template <> __host__ __device__ inline cplx vfrom<cplx>(cplx a) { return a; }
+template <> __host__ __device__ inline cplxf vfrom<cplxf>(cplx a) { return to_f32(a); }
+
 // ---- per-RHS solver scalars kept on the device ---------------------------------------------
 // One record per right-hand side of the batch; written only by the single-block "finalize"
 // kernels, read by every vector kernel.  Plain doubles so the host can memcpy it.
@@ -147,6 +173,8 @@ struct ApplyArgs {
     double omega_j = 0.0;           // EPI_JACOBI: damping
     const int *tiles = nullptr;     // optional list of tile ids to process (frame tiles of the strip relaxation)
     int ntiles = 0;
+    int f32 = 0;                    // 1: planes / X / Y / W / dinv are single-precision complex (multigrid levels);
+                                    //    only EPI_NONE / EPI_RESID / EPI_JACOBI, unscaled, forward
     int profile = 1;                // count this launch in the roofline timing of the handle that owns the solve
 };
 int helm_launch_apply(helm_op *op, const ApplyArgs &a);

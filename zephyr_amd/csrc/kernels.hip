@@ -54,29 +54,31 @@ __device__ inline int xcd_swizzle(int bid, int nblk) {
 // ------------------------------------------------------------------------------------------
 // stencil apply
 // ------------------------------------------------------------------------------------------
-struct StencilParams {
-    const cplx *planes;
-    const cplx *X;
-    cplx *Y;
-    const cplx *W;
+template <class V>
+struct StencilParamsT {
+    const V *planes;
+    const V *X;
+    V *Y;
+    const V *W;
     long long ld, N;
     int nz, nx, nrhs, ntx, ntz, nblk;
     const RhsScal *scal;
     double *part;
-    const cplx *dinv;
+    const V *dinv;
     double omega_j;
     const int *tiles;
 };
+typedef StencilParamsT<cplx> StencilParams;
 
 constexpr int TX = 64;
 
-template <int P, bool SCALED, bool ADJ, int EPI>
-__global__ __launch_bounds__(256) void k_stencil(StencilParams q) {
+template <class V, int P, bool SCALED, bool ADJ, int EPI>
+__global__ __launch_bounds__(256) void k_stencil_t(StencilParamsT<V> q) {
     constexpr int TZ = 4 * P;
     constexpr int LW = TX + 2;             // tile row length in elements
     constexpr int LR = TZ + 2;             // tile rows
     constexpr int NLOAD = (LR + 3) / 4;    // main-column row loads per wave
-    __shared__ __attribute__((aligned(16))) cplx tile[2][LR * LW];
+    __shared__ __attribute__((aligned(16))) V tile[2][LR * LW];
     __shared__ double red[16];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -90,15 +92,15 @@ __global__ __launch_bounds__(256) void k_stencil(StencilParams q) {
     const bool colok = col < nx;
 
     // ---- coefficients for this thread's P points, kept in registers over the RHS loop ----
-    cplx cf[P][9];
+    V cf[P][9];
 #pragma unroll
     for (int j = 0; j < P; ++j) {
         const int row = z0 + wave * P + j;
         const bool ok = colok && row < nz;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            if (SCALED && k == 4) { cf[j][k] = cmake(1.0, 0.0); continue; }
-            cplx v = cmake(0.0, 0.0);
+            if (SCALED && k == 4) { cf[j][k] = vone<V>(); continue; }
+            V v = vzero<V>();
             if (!ADJ) {
                 if (ok) v = q.planes[(long long)k * N + (long long)row * nx + col];
             } else {
@@ -114,19 +116,19 @@ __global__ __launch_bounds__(256) void k_stencil(StencilParams q) {
     }
 
     // ---- RHS loop with register prefetch + double-buffered LDS tile ----
-    cplx pre[NLOAD];
-    cplx prehalo = cmake(0.0, 0.0);
+    V pre[NLOAD];
+    V prehalo = vzero<V>();
     auto prefetch = [&](int b) {
-        const cplx *Xb = q.X + (long long)b * q.ld;
+        const V *Xb = q.X + (long long)b * q.ld;
 #pragma unroll
         for (int l = 0; l < NLOAD; ++l) {
             const int r = wave + 4 * l;                 // tile row
             const int grow = z0 - 1 + r;
-            cplx v = cmake(0.0, 0.0);
+            V v = vzero<V>();
             if (r < LR && colok && grow >= 0 && grow < nz) v = Xb[(long long)grow * nx + col];
             pre[l] = v;
         }
-        prehalo = cmake(0.0, 0.0);
+        prehalo = vzero<V>();
         if (tid < 2 * LR) {
             const int r = tid >> 1, side = tid & 1;
             const int grow = z0 - 1 + r, gcol = side ? x0 + TX : x0 - 1;
@@ -157,14 +159,14 @@ __global__ __launch_bounds__(256) void k_stencil(StencilParams q) {
         if (bn < q.nrhs) prefetch(bn);
         __syncthreads();
 
-        cplx acc[P];
+        V acc[P];
 #pragma unroll
-        for (int j = 0; j < P; ++j) acc[j] = cmake(0.0, 0.0);
-        cplx xc_keep[P];
-        const cplx *trow = &tile[buf][(wave * P) * LW + lane];
+        for (int j = 0; j < P; ++j) acc[j] = vzero<V>();
+        V xc_keep[P];
+        const V *trow = &tile[buf][(wave * P) * LW + lane];
 #pragma unroll
         for (int rr = 0; rr < P + 2; ++rr) {
-            const cplx xl = trow[rr * LW + 0], xm = trow[rr * LW + 1], xr = trow[rr * LW + 2];
+            const V xl = trow[rr * LW + 0], xm = trow[rr * LW + 1], xr = trow[rr * LW + 2];
 #pragma unroll
             for (int j = 0; j < P; ++j) {
                 const int dzi = rr - j;            // 0,1,2 <-> dz = -1,0,+1
@@ -178,44 +180,44 @@ __global__ __launch_bounds__(256) void k_stencil(StencilParams q) {
         }
 
         double dsum[4] = {0.0, 0.0, 0.0, 0.0};
-        cplx *Yb = q.Y + (long long)b * q.ld;
-        const cplx *Wb = (EPI == EPI_DOT_W || EPI == EPI_RESID || EPI == EPI_JACOBI || EPI == EPI_DOT_WY) ? q.W + (long long)b * q.ld : nullptr;
+        V *Yb = q.Y + (long long)b * q.ld;
+        const V *Wb = (EPI == EPI_DOT_W || EPI == EPI_RESID || EPI == EPI_JACOBI || EPI == EPI_DOT_WY) ? q.W + (long long)b * q.ld : nullptr;
 #pragma unroll
         for (int j = 0; j < P; ++j) {
             const int row = z0 + wave * P + j;
             if (colok && row < nz) {
                 const long long idx = (long long)row * nx + col;
-                cplx y = acc[j];
+                V y = acc[j];
                 if (EPI == EPI_RESID) {
-                    const cplx w = Wb[idx];
+                    const V w = Wb[idx];
                     y = csub(w, y);
                     dsum[0] += cabs2(y);
                 } else if (EPI == EPI_DOT_W) {
-                    const cplx w = Wb[idx];          // (w, y) = sum conj(w) y
+                    const V w = Wb[idx];          // (w, y) = sum conj(w) y
                     dsum[0] += w.x * y.x + w.y * y.y;
                     dsum[1] += w.x * y.y - w.y * y.x;
                 } else if (EPI == EPI_DOT_XY) {
-                    const cplx x = xc_keep[j];       // (y, x) = sum conj(y) x ; (y, y)
+                    const V x = xc_keep[j];       // (y, x) = sum conj(y) x ; (y, y)
                     dsum[0] += y.x * x.x + y.y * x.y;
                     dsum[1] += y.x * x.y - y.y * x.x;
                     dsum[2] += cabs2(y);
                 } else if (EPI == EPI_DOT_YY) {
                     dsum[0] += cabs2(y);
                 } else if (EPI == EPI_DOT_WY) {
-                    const cplx w = Wb[idx];          // (y, w) = sum conj(y) w ; (y, y)
+                    const V w = Wb[idx];          // (y, w) = sum conj(y) w ; (y, y)
                     dsum[0] += y.x * w.x + y.y * w.y;
                     dsum[1] += y.x * w.y - y.y * w.x;
                     dsum[2] += cabs2(y);
                 } else if (EPI == EPI_JACOBI) {
-                    const cplx res = csub(Wb[idx], y);
-                    const cplx d = q.dinv[idx];
+                    const V res = csub(Wb[idx], y);
+                    const V d = q.dinv[idx];
                     y = xc_keep[j];
                     cfma(y, cscale(d, q.omega_j), res);
                 }
                 Yb[idx] = y;
             }
         }
-        if (EPI != EPI_NONE && EPI != EPI_JACOBI) {
+        if (EPI != EPI_NONE && EPI != EPI_JACOBI && sizeof(V) == sizeof(cplx)) {   // single-precision (multigrid) launches need no partials
             block_sum<4>(dsum, red);
             if (tid == 0) {
                 double *pp = q.part + ((long long)b * 4) * q.nblk + blockIdx.x;
@@ -579,17 +581,40 @@ int helm_vec_num_blocks(const helm_op *op) { return vec_blocks(op->N); }
 template <int P, bool SCALED, bool ADJ>
 static void launch_stencil_epi(hipStream_t st, dim3 grid, const StencilParams &q, int epi) {
     switch (epi) {
-    case EPI_NONE: hipLaunchKernelGGL((k_stencil<P, SCALED, ADJ, EPI_NONE>), grid, dim3(256), 0, st, q); break;
-    case EPI_DOT_W: hipLaunchKernelGGL((k_stencil<P, SCALED, ADJ, EPI_DOT_W>), grid, dim3(256), 0, st, q); break;
-    case EPI_DOT_XY: hipLaunchKernelGGL((k_stencil<P, SCALED, ADJ, EPI_DOT_XY>), grid, dim3(256), 0, st, q); break;
-    case EPI_DOT_YY: hipLaunchKernelGGL((k_stencil<P, SCALED, ADJ, EPI_DOT_YY>), grid, dim3(256), 0, st, q); break;
-    case EPI_RESID: hipLaunchKernelGGL((k_stencil<P, SCALED, ADJ, EPI_RESID>), grid, dim3(256), 0, st, q); break;
-    case EPI_JACOBI: hipLaunchKernelGGL((k_stencil<P, SCALED, ADJ, EPI_JACOBI>), grid, dim3(256), 0, st, q); break;
-    case EPI_DOT_WY: hipLaunchKernelGGL((k_stencil<P, SCALED, ADJ, EPI_DOT_WY>), grid, dim3(256), 0, st, q); break;
+    case EPI_NONE: hipLaunchKernelGGL((k_stencil_t<cplx, P, SCALED, ADJ, EPI_NONE>), grid, dim3(256), 0, st, q); break;
+    case EPI_DOT_W: hipLaunchKernelGGL((k_stencil_t<cplx, P, SCALED, ADJ, EPI_DOT_W>), grid, dim3(256), 0, st, q); break;
+    case EPI_DOT_XY: hipLaunchKernelGGL((k_stencil_t<cplx, P, SCALED, ADJ, EPI_DOT_XY>), grid, dim3(256), 0, st, q); break;
+    case EPI_DOT_YY: hipLaunchKernelGGL((k_stencil_t<cplx, P, SCALED, ADJ, EPI_DOT_YY>), grid, dim3(256), 0, st, q); break;
+    case EPI_RESID: hipLaunchKernelGGL((k_stencil_t<cplx, P, SCALED, ADJ, EPI_RESID>), grid, dim3(256), 0, st, q); break;
+    case EPI_JACOBI: hipLaunchKernelGGL((k_stencil_t<cplx, P, SCALED, ADJ, EPI_JACOBI>), grid, dim3(256), 0, st, q); break;
+    case EPI_DOT_WY: hipLaunchKernelGGL((k_stencil_t<cplx, P, SCALED, ADJ, EPI_DOT_WY>), grid, dim3(256), 0, st, q); break;
     }
 }
 
+// single-precision launches (multigrid levels): unscaled, forward, EPI_NONE / EPI_RESID / EPI_JACOBI
+static int launch_apply_f32(helm_op *op, const ApplyArgs &a) {
+    StencilParamsT<cplxf> q;
+    q.planes = (const cplxf *)a.planes; q.X = (const cplxf *)a.X; q.Y = (cplxf *)a.Y; q.W = (const cplxf *)a.W; q.ld = a.ld; q.N = op->N;
+    q.nz = op->nz; q.nx = op->nx; q.nrhs = a.nrhs;
+    q.ntx = (op->nx + TX - 1) / TX; q.ntz = (op->nz + 4 * STENCIL_P - 1) / (4 * STENCIL_P);
+    q.nblk = a.tiles ? a.ntiles : q.ntx * q.ntz;
+    q.scal = a.scal; q.part = a.part; q.dinv = (const cplxf *)a.dinv; q.omega_j = a.omega_j; q.tiles = a.tiles;
+    if (q.nblk < 1) return HELM_OK;
+    int split = 1;
+    if (q.nblk < 1024) { split = (1024 + q.nblk - 1) / q.nblk; if (split > a.nrhs) split = a.nrhs; if (split < 1) split = 1; }
+    dim3 grid(q.nblk, split);
+    switch (a.epi) {
+    case EPI_NONE: hipLaunchKernelGGL((k_stencil_t<cplxf, STENCIL_P, false, false, EPI_NONE>), grid, dim3(256), 0, op->stream, q); break;
+    case EPI_RESID: hipLaunchKernelGGL((k_stencil_t<cplxf, STENCIL_P, false, false, EPI_RESID>), grid, dim3(256), 0, op->stream, q); break;
+    case EPI_JACOBI: hipLaunchKernelGGL((k_stencil_t<cplxf, STENCIL_P, false, false, EPI_JACOBI>), grid, dim3(256), 0, op->stream, q); break;
+    default: HELM_FAIL(op, HELM_ERR_ARG, "unsupported single-precision stencil epilogue");
+    }
+    HIP_TRY(op, hipGetLastError());
+    return HELM_OK;
+}
+
 int helm_launch_apply(helm_op *op, const ApplyArgs &a) {
+    if (a.f32) return launch_apply_f32(op, a);
     StencilParams q;
     q.planes = a.planes; q.X = a.X; q.Y = a.Y; q.W = a.W; q.ld = a.ld; q.N = op->N;
     q.nz = op->nz; q.nx = op->nx; q.nrhs = a.nrhs;
