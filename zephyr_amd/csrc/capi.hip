@@ -406,7 +406,7 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
     if (rc) return rc;
     // preconditioner choice: multigrid for the main block when asked for (or AUTO on Eurus, where it is validated)
     bool use_mg = false;
-    if (block == 0 && (o.method == HELM_MG || (o.method == HELM_AUTO && op->variant == HELM_EURUS && std::min(op->nz, op->nx) >= 32))) {
+    if (block == 0 && (o.method == HELM_MG || (o.method == HELM_AUTO && std::min(op->nz, op->nx) >= 32))) {
         rc = mg_setup(op, Bmax);
         if (rc == HELM_OK) use_mg = true;
         else if (o.method == HELM_MG) return rc;

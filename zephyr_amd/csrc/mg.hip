@@ -477,7 +477,7 @@ int mg_setup(helm_op *op, int batch) {
     if (std::isfinite(op->a_tau) && op->a_tau != 0.0) inv_tau += 1.0 / op->a_tau;
     const double tauM = 1.0 / inv_tau;
     const double cpml_weak = op->variant == HELM_EURUS ? std::min(P->cpml_m, op->a_cpml) : 0.0;
-    const double mz_weak = env_double("HELM_MG_MZ_PMLSCALE", 0.02);
+    const double mz_weak = env_double("HELM_MG_MZ_PMLSCALE", 0.1);
 
     // ---- levels (operators assembled in double precision by the regular assembly kernels) ----
     std::vector<cplx> c = op->h_c;
