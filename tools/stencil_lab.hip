@@ -123,8 +123,9 @@ double max_err(const std::vector<cplx> &a, const std::vector<cplx> &b) {
 }
 
 template <int P>
-void run_tile(const char *name, const cplx *dC, const cplx *dX, cplx *dY, int n, long long N, int B, const std::vector<cplx> &ref, double bytes) {
+void run_tile(const char *name, const cplx *dC, const cplx *dX, cplx *dY, int n, long long N, int B, const std::vector<cplx> &ref, double bytes, int tiled = 0) {
     StencilParams q;
+    q.planes_tiled = tiled; q.U = nullptr; q.E = nullptr; q.nzc = q.nxc = 0;
     q.planes = dC; q.X = dX; q.Y = dY; q.W = nullptr; q.ld = N; q.N = N; q.nz = n; q.nx = n; q.nrhs = B;
     q.ntx = (n + 63) / 64; q.ntz = (n + 4 * P - 1) / (4 * P); q.nblk = q.ntx * q.ntz; q.scal = nullptr; q.part = nullptr; q.dinv = nullptr; q.omega_j = 0; q.tiles = nullptr;
     int split = 1;
@@ -178,7 +179,19 @@ int main(int argc, char **argv) {
     run_tile<1>("lds-tile P=1", dC, dX, dY, n, N, B, ref, bytes);
     run_tile<2>("lds-tile P=2 (current)", dC, dX, dY, n, N, B, ref, bytes);
     run_tile<4>("lds-tile P=4", dC, dX, dY, n, N, B, ref, bytes);
-    for (int ZC : {16, 32, 64}) {
+    {   // tile-blocked coefficient layout, P=2 (64 x 8 tiles)
+        const int ntx = (n + 63) / 64, ntz = (n + 7) / 8;
+        std::vector<cplx> hT((size_t)ntx * ntz * 9 * 512, cmake(0, 0));
+        for (int tz = 0; tz < ntz; ++tz) for (int tx = 0; tx < ntx; ++tx) for (int k = 0; k < 9; ++k) for (int r = 0; r < 8; ++r) for (int l = 0; l < 64; ++l) {
+            const int row = tz * 8 + r, col = tx * 64 + l;
+            if (row < n && col < n) hT[(((size_t)(tz * ntx + tx) * 9 + k) * 8 + r) * 64 + l] = hC[(size_t)k * N + (size_t)row * n + col];
+        }
+        cplx *dT; CK(hipMalloc(&dT, hT.size() * sizeof(cplx)));
+        CK(hipMemcpy(dT, hT.data(), hT.size() * sizeof(cplx), hipMemcpyHostToDevice));
+        run_tile<2>("lds-tile P=2 tiled planes", dT, dX, dY, n, N, B, ref, bytes, 1);
+        CK(hipFree(dT));
+    }
+    for (int ZC : {16}) {
         run_march<2, 4>("march BT=2 G=4", ZC, dC, dX, dY, n, N, B, ref, bytes);
         run_march<4, 2>("march BT=4 G=2", ZC, dC, dX, dY, n, N, B, ref, bytes);
         run_march<4, 1>("march BT=4 G=1", ZC, dC, dX, dY, n, N, B, ref, bytes);

@@ -173,6 +173,9 @@ struct ApplyArgs {
     double omega_j = 0.0;           // EPI_JACOBI: damping
     const int *tiles = nullptr;     // optional list of tile ids to process (frame tiles of the strip relaxation)
     int ntiles = 0;
+    int planes_tiled = 0;           // 1: `planes` points to the tile-blocked copy of the planes
+    int xmode = 0;                  // 1: input = omega_j dinv (.) W (also written to U), with EPI_RESID; 2: input = X + P E, with EPI_JACOBI
+    cplx *U = nullptr; const cplx *E = nullptr; int nzc = 0, nxc = 0;
     int f32 = 0;                    // 1: planes / X / Y / W / dinv are single-precision complex (multigrid levels);
                                     //    only EPI_NONE / EPI_RESID / EPI_JACOBI, unscaled, forward
     int profile = 1;                // count this launch in the roofline timing of the handle that owns the solve

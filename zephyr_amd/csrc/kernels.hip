@@ -67,12 +67,21 @@ struct StencilParamsT {
     const V *dinv;
     double omega_j;
     const int *tiles;
+    int planes_tiled;     // 1: planes are stored tile-blocked, [tile][k][row in tile][64] (one contiguous 9*TZ KB chunk per tile)
+    // fused multigrid stages (XMODE template parameter)
+    V *U;                 // XMODE 1: the smoothed iterate u = omega_j dinv (.) W is also written here
+    const V *E;           // XMODE 2: coarse-grid correction, [nrhs][nzc*nxc]; the input is X + P E (bilinear)
+    int nzc, nxc;
 };
 typedef StencilParamsT<cplx> StencilParams;
 
 constexpr int TX = 64;
 
-template <class V, int P, bool SCALED, bool ADJ, int EPI>
+// XMODE selects how the input tile is produced:
+//   0  X is read                                                       (everything else)
+//   1  X = omega_j * dinv (.) W, also stored to U        [multigrid: first Jacobi sweep fused into the residual]
+//   2  X = X + P E (bilinear prolongation of E)          [multigrid: coarse correction fused into the post-smoothing sweep]
+template <class V, int P, bool SCALED, bool ADJ, int EPI, int XMODE = 0>
 __global__ __launch_bounds__(256) void k_stencil_t(StencilParamsT<V> q) {
     constexpr int TZ = 4 * P;
     constexpr int LW = TX + 2;             // tile row length in elements
@@ -102,7 +111,8 @@ __global__ __launch_bounds__(256) void k_stencil_t(StencilParamsT<V> q) {
             if (SCALED && k == 4) { cf[j][k] = vone<V>(); continue; }
             V v = vzero<V>();
             if (!ADJ) {
-                if (ok) v = q.planes[(long long)k * N + (long long)row * nx + col];
+                if (q.planes_tiled) v = q.planes[((long long)t * 9 + k) * (TZ * TX) + (wave * P + j) * TX + lane];
+                else if (ok) v = q.planes[(long long)k * N + (long long)row * nx + col];
             } else {
                 // (A^H x)[i] = sum over neighbours n of conj(A[n,i]) x[n]; the entry A[n,i] sits in
                 // plane slot(-dz,-dx) at point n = i + (dz,dx)
@@ -118,21 +128,42 @@ __global__ __launch_bounds__(256) void k_stencil_t(StencilParamsT<V> q) {
     // ---- RHS loop with register prefetch + double-buffered LDS tile ----
     V pre[NLOAD];
     V prehalo = vzero<V>();
+    // value of the (virtual) input vector at grid point (grow, gcol) of right-hand side b
+    auto input_at = [&](int b, int grow, int gcol) -> V {
+        const long long idx = (long long)grow * nx + gcol;
+        if (XMODE == 1) {
+            return cmul(cscale(q.dinv[idx], q.omega_j), q.W[(long long)b * q.ld + idx]);
+        } else if (XMODE == 2) {
+            V v = q.X[(long long)b * q.ld + idx];
+            const V *e = q.E + (long long)b * q.nzc * q.nxc;
+            const int I = grow >> 1, J = gcol >> 1;
+            const bool oi = grow & 1, oj = gcol & 1;
+            const double wi0 = oi ? 0.5 : 1.0, wj0 = oj ? 0.5 : 1.0;
+            V a = cscale(e[(long long)I * q.nxc + J], wi0 * wj0);
+            if (oj && J + 1 < q.nxc) { const V c1 = e[(long long)I * q.nxc + J + 1]; a.x += wi0 * 0.5 * c1.x; a.y += wi0 * 0.5 * c1.y; }
+            if (oi && I + 1 < q.nzc) {
+                const V c2 = e[(long long)(I + 1) * q.nxc + J]; a.x += 0.5 * wj0 * c2.x; a.y += 0.5 * wj0 * c2.y;
+                if (oj && J + 1 < q.nxc) { const V c3 = e[(long long)(I + 1) * q.nxc + J + 1]; a.x += 0.25 * c3.x; a.y += 0.25 * c3.y; }
+            }
+            return cadd(v, a);
+        } else {
+            return q.X[(long long)b * q.ld + idx];
+        }
+    };
     auto prefetch = [&](int b) {
-        const V *Xb = q.X + (long long)b * q.ld;
 #pragma unroll
         for (int l = 0; l < NLOAD; ++l) {
             const int r = wave + 4 * l;                 // tile row
             const int grow = z0 - 1 + r;
             V v = vzero<V>();
-            if (r < LR && colok && grow >= 0 && grow < nz) v = Xb[(long long)grow * nx + col];
+            if (r < LR && colok && grow >= 0 && grow < nz) v = input_at(b, grow, col);
             pre[l] = v;
         }
         prehalo = vzero<V>();
         if (tid < 2 * LR) {
             const int r = tid >> 1, side = tid & 1;
             const int grow = z0 - 1 + r, gcol = side ? x0 + TX : x0 - 1;
-            if (grow >= 0 && grow < nz && gcol >= 0 && gcol < nx) prehalo = Xb[(long long)grow * nx + gcol];
+            if (grow >= 0 && grow < nz && gcol >= 0 && gcol < nx) prehalo = input_at(b, grow, gcol);
         }
     };
     auto stage = [&](int buf) {
@@ -192,6 +223,7 @@ __global__ __launch_bounds__(256) void k_stencil_t(StencilParamsT<V> q) {
                     const V w = Wb[idx];
                     y = csub(w, y);
                     dsum[0] += cabs2(y);
+                    if (XMODE == 1) q.U[(long long)b * q.ld + idx] = xc_keep[j];
                 } else if (EPI == EPI_DOT_W) {
                     const V w = Wb[idx];          // (w, y) = sum conj(w) y
                     dsum[0] += w.x * y.x + w.y * y.y;
@@ -598,12 +630,16 @@ static int launch_apply_f32(helm_op *op, const ApplyArgs &a) {
     q.nz = op->nz; q.nx = op->nx; q.nrhs = a.nrhs;
     q.ntx = (op->nx + TX - 1) / TX; q.ntz = (op->nz + 4 * STENCIL_P - 1) / (4 * STENCIL_P);
     q.nblk = a.tiles ? a.ntiles : q.ntx * q.ntz;
-    q.scal = a.scal; q.part = a.part; q.dinv = (const cplxf *)a.dinv; q.omega_j = a.omega_j; q.tiles = a.tiles;
+    q.scal = a.scal; q.part = a.part; q.dinv = (const cplxf *)a.dinv; q.omega_j = a.omega_j; q.tiles = a.tiles; q.planes_tiled = 0;
+    q.U = (cplxf *)a.U; q.E = (const cplxf *)a.E; q.nzc = a.nzc; q.nxc = a.nxc;
     if (q.nblk < 1) return HELM_OK;
     int split = 1;
     if (q.nblk < 1024) { split = (1024 + q.nblk - 1) / q.nblk; if (split > a.nrhs) split = a.nrhs; if (split < 1) split = 1; }
     dim3 grid(q.nblk, split);
-    switch (a.epi) {
+    if (a.xmode == 1 && a.epi == EPI_RESID) hipLaunchKernelGGL((k_stencil_t<cplxf, STENCIL_P, false, false, EPI_RESID, 1>), grid, dim3(256), 0, op->stream, q);
+    else if (a.xmode == 2 && a.epi == EPI_JACOBI) hipLaunchKernelGGL((k_stencil_t<cplxf, STENCIL_P, false, false, EPI_JACOBI, 2>), grid, dim3(256), 0, op->stream, q);
+    else if (a.xmode != 0) HELM_FAIL(op, HELM_ERR_ARG, "unsupported fused stencil mode");
+    else switch (a.epi) {
     case EPI_NONE: hipLaunchKernelGGL((k_stencil_t<cplxf, STENCIL_P, false, false, EPI_NONE>), grid, dim3(256), 0, op->stream, q); break;
     case EPI_RESID: hipLaunchKernelGGL((k_stencil_t<cplxf, STENCIL_P, false, false, EPI_RESID>), grid, dim3(256), 0, op->stream, q); break;
     case EPI_JACOBI: hipLaunchKernelGGL((k_stencil_t<cplxf, STENCIL_P, false, false, EPI_JACOBI>), grid, dim3(256), 0, op->stream, q); break;
@@ -620,7 +656,8 @@ int helm_launch_apply(helm_op *op, const ApplyArgs &a) {
     q.nz = op->nz; q.nx = op->nx; q.nrhs = a.nrhs;
     q.ntx = (op->nx + TX - 1) / TX; q.ntz = (op->nz + 4 * STENCIL_P - 1) / (4 * STENCIL_P);
     q.nblk = a.tiles ? a.ntiles : q.ntx * q.ntz;
-    q.scal = a.scal; q.part = a.part; q.dinv = a.dinv; q.omega_j = a.omega_j; q.tiles = a.tiles;
+    q.scal = a.scal; q.part = a.part; q.dinv = a.dinv; q.omega_j = a.omega_j; q.tiles = a.tiles; q.planes_tiled = a.planes_tiled;
+    q.U = a.U; q.E = a.E; q.nzc = a.nzc; q.nxc = a.nxc;
     if (q.nblk < 1) return HELM_OK;
     int split = 1;
     if (q.nblk < 1024) { split = (1024 + q.nblk - 1) / q.nblk; if (split > a.nrhs) split = a.nrhs; if (split < 1) split = 1; }
@@ -638,7 +675,13 @@ int helm_launch_apply(helm_op *op, const ApplyArgs &a) {
             hipEventRecord(e0, op->stream);
         } else e0 = nullptr;
     }
-    if (a.scaled) {
+    if (a.xmode == 1 && a.epi == EPI_RESID && !a.scaled && !a.adjoint) {
+        hipLaunchKernelGGL((k_stencil_t<cplx, STENCIL_P, false, false, EPI_RESID, 1>), grid, dim3(256), 0, op->stream, q);
+    } else if (a.xmode == 2 && a.epi == EPI_JACOBI && !a.scaled && !a.adjoint) {
+        hipLaunchKernelGGL((k_stencil_t<cplx, STENCIL_P, false, false, EPI_JACOBI, 2>), grid, dim3(256), 0, op->stream, q);
+    } else if (a.xmode != 0) {
+        HELM_FAIL(op, HELM_ERR_ARG, "unsupported fused stencil mode");
+    } else if (a.scaled) {
         if (a.adjoint) launch_stencil_epi<STENCIL_P, true, true>(op->stream, grid, q, a.epi);
         else launch_stencil_epi<STENCIL_P, true, false>(op->stream, grid, q, a.epi);
     } else {

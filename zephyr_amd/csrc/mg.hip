@@ -49,6 +49,7 @@ struct MgPrecond {
     int batch = 0;
     double omega_j = 0.8, beta = 0.5, cpml_m = 30.0, wstrip = 1.0;
     int nu1 = 1, nu2 = 1, sweeps = 4, min_n = 16;
+    bool fuse = true;        // fuse jac0 into the residual and the prolongation into the post-smoothing sweep
     int fdepth = 0;          // levels < fdepth revisit their coarse level a second time (truncated F-cycle); 0 = V-cycle
 };
 
@@ -468,6 +469,7 @@ int mg_setup(helm_op *op, int batch) {
     P->nu2 = env_int("HELM_MG_NU2", 1);
     P->min_n = env_int("HELM_MG_MIN_N", 16);
     P->fdepth = env_int("HELM_MG_FDEPTH", 3);
+    P->fuse = env_int("HELM_MG_FUSE", 0) != 0;   // measured: no gain (extra address math in the tile load offsets the saved pass)
     P->W = op->nPML + 2;
     if (2 * P->W + 2 > op->nx || 2 * P->W + 2 > op->nz) P->sweeps = 0;      // grid too small for a frame: plain cycle
 
@@ -525,8 +527,10 @@ namespace {
 
 template <class V>
 int stencil_level(helm_op *op, helm_op *lo, const void *planes, const V *x, V *y, const V *w, int nrhs, int epi, const RhsScal *scal,
-                  const void *dinv = nullptr, double omega_j = 0.0, const int *tiles = nullptr, int ntiles = 0) {
+                  const void *dinv = nullptr, double omega_j = 0.0, const int *tiles = nullptr, int ntiles = 0,
+                  int xmode = 0, V *uout = nullptr, const V *ecoarse = nullptr, int nzc = 0, int nxc = 0) {
     ApplyArgs a;
+    a.xmode = xmode; a.U = (cplx *)uout; a.E = (const cplx *)ecoarse; a.nzc = nzc; a.nxc = nxc;
     a.planes = (const cplx *)planes; a.X = (const cplx *)x; a.Y = (cplx *)y; a.W = (const cplx *)w; a.ld = lo->N; a.nrhs = nrhs; a.epi = epi;
     a.scal = scal; a.dinv = (const cplx *)dinv; a.omega_j = omega_j; a.profile = 0; a.part = (double *)op->d_part;
     a.tiles = tiles; a.ntiles = ntiles; a.f32 = sizeof(V) == sizeof(cplxf) ? 1 : 0;
@@ -550,15 +554,21 @@ int vcycle(helm_op *op, MgPrecond *P, int l, const V *f, V *u_out, int nrhs, con
     const int pingpongs = (P->nu1 - 1) + P->nu2;
     V *u = (pingpongs & 1) ? (V *)L.t : u_out, *alt = (pingpongs & 1) ? u_out : (V *)L.t;
     dim3 vg(vblocks(N), nrhs);
-    hipLaunchKernelGGL((k_jac0<V>), vg, dim3(256), 0, st, (const V *)L.dinv, f, u, N, P->omega_j, scal);
     int rc;
-    for (int k = 0; k < P->nu1 - 1; ++k) {
-        rc = stencil_level<V>(op, lo, L.C, u, alt, f, nrhs, EPI_JACOBI, scal, L.dinv, P->omega_j);
+    if (P->fuse && P->nu1 == 1) {
+        // first sweep from zero fused into the residual: u = w D^-1 f on the fly, r = f - M u, u stored
+        rc = stencil_level<V>(op, lo, L.C, (const V *)nullptr, (V *)L.r, f, nrhs, EPI_RESID, scal, L.dinv, P->omega_j, nullptr, 0, 1, u);
         if (rc) return rc;
-        std::swap(u, alt);
+    } else {
+        hipLaunchKernelGGL((k_jac0<V>), vg, dim3(256), 0, st, (const V *)L.dinv, f, u, N, P->omega_j, scal);
+        for (int k = 0; k < P->nu1 - 1; ++k) {
+            rc = stencil_level<V>(op, lo, L.C, u, alt, f, nrhs, EPI_JACOBI, scal, L.dinv, P->omega_j);
+            if (rc) return rc;
+            std::swap(u, alt);
+        }
+        rc = stencil_level<V>(op, lo, L.C, u, (V *)L.r, f, nrhs, EPI_RESID, scal);
+        if (rc) return rc;
     }
-    rc = stencil_level<V>(op, lo, L.C, u, (V *)L.r, f, nrhs, EPI_RESID, scal);
-    if (rc) return rc;
     MgLevel &C = P->lv[l + 1];
     dim3 cg(vblocks(C.op->N), nrhs);
     hipLaunchKernelGGL((k_restrict<V>), cg, dim3(256), 0, st, (const V *)L.r, (V *)C.f, lo->nz, lo->nx, C.op->nz, C.op->nx, scal);
@@ -572,8 +582,17 @@ int vcycle(helm_op *op, MgPrecond *P, int l, const V *f, V *u_out, int nrhs, con
         if (rc) return rc;
         hipLaunchKernelGGL((k_axpy1<V>), cg, dim3(256), 0, st, (const V *)C.f2, (V *)C.u, C.op->N, scal);
     }
-    hipLaunchKernelGGL((k_prolong_add<V>), vg, dim3(256), 0, st, (const V *)C.u, u, lo->nz, lo->nx, C.op->nz, C.op->nx, scal);
-    for (int k = 0; k < P->nu2; ++k) {
+    int k0 = 0;
+    if (P->fuse && P->nu2 >= 1) {
+        // coarse correction fused into the first post-smoothing sweep: input = u + P e
+        rc = stencil_level<V>(op, lo, L.C, u, alt, f, nrhs, EPI_JACOBI, scal, L.dinv, P->omega_j, nullptr, 0, 2, nullptr, (const V *)C.u, C.op->nz, C.op->nx);
+        if (rc) return rc;
+        std::swap(u, alt);
+        k0 = 1;
+    } else {
+        hipLaunchKernelGGL((k_prolong_add<V>), vg, dim3(256), 0, st, (const V *)C.u, u, lo->nz, lo->nx, C.op->nz, C.op->nx, scal);
+    }
+    for (int k = k0; k < P->nu2; ++k) {
         rc = stencil_level<V>(op, lo, L.C, u, alt, f, nrhs, EPI_JACOBI, scal, L.dinv, P->omega_j);
         if (rc) return rc;
         std::swap(u, alt);
