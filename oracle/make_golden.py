@@ -246,6 +246,26 @@ def g6_survey():
     np.savez_compressed(os.path.join(OUT, 'g6_survey.npz'), **out)
 
 
+def g8_25d():
+    '''MiniZephyr25D: the reference's test configurations (test_MiniZephyr.py:35-56,116-152).'''
+    nx, nz = 100, 200
+    out = {}
+    sc = dict(c=2500., rho=1., nx=nx, nz=nz, freq=2e2, nky=20, parallel=False)
+    sloc = np.array([[25., 25.]])
+    op = zb.MiniZephyr25D(sc)
+    u = (op * zb.SimpleSource(sc)(sloc))[:, 0].reshape((nz, nx))
+    out['pkys'] = np.array([complex(k).real for k in op.pkys])
+    out['premuls'] = np.array([complex(s['premul']).real for s in op.spUpdates])
+    out['line'] = u[np.arange(5, 196, 10), 60]
+    uA = zb.AnalyticalHelmholtz(dict(sc, **{'3D': True}))(sloc).reshape((nz, nx))
+    seg = (uA[40:180, 40:80] - u[40:180, 40:80]) / abs(uA[40:180, 40:80])
+    out['analytic_err'] = np.sqrt((seg.conj() * seg).sum()) / seg.size
+    sc4 = dict(sc, nky=4)
+    u4 = (zb.MiniZephyr25D(sc4) * zb.SimpleSource(sc4)(np.array([[50., 100.]])))[:, 0].reshape((nz, nx))
+    out['nky4_line'] = u4[np.arange(5, 196, 10), 60]
+    np.savez_compressed(os.path.join(OUT, 'g8_25d.npz'), **out)
+
+
 def g7_analytic():
     sc = dict(c=2500., rho=1., nx=100, nz=200, freq=2e2)
     out = {}
@@ -255,8 +275,8 @@ def g7_analytic():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7']
-    table = dict(g1=g1_minizephyr_planes, g2=g2_eurus_planes, g3=g3_wavefields, g4=g4_multifreq, g5=g5_sources, g6=g6_survey, g7=g7_analytic)
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8']
+    table = dict(g1=g1_minizephyr_planes, g2=g2_eurus_planes, g3=g3_wavefields, g4=g4_multifreq, g5=g5_sources, g6=g6_survey, g7=g7_analytic, g8=g8_25d)
     for name in which:
         table[name]()
         print('wrote', name, flush=True)

@@ -185,3 +185,39 @@ def test_full_size_properties_1024(helm_lib):
     u2 = op * q
     assert np.array_equal(u, u2)
     assert max(i['iterations'] for i in op.lastInfo) < 2000
+
+
+def test_device_resident_gradient_equals_host_gradient(helm_lib):
+    """Jtvec mux branch through helm_imaging_accumulate_device (wavefields never leave HBM) == numpy imaging."""
+    import zephyr_amd as za
+    from zephyr_amd.problem import Helm2DProblem
+    from zephyr_amd.survey import Helm2DSurvey
+    g = load('g6_survey.npz')
+    nz, nx = g['c'].shape
+    base = dict(nx=nx, nz=nz, dx=10., dz=10., c=g['c'], rho=g['rho'], nPML=6, freqs=list(g['freqs']), Disc=za.MiniZephyrHD,
+                sterms=g['sterms'], geom=dict(src=g['src'], rec=g['rec'], mode='fixed'), scaleTerm=0.7 + 0.2j)
+    out = []
+    for host in (False, True):
+        prob, surv = Helm2DProblem(dict(base, hostGradient=host)), Helm2DSurvey(base)
+        prob.pair(surv)
+        assert prob._deviceGradientAvailable() is (not host)
+        out.append(prob.Jtvec(None, g['resid']))
+    assert nrm(out[0], out[1]) <= 1e-9
+    assert nrm(out[0] / (0.7 + 0.2j) ** 2, g['g_mux']) <= 1e-6
+
+
+def test_minizephyr25d_reference_configuration(helm_lib):
+    """test_MiniZephyr.py:116-152 (nky=20 vs the analytic 3-D Green's function) and :35-56 (nky=4)."""
+    import zephyr_amd as za
+    g = load('g8_25d.npz')
+    nx, nz = 100, 200
+    sc = dict(c=2500., rho=1., nx=nx, nz=nz, freq=2e2, nky=20, parallel=False)
+    sloc = np.array([[25., 25.]])
+    u = (za.MiniZephyr25D(sc) * za.SimpleSource(sc)(sloc))[:, 0].reshape((nz, nx))
+    assert nrm(u[np.arange(5, 196, 10), 60], g['line']) <= 1e-7
+    uA = za.AnalyticalHelmholtz(dict(sc, **{'3D': True}))(sloc).reshape((nz, nx))
+    seg = (uA[40:180, 40:80] - u[40:180, 40:80]) / abs(uA[40:180, 40:80])
+    assert abs(np.sqrt((seg.conj() * seg).sum()) / seg.size) < 1e-2
+    sc4 = dict(sc, nky=4)
+    u4 = (za.MiniZephyr25D(sc4) * za.SimpleSource(sc4)(np.array([[50., 100.]])))[:, 0].reshape((nz, nx))
+    assert nrm(u4[np.arange(5, 196, 10), 60], g['nky4_line']) <= 1e-7

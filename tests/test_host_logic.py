@@ -200,3 +200,13 @@ def test_marmousi_like_is_deterministic_and_in_range():
     assert np.array_equal(a, b)
     assert a.shape == (96, 128) and a.min() >= 1500. and a.max() <= 5500.
     assert a.std() > 300.
+
+
+def test_minizephyr25d_wavenumbers_and_weights():
+    g = load('g8_25d.npz')
+    op = za.MiniZephyr25D(dict(c=2500., rho=1., nx=100, nz=200, freq=2e2, nky=20, parallel=False))
+    assert np.allclose(op.pkys, g['pkys'], rtol=1e-14, atol=0)
+    assert np.allclose([complex(u['premul']).real for u in op.spUpdates], g['premuls'], rtol=1e-14, atol=0)
+    assert len(op.subProblems) == 20 and op.subProblems[0].__class__ is za.MiniZephyr
+    assert np.isclose(op.scaleTerm, np.exp(1j * np.pi) / (4 * np.pi))
+    assert 'nky' not in op.systemConfig

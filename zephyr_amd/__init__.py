@@ -9,13 +9,13 @@ from .config import AttributeMapper, BaseSCCache, SCFilter
 from .discretization import BaseDiscretization, DiscretizationWrapper
 from .distributors import BaseDist, BaseMPDist, MultiFreq, SerialMultiFreq, ViscoMultiFreq
 from .eurus import Eurus, EurusHD
-from .minizephyr import MiniZephyr, MiniZephyrHD
+from .minizephyr import MiniZephyr, MiniZephyrHD, MiniZephyr25D
 from .source import (FakeSource, SimpleSource, StackedSimpleSource, SparseKaiserSource, KaiserSource,
                      AnisotropicKaiserSource)
 
 __all__ = [
     'AnalyticalHelmholtz', 'BaseModelDependent', 'BaseAnisotropic', 'AttributeMapper', 'BaseSCCache', 'SCFilter',
     'BaseDiscretization', 'DiscretizationWrapper', 'BaseDist', 'BaseMPDist', 'MultiFreq', 'SerialMultiFreq',
-    'ViscoMultiFreq', 'Eurus', 'EurusHD', 'MiniZephyr', 'MiniZephyrHD', 'FakeSource', 'SimpleSource',
+    'ViscoMultiFreq', 'Eurus', 'EurusHD', 'MiniZephyr', 'MiniZephyrHD', 'MiniZephyr25D', 'FakeSource', 'SimpleSource',
     'StackedSimpleSource', 'SparseKaiserSource', 'KaiserSource', 'AnisotropicKaiserSource',
 ]

@@ -79,6 +79,14 @@ def load():
     """Load libhelm.so (once).  Raises if it has not been built."""
     global _lib
     if _lib is None:
+        # PyTorch-ROCm wheels bundle their own libamdhip64.so.7; whichever copy of that soname is mapped first serves
+        # the whole process.  Load torch's first (when it is installed) so that torch tensors / RCCL and libhelm share
+        # ONE HIP runtime -- the other order leaves torch without a visible GPU.
+        if os.environ.get('HELM_NO_TORCH_PRELOAD', '0') != '1':
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         if not os.path.exists(LIB_PATH):
             raise ImportError('libhelm.so not found at %s: run `python -c "import __graft_entry__ as g; g.build()"` '
                               '(hipcc --offload-arch=gfx950).  There is no CPU fallback.' % LIB_PATH)

@@ -235,6 +235,12 @@ class BaseDiscretization(BaseModelDependent):
             raise ArithmeticError('%d of %d right-hand sides did not reach rtol=%g' % (rc, nrhs, self.rtol))
         return self.lastInfo
 
+    def imagingAccumulateDevice(self, d_uf, d_ub, nsrc, d_scaler, d_g):
+        'G += scaler * sum_s UF[s] * UB[s] on the device (zero-lag imaging condition, problem.py:152); all device pointers'
+        lib = _lib.load()
+        _lib.check(lib.helm_imaging_accumulate_device(self.handle, ctypes.c_void_p(d_uf), ctypes.c_void_p(d_ub), int(nsrc),
+                                                      ctypes.c_void_p(d_scaler), ctypes.c_void_p(d_g)), self.handle)
+
     def setProfiling(self, on=True):
         'time every stencil-apply launch of subsequent solves with HIP events on the solver stream'
         _lib.check(_lib.load().helm_set_profiling(self.handle, 1 if on else 0), self.handle)

@@ -1,7 +1,8 @@
 """MiniZephyr / MiniZephyrHD on the GPU (interface of zephyr/backend/minizephyr.py:27-343)."""
 import numpy as np
 from . import _lib
-from .discretization import BaseDiscretization
+from functools import reduce
+from .discretization import BaseDiscretization, DiscretizationWrapper
 from .sparse import planes_to_csr
 
 
@@ -50,3 +51,65 @@ class MiniZephyrHD(MiniZephyr):
     @property
     def premul(self):
         return getattr(self, '_premul', np.sqrt(2j * np.pi * self.freq))
+
+
+class MiniZephyr25D(BaseDiscretization, DiscretizationWrapper):
+    """2.5-D modelling by Fourier summation over cross-line wavenumbers: nky MiniZephyr sub-problems
+    with `ky` and quadrature weights in `premul`, summed and scaled by e^{i pi}/(4 pi)
+    (minizephyr.py:346-460).  Every sub-problem is an independent GPU operator; the reference's
+    per-ky process pool (`parallel`) is accepted and ignored."""
+
+    initMap = {
+        'Disc':           (False,    '_Disc',      None),
+        'nky':            (True,     '_nky',       np.int64),
+        'parallel':       (False,    '_parallel',  bool),
+        'cmin':           (False,    '_cmin',      np.float64),
+    }
+
+    maskKeys = ['nky', 'Disc', 'parallel']
+
+    @property
+    def Disc(self):
+        if getattr(self, '_Disc', None) is None:
+            self._Disc = MiniZephyr
+        return self._Disc
+
+    @property
+    def nky(self):
+        if getattr(self, '_nky', None) is None:
+            self._nky = 1
+        return self._nky
+
+    @property
+    def cmin(self):
+        'minimum velocity of the model (or a representative equivalent)'
+        if getattr(self, '_cmin', None) is None:
+            return np.min(self.c)
+        return self._cmin
+
+    @property
+    def pkys(self):
+        'regularly sampled cross-line wavenumbers (an inverse DFT quadrature), minizephyr.py:380-394'
+        indices = np.arange(self.nky)
+        dky = self.freq / (self.cmin * (self.nky - 1)) if self.nky > 1 else 0.
+        return indices * np.real(dky)
+
+    @property
+    def kyweights(self):
+        return 1. + (np.arange(self.nky) > 0)
+
+    @property
+    def spUpdates(self):
+        weightfac = 1. / (2 * self.nky - 1) if self.nky > 1 else 1.
+        return [{'ky': ky, 'premul': weightfac * (1. + (ky > 0))} for ky in self.pkys]
+
+    @property
+    def parallel(self):
+        return False
+
+    @property
+    def scaleTerm(self):
+        return getattr(self, '_scaleTerm', 1.) * np.exp(1j * np.pi) / (4 * np.pi)
+
+    def __mul__(self, rhs):
+        return self.scaleTerm * reduce(np.add, (sub * rhs for sub in self.subProblems))

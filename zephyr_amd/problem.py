@@ -27,6 +27,7 @@ class HelmBaseProblem(BaseModelDependent, BaseSCCache):
         #   key              required  rename       cast
         'SystemWrapper':    (True,     None,        None),
         'shardFreqs':       (False,    '_shard',    bool),
+        'hostGradient':     (False,    '_hostGradient', bool),    # force the numpy imaging condition
     }
 
     surveyPair = HelmBaseSurvey
@@ -140,6 +141,8 @@ class HelmBaseProblem(BaseModelDependent, BaseSCCache):
         qb = sv.getResidualSources(resid)
         owned = self.ownedFreqs
         g = np.zeros(self.nrow, dtype=np.complex128)
+        if u is None and self._deviceGradientAvailable():
+            return self._JtvecDevice(qb, owned)
         if u is None:
             qf = sv.getSources()
             qm = [sp.hstack((qf[i], qb[i])) if i in owned else None for i in range(sv.nfreq)]
@@ -154,6 +157,48 @@ class HelmBaseProblem(BaseModelDependent, BaseSCCache):
         if len(owned) != sv.nfreq:
             g = parallel.allreduce_sum(g)
         return g if u is None else g.real
+
+    # ---- device-resident gradient (mux branch) -------------------------------------------------------------
+    def _deviceGradientAvailable(self):
+        'true when the sub-problems are GPU operators and torch can hold the buffers in HBM'
+        if getattr(self, '_hostGradient', False):
+            return False
+        subs = self.system.subProblems
+        if not subs or not hasattr(subs[0], 'solveDevice'):
+            return False
+        try:
+            from . import _lib
+            if _lib.load().helm_device_count() <= 0:
+                return False
+            import torch
+            return torch.cuda.device_count() > 0
+        except Exception:
+            return False
+
+    def _JtvecDevice(self, qb, owned):
+        '''mux branch with wavefields kept in HBM: per owned frequency upload [qf | qb], solve 2*nsrc right-hand
+        sides on the device, accumulate scaler * sum_s uF (.) uB with the imaging kernel; ONE all-reduce of G.'''
+        import torch
+        sv = self.survey
+        nsrc, N = sv.nsrc, self.nrow
+        subs = self.system.subProblems
+        scale = complex(self.system.scaleTerm)
+        dev = torch.device('cuda', subs[owned[0]].device if owned else torch.cuda.current_device())
+        G = torch.zeros(N, dtype=torch.complex128, device=dev)
+        qf = sv.getSources()
+        U = torch.empty((2 * nsrc, N), dtype=torch.complex128, device=dev)
+        for ifreq in owned:
+            sub = subs[ifreq]
+            qm = sp.hstack((qf[ifreq], qb[ifreq])).toarray()
+            R = torch.from_numpy(np.ascontiguousarray(qm.T)).to(dev)
+            scaler = torch.from_numpy(np.ascontiguousarray(self.gradientScaler(ifreq) * scale * scale)).to(dev)
+            torch.cuda.synchronize(dev)
+            sub.solveDevice(R.data_ptr(), U.data_ptr(), 2 * nsrc, N)
+            sub.imagingAccumulateDevice(U.data_ptr(), U.data_ptr() + nsrc * N * 16, nsrc, scaler.data_ptr(), G.data_ptr())
+        if len(owned) != sv.nfreq:
+            parallel.allreduce_sum_device(G)
+        torch.cuda.synchronize(dev)
+        return G.cpu().numpy()
 
     @property
     def factors(self):
