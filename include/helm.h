@@ -44,7 +44,7 @@ extern "C" {
 typedef struct helm_op helm_op;
 
 /* discretisation variants */
-enum { HELM_MINIZEPHYR = 0, HELM_EURUS = 1 };
+enum { HELM_MINIZEPHYR = 0, HELM_EURUS = 1, HELM_3D = 2 /* 27-point 3-D operator, created with helm_create3d */ };
 
 /* Krylov methods */
 enum {
@@ -91,6 +91,13 @@ const char *helm_version(void);
  * Returns NULL on failure; helm_last_error(NULL) holds the reason. */
 helm_op *helm_create(int device, int variant, int nz, int nx, double dx, double dz,
                      int nPML, const int *freeSurf);
+/* 3-D 27-point operator on an (nz, ny, nx) grid, linear index (iz*ny + iy)*nx + ix; 27 planes,
+ * k = 9*(oz+1) + 3*(oy+1) + (ox+1).  No reference counterpart (the reference has no 3-D discretisation:
+ * zephyr/backend/base.py:20,36-40, source.py:43-44); definition in oracle/helm3d_oracle.py.  All other entry
+ * points (set_model with theta/eps/delta NULL, assemble with ky ignored and cPML the layer amplitude,
+ * get_diagonals, apply, solve with rows = N) work on the returned handle; solves use the Jacobi-preconditioned
+ * BiCGSTAB / CGNR (HELM_MG is 2-D only). */
+helm_op *helm_create3d(int device, int nz, int ny, int nx, double dx, double dy, double dz, int nPML);
 void helm_destroy(helm_op *op);
 const char *helm_last_error(const helm_op *op);
 

@@ -1,0 +1,62 @@
+"""GPU: the 3-D 27-point operator (BASELINE config 5; no reference counterpart -> parity against this project's
+own CPU statement oracle/helm3d_oracle.py, sparse LU at a small size, and the analytic 3-D Green's function)."""
+import numpy as np
+import pytest
+
+from oracle import helm3d_oracle as h3
+
+pytestmark = pytest.mark.gpu
+
+
+def nrm(a, b):
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+def test_3d_coefficients_and_apply_match_oracle(helm_lib):
+    import zephyr_amd as za
+    nz, ny, nx = 20, 26, 70                  # x not a multiple of the 64-wide tile, y not a multiple of 4
+    rng = np.random.default_rng(5)
+    c = (1800. + 1500. * rng.random((nz, ny, nx))) * (1 + 0.01j)
+    rho = 1000. + 500. * rng.random((nz, ny, nx))
+    cfg = dict(nx=nx, ny=ny, nz=nz, dx=9., dy=11., dz=10., c=c, rho=rho, freq=11., tau=0.5, nPML=6, cPML=250.)
+    op = za.Helm3D(cfg)
+    C = h3.helm3d_coefficients(nz, ny, nx, c, rho, 11., dx=9., dy=11., dz=10., tau=0.5, nPML=6, cPML=250.)
+    got = op.diagonals()
+    scale = np.abs(C).max()
+    assert np.abs(got - C).max() <= 1e-12 * scale
+    X = rng.standard_normal((nz * ny * nx, 3)) + 1j * rng.standard_normal((nz * ny * nx, 3))
+    ref = h3.stencil_apply3(C, X)
+    assert np.abs(op.applyForward(X) - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def test_3d_solve_matches_sparse_lu(helm_lib):
+    import zephyr_amd as za
+    n = 22
+    rng = np.random.default_rng(6)
+    c = 2000. + 600. * rng.random((n, n, n))
+    cfg = dict(nx=n, ny=n, nz=n, dx=10., c=c, rho=1., freq=14., nPML=5, cPML=200., rtol=1e-10, maxit=50000)
+    q = np.zeros((n ** 3, 2), complex)
+    q[(11 * n + 11) * n + 11, 0] = 1.
+    q[(8 * n + 13) * n + 9, 1] = 1j
+    op = za.Helm3D(cfg)
+    u = op * q
+    C = h3.helm3d_coefficients(n, n, n, c, 1., 14., dx=10., nPML=5, cPML=200.)
+    ref = h3.DirectOperator3(C) * q
+    assert nrm(u, ref) <= 1e-7, op.lastInfo
+    assert all(i['relres'] <= 1e-10 for i in op.lastInfo)
+
+
+def test_3d_analytic_green_function(helm_lib):
+    """homogeneous c = 2000 m/s, interior window: |u - G| / |G| < 5e-2 with G = -rho h^3 e^{ikr} / (4 pi r)"""
+    import zephyr_amd as za
+    n, dx, f, c0 = 64, 10., 12., 2000.
+    cfg = dict(nx=n, ny=n, nz=n, dx=dx, c=c0, rho=1., freq=f, nPML=10, rtol=1e-8, maxit=100000)
+    q = np.zeros(n ** 3, complex)
+    s = n // 2
+    q[(s * n + s) * n + s] = 1.
+    u = (za.Helm3D(cfg) * q).reshape((n, n, n))
+    iz, iy, ix = np.mgrid[0:n, 0:n, 0:n]
+    r = dx * np.sqrt((iz - s) ** 2 + (iy - s) ** 2 + (ix - s) ** 2)
+    m = (r > 3 * dx) & (iz > 12) & (iz < n - 13) & (iy > 12) & (iy < n - 13) & (ix > 12) & (ix < n - 13)
+    g = h3.green3d(2 * np.pi * f / c0, r[m], 1.0, dx ** 3)
+    assert np.linalg.norm(u[m] - g) / np.linalg.norm(g) < 5e-2

@@ -9,6 +9,7 @@ from .config import AttributeMapper, BaseSCCache, SCFilter
 from .discretization import BaseDiscretization, DiscretizationWrapper
 from .distributors import BaseDist, BaseMPDist, MultiFreq, SerialMultiFreq, ViscoMultiFreq
 from .eurus import Eurus, EurusHD
+from .helm3d import Helm3D
 from .minizephyr import MiniZephyr, MiniZephyrHD, MiniZephyr25D
 from .source import (FakeSource, SimpleSource, StackedSimpleSource, SparseKaiserSource, KaiserSource,
                      AnisotropicKaiserSource)
@@ -16,6 +17,6 @@ from .source import (FakeSource, SimpleSource, StackedSimpleSource, SparseKaiser
 __all__ = [
     'AnalyticalHelmholtz', 'BaseModelDependent', 'BaseAnisotropic', 'AttributeMapper', 'BaseSCCache', 'SCFilter',
     'BaseDiscretization', 'DiscretizationWrapper', 'BaseDist', 'BaseMPDist', 'MultiFreq', 'SerialMultiFreq',
-    'ViscoMultiFreq', 'Eurus', 'EurusHD', 'MiniZephyr', 'MiniZephyrHD', 'MiniZephyr25D', 'FakeSource', 'SimpleSource',
+    'ViscoMultiFreq', 'Eurus', 'EurusHD', 'Helm3D', 'MiniZephyr', 'MiniZephyrHD', 'MiniZephyr25D', 'FakeSource', 'SimpleSource',
     'StackedSimpleSource', 'SparseKaiserSource', 'KaiserSource', 'AnisotropicKaiserSource',
 ]

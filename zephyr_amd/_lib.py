@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libhelm.so')
 
-HELM_MINIZEPHYR, HELM_EURUS = 0, 1
+HELM_MINIZEPHYR, HELM_EURUS, HELM_3D = 0, 1, 2
 HELM_BICGSTAB, HELM_CGNR, HELM_AUTO, HELM_MG = 0, 1, 2, 3
 METHODS = {'bicgstab': HELM_BICGSTAB, 'cgnr': HELM_CGNR, 'auto': HELM_AUTO, 'mg': HELM_MG}
 
@@ -46,6 +46,8 @@ _SIGNATURES = {
     'helm_version': (ctypes.c_char_p, []),
     'helm_create': (ctypes.c_void_p, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                       ctypes.c_double, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
+    'helm_create3d': (ctypes.c_void_p, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                        ctypes.c_double, ctypes.c_double, ctypes.c_int]),
     'helm_destroy': (None, [ctypes.c_void_p]),
     'helm_last_error': (ctypes.c_char_p, [ctypes.c_void_p]),
     'helm_set_stream': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),

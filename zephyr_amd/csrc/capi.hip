@@ -33,6 +33,18 @@ extern "C" int helm_device_count(void) {
 #define HIP_TRY_NULL(call) do { hipError_t _e = (call); if (_e != hipSuccess) { char _b[256]; \
     snprintf(_b, sizeof(_b), "%s failed: %s", #call, hipGetErrorString(_e)); helm_set_error(nullptr, _b); delete op; return nullptr; } } while (0)
 
+static helm_op *create_common(helm_op *op);
+
+extern "C" helm_op *helm_create3d(int device, int nz, int ny, int nx, double dx, double dy, double dz, int nPML) {
+    if (nz < 3 || ny < 3 || nx < 3) { helm_set_error(nullptr, "nz, ny and nx must be >= 3"); return nullptr; }
+    if (!(dx > 0) || !(dy > 0) || !(dz > 0)) { helm_set_error(nullptr, "grid spacings must be positive"); return nullptr; }
+    helm_op *op = new helm_op();
+    op->device = device; op->variant = HELM_3D; op->nz = nz; op->ny = ny; op->nx = nx; op->N = (long long)nz * ny * nx;
+    op->dx = dx; op->dy = dy; op->dz = dz; op->nPML = nPML;
+    op->nblocks = 1; op->nplanes = 27; op->centre = 13;
+    return create_common(op);
+}
+
 extern "C" helm_op *helm_create(int device, int variant, int nz, int nx, double dx, double dz, int nPML, const int *freeSurf) {
     if (nz < 3 || nx < 3) { helm_set_error(nullptr, "nz and nx must be >= 3"); return nullptr; }
     if (variant != HELM_MINIZEPHYR && variant != HELM_EURUS) { helm_set_error(nullptr, "unknown variant"); return nullptr; }
@@ -43,14 +55,19 @@ extern "C" helm_op *helm_create(int device, int variant, int nz, int nx, double 
     if (freeSurf) for (int i = 0; i < 4; ++i) op->fs[i] = freeSurf[i] ? 1 : 0;
     op->nblocks = variant == HELM_EURUS ? 4 : 1;
     if (nPML < 0) { op->block0_only = true; op->nPML = -nPML; op->nblocks = 1; }   // internal: preconditioner level
+    return create_common(op);
+}
+
+static helm_op *create_common(helm_op *op) {
+    const int device = op->device;
     HIP_TRY_NULL(hipSetDevice(device));
     HIP_TRY_NULL(hipStreamCreateWithFlags(&op->stream, hipStreamNonBlocking));
     op->own_stream = true;
     const size_t N = (size_t)op->N;
     HIP_TRY_NULL(hipMalloc(&op->d_c, N * sizeof(cplx)));
     HIP_TRY_NULL(hipMalloc(&op->d_rho, N * sizeof(double)));
-    HIP_TRY_NULL(hipMalloc(&op->d_C, (size_t)op->nblocks * 9 * N * sizeof(cplx)));
-    HIP_TRY_NULL(hipMalloc(&op->d_Cs, (size_t)op->nblocks * 9 * N * sizeof(cplx)));
+    HIP_TRY_NULL(hipMalloc(&op->d_C, (size_t)op->nblocks * op->nplanes * N * sizeof(cplx)));
+    HIP_TRY_NULL(hipMalloc(&op->d_Cs, (size_t)op->nblocks * op->nplanes * N * sizeof(cplx)));
     HIP_TRY_NULL(hipMalloc(&op->d_dinv, (size_t)op->nblocks * N * sizeof(cplx)));
     return op;
 }
@@ -132,7 +149,7 @@ extern "C" int helm_assemble(helm_op *op, double freq_re, double freq_im, double
     if (!op) return HELM_ERR_ARG;
     if (!op->has_model) HELM_FAIL(op, HELM_ERR_STATE, "helm_set_model must be called before helm_assemble");
     HIP_TRY(op, hipSetDevice(op->device));
-    int rc = helm_launch_assemble(op, freq_re, freq_im, tau, ky, cPML);
+    int rc = op->ny > 0 ? helm3d_launch_assemble(op, freq_re, freq_im, tau, cPML) : helm_launch_assemble(op, freq_re, freq_im, tau, ky, cPML);
     if (rc) return rc;
     rc = helm_launch_scale_planes(op);
     if (rc) return rc;
@@ -147,7 +164,7 @@ extern "C" int helm_get_diagonals(helm_op *op, double *out) {
     if (!op || !out) return HELM_ERR_ARG;
     if (!op->assembled) HELM_FAIL(op, HELM_ERR_STATE, "operator not assembled");
     HIP_TRY(op, hipSetDevice(op->device));
-    HIP_TRY(op, hipMemcpy(out, op->d_C, (size_t)op->nblocks * 9 * op->N * sizeof(cplx), hipMemcpyDeviceToHost));
+    HIP_TRY(op, hipMemcpy(out, op->d_C, (size_t)op->nblocks * op->nplanes * op->N * sizeof(cplx), hipMemcpyDeviceToHost));
     return HELM_OK;
 }
 
@@ -201,7 +218,7 @@ extern "C" int helm_apply_device(helm_op *op, int block, int adjoint, const void
     HIP_TRY(op, hipSetDevice(op->device));
     timing_begin(op);
     ApplyArgs a = ApplyArgs();
-    a.planes = op->d_C + (long long)block * 9 * op->N; a.X = (const cplx *)dX; a.Y = (cplx *)dY; a.W = nullptr;
+    a.planes = op->d_C + (long long)block * op->nplanes * op->N; a.X = (const cplx *)dX; a.Y = (cplx *)dY; a.W = nullptr;
     a.ld = op->N; a.nrhs = nrhs; a.scaled = 0; a.adjoint = adjoint ? 1 : 0; a.epi = EPI_NONE; a.scal = nullptr; a.part = nullptr;
     int rc = helm_launch_apply(op, a);
     if (rc) return rc;
@@ -252,7 +269,7 @@ int upload_scal(helm_op *op, int nrhs) {
 
 ApplyArgs scaled_apply(helm_op *op, int block, const cplx *X, cplx *Y, const cplx *W, int nrhs, int adjoint, int epi, bool masked) {
     ApplyArgs a = ApplyArgs();
-    a.planes = op->d_Cs + (long long)block * 9 * op->N; a.X = X; a.Y = Y; a.W = W; a.ld = op->N; a.nrhs = nrhs;
+    a.planes = op->d_Cs + (long long)block * op->nplanes * op->N; a.X = X; a.Y = Y; a.W = W; a.ld = op->N; a.nrhs = nrhs;
     a.scaled = 1; a.adjoint = adjoint; a.epi = epi; a.scal = masked ? op->d_scal : nullptr; a.part = (double *)op->d_part;
     return a;
 }
@@ -406,7 +423,8 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
     if (rc) return rc;
     // preconditioner choice: multigrid for the main block when asked for (or AUTO on Eurus, where it is validated)
     bool use_mg = false;
-    if (block == 0 && (o.method == HELM_MG || (o.method == HELM_AUTO && std::min(op->nz, op->nx) >= 32))) {
+    if (op->ny > 0 && o.method == HELM_MG) HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "the multigrid preconditioner is 2-D only");
+    if (op->ny == 0 && block == 0 && (o.method == HELM_MG || (o.method == HELM_AUTO && std::min(op->nz, op->nx) >= 32))) {
         rc = mg_setup(op, Bmax);
         if (rc == HELM_OK) use_mg = true;
         else if (o.method == HELM_MG) return rc;
@@ -425,7 +443,7 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
         B.phat = base + 9 * vs; B.shat = base + 10 * vs;
         B.pre = use_mg;
         B.bbar = use_mg ? qprime : B.bscaled;
-        B.planes = use_mg ? op->d_C + (long long)block * 9 * N : op->d_Cs + (long long)block * 9 * N;
+        B.planes = use_mg ? op->d_C + (long long)block * op->nplanes * N : op->d_Cs + (long long)block * op->nplanes * N;
         const int nblk = std::max(helm_apply_num_blocks(op), helm_vec_num_blocks(op));
         char *ptail = (char *)op->d_part + (size_t)Bmax * 4 * nblk * sizeof(double);
         B.d_aux = (double *)ptail; B.d_mask = (int *)(ptail + (size_t)Bmax * 2 * sizeof(double));
@@ -479,7 +497,7 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
             }
             // true residual of the UNSCALED system: s = q' - A x
             ApplyArgs a = ApplyArgs();
-            a.planes = op->d_C + (long long)block * 9 * N; a.X = B.w.x; a.Y = B.w.s; a.W = qprime; a.ld = N; a.nrhs = n;
+            a.planes = op->d_C + (long long)block * op->nplanes * N; a.X = B.w.x; a.Y = B.w.s; a.W = qprime; a.ld = N; a.nrhs = n;
             a.scaled = 0; a.adjoint = 0; a.epi = EPI_RESID; a.scal = nullptr; a.part = (double *)op->d_part;
             rc = helm_launch_apply(op, a);
             if (rc) return rc;

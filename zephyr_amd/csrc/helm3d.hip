@@ -1,0 +1,279 @@
+// 3-D 27-point Helmholtz operator (BASELINE config 5).  The reference has no 3-D discretisation
+// (zephyr/backend/base.py:20,36-40 only reserves `ny`; source.py:43-44 raises NotImplementedError), so the
+// operator is defined by this project -- see oracle/helm3d_oracle.py for the formula and its analytic check.
+//
+//   C_o = bbar_o (Lx(ox) m(oy) m(oz)/dx^2 + m(ox) Ly(oy) m(oz)/dy^2 + m(ox) m(oy) Lz(oz)/dz^2)
+//         + K_{p+o} (a [o==0] + (1-a) m(ox) m(oy) m(oz)),   slot k = 9 (oz+1) + 3 (oy+1) + (ox+1)
+//
+// Kernels: k_assemble_3d (model -> 27 planes) and k_stencil3 (batched apply: one 64 x 4 tile of one z-plane per
+// workgroup, the three z-planes of the input staged in LDS with halo, the thread's 27 coefficients held in
+// registers over the right-hand-side loop, same fused epilogues as the 2-D kernel).  Everything else (Krylov
+// vector kernels, finalize kernels, drivers) is shared with the 2-D path.
+#include "helm_internal.hpp"
+#include <complex>
+
+namespace {
+
+__device__ inline int clampi3(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+struct Asm3Params {
+    int nz, ny, nx;
+    double dx, dy, dz;
+    cplx om;
+    double blend;
+};
+
+// Lt: [axis][3][n] laid out as Lx(-1)[nx], Lx(0)[nx], Lx(+1)[nx], Ly..., Lz...
+__global__ __launch_bounds__(256) void k_assemble_3d(Asm3Params P, const cplx *__restrict__ c, const double *__restrict__ rho,
+                                                     const cplx *__restrict__ Lx, const cplx *__restrict__ Ly, const cplx *__restrict__ Lz,
+                                                     cplx *__restrict__ C) {
+    const long long N = (long long)P.nz * P.ny * P.nx;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int ix = (int)(i % P.nx), iy = (int)((i / P.nx) % P.ny), iz = (int)(i / ((long long)P.nx * P.ny));
+    const bool edge = ix == 0 || ix == P.nx - 1 || iy == 0 || iy == P.ny - 1 || iz == 0 || iz == P.nz - 1;
+    const double b0 = 1.0 / rho[i];
+    const cplx om2 = cmul(P.om, P.om);
+    const double idx2 = 1.0 / (P.dx * P.dx), idy2 = 1.0 / (P.dy * P.dy), idz2 = 1.0 / (P.dz * P.dz);
+#pragma unroll 1
+    for (int oz = -1; oz <= 1; ++oz)
+#pragma unroll 1
+        for (int oy = -1; oy <= 1; ++oy)
+#pragma unroll
+            for (int ox = -1; ox <= 1; ++ox) {
+                const int k = 9 * (oz + 1) + 3 * (oy + 1) + (ox + 1);
+                cplx out;
+                if (edge) out = (k == 13) ? cmake(1.0, 0.0) : cmake(0.0, 0.0);
+                else {
+                    const int jz = clampi3(iz + oz, 0, P.nz - 1), jy = clampi3(iy + oy, 0, P.ny - 1), jx = clampi3(ix + ox, 0, P.nx - 1);
+                    const long long j = ((long long)jz * P.ny + jy) * P.nx + jx;
+                    const double rj = rho[j];
+                    const cplx cj = c[j];
+                    const double bbar = (b0 + 1.0 / rj) / 2.0;
+                    const cplx Knb = cdiv(om2, cscale(cmul(cj, cj), rj));
+                    const double mx = ox == 0 ? 2.0 / 3.0 : 1.0 / 6.0, my = oy == 0 ? 2.0 / 3.0 : 1.0 / 6.0, mz = oz == 0 ? 2.0 / 3.0 : 1.0 / 6.0;
+                    const cplx lx = cscale(Lx[(long long)(ox + 1) * P.nx + ix], my * mz * idx2);
+                    const cplx ly = cscale(Ly[(long long)(oy + 1) * P.ny + iy], mx * mz * idy2);
+                    const cplx lz = cscale(Lz[(long long)(oz + 1) * P.nz + iz], mx * my * idz2);
+                    const double mass = ((k == 13) ? P.blend : 0.0) + (1.0 - P.blend) * mx * my * mz;
+                    out = cadd(cscale(cadd(cadd(lx, ly), lz), bbar), cscale(Knb, mass));
+                }
+                C[(long long)k * N + i] = out;
+            }
+}
+
+// ---- batched 27-point apply -----------------------------------------------------------------------
+struct Stencil3Params {
+    const cplx *planes;      // 27 planes, stride N
+    const cplx *X;
+    cplx *Y;
+    const cplx *W;
+    long long ld, N;
+    int nz, ny, nx, nrhs, ntx, nty, nblk;
+    const RhsScal *scal;
+    double *part;
+};
+
+__device__ inline double wave_sum3(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__device__ inline int xcd_swizzle3(int bid, int nblk) {
+    const int q = nblk / HELM_NXCD, rem = nblk % HELM_NXCD;
+    const int x = bid % HELM_NXCD, k = bid / HELM_NXCD;
+    return x * q + (x < rem ? x : rem) + k;
+}
+
+constexpr int T3X = 64, T3Y = 4;
+
+template <bool SCALED, int EPI>
+__global__ __launch_bounds__(256) void k_stencil3(Stencil3Params q) {
+    constexpr int LW = T3X + 2, LH = T3Y + 2;          // one staged plane: LH rows of LW
+    constexpr int PLANE = LW * LH;                      // 396 elements
+    constexpr int NEL = 3 * PLANE;                      // three z-planes
+    constexpr int NLOAD = (NEL + 255) / 256;            // elements staged per thread
+    __shared__ __attribute__((aligned(16))) cplx tile[2][NEL];
+    __shared__ double red[16];
+
+    const int tid = threadIdx.x, lane = tid & 63, wy = tid >> 6;
+    const int t = xcd_swizzle3(blockIdx.x, q.nblk);
+    const int tx = t % q.ntx, ty = (t / q.ntx) % q.nty, iz = t / (q.ntx * q.nty);
+    const int x0 = tx * T3X, y0 = ty * T3Y;
+    const int nz = q.nz, ny = q.ny, nx = q.nx;
+    const long long N = q.N;
+    const int col = x0 + lane, row = y0 + wy;
+    const bool ok = col < nx && row < ny;
+    const long long idx = ((long long)iz * ny + row) * nx + col;
+
+    cplx cf[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        if (SCALED && k == 13) cf[k] = cmake(1.0, 0.0);
+        else cf[k] = ok ? q.planes[(long long)k * N + idx] : cmake(0.0, 0.0);
+    }
+
+    // staging map: element e of the 3-plane tile -> (plane p, tile row r, tile column cc)
+    cplx pre[NLOAD];
+    auto prefetch = [&](int b) {
+        const cplx *Xb = q.X + (long long)b * q.ld;
+#pragma unroll
+        for (int l = 0; l < NLOAD; ++l) {
+            const int e = tid + 256 * l;
+            cplx v = cmake(0.0, 0.0);
+            if (e < NEL) {
+                const int p = e / PLANE, rem = e - p * PLANE, r = rem / LW, cc = rem - r * LW;
+                const int gz = iz - 1 + p, gy = y0 - 1 + r, gx = x0 - 1 + cc;
+                if (gz >= 0 && gz < nz && gy >= 0 && gy < ny && gx >= 0 && gx < nx) v = Xb[((long long)gz * ny + gy) * nx + gx];
+            }
+            pre[l] = v;
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int l = 0; l < NLOAD; ++l) {
+            const int e = tid + 256 * l;
+            if (e < NEL) tile[buf][e] = pre[l];
+        }
+    };
+
+    const int bstep = gridDim.y;
+    int b = blockIdx.y;
+    auto active = [&](int bb) { return q.scal == nullptr || q.scal[bb].status == ST_ACTIVE; };
+    while (b < q.nrhs && !active(b)) b += bstep;
+    if (b < q.nrhs) prefetch(b);
+    int buf = 0;
+    while (b < q.nrhs) {
+        stage(buf);
+        int bn = b + bstep;
+        while (bn < q.nrhs && !active(bn)) bn += bstep;
+        if (bn < q.nrhs) prefetch(bn);
+        __syncthreads();
+
+        cplx acc = cmake(0.0, 0.0), xc = cmake(0.0, 0.0);
+        const cplx *tb = &tile[buf][wy * LW + lane];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    const int k = 9 * p + 3 * r + cc;
+                    const cplx xv = tb[p * PLANE + r * LW + cc];
+                    if (SCALED && k == 13) { acc.x += xv.x; acc.y += xv.y; }
+                    else cfma(acc, cf[k], xv);
+                    if (k == 13) xc = xv;
+                }
+        double dsum[4] = {0.0, 0.0, 0.0, 0.0};
+        if (ok) {
+            cplx y = acc;
+            const long long g = (long long)b * q.ld + idx;
+            if (EPI == EPI_RESID) { const cplx w = q.W[g]; y = csub(w, y); dsum[0] += cabs2(y); }
+            else if (EPI == EPI_DOT_W) { const cplx w = q.W[g]; dsum[0] += w.x * y.x + w.y * y.y; dsum[1] += w.x * y.y - w.y * y.x; }
+            else if (EPI == EPI_DOT_XY) { dsum[0] += y.x * xc.x + y.y * xc.y; dsum[1] += y.x * xc.y - y.y * xc.x; dsum[2] += cabs2(y); }
+            else if (EPI == EPI_DOT_YY) { dsum[0] += cabs2(y); }
+            q.Y[g] = y;
+        }
+        if (EPI != EPI_NONE) {
+            const int wave = tid >> 6;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) dsum[qq] = wave_sum3(dsum[qq]);
+            if (lane == 0) { red[wave * 4 + 0] = dsum[0]; red[wave * 4 + 1] = dsum[1]; red[wave * 4 + 2] = dsum[2]; red[wave * 4 + 3] = dsum[3]; }
+            __syncthreads();
+            if (tid == 0) {
+                double *pp = q.part + ((long long)b * 4) * q.nblk + blockIdx.x;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) pp[(long long)qq * q.nblk] = (red[qq] + red[4 + qq]) + (red[8 + qq] + red[12 + qq]);
+            }
+            __syncthreads();
+        }
+        buf ^= 1;
+        b = bn;
+    }
+}
+
+void profile3(int n, int npml, double h, double cpml, std::complex<double> om, std::vector<cplx> &Lt) {
+    // padded stretch profile xi and the three Laplacian factor arrays L(-1), L(0), L(+1)
+    std::vector<double> g(n, 0.0);
+    const double L = h * (npml - 1);
+    for (int k = 0; k < npml && k < n; ++k) g[k] = cpml * cos((M_PI / 2) * (k * h / L));
+    for (int k = 0; k < npml && k < n; ++k) g[n - npml + k] = cpml * cos((M_PI / 2) * ((npml - 1 - k) * h / L));
+    std::vector<std::complex<double>> xi(n + 2);
+    for (int p = 0; p < n + 2; ++p) {
+        const int k = p == 0 ? 0 : (p == n + 1 ? n - 1 : p - 1);
+        xi[p] = 1.0 - std::complex<double>(0.0, g[k]) / om;
+    }
+    Lt.resize((size_t)3 * n);
+    for (int i = 0; i < n; ++i) {
+        const std::complex<double> c = xi[i + 1];
+        const std::complex<double> lm = 1.0 / (c * (c + xi[i]) / 2.0), lp = 1.0 / (c * (c + xi[i + 2]) / 2.0);
+        const std::complex<double> l0 = -(lm + lp);
+        Lt[i] = cmake(lm.real(), lm.imag());
+        Lt[(size_t)n + i] = cmake(l0.real(), l0.imag());
+        Lt[(size_t)2 * n + i] = cmake(lp.real(), lp.imag());
+    }
+}
+
+}  // namespace
+
+int helm3d_launch_assemble(helm_op *op, double freq_re, double freq_im, double tau, double cPML) {
+    if (op->nPML < 2 || op->nPML > op->nx || op->nPML > op->ny || op->nPML > op->nz) HELM_FAIL(op, HELM_ERR_ARG, "nPML out of range for the grid");
+    std::complex<double> om(2.0 * M_PI * freq_re, 2.0 * M_PI * freq_im);
+    if (std::isfinite(tau) && tau != 0.0) om -= std::complex<double>(0.0, 1.0 / tau);
+    std::vector<cplx> Lx, Ly, Lz;
+    profile3(op->nx, op->nPML, op->dx, cPML, om, Lx);
+    profile3(op->ny, op->nPML, op->dy, cPML, om, Ly);
+    profile3(op->nz, op->nPML, op->dz, cPML, om, Lz);
+    std::vector<cplx> all(Lx);
+    all.insert(all.end(), Ly.begin(), Ly.end());
+    all.insert(all.end(), Lz.begin(), Lz.end());
+    cplx *d_L = nullptr;
+    HIP_TRY(op, hipMalloc(&d_L, all.size() * sizeof(cplx)));
+    HIP_TRY(op, hipMemcpyAsync(d_L, all.data(), all.size() * sizeof(cplx), hipMemcpyHostToDevice, op->stream));
+    Asm3Params P;
+    P.nz = op->nz; P.ny = op->ny; P.nx = op->nx; P.dx = op->dx; P.dy = op->dy; P.dz = op->dz;
+    P.om = cmake(om.real(), om.imag()); P.blend = 0.5;
+    const int blocks = (int)((op->N + 255) / 256);
+    hipLaunchKernelGGL(k_assemble_3d, dim3(blocks), dim3(256), 0, op->stream, P, (const cplx *)op->d_c, (const double *)op->d_rho,
+                       (const cplx *)d_L, (const cplx *)(d_L + 3 * (size_t)op->nx), (const cplx *)(d_L + 3 * (size_t)op->nx + 3 * (size_t)op->ny), op->d_C);
+    HIP_TRY(op, hipGetLastError());
+    HIP_TRY(op, hipStreamSynchronize(op->stream));
+    HIP_TRY(op, hipFree(d_L));
+    return HELM_OK;
+}
+
+int helm3d_apply_num_blocks(const helm_op *op) {
+    return ((op->nx + T3X - 1) / T3X) * ((op->ny + T3Y - 1) / T3Y) * op->nz;
+}
+
+template <bool SCALED>
+static void launch3_epi(hipStream_t st, dim3 grid, const Stencil3Params &q, int epi) {
+    switch (epi) {
+    case EPI_NONE: hipLaunchKernelGGL((k_stencil3<SCALED, EPI_NONE>), grid, dim3(256), 0, st, q); break;
+    case EPI_DOT_W: hipLaunchKernelGGL((k_stencil3<SCALED, EPI_DOT_W>), grid, dim3(256), 0, st, q); break;
+    case EPI_DOT_XY: hipLaunchKernelGGL((k_stencil3<SCALED, EPI_DOT_XY>), grid, dim3(256), 0, st, q); break;
+    case EPI_DOT_YY: hipLaunchKernelGGL((k_stencil3<SCALED, EPI_DOT_YY>), grid, dim3(256), 0, st, q); break;
+    case EPI_RESID: hipLaunchKernelGGL((k_stencil3<SCALED, EPI_RESID>), grid, dim3(256), 0, st, q); break;
+    default: break;
+    }
+}
+
+int helm3d_launch_apply(helm_op *op, const ApplyArgs &a, hipEvent_t e0, hipEvent_t e1) {
+    if (a.adjoint) HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "adjoint apply is not available for the 3-D operator");
+    if (a.epi == EPI_JACOBI || a.epi == EPI_DOT_WY) HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "epilogue not available for the 3-D operator");
+    Stencil3Params q;
+    q.planes = a.planes; q.X = a.X; q.Y = a.Y; q.W = a.W; q.ld = a.ld; q.N = op->N;
+    q.nz = op->nz; q.ny = op->ny; q.nx = op->nx; q.nrhs = a.nrhs;
+    q.ntx = (op->nx + T3X - 1) / T3X; q.nty = (op->ny + T3Y - 1) / T3Y; q.nblk = q.ntx * q.nty * op->nz;
+    q.scal = a.scal; q.part = a.part;
+    int split = 1;
+    if (q.nblk < 2048) { split = (2048 + q.nblk - 1) / q.nblk; if (split > a.nrhs) split = a.nrhs; if (split < 1) split = 1; }
+    dim3 grid(q.nblk, split);
+    if (e0) hipEventRecord(e0, op->stream);
+    if (a.scaled) launch3_epi<true>(op->stream, grid, q, a.epi);
+    else launch3_epi<false>(op->stream, grid, q, a.epi);
+    if (e1) hipEventRecord(e1, op->stream);
+    HIP_TRY(op, hipGetLastError());
+    return HELM_OK;
+}

@@ -90,8 +90,10 @@ enum { ST_ACTIVE = 0, ST_CONVERGED = 1, ST_BREAKDOWN = 2, ST_FROZEN = 3, ST_PARK
 // ---- the handle ---------------------------------------------------------------------------
 struct helm_op {
     int device = 0, variant = 0, nz = 0, nx = 0, nPML = 10;
+    int ny = 0;                  // > 0: 3-D operator on an (nz, ny, nx) grid (27 planes), 0: 2-D (9 planes)
+    int nplanes = 9, centre = 4; // planes per block and index of the diagonal plane
     long long N = 0;
-    double dx = 1, dz = 1;
+    double dx = 1, dz = 1, dy = 1;
     int fs[4] = {0, 0, 0, 0};
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -181,6 +183,12 @@ struct ApplyArgs {
     int profile = 1;                // count this launch in the roofline timing of the handle that owns the solve
 };
 int helm_launch_apply(helm_op *op, const ApplyArgs &a);
+
+// ---- 3-D operator (helm3d.hip) -------------------------------------------------------------------
+int helm3d_launch_assemble(helm_op *op, double freq_re, double freq_im, double tau, double cPML);
+int helm3d_launch_apply(helm_op *op, const ApplyArgs &a, hipEvent_t e0, hipEvent_t e1);
+int helm3d_apply_num_blocks(const helm_op *op);
+
 int helm_apply_num_blocks(const helm_op *op);
 
 int helm_launch_scale_planes(helm_op *op);   // d_Cs, d_dinv from d_C

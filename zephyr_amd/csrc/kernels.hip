@@ -268,27 +268,26 @@ __global__ __launch_bounds__(256) void k_stencil_t(StencilParamsT<V> q) {
 // elementwise / vector kernels (grid.x over points with a grid-stride loop, grid.y = rhs)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_scale_planes(const cplx *__restrict__ C, cplx *__restrict__ Cs,
-                                                      cplx *__restrict__ dinv, long long N, int nblocks, double floor_frac) {
+                                                      cplx *__restrict__ dinv, long long N, int nblocks, double floor_frac,
+                                                      int nplanes, int centre) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     for (int m = 0; m < nblocks; ++m) {
-        const cplx *Cm = C + (long long)m * 9 * N;
-        cplx *Sm = Cs + (long long)m * 9 * N;
-        cplx d = Cm[4 * N + i];
+        const cplx *Cm = C + (long long)m * nplanes * N;
+        cplx *Sm = Cs + (long long)m * nplanes * N;
+        cplx d = Cm[(long long)centre * N + i];
         const bool zero = (d.x == 0.0 && d.y == 0.0);
         if (floor_frac > 0.0 && !zero) {
             // smoother safeguard on multigrid levels: where the diagonal nearly cancels (k h ~ 2: mass term
             // against the Laplacian) keep its phase but not less than floor_frac of the row's absolute sum
             double rows = 0.0;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) rows += sqrt(cabs2(Cm[(long long)k * N + i]));
+            for (int k = 0; k < nplanes; ++k) rows += sqrt(cabs2(Cm[(long long)k * N + i]));
             const double ad = sqrt(cabs2(d));
             if (ad < floor_frac * rows) d = cscale(d, floor_frac * rows / ad);
         }
         const cplx di = zero ? cmake(0.0, 0.0) : crecip(d);
         dinv[(long long)m * N + i] = di;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) Sm[(long long)k * N + i] = (k == 4) ? cmake(1.0, 0.0) : cmul(Cm[(long long)k * N + i], di);
+        for (int k = 0; k < nplanes; ++k) Sm[(long long)k * N + i] = (k == centre) ? cmake(1.0, 0.0) : cmul(Cm[(long long)k * N + i], di);
     }
 }
 
@@ -605,6 +604,7 @@ inline int vec_blocks(long long N) {
 #endif
 
 int helm_apply_num_blocks(const helm_op *op) {
+    if (op->ny > 0) return helm3d_apply_num_blocks(op);
     const int ntx = (op->nx + TX - 1) / TX, ntz = (op->nz + 4 * STENCIL_P - 1) / (4 * STENCIL_P);
     return ntx * ntz;
 }
@@ -650,6 +650,23 @@ static int launch_apply_f32(helm_op *op, const ApplyArgs &a) {
 }
 
 int helm_launch_apply(helm_op *op, const ApplyArgs &a) {
+    if (op->ny > 0) {           // 3-D operator: own kernel, same profiling bookkeeping
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (op->profiling && a.profile && op->ev_pool.size() < 8192) {
+            if (op->ev_used + 2 > op->ev_pool.size())
+                for (int i = 0; i < 64; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) HELM_FAIL(op, HELM_ERR_DEVICE, "hipEventCreate failed"); op->ev_pool.push_back(e); }
+            e0 = op->ev_pool[op->ev_used]; e1 = op->ev_pool[op->ev_used + 1];
+        }
+        int rc = helm3d_launch_apply(op, a, e0, e1);
+        if (rc) return rc;
+        if (e0) {
+            const int nact = (a.scal && op->active_hint >= 0 && op->active_hint < a.nrhs) ? op->active_hint : a.nrhs;
+            const bool operand = (a.epi == EPI_DOT_W || a.epi == EPI_RESID);
+            op->ev_pending.push_back(std::make_pair((int)op->ev_used, (double)op->N * (32.0 * nact + 432.0 + (operand ? 16.0 * nact : 0.0))));
+            op->ev_used += 2;
+        }
+        return HELM_OK;
+    }
     if (a.f32) return launch_apply_f32(op, a);
     StencilParams q;
     q.planes = a.planes; q.X = a.X; q.Y = a.Y; q.W = a.W; q.ld = a.ld; q.N = op->N;
@@ -703,7 +720,7 @@ int helm_launch_apply(helm_op *op, const ApplyArgs &a) {
 
 int helm_launch_scale_planes(helm_op *op) {
     const int blocks = (int)((op->N + 255) / 256);
-    hipLaunchKernelGGL(k_scale_planes, dim3(blocks), dim3(256), 0, op->stream, op->d_C, op->d_Cs, op->d_dinv, op->N, op->nblocks, op->diag_floor);
+    hipLaunchKernelGGL(k_scale_planes, dim3(blocks), dim3(256), 0, op->stream, op->d_C, op->d_Cs, op->d_dinv, op->N, op->nblocks, op->diag_floor, op->nplanes, op->centre);
     HIP_TRY(op, hipGetLastError());
     return HELM_OK;
 }
