@@ -78,7 +78,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--n', type=int, default=1024, help='grid side (1024 = BASELINE workload)')
+    ap.add_argument('--grid', '--n', dest='n', type=int, default=1024, help='grid side (1024 = BASELINE workload)')
     ap.add_argument('--dx', type=float, default=9.0)
     ap.add_argument('--batch', type=int, default=32, help='sources per work item')
     ap.add_argument('--rtol', type=float, default=1e-10)
@@ -93,10 +93,12 @@ def main():
 
     import torch
     import torch.distributed as dist
+    backend = os.environ.get('HELM_BENCH_BACKEND', 'nccl')      # 'gloo' only for single-GPU dry runs of the N>1 logic
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
@@ -154,7 +156,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Config 5 probe: 3-D 27-point operator, 256 x 256 x 128, homogeneous c = 2000 m/s, h = 10 m.
+Times the batched apply (algorithmic bytes N*(32*B + 432)) and Jacobi-BiCGSTAB solves."""
+import argparse, ctypes, json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import __graft_entry__ as g
+g.build()
+from zephyr_amd import Helm3D, _lib
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--nx', type=int, default=256); ap.add_argument('--ny', type=int, default=256); ap.add_argument('--nz', type=int, default=128)
+ap.add_argument('--freqs', type=float, nargs='+', default=[2., 5.]); ap.add_argument('--nsrc', type=int, default=4)
+ap.add_argument('--maxit', type=int, default=60000); ap.add_argument('--rtol', type=float, default=1e-8)
+ap.add_argument('--no-solve', action='store_true')
+a = ap.parse_args()
+nx, ny, nz = a.nx, a.ny, a.nz
+N = nx * ny * nz
+cfg = dict(nx=nx, ny=ny, nz=nz, dx=10., c=2000., rho=1., freq=a.freqs[0], nPML=10, rtol=a.rtol, maxit=a.maxit, batch=a.nsrc)
+op = Helm3D(cfg)
+lib = _lib.load()
+dev = torch.device('cuda', 0)
+out = {'grid': [nz, ny, nx], 'apply': []}
+for B in (1, 4, 8, 16):
+    X = torch.randn((B, N), dtype=torch.complex128, device=dev)
+    Y = torch.empty_like(X)
+    torch.cuda.synchronize()
+    op.setProfiling(True)
+    ms, bytes_ = 0.0, 0.0
+    for rep in range(6):
+        _lib.check(lib.helm_apply_device(op.handle, 0, 0, ctypes.c_void_p(X.data_ptr()), ctypes.c_void_p(Y.data_ptr()), B), op.handle)
+        t = op.lastTiming()
+        if rep >= 1:
+            ms += t['apply_ms']; bytes_ += t['apply_bytes']
+    out['apply'].append({'B': B, 'us': 1e3 * ms / 5, 'GBps_algorithmic': bytes_ / (ms * 1e-3) / 1e9})
+    print('apply B=%2d  %8.1f us  %7.1f GB/s (N*(32B+432))' % (B, 1e3 * ms / 5, bytes_ / (ms * 1e-3) / 1e9), flush=True)
+    del X, Y
+op.setProfiling(False)
+if not a.no_solve:
+    out['solve'] = []
+    for f in a.freqs:
+        cfg['freq'] = f
+        op = Helm3D(cfg)
+        q = np.zeros((N, a.nsrc), complex)
+        for s in range(a.nsrc):
+            q[((20 + 5 * s) * ny + ny // 2) * nx + nx // 4 + 30 * s, s] = 1.
+        t0 = time.time()
+        try:
+            u = op * q
+            status = 'ok'
+        except ArithmeticError as e:
+            status = str(e)
+        dt = time.time() - t0
+        its = [i['iterations'] for i in op.lastInfo]
+        out['solve'].append({'freq': f, 'nsrc': a.nsrc, 'seconds': dt, 'iterations': its, 'status': status})
+        print('solve f=%g Hz nsrc=%d  %.2f s  its %s  %s' % (f, a.nsrc, dt, its, status), flush=True)
+        del op
+print(json.dumps(out))
