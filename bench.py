@@ -80,7 +80,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--grid', '--n', dest='n', type=int, default=1024, help='grid side (1024 = BASELINE workload)')
     ap.add_argument('--dx', type=float, default=9.0)
-    ap.add_argument('--batch', type=int, default=32, help='sources per work item')
+    ap.add_argument('--batch', type=int, default=64, help='sources per work item')
     ap.add_argument('--rtol', type=float, default=1e-10)
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--method', default='auto')

@@ -190,6 +190,7 @@ int helm3d_launch_apply(helm_op *op, const ApplyArgs &a, hipEvent_t e0, hipEvent
 int helm3d_apply_num_blocks(const helm_op *op);
 
 int helm_apply_num_blocks(const helm_op *op);
+int helm_stencil_tile_rows();     // rows of the 64-wide stencil tile (4 * STENCIL_P)
 
 int helm_launch_scale_planes(helm_op *op);   // d_Cs, d_dinv from d_C
 

@@ -600,8 +600,10 @@ inline int vec_blocks(long long N) {
 // host launchers
 // ==========================================================================================
 #ifndef STENCIL_P
-#define STENCIL_P 2
+#define STENCIL_P 1
 #endif
+
+int helm_stencil_tile_rows() { return 4 * STENCIL_P; }
 
 int helm_apply_num_blocks(const helm_op *op) {
     if (op->ny > 0) return helm3d_apply_num_blocks(op);

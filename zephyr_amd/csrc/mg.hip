@@ -509,8 +509,8 @@ int mg_setup(helm_op *op, int batch) {
         if (!P->sop) { helm_set_error(op, helm_last_error(nullptr)); mg_destroy(op); return HELM_ERR_DEVICE; }
         int rc = assemble_child(op, P->sop, op->h_c, op->h_rho, op->h_theta, op->h_eps, op->h_delta, tauM, op->a_cpml);
         if (rc) { helm_set_error(op, helm_last_error(P->sop)); mg_destroy(op); return rc; }
-        // stencil tiles (64 x 8, STENCIL_P = 2) that touch the frame
-        const int W = P->W, TZ = 8, ntx = (op->nx + 63) / 64, ntz = (op->nz + TZ - 1) / TZ;
+        // stencil tiles (64 x helm_stencil_tile_rows()) that touch the frame
+        const int W = P->W, TZ = helm_stencil_tile_rows(), ntx = (op->nx + 63) / 64, ntz = (op->nz + TZ - 1) / TZ;
         std::vector<int> tiles;
         for (int tz = 0; tz < ntz; ++tz) for (int tx = 0; tx < ntx; ++tx) {
             const int z0 = tz * TZ, z1 = std::min(z0 + TZ, op->nz) - 1, x0 = tx * 64, x1 = std::min(x0 + 64, op->nx) - 1;
