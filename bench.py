@@ -184,6 +184,15 @@ def main():
                          'bytes_per_launch_algorithmic': apply_bytes / apply_launches if apply_launches else None,
                          'apply_share_of_solve_time': apply_ms / solve_ms if solve_ms > 0 else None},
         }
+        # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same
+        # command; bench.py cannot run the profiler on itself) -- only when it was collected for this workload
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+            if pmc.get('batch') == B and pmc.get('grid') == [n, n]:
+                out['roofline']['traffic'] = pmc['traffic_bytes_per_launch_outer_applies']
+                out['roofline']['traffic_source'] = 'profiles/r01_pmc_traffic.json'
+        except Exception:
+            pass
         if world == 1 and not args.no_cpu:
             cb, _ = cpu_baseline(cfg, freqs, q_all)
             out['cpu_baseline'] = cb
