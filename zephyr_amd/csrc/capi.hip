@@ -482,8 +482,33 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
                 for (int b = 0; b < n; ++b) { B.h_mask[b] = (op->h_scal[b].status == ST_ACTIVE); any = any || B.h_mask[b]; }
                 if (any) { rc = run_cgnr(op, block, B, o.maxit, check_every); if (rc) return rc; }
             } else {
-                rc = run_bicgstab(op, block, B, o.maxit, check_every, 25, restarts);
+                // in AUTO mode a preconditioned run that has not converged after 5000 iterations is handed to CGNR
+                const int cap = (use_mg && o.method == HELM_AUTO) ? std::min(o.maxit, 5000) : o.maxit;
+                rc = run_bicgstab(op, block, B, cap, check_every, 25, restarts);
                 if (rc) return rc;
+                if (o.method == HELM_AUTO && use_mg && round == 0) {
+                    rc = download_scal(op, n);
+                    if (rc) return rc;
+                    bool any = false;
+                    for (int b = 0; b < n; ++b) {
+                        const int st = op->h_scal[b].status;
+                        B.h_mask[b] = (st == ST_BREAKDOWN || st == ST_FROZEN);
+                        any = any || B.h_mask[b];
+                    }
+                    if (any) {     // safety net: Jacobi-scaled CGNR from the current iterate
+                        helm_launch_norm2(op, B.bscaled, n);
+                        helm_launch_fin_ex(op, FIN_NORM, n, helm_vec_num_blocks(op), nullptr, B.d_aux);
+                        HIP_TRY(op, hipMemcpyAsync(B.h_aux, B.d_aux, n * sizeof(double), hipMemcpyDeviceToHost, op->stream));
+                        HIP_TRY(op, hipStreamSynchronize(op->stream));
+                        for (int b = 0; b < n; ++b) if (B.h_mask[b]) {
+                            RhsScal &S = op->h_scal[b];
+                            total_iters[b] += S.iters; method_used[b] = HELM_CGNR;
+                            S.bb = B.h_aux[b]; S.tol2 = 0.25 * o.rtol * o.rtol;
+                        }
+                        rc = run_cgnr(op, block, B, o.maxit, 50);
+                        if (rc) return rc;
+                    }
+                }
                 if (o.method == HELM_AUTO && !use_mg) {
                     rc = download_scal(op, n);
                     if (rc) return rc;
