@@ -155,11 +155,11 @@ def test_edge_cases_and_error_conventions(helm_lib):
     with pytest.raises(ValueError):
         za.Eurus(cfg) * np.zeros((3 * nz * nx, 1), complex)
     rng = np.random.default_rng(0)
-    tti = dict(cfg, eps=0.2 * rng.random((nz, nx)), delta=0.1 * rng.random((nz, nx)))
-    with pytest.raises(HelmError) as ei:                                       # coupled two-field system: next round
+    tti = dict(cfg, eps=0.2 * rng.random((nz, nx)), delta=0.1 * rng.random((nz, nx)), method='mg')
+    with pytest.raises(HelmError) as ei:                                       # the coupled system has no multigrid path
         za.Eurus(tti) * np.ones((nz * nx, 1), complex)
     assert 'UNSUPPORTED' in str(ei.value)
-    assert za.Eurus(tti).diagonals().shape == (4, 9, nz, nx)                    # assembly and apply still available
+    assert za.Eurus(tti).diagonals().shape == (4, 9, nz, nx)
     capped = za.MiniZephyr(dict(cfg, maxit=20, method='bicgstab'))
     with pytest.raises(ArithmeticError):
         capped * np.eye(nz * nx, 1, -820)[:, 0].astype(complex)
@@ -221,3 +221,29 @@ def test_minizephyr25d_reference_configuration(helm_lib):
     sc4 = dict(sc, nky=4)
     u4 = (za.MiniZephyr25D(sc4) * za.SimpleSource(sc4)(np.array([[50., 100.]])))[:, 0].reshape((nz, nx))
     assert nrm(u4[np.arange(5, 196, 10), 60], g['nky4_line']) <= 1e-7
+
+
+def test_eurus_tti_coupled_two_field_system(helm_lib):
+    """eps != delta: M3 != 0, the full 2N x 2N system [[M1,M2],[M3,M4]] is solved (eurus.py:430-464); N-row and
+    stacked 2N-row right-hand sides against the sparse LU of the reference-identical matrix."""
+    import zephyr_amd as za
+    nz, nx = 44, 52
+    c, rho = hetero(nz, nx, 13)
+    rng = np.random.default_rng(14)
+    theta = 0.5 * rng.random((nz, nx)) - 0.25
+    eps = 0.25 * rng.random((nz, nx))
+    delta = 0.12 * rng.random((nz, nx))
+    cfg = dict(nx=nx, nz=nz, dx=10., dz=10., c=c, rho=rho, freq=9., nPML=6, theta=theta, eps=eps, delta=delta, rtol=1e-10, maxit=400000)
+    C4 = ho.eurus_coefficients(nz, nx, c, rho, 9., dx=10., dz=10., nPML=6, theta=theta, eps=eps, delta=delta)
+    assert np.abs(C4[2]).max() > 0                     # genuinely coupled
+    lu = ho.DirectOperator(C4, eurus=True)
+    q = za.SimpleSource(cfg)(np.array([[250., 220.], [330., 150.]]))
+    op = za.Eurus(cfg)
+    u = op * q
+    assert u.shape == q.shape
+    assert nrm(u, lu * q) <= 1e-7, op.lastInfo
+    q2 = np.vstack([q, 0.3j * q[::-1]])
+    u2 = op * q2
+    assert u2.shape == q2.shape
+    assert nrm(u2, lu * q2) <= 1e-7, op.lastInfo
+    assert all(i['relres'] <= 1e-10 for i in op.lastInfo)

@@ -125,7 +125,7 @@ double max_err(const std::vector<cplx> &a, const std::vector<cplx> &b) {
 template <int P>
 void run_tile(const char *name, const cplx *dC, const cplx *dX, cplx *dY, int n, long long N, int B, const std::vector<cplx> &ref, double bytes, int tiled = 0) {
     StencilParams q;
-    q.planes_tiled = tiled; q.U = nullptr; q.E = nullptr; q.nzc = q.nxc = 0;
+    q.planes_tiled = tiled; q.U = nullptr; q.E = nullptr; q.nzc = q.nxc = 0; q.acc = 0; q.part_stride = 1; q.part_off = 0;
     q.planes = dC; q.X = dX; q.Y = dY; q.W = nullptr; q.ld = N; q.N = N; q.nz = n; q.nx = n; q.nrhs = B;
     q.ntx = (n + 63) / 64; q.ntz = (n + 4 * P - 1) / (4 * P); q.nblk = q.ntx * q.ntz; q.scal = nullptr; q.part = nullptr; q.dinv = nullptr; q.omega_j = 0; q.tiles = nullptr;
     int split = 1;

@@ -64,6 +64,7 @@ static helm_op *create_common(helm_op *op) {
     HIP_TRY_NULL(hipStreamCreateWithFlags(&op->stream, hipStreamNonBlocking));
     op->own_stream = true;
     const size_t N = (size_t)op->N;
+    op->Nv = op->N;
     HIP_TRY_NULL(hipMalloc(&op->d_c, N * sizeof(cplx)));
     HIP_TRY_NULL(hipMalloc(&op->d_rho, N * sizeof(double)));
     HIP_TRY_NULL(hipMalloc(&op->d_C, (size_t)op->nblocks * op->nplanes * N * sizeof(cplx)));
@@ -77,7 +78,7 @@ extern "C" void helm_destroy(helm_op *op) {
     hipSetDevice(op->device);
     if (op->stream) hipStreamSynchronize(op->stream);
     hipFree(op->d_c); hipFree(op->d_rho); hipFree(op->d_theta); hipFree(op->d_eps); hipFree(op->d_delta);
-    hipFree(op->d_C); hipFree(op->d_Cs); hipFree(op->d_dinv);
+    hipFree(op->d_C); hipFree(op->d_Cs); hipFree(op->d_dinv); hipFree(op->d_S); hipFree(op->d_rs);
     if (op->mg) mg_destroy(op);
     hipFree(op->d_ws); hipFree(op->d_part); hipFree(op->d_scal);
     if (op->h_scal) hipHostFree(op->h_scal);
@@ -177,7 +178,7 @@ static int ensure_ws(helm_op *op, size_t bytes) {
     return HELM_OK;
 }
 static int ensure_part(helm_op *op, int nrhs) {
-    const int nblk = std::max(helm_apply_num_blocks(op), helm_vec_num_blocks(op));
+    const int nblk = std::max(2 * helm_apply_num_blocks(op), helm_vec_num_blocks(op));
     const size_t bytes = (size_t)nrhs * 4 * nblk * sizeof(double) + (size_t)nrhs * (2 * sizeof(double) + sizeof(int)) + 256;
     if (op->part_bytes < bytes) {
         if (op->d_part) { hipFree(op->d_part); op->d_part = nullptr; op->part_bytes = 0; }
@@ -252,6 +253,8 @@ struct Batch {
     cplx *bscaled = nullptr;                 // D^-1 q' (right-hand side of the Jacobi-scaled system; CGNR fallback)
     cplx *phat = nullptr, *shat = nullptr;   // preconditioned directions (MG mode)
     bool pre = false;    // true: BiCGSTAB on A right-preconditioned by multigrid; false: Jacobi-scaled system
+    bool sys2 = false;   // coupled two-field Eurus system (vectors of length 2N, four stencil launches per apply)
+    int nba = 0;         // partial sums written by one (system) apply
     const cplx *planes = nullptr;            // planes of the iterated operator (raw for pre, scaled otherwise)
     int *d_mask; double *d_aux;      // device, nrhs ints / 2*nrhs doubles (inside d_part tail)
     int *h_mask; double *h_aux;      // pinned (inside h_scal tail)
@@ -282,6 +285,34 @@ ApplyArgs batch_apply(helm_op *op, const Batch &B, const cplx *X, cplx *Y, const
     return a;
 }
 
+// Apply of the coupled Eurus system [[M1, M2], [M3, M4]] (or its conjugate transpose) to vectors [u; v] of length 2N:
+// four stencil launches, the second of each output half accumulating into the first and carrying the fused epilogue.
+// raw = unscaled planes (true residual), otherwise the row-equilibrated system d_S.
+int launch_sys2_apply(helm_op *op, bool raw, int adjoint, const cplx *X, cplx *Y, const cplx *W, int nrhs, int epi, const RhsScal *scal) {
+    const long long N = op->N;
+    const int nblk = helm_apply_num_blocks(op);
+    const cplx *P = raw ? op->d_C : op->d_S;
+    if (epi == EPI_DOT_XY) { epi = EPI_DOT_WY; W = X; }
+    for (int half = 0; half < 2; ++half) {
+        // forward: out_half = M[half][0] in0 + M[half][1] in1 ; adjoint: out_half = M[0][half]^H in0 + M[1][half]^H in1
+        const int blkA = adjoint ? (0 * 2 + half) : (half * 2 + 0), blkB = adjoint ? (1 * 2 + half) : (half * 2 + 1);
+        ApplyArgs a = ApplyArgs();
+        a.ld = 2 * N; a.nrhs = nrhs; a.scal = scal; a.part = (double *)op->d_part; a.part_stride = 2 * nblk; a.adjoint = adjoint; a.scaled = 0;
+        a.planes = P + (long long)blkA * 9 * N; a.X = X; a.Y = Y + half * N; a.epi = EPI_NONE; a.profile = 0;
+        int rc = helm_launch_apply(op, a);
+        if (rc) return rc;
+        a.planes = P + (long long)blkB * 9 * N; a.X = X + N; a.acc = 1; a.epi = epi; a.W = W ? W + half * N : nullptr; a.part_off = half * nblk; a.profile = 1;
+        rc = helm_launch_apply(op, a);
+        if (rc) return rc;
+    }
+    return HELM_OK;
+}
+
+int launch_batch_apply(helm_op *op, const Batch &B, const cplx *X, cplx *Y, const cplx *W, int epi) {
+    if (B.sys2) return launch_sys2_apply(op, false, 0, X, Y, W, B.nrhs, epi, op->d_scal);
+    return helm_launch_apply(op, batch_apply(op, B, X, Y, W, epi));
+}
+
 // Restart the right-hand sides flagged in h_mask from their current iterate x:
 // r = bbar - Abar x, r0 = r, p = v = 0, scalars reset.  Host copy of scal must be fresh.
 int restart_masked(helm_op *op, int block, Batch &B) {
@@ -293,17 +324,17 @@ int restart_masked(helm_op *op, int block, Batch &B) {
     int rc = upload_scal(op, n);
     if (rc) return rc;
     HIP_TRY(op, hipMemcpyAsync(B.d_mask, B.h_mask, n * sizeof(int), hipMemcpyHostToDevice, op->stream));
-    rc = helm_launch_apply(op, batch_apply(op, B, B.w.x, B.w.r, B.bbar, EPI_RESID));
+    rc = launch_batch_apply(op, B, B.w.x, B.w.r, B.bbar, EPI_RESID);
     if (rc) return rc;
     helm_launch_restart_copy_mask(op, B.w, n, B.d_mask);
-    helm_launch_fin_ex(op, FIN_RESTART, n, helm_apply_num_blocks(op), B.d_mask, nullptr);
+    helm_launch_fin_ex(op, FIN_RESTART, n, B.nba, B.d_mask, nullptr);
     HIP_TRY(op, hipGetLastError());
     return HELM_OK;
 }
 
 int run_bicgstab(helm_op *op, int block, Batch &B, int maxit, int check_every, int max_restarts, std::vector<int> &restarts) {
     const int n = B.nrhs;
-    const int nba = helm_apply_num_blocks(op), nbv = helm_vec_num_blocks(op);
+    const int nba = B.nba, nbv = helm_vec_num_blocks(op);
     int it_done = 0;
     while (true) {
         int rc = download_scal(op, n);
@@ -338,15 +369,15 @@ int run_bicgstab(helm_op *op, int block, Batch &B, int maxit, int check_every, i
             helm_launch_bicg_p(op, B.w, n);
             const cplx *pin = B.w.p, *sin = B.w.s;
             if (B.pre) { rc = mg_apply(op, B.w.p, B.phat, n, op->d_scal); if (rc) return rc; pin = B.phat; }
-            rc = helm_launch_apply(op, batch_apply(op, B, pin, B.w.v, B.w.r0, EPI_DOT_W));
+            rc = launch_batch_apply(op, B, pin, B.w.v, B.w.r0, EPI_DOT_W);
             if (rc) return rc;
             helm_launch_fin(op, FIN_ALPHA, n, nba);
             helm_launch_bicg_s(op, B.w, n);
             if (B.pre) {
                 rc = mg_apply(op, B.w.s, B.shat, n, op->d_scal); if (rc) return rc; sin = B.shat;
-                rc = helm_launch_apply(op, batch_apply(op, B, sin, B.w.t, B.w.s, EPI_DOT_WY));
+                rc = launch_batch_apply(op, B, sin, B.w.t, B.w.s, EPI_DOT_WY);
             } else {
-                rc = helm_launch_apply(op, batch_apply(op, B, sin, B.w.t, nullptr, EPI_DOT_XY));
+                rc = launch_batch_apply(op, B, sin, B.w.t, nullptr, EPI_DOT_XY);
             }
             if (rc) return rc;
             helm_launch_fin(op, FIN_OMEGA, n, nba);
@@ -363,7 +394,7 @@ int run_bicgstab(helm_op *op, int block, Batch &B, int maxit, int check_every, i
 // CGNR on the Jacobi-scaled system for the right-hand sides flagged in h_mask (warm start from x).
 int run_cgnr(helm_op *op, int block, Batch &B, int maxit, int check_every) {
     const int n = B.nrhs;
-    const int nba = helm_apply_num_blocks(op), nbv = helm_vec_num_blocks(op);
+    const int nba = B.nba, nbv = helm_vec_num_blocks(op);
     // r = bbar - Abar x for flagged RHS; others frozen
     for (int b = 0; b < n; ++b) {
         RhsScal &S = op->h_scal[b];
@@ -372,10 +403,14 @@ int run_cgnr(helm_op *op, int block, Batch &B, int maxit, int check_every) {
     }
     int rc = upload_scal(op, n);
     if (rc) return rc;
-    rc = helm_launch_apply(op, scaled_apply(op, block, B.w.x, B.w.r, B.bscaled, n, 0, EPI_RESID, true));
+    auto cg_apply = [&](const cplx *X, cplx *Y, const cplx *W, int adjoint, int epi) -> int {
+        if (B.sys2) return launch_sys2_apply(op, false, adjoint, X, Y, W, n, epi, op->d_scal);
+        return helm_launch_apply(op, scaled_apply(op, block, X, Y, W, n, adjoint, epi, true));
+    };
+    rc = cg_apply(B.w.x, B.w.r, B.bscaled, 0, EPI_RESID);
     if (rc) return rc;
     helm_launch_fin(op, FIN_CG_RR, n, nba);            // rr (and convergence check); iters becomes 1
-    rc = helm_launch_apply(op, scaled_apply(op, block, B.w.r, B.w.s, nullptr, n, 1, EPI_DOT_YY, true));   // z = A^H r
+    rc = cg_apply(B.w.r, B.w.s, nullptr, 1, EPI_DOT_YY);   // z = A^H r
     if (rc) return rc;
     helm_launch_fin(op, FIN_CG_INIT, n, nba);
     helm_launch_cg_p(op, B.w, n, 1);
@@ -395,12 +430,12 @@ int run_cgnr(helm_op *op, int block, Batch &B, int maxit, int check_every) {
         if (!any_active) break;
         const int chunk = std::max(1, std::min(check_every, maxit - min_iters));
         for (int k = 0; k < chunk; ++k) {
-            rc = helm_launch_apply(op, scaled_apply(op, block, B.w.p, B.w.v, nullptr, n, 0, EPI_DOT_YY, true));   // w = A p
+            rc = cg_apply(B.w.p, B.w.v, nullptr, 0, EPI_DOT_YY);   // w = A p
             if (rc) return rc;
             helm_launch_fin(op, FIN_CG_ALPHA, n, nba);
             helm_launch_cg_xr(op, B.w, n);
             helm_launch_fin(op, FIN_CG_RR, n, nbv);
-            rc = helm_launch_apply(op, scaled_apply(op, block, B.w.r, B.w.s, nullptr, n, 1, EPI_DOT_YY, true)); // z = A^H r
+            rc = cg_apply(B.w.r, B.w.s, nullptr, 1, EPI_DOT_YY); // z = A^H r
             if (rc) return rc;
             helm_launch_fin(op, FIN_CG_BETA, n, nba);
             helm_launch_cg_p(op, B.w, n, 0);
@@ -412,19 +447,36 @@ int run_cgnr(helm_op *op, int block, Batch &B, int maxit, int check_every) {
 
 // Solve M_block X = premul * RHS[:, row_off : row_off+N] - sub   for nrhs right-hand sides.
 // dXout: [nrhs][N] (NOT conjugated).  info (optional) is filled per RHS.
+struct NvGuard {     // Krylov vector length of the handle for the duration of a solve
+    helm_op *op; long long old;
+    NvGuard(helm_op *o, long long nv) : op(o), old(o->Nv) { o->Nv = nv; }
+    ~NvGuard() { op->Nv = old; }
+};
+
+// sys2 != 0: the coupled two-field Eurus system (block ignored, vectors [u; v] of length 2N, rows_in = N or 2N rows of
+// right-hand side per source; sub unused); dXout then holds 2N values per right-hand side.
 int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long long row_off, cplx premul,
-                const cplx *sub, cplx *dXout, int nrhs, const helm_solve_opts &o, helm_solve_info *info) {
+                const cplx *sub, cplx *dXout, int nrhs, const helm_solve_opts &o, helm_solve_info *info,
+                int sys2 = 0, long long rows_in = 0) {
     const long long N = op->N;
+    const long long NV = sys2 ? 2 * N : N;
+    NvGuard guard(op, NV);
     int Bmax = o.batch > 0 ? o.batch : 16;
     if (Bmax > nrhs) Bmax = nrhs;
-    int rc = ensure_ws(op, (size_t)11 * Bmax * N * sizeof(cplx));
+    int rc = ensure_ws(op, (size_t)11 * Bmax * NV * sizeof(cplx));
     if (rc) return rc;
+    if (sys2) {
+        // the coupled TTI system is only tractable by the normal-equations method on the row-equilibrated system
+        if (o.method == HELM_MG || o.method == HELM_BICGSTAB) HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "the coupled TTI system (eps != delta) is solved with row-equilibrated CGNR only (method 'auto' or 'cgnr')");
+        rc = helm_launch_rowscaled_system(op);
+        if (rc) return rc;
+    }
     rc = ensure_part(op, Bmax);
     if (rc) return rc;
     // preconditioner choice: multigrid for the main block when asked for (or AUTO on Eurus, where it is validated)
     bool use_mg = false;
     if (op->ny > 0 && o.method == HELM_MG) HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "the multigrid preconditioner is 2-D only");
-    if (op->ny == 0 && block == 0 && (o.method == HELM_MG || (o.method == HELM_AUTO && std::min(op->nz, op->nx) >= 32))) {
+    if (!sys2 && op->ny == 0 && block == 0 && (o.method == HELM_MG || (o.method == HELM_AUTO && std::min(op->nz, op->nx) >= 32))) {
         rc = mg_setup(op, Bmax);
         if (rc == HELM_OK) use_mg = true;
         else if (o.method == HELM_MG) return rc;
@@ -436,7 +488,9 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
         Batch B;
         B.nrhs = n;
         cplx *base = (cplx *)op->d_ws;
-        const long long vs = (long long)Bmax * N;
+        const long long vs = (long long)Bmax * NV;
+        B.sys2 = sys2 != 0;
+        B.nba = (sys2 ? 2 : 1) * helm_apply_num_blocks(op);
         B.w.x = base; B.w.r = base + vs; B.w.r0 = base + 2 * vs; B.w.p = base + 3 * vs; B.w.v = base + 4 * vs;
         B.w.s = base + 5 * vs; B.w.t = base + 6 * vs; B.bscaled = base + 7 * vs;
         cplx *qprime = base + 8 * vs;
@@ -444,7 +498,7 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
         B.pre = use_mg;
         B.bbar = use_mg ? qprime : B.bscaled;
         B.planes = use_mg ? op->d_C + (long long)block * op->nplanes * N : op->d_Cs + (long long)block * op->nplanes * N;
-        const int nblk = std::max(helm_apply_num_blocks(op), helm_vec_num_blocks(op));
+        const int nblk = std::max(2 * helm_apply_num_blocks(op), helm_vec_num_blocks(op));
         char *ptail = (char *)op->d_part + (size_t)Bmax * 4 * nblk * sizeof(double);
         B.d_aux = (double *)ptail; B.d_mask = (int *)(ptail + (size_t)Bmax * 2 * sizeof(double));
         char *htail = (char *)op->h_scal + (size_t)op->scal_cap * sizeof(RhsScal);
@@ -453,12 +507,26 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
         const cplx *rhs_b = dRHS + (long long)first * rhs_ld;
         const cplx *sub_b = sub ? sub + (long long)first * N : nullptr;
         // q' = premul*rhs - sub (unscaled), ||q'||^2 -> aux[n..2n)
-        rc = helm_launch_prep_rhs(op, rhs_b, rhs_ld, row_off, premul, sub_b, qprime, n);
-        if (rc) return rc;
+        if (sys2) {
+            HIP_TRY(op, hipMemsetAsync(qprime, 0, (size_t)n * NV * sizeof(cplx), op->stream));
+            HIP_TRY(op, hipMemsetAsync(B.bscaled, 0, (size_t)n * NV * sizeof(cplx), op->stream));
+            for (int half = 0; half < (rows_in == 2 * N ? 2 : 1); ++half) {
+                rc = helm_launch_prep_rhs_ex(op, rhs_b, rhs_ld, half * N, premul, nullptr, qprime, NV, half * N, n);
+                if (rc) return rc;
+                rc = helm_launch_prep_rhs_rs(op, rhs_b, rhs_ld, half * N, premul, op->d_rs + half * N, B.bscaled, NV, half * N, n);
+                if (rc) return rc;
+            }
+        } else {
+            rc = helm_launch_prep_rhs(op, rhs_b, rhs_ld, row_off, premul, sub_b, qprime, n);
+            if (rc) return rc;
+        }
         helm_launch_norm2(op, qprime, n);
         helm_launch_fin_ex(op, FIN_NORM, n, helm_vec_num_blocks(op), nullptr, B.d_aux + n);
         // scaled system start
-        {
+        if (sys2) {
+            rc = helm_launch_krylov_init(op, B.bscaled, B.w, n, o.rtol * 0.5);
+            if (rc) return rc;
+        } else {
             VecPtrs w = B.w;
             w.t = B.bscaled;   // init writes the scaled right-hand side through w.t
             // NB: row offset is applied by giving prep a shifted base pointer
@@ -470,12 +538,12 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
             }
         }
         std::vector<int> restarts(n, 0);
-        std::vector<int> method_used(n, o.method == HELM_CGNR ? HELM_CGNR : (use_mg ? HELM_MG : HELM_BICGSTAB));
+        std::vector<int> method_used(n, (o.method == HELM_CGNR || sys2) ? HELM_CGNR : (use_mg ? HELM_MG : HELM_BICGSTAB));
         std::vector<int> total_iters(n, 0);
         std::vector<double> relres(n, 0.0);
         const int max_refine = 3;
         for (int round = 0; round <= max_refine; ++round) {
-            if (o.method == HELM_CGNR) {
+            if (o.method == HELM_CGNR || sys2) {
                 rc = download_scal(op, n);
                 if (rc) return rc;
                 bool any = false;
@@ -509,7 +577,7 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
                         if (rc) return rc;
                     }
                 }
-                if (o.method == HELM_AUTO && !use_mg) {
+                if (o.method == HELM_AUTO && !use_mg && !sys2) {
                     rc = download_scal(op, n);
                     if (rc) return rc;
                     bool any = false;
@@ -521,12 +589,16 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
                 }
             }
             // true residual of the UNSCALED system: s = q' - A x
-            ApplyArgs a = ApplyArgs();
-            a.planes = op->d_C + (long long)block * op->nplanes * N; a.X = B.w.x; a.Y = B.w.s; a.W = qprime; a.ld = N; a.nrhs = n;
-            a.scaled = 0; a.adjoint = 0; a.epi = EPI_RESID; a.scal = nullptr; a.part = (double *)op->d_part;
-            rc = helm_launch_apply(op, a);
+            if (sys2) {
+                rc = launch_sys2_apply(op, true, 0, B.w.x, B.w.s, qprime, n, EPI_RESID, nullptr);
+            } else {
+                ApplyArgs a = ApplyArgs();
+                a.planes = op->d_C + (long long)block * op->nplanes * N; a.X = B.w.x; a.Y = B.w.s; a.W = qprime; a.ld = N; a.nrhs = n;
+                a.scaled = 0; a.adjoint = 0; a.epi = EPI_RESID; a.scal = nullptr; a.part = (double *)op->d_part;
+                rc = helm_launch_apply(op, a);
+            }
             if (rc) return rc;
-            helm_launch_fin_ex(op, FIN_NORM, n, helm_apply_num_blocks(op), nullptr, B.d_aux);
+            helm_launch_fin_ex(op, FIN_NORM, n, B.nba, nullptr, B.d_aux);
             HIP_TRY(op, hipMemcpyAsync(B.h_aux, B.d_aux, 2 * n * sizeof(double), hipMemcpyDeviceToHost, op->stream));
             rc = download_scal(op, n);
             if (rc) return rc;
@@ -544,7 +616,7 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
                 }
             }
             if (!refine) break;
-            if (o.method == HELM_CGNR) {
+            if (o.method == HELM_CGNR || sys2) {
                 for (int b = 0; b < n; ++b) if (B.h_mask[b]) op->h_scal[b].status = ST_ACTIVE;
                 upload_scal(op, n);
             } else {
@@ -568,7 +640,7 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
             }
             (void)ok;
         }
-        HIP_TRY(op, hipMemcpyAsync(dXout + (long long)first * N, B.w.x, (size_t)n * N * sizeof(cplx), hipMemcpyDeviceToDevice, op->stream));
+        HIP_TRY(op, hipMemcpyAsync(dXout + (long long)first * NV, B.w.x, (size_t)n * NV * sizeof(cplx), hipMemcpyDeviceToDevice, op->stream));
         HIP_TRY(op, hipStreamSynchronize(op->stream));
     }
     return unconverged;
@@ -603,17 +675,29 @@ extern "C" int helm_solve_device(helm_op *op, const void *dRHS, void *dU, int nr
     HIP_TRY(op, hipMalloc(&dX, (size_t)nrhs * N * sizeof(cplx)));
     auto cleanup = [&]() { hipFree(dX); hipEventDestroy(e0); hipEventDestroy(e1); };
 
-    if (op->variant == HELM_MINIZEPHYR || !stacked) {
+    if (op->variant == HELM_EURUS && !op->block_zero[2]) {
+        // eps != delta: M3 != 0, the two fields are coupled -> Jacobi-BiCGSTAB on the full 2N x 2N system
+        // (eurus.py:430-464,512-533); N-row right-hand sides are zero-padded and the result clipped
+        cplx *dW = nullptr;
+        if (hipMalloc(&dW, (size_t)nrhs * 2 * N * sizeof(cplx)) != hipSuccess) { cleanup(); HELM_FAIL(op, HELM_ERR_DEVICE, "hipMalloc failed"); }
+        int rc = solve_block(op, 0, (const cplx *)dRHS, rows, 0, premul, nullptr, dW, nrhs, o, info, 1, rows);
+        if (rc >= 0) {
+            result = rc;
+            rc = helm_launch_finish_ex(op, dW, 2 * N, 0, (cplx *)dU, rows, 0, nrhs);
+            if (!rc && stacked) rc = helm_launch_finish_ex(op, dW, 2 * N, N, (cplx *)dU, rows, N, nrhs);
+            if (!rc && hipStreamSynchronize(op->stream) != hipSuccess) rc = HELM_ERR_DEVICE;
+        }
+        hipFree(dW);
+        if (rc < 0) { cleanup(); return rc; }
+    } else if (op->variant == HELM_MINIZEPHYR || !stacked) {
         // Eurus with an N-row right-hand side: zero-padded second field => v = 0 and M1 u = q
-        // provided M3 == 0 (eurus.py:512-533)
-        if (op->variant == HELM_EURUS && !op->block_zero[2]) { cleanup(); HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "Eurus with eps != delta couples both fields (M3 != 0): coupled 2N solve not available yet"); }
+        // when M3 == 0 (eurus.py:512-533)
         int rc = solve_block(op, 0, (const cplx *)dRHS, rows, 0, premul, nullptr, dX, nrhs, o, info);
         if (rc < 0) { cleanup(); return rc; }
         result = rc;
         rc = helm_launch_finish(op, dX, (cplx *)dU, rows, nrhs, 0);
         if (rc) { cleanup(); return rc; }
     } else {
-        if (!op->block_zero[2]) { cleanup(); HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "Eurus with eps != delta couples both fields (M3 != 0): coupled 2N solve not available yet"); }
         // block-triangular: v = M4^-1 q2 ; u = M1^-1 (q1 - M2 v)
         cplx *dV = nullptr, *dT = nullptr;
         if (hipMalloc(&dV, (size_t)nrhs * N * sizeof(cplx)) != hipSuccess || hipMalloc(&dT, (size_t)nrhs * N * sizeof(cplx)) != hipSuccess) {

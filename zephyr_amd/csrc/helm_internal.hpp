@@ -93,6 +93,7 @@ struct helm_op {
     int ny = 0;                  // > 0: 3-D operator on an (nz, ny, nx) grid (27 planes), 0: 2-D (9 planes)
     int nplanes = 9, centre = 4; // planes per block and index of the diagonal plane
     long long N = 0;
+    long long Nv = 0;            // length of the Krylov vectors (= N; 2N while the coupled Eurus system is being solved)
     double dx = 1, dz = 1, dy = 1;
     int fs[4] = {0, 0, 0, 0};
     hipStream_t stream = nullptr;
@@ -116,6 +117,8 @@ struct helm_op {
     cplx *d_C = nullptr;      // nblocks * 9 * N   raw planes
     cplx *d_Cs = nullptr;     // nblocks * 9 * N   planes divided by the centre plane (Jacobi-scaled)
     cplx *d_dinv = nullptr;   // nblocks * N       1 / centre plane
+    cplx *d_S = nullptr;      // coupled Eurus system: the four blocks scaled by the inverse 2-norm of their system row (36N), on demand
+    double *d_rs = nullptr;   // 2N inverse row norms of the 2N x 2N system
     bool assembled = false;
     bool block_zero[4] = {false, false, false, false};   // block is identically zero (e.g. Eurus M3 isotropic)
 
@@ -176,6 +179,8 @@ struct ApplyArgs {
     const int *tiles = nullptr;     // optional list of tile ids to process (frame tiles of the strip relaxation)
     int ntiles = 0;
     int planes_tiled = 0;           // 1: `planes` points to the tile-blocked copy of the planes
+    int acc = 0;                    // 1: y = Y_old + A x (second half of a two-block row of the coupled Eurus system)
+    int part_stride = 0, part_off = 0;   // partial-sum layout override: [rhs][q][part_stride], this launch writes at part_off + block
     int xmode = 0;                  // 1: input = omega_j dinv (.) W (also written to U), with EPI_RESID; 2: input = X + P E, with EPI_JACOBI
     cplx *U = nullptr; const cplx *E = nullptr; int nzc = 0, nxc = 0;
     int f32 = 0;                    // 1: planes / X / Y / W / dinv are single-precision complex (multigrid levels);
@@ -211,6 +216,12 @@ int helm_launch_cg_xr(helm_op *op, VecPtrs w, int nrhs);      // x += alpha p ; 
 int helm_launch_cg_p(helm_op *op, VecPtrs w, int nrhs, int first);   // p = z(s) + beta p
 // misc
 int helm_launch_finish(helm_op *op, const cplx *x, cplx *dU, long long u_ld, int nrhs, long long row_off);   // U = conj(x)
+int helm_launch_finish_ex(helm_op *op, const cplx *x, long long x_ld, long long x_off, cplx *dU, long long u_ld, long long row_off, int nrhs);
+int helm_launch_prep_rhs_ex(helm_op *op, const cplx *dRHS, long long rhs_ld, long long row_off, cplx premul, const cplx *scale,
+                            cplx *out, long long out_ld, long long out_off, int nrhs);
+int helm_launch_rowscaled_system(helm_op *op);    // d_S, d_rs
+int helm_launch_prep_rhs_rs(helm_op *op, const cplx *dRHS, long long rhs_ld, long long row_off, cplx premul, const double *rs,
+                            cplx *out, long long out_ld, long long out_off, int nrhs);
 int helm_launch_prep_rhs(helm_op *op, const cplx *dRHS, long long rhs_ld, long long row_off, cplx premul, const cplx *sub, cplx *out, int nrhs); // out = premul*rhs - sub
 int helm_launch_imaging(helm_op *op, const cplx *uf, const cplx *ub, int nsrc, const cplx *scaler, cplx *g);
 int helm_launch_zero(helm_op *op, cplx *p, long long n);

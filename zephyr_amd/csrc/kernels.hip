@@ -69,6 +69,7 @@ struct StencilParamsT {
     const int *tiles;
     int planes_tiled;     // 1: planes are stored tile-blocked, [tile][k][row in tile][64] (one contiguous 9*TZ KB chunk per tile)
     // fused multigrid stages (XMODE template parameter)
+    int acc, part_stride, part_off;
     V *U;                 // XMODE 1: the smoothed iterate u = omega_j dinv (.) W is also written here
     const V *E;           // XMODE 2: coarse-grid correction, [nrhs][nzc*nxc]; the input is X + P E (bilinear)
     int nzc, nxc;
@@ -219,6 +220,7 @@ __global__ __launch_bounds__(256) void k_stencil_t(StencilParamsT<V> q) {
             if (colok && row < nz) {
                 const long long idx = (long long)row * nx + col;
                 V y = acc[j];
+                if (q.acc) y = cadd(y, Yb[idx]);
                 if (EPI == EPI_RESID) {
                     const V w = Wb[idx];
                     y = csub(w, y);
@@ -252,11 +254,11 @@ __global__ __launch_bounds__(256) void k_stencil_t(StencilParamsT<V> q) {
         if (EPI != EPI_NONE && EPI != EPI_JACOBI && sizeof(V) == sizeof(cplx)) {   // single-precision (multigrid) launches need no partials
             block_sum<4>(dsum, red);
             if (tid == 0) {
-                double *pp = q.part + ((long long)b * 4) * q.nblk + blockIdx.x;
+                double *pp = q.part + ((long long)b * 4) * q.part_stride + q.part_off + blockIdx.x;
                 pp[0] = dsum[0];
-                pp[(long long)q.nblk] = dsum[1];
-                pp[2LL * q.nblk] = dsum[2];
-                pp[3LL * q.nblk] = dsum[3];
+                pp[(long long)q.part_stride] = dsum[1];
+                pp[2LL * q.part_stride] = dsum[2];
+                pp[3LL * q.part_stride] = dsum[3];
             }
         }
         buf ^= 1;
@@ -440,6 +442,56 @@ __global__ __launch_bounds__(256) void k_finish(const cplx *__restrict__ x, cplx
         U[(long long)b * u_ld + row_off + i] = cconj(x[(long long)b * N + i]);
 }
 
+__global__ __launch_bounds__(256) void k_finish_ex(const cplx *__restrict__ x, long long x_ld, long long x_off, cplx *__restrict__ U, long long u_ld,
+                                                   long long row_off, long long N) {
+    const int b = blockIdx.y;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x)
+        U[(long long)b * u_ld + row_off + i] = cconj(x[(long long)b * x_ld + x_off + i]);
+}
+
+// out[b*out_ld + out_off + i] = scale[i] * premul * rhs[b*rhs_ld + row_off + i]
+__global__ __launch_bounds__(256) void k_prep_rhs_ex(const cplx *__restrict__ rhs, long long rhs_ld, long long row_off, cplx premul,
+                                                     const cplx *__restrict__ scale, cplx *__restrict__ out, long long out_ld, long long out_off, long long N) {
+    const int b = blockIdx.y;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x) {
+        cplx v = cmul(premul, rhs[(long long)b * rhs_ld + row_off + i]);
+        if (scale) v = cmul(scale[i], v);
+        out[(long long)b * out_ld + out_off + i] = v;
+    }
+}
+
+// Row equilibration of the coupled two-field Eurus system [[M1, M2], [M3, M4]]: every system row is divided by its
+// 2-norm (the diagonal of M4 nearly vanishes where eps ~ delta, so Jacobi scaling is useless there).
+__global__ __launch_bounds__(256) void k_rowscale_system(const cplx *__restrict__ C, cplx *__restrict__ S, double *__restrict__ rs, long long N) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+#pragma unroll
+    for (int row = 0; row < 2; ++row) {
+        double n2 = 0.0;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) n2 += cabs2(C[((long long)(2 * row + blk) * 9 + k) * N + i]);
+        const double inv = n2 > 0.0 ? 1.0 / sqrt(n2) : 0.0;
+        rs[(long long)row * N + i] = inv;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const long long idx = ((long long)(2 * row + blk) * 9 + k) * N + i;
+                S[idx] = cscale(C[idx], inv);
+            }
+    }
+}
+
+// out[b*out_ld + out_off + i] = rs[i] * premul * rhs[b*rhs_ld + row_off + i]   (real row scale)
+__global__ __launch_bounds__(256) void k_prep_rhs_rs(const cplx *__restrict__ rhs, long long rhs_ld, long long row_off, cplx premul,
+                                                     const double *__restrict__ rs, cplx *__restrict__ out, long long out_ld, long long out_off, long long N) {
+    const int b = blockIdx.y;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x)
+        out[(long long)b * out_ld + out_off + i] = cscale(cmul(premul, rhs[(long long)b * rhs_ld + row_off + i]), rs[i]);
+}
+
 __global__ __launch_bounds__(256) void k_zero(cplx *__restrict__ p, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         p[i] = cmake(0.0, 0.0);
@@ -610,7 +662,7 @@ int helm_apply_num_blocks(const helm_op *op) {
     const int ntx = (op->nx + TX - 1) / TX, ntz = (op->nz + 4 * STENCIL_P - 1) / (4 * STENCIL_P);
     return ntx * ntz;
 }
-int helm_vec_num_blocks(const helm_op *op) { return vec_blocks(op->N); }
+int helm_vec_num_blocks(const helm_op *op) { return vec_blocks(op->Nv > 0 ? op->Nv : op->N); }
 
 template <int P, bool SCALED, bool ADJ>
 static void launch_stencil_epi(hipStream_t st, dim3 grid, const StencilParams &q, int epi) {
@@ -633,7 +685,7 @@ static int launch_apply_f32(helm_op *op, const ApplyArgs &a) {
     q.ntx = (op->nx + TX - 1) / TX; q.ntz = (op->nz + 4 * STENCIL_P - 1) / (4 * STENCIL_P);
     q.nblk = a.tiles ? a.ntiles : q.ntx * q.ntz;
     q.scal = a.scal; q.part = a.part; q.dinv = (const cplxf *)a.dinv; q.omega_j = a.omega_j; q.tiles = a.tiles; q.planes_tiled = 0;
-    q.U = (cplxf *)a.U; q.E = (const cplxf *)a.E; q.nzc = a.nzc; q.nxc = a.nxc;
+    q.U = (cplxf *)a.U; q.E = (const cplxf *)a.E; q.nzc = a.nzc; q.nxc = a.nxc; q.acc = 0; q.part_stride = q.nblk; q.part_off = 0;
     if (q.nblk < 1) return HELM_OK;
     int split = 1;
     if (q.nblk < 1024) { split = (1024 + q.nblk - 1) / q.nblk; if (split > a.nrhs) split = a.nrhs; if (split < 1) split = 1; }
@@ -677,6 +729,7 @@ int helm_launch_apply(helm_op *op, const ApplyArgs &a) {
     q.nblk = a.tiles ? a.ntiles : q.ntx * q.ntz;
     q.scal = a.scal; q.part = a.part; q.dinv = a.dinv; q.omega_j = a.omega_j; q.tiles = a.tiles; q.planes_tiled = a.planes_tiled;
     q.U = a.U; q.E = a.E; q.nzc = a.nzc; q.nxc = a.nxc;
+    q.acc = a.acc; q.part_stride = a.part_stride > 0 ? a.part_stride : q.nblk; q.part_off = a.part_off;
     if (q.nblk < 1) return HELM_OK;
     int split = 1;
     if (q.nblk < 1024) { split = (1024 + q.nblk - 1) / q.nblk; if (split > a.nrhs) split = a.nrhs; if (split < 1) split = 1; }
@@ -729,8 +782,8 @@ int helm_launch_scale_planes(helm_op *op) {
 
 int helm_launch_prep_rhs(helm_op *op, const cplx *dRHS, long long rhs_ld, long long row_off, cplx premul,
                          const cplx *sub, cplx *out, int nrhs) {
-    dim3 grid(vec_blocks(op->N), nrhs);
-    hipLaunchKernelGGL(k_prep_rhs, grid, dim3(256), 0, op->stream, dRHS, rhs_ld, row_off, premul, sub, (const cplx *)nullptr, out, op->N);
+    dim3 grid(vec_blocks(op->Nv), nrhs);
+    hipLaunchKernelGGL(k_prep_rhs, grid, dim3(256), 0, op->stream, dRHS, rhs_ld, row_off, premul, sub, (const cplx *)nullptr, out, op->Nv);
     HIP_TRY(op, hipGetLastError());
     return HELM_OK;
 }
@@ -739,10 +792,10 @@ int helm_launch_prep_rhs(helm_op *op, const cplx *dRHS, long long rhs_ld, long l
 int helm_launch_bicg_init(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, cplx premul, const cplx *sub,
                           VecPtrs w, int nrhs, double rtol) {
     // w.t temporarily receives bbar = dinv * (premul*rhs - sub); the caller copies/keeps it
-    dim3 grid(vec_blocks(op->N), nrhs);
+    dim3 grid(vec_blocks(op->Nv), nrhs);
     hipLaunchKernelGGL(k_prep_rhs, grid, dim3(256), 0, op->stream, dRHS, rhs_ld, (long long)0, premul, sub,
-                       (const cplx *)(op->d_dinv + (long long)block * op->N), w.t, op->N);
-    hipLaunchKernelGGL(k_krylov_init, grid, dim3(256), 0, op->stream, (const cplx *)w.t, w, op->N, (double *)op->d_part, (int)grid.x);
+                       (const cplx *)(op->d_dinv + (long long)block * op->N), w.t, op->Nv);
+    hipLaunchKernelGGL(k_krylov_init, grid, dim3(256), 0, op->stream, (const cplx *)w.t, w, op->Nv, (double *)op->d_part, (int)grid.x);
     FinParams f; f.scal = op->d_scal; f.part = (const double *)op->d_part; f.nblk = grid.x; f.which = FIN_BICG_INIT; f.rtol = rtol; f.mask = nullptr; f.aux = nullptr;
     hipLaunchKernelGGL(k_fin, dim3(nrhs), dim3(256), 0, op->stream, f);
     HIP_TRY(op, hipGetLastError());
@@ -751,8 +804,8 @@ int helm_launch_bicg_init(helm_op *op, int block, const cplx *dRHS, long long rh
 
 // x = 0, r = r0 = bvec, p = v = 0 and the scalar records, for a system whose right-hand side is already formed
 int helm_launch_krylov_init(helm_op *op, const cplx *bvec, VecPtrs w, int nrhs, double rtol) {
-    dim3 grid(vec_blocks(op->N), nrhs);
-    hipLaunchKernelGGL(k_krylov_init, grid, dim3(256), 0, op->stream, bvec, w, op->N, (double *)op->d_part, (int)grid.x);
+    dim3 grid(vec_blocks(op->Nv), nrhs);
+    hipLaunchKernelGGL(k_krylov_init, grid, dim3(256), 0, op->stream, bvec, w, op->Nv, (double *)op->d_part, (int)grid.x);
     FinParams f; f.scal = op->d_scal; f.part = (const double *)op->d_part; f.nblk = grid.x; f.which = FIN_BICG_INIT; f.rtol = rtol; f.mask = nullptr; f.aux = nullptr;
     hipLaunchKernelGGL(k_fin, dim3(nrhs), dim3(256), 0, op->stream, f);
     HIP_TRY(op, hipGetLastError());
@@ -760,28 +813,28 @@ int helm_launch_krylov_init(helm_op *op, const cplx *bvec, VecPtrs w, int nrhs, 
 }
 
 int helm_launch_bicg_p(helm_op *op, VecPtrs w, int nrhs) {
-    dim3 grid(vec_blocks(op->N), nrhs);
-    hipLaunchKernelGGL(k_bicg_p, grid, dim3(256), 0, op->stream, w, op->N, (const RhsScal *)op->d_scal);
+    dim3 grid(vec_blocks(op->Nv), nrhs);
+    hipLaunchKernelGGL(k_bicg_p, grid, dim3(256), 0, op->stream, w, op->Nv, (const RhsScal *)op->d_scal);
     return HELM_OK;
 }
 int helm_launch_bicg_s(helm_op *op, VecPtrs w, int nrhs) {
-    dim3 grid(vec_blocks(op->N), nrhs);
-    hipLaunchKernelGGL(k_bicg_s, grid, dim3(256), 0, op->stream, w, op->N, (const RhsScal *)op->d_scal);
+    dim3 grid(vec_blocks(op->Nv), nrhs);
+    hipLaunchKernelGGL(k_bicg_s, grid, dim3(256), 0, op->stream, w, op->Nv, (const RhsScal *)op->d_scal);
     return HELM_OK;
 }
 int helm_launch_bicg_xr(helm_op *op, VecPtrs w, const cplx *xp, const cplx *xs, int nrhs) {
-    dim3 grid(vec_blocks(op->N), nrhs);
-    hipLaunchKernelGGL(k_bicg_xr, grid, dim3(256), 0, op->stream, w, xp, xs, op->N, (const RhsScal *)op->d_scal, (double *)op->d_part, (int)grid.x);
+    dim3 grid(vec_blocks(op->Nv), nrhs);
+    hipLaunchKernelGGL(k_bicg_xr, grid, dim3(256), 0, op->stream, w, xp, xs, op->Nv, (const RhsScal *)op->d_scal, (double *)op->d_part, (int)grid.x);
     return HELM_OK;
 }
 int helm_launch_cg_xr(helm_op *op, VecPtrs w, int nrhs) {
-    dim3 grid(vec_blocks(op->N), nrhs);
-    hipLaunchKernelGGL(k_cg_xr, grid, dim3(256), 0, op->stream, w, op->N, (const RhsScal *)op->d_scal, (double *)op->d_part, (int)grid.x);
+    dim3 grid(vec_blocks(op->Nv), nrhs);
+    hipLaunchKernelGGL(k_cg_xr, grid, dim3(256), 0, op->stream, w, op->Nv, (const RhsScal *)op->d_scal, (double *)op->d_part, (int)grid.x);
     return HELM_OK;
 }
 int helm_launch_cg_p(helm_op *op, VecPtrs w, int nrhs, int first) {
-    dim3 grid(vec_blocks(op->N), nrhs);
-    hipLaunchKernelGGL(k_cg_p, grid, dim3(256), 0, op->stream, w, op->N, (const RhsScal *)op->d_scal, first);
+    dim3 grid(vec_blocks(op->Nv), nrhs);
+    hipLaunchKernelGGL(k_cg_p, grid, dim3(256), 0, op->stream, w, op->Nv, (const RhsScal *)op->d_scal, first);
     return HELM_OK;
 }
 
@@ -798,20 +851,51 @@ int helm_launch_fin_ex(helm_op *op, int which, int nrhs, int nblk_part, const in
 }
 
 int helm_launch_restart_copy_mask(helm_op *op, VecPtrs w, int nrhs, const int *mask) {
-    dim3 grid(vec_blocks(op->N), nrhs);
-    hipLaunchKernelGGL(k_restart_copy, grid, dim3(256), 0, op->stream, w, op->N, mask);
+    dim3 grid(vec_blocks(op->Nv), nrhs);
+    hipLaunchKernelGGL(k_restart_copy, grid, dim3(256), 0, op->stream, w, op->Nv, mask);
     return HELM_OK;
 }
 
 int helm_launch_norm2(helm_op *op, const cplx *a, int nrhs) {
-    dim3 grid(vec_blocks(op->N), nrhs);
-    hipLaunchKernelGGL(k_norm2, grid, dim3(256), 0, op->stream, a, op->N, (double *)op->d_part, (int)grid.x);
+    dim3 grid(vec_blocks(op->Nv), nrhs);
+    hipLaunchKernelGGL(k_norm2, grid, dim3(256), 0, op->stream, a, op->Nv, (double *)op->d_part, (int)grid.x);
     return HELM_OK;
 }
 
 int helm_launch_finish(helm_op *op, const cplx *x, cplx *dU, long long u_ld, int nrhs, long long row_off) {
+    dim3 grid(vec_blocks(op->Nv), nrhs);
+    hipLaunchKernelGGL(k_finish, grid, dim3(256), 0, op->stream, x, dU, u_ld, row_off, op->Nv);
+    HIP_TRY(op, hipGetLastError());
+    return HELM_OK;
+}
+
+int helm_launch_finish_ex(helm_op *op, const cplx *x, long long x_ld, long long x_off, cplx *dU, long long u_ld, long long row_off, int nrhs) {
     dim3 grid(vec_blocks(op->N), nrhs);
-    hipLaunchKernelGGL(k_finish, grid, dim3(256), 0, op->stream, x, dU, u_ld, row_off, op->N);
+    hipLaunchKernelGGL(k_finish_ex, grid, dim3(256), 0, op->stream, x, x_ld, x_off, dU, u_ld, row_off, op->N);
+    HIP_TRY(op, hipGetLastError());
+    return HELM_OK;
+}
+
+int helm_launch_prep_rhs_ex(helm_op *op, const cplx *dRHS, long long rhs_ld, long long row_off, cplx premul, const cplx *scale,
+                            cplx *out, long long out_ld, long long out_off, int nrhs) {
+    dim3 grid(vec_blocks(op->N), nrhs);
+    hipLaunchKernelGGL(k_prep_rhs_ex, grid, dim3(256), 0, op->stream, dRHS, rhs_ld, row_off, premul, scale, out, out_ld, out_off, op->N);
+    HIP_TRY(op, hipGetLastError());
+    return HELM_OK;
+}
+
+int helm_launch_rowscaled_system(helm_op *op) {
+    if (!op->d_S) HIP_TRY(op, hipMalloc(&op->d_S, (size_t)36 * op->N * sizeof(cplx)));
+    if (!op->d_rs) HIP_TRY(op, hipMalloc(&op->d_rs, (size_t)2 * op->N * sizeof(double)));
+    hipLaunchKernelGGL(k_rowscale_system, dim3((unsigned)((op->N + 255) / 256)), dim3(256), 0, op->stream, (const cplx *)op->d_C, op->d_S, op->d_rs, op->N);
+    HIP_TRY(op, hipGetLastError());
+    return HELM_OK;
+}
+
+int helm_launch_prep_rhs_rs(helm_op *op, const cplx *dRHS, long long rhs_ld, long long row_off, cplx premul, const double *rs,
+                            cplx *out, long long out_ld, long long out_off, int nrhs) {
+    dim3 grid(vec_blocks(op->N), nrhs);
+    hipLaunchKernelGGL(k_prep_rhs_rs, grid, dim3(256), 0, op->stream, dRHS, rhs_ld, row_off, premul, rs, out, out_ld, out_off, op->N);
     HIP_TRY(op, hipGetLastError());
     return HELM_OK;
 }
