@@ -84,6 +84,7 @@ def main():
     ap.add_argument('--rtol', type=float, default=1e-10)
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--method', default='auto')
+    ap.add_argument('--streams', type=int, default=1, help='work items in flight per GPU (host threads, one operator handle / HIP stream each)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -122,14 +123,15 @@ def main():
 
     ops = {}
 
-    def run_item(w, profile):
+    def run_item(w, profile, ubuf=None):
+        ubuf = d_u if ubuf is None else ubuf
         fi, bi = work_item(w, nb)
         sc = dict(cfg)
         sc.update(freq=float(freqs[fi]), rtol=args.rtol, maxit=400000, method=args.method, batch=B, device=local)
         op = Eurus(sc)                   # assembly on the GPU happens inside the timed region
         op.setProfiling(profile)
         rhs_ptr = d_rhs.data_ptr() + bi * B * N * 16
-        info = op.solveDevice(rhs_ptr, d_u.data_ptr(), B, N)
+        info = op.solveDevice(rhs_ptr, ubuf.data_ptr(), B, N)
         t = op.lastTiming()
         del op.factors
         return fi, info, t
@@ -147,8 +149,26 @@ def main():
     t0 = time.perf_counter()
     iters, apply_ms, apply_launches, apply_bytes, solve_ms = [], 0.0, 0, 0.0, 0.0
     freq_used = []
-    for k in range(args.steps):
-        fi, info, t = run_item(rank + world * (args.warmup + k), True)
+    results = [None] * args.steps
+    if args.streams <= 1:
+        for k in range(args.steps):
+            results[k] = run_item(rank + world * (args.warmup + k), True)
+    else:
+        # several work items in flight: each host thread drives its own operator handle (own HIP stream); ctypes
+        # releases the GIL, so the latency-bound coarse multigrid levels of one item overlap the fine levels of another
+        import threading
+        bufs = [torch.empty((B, N), dtype=torch.complex128, device=dev) for _ in range(args.streams)]
+        torch.cuda.synchronize()
+
+        def worker(tid):
+            for k in range(tid, args.steps, args.streams):
+                results[k] = run_item(rank + world * (args.warmup + k), True, bufs[tid])
+        threads = [threading.Thread(target=worker, args=(t,)) for t in range(args.streams)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+    for fi, info, t in results:
         iters += [i['iterations'] for i in info]
         freq_used.append(float(freqs[fi]))
         apply_ms += t['apply_ms']; apply_launches += t['apply_launches']; apply_bytes += t['apply_bytes']
@@ -173,7 +193,7 @@ def main():
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'Eurus 2D isotropic %dx%d synthetic-Marmousi (seed 20240512, dx=%g m), 16 freqs 2-9.5 Hz x 256 Kaiser sources; '
                                    'step = assemble 1 frequency + solve %d sources to true relres<=%g (method=%s: BiCGSTAB right-preconditioned by shifted-Laplacian multigrid with damped-Jacobi smoothing + PML line relaxation)' % (n, n, dx, B, args.rtol, args.method),
-                       'grid': [n, n], 'sources_per_step': B, 'freqs_hz_this_run': freq_used, 'sharding': 'work items (freq, source batch) round-robin over ranks',
+                       'grid': [n, n], 'sources_per_step': B, 'work_items_in_flight': args.streams, 'freqs_hz_this_run': freq_used, 'sharding': 'work items (freq, source batch) round-robin over ranks',
                        'iterations_per_rhs_mean': float(np.mean(iters)) if iters else None,
                        'iterations_per_rhs_max': int(np.max(iters)) if iters else None},
             'roofline': {'bound': 'hbm', 'kernel': 'k_stencil (batched 9-pt complex128 apply with fused dot-product epilogue), outer-iteration launches',
@@ -184,6 +204,33 @@ def main():
                          'bytes_per_launch_algorithmic': apply_bytes / apply_launches if apply_launches else None,
                          'apply_share_of_solve_time': apply_ms / solve_ms if solve_ms > 0 else None},
         }
+        # stencil-apply microbenchmark of SURVEY.md 8(d) (outside the timed region): Y = A X on random X, B right-hand sides,
+        # algorithmic bytes N*(32*B + 144), HIP events on the solver stream
+        if world == 1:
+            try:
+                import ctypes
+                from zephyr_amd import _lib
+                sc = dict(cfg); sc.update(freq=float(freqs[8]), device=local)
+                opm = Eurus(sc)
+                opm.setProfiling(True)
+                gen = torch.Generator(device=dev); gen.manual_seed(1234)
+                micro = []
+                for Bm in (1, 8, 32, 64):
+                    X = torch.randn((Bm, N, 2), dtype=torch.float64, device=dev, generator=gen)
+                    Y = torch.empty_like(X)
+                    torch.cuda.synchronize()
+                    ms = by = 0.0
+                    for rep in range(6):
+                        _lib.check(_lib.load().helm_apply_device(opm.handle, 0, 0, ctypes.c_void_p(X.data_ptr()), ctypes.c_void_p(Y.data_ptr()), Bm), opm.handle)
+                        tm = opm.lastTiming()
+                        if rep:
+                            ms += tm['apply_ms']; by += tm['apply_bytes']
+                    micro.append({'B': Bm, 'us': 1e3 * ms / 5, 'GBps': by / (ms * 1e-3) / 1e9, 'frac_of_peak': by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+                    del X, Y
+                out['roofline']['apply_microbench'] = micro
+                del opm.factors
+            except Exception as exc:          # never let the extra measurement break the bench line
+                out['roofline']['apply_microbench'] = 'failed: %s' % exc
         # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same
         # command; bench.py cannot run the profiler on itself) -- only when it was collected for this workload
         try:

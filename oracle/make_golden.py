@@ -266,6 +266,46 @@ def g8_25d():
     np.savez_compressed(os.path.join(OUT, 'g8_25d.npz'), **out)
 
 
+def ibm_to_float(words):
+    '''IBM System/360 single precision (big-endian uint32 words) -> float64'''
+    w = np.asarray(words, dtype=np.uint64)
+    sign = np.where(w >> 31, -1.0, 1.0)
+    exponent = ((w >> 24) & 0x7f).astype(np.int64) - 64
+    mantissa = (w & 0x00ffffff).astype(np.float64) / float(1 << 24)
+    return sign * mantissa * np.power(16.0, exponent)
+
+
+def g9_xhlayr():
+    '''The reference's own heterogeneous fixture: notebooks/Time Comprehensive/xhlayr.vp (SEG-Y, IBM floats,
+    100 traces x 200 samples) with the geometry of xhlayr.ini (sources at x=15, receivers at x=85, z=15..185 step 2).
+    Stores the decoded model and the reference's receiver data for a subset of sources at 100 Hz.'''
+    raw = open(os.path.join(REF, 'notebooks', 'Time Comprehensive', 'xhlayr.vp'), 'rb').read()
+    ns = int.from_bytes(raw[3220:3222], 'big'); fmt = int.from_bytes(raw[3224:3226], 'big')
+    assert ns == 200 and fmt == 1
+    ntr = (len(raw) - 3600) // (240 + 4 * ns)
+    traces = []
+    for t in range(ntr):
+        off = 3600 + t * (240 + 4 * ns) + 240
+        traces.append(ibm_to_float(np.frombuffer(raw[off:off + 4 * ns], dtype='>u4')))
+    c = np.array(traces).T                      # (nz=200, nx=100)
+    nz, nx = c.shape
+    zs = np.arange(15., 186., 2.)
+    src = np.stack([np.full(zs.size, 15.), zs], 1)[::11]       # 8 of the 86 sources
+    rec = np.stack([np.full(zs.size, 85.), zs], 1)
+    sc = dict(nx=nx, nz=nz, dx=1., dz=1., c=c, freq=100.)
+    op = zb.MiniZephyrHD(sc)
+    q = zb.SparseKaiserSource(sc)(src)
+    u = op * q
+    R = zb.SparseKaiserSource(sc)(rec).T
+    data = R * u
+    out = dict(c=c.astype(np.float64), src=src, rec=rec, freq=100., data=np.asarray(data), u_src0_col60=u[:, 0].reshape((nz, nx))[:, 60])
+    Cm = ho.minizephyr_coefficients(nz, nx, c, ho.gardner_rho(c.astype(complex)), 100.)
+    mine = ho.DirectOperator(Cm, premul=ho.premul_hd(100.)) * q
+    assert np.linalg.norm(mine - u) / np.linalg.norm(u) <= 1e-10
+    np.savez_compressed(os.path.join(OUT, 'g9_xhlayr.npz'), **out)
+    print('xhlayr model', c.min(), c.max(), 'data', np.abs(data).max())
+
+
 def g7_analytic():
     sc = dict(c=2500., rho=1., nx=100, nz=200, freq=2e2)
     out = {}
@@ -275,8 +315,8 @@ def g7_analytic():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8']
-    table = dict(g1=g1_minizephyr_planes, g2=g2_eurus_planes, g3=g3_wavefields, g4=g4_multifreq, g5=g5_sources, g6=g6_survey, g7=g7_analytic, g8=g8_25d)
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9']
+    table = dict(g1=g1_minizephyr_planes, g2=g2_eurus_planes, g3=g3_wavefields, g4=g4_multifreq, g5=g5_sources, g6=g6_survey, g7=g7_analytic, g8=g8_25d, g9=g9_xhlayr)
     for name in which:
         table[name]()
         print('wrote', name, flush=True)

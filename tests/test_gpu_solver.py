@@ -247,3 +247,16 @@ def test_eurus_tti_coupled_two_field_system(helm_lib):
     assert u2.shape == q2.shape
     assert nrm(u2, lu * q2) <= 1e-7, op.lastInfo
     assert all(i['relres'] <= 1e-10 for i in op.lastInfo)
+
+
+def test_xhlayr_fixture_on_gpu(helm_lib):
+    """the reference's heterogeneous SEG-Y fixture (decoded by oracle/make_golden.py): receiver data at 100 Hz"""
+    import zephyr_amd as za
+    g = load('g9_xhlayr.npz')
+    c = g['c']; nz, nx = c.shape
+    sc = dict(nx=nx, nz=nz, dx=1., dz=1., c=c, freq=float(g['freq']))
+    q = za.SparseKaiserSource(sc)(g['src'])
+    R = za.SparseKaiserSource(sc)(g['rec']).T
+    u = za.MiniZephyrHD(sc) * q
+    assert nrm(R @ u, g['data']) <= 1e-7
+    assert nrm(u[:, 0].reshape((nz, nx))[:, 60], g['u_src0_col60']) <= 1e-7

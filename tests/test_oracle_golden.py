@@ -137,3 +137,20 @@ def test_oracle_bicgstab_converges_to_lu():
     ref = (ho.DirectOperator(C) * q).conj()
     assert its < 20000
     assert np.linalg.norm(x - ref) / np.linalg.norm(ref) < 1e-7
+
+
+def test_xhlayr_fixture_receiver_data():
+    """the reference's own heterogeneous fixture (notebooks/Time Comprehensive/xhlayr.vp + .ini geometry), MiniZephyrHD 100 Hz"""
+    import scipy.sparse as sp
+    g = load('g9_xhlayr.npz')
+    c = g['c']; nz, nx = c.shape
+    assert (nz, nx) == (200, 100) and 1900 < c.min() < c.max() < 4100
+    C = ho.minizephyr_coefficients(nz, nx, c, ho.gardner_rho(c), float(g['freq']))
+    # sources/receivers through the product's (golden-checked) Kaiser source so that the oracle sees the same right-hand sides
+    from zephyr_amd import SparseKaiserSource
+    sc = dict(nx=nx, nz=nz, dx=1., dz=1.)
+    q = SparseKaiserSource(sc)(g['src']).toarray()
+    R = SparseKaiserSource(sc)(g['rec']).T
+    u = ho.DirectOperator(C, premul=ho.premul_hd(float(g['freq']))) * q
+    assert np.linalg.norm(R @ u - g['data']) / np.linalg.norm(g['data']) <= 1e-9
+    assert rel(u[:, 0].reshape((nz, nx))[:, 60], g['u_src0_col60']) <= 1e-9
