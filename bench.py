@@ -104,6 +104,10 @@ def main():
     dev = torch.device('cuda', local)
 
     import __graft_entry__ as g
+    if world > 1:                      # one rank checks / rebuilds the library, the others wait for it
+        if rank == 0:
+            g.build()
+        dist.barrier()
     g.build()
     from zephyr_amd import Eurus, SparseKaiserSource
 

@@ -260,3 +260,53 @@ def test_xhlayr_fixture_on_gpu(helm_lib):
     u = za.MiniZephyrHD(sc) * q
     assert nrm(R @ u, g['data']) <= 1e-7
     assert nrm(u[:, 0].reshape((nz, nx))[:, 60], g['u_src0_col60']) <= 1e-7
+
+
+@pytest.mark.parametrize('case', ['mz_freesurf', 'mz_visco_tau', 'eurus_rect', 'eurus_elliptical', 'mz_dxdz', 'eurus_small_pml'])
+def test_default_solver_is_robust_across_configurations(helm_lib, case):
+    """method='auto' (multigrid-preconditioned, with its safety net) on configurations the reference supports:
+    free surface, complex velocity + Laplace damping, rectangular grids, elliptical anisotropy, dx != dz, thin PML."""
+    import zephyr_amd as za
+    from zephyr_amd.models import marmousi_like
+    rng = np.random.default_rng(77)
+    if case == 'mz_freesurf':
+        nz, nx = 150, 230
+        c = marmousi_like(nz, nx, 10.)
+        cfg = dict(nx=nx, nz=nz, dx=10., dz=10., c=c, freq=7., freeSurf=(True, False, False, False))
+        cls, oracle = za.MiniZephyr, lambda: ho.minizephyr_coefficients(nz, nx, c, ho.gardner_rho(c), 7., dx=10., dz=10., freeSurf=(True, False, False, False))
+    elif case == 'mz_visco_tau':
+        nz, nx = 160, 160
+        cr = marmousi_like(nz, nx, 8.)
+        c = cr + 0.5j * cr / 60.
+        cfg = dict(nx=nx, nz=nz, dx=8., dz=8., c=c, rho=2000., freq=9., tau=1.5)
+        cls, oracle = za.MiniZephyrHD, lambda: ho.minizephyr_coefficients(nz, nx, c, 2000., 9., dx=8., dz=8., tau=1.5)
+    elif case == 'eurus_rect':
+        nz, nx = 120, 330
+        c = marmousi_like(nz, nx, 12.)
+        cfg = dict(nx=nx, nz=nz, dx=12., dz=12., c=c, freq=6.)
+        cls, oracle = za.Eurus, lambda: ho.eurus_coefficients(nz, nx, c, ho.gardner_rho(c), 6., dx=12., dz=12.)
+    elif case == 'eurus_elliptical':
+        nz, nx = 140, 140
+        c = marmousi_like(nz, nx, 10.)
+        d = 0.15 * rng.random((nz, nx)); th = 0.4 * rng.random((nz, nx)) - 0.2
+        cfg = dict(nx=nx, nz=nz, dx=10., dz=10., c=c, freq=8., eps=d, delta=d, theta=th)
+        cls, oracle = za.Eurus, lambda: ho.eurus_coefficients(nz, nx, c, ho.gardner_rho(c), 8., dx=10., dz=10., eps=d, delta=d, theta=th)
+    elif case == 'mz_dxdz':
+        nz, nx = 130, 170
+        c = marmousi_like(nz, nx, 10.)
+        cfg = dict(nx=nx, nz=nz, dx=12., dz=8., c=c, rho=1800., freq=8., nPML=14)
+        cls, oracle = za.MiniZephyr, lambda: ho.minizephyr_coefficients(nz, nx, c, 1800., 8., dx=12., dz=8., nPML=14)
+    else:
+        nz, nx = 128, 128
+        c = marmousi_like(nz, nx, 10.)
+        cfg = dict(nx=nx, nz=nz, dx=10., dz=10., c=c, freq=10., nPML=5, cPML=400.)
+        cls, oracle = za.Eurus, lambda: ho.eurus_coefficients(nz, nx, c, ho.gardner_rho(c), 10., dx=10., dz=10., nPML=5, cPML=400.)
+    locs = np.array([[0.3 * nx * cfg['dx'], 0.15 * nz * cfg['dz']], [0.7 * nx * cfg['dx'], 0.6 * nz * cfg['dz']]])
+    q = za.SparseKaiserSource(cfg)(locs).toarray()
+    op = cls(cfg)
+    u = op * q
+    C = oracle()
+    premul = complex(op.premul)
+    ref = ho.DirectOperator(C, premul=premul, eurus=(cls is za.Eurus)) * q
+    assert nrm(u, ref) <= 1e-7, op.lastInfo
+    assert max(i['iterations'] for i in op.lastInfo) < 20000, op.lastInfo
