@@ -73,6 +73,61 @@ def cpu_baseline(cfg, freqs, q_host, sample_rhs=8):
                        % (f, t1 - t0, t2 - t1, sample_rhs, t_rhs, os.cpu_count())), u
 
 
+def _pool_worker(job):
+    '''one frequency of the CPU path in its own process (spawned: no GPU state is inherited)'''
+    n, dx, f, nsolve = job
+    import numpy as _np
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=1)
+    except Exception:
+        pass
+    from oracle import helm_oracle as ho
+    from zephyr_amd.models import marmousi_like
+    t0 = time.perf_counter()
+    c = marmousi_like(n, n, dx)
+    C4 = ho.eurus_coefficients(n, n, c, ho.gardner_rho(c), f, dx=dx, dz=dx, nPML=10, cPML=1e3)
+    op = ho.DirectOperator(C4[0])
+    op.factor()
+    t1 = time.perf_counter()
+    q = _np.zeros((n * n, nsolve), complex)
+    q[2 * n + n // 2 + _np.arange(nsolve) * 7, _np.arange(nsolve)] = 1.
+    op * q
+    t2 = time.perf_counter()
+    return (t1 - t0, (t2 - t1) / nsolve)
+
+
+def cpu_baseline_pool(cfg, freqs, nproc=16, nsolve=4):
+    '''The reference's MultiFreq pool mode (distributors.py:92-96,161-168): one process per frequency, all 16
+    frequencies of the job factored concurrently, single-thread SuperLU each.'''
+    import multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    jobs = [(cfg['nx'], cfg['dx'], float(f), nsolve) for f in freqs[:nproc]]
+    # the children must come up with single-thread BLAS: limiting after scipy's OpenBLAS has spun up its
+    # threads in 16 processes at once oversubscribes the host badly enough to look like a hang
+    keys = ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS')
+    saved = {k: os.environ.get(k) for k in keys}
+    for k in keys:
+        os.environ[k] = '1'
+    t0 = time.perf_counter()
+    try:
+        with ctx.Pool(len(jobs)) as pool:
+            res = pool.map_async(_pool_worker, jobs).get(timeout=600)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    wall = time.perf_counter() - t0
+    setup = max(r[0] for r in res); per_rhs = max(r[1] for r in res)
+    wps = len(jobs) * NSRC / (setup + NSRC * per_rhs)
+    return dict(value=wps, unit='wavefields/s', cores=len(jobs), kind='port',
+                sample='%d frequencies of the %d^2 job in %d concurrent single-thread processes (the reference MultiFreq pool mode): slowest assemble+factor %.1fs, '
+                       'slowest back-substitution %.3fs per source (%d measured), extrapolated to 256 sources per frequency; wall of the sample %.1fs'
+                       % (len(jobs), cfg['nx'], len(jobs), setup, per_rhs, nsolve, wall))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -83,6 +138,7 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='sources per work item')
     ap.add_argument('--rtol', type=float, default=1e-10)
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
+    ap.add_argument('--cpu-pool', action='store_true', help='also time the 16-process CPU pool mode (adds ~1 min)')
     ap.add_argument('--method', default='auto')
     ap.add_argument('--streams', type=int, default=1, help='work items in flight per GPU (host threads, one operator handle / HIP stream each)')
     args = ap.parse_args()
@@ -247,6 +303,11 @@ def main():
         if world == 1 and not args.no_cpu:
             cb, _ = cpu_baseline(cfg, freqs, q_all)
             out['cpu_baseline'] = cb
+            if args.cpu_pool and (os.cpu_count() or 1) >= 32:
+                try:
+                    out['cpu_baseline_pool'] = cpu_baseline_pool(cfg, freqs)
+                except Exception as exc:
+                    out['cpu_baseline_pool'] = 'failed: %s' % exc
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
