@@ -306,6 +306,75 @@ def g9_xhlayr():
     print('xhlayr model', c.min(), c.max(), 'data', np.abs(data).max())
 
 
+def g10_omega():
+    """OMEGA project I/O and the `zephyr model` job (db.py:35-66,81-271; util.py:21-157; jobs.py:88-207), and Jvec
+    (problem.py:87-122), run through the reference.  The project files xhlayr.ini / xhlayr.vp are data fixtures of the
+    reference (notebooks/Time Comprehensive) and are copied next to the vectors."""
+    import shutil, tempfile, builtins
+    np.float = float                                    # db.py:179 uses the alias numpy 2 removed
+    builtins.unicode = str                              # db.py:124
+    builtins.xrange = range                             # problem.py:101
+    from zephyr.middleware import util as zu, db as zdb
+    from zephyr.middleware import Helm2DViscoProblem, Helm2DProblem, Helm2DSurvey
+    src_dir = os.path.join(REF, 'notebooks', 'Time Comprehensive')
+    fx = os.path.join(OUT, 'xhlayr')
+    os.makedirs(fx, exist_ok=True)
+    for fn in ('xhlayr.ini', 'xhlayr.vp'):
+        shutil.copyfile(os.path.join(src_dir, fn), os.path.join(fx, fn))
+        os.chmod(os.path.join(fx, fn), 0o644)
+    ini = zu.readini(os.path.join(fx, 'xhlayr.ini'))
+    out = {}
+    for k, v in ini.items():
+        if isinstance(v, (int, float, bool, np.ndarray)):
+            out['ini_' + k] = np.asarray(v)
+        elif isinstance(v, list) and v and isinstance(v[0], int):
+            out['ini_' + k] = np.asarray(v)
+    out['ini_strings'] = np.array([ini['datain'], ini['dataout'], ini['we']])
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    try:
+        for fn in ('xhlayr.ini', 'xhlayr.vp'):
+            shutil.copyfile(os.path.join(fx, fn), os.path.join(tmp, fn))
+        os.chdir(tmp)
+        ds = zdb.FullwvDatastore('xhlayr')
+        sc = ds.systemConfig
+        out['sc_c'] = np.asarray(sc['c'], dtype=np.float64)
+        out['sc_freqs'] = np.asarray(sc['freqs'])
+        out['sc_src'] = sc['geom']['src']; out['sc_rec'] = sc['geom']['rec']
+        out['sc_scalars'] = np.array([sc['nx'], sc['nz'], sc['dx'], sc['dz'], sc['xorig'], sc['zorig'], sc['nky'], sc['ireg'], sc['freqBase'], sc['tau']], dtype=np.float64)
+        out['sc_freeSurf'] = np.array(sc['freeSurf'])
+        # the OmegaJob pipeline (jobs.py:88-127,202-207) on three of the project's frequencies and every 6th source
+        fid = [9, 19, 29]
+        sc2 = dict(sc, freqs=[float(sc['freqs'][i]) for i in fid], Disc=zb.MiniZephyrHD, parallel=False,
+                   geom=dict(src=sc['geom']['src'][::6], rec=sc['geom']['rec'], mode='fixed'))
+        prob, surv = Helm2DViscoProblem(sc2), Helm2DSurvey(sc2)
+        prob.pair(surv)
+        data = surv.dpred()
+        data.shape = (surv.nrec, surv.nsrc, surv.nfreq)
+        zdb.UtoutWriter(sc2)(data)
+        out['job_fid'] = np.array(fid); out['job_src_step'] = 6
+        out['job_data'] = data
+        out['job_utout'] = np.frombuffer(open('xhlayr.utout', 'rb').read(), dtype=np.uint8)
+        # damped variant of the writer: omega + i/tau in column 0
+        zdb.UtoutWriter(dict(sc2, tau=0.4))(data, ftype='utdamp')
+        out['job_utout_tau'] = np.frombuffer(open('xhlayr.utdamp', 'rb').read(), dtype=np.uint8)
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp)
+    # Jvec on the g6 survey (fixed geometry)
+    g6 = np.load(os.path.join(OUT, 'g6_survey.npz'))
+    sc6 = dict(nx=80, nz=60, dx=10., dz=10., c=g6['c'], rho=g6['rho'], nPML=6, freqs=[6., 9., 14.], Disc=zb.MiniZephyrHD, parallel=False,
+               sterms=g6['sterms'], geom=dict(src=g6['src'], rec=g6['rec'], mode='fixed'))
+    prob, surv = Helm2DProblem(sc6), Helm2DSurvey(sc6)
+    prob.pair(surv)
+    rng = np.random.default_rng(77)
+    v = rng.standard_normal(60 * 80) * 30.
+    out['jvec_v'] = v
+    out['jvec'] = prob.Jvec(None, v)
+    np.savez_compressed(os.path.join(OUT, 'g10_omega.npz'), **out)
+    print('g10: ini nom', ini['nom'], 'utout bytes', out['job_utout'].size, '|Jvec|', np.abs(out['jvec']).max())
+
+
 def g7_analytic():
     sc = dict(c=2500., rho=1., nx=100, nz=200, freq=2e2)
     out = {}
@@ -315,8 +384,8 @@ def g7_analytic():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9']
-    table = dict(g1=g1_minizephyr_planes, g2=g2_eurus_planes, g3=g3_wavefields, g4=g4_multifreq, g5=g5_sources, g6=g6_survey, g7=g7_analytic, g8=g8_25d, g9=g9_xhlayr)
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10']
+    table = dict(g1=g1_minizephyr_planes, g2=g2_eurus_planes, g3=g3_wavefields, g4=g4_multifreq, g5=g5_sources, g6=g6_survey, g7=g7_analytic, g8=g8_25d, g9=g9_xhlayr, g10=g10_omega)
     for name in which:
         table[name]()
         print('wrote', name, flush=True)

@@ -104,6 +104,11 @@ class HelmBaseProblem(BaseModelDependent, BaseSCCache):
         omega, c = self.scaledTerms(ifreq)
         return self.survey.postProcessors[ifreq](-(omega ** 2 / c ** 3).ravel())
 
+    def sensScaler(self, ifreq):
+        'problem.py:83-85'
+        omega, c = self.scaledTerms(ifreq)
+        return self.survey.postProcessors[ifreq](-(c ** 3 / omega ** 2).ravel())
+
     # ---- forward -----------------------------------------------------------------------------------------
     def lazyFields(self, m=None):
         'generator of forward wavefields (N, nsrc) for the owned frequencies, in frequency order (problem.py:166-179)'
@@ -120,6 +125,33 @@ class HelmBaseProblem(BaseModelDependent, BaseSCCache):
         self.updateModel(m)
         qf = self.survey.getSources()
         return list(self.system * qf)
+
+    # ---- sensitivity times vector ------------------------------------------------------------------------
+    def Jvec(self, m=None, v=None, u=None):
+        """Data perturbation for a model perturbation v (problem.py:87-122): one virtual source
+        `v * (-c^3/omega^2)` per frequency is solved, and dpert[:, :, f] is the outer product of the
+        receiver and source samplings of that field.  Fixed receiver arrays only: the reference's
+        relative-geometry branch multiplies mismatched shapes (problem.py:117-120)."""
+        if not self.ispaired:
+            raise Exception('%s instance is not paired to a survey' % (self.__class__.__name__,))
+        if v is None:
+            raise Exception('Actually, Jvec requires a perturbation vector')
+        self.updateModel(m)
+        sv = self.survey
+        if sv.mode != 'fixed':
+            raise ValueError('dimension mismatch')
+        perturb = np.asarray(v).reshape((self.nz * self.nx, 1))
+        qv = [sv.preProcessors[i](perturb * self.sensScaler(i).reshape((self.nz * self.nx, 1))) for i in range(sv.nfreq)]
+        qf = sv.getSources()
+        owned = self.ownedFreqs
+        dpert = np.zeros((sv.nrec, sv.nsrc, sv.nfreq), dtype=np.complex128)
+        for ifreq, uFreq in self._solveOwned(qv):
+            srcTerms = qf[ifreq].T * uFreq
+            recTerms = sv.rVec(0) * uFreq
+            dpert[:, :, ifreq] = np.asarray(recTerms).reshape((sv.nrec, 1)) * np.asarray(srcTerms).reshape((1, sv.nsrc))
+        if len(owned) != sv.nfreq:
+            dpert = parallel.allreduce_sum(dpert)
+        return dpert.ravel()
 
     # ---- gradient ----------------------------------------------------------------------------------------
     def Jtvec(self, m=None, v=None, u=None):
