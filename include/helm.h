@@ -51,8 +51,12 @@ enum {
     HELM_BICGSTAB = 0,   /* Jacobi-preconditioned BiCGSTAB */
     HELM_CGNR = 1,       /* Jacobi-scaled CGNR */
     HELM_AUTO = 2,       /* HELM_MG where available, else BiCGSTAB; CGNR for right-hand sides that break down */
-    HELM_MG = 3          /* BiCGSTAB right-preconditioned by shifted-Laplacian multigrid (damped-Jacobi smoothing)
+    HELM_MG = 3,         /* BiCGSTAB right-preconditioned by shifted-Laplacian multigrid (damped-Jacobi smoothing)
                             + PML strip line relaxation */
+    HELM_DIRECT = 4      /* sparse direct: nested-dissection multifrontal factorisation kept on the handle until the next
+                            helm_assemble and re-used for every right-hand side (what the reference's sparse LU does,
+                            discretization.py:78-103), plus iterative refinement with the stencil kernel to rtol.
+                            2-D single-block systems only (MiniZephyr; Eurus with eps == delta) */
 };
 
 /* hard errors */
@@ -66,7 +70,7 @@ enum {
 };
 
 typedef struct helm_solve_opts {
-    int method;        /* HELM_BICGSTAB | HELM_CGNR | HELM_AUTO */
+    int method;        /* HELM_BICGSTAB | HELM_CGNR | HELM_AUTO | HELM_MG | HELM_DIRECT */
     double rtol;       /* stop when ||q' - A u||_2 / ||q'||_2 <= rtol (q' = premul*rhs), per RHS */
     int maxit;         /* iteration cap per right-hand side */
     int check_every;   /* iterations between host-side convergence checks (0 = default) */
@@ -75,7 +79,7 @@ typedef struct helm_solve_opts {
 } helm_solve_opts;
 
 typedef struct helm_solve_info {
-    int iterations;    /* iterations used by this right-hand side */
+    int iterations;    /* iterations used by this right-hand side (HELM_DIRECT: triangular solves incl. refinement) */
     int status;        /* 0 converged, 1 iteration cap, 2 breakdown (not recovered) */
     int restarts;      /* BiCGSTAB restarts taken */
     int method;        /* method that produced the returned wavefield */
@@ -143,6 +147,10 @@ typedef struct helm_timing {
     double apply_ms;
     long long apply_launches;
     double apply_bytes;      /* sum over launches of N*(32*B + 144) */
+    double factor_ms;        /* HELM_DIRECT: factorisation time when this solve had to factor, else 0 */
+    double gemm_ms;          /* HELM_DIRECT: ms / launches / flops (8 M N K per batch item) of the dense complex GEMM kernel */
+    long long gemm_launches;
+    double gemm_flops;
 } helm_timing;
 int helm_last_timing(const helm_op *op, helm_timing *out);
 /* enable per-launch HIP-event timing of the stencil kernel inside solves (costs a little) */
@@ -153,6 +161,18 @@ int helm_set_profiling(helm_op *op, int on);
  * problem.py:152).  scaler: N complex (= -w^2/c^3).  All device pointers. */
 int helm_imaging_accumulate_device(helm_op *op, const void *dUF, const void *dUB, int nsrc,
                                    const void *dScaler, void *dG);
+
+/* --- diagnostics of the direct solver ---------------------------------------------------- */
+/* Elimination-tree plan of an (nz, nx) grid (host only, no GPU needed).  out == NULL: returns the number of fronts;
+ * else writes 12 ints per front in processing order {z0, z1, x0, x1, cut, pos, s, m, kid0, kid1, smax, mmax}. */
+int helm_direct_plan(int nz, int nx, int leaf, int *out, int cap);
+/* cells (z*nx + x) of front `node` in local order [separator | ring]; returns s + m, or < 0 if the closed-form
+ * index maps disagree with each other */
+int helm_direct_plan_front(int nz, int nx, int leaf, int node, long long *cells, int cap);
+/* dense kernels on host data (row-major complex128, batch contiguous): C = beta C + alpha A B; in-place inverse */
+int helm_debug_zgemm(int device, int M, int N, int K, const double *alpha, const double *A, const double *B,
+                     const double *beta, double *C, int batch);
+int helm_debug_inverse(int device, int n, double *A, int batch);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,112 @@
+"""GPU: the sparse direct path (direct.hip) -- dense kernels against numpy, wavefields against sparse LU and the
+reference's golden vectors, factor re-use, refinement and error conventions."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from oracle import helm_oracle as ho
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def nrm(a, b):
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+def crand(rng, *shape):
+    return rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+
+
+@pytest.mark.parametrize('M,N,K,batch', [(64, 64, 8, 1), (36, 256, 64, 7), (1, 1, 1, 3), (65, 67, 9, 2), (130, 33, 71, 3), (9, 256, 9, 40)])
+def test_batched_zgemm(helm_lib, M, N, K, batch):
+    rng = np.random.default_rng(M * 7 + N)
+    A, B, C = crand(rng, batch, M, K), crand(rng, batch, K, N), crand(rng, batch, M, N)
+    for alpha, beta in ((1 + 0j, 0j), (-1 + 0j, 1 + 0j), (0.3 - 0.2j, 0.5 + 0.1j)):
+        ref = alpha * (A @ B) + (beta * C if beta != 0 else 0)
+        out = np.ascontiguousarray(C if beta != 0 else np.full_like(C, np.nan))     # beta == 0 must not read C
+        al, be = np.array([alpha.real, alpha.imag]), np.array([beta.real, beta.imag])
+        rc = helm_lib.helm_debug_zgemm(0, M, N, K, al.ctypes.data_as(ctypes.c_void_p), np.ascontiguousarray(A).ctypes.data_as(ctypes.c_void_p),
+                                       np.ascontiguousarray(B).ctypes.data_as(ctypes.c_void_p), be.ctypes.data_as(ctypes.c_void_p),
+                                       out.ctypes.data_as(ctypes.c_void_p), batch)
+        assert rc == 0
+        assert np.abs(out - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()) * K
+
+
+@pytest.mark.parametrize('n,batch', [(1, 2), (5, 3), (32, 4), (33, 2), (64, 5), (100, 2), (257, 1)])
+def test_batched_inverse(helm_lib, n, batch):
+    rng = np.random.default_rng(n)
+    A = crand(rng, batch, n, n) + 2.0 * np.sqrt(n) * np.eye(n)        # leading blocks comfortably invertible
+    if n == 5:
+        A[0, 0, 0] = 0.0                                              # forces a row exchange in the base block
+    out = np.ascontiguousarray(A.copy())
+    assert helm_lib.helm_debug_inverse(0, n, out.ctypes.data_as(ctypes.c_void_p), batch) == 0
+    for b in range(batch):
+        assert np.abs(out[b] @ A[b] - np.eye(n)).max() <= 1e-10
+
+
+@pytest.mark.parametrize('cls', ['MiniZephyr', 'Eurus'])
+@pytest.mark.parametrize('nz,nx', [(64, 64), (70, 90), (41, 150), (9, 9)])
+def test_direct_matches_sparse_lu(helm_lib, cls, nz, nx):
+    import zephyr_amd as za
+    rng = np.random.default_rng(nz + nx)
+    c = 1800. + 2200. * rng.random((nz, nx))
+    rho = 1000. + 600. * rng.random((nz, nx))
+    npml = 8 if min(nz, nx) > 20 else 2
+    cfg = dict(nx=nx, nz=nz, dx=10., dz=10., c=c, rho=rho, freq=9., nPML=npml, rtol=1e-11, method='direct')
+    src = np.stack([np.linspace(20., 10. * nx - 30., 5), np.linspace(15., 10. * nz - 25., 5)], 1)
+    q = za.SimpleSource(cfg)(src)
+    op = getattr(za, cls)(cfg)
+    u = op * q
+    if cls == 'MiniZephyr':
+        ref = ho.DirectOperator(ho.minizephyr_coefficients(nz, nx, c, rho, 9., dx=10., dz=10., nPML=npml)) * q
+    else:
+        ref = ho.DirectOperator(ho.eurus_coefficients(nz, nx, c, rho, 9., dx=10., dz=10., nPML=npml), eurus=True) * q
+    assert nrm(u, ref) <= 1e-9, op.lastInfo
+    assert all(i['status'] == 0 and i['relres'] <= 1e-11 and i['method'] == 4 and 1 <= i['iterations'] <= 4 for i in op.lastInfo)
+    t = op.lastTiming()
+    assert t['factor_ms'] > 0
+    u2 = op * q                              # factors are kept on the handle
+    assert op.lastTiming()['factor_ms'] == 0
+    assert np.array_equal(u, u2)             # and the path is bit-reproducible
+
+
+def test_direct_golden_wavefields_and_stacked_eurus(helm_lib):
+    import zephyr_amd as za
+    g = np.load(os.path.join(GOLD, 'g9_xhlayr.npz'))
+    nz, nx = g['c'].shape
+    sc = dict(nx=nx, nz=nz, dx=1., dz=1., c=g['c'], freq=float(g['freq']), method='direct', rtol=1e-11)
+    op = za.MiniZephyrHD(sc)
+    u = op * za.SparseKaiserSource(sc)(g['src'])
+    R = za.SparseKaiserSource(sc)(g['rec']).T
+    assert nrm(R * u, g['data']) <= 1e-8
+    # Eurus, 2N-row stacked right-hand side: block-triangular solve with two factorisations (M4 then M1)
+    nz, nx = 48, 56
+    rng = np.random.default_rng(5)
+    c = 2000. + 1000. * rng.random((nz, nx))
+    cfg = dict(nx=nx, nz=nz, dx=10., dz=10., c=c, freq=8., nPML=6, method='direct', rtol=1e-11)
+    q = np.zeros((2 * nz * nx, 2), complex)
+    q[20 * nx + 30, 0] = 1.0; q[nz * nx + 25 * nx + 12, 1] = 1.0; q[nz * nx + 10 * nx + 40, 0] = 0.5
+    op = za.Eurus(cfg)
+    u = op * q
+    ref = ho.DirectOperator(ho.eurus_coefficients(nz, nx, c, ho.gardner_rho(c.astype(complex)), 8., dx=10., dz=10., nPML=6), eurus=True) * q
+    assert nrm(u, ref) <= 1e-8
+
+
+def test_direct_new_frequency_refactors_and_unsupported_cases(helm_lib):
+    import zephyr_amd as za
+    nz, nx = 40, 44
+    c = np.full((nz, nx), 2500.)
+    cfg = dict(nx=nx, nz=nz, dx=10., dz=10., c=c, freq=6., nPML=6, method='direct')
+    q = za.SimpleSource(cfg)(np.array([[200., 210.]]))
+    dist = za.MultiFreq(dict(cfg, Disc=za.MiniZephyr, freqs=[6., 11.]))
+    us = list(dist * q)
+    for f, u in zip((6., 11.), us):
+        ref = ho.DirectOperator(ho.minizephyr_coefficients(nz, nx, c, ho.gardner_rho(c.astype(complex)), f, dx=10., dz=10., nPML=6)) * q
+        assert nrm(u, ref) <= 1e-9
+    # coupled TTI system: not a single-block system
+    tti = dict(cfg, theta=np.full((nz, nx), 0.3), eps=np.full((nz, nx), 0.2), delta=np.full((nz, nx), 0.05))
+    with pytest.raises(Exception):
+        za.Eurus(tti) * q

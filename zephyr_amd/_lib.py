@@ -12,8 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libhelm.so')
 
 HELM_MINIZEPHYR, HELM_EURUS, HELM_3D = 0, 1, 2
-HELM_BICGSTAB, HELM_CGNR, HELM_AUTO, HELM_MG = 0, 1, 2, 3
-METHODS = {'bicgstab': HELM_BICGSTAB, 'cgnr': HELM_CGNR, 'auto': HELM_AUTO, 'mg': HELM_MG}
+HELM_BICGSTAB, HELM_CGNR, HELM_AUTO, HELM_MG, HELM_DIRECT = 0, 1, 2, 3, 4
+METHODS = {'bicgstab': HELM_BICGSTAB, 'cgnr': HELM_CGNR, 'auto': HELM_AUTO, 'mg': HELM_MG, 'direct': HELM_DIRECT}
 
 ERRORS = {-1: 'HELM_ERR_ARG', -2: 'HELM_ERR_DEVICE', -3: 'HELM_ERR_STATE', -4: 'HELM_ERR_UNSUPPORTED', -5: 'HELM_ERR_PML'}
 
@@ -36,7 +36,9 @@ class SolveInfo(ctypes.Structure):
 
 class Timing(ctypes.Structure):
     _fields_ = [('solve_ms', ctypes.c_double), ('apply_ms', ctypes.c_double),
-                ('apply_launches', ctypes.c_longlong), ('apply_bytes', ctypes.c_double)]
+                ('apply_launches', ctypes.c_longlong), ('apply_bytes', ctypes.c_double),
+                ('factor_ms', ctypes.c_double), ('gemm_ms', ctypes.c_double),
+                ('gemm_launches', ctypes.c_longlong), ('gemm_flops', ctypes.c_double)]
 
 
 # every symbol include/helm.h declares, with its ctypes signature
@@ -68,6 +70,11 @@ _SIGNATURES = {
     'helm_set_profiling': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'helm_imaging_accumulate_device': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                                       ctypes.c_void_p, ctypes.c_void_p]),
+    'helm_direct_plan': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]),
+    'helm_direct_plan_front': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]),
+    'helm_debug_zgemm': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
+    'helm_debug_inverse': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]),
 }
 
 _lib = None

@@ -3,6 +3,7 @@
 // The drivers only enqueue kernels: all vectors and all scalar recurrences stay on the device;
 // the host looks at the per-RHS status records every `check_every` iterations.
 #include "helm_internal.hpp"
+#include "direct.hpp"
 #include <cstring>
 #include <algorithm>
 #include <limits>
@@ -80,6 +81,7 @@ extern "C" void helm_destroy(helm_op *op) {
     hipFree(op->d_c); hipFree(op->d_rho); hipFree(op->d_theta); hipFree(op->d_eps); hipFree(op->d_delta);
     hipFree(op->d_C); hipFree(op->d_Cs); hipFree(op->d_dinv); hipFree(op->d_S); hipFree(op->d_rs);
     if (op->mg) mg_destroy(op);
+    for (int b = 0; b < 4; ++b) { nd_free(op->direct[b]); op->direct[b] = nullptr; }
     hipFree(op->d_ws); hipFree(op->d_part); hipFree(op->d_scal);
     if (op->h_scal) hipHostFree(op->h_scal);
     for (hipEvent_t e : op->ev_pool) hipEventDestroy(e);
@@ -158,6 +160,8 @@ extern "C" int helm_assemble(helm_op *op, double freq_re, double freq_im, double
     op->assembled = true;
     op->a_freq_re = freq_re; op->a_freq_im = freq_im; op->a_tau = tau; op->a_ky = ky; op->a_cpml = cPML;
     if (op->mg) mg_destroy(op);      // preconditioner belongs to the previous frequency
+    for (int b = 0; b < 4; ++b) { nd_free(op->direct[b]); op->direct[b] = nullptr; }   // and so do the direct factors
+    op->direct_failed = false;
     return HELM_OK;
 }
 
@@ -199,7 +203,9 @@ static int ensure_part(helm_op *op, int nrhs) {
 static void timing_begin(helm_op *op) {
     op->ev_used = 0;
     op->ev_pending.clear();
+    op->ev_pending_gemm.clear();
     op->timing.apply_ms = 0; op->timing.apply_launches = 0; op->timing.apply_bytes = 0;
+    op->timing.factor_ms = 0; op->timing.gemm_ms = 0; op->timing.gemm_launches = 0; op->timing.gemm_flops = 0;
 }
 static void timing_collect(helm_op *op) {
     for (auto &pr : op->ev_pending) {
@@ -209,6 +215,13 @@ static void timing_collect(helm_op *op) {
         }
     }
     op->ev_pending.clear();
+    for (auto &pr : op->ev_pending_gemm) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, op->ev_pool[pr.first], op->ev_pool[pr.first + 1]) == hipSuccess) {
+            op->timing.gemm_ms += ms; op->timing.gemm_launches += 1; op->timing.gemm_flops += pr.second;
+        }
+    }
+    op->ev_pending_gemm.clear();
     op->ev_used = 0;
 }
 
@@ -453,12 +466,109 @@ struct NvGuard {     // Krylov vector length of the handle for the duration of a
     ~NvGuard() { op->Nv = old; }
 };
 
+
+// Sparse direct path (direct.hip): factor once per assembled operator, then per batch q' -> x by the multifrontal
+// triangular solves and iterative refinement on the true residual q' - A x (stencil kernel) until rtol is met.
+int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long long row_off, cplx premul,
+                       const cplx *sub, cplx *dXout, int nrhs, const helm_solve_opts &o, helm_solve_info *info) {
+    const long long N = op->N;
+    if ((long long)((N + 31) / 32) > 65535) HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "direct solver: grid too large (more than 2M cells)");
+    int rc;
+    if (!op->direct[block]) {
+        const char *e = getenv("HELM_ND_LEAF");
+        const int leaf = e ? std::max(2, atoi(e)) : 8;
+        hipEvent_t f0, f1;
+        HIP_TRY(op, hipEventCreate(&f0)); HIP_TRY(op, hipEventCreate(&f1));
+        hipEventRecord(f0, op->stream);
+        NdFactor *f = nullptr;
+        rc = nd_factor(op, block, leaf, &f);
+        hipEventRecord(f1, op->stream);
+        hipEventSynchronize(f1);
+        float ms = 0.f; hipEventElapsedTime(&ms, f0, f1);
+        hipEventDestroy(f0); hipEventDestroy(f1);
+        if (rc) return rc;
+        op->direct[block] = f;
+        op->timing.factor_ms += ms;
+    }
+    NdFactor *f = op->direct[block];
+    const long long per_rhs = nd_solve_ws_elems(f->plan, 1) + 3 * N;
+    int Bmax = o.batch > 0 ? o.batch : 256;
+    if (Bmax > nrhs) Bmax = nrhs;
+    const char *capenv = getenv("HELM_ND_WS_GB");
+    const double cap = (capenv ? atof(capenv) : 32.0) * 1e9;
+    while (Bmax > 1 && (double)per_rhs * Bmax * sizeof(cplx) > cap) Bmax = (Bmax + 1) / 2;
+    rc = ensure_ws(op, (size_t)per_rhs * Bmax * sizeof(cplx));
+    if (rc) return rc;
+    rc = ensure_part(op, Bmax);
+    if (rc) return rc;
+    const int nblk = std::max(2 * helm_apply_num_blocks(op), helm_vec_num_blocks(op));
+    char *ptail = (char *)op->d_part + (size_t)Bmax * 4 * nblk * sizeof(double);
+    double *d_aux = (double *)ptail;
+    char *htail = (char *)op->h_scal + (size_t)op->scal_cap * sizeof(RhsScal);
+    double *h_aux = (double *)htail;
+    const int max_refine = 3;
+    int unconverged = 0;
+    for (int first = 0; first < nrhs; first += Bmax) {
+        const int n = std::min(Bmax, nrhs - first);
+        cplx *q = (cplx *)op->d_ws, *x = q + (long long)Bmax * N, *r = q + 2LL * Bmax * N, *nws = q + 3LL * Bmax * N;
+        const cplx *rhs_b = dRHS + (long long)first * rhs_ld;
+        const cplx *sub_b = sub ? sub + (long long)first * N : nullptr;
+        rc = helm_launch_prep_rhs(op, rhs_b, rhs_ld, row_off, premul, sub_b, q, n);
+        if (rc) return rc;
+        helm_launch_norm2(op, q, n);
+        helm_launch_fin_ex(op, FIN_NORM, n, helm_vec_num_blocks(op), nullptr, d_aux + n);
+        HIP_TRY(op, hipMemcpyAsync(x, q, (size_t)n * N * sizeof(cplx), hipMemcpyDeviceToDevice, op->stream));
+        rc = nd_solve(op, f, x, n, nws);
+        if (rc) return rc;
+        std::vector<double> relres(n, 0.0);
+        int solves = 1;
+        for (int round = 0; ; ++round) {
+            ApplyArgs a = ApplyArgs();
+            a.planes = op->d_C + (long long)block * op->nplanes * N; a.X = x; a.Y = r; a.W = q; a.ld = N; a.nrhs = n;
+            a.scaled = 0; a.adjoint = 0; a.epi = EPI_RESID; a.scal = nullptr; a.part = (double *)op->d_part;
+            rc = helm_launch_apply(op, a);
+            if (rc) return rc;
+            helm_launch_fin_ex(op, FIN_NORM, n, helm_apply_num_blocks(op), nullptr, d_aux);
+            HIP_TRY(op, hipMemcpyAsync(h_aux, d_aux, 2 * n * sizeof(double), hipMemcpyDeviceToHost, op->stream));
+            HIP_TRY(op, hipStreamSynchronize(op->stream));
+            bool all_ok = true;
+            for (int b = 0; b < n; ++b) {
+                const double qq = h_aux[n + b];
+                relres[b] = qq > 0 ? sqrt(h_aux[b] / qq) : 0.0;
+                if (!(relres[b] <= o.rtol)) all_ok = false;
+            }
+            if (all_ok || round >= max_refine) break;
+            rc = nd_solve(op, f, r, n, nws);       // dx = A^-1 r
+            if (rc) return rc;
+            nd_axpy_one(op, x, r, (long long)n * N);
+            solves += 1;
+        }
+        for (int b = 0; b < n; ++b) {
+            const bool ok = relres[b] <= o.rtol * 1.0000001;
+            if (!ok) unconverged += 1;
+            if (info) {
+                helm_solve_info &I = info[first + b];
+                I.iterations += solves; I.method = HELM_DIRECT;
+                I.relres = std::max(I.relres, relres[b]);
+                I.status = std::max(I.status, ok ? 0 : 1);
+            }
+        }
+        HIP_TRY(op, hipMemcpyAsync(dXout + (long long)first * N, x, (size_t)n * N * sizeof(cplx), hipMemcpyDeviceToDevice, op->stream));
+        HIP_TRY(op, hipStreamSynchronize(op->stream));
+    }
+    return unconverged;
+}
+
 // sys2 != 0: the coupled two-field Eurus system (block ignored, vectors [u; v] of length 2N, rows_in = N or 2N rows of
 // right-hand side per source; sub unused); dXout then holds 2N values per right-hand side.
 int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long long row_off, cplx premul,
                 const cplx *sub, cplx *dXout, int nrhs, const helm_solve_opts &o, helm_solve_info *info,
                 int sys2 = 0, long long rows_in = 0) {
     const long long N = op->N;
+    if (o.method == HELM_DIRECT) {
+        if (sys2 || op->ny > 0) HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "the direct solver handles 2-D single-block systems only (not the coupled TTI system, not 3-D)");
+        return solve_block_direct(op, block, dRHS, rhs_ld, row_off, premul, sub, dXout, nrhs, o, info);
+    }
     const long long NV = sys2 ? 2 * N : N;
     NvGuard guard(op, NV);
     int Bmax = o.batch > 0 ? o.batch : 16;

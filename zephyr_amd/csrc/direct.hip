@@ -1,0 +1,636 @@
+// Sparse direct solver for the 2-D 9-point operators: geometric nested dissection + multifrontal
+// factorisation with explicit front inverses, batched level by level.
+//
+// What it replaces: the reference hands A to a sparse LU (`problemo.BestSolver` -> SuperLU,
+// zephyr/backend/discretization.py:78-103) and re-uses the factors for every source.  This is the same
+// idea laid out for the GPU: the elimination tree of a regular grid is known in closed form, every front of
+// one tree level has the same (padded) shape, so each level is a handful of strided-batched dense kernels.
+//
+//   tree      recursive bisection of the (nz, nx) rectangle by one-cell-wide separator lines (a one-cell line
+//             separates a 9-point stencil); regions with both sides <= LEAF are eliminated whole.
+//   front     [separator cells | ring of cells around the subtree's region] -- the ring cells are exactly the
+//             ancestors' separator cells the subtree touches.  Index <-> cell maps are closed-form (nd_local /
+//             nd_cell), so no index lists are stored.
+//   factor    F11^-1 (recursive 2x2 block inversion on batched GEMMs, 32x32 Gauss-Jordan base with row pivoting),
+//             G21 = F21 F11^-1, Schur S = F22 - G21 F12 extend-added into the parent (child 0 then child 1:
+//             deterministic).
+//   solve     forward: front-local vectors travel up the tree exactly like the Schur complements;
+//             backward: x_S = F11^-1 (y_S - F12 x_B), top-down.  Pure GEMMs on node-major right-hand sides
+//             X[cell][rhs], no atomics, bit-reproducible.
+//   accuracy  pivoting is confined to the 32x32 base blocks, so one or two steps of iterative refinement with
+//             the stencil kernel (capi.hip) bring the residual to the requested tolerance.
+//
+// All dense arithmetic is fp64 complex on the vector ALUs (MI355X: fp64 MFMA rate == fp64 vector FMA rate, so
+// MFMA buys nothing here); the solve phase is bound by reading the factors and the right-hand sides from HBM.
+#include "helm_internal.hpp"
+#include "direct.hpp"
+#include <algorithm>
+
+namespace {
+
+// ---- plan ------------------------------------------------------------------------------------------------------
+struct Build {
+    int nz, nx, leaf;
+    std::vector<NdDev> nodes;      // creation order
+    std::vector<int> level;
+    std::vector<int> parent;
+};
+
+void fill_geometry(NdDev &n, int nz, int nx) {
+    const int h = n.z1 - n.z0, w = n.x1 - n.x0;
+    n.s = n.cut < 0 ? h * w : (n.cut == 0 ? w : h);
+    n.xlo = std::max(n.x0 - 1, 0);
+    const int xhi = std::min(n.x1, nx - 1);
+    const int wrow = xhi - n.xlo + 1;
+    n.ntop = n.z0 > 0 ? wrow : 0;
+    n.nbot = n.z1 < nz ? wrow : 0;
+    n.nleft = n.x0 > 0 ? h : 0;
+    n.nright = n.x1 < nx ? h : 0;
+    n.m = n.ntop + n.nbot + n.nleft + n.nright;
+}
+
+int build_rec(Build &B, int z0, int z1, int x0, int x1, int lev, int parent) {
+    NdDev n = NdDev();
+    n.z0 = z0; n.z1 = z1; n.x0 = x0; n.x1 = x1; n.kid[0] = n.kid[1] = -1;
+    const int h = z1 - z0, w = x1 - x0;
+    const int me = (int)B.nodes.size();
+    if (h <= B.leaf && w <= B.leaf) { n.cut = -1; n.pos = -1; }
+    else if (h >= w) { n.cut = 0; n.pos = z0 + h / 2; }
+    else { n.cut = 1; n.pos = x0 + w / 2; }
+    fill_geometry(n, B.nz, B.nx);
+    B.nodes.push_back(n); B.level.push_back(lev); B.parent.push_back(parent);
+    if (n.cut == 0) {
+        int k = 0;
+        if (n.pos > z0) { int c = build_rec(B, z0, n.pos, x0, x1, lev + 1, me); B.nodes[me].kid[k++] = c; }
+        if (z1 > n.pos + 1) { int c = build_rec(B, n.pos + 1, z1, x0, x1, lev + 1, me); B.nodes[me].kid[k++] = c; }
+    } else if (n.cut == 1) {
+        int k = 0;
+        if (n.pos > x0) { int c = build_rec(B, z0, z1, x0, n.pos, lev + 1, me); B.nodes[me].kid[k++] = c; }
+        if (x1 > n.pos + 1) { int c = build_rec(B, z0, z1, n.pos + 1, x1, lev + 1, me); B.nodes[me].kid[k++] = c; }
+    }
+    return me;
+}
+
+}  // namespace
+
+int nd_build_plan(NdPlan &P, int nz, int nx, int leaf) {
+    Build B; B.nz = nz; B.nx = nx; B.leaf = std::max(2, leaf);
+    build_rec(B, 0, nz, 0, nx, 0, -1);
+    const int nn = (int)B.nodes.size();
+    int maxlev = 0;
+    for (int l : B.level) maxlev = std::max(maxlev, l);
+    // processing order: deepest level first; within a level the leaves, then the separators
+    std::vector<int> order; order.reserve(nn);
+    P.groups.clear();
+    for (int lev = maxlev; lev >= 0; --lev)
+        for (int kind = 0; kind < 2; ++kind) {
+            NdGroup g = NdGroup(); g.first = (int)order.size(); g.level = lev; g.leaf = kind == 0;
+            for (int i = 0; i < nn; ++i)
+                if (B.level[i] == lev && (B.nodes[i].cut < 0) == (kind == 0)) {
+                    order.push_back(i);
+                    g.smax = std::max(g.smax, B.nodes[i].s); g.mmax = std::max(g.mmax, B.nodes[i].m);
+                }
+            g.cnt = (int)order.size() - g.first;
+            if (g.cnt > 0) P.groups.push_back(g);
+        }
+    std::vector<int> newidx(nn);
+    for (int k = 0; k < nn; ++k) newidx[order[k]] = k;
+    P.nodes.resize(nn);
+    for (int k = 0; k < nn; ++k) {
+        NdDev n = B.nodes[order[k]];
+        for (int c = 0; c < 2; ++c) if (n.kid[c] >= 0) n.kid[c] = newidx[n.kid[c]];
+        P.nodes[k] = n;
+    }
+    P.nz = nz; P.nx = nx; P.leaf = B.leaf; P.nlevels = maxlev + 1;
+    // arenas: fronts (factor) and front vectors (solve) of level L live in region L % 2
+    std::vector<long long> lev_f(maxlev + 1, 0), lev_v(maxlev + 1, 0);
+    long long fac = 0;
+    for (size_t gi = 0; gi < P.groups.size(); ++gi) {
+        NdGroup &g = P.groups[gi];
+        const long long nmax = g.smax + g.mmax;
+        g.foff = lev_f[g.level]; g.voff = lev_v[g.level];
+        lev_f[g.level] += (long long)g.cnt * nmax * nmax;
+        lev_v[g.level] += (long long)g.cnt * nmax;
+        g.finv = fac; fac += (long long)g.cnt * g.smax * g.smax;
+        g.g21 = fac; fac += (long long)g.cnt * g.mmax * g.smax;
+        g.f12 = fac; fac += (long long)g.cnt * g.smax * g.mmax;
+    }
+    P.fac_elems = fac;
+    P.fregion = 0; P.vregion = 0; P.work_elems = 0;
+    for (int l = 0; l <= maxlev; ++l) { P.fregion = std::max(P.fregion, lev_f[l]); P.vregion = std::max(P.vregion, lev_v[l]); }
+    for (size_t gi = 0; gi < P.groups.size(); ++gi) {
+        NdGroup &g = P.groups[gi];
+        g.foff += (long long)(g.level & 1) * P.fregion;
+        g.voff += (long long)(g.level & 1) * P.vregion;
+        P.work_elems = std::max(P.work_elems, (long long)g.cnt * g.smax * g.smax);
+        for (int j = 0; j < g.cnt; ++j) {
+            NdDev &n = P.nodes[g.first + j];
+            const long long nmax = g.smax + g.mmax;
+            n.smax = g.smax; n.mmax = g.mmax;
+            n.foff = g.foff + (long long)j * nmax * nmax;
+            n.voff = g.voff + (long long)j * nmax;
+        }
+    }
+    return HELM_OK;
+}
+
+// ---- kernels ---------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void k_nd_assemble(const NdDev *nodes, int first, cplx *arenaF, const cplx *planes, int nz, int nx) {
+    const NdDev n = nodes[first + blockIdx.y];
+    cplx *F = arenaF + n.foff;
+    const int ld = n.smax + n.mmax;
+    const long long N = (long long)nz * nx;
+    const int tot = n.s + n.m;
+    for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < n.smax; a += gridDim.x * blockDim.x)
+        if (a >= n.s) F[(long long)a * ld + a] = cmake(1.0, 0.0);     // padded separator slots: identity
+    for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < tot; a += gridDim.x * blockDim.x) {
+        int z, x;
+        nd_cell(n, a, z, x);
+        const long long ra = nd_pos(n, a);
+        #pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int z2 = z + k / 3 - 1, x2 = x + k % 3 - 1;
+            if (z2 < 0 || z2 >= nz || x2 < 0 || x2 >= nx) continue;
+            const int b = nd_local(n, nz, nx, z2, x2);
+            if (b < 0 || (a >= n.s && b >= n.s)) continue;            // ring x ring entries belong to an ancestor
+            F[ra * ld + nd_pos(n, b)] = planes[(long long)k * N + (long long)z * nx + x];
+        }
+    }
+}
+
+// parent front += Schur complement of child `slot` (rows of the child's F22 spread over gridDim.x blocks)
+__global__ __launch_bounds__(256) void k_nd_extend_add(const NdDev *nodes, int first, int slot, cplx *arenaF, int nz, int nx) {
+    extern __shared__ int map[];
+    const NdDev p = nodes[first + blockIdx.y];
+    if (p.kid[slot] < 0) return;
+    const NdDev c = nodes[p.kid[slot]];
+    for (int a = threadIdx.x; a < c.m; a += blockDim.x) {
+        int z, x;
+        nd_cell(c, c.s + a, z, x);
+        map[a] = nd_pos(p, nd_local(p, nz, nx, z, x));
+    }
+    __syncthreads();
+    const cplx *Fc = arenaF + c.foff;
+    cplx *Fp = arenaF + p.foff;
+    const int ldc = c.smax + c.mmax, ldp = p.smax + p.mmax;
+    for (int a = blockIdx.x; a < c.m; a += gridDim.x) {
+        const cplx *src = Fc + (long long)(c.smax + a) * ldc + c.smax;
+        cplx *dst = Fp + (long long)map[a] * ldp;
+        for (int b = threadIdx.x; b < c.m; b += blockDim.x) {
+            cplx v = dst[map[b]];
+            dst[map[b]] = cadd(v, src[b]);
+        }
+    }
+}
+
+// ---- strided-batched complex GEMM: C = beta C + alpha A B, row-major ----------------------------------------------
+// 64x64 tile, K step 8, 256 threads each owning a 4x4 block; the next K slab is fetched into registers while the
+// current one is multiplied out of LDS.
+#define GB_M 64
+#define GB_N 64
+#define GB_K 8
+__global__ __launch_bounds__(256) void k_zgemm(int M, int Nn, int K, cplx alpha, const cplx *A0, int lda, long long sa,
+                                               const cplx *B0, int ldb, long long sb, cplx beta, cplx *C0, int ldc, long long sc) {
+    __shared__ cplx As[GB_K][GB_M + 1];
+    __shared__ cplx Bs[GB_K][GB_N];
+    const cplx *A = A0 + (long long)blockIdx.z * sa;
+    const cplx *B = B0 + (long long)blockIdx.z * sb;
+    cplx *C = C0 + (long long)blockIdx.z * sc;
+    const int m0 = blockIdx.y * GB_M, n0 = blockIdx.x * GB_N;
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    // loader roles: A slab 64 rows x 8 k (2 elements per thread), B slab 8 k x 64 cols (2 per thread)
+    const int ar = tid >> 3, ak = tid & 7;          // rows ar and ar+32
+    const int bk = tid >> 6, bc = tid & 63;         // k rows bk and bk+4
+    cplx acc[4][4];
+    #pragma unroll
+    for (int i = 0; i < 4; ++i)
+        #pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = cmake(0.0, 0.0);
+    cplx ra0, ra1, rb0, rb1;
+    const cplx zero = cmake(0.0, 0.0);
+    auto fetch = [&](int k0) {
+        const int kk = k0 + ak;
+        ra0 = (m0 + ar < M && kk < K) ? A[(long long)(m0 + ar) * lda + kk] : zero;
+        ra1 = (m0 + ar + 32 < M && kk < K) ? A[(long long)(m0 + ar + 32) * lda + kk] : zero;
+        rb0 = (k0 + bk < K && n0 + bc < Nn) ? B[(long long)(k0 + bk) * ldb + n0 + bc] : zero;
+        rb1 = (k0 + bk + 4 < K && n0 + bc < Nn) ? B[(long long)(k0 + bk + 4) * ldb + n0 + bc] : zero;
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += GB_K) {
+        As[ak][ar] = ra0; As[ak][ar + 32] = ra1;
+        Bs[bk][bc] = rb0; Bs[bk + 4][bc] = rb1;
+        __syncthreads();
+        if (k0 + GB_K < K) fetch(k0 + GB_K);
+        #pragma unroll
+        for (int k = 0; k < GB_K; ++k) {
+            cplx a[4], b[4];
+            #pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[k][ty * 4 + i];
+            #pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = Bs[k][tx * 4 + j];
+            #pragma unroll
+            for (int i = 0; i < 4; ++i)
+                #pragma unroll
+                for (int j = 0; j < 4; ++j) cfma(acc[i][j], a[i], b[j]);
+        }
+        __syncthreads();
+    }
+    const bool b0 = (beta.x == 0.0 && beta.y == 0.0);
+    #pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = m0 + ty * 4 + i;
+        if (r >= M) continue;
+        #pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cc = n0 + tx * 4 + j;
+            if (cc >= Nn) continue;
+            cplx v = cmul(alpha, acc[i][j]);
+            if (!b0) v = cadd(v, cmul(beta, C[(long long)r * ldc + cc]));
+            C[(long long)r * ldc + cc] = v;
+        }
+    }
+}
+
+// ---- in-place inverse of n x n blocks, n <= 32: Gauss-Jordan with row pivoting in LDS, one workgroup per matrix ----
+#define GJ_MAX 32
+__global__ __launch_bounds__(256) void k_gj_inverse(cplx *A0, int ld, long long stride, int n) {
+    __shared__ cplx a[GJ_MAX][GJ_MAX + 1];
+    __shared__ cplx fcol[GJ_MAX];
+    __shared__ int piv[GJ_MAX];
+    cplx *A = A0 + (long long)blockIdx.x * stride;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < n * n; e += 256) a[e / n][e % n] = A[(long long)(e / n) * ld + e % n];
+    __syncthreads();
+    for (int k = 0; k < n; ++k) {
+        if (tid < 64) {
+            double val = (tid >= k && tid < n) ? cabs2(a[tid][k]) : -1.0;
+            int idx = tid;
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ov = __shfl_down(val, off);
+                const int oi = __shfl_down(idx, off);
+                if (ov > val) { val = ov; idx = oi; }
+            }
+            if (tid == 0) piv[k] = idx;
+        }
+        __syncthreads();
+        const int p = piv[k];
+        if (p != k && tid < n) { cplx t = a[k][tid]; a[k][tid] = a[p][tid]; a[p][tid] = t; }
+        __syncthreads();
+        const cplx d = crecip(a[k][k]);
+        if (tid < n) fcol[tid] = a[tid][k];
+        __syncthreads();
+        if (tid < n) a[k][tid] = (tid == k) ? d : cmul(a[k][tid], d);
+        __syncthreads();
+        for (int e = tid; e < n * n; e += 256) {
+            const int i = e / n, j = e % n;
+            if (i == k) continue;
+            cplx base = (j == k) ? cmake(0.0, 0.0) : a[i][j];
+            a[i][j] = csub(base, cmul(fcol[i], a[k][j]));
+        }
+        __syncthreads();
+    }
+    for (int k = n - 1; k >= 0; --k) {
+        const int p = piv[k];
+        if (p != k && tid < n) { cplx t = a[tid][k]; a[tid][k] = a[tid][p]; a[tid][p] = t; }
+        __syncthreads();
+    }
+    for (int e = tid; e < n * n; e += 256) A[(long long)(e / n) * ld + e % n] = a[e / n][e % n];
+}
+
+__global__ void k_copy2d(const cplx *src, int lds_, long long ss, cplx *dst, int ldd, long long sd, int rows, int cols) {
+    const cplx *s = src + (long long)blockIdx.z * ss;
+    cplx *d = dst + (long long)blockIdx.z * sd;
+    for (int r = blockIdx.y; r < rows; r += gridDim.y)
+        for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x)
+            d[(long long)r * ldd + c] = s[(long long)r * lds_ + c];
+}
+
+// ---- solve-phase data movement -----------------------------------------------------------------------------------
+// out[i][r] = in[r][i]   (in: rows x cols)
+__global__ __launch_bounds__(256) void k_transpose(const cplx *in, long long rows, long long cols, cplx *out) {
+    __shared__ cplx t[32][33];
+    const long long c0 = (long long)blockIdx.x * 32, r0 = (long long)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8)
+        if (r0 + j < rows && c0 + tx < cols) t[j][tx] = in[(r0 + j) * cols + c0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < cols && r0 + tx < rows) out[(c0 + j) * rows + r0 + tx] = t[tx][j];
+}
+
+// V[row][r] for the padded front vector of every node of a group: separator rows <- Xt, everything else <- 0 (mode 0);
+// mode 1 additionally fills the ring rows from Xt (backward pass)
+__global__ __launch_bounds__(256) void k_nd_vec_gather(const NdDev *nodes, int first, cplx *arenaV, const cplx *Xt, int nrhs, int nx, int mode) {
+    const NdDev n = nodes[first + blockIdx.y];
+    cplx *V = arenaV + n.voff * nrhs;
+    const int nmax = n.smax + n.mmax;
+    for (int row = blockIdx.x; row < nmax; row += gridDim.x) {
+        int a = -1;
+        if (row < n.s) a = row;
+        else if (mode == 1 && row >= n.smax && row - n.smax < n.m) a = n.s + row - n.smax;
+        cplx *dst = V + (long long)row * nrhs;
+        if (a >= 0) {
+            int z, x;
+            nd_cell(n, a, z, x);
+            const cplx *src = Xt + ((long long)z * nx + x) * nrhs;
+            for (int r = threadIdx.x; r < nrhs; r += blockDim.x) dst[r] = src[r];
+        } else {
+            for (int r = threadIdx.x; r < nrhs; r += blockDim.x) dst[r] = cmake(0.0, 0.0);
+        }
+    }
+}
+
+// parent vector += outgoing ring part of child `slot`
+__global__ __launch_bounds__(256) void k_nd_vec_extend_add(const NdDev *nodes, int first, int slot, cplx *arenaV, int nrhs, int nz, int nx) {
+    const NdDev p = nodes[first + blockIdx.y];
+    if (p.kid[slot] < 0) return;
+    const NdDev c = nodes[p.kid[slot]];
+    const cplx *Vc = arenaV + c.voff * nrhs;
+    cplx *Vp = arenaV + p.voff * nrhs;
+    for (int a = blockIdx.x; a < c.m; a += gridDim.x) {
+        int z, x;
+        nd_cell(c, c.s + a, z, x);
+        const int row = nd_pos(p, nd_local(p, nz, nx, z, x));
+        const cplx *src = Vc + (long long)(c.smax + a) * nrhs;
+        cplx *dst = Vp + (long long)row * nrhs;
+        for (int r = threadIdx.x; r < nrhs; r += blockDim.x) dst[r] = cadd(dst[r], src[r]);
+    }
+}
+
+// Xt[separator cells] <- rows [0, s) of a per-node buffer with `rows_per_node` rows
+__global__ __launch_bounds__(256) void k_nd_vec_store(const NdDev *nodes, int first, const cplx *buf, long long group_off, int rows_per_node,
+                                                      cplx *Xt, int nrhs, int nx) {
+    const NdDev n = nodes[first + blockIdx.y];
+    const cplx *V = buf + (group_off + (long long)blockIdx.y * rows_per_node) * nrhs;
+    for (int a = blockIdx.x; a < n.s; a += gridDim.x) {
+        int z, x;
+        nd_cell(n, a, z, x);
+        cplx *dst = Xt + ((long long)z * nx + x) * nrhs;
+        const cplx *src = V + (long long)a * nrhs;
+        for (int r = threadIdx.x; r < nrhs; r += blockDim.x) dst[r] = src[r];
+    }
+}
+
+// y += x  (refinement update), n elements
+__global__ void k_axpy_one(cplx *y, const cplx *x, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] = cadd(y[i], x[i]);
+}
+
+// op may be null (diagnostic entry points): default stream, no profiling
+int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, long long sa, const cplx *B, int ldb, long long sb,
+         cplx beta, cplx *C, int ldc, long long sc, int batch) {
+    if (M <= 0 || Nn <= 0 || batch <= 0) return 0;
+    hipStream_t st = op ? op->stream : nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (op && op->profiling) {
+        if (op->ev_used + 2 > op->ev_pool.size() && op->ev_pool.size() < 16384)
+            for (int i = 0; i < 64; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; op->ev_pool.push_back(e); }
+        if (op->ev_used + 2 <= op->ev_pool.size()) { e0 = op->ev_pool[op->ev_used]; e1 = op->ev_pool[op->ev_used + 1]; }
+    }
+    if (e0) hipEventRecord(e0, st);
+    for (int b0 = 0; b0 < batch; b0 += 65535) {
+        const int nb = std::min(65535, batch - b0);
+        dim3 grid((Nn + GB_N - 1) / GB_N, (M + GB_M - 1) / GB_M, nb);
+        hipLaunchKernelGGL(k_zgemm, grid, dim3(256), 0, st, M, Nn, K, alpha, A + b0 * sa, lda, sa, B + b0 * sb, ldb, sb, beta, C + b0 * sc, ldc, sc);
+    }
+    if (e0) {
+        hipEventRecord(e1, st);
+        op->ev_pending_gemm.push_back(std::make_pair((int)op->ev_used, 8.0 * M * (double)Nn * K * batch));
+        op->ev_used += 2;
+    }
+    return 0;
+}
+
+// in-place inverse of `batch` n x n blocks (row-major, leading dimension ld, batch stride `stride`); W: workspace with
+// batch stride ws, at least n*n elements per matrix
+void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cplx *W, long long ws) {
+    hipStream_t st = op ? op->stream : nullptr;
+    if (n <= GJ_MAX) {
+        for (int b0 = 0; b0 < batch; b0 += 1 << 20) {
+            const int nb = std::min(1 << 20, batch - b0);
+            hipLaunchKernelGGL(k_gj_inverse, dim3(nb), dim3(256), 0, st, M + b0 * stride, ld, stride, n);
+        }
+        return;
+    }
+    const int s1 = n / 2, s2 = n - s1;
+    cplx *A = M, *B = M + s1, *C = M + (long long)s1 * ld, *D = M + (long long)s1 * ld + s1;
+    cplx *T1 = W, *T2 = W + (long long)s1 * s2, *Wn = W + 2LL * s1 * s2;
+    const cplx one = cmake(1, 0), mone = cmake(-1, 0), zero = cmake(0, 0);
+    invert(op, A, ld, stride, s1, batch, Wn, ws);
+    gemm(op, s2, s1, s1, one, C, ld, stride, A, ld, stride, zero, T1, s1, ws, batch);       // T1 = C A^-1
+    gemm(op, s2, s2, s1, mone, T1, s1, ws, B, ld, stride, one, D, ld, stride, batch);       // D  = D - T1 B  (Schur)
+    invert(op, D, ld, stride, s2, batch, Wn, ws);
+    gemm(op, s1, s2, s1, one, A, ld, stride, B, ld, stride, zero, T2, s2, ws, batch);       // T2 = A^-1 B
+    gemm(op, s1, s2, s2, mone, T2, s2, ws, D, ld, stride, zero, B, ld, stride, batch);      // B  = -T2 S^-1
+    gemm(op, s2, s1, s2, mone, D, ld, stride, T1, s1, ws, zero, C, ld, stride, batch);      // C  = -S^-1 T1
+    gemm(op, s1, s1, s2, mone, B, ld, stride, T1, s1, ws, one, A, ld, stride, batch);       // A  = A^-1 - B T1
+}
+
+}  // namespace
+
+// ---- factorisation ---------------------------------------------------------------------------------------------
+void nd_free(NdFactor *f) {
+    if (!f) return;
+    if (f->d_nodes) hipFree(f->d_nodes);
+    if (f->d_fac) hipFree(f->d_fac);
+    delete f;
+}
+
+int nd_factor(helm_op *op, int block, int leaf, NdFactor **out) {
+    NdFactor *f = new NdFactor();
+    nd_build_plan(f->plan, op->nz, op->nx, leaf);
+    NdPlan &P = f->plan;
+    hipStream_t st = op->stream;
+    cplx *arenaF = nullptr, *work = nullptr;
+    auto fail = [&](const char *what, hipError_t e) {
+        char b[256]; snprintf(b, sizeof(b), "direct solver: %s failed: %s", what, hipGetErrorString(e)); helm_set_error(op, b);
+        if (arenaF) hipFree(arenaF);
+        if (work) hipFree(work);
+        nd_free(f);
+        return HELM_ERR_DEVICE;
+    };
+    hipError_t e;
+    if ((e = hipMalloc((void **)&f->d_nodes, P.nodes.size() * sizeof(NdDev))) != hipSuccess) return fail("hipMalloc(nodes)", e);
+    if ((e = hipMemcpyAsync(f->d_nodes, P.nodes.data(), P.nodes.size() * sizeof(NdDev), hipMemcpyHostToDevice, st)) != hipSuccess) return fail("upload", e);
+    if ((e = hipMalloc((void **)&f->d_fac, (size_t)P.fac_elems * sizeof(cplx))) != hipSuccess) return fail("hipMalloc(factors)", e);
+    if ((e = hipMalloc((void **)&arenaF, (size_t)2 * P.fregion * sizeof(cplx))) != hipSuccess) return fail("hipMalloc(fronts)", e);
+    if ((e = hipMalloc((void **)&work, (size_t)P.work_elems * sizeof(cplx))) != hipSuccess) return fail("hipMalloc(work)", e);
+    const cplx *planes = op->d_C + (long long)block * op->nplanes * op->N;
+    const cplx one = cmake(1, 0), mone = cmake(-1, 0), zero = cmake(0, 0);
+    double flops = 0;
+    for (size_t gi = 0; gi < P.groups.size(); ++gi) {
+        const NdGroup &g = P.groups[gi];
+        const int nmax = g.smax + g.mmax;
+        const long long fs = (long long)nmax * nmax;
+        cplx *F = arenaF + g.foff;
+        if ((e = hipMemsetAsync(F, 0, (size_t)g.cnt * fs * sizeof(cplx), st)) != hipSuccess) return fail("memset", e);
+        for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
+            const int nb = std::min(65535, g.cnt - j0);
+            hipLaunchKernelGGL(k_nd_assemble, dim3((nmax + 255) / 256, nb), dim3(256), 0, st, f->d_nodes, g.first + j0, arenaF, planes, op->nz, op->nx);
+        }
+        if (!g.leaf) {
+            // children's ring sizes are bounded by this group's front size
+            const size_t shm = (size_t)(2 * nmax + 8) * sizeof(int);
+            for (int slot = 0; slot < 2; ++slot)
+                for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
+                    const int nb = std::min(65535, g.cnt - j0);
+                    const int rb = std::max(1, std::min(nmax, 16384 / std::max(1, nb)));
+                    hipLaunchKernelGGL(k_nd_extend_add, dim3(rb, nb), dim3(256), shm, st, f->d_nodes, g.first + j0, slot, arenaF, op->nz, op->nx);
+                }
+        }
+        invert(op, F, nmax, fs, g.smax, g.cnt, work, (long long)g.smax * g.smax);
+        cplx *Finv = f->d_fac + g.finv, *G21 = f->d_fac + g.g21, *F12 = f->d_fac + g.f12;
+        const int zb = std::min(g.cnt, 65535);
+        for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
+            const int nb = std::min(65535, g.cnt - j0);
+            hipLaunchKernelGGL(k_copy2d, dim3((g.smax + 63) / 64, std::min(g.smax, 64), nb), dim3(64), 0, st,
+                               F + j0 * fs, nmax, fs, Finv + (long long)j0 * g.smax * g.smax, g.smax, (long long)g.smax * g.smax, g.smax, g.smax);
+            if (g.mmax > 0)
+                hipLaunchKernelGGL(k_copy2d, dim3((g.mmax + 63) / 64, std::min(g.smax, 64), nb), dim3(64), 0, st,
+                                   F + j0 * fs + g.smax, nmax, fs, F12 + (long long)j0 * g.smax * g.mmax, g.mmax, (long long)g.smax * g.mmax, g.smax, g.mmax);
+        }
+        (void)zb;
+        if (g.mmax > 0) {
+            // G21 = F21 F11^-1 ; F22 -= G21 F12
+            gemm(op, g.mmax, g.smax, g.smax, one, F + (long long)g.smax * nmax, nmax, fs, F, nmax, fs, zero, G21, g.smax, (long long)g.mmax * g.smax, g.cnt);
+            gemm(op, g.mmax, g.mmax, g.smax, mone, G21, g.smax, (long long)g.mmax * g.smax, F + g.smax, nmax, fs, one,
+                 F + (long long)g.smax * nmax + g.smax, nmax, fs, g.cnt);
+        }
+        flops += (double)g.cnt * 8.0 * (2.0 * g.smax * g.smax * g.smax + (double)g.smax * g.smax * g.mmax + (double)g.smax * g.mmax * g.mmax);
+    }
+    e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) return fail("factorisation kernels", e);
+    hipFree(arenaF); hipFree(work);
+    f->block = block; f->flops = flops;
+    *out = f;
+    return HELM_OK;
+}
+
+// ---- solve: X (nrhs x N, each right-hand side contiguous) -> solution in place --------------------------------------
+// ws: workspace of nd_solve_ws_elems(plan, nrhs) elements
+long long nd_solve_ws_elems(const NdPlan &P, int nrhs) { return ((long long)P.nz * P.nx + 2 * P.vregion) * nrhs; }
+
+int nd_solve(helm_op *op, NdFactor *f, cplx *X, int nrhs, cplx *ws) {
+    const NdPlan &P = f->plan;
+    hipStream_t st = op->stream;
+    const long long N = (long long)P.nz * P.nx;
+    cplx *Xt = ws, *arenaV = ws + N * nrhs;
+    const cplx one = cmake(1, 0), mone = cmake(-1, 0), zero = cmake(0, 0);
+    hipLaunchKernelGGL(k_transpose, dim3((unsigned)((N + 31) / 32), (nrhs + 31) / 32), dim3(256), 0, st, X, (long long)nrhs, N, Xt);
+    // forward elimination, leaves to root
+    for (size_t gi = 0; gi < P.groups.size(); ++gi) {
+        const NdGroup &g = P.groups[gi];
+        const int nmax = g.smax + g.mmax;
+        cplx *V = arenaV + g.voff * nrhs;
+        for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
+            const int nb = std::min(65535, g.cnt - j0);
+            hipLaunchKernelGGL(k_nd_vec_gather, dim3(std::min(nmax, 128), nb), dim3(256), 0, st, f->d_nodes, g.first + j0, arenaV, Xt, nrhs, P.nx, 0);
+        }
+        if (!g.leaf) {
+            for (int slot = 0; slot < 2; ++slot)
+                for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
+                    const int nb = std::min(65535, g.cnt - j0);
+                    hipLaunchKernelGGL(k_nd_vec_extend_add, dim3(std::min(nmax, 128), nb), dim3(256), 0, st, f->d_nodes, g.first + j0, slot, arenaV, nrhs, P.nz, P.nx);
+                }
+            for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
+                const int nb = std::min(65535, g.cnt - j0);
+                hipLaunchKernelGGL(k_nd_vec_store, dim3(std::min(g.smax, 128), nb), dim3(256), 0, st, f->d_nodes, g.first + j0, arenaV, g.voff + (long long)j0 * nmax, nmax, Xt, nrhs, P.nx);
+            }
+        }
+        if (g.mmax > 0)     // outgoing ring part: V_B -= G21 V_S
+            gemm(op, g.mmax, nrhs, g.smax, mone, f->d_fac + g.g21, g.smax, (long long)g.mmax * g.smax, V, nrhs, (long long)nmax * nrhs, one,
+                 V + (long long)g.smax * nrhs, nrhs, (long long)nmax * nrhs, g.cnt);
+    }
+    // back substitution, root to leaves
+    for (size_t gk = P.groups.size(); gk-- > 0;) {
+        const NdGroup &g = P.groups[gk];
+        const int nmax = g.smax + g.mmax;
+        cplx *V = arenaV + g.voff * nrhs;
+        // the other region is free in this pass: separator results go there
+        const long long xs_off = g.voff + ((g.level & 1) ? -P.vregion : P.vregion);
+        cplx *XS = arenaV + xs_off * nrhs;
+        for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
+            const int nb = std::min(65535, g.cnt - j0);
+            hipLaunchKernelGGL(k_nd_vec_gather, dim3(std::min(nmax, 128), nb), dim3(256), 0, st, f->d_nodes, g.first + j0, arenaV, Xt, nrhs, P.nx, 1);
+        }
+        if (g.mmax > 0)
+            gemm(op, g.smax, nrhs, g.mmax, mone, f->d_fac + g.f12, g.mmax, (long long)g.smax * g.mmax, V + (long long)g.smax * nrhs, nrhs, (long long)nmax * nrhs,
+                 one, V, nrhs, (long long)nmax * nrhs, g.cnt);
+        gemm(op, g.smax, nrhs, g.smax, one, f->d_fac + g.finv, g.smax, (long long)g.smax * g.smax, V, nrhs, (long long)nmax * nrhs, zero,
+             XS, nrhs, (long long)g.smax * nrhs, g.cnt);
+        for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
+            const int nb = std::min(65535, g.cnt - j0);
+            hipLaunchKernelGGL(k_nd_vec_store, dim3(std::min(g.smax, 128), nb), dim3(256), 0, st, f->d_nodes, g.first + j0, arenaV, xs_off + (long long)j0 * g.smax, g.smax, Xt, nrhs, P.nx);
+        }
+    }
+    hipLaunchKernelGGL(k_transpose, dim3((nrhs + 31) / 32, (unsigned)((N + 31) / 32)), dim3(256), 0, st, Xt, N, (long long)nrhs, X);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { char b[256]; snprintf(b, sizeof(b), "direct solver: solve kernels failed: %s", hipGetErrorString(e)); helm_set_error(op, b); return HELM_ERR_DEVICE; }
+    return HELM_OK;
+}
+
+int nd_axpy_one(helm_op *op, cplx *y, const cplx *x, long long n) {
+    hipLaunchKernelGGL(k_axpy_one, dim3((unsigned)std::min<long long>((n + 255) / 256, 65535)), dim3(256), 0, op->stream, y, x, n);
+    return HELM_OK;
+}
+
+// ---- diagnostics exported through the C ABI (host side of the plan; dense kernels on small inputs) ---------------------
+extern "C" int helm_direct_plan(int nz, int nx, int leaf, int *out, int cap) {
+    NdPlan P;
+    nd_build_plan(P, nz, nx, leaf);
+    const int nn = (int)P.nodes.size();
+    if (!out) return nn;
+    for (int i = 0; i < nn && i < cap; ++i) {
+        const NdDev &n = P.nodes[i];
+        int *o = out + 12 * i;
+        o[0] = n.z0; o[1] = n.z1; o[2] = n.x0; o[3] = n.x1; o[4] = n.cut; o[5] = n.pos; o[6] = n.s; o[7] = n.m;
+        o[8] = n.kid[0]; o[9] = n.kid[1]; o[10] = n.smax; o[11] = n.mmax;
+    }
+    return nn;
+}
+
+// cells (z * nx + x) of the front of node `node` in local order; returns s + m, or a negative value when the
+// inverse map nd_local disagrees with nd_cell (self-check of the closed-form index maps)
+extern "C" int helm_direct_plan_front(int nz, int nx, int leaf, int node, long long *cells, int cap) {
+    NdPlan P;
+    nd_build_plan(P, nz, nx, leaf);
+    if (node < 0 || node >= (int)P.nodes.size()) return HELM_ERR_ARG;
+    const NdDev &n = P.nodes[node];
+    for (int a = 0; a < n.s + n.m; ++a) {
+        int z, x;
+        nd_cell(n, a, z, x);
+        if (z < 0 || z >= nz || x < 0 || x >= nx) return -100;
+        if (nd_local(n, nz, nx, z, x) != a) return -101;
+        if (cells && a < cap) cells[a] = (long long)z * nx + x;
+    }
+    return n.s + n.m;
+}
+
+extern "C" int helm_debug_zgemm(int device, int M, int Nn, int K, const double *alpha, const double *A, const double *B, const double *beta, double *C, int batch) {
+    if (hipSetDevice(device) != hipSuccess) return HELM_ERR_DEVICE;
+    cplx *dA, *dB, *dC;
+    const size_t na = (size_t)batch * M * K, nb = (size_t)batch * K * Nn, nc = (size_t)batch * M * Nn;
+    if (hipMalloc((void **)&dA, na * 16) != hipSuccess || hipMalloc((void **)&dB, nb * 16) != hipSuccess || hipMalloc((void **)&dC, nc * 16) != hipSuccess) return HELM_ERR_DEVICE;
+    hipMemcpy(dA, A, na * 16, hipMemcpyHostToDevice); hipMemcpy(dB, B, nb * 16, hipMemcpyHostToDevice); hipMemcpy(dC, C, nc * 16, hipMemcpyHostToDevice);
+    gemm((helm_op *)nullptr, M, Nn, K, cmake(alpha[0], alpha[1]), dA, K, (long long)M * K, dB, Nn, (long long)K * Nn, cmake(beta[0], beta[1]), dC, Nn, (long long)M * Nn, batch);
+    hipError_t e = hipDeviceSynchronize();
+    hipMemcpy(C, dC, nc * 16, hipMemcpyDeviceToHost);
+    hipFree(dA); hipFree(dB); hipFree(dC);
+    return e == hipSuccess ? HELM_OK : HELM_ERR_DEVICE;
+}
+
+extern "C" int helm_debug_inverse(int device, int n, double *A, int batch) {
+    if (hipSetDevice(device) != hipSuccess) return HELM_ERR_DEVICE;
+    cplx *dA, *dW;
+    const size_t na = (size_t)batch * n * n;
+    if (hipMalloc((void **)&dA, na * 16) != hipSuccess || hipMalloc((void **)&dW, na * 16) != hipSuccess) return HELM_ERR_DEVICE;
+    hipMemcpy(dA, A, na * 16, hipMemcpyHostToDevice);
+    invert((helm_op *)nullptr, dA, n, (long long)n * n, n, batch, dW, (long long)n * n);
+    hipError_t e = hipDeviceSynchronize();
+    hipMemcpy(A, dA, na * 16, hipMemcpyDeviceToHost);
+    hipFree(dA); hipFree(dW);
+    return e == hipSuccess ? HELM_OK : HELM_ERR_DEVICE;
+}

@@ -1,0 +1,79 @@
+// Nested-dissection direct solver: plan structures and the closed-form front index maps (host + device).
+#pragma once
+#include "helm_internal.hpp"
+
+struct NdDev {                // one front = one node of the elimination tree
+    int z0, z1, x0, x1;       // region of the subtree (half-open)
+    int cut, pos;             // -1: leaf, all cells of the region are eliminated; 0: separator row z = pos; 1: separator column x = pos
+    int s, m;                 // separator cells, ring cells
+    int ntop, nbot, nleft, nright, xlo;   // ring segments clipped to the grid: row z0-1, row z1 (x from xlo), column x0-1, column x1 (z from z0)
+    int kid[2];               // children (indices in processing order), -1: none
+    int smax, mmax;           // padded sizes of the node's group
+    long long foff;           // front matrix offset in the factorisation arena (elements)
+    long long voff;           // front vector offset in the solve arena (rows; x nrhs elements)
+};
+
+struct NdGroup {              // nodes of one tree level and kind: one strided batch
+    int first = 0, cnt = 0, level = 0;
+    bool leaf = false;
+    int smax = 0, mmax = 0;
+    long long foff = 0, voff = 0;
+    long long finv = 0, g21 = 0, f12 = 0;      // offsets of F11^-1 [cnt][smax][smax], G21 [cnt][mmax][smax], F12 [cnt][smax][mmax]
+};
+
+struct NdPlan {
+    int nz = 0, nx = 0, leaf = 8, nlevels = 0;
+    std::vector<NdDev> nodes;                  // processing order: deepest level first
+    std::vector<NdGroup> groups;
+    long long fac_elems = 0, fregion = 0, vregion = 0, work_elems = 0;
+};
+
+struct NdFactor {
+    NdPlan plan;
+    NdDev *d_nodes = nullptr;
+    cplx *d_fac = nullptr;
+    int block = 0;
+    double flops = 0;
+};
+
+// local index of cell (z, x) in the front: [0, s) separator, [s, s+m) ring; -1 when the cell is not in the front
+__host__ __device__ inline int nd_local(const NdDev &n, int nz, int nx, int z, int x) {
+    (void)nz; (void)nx;
+    if (n.cut < 0) { if (z >= n.z0 && z < n.z1 && x >= n.x0 && x < n.x1) return (z - n.z0) * (n.x1 - n.x0) + (x - n.x0); }
+    else if (n.cut == 0) { if (z == n.pos && x >= n.x0 && x < n.x1) return x - n.x0; }
+    else { if (x == n.pos && z >= n.z0 && z < n.z1) return z - n.z0; }
+    const int wrow = n.ntop ? n.ntop : n.nbot;
+    if (n.ntop && z == n.z0 - 1 && x >= n.xlo && x < n.xlo + wrow) return n.s + (x - n.xlo);
+    if (n.nbot && z == n.z1 && x >= n.xlo && x < n.xlo + wrow) return n.s + n.ntop + (x - n.xlo);
+    if (n.nleft && x == n.x0 - 1 && z >= n.z0 && z < n.z1) return n.s + n.ntop + n.nbot + (z - n.z0);
+    if (n.nright && x == n.x1 && z >= n.z0 && z < n.z1) return n.s + n.ntop + n.nbot + n.nleft + (z - n.z0);
+    return -1;
+}
+
+// cell of local index a (0 <= a < s + m)
+__host__ __device__ inline void nd_cell(const NdDev &n, int a, int &z, int &x) {
+    if (a < n.s) {
+        if (n.cut < 0) { const int w = n.x1 - n.x0; z = n.z0 + a / w; x = n.x0 + a % w; }
+        else if (n.cut == 0) { z = n.pos; x = n.x0 + a; }
+        else { z = n.z0 + a; x = n.pos; }
+        return;
+    }
+    a -= n.s;
+    if (a < n.ntop) { z = n.z0 - 1; x = n.xlo + a; return; }
+    a -= n.ntop;
+    if (a < n.nbot) { z = n.z1; x = n.xlo + a; return; }
+    a -= n.nbot;
+    if (a < n.nleft) { z = n.z0 + a; x = n.x0 - 1; return; }
+    a -= n.nleft;
+    z = n.z0 + a; x = n.x1;
+}
+
+// row / column of local index a in the padded front (separator block padded to smax)
+__host__ __device__ inline int nd_pos(const NdDev &n, int a) { return a < n.s ? a : n.smax + (a - n.s); }
+
+int nd_build_plan(NdPlan &P, int nz, int nx, int leaf);
+int nd_factor(helm_op *op, int block, int leaf, NdFactor **out);
+void nd_free(NdFactor *f);
+long long nd_solve_ws_elems(const NdPlan &P, int nrhs);
+int nd_solve(helm_op *op, NdFactor *f, cplx *X, int nrhs, cplx *ws);
+int nd_axpy_one(helm_op *op, cplx *y, const cplx *x, long long n);

@@ -113,6 +113,8 @@ struct helm_op {
     double diag_floor = 0.0;      // preconditioner levels: floor on |diag| as a fraction of the row's absolute sum (smoother safeguard)
     double a_freq_re = 0, a_freq_im = 0, a_tau = 0, a_ky = 0, a_cpml = 0;   // parameters of the last assemble
     struct MgPrecond *mg = nullptr;
+    struct NdFactor *direct[4] = {nullptr, nullptr, nullptr, nullptr};   // sparse direct factors per block, valid until the next assemble
+    bool direct_failed = false;
     int nblocks = 1;
     cplx *d_C = nullptr;      // nblocks * 9 * N   raw planes
     cplx *d_Cs = nullptr;     // nblocks * 9 * N   planes divided by the centre plane (Jacobi-scaled)
@@ -129,9 +131,10 @@ struct helm_op {
 
     // timing / profiling
     bool profiling = false;
-    helm_timing timing = {0, 0, 0, 0};
+    helm_timing timing = {0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<hipEvent_t> ev_pool;
     std::vector<std::pair<int, double>> ev_pending;   // (event-pair index, bytes)
+    std::vector<std::pair<int, double>> ev_pending_gemm;   // (event-pair index, flops) of the direct solver's GEMM launches
     size_t ev_used = 0;
     int active_hint = -1;        // right-hand sides currently iterating (for the byte count of profiled launches)
 
