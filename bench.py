@@ -24,6 +24,7 @@ if ROOT not in sys.path:
 
 NFREQ, NSRC = 16, 256
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+F64_PEAK_TFLOPS = 78.6    # MI355X fp64 dense peak, vector FMA = MFMA f64 rate (AMD spec)
 
 
 def build_config(n, dx):
@@ -135,7 +136,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--grid', '--n', dest='n', type=int, default=1024, help='grid side (1024 = BASELINE workload)')
     ap.add_argument('--dx', type=float, default=9.0)
-    ap.add_argument('--batch', type=int, default=64, help='sources per work item')
+    ap.add_argument('--batch', type=int, default=256, help='sources per work item (256 = all sources of a frequency)')
     ap.add_argument('--rtol', type=float, default=1e-10)
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--cpu-pool', action='store_true', help='also time the 16-process CPU pool mode (adds ~1 min)')
@@ -208,6 +209,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     iters, apply_ms, apply_launches, apply_bytes, solve_ms = [], 0.0, 0, 0.0, 0.0
+    gemm_ms, gemm_launches, gemm_flops, factor_ms, methods = 0.0, 0, 0.0, 0.0, set()
     freq_used = []
     results = [None] * args.steps
     if args.streams <= 1:
@@ -233,6 +235,8 @@ def main():
         freq_used.append(float(freqs[fi]))
         apply_ms += t['apply_ms']; apply_launches += t['apply_launches']; apply_bytes += t['apply_bytes']
         solve_ms += t['solve_ms']
+        gemm_ms += t['gemm_ms']; gemm_launches += t['gemm_launches']; gemm_flops += t['gemm_flops']; factor_ms += t['factor_ms']
+        methods.update(i['method'] for i in info)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -246,24 +250,42 @@ def main():
     out = None
     if rank == 0:
         achieved = (apply_bytes / (apply_ms * 1e-3)) / 1e9 if apply_ms > 0 else 0.0
+        direct = methods == {4}
+        how = ('sparse direct: nested-dissection multifrontal factorisation of A(f) on the GPU, kept for all sources of the frequency, '
+               'triangular solves as batched complex GEMMs + iterative refinement with the stencil kernel' if direct else
+               'BiCGSTAB right-preconditioned by shifted-Laplacian multigrid with damped-Jacobi smoothing + PML line relaxation')
+        stencil = {'bound': 'hbm', 'kernel': 'k_stencil (batched 9-pt complex128 apply with fused dot-product / residual epilogue), launches inside the timed solves',
+                   'bytes_formula': 'N*(32*B_active + 144) for the apply + N*16*B_active for the epilogue operand it must read',
+                   'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                   'traffic': None, 'launches_timed': int(apply_launches),
+                   'avg_launch_us': 1e3 * apply_ms / apply_launches if apply_launches else None,
+                   'bytes_per_launch_algorithmic': apply_bytes / apply_launches if apply_launches else None,
+                   'apply_share_of_solve_time': apply_ms / solve_ms if solve_ms > 0 else None}
         out = {
             'metric': 'wavefields/sec (freq x source solves/s) on 1024^2 grid',
             'value': value, 'unit': 'wavefields/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'Eurus 2D isotropic %dx%d synthetic-Marmousi (seed 20240512, dx=%g m), 16 freqs 2-9.5 Hz x 256 Kaiser sources; '
-                                   'step = assemble 1 frequency + solve %d sources to true relres<=%g (method=%s: BiCGSTAB right-preconditioned by shifted-Laplacian multigrid with damped-Jacobi smoothing + PML line relaxation)' % (n, n, dx, B, args.rtol, args.method),
+                                   'step = create + assemble 1 frequency + solve %d sources to true relres<=%g (method=%s: %s)' % (n, n, dx, B, args.rtol, args.method, how),
                        'grid': [n, n], 'sources_per_step': B, 'work_items_in_flight': args.streams, 'freqs_hz_this_run': freq_used, 'sharding': 'work items (freq, source batch) round-robin over ranks',
-                       'iterations_per_rhs_mean': float(np.mean(iters)) if iters else None,
-                       'iterations_per_rhs_max': int(np.max(iters)) if iters else None},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_stencil (batched 9-pt complex128 apply with fused dot-product epilogue), outer-iteration launches',
-                         'bytes_formula': 'N*(32*B_active + 144) for the apply + N*16*B_active for the epilogue operand (r0 or s) it must read',
-                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': None, 'launches_timed': int(apply_launches),
-                         'avg_launch_us': 1e3 * apply_ms / apply_launches if apply_launches else None,
-                         'bytes_per_launch_algorithmic': apply_bytes / apply_launches if apply_launches else None,
-                         'apply_share_of_solve_time': apply_ms / solve_ms if solve_ms > 0 else None},
+                       'solves_or_iterations_per_rhs_mean': float(np.mean(iters)) if iters else None,
+                       'solves_or_iterations_per_rhs_max': int(np.max(iters)) if iters else None,
+                       'device_ms_per_step': {'solve_call': solve_ms / args.steps, 'of_which_factorisation': factor_ms / args.steps}},
         }
+        if direct:
+            tf = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'k_zgemm (strided-batched complex128 GEMM of the multifrontal factorisation and triangular solves; fp64 FMAs on the vector '
+                                                           'ALUs, whose rate equals the fp64 MFMA rate on MI355X)',
+                               'flops_formula': '8*M*N*K per batch item (4 real multiply-adds per complex one)',
+                               'achieved': tf, 'peak': F64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / F64_PEAK_TFLOPS, 'traffic': None,
+                               'launches_timed': int(gemm_launches), 'avg_launch_us': 1e3 * gemm_ms / gemm_launches if gemm_launches else None,
+                               'flops_per_launch_algorithmic': gemm_flops / gemm_launches if gemm_launches else None,
+                               'gemm_share_of_solve_time': gemm_ms / solve_ms if solve_ms > 0 else None}
+            out['stencil_roofline'] = stencil
+        else:
+            out['roofline'] = stencil
+        micro_target = out['stencil_roofline'] if direct else out['roofline']
         # stencil-apply microbenchmark of SURVEY.md 8(d) (outside the timed region): Y = A X on random X, B right-hand sides,
         # algorithmic bytes N*(32*B + 144), HIP events on the solver stream
         if world == 1:
@@ -287,15 +309,15 @@ def main():
                             ms += tm['apply_ms']; by += tm['apply_bytes']
                     micro.append({'B': Bm, 'us': 1e3 * ms / 5, 'GBps': by / (ms * 1e-3) / 1e9, 'frac_of_peak': by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
                     del X, Y
-                out['roofline']['apply_microbench'] = micro
+                micro_target['apply_microbench'] = micro
                 del opm.factors
             except Exception as exc:          # never let the extra measurement break the bench line
-                out['roofline']['apply_microbench'] = 'failed: %s' % exc
+                micro_target['apply_microbench'] = 'failed: %s' % exc
         # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same
         # command; bench.py cannot run the profiler on itself) -- only when it was collected for this workload
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
-            if pmc.get('batch') == B and pmc.get('grid') == [n, n]:
+            if not direct and pmc.get('batch') == B and pmc.get('grid') == [n, n]:
                 out['roofline']['traffic'] = pmc['traffic_bytes_per_launch_outer_applies']
                 out['roofline']['traffic_source'] = 'profiles/r01_pmc_traffic.json'
         except Exception:

@@ -4,6 +4,7 @@
 // the host looks at the per-RHS status records every `check_every` iterations.
 #include "helm_internal.hpp"
 #include "direct.hpp"
+#include <mutex>
 #include <cstring>
 #include <algorithm>
 #include <limits>
@@ -33,6 +34,14 @@ extern "C" int helm_device_count(void) {
 
 #define HIP_TRY_NULL(call) do { hipError_t _e = (call); if (_e != hipSuccess) { char _b[256]; \
     snprintf(_b, sizeof(_b), "%s failed: %s", #call, hipGetErrorString(_e)); helm_set_error(nullptr, _b); delete op; return nullptr; } } while (0)
+
+// Scratch of the direct path (fronts while factoring, front vectors while solving) is tens of GB at the bench size and
+// is only needed during a call, so all handles of a process share one buffer; a handle that finds it taken (another
+// host thread is inside a solve) falls back to its own.
+struct SharedWs { std::mutex mu; void *ptr = nullptr; size_t bytes = 0; int device = -1; bool busy = false; };
+static SharedWs g_shared_ws;
+static int g_live_handles = 0;     // guarded by g_shared_ws.mu
+
 
 static helm_op *create_common(helm_op *op);
 
@@ -66,6 +75,7 @@ static helm_op *create_common(helm_op *op) {
     op->own_stream = true;
     const size_t N = (size_t)op->N;
     op->Nv = op->N;
+    { std::lock_guard<std::mutex> lk(g_shared_ws.mu); g_live_handles += 1; }
     HIP_TRY_NULL(hipMalloc(&op->d_c, N * sizeof(cplx)));
     HIP_TRY_NULL(hipMalloc(&op->d_rho, N * sizeof(double)));
     HIP_TRY_NULL(hipMalloc(&op->d_C, (size_t)op->nblocks * op->nplanes * N * sizeof(cplx)));
@@ -87,6 +97,10 @@ extern "C" void helm_destroy(helm_op *op) {
     for (hipEvent_t e : op->ev_pool) hipEventDestroy(e);
     if (op->own_stream && op->stream) hipStreamDestroy(op->stream);
     delete op;
+    std::lock_guard<std::mutex> lk(g_shared_ws.mu);
+    if (--g_live_handles <= 0 && !g_shared_ws.busy && g_shared_ws.ptr) {      // last handle gone: give the scratch back
+        hipFree(g_shared_ws.ptr); g_shared_ws.ptr = nullptr; g_shared_ws.bytes = 0; g_live_handles = 0;
+    }
 }
 
 extern "C" int helm_set_stream(helm_op *op, void *hip_stream) {
@@ -467,6 +481,34 @@ struct NvGuard {     // Krylov vector length of the handle for the duration of a
 };
 
 
+void *ws_checkout(helm_op *op, size_t bytes, bool *shared) {
+    {
+        std::lock_guard<std::mutex> lk(g_shared_ws.mu);
+        if (!g_shared_ws.busy && (g_shared_ws.ptr == nullptr || g_shared_ws.device == op->device)) {
+            if (g_shared_ws.bytes < bytes) {
+                if (g_shared_ws.ptr) hipFree(g_shared_ws.ptr);
+                g_shared_ws.ptr = nullptr; g_shared_ws.bytes = 0;
+                if (hipMalloc(&g_shared_ws.ptr, bytes) != hipSuccess) { g_shared_ws.ptr = nullptr; (void)hipGetLastError(); }
+                else { g_shared_ws.bytes = bytes; g_shared_ws.device = op->device; }
+            }
+            if (g_shared_ws.ptr) { g_shared_ws.busy = true; *shared = true; return g_shared_ws.ptr; }
+        }
+    }
+    *shared = false;
+    if (ensure_ws(op, bytes) != HELM_OK) return nullptr;
+    return op->d_ws;
+}
+void ws_checkin(bool shared) {
+    if (!shared) return;
+    std::lock_guard<std::mutex> lk(g_shared_ws.mu);
+    g_shared_ws.busy = false;
+}
+struct WsLease {
+    bool shared = false; void *ptr = nullptr;
+    WsLease(helm_op *op, size_t bytes) { ptr = ws_checkout(op, bytes, &shared); }
+    ~WsLease() { ws_checkin(shared); }
+};
+
 // Sparse direct path (direct.hip): factor once per assembled operator, then per batch q' -> x by the multifrontal
 // triangular solves and iterative refinement on the true residual q' - A x (stencil kernel) until rtol is met.
 int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long long row_off, cplx premul,
@@ -474,31 +516,35 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
     const long long N = op->N;
     if ((long long)((N + 31) / 32) > 65535) HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "direct solver: grid too large (more than 2M cells)");
     int rc;
-    if (!op->direct[block]) {
-        const char *e = getenv("HELM_ND_LEAF");
-        const int leaf = e ? std::max(2, atoi(e)) : 8;
-        hipEvent_t f0, f1;
-        HIP_TRY(op, hipEventCreate(&f0)); HIP_TRY(op, hipEventCreate(&f1));
-        hipEventRecord(f0, op->stream);
-        NdFactor *f = nullptr;
-        rc = nd_factor(op, block, leaf, &f);
-        hipEventRecord(f1, op->stream);
-        hipEventSynchronize(f1);
-        float ms = 0.f; hipEventElapsedTime(&ms, f0, f1);
-        hipEventDestroy(f0); hipEventDestroy(f1);
-        if (rc) return rc;
-        op->direct[block] = f;
-        op->timing.factor_ms += ms;
-    }
     NdFactor *f = op->direct[block];
-    const long long per_rhs = nd_solve_ws_elems(f->plan, 1) + 3 * N;
+    const bool need_factor = (f == nullptr);
+    if (need_factor) {
+        const char *e = getenv("HELM_ND_LEAF");
+        f = new NdFactor();
+        nd_build_plan(f->plan, op->nz, op->nx, e ? std::max(2, atoi(e)) : 8);
+    }
+    const long long per_rhs = nd_solve_ws_elems(f->plan, 1) + 2 * N;
     int Bmax = o.batch > 0 ? o.batch : 256;
     if (Bmax > nrhs) Bmax = nrhs;
     const char *capenv = getenv("HELM_ND_WS_GB");
     const double cap = (capenv ? atof(capenv) : 32.0) * 1e9;
     while (Bmax > 1 && (double)per_rhs * Bmax * sizeof(cplx) > cap) Bmax = (Bmax + 1) / 2;
-    rc = ensure_ws(op, (size_t)per_rhs * Bmax * sizeof(cplx));
-    if (rc) return rc;
+    const long long ws_elems = std::max(per_rhs * Bmax, need_factor ? nd_factor_ws_elems(f->plan) : 0LL);
+    WsLease lease(op, (size_t)ws_elems * sizeof(cplx));
+    if (!lease.ptr) { if (need_factor) nd_free(f); HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: cannot allocate %.1f GB of scratch", ws_elems * 16e-9); }
+    if (need_factor) {
+        hipEvent_t f0, f1;
+        HIP_TRY(op, hipEventCreate(&f0)); HIP_TRY(op, hipEventCreate(&f1));
+        hipEventRecord(f0, op->stream);
+        rc = nd_factor(op, block, f, (cplx *)lease.ptr);
+        hipEventRecord(f1, op->stream);
+        hipEventSynchronize(f1);
+        float ms = 0.f; hipEventElapsedTime(&ms, f0, f1);
+        hipEventDestroy(f0); hipEventDestroy(f1);
+        if (rc) { nd_free(f); return rc; }
+        op->direct[block] = f;
+        op->timing.factor_ms += ms;
+    }
     rc = ensure_part(op, Bmax);
     if (rc) return rc;
     const int nblk = std::max(2 * helm_apply_num_blocks(op), helm_vec_num_blocks(op));
@@ -510,15 +556,15 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
     int unconverged = 0;
     for (int first = 0; first < nrhs; first += Bmax) {
         const int n = std::min(Bmax, nrhs - first);
-        cplx *q = (cplx *)op->d_ws, *x = q + (long long)Bmax * N, *r = q + 2LL * Bmax * N, *nws = q + 3LL * Bmax * N;
+        cplx *q = (cplx *)lease.ptr, *r = q + (long long)Bmax * N, *nws = q + 2LL * Bmax * N;
+        cplx *x = dXout + (long long)first * N;
         const cplx *rhs_b = dRHS + (long long)first * rhs_ld;
         const cplx *sub_b = sub ? sub + (long long)first * N : nullptr;
         rc = helm_launch_prep_rhs(op, rhs_b, rhs_ld, row_off, premul, sub_b, q, n);
         if (rc) return rc;
         helm_launch_norm2(op, q, n);
         helm_launch_fin_ex(op, FIN_NORM, n, helm_vec_num_blocks(op), nullptr, d_aux + n);
-        HIP_TRY(op, hipMemcpyAsync(x, q, (size_t)n * N * sizeof(cplx), hipMemcpyDeviceToDevice, op->stream));
-        rc = nd_solve(op, f, x, n, nws);
+        rc = nd_solve(op, f, q, x, n, nws);
         if (rc) return rc;
         std::vector<double> relres(n, 0.0);
         int solves = 1;
@@ -538,7 +584,7 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
                 if (!(relres[b] <= o.rtol)) all_ok = false;
             }
             if (all_ok || round >= max_refine) break;
-            rc = nd_solve(op, f, r, n, nws);       // dx = A^-1 r
+            rc = nd_solve(op, f, r, r, n, nws);       // dx = A^-1 r
             if (rc) return rc;
             nd_axpy_one(op, x, r, (long long)n * N);
             solves += 1;
@@ -553,7 +599,6 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
                 I.status = std::max(I.status, ok ? 0 : 1);
             }
         }
-        HIP_TRY(op, hipMemcpyAsync(dXout + (long long)first * N, x, (size_t)n * N * sizeof(cplx), hipMemcpyDeviceToDevice, op->stream));
         HIP_TRY(op, hipStreamSynchronize(op->stream));
     }
     return unconverged;
@@ -568,6 +613,19 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
     if (o.method == HELM_DIRECT) {
         if (sys2 || op->ny > 0) HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "the direct solver handles 2-D single-block systems only (not the coupled TTI system, not 3-D)");
         return solve_block_direct(op, block, dRHS, rhs_ld, row_off, premul, sub, dXout, nrhs, o, info);
+    }
+    // AUTO: the sparse direct path wherever it applies (2-D single-block systems that fit), else / on failure the
+    // multigrid-preconditioned Krylov path below
+    if (o.method == HELM_AUTO && !sys2 && op->ny == 0 && !op->direct_failed && (N + 31) / 32 <= 65535) {
+        const char *e = getenv("HELM_AUTO_DIRECT");
+        if (!e || atoi(e) != 0) {
+            std::vector<helm_solve_info> saved;
+            if (info) saved.assign(info, info + nrhs);
+            const int rc = solve_block_direct(op, block, dRHS, rhs_ld, row_off, premul, sub, dXout, nrhs, o, info);
+            if (rc == 0) return 0;
+            op->direct_failed = true;
+            if (info) std::copy(saved.begin(), saved.end(), info);
+        }
     }
     const long long NV = sys2 ? 2 * N : N;
     NvGuard guard(op, NV);

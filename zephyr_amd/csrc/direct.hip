@@ -438,25 +438,23 @@ void nd_free(NdFactor *f) {
     delete f;
 }
 
-int nd_factor(helm_op *op, int block, int leaf, NdFactor **out) {
-    NdFactor *f = new NdFactor();
-    nd_build_plan(f->plan, op->nz, op->nx, leaf);
+long long nd_factor_ws_elems(const NdPlan &P) { return 2 * P.fregion + P.work_elems; }
+
+// ws: nd_factor_ws_elems(plan) elements of scratch (fronts of two adjacent levels + inversion workspace)
+int nd_factor(helm_op *op, int block, NdFactor *f, cplx *ws) {
     NdPlan &P = f->plan;
     hipStream_t st = op->stream;
-    cplx *arenaF = nullptr, *work = nullptr;
+    cplx *arenaF = ws, *work = ws + 2 * P.fregion;
     auto fail = [&](const char *what, hipError_t e) {
         char b[256]; snprintf(b, sizeof(b), "direct solver: %s failed: %s", what, hipGetErrorString(e)); helm_set_error(op, b);
-        if (arenaF) hipFree(arenaF);
-        if (work) hipFree(work);
-        nd_free(f);
         return HELM_ERR_DEVICE;
     };
     hipError_t e;
-    if ((e = hipMalloc((void **)&f->d_nodes, P.nodes.size() * sizeof(NdDev))) != hipSuccess) return fail("hipMalloc(nodes)", e);
-    if ((e = hipMemcpyAsync(f->d_nodes, P.nodes.data(), P.nodes.size() * sizeof(NdDev), hipMemcpyHostToDevice, st)) != hipSuccess) return fail("upload", e);
-    if ((e = hipMalloc((void **)&f->d_fac, (size_t)P.fac_elems * sizeof(cplx))) != hipSuccess) return fail("hipMalloc(factors)", e);
-    if ((e = hipMalloc((void **)&arenaF, (size_t)2 * P.fregion * sizeof(cplx))) != hipSuccess) return fail("hipMalloc(fronts)", e);
-    if ((e = hipMalloc((void **)&work, (size_t)P.work_elems * sizeof(cplx))) != hipSuccess) return fail("hipMalloc(work)", e);
+    if (!f->d_nodes) {
+        if ((e = hipMalloc((void **)&f->d_nodes, P.nodes.size() * sizeof(NdDev))) != hipSuccess) return fail("hipMalloc(nodes)", e);
+        if ((e = hipMemcpyAsync(f->d_nodes, P.nodes.data(), P.nodes.size() * sizeof(NdDev), hipMemcpyHostToDevice, st)) != hipSuccess) return fail("upload", e);
+    }
+    if (!f->d_fac && (e = hipMalloc((void **)&f->d_fac, (size_t)P.fac_elems * sizeof(cplx))) != hipSuccess) return fail("hipMalloc(factors)", e);
     const cplx *planes = op->d_C + (long long)block * op->nplanes * op->N;
     const cplx one = cmake(1, 0), mone = cmake(-1, 0), zero = cmake(0, 0);
     double flops = 0;
@@ -503,23 +501,21 @@ int nd_factor(helm_op *op, int block, int leaf, NdFactor **out) {
     e = hipStreamSynchronize(st);
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) return fail("factorisation kernels", e);
-    hipFree(arenaF); hipFree(work);
     f->block = block; f->flops = flops;
-    *out = f;
     return HELM_OK;
 }
 
-// ---- solve: X (nrhs x N, each right-hand side contiguous) -> solution in place --------------------------------------
+// ---- solve: Xin (nrhs x N, each right-hand side contiguous) -> Xout (may alias Xin) --------------------------------------
 // ws: workspace of nd_solve_ws_elems(plan, nrhs) elements
 long long nd_solve_ws_elems(const NdPlan &P, int nrhs) { return ((long long)P.nz * P.nx + 2 * P.vregion) * nrhs; }
 
-int nd_solve(helm_op *op, NdFactor *f, cplx *X, int nrhs, cplx *ws) {
+int nd_solve(helm_op *op, NdFactor *f, const cplx *Xin, cplx *Xout, int nrhs, cplx *ws) {
     const NdPlan &P = f->plan;
     hipStream_t st = op->stream;
     const long long N = (long long)P.nz * P.nx;
     cplx *Xt = ws, *arenaV = ws + N * nrhs;
     const cplx one = cmake(1, 0), mone = cmake(-1, 0), zero = cmake(0, 0);
-    hipLaunchKernelGGL(k_transpose, dim3((unsigned)((N + 31) / 32), (nrhs + 31) / 32), dim3(256), 0, st, X, (long long)nrhs, N, Xt);
+    hipLaunchKernelGGL(k_transpose, dim3((unsigned)((N + 31) / 32), (nrhs + 31) / 32), dim3(256), 0, st, Xin, (long long)nrhs, N, Xt);
     // forward elimination, leaves to root
     for (size_t gi = 0; gi < P.groups.size(); ++gi) {
         const NdGroup &g = P.groups[gi];
@@ -566,7 +562,7 @@ int nd_solve(helm_op *op, NdFactor *f, cplx *X, int nrhs, cplx *ws) {
             hipLaunchKernelGGL(k_nd_vec_store, dim3(std::min(g.smax, 128), nb), dim3(256), 0, st, f->d_nodes, g.first + j0, arenaV, xs_off + (long long)j0 * g.smax, g.smax, Xt, nrhs, P.nx);
         }
     }
-    hipLaunchKernelGGL(k_transpose, dim3((nrhs + 31) / 32, (unsigned)((N + 31) / 32)), dim3(256), 0, st, Xt, N, (long long)nrhs, X);
+    hipLaunchKernelGGL(k_transpose, dim3((nrhs + 31) / 32, (unsigned)((N + 31) / 32)), dim3(256), 0, st, Xt, N, (long long)nrhs, Xout);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { char b[256]; snprintf(b, sizeof(b), "direct solver: solve kernels failed: %s", hipGetErrorString(e)); helm_set_error(op, b); return HELM_ERR_DEVICE; }
     return HELM_OK;

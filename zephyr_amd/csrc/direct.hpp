@@ -72,8 +72,9 @@ __host__ __device__ inline void nd_cell(const NdDev &n, int a, int &z, int &x) {
 __host__ __device__ inline int nd_pos(const NdDev &n, int a) { return a < n.s ? a : n.smax + (a - n.s); }
 
 int nd_build_plan(NdPlan &P, int nz, int nx, int leaf);
-int nd_factor(helm_op *op, int block, int leaf, NdFactor **out);
+long long nd_factor_ws_elems(const NdPlan &P);
+int nd_factor(helm_op *op, int block, NdFactor *f, cplx *ws);    // f->plan must be built
 void nd_free(NdFactor *f);
 long long nd_solve_ws_elems(const NdPlan &P, int nrhs);
-int nd_solve(helm_op *op, NdFactor *f, cplx *X, int nrhs, cplx *ws);
+int nd_solve(helm_op *op, NdFactor *f, const cplx *Xin, cplx *Xout, int nrhs, cplx *ws);
 int nd_axpy_one(helm_op *op, cplx *y, const cplx *x, long long n);
