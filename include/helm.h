@@ -162,6 +162,10 @@ int helm_set_profiling(helm_op *op, int on);
 int helm_imaging_accumulate_device(helm_op *op, const void *dUF, const void *dUB, int nsrc,
                                    const void *dScaler, void *dG);
 
+/* Free the scratch memory the library keeps between calls (the direct path's shared workspace, tens of GB at
+ * 1024^2 x 256 right-hand sides).  HELM_ERR_STATE while a solve is using it. */
+int helm_trim(void);
+
 /* --- diagnostics of the direct solver ---------------------------------------------------- */
 /* Elimination-tree plan of an (nz, nx) grid (host only, no GPU needed).  out == NULL: returns the number of fronts;
  * else writes 12 ints per front in processing order {z0, z1, x0, x1, cut, pos, s, m, kid0, kid1, smax, mmax}. */

@@ -70,6 +70,7 @@ _SIGNATURES = {
     'helm_set_profiling': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'helm_imaging_accumulate_device': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                                       ctypes.c_void_p, ctypes.c_void_p]),
+    'helm_trim': (ctypes.c_int, []),
     'helm_direct_plan': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]),
     'helm_direct_plan_front': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]),
     'helm_debug_zgemm': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,

@@ -98,9 +98,17 @@ extern "C" void helm_destroy(helm_op *op) {
     if (op->own_stream && op->stream) hipStreamDestroy(op->stream);
     delete op;
     std::lock_guard<std::mutex> lk(g_shared_ws.mu);
-    if (--g_live_handles <= 0 && !g_shared_ws.busy && g_shared_ws.ptr) {      // last handle gone: give the scratch back
-        hipFree(g_shared_ws.ptr); g_shared_ws.ptr = nullptr; g_shared_ws.bytes = 0; g_live_handles = 0;
-    }
+    g_live_handles -= 1;
+}
+
+// Release what the library caches between calls (the shared scratch of the direct path).  The scratch is kept across
+// handles on purpose -- allocating tens of GB costs far more than a solve -- so a host that wants the memory back says so.
+extern "C" int helm_trim(void) {
+    std::lock_guard<std::mutex> lk(g_shared_ws.mu);
+    if (g_shared_ws.busy) return HELM_ERR_STATE;
+    if (g_shared_ws.ptr) { hipSetDevice(g_shared_ws.device); hipFree(g_shared_ws.ptr); }
+    g_shared_ws.ptr = nullptr; g_shared_ws.bytes = 0; g_shared_ws.device = -1;
+    return HELM_OK;
 }
 
 extern "C" int helm_set_stream(helm_op *op, void *hip_stream) {
@@ -521,15 +529,16 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
     if (need_factor) {
         const char *e = getenv("HELM_ND_LEAF");
         f = new NdFactor();
-        nd_build_plan(f->plan, op->nz, op->nx, e ? std::max(2, atoi(e)) : 8);
+        rc = nd_get_plan(op, e ? std::max(2, atoi(e)) : 8, &f->pd);
+        if (rc) { nd_free(f); return rc; }
     }
-    const long long per_rhs = nd_solve_ws_elems(f->plan, 1) + 2 * N;
+    const long long per_rhs = nd_solve_ws_elems(f->pd->plan, 1) + 2 * N;
     int Bmax = o.batch > 0 ? o.batch : 256;
     if (Bmax > nrhs) Bmax = nrhs;
     const char *capenv = getenv("HELM_ND_WS_GB");
     const double cap = (capenv ? atof(capenv) : 32.0) * 1e9;
     while (Bmax > 1 && (double)per_rhs * Bmax * sizeof(cplx) > cap) Bmax = (Bmax + 1) / 2;
-    const long long ws_elems = std::max(per_rhs * Bmax, need_factor ? nd_factor_ws_elems(f->plan) : 0LL);
+    const long long ws_elems = std::max(per_rhs * Bmax, need_factor ? nd_factor_ws_elems(f->pd->plan) : 0LL);
     WsLease lease(op, (size_t)ws_elems * sizeof(cplx));
     if (!lease.ptr) { if (need_factor) nd_free(f); HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: cannot allocate %.1f GB of scratch", ws_elems * 16e-9); }
     if (need_factor) {

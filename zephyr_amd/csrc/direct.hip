@@ -25,6 +25,7 @@
 #include "helm_internal.hpp"
 #include "direct.hpp"
 #include <algorithm>
+#include <mutex>
 
 namespace {
 
@@ -101,7 +102,7 @@ int nd_build_plan(NdPlan &P, int nz, int nx, int leaf) {
         for (int c = 0; c < 2; ++c) if (n.kid[c] >= 0) n.kid[c] = newidx[n.kid[c]];
         P.nodes[k] = n;
     }
-    P.nz = nz; P.nx = nx; P.leaf = B.leaf; P.nlevels = maxlev + 1;
+    P.nz = nz; P.nx = nx; P.leaf = B.leaf; P.nlevels = maxlev + 1; P.total_rows = 0;
     // arenas: fronts (factor) and front vectors (solve) of level L live in region L % 2
     std::vector<long long> lev_f(maxlev + 1, 0), lev_v(maxlev + 1, 0);
     long long fac = 0;
@@ -109,6 +110,7 @@ int nd_build_plan(NdPlan &P, int nz, int nx, int leaf) {
         NdGroup &g = P.groups[gi];
         const long long nmax = g.smax + g.mmax;
         g.foff = lev_f[g.level]; g.voff = lev_v[g.level];
+        g.roff = P.total_rows; P.total_rows += (long long)g.cnt * nmax;
         lev_f[g.level] += (long long)g.cnt * nmax * nmax;
         lev_v[g.level] += (long long)g.cnt * nmax;
         g.finv = fac; fac += (long long)g.cnt * g.smax * g.smax;
@@ -129,6 +131,7 @@ int nd_build_plan(NdPlan &P, int nz, int nx, int leaf) {
             n.smax = g.smax; n.mmax = g.mmax;
             n.foff = g.foff + (long long)j * nmax * nmax;
             n.voff = g.voff + (long long)j * nmax;
+            n.roff = g.roff + (long long)j * nmax;
         }
     }
     return HELM_OK;
@@ -320,55 +323,68 @@ __global__ __launch_bounds__(256) void k_transpose(const cplx *in, long long row
         if (c0 + j < cols && r0 + tx < rows) out[(c0 + j) * rows + r0 + tx] = t[tx][j];
 }
 
-// V[row][r] for the padded front vector of every node of a group: separator rows <- Xt, everything else <- 0 (mode 0);
-// mode 1 additionally fills the ring rows from Xt (backward pass)
-__global__ __launch_bounds__(256) void k_nd_vec_gather(const NdDev *nodes, int first, cplx *arenaV, const cplx *Xt, int nrhs, int nx, int mode) {
+// row table (see NdPlanDev): one thread per padded row of the group's fronts
+__global__ __launch_bounds__(256) void k_nd_build_tab(const NdDev *nodes, int first, int4 *tab, int nz, int nx) {
     const NdDev n = nodes[first + blockIdx.y];
-    cplx *V = arenaV + n.voff * nrhs;
     const int nmax = n.smax + n.mmax;
-    for (int row = blockIdx.x; row < nmax; row += gridDim.x) {
+    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < nmax; row += gridDim.x * blockDim.x) {
         int a = -1;
         if (row < n.s) a = row;
-        else if (mode == 1 && row >= n.smax && row - n.smax < n.m) a = n.s + row - n.smax;
-        cplx *dst = V + (long long)row * nrhs;
+        else if (row >= n.smax && row - n.smax < n.m) a = n.s + row - n.smax;
+        int4 e = make_int4(-1, -1, -1, row < n.s ? 1 : 0);
         if (a >= 0) {
             int z, x;
             nd_cell(n, a, z, x);
-            const cplx *src = Xt + ((long long)z * nx + x) * nrhs;
-            for (int r = threadIdx.x; r < nrhs; r += blockDim.x) dst[r] = src[r];
-        } else {
-            for (int r = threadIdx.x; r < nrhs; r += blockDim.x) dst[r] = cmake(0.0, 0.0);
+            e.x = z * nx + x;
+            for (int k = 0; k < 2; ++k) {
+                if (n.kid[k] < 0) continue;
+                const NdDev c = nodes[n.kid[k]];
+                const int la = nd_local(c, nz, nx, z, x);
+                if (la >= c.s) { const int src = (int)(c.voff + c.smax + (la - c.s)); if (k == 0) e.y = src; else e.z = src; }
+            }
+        }
+        tab[n.roff + row] = e;
+    }
+}
+
+// forward pass, one group: V[row] = [separator row: Xt[cell]] + outgoing rows of the children; separator rows of
+// non-leaf fronts are final (y_S) and written back to Xt.  blockDim = (LX, 256 / LX), LX lanes over the right-hand sides.
+__global__ __launch_bounds__(256) void k_nd_fwd_rows(const int4 *tab, cplx *V, const cplx *arenaV, cplx *Xt, long long rows, int nrhs, int write_back) {
+    for (long long row = (long long)blockIdx.x * blockDim.y + threadIdx.y; row < rows; row += (long long)gridDim.x * blockDim.y) {
+        const int4 e = tab[row];
+        cplx *dst = V + row * nrhs;
+        const cplx *s0 = e.w ? Xt + (long long)e.x * nrhs : nullptr;
+        const cplx *s1 = e.y >= 0 ? arenaV + (long long)e.y * nrhs : nullptr;
+        const cplx *s2 = e.z >= 0 ? arenaV + (long long)e.z * nrhs : nullptr;
+        for (int r = threadIdx.x; r < nrhs; r += blockDim.x) {
+            cplx acc = s0 ? s0[r] : cmake(0.0, 0.0);
+            if (s1) acc = cadd(acc, s1[r]);
+            if (s2) acc = cadd(acc, s2[r]);
+            dst[r] = acc;
+            if (write_back && e.w) Xt[(long long)e.x * nrhs + r] = acc;
         }
     }
 }
 
-// parent vector += outgoing ring part of child `slot`
-__global__ __launch_bounds__(256) void k_nd_vec_extend_add(const NdDev *nodes, int first, int slot, cplx *arenaV, int nrhs, int nz, int nx) {
-    const NdDev p = nodes[first + blockIdx.y];
-    if (p.kid[slot] < 0) return;
-    const NdDev c = nodes[p.kid[slot]];
-    const cplx *Vc = arenaV + c.voff * nrhs;
-    cplx *Vp = arenaV + p.voff * nrhs;
-    for (int a = blockIdx.x; a < c.m; a += gridDim.x) {
-        int z, x;
-        nd_cell(c, c.s + a, z, x);
-        const int row = nd_pos(p, nd_local(p, nz, nx, z, x));
-        const cplx *src = Vc + (long long)(c.smax + a) * nrhs;
-        cplx *dst = Vp + (long long)row * nrhs;
-        for (int r = threadIdx.x; r < nrhs; r += blockDim.x) dst[r] = cadd(dst[r], src[r]);
+// backward pass: V[row] = Xt[cell of the row] (separator and ring rows), 0 for padding
+__global__ __launch_bounds__(256) void k_nd_bwd_gather(const int4 *tab, cplx *V, const cplx *Xt, long long rows, int nrhs) {
+    for (long long row = (long long)blockIdx.x * blockDim.y + threadIdx.y; row < rows; row += (long long)gridDim.x * blockDim.y) {
+        const int4 e = tab[row];
+        cplx *dst = V + row * nrhs;
+        const cplx *src = e.x >= 0 ? Xt + (long long)e.x * nrhs : nullptr;
+        for (int r = threadIdx.x; r < nrhs; r += blockDim.x) dst[r] = src ? src[r] : cmake(0.0, 0.0);
     }
 }
 
-// Xt[separator cells] <- rows [0, s) of a per-node buffer with `rows_per_node` rows
-__global__ __launch_bounds__(256) void k_nd_vec_store(const NdDev *nodes, int first, const cplx *buf, long long group_off, int rows_per_node,
-                                                      cplx *Xt, int nrhs, int nx) {
-    const NdDev n = nodes[first + blockIdx.y];
-    const cplx *V = buf + (group_off + (long long)blockIdx.y * rows_per_node) * nrhs;
-    for (int a = blockIdx.x; a < n.s; a += gridDim.x) {
-        int z, x;
-        nd_cell(n, a, z, x);
-        cplx *dst = Xt + ((long long)z * nx + x) * nrhs;
-        const cplx *src = V + (long long)a * nrhs;
+// backward pass: Xt[separator cells] = XS (cnt x smax rows)
+__global__ __launch_bounds__(256) void k_nd_bwd_store(const int4 *tab, const cplx *XS, cplx *Xt, long long rows, int smax, int nmax, int nrhs) {
+    for (long long row = (long long)blockIdx.x * blockDim.y + threadIdx.y; row < rows; row += (long long)gridDim.x * blockDim.y) {
+        const long long j = row / smax;
+        const int a = (int)(row - j * smax);
+        const int4 e = tab[j * nmax + a];
+        if (!e.w) continue;
+        const cplx *src = XS + row * nrhs;
+        cplx *dst = Xt + (long long)e.x * nrhs;
         for (int r = threadIdx.x; r < nrhs; r += blockDim.x) dst[r] = src[r];
     }
 }
@@ -430,10 +446,54 @@ void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cp
 
 }  // namespace
 
+// ---- plan cache ---------------------------------------------------------------------------------------------------
+NdPlanDev::~NdPlanDev() {
+    if (d_nodes) hipFree(d_nodes);
+    if (d_tab) hipFree(d_tab);
+}
+
+namespace {
+std::mutex g_plan_mu;
+std::vector<std::shared_ptr<NdPlanDev>> g_plans;     // most recently used last, at most 4 kept alive by the cache
+}
+
+int nd_get_plan(helm_op *op, int leaf, std::shared_ptr<NdPlanDev> *out) {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    for (size_t i = 0; i < g_plans.size(); ++i) {
+        const NdPlanDev &c = *g_plans[i];
+        if (c.device == op->device && c.plan.nz == op->nz && c.plan.nx == op->nx && c.plan.leaf == std::max(2, leaf)) {
+            std::shared_ptr<NdPlanDev> hit = g_plans[i];
+            g_plans.erase(g_plans.begin() + i); g_plans.push_back(hit);
+            *out = hit;
+            return HELM_OK;
+        }
+    }
+    std::shared_ptr<NdPlanDev> pd(new NdPlanDev());
+    pd->device = op->device;
+    nd_build_plan(pd->plan, op->nz, op->nx, leaf);
+    const NdPlan &P = pd->plan;
+    if (2 * P.vregion >= (1LL << 31) || P.total_rows >= (1LL << 31)) HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "direct solver: grid too large for 32-bit row indices");
+    HIP_TRY(op, hipMalloc((void **)&pd->d_nodes, P.nodes.size() * sizeof(NdDev)));
+    HIP_TRY(op, hipMalloc((void **)&pd->d_tab, (size_t)P.total_rows * sizeof(int4)));
+    HIP_TRY(op, hipMemcpyAsync(pd->d_nodes, P.nodes.data(), P.nodes.size() * sizeof(NdDev), hipMemcpyHostToDevice, op->stream));
+    for (size_t gi = 0; gi < P.groups.size(); ++gi) {
+        const NdGroup &g = P.groups[gi];
+        const int nmax = g.smax + g.mmax;
+        for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
+            const int nb = std::min(65535, g.cnt - j0);
+            hipLaunchKernelGGL(k_nd_build_tab, dim3((nmax + 255) / 256, nb), dim3(256), 0, op->stream, pd->d_nodes, g.first + j0, pd->d_tab, P.nz, P.nx);
+        }
+    }
+    HIP_TRY(op, hipStreamSynchronize(op->stream));      // the host-side node array may go away after this
+    g_plans.push_back(pd);
+    if (g_plans.size() > 4) g_plans.erase(g_plans.begin());
+    *out = pd;
+    return HELM_OK;
+}
+
 // ---- factorisation ---------------------------------------------------------------------------------------------
 void nd_free(NdFactor *f) {
     if (!f) return;
-    if (f->d_nodes) hipFree(f->d_nodes);
     if (f->d_fac) hipFree(f->d_fac);
     delete f;
 }
@@ -442,7 +502,8 @@ long long nd_factor_ws_elems(const NdPlan &P) { return 2 * P.fregion + P.work_el
 
 // ws: nd_factor_ws_elems(plan) elements of scratch (fronts of two adjacent levels + inversion workspace)
 int nd_factor(helm_op *op, int block, NdFactor *f, cplx *ws) {
-    NdPlan &P = f->plan;
+    const NdPlan &P = f->pd->plan;
+    const NdDev *d_nodes = f->pd->d_nodes;
     hipStream_t st = op->stream;
     cplx *arenaF = ws, *work = ws + 2 * P.fregion;
     auto fail = [&](const char *what, hipError_t e) {
@@ -450,10 +511,6 @@ int nd_factor(helm_op *op, int block, NdFactor *f, cplx *ws) {
         return HELM_ERR_DEVICE;
     };
     hipError_t e;
-    if (!f->d_nodes) {
-        if ((e = hipMalloc((void **)&f->d_nodes, P.nodes.size() * sizeof(NdDev))) != hipSuccess) return fail("hipMalloc(nodes)", e);
-        if ((e = hipMemcpyAsync(f->d_nodes, P.nodes.data(), P.nodes.size() * sizeof(NdDev), hipMemcpyHostToDevice, st)) != hipSuccess) return fail("upload", e);
-    }
     if (!f->d_fac && (e = hipMalloc((void **)&f->d_fac, (size_t)P.fac_elems * sizeof(cplx))) != hipSuccess) return fail("hipMalloc(factors)", e);
     const cplx *planes = op->d_C + (long long)block * op->nplanes * op->N;
     const cplx one = cmake(1, 0), mone = cmake(-1, 0), zero = cmake(0, 0);
@@ -466,7 +523,7 @@ int nd_factor(helm_op *op, int block, NdFactor *f, cplx *ws) {
         if ((e = hipMemsetAsync(F, 0, (size_t)g.cnt * fs * sizeof(cplx), st)) != hipSuccess) return fail("memset", e);
         for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
             const int nb = std::min(65535, g.cnt - j0);
-            hipLaunchKernelGGL(k_nd_assemble, dim3((nmax + 255) / 256, nb), dim3(256), 0, st, f->d_nodes, g.first + j0, arenaF, planes, op->nz, op->nx);
+            hipLaunchKernelGGL(k_nd_assemble, dim3((nmax + 255) / 256, nb), dim3(256), 0, st, d_nodes, g.first + j0, arenaF, planes, op->nz, op->nx);
         }
         if (!g.leaf) {
             // children's ring sizes are bounded by this group's front size
@@ -475,7 +532,7 @@ int nd_factor(helm_op *op, int block, NdFactor *f, cplx *ws) {
                 for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
                     const int nb = std::min(65535, g.cnt - j0);
                     const int rb = std::max(1, std::min(nmax, 16384 / std::max(1, nb)));
-                    hipLaunchKernelGGL(k_nd_extend_add, dim3(rb, nb), dim3(256), shm, st, f->d_nodes, g.first + j0, slot, arenaF, op->nz, op->nx);
+                    hipLaunchKernelGGL(k_nd_extend_add, dim3(rb, nb), dim3(256), shm, st, d_nodes, g.first + j0, slot, arenaF, op->nz, op->nx);
                 }
         }
         invert(op, F, nmax, fs, g.smax, g.cnt, work, (long long)g.smax * g.smax);
@@ -510,32 +567,24 @@ int nd_factor(helm_op *op, int block, NdFactor *f, cplx *ws) {
 long long nd_solve_ws_elems(const NdPlan &P, int nrhs) { return ((long long)P.nz * P.nx + 2 * P.vregion) * nrhs; }
 
 int nd_solve(helm_op *op, NdFactor *f, const cplx *Xin, cplx *Xout, int nrhs, cplx *ws) {
-    const NdPlan &P = f->plan;
+    const NdPlan &P = f->pd->plan;
+    const int4 *tab = f->pd->d_tab;
     hipStream_t st = op->stream;
     const long long N = (long long)P.nz * P.nx;
     cplx *Xt = ws, *arenaV = ws + N * nrhs;
     const cplx one = cmake(1, 0), mone = cmake(-1, 0), zero = cmake(0, 0);
+    int lx = 1;
+    while (lx < nrhs && lx < 256) lx <<= 1;
+    const dim3 rb(lx, 256 / lx);
+    auto rgrid = [&](long long rows) { return dim3((unsigned)std::min<long long>((rows + rb.y - 1) / rb.y, 1 << 20)); };
     hipLaunchKernelGGL(k_transpose, dim3((unsigned)((N + 31) / 32), (nrhs + 31) / 32), dim3(256), 0, st, Xin, (long long)nrhs, N, Xt);
     // forward elimination, leaves to root
     for (size_t gi = 0; gi < P.groups.size(); ++gi) {
         const NdGroup &g = P.groups[gi];
         const int nmax = g.smax + g.mmax;
+        const long long rows = (long long)g.cnt * nmax;
         cplx *V = arenaV + g.voff * nrhs;
-        for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
-            const int nb = std::min(65535, g.cnt - j0);
-            hipLaunchKernelGGL(k_nd_vec_gather, dim3(std::min(nmax, 128), nb), dim3(256), 0, st, f->d_nodes, g.first + j0, arenaV, Xt, nrhs, P.nx, 0);
-        }
-        if (!g.leaf) {
-            for (int slot = 0; slot < 2; ++slot)
-                for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
-                    const int nb = std::min(65535, g.cnt - j0);
-                    hipLaunchKernelGGL(k_nd_vec_extend_add, dim3(std::min(nmax, 128), nb), dim3(256), 0, st, f->d_nodes, g.first + j0, slot, arenaV, nrhs, P.nz, P.nx);
-                }
-            for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
-                const int nb = std::min(65535, g.cnt - j0);
-                hipLaunchKernelGGL(k_nd_vec_store, dim3(std::min(g.smax, 128), nb), dim3(256), 0, st, f->d_nodes, g.first + j0, arenaV, g.voff + (long long)j0 * nmax, nmax, Xt, nrhs, P.nx);
-            }
-        }
+        hipLaunchKernelGGL(k_nd_fwd_rows, rgrid(rows), rb, 0, st, tab + g.roff, V, arenaV, Xt, rows, nrhs, g.leaf ? 0 : 1);
         if (g.mmax > 0)     // outgoing ring part: V_B -= G21 V_S
             gemm(op, g.mmax, nrhs, g.smax, mone, f->d_fac + g.g21, g.smax, (long long)g.mmax * g.smax, V, nrhs, (long long)nmax * nrhs, one,
                  V + (long long)g.smax * nrhs, nrhs, (long long)nmax * nrhs, g.cnt);
@@ -544,23 +593,19 @@ int nd_solve(helm_op *op, NdFactor *f, const cplx *Xin, cplx *Xout, int nrhs, cp
     for (size_t gk = P.groups.size(); gk-- > 0;) {
         const NdGroup &g = P.groups[gk];
         const int nmax = g.smax + g.mmax;
+        const long long rows = (long long)g.cnt * nmax;
         cplx *V = arenaV + g.voff * nrhs;
         // the other region is free in this pass: separator results go there
         const long long xs_off = g.voff + ((g.level & 1) ? -P.vregion : P.vregion);
         cplx *XS = arenaV + xs_off * nrhs;
-        for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
-            const int nb = std::min(65535, g.cnt - j0);
-            hipLaunchKernelGGL(k_nd_vec_gather, dim3(std::min(nmax, 128), nb), dim3(256), 0, st, f->d_nodes, g.first + j0, arenaV, Xt, nrhs, P.nx, 1);
-        }
+        hipLaunchKernelGGL(k_nd_bwd_gather, rgrid(rows), rb, 0, st, tab + g.roff, V, Xt, rows, nrhs);
         if (g.mmax > 0)
             gemm(op, g.smax, nrhs, g.mmax, mone, f->d_fac + g.f12, g.mmax, (long long)g.smax * g.mmax, V + (long long)g.smax * nrhs, nrhs, (long long)nmax * nrhs,
                  one, V, nrhs, (long long)nmax * nrhs, g.cnt);
         gemm(op, g.smax, nrhs, g.smax, one, f->d_fac + g.finv, g.smax, (long long)g.smax * g.smax, V, nrhs, (long long)nmax * nrhs, zero,
              XS, nrhs, (long long)g.smax * nrhs, g.cnt);
-        for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
-            const int nb = std::min(65535, g.cnt - j0);
-            hipLaunchKernelGGL(k_nd_vec_store, dim3(std::min(g.smax, 128), nb), dim3(256), 0, st, f->d_nodes, g.first + j0, arenaV, xs_off + (long long)j0 * g.smax, g.smax, Xt, nrhs, P.nx);
-        }
+        const long long srows = (long long)g.cnt * g.smax;
+        hipLaunchKernelGGL(k_nd_bwd_store, rgrid(srows), rb, 0, st, tab + g.roff, XS, Xt, srows, g.smax, nmax, nrhs);
     }
     hipLaunchKernelGGL(k_transpose, dim3((nrhs + 31) / 32, (unsigned)((N + 31) / 32)), dim3(256), 0, st, Xt, N, (long long)nrhs, Xout);
     hipError_t e = hipGetLastError();

@@ -1,6 +1,7 @@
 // Nested-dissection direct solver: plan structures and the closed-form front index maps (host + device).
 #pragma once
 #include "helm_internal.hpp"
+#include <memory>
 
 struct NdDev {                // one front = one node of the elimination tree
     int z0, z1, x0, x1;       // region of the subtree (half-open)
@@ -11,6 +12,7 @@ struct NdDev {                // one front = one node of the elimination tree
     int smax, mmax;           // padded sizes of the node's group
     long long foff;           // front matrix offset in the factorisation arena (elements)
     long long voff;           // front vector offset in the solve arena (rows; x nrhs elements)
+    long long roff;           // first row of this front in the row table
 };
 
 struct NdGroup {              // nodes of one tree level and kind: one strided batch
@@ -18,6 +20,7 @@ struct NdGroup {              // nodes of one tree level and kind: one strided b
     bool leaf = false;
     int smax = 0, mmax = 0;
     long long foff = 0, voff = 0;
+    long long roff = 0;                        // first row of the group in the row table (cnt * (smax + mmax) rows)
     long long finv = 0, g21 = 0, f12 = 0;      // offsets of F11^-1 [cnt][smax][smax], G21 [cnt][mmax][smax], F12 [cnt][smax][mmax]
 };
 
@@ -25,12 +28,24 @@ struct NdPlan {
     int nz = 0, nx = 0, leaf = 8, nlevels = 0;
     std::vector<NdDev> nodes;                  // processing order: deepest level first
     std::vector<NdGroup> groups;
-    long long fac_elems = 0, fregion = 0, vregion = 0, work_elems = 0;
+    long long fac_elems = 0, fregion = 0, vregion = 0, work_elems = 0, total_rows = 0;
+};
+
+// Row table of the solve phase, one entry per padded front row:
+//   x: grid cell of the row (separator or ring cell), -1 for padding
+//   y, z: arena rows (front-vector rows, region offset included) of the children's outgoing rows that land here, -1: none
+//   w: 1 for separator rows
+// Built once per plan by a kernel from the closed-form index maps.
+struct NdPlanDev {            // plan + its device-resident tables, shared by every handle with the same grid on a device
+    NdPlan plan;
+    int device = 0;
+    NdDev *d_nodes = nullptr;
+    int4 *d_tab = nullptr;
+    ~NdPlanDev();
 };
 
 struct NdFactor {
-    NdPlan plan;
-    NdDev *d_nodes = nullptr;
+    std::shared_ptr<NdPlanDev> pd;
     cplx *d_fac = nullptr;
     int block = 0;
     double flops = 0;
@@ -73,7 +88,8 @@ __host__ __device__ inline int nd_pos(const NdDev &n, int a) { return a < n.s ? 
 
 int nd_build_plan(NdPlan &P, int nz, int nx, int leaf);
 long long nd_factor_ws_elems(const NdPlan &P);
-int nd_factor(helm_op *op, int block, NdFactor *f, cplx *ws);    // f->plan must be built
+int nd_get_plan(helm_op *op, int leaf, std::shared_ptr<NdPlanDev> *out);    // cached per (device, grid, leaf)
+int nd_factor(helm_op *op, int block, NdFactor *f, cplx *ws);    // f->pd must be set
 void nd_free(NdFactor *f);
 long long nd_solve_ws_elems(const NdPlan &P, int nrhs);
 int nd_solve(helm_op *op, NdFactor *f, const cplx *Xin, cplx *Xout, int nrhs, cplx *ws);
