@@ -110,3 +110,43 @@ def test_direct_new_frequency_refactors_and_unsupported_cases(helm_lib):
     tti = dict(cfg, theta=np.full((nz, nx), 0.3), eps=np.full((nz, nx), 0.2), delta=np.full((nz, nx), 0.05))
     with pytest.raises(Exception):
         za.Eurus(tti) * q
+
+
+def test_auto_prefers_direct_and_falls_back_to_krylov(helm_lib, monkeypatch):
+    import zephyr_amd as za
+    nz, nx = 64, 72
+    rng = np.random.default_rng(11)
+    c = 2000. + 1500. * rng.random((nz, nx))
+    cfg = dict(nx=nx, nz=nz, dx=10., dz=10., c=c, freq=7., nPML=8, rtol=1e-10)
+    q = za.SimpleSource(cfg)(np.array([[300., 320.], [500., 200.]]))
+    ref = ho.DirectOperator(ho.eurus_coefficients(nz, nx, c, ho.gardner_rho(c.astype(complex)), 7., dx=10., dz=10., nPML=8), eurus=True) * q
+    op = za.Eurus(cfg)                       # method defaults to 'auto'
+    u = op * q
+    assert all(i['method'] == 4 for i in op.lastInfo) and nrm(u, ref) <= 1e-8
+    monkeypatch.setenv('HELM_ND_INJECT_FAILURE', '1')
+    op2 = za.Eurus(cfg)
+    u2 = op2 * q
+    assert all(i['method'] == 3 and i['status'] == 0 and i['iterations'] > 5 for i in op2.lastInfo), op2.lastInfo
+    assert nrm(u2, ref) <= 1e-7
+    with pytest.raises(Exception) as ei:
+        za.Eurus(dict(cfg, method='direct')) * q
+    assert 'injected' in str(ei.value)
+    monkeypatch.delenv('HELM_ND_INJECT_FAILURE')
+    assert helm_lib.helm_trim() == 0
+
+
+def test_direct_free_surface_and_viscous_configurations(helm_lib):
+    """configurations the reference supports on the MiniZephyr side: free surfaces (sign-flipped identity rows), complex
+    velocity (Q), Laplace damping tau, dx != dz"""
+    import zephyr_amd as za
+    nz, nx = 60, 84
+    rng = np.random.default_rng(2)
+    c = (2200. + 800. * rng.random((nz, nx))) * (1 + 0.5j / 80.)
+    rho = 1800. + 300. * rng.random((nz, nx))
+    cfg = dict(nx=nx, nz=nz, dx=8., dz=12., c=c, rho=rho, freq=10., nPML=7, tau=0.6, freeSurf=(True, False, False, True),
+               method='direct', rtol=1e-11)
+    q = za.SimpleSource(cfg)(np.array([[250., 300.], [420., 90.]]))
+    op = za.MiniZephyr(cfg)
+    u = op * q
+    C = ho.minizephyr_coefficients(nz, nx, c, rho, 10., dx=8., dz=12., nPML=7, tau=0.6, freeSurf=(True, False, False, True))
+    assert nrm(u, ho.DirectOperator(C) * q) <= 1e-9

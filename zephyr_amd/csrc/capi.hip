@@ -522,10 +522,13 @@ struct WsLease {
 int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long long row_off, cplx premul,
                        const cplx *sub, cplx *dXout, int nrhs, const helm_solve_opts &o, helm_solve_info *info) {
     const long long N = op->N;
-    if ((long long)((N + 31) / 32) > 65535) HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "direct solver: grid too large (more than 2M cells)");
     int rc;
     NdFactor *f = op->direct[block];
     const bool need_factor = (f == nullptr);
+    {   // fault injection for the tests of the AUTO fallback
+        const char *inj = getenv("HELM_ND_INJECT_FAILURE");
+        if (inj && atoi(inj) != 0) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: injected failure (HELM_ND_INJECT_FAILURE)");
+    }
     if (need_factor) {
         const char *e = getenv("HELM_ND_LEAF");
         f = new NdFactor();
@@ -625,7 +628,7 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
     }
     // AUTO: the sparse direct path wherever it applies (2-D single-block systems that fit), else / on failure the
     // multigrid-preconditioned Krylov path below
-    if (o.method == HELM_AUTO && !sys2 && op->ny == 0 && !op->direct_failed && (N + 31) / 32 <= 65535) {
+    if (o.method == HELM_AUTO && !sys2 && op->ny == 0 && !op->direct_failed) {
         const char *e = getenv("HELM_AUTO_DIRECT");
         if (!e || atoi(e) != 0) {
             std::vector<helm_solve_info> saved;

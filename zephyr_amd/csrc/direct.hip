@@ -312,9 +312,10 @@ __global__ void k_copy2d(const cplx *src, int lds_, long long ss, cplx *dst, int
 
 // ---- solve-phase data movement -----------------------------------------------------------------------------------
 // out[i][r] = in[r][i]   (in: rows x cols)
-__global__ __launch_bounds__(256) void k_transpose(const cplx *in, long long rows, long long cols, cplx *out) {
+// (the long dimension always rides on gridDim.x: `swap` exchanges the roles of blockIdx.x / blockIdx.y)
+__global__ __launch_bounds__(256) void k_transpose(const cplx *in, long long rows, long long cols, cplx *out, int swap) {
     __shared__ cplx t[32][33];
-    const long long c0 = (long long)blockIdx.x * 32, r0 = (long long)blockIdx.y * 32;
+    const long long c0 = (long long)(swap ? blockIdx.y : blockIdx.x) * 32, r0 = (long long)(swap ? blockIdx.x : blockIdx.y) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int j = ty; j < 32; j += 8)
         if (r0 + j < rows && c0 + tx < cols) t[j][tx] = in[(r0 + j) * cols + c0 + tx];
@@ -577,7 +578,7 @@ int nd_solve(helm_op *op, NdFactor *f, const cplx *Xin, cplx *Xout, int nrhs, cp
     while (lx < nrhs && lx < 256) lx <<= 1;
     const dim3 rb(lx, 256 / lx);
     auto rgrid = [&](long long rows) { return dim3((unsigned)std::min<long long>((rows + rb.y - 1) / rb.y, 1 << 20)); };
-    hipLaunchKernelGGL(k_transpose, dim3((unsigned)((N + 31) / 32), (nrhs + 31) / 32), dim3(256), 0, st, Xin, (long long)nrhs, N, Xt);
+    hipLaunchKernelGGL(k_transpose, dim3((unsigned)((N + 31) / 32), (nrhs + 31) / 32), dim3(256), 0, st, Xin, (long long)nrhs, N, Xt, 0);
     // forward elimination, leaves to root
     for (size_t gi = 0; gi < P.groups.size(); ++gi) {
         const NdGroup &g = P.groups[gi];
@@ -607,7 +608,7 @@ int nd_solve(helm_op *op, NdFactor *f, const cplx *Xin, cplx *Xout, int nrhs, cp
         const long long srows = (long long)g.cnt * g.smax;
         hipLaunchKernelGGL(k_nd_bwd_store, rgrid(srows), rb, 0, st, tab + g.roff, XS, Xt, srows, g.smax, nmax, nrhs);
     }
-    hipLaunchKernelGGL(k_transpose, dim3((nrhs + 31) / 32, (unsigned)((N + 31) / 32)), dim3(256), 0, st, Xt, N, (long long)nrhs, Xout);
+    hipLaunchKernelGGL(k_transpose, dim3((unsigned)((N + 31) / 32), (nrhs + 31) / 32), dim3(256), 0, st, Xt, N, (long long)nrhs, Xout, 1);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { char b[256]; snprintf(b, sizeof(b), "direct solver: solve kernels failed: %s", hipGetErrorString(e)); helm_set_error(op, b); return HELM_ERR_DEVICE; }
     return HELM_OK;
