@@ -5,6 +5,7 @@
 #include "helm_internal.hpp"
 #include "direct.hpp"
 #include <mutex>
+#include <map>
 #include <cstring>
 #include <algorithm>
 #include <limits>
@@ -42,6 +43,39 @@ struct SharedWs { std::mutex mu; void *ptr = nullptr; size_t bytes = 0; int devi
 static SharedWs g_shared_ws;
 static int g_live_handles = 0;     // guarded by g_shared_ws.mu
 
+struct DevPool { std::mutex mu; std::multimap<std::pair<int, size_t>, void *> idle; size_t held = 0; };
+static DevPool g_pool;
+static const size_t kPoolMinBytes = (size_t)16 << 20, kPoolCapBytes = (size_t)24 << 30;
+
+void *helm_pool_alloc(int device, size_t bytes) {
+    {
+        std::lock_guard<std::mutex> lk(g_pool.mu);
+        auto it = g_pool.idle.find(std::make_pair(device, bytes));
+        if (it != g_pool.idle.end()) { void *p = it->second; g_pool.idle.erase(it); g_pool.held -= bytes; return p; }
+    }
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        // under memory pressure give the cached buffers back and try once more
+        std::lock_guard<std::mutex> lk(g_pool.mu);
+        for (auto &kv : g_pool.idle) hipFree(kv.second);
+        g_pool.idle.clear(); g_pool.held = 0;
+        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    }
+    return p;
+}
+void helm_pool_free(int device, void *p, size_t bytes) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_pool.mu);
+        if (bytes >= kPoolMinBytes && g_pool.held + bytes <= kPoolCapBytes) {
+            g_pool.idle.insert(std::make_pair(std::make_pair(device, bytes), p)); g_pool.held += bytes;
+            return;
+        }
+    }
+    hipFree(p);
+}
+
 
 static helm_op *create_common(helm_op *op);
 
@@ -78,9 +112,8 @@ static helm_op *create_common(helm_op *op) {
     { std::lock_guard<std::mutex> lk(g_shared_ws.mu); g_live_handles += 1; }
     HIP_TRY_NULL(hipMalloc(&op->d_c, N * sizeof(cplx)));
     HIP_TRY_NULL(hipMalloc(&op->d_rho, N * sizeof(double)));
-    HIP_TRY_NULL(hipMalloc(&op->d_C, (size_t)op->nblocks * op->nplanes * N * sizeof(cplx)));
-    HIP_TRY_NULL(hipMalloc(&op->d_Cs, (size_t)op->nblocks * op->nplanes * N * sizeof(cplx)));
-    HIP_TRY_NULL(hipMalloc(&op->d_dinv, (size_t)op->nblocks * N * sizeof(cplx)));
+    op->d_C = (cplx *)helm_pool_alloc(device, (size_t)op->nblocks * op->nplanes * N * sizeof(cplx));
+    if (!op->d_C) { helm_set_error(nullptr, "hipMalloc of the coefficient planes failed"); hipFree(op->d_c); hipFree(op->d_rho); delete op; return nullptr; }
     return op;
 }
 
@@ -89,7 +122,12 @@ extern "C" void helm_destroy(helm_op *op) {
     hipSetDevice(op->device);
     if (op->stream) hipStreamSynchronize(op->stream);
     hipFree(op->d_c); hipFree(op->d_rho); hipFree(op->d_theta); hipFree(op->d_eps); hipFree(op->d_delta);
-    hipFree(op->d_C); hipFree(op->d_Cs); hipFree(op->d_dinv); hipFree(op->d_S); hipFree(op->d_rs);
+    {
+        const size_t pb = (size_t)op->nblocks * op->nplanes * (size_t)op->N * sizeof(cplx);
+        helm_pool_free(op->device, op->d_C, pb); helm_pool_free(op->device, op->d_Cs, pb);
+        helm_pool_free(op->device, op->d_dinv, (size_t)op->nblocks * (size_t)op->N * sizeof(cplx));
+    }
+    hipFree(op->d_S); hipFree(op->d_rs);
     if (op->mg) mg_destroy(op);
     for (int b = 0; b < 4; ++b) { nd_free(op->direct[b]); op->direct[b] = nullptr; }
     hipFree(op->d_ws); hipFree(op->d_part); hipFree(op->d_scal);
@@ -108,6 +146,9 @@ extern "C" int helm_trim(void) {
     if (g_shared_ws.busy) return HELM_ERR_STATE;
     if (g_shared_ws.ptr) { hipSetDevice(g_shared_ws.device); hipFree(g_shared_ws.ptr); }
     g_shared_ws.ptr = nullptr; g_shared_ws.bytes = 0; g_shared_ws.device = -1;
+    std::lock_guard<std::mutex> lp(g_pool.mu);
+    for (auto &kv : g_pool.idle) { hipSetDevice(kv.first.first); hipFree(kv.second); }
+    g_pool.idle.clear(); g_pool.held = 0;
     return HELM_OK;
 }
 
@@ -176,14 +217,26 @@ extern "C" int helm_assemble(helm_op *op, double freq_re, double freq_im, double
     HIP_TRY(op, hipSetDevice(op->device));
     int rc = op->ny > 0 ? helm3d_launch_assemble(op, freq_re, freq_im, tau, cPML) : helm_launch_assemble(op, freq_re, freq_im, tau, ky, cPML);
     if (rc) return rc;
-    rc = helm_launch_scale_planes(op);
-    if (rc) return rc;
+    op->scaled_ok = false;
+    if (op->block0_only) { rc = helm_ensure_scaled(op); if (rc) return rc; }     // multigrid levels always smooth with 1/diag
     HIP_TRY(op, hipStreamSynchronize(op->stream));
     op->assembled = true;
     op->a_freq_re = freq_re; op->a_freq_im = freq_im; op->a_tau = tau; op->a_ky = ky; op->a_cpml = cPML;
     if (op->mg) mg_destroy(op);      // preconditioner belongs to the previous frequency
     for (int b = 0; b < 4; ++b) { nd_free(op->direct[b]); op->direct[b] = nullptr; }   // and so do the direct factors
     op->direct_failed = false;
+    return HELM_OK;
+}
+
+int helm_ensure_scaled(helm_op *op) {
+    if (op->scaled_ok) return HELM_OK;
+    const size_t N = (size_t)op->N;
+    if (!op->d_Cs) op->d_Cs = (cplx *)helm_pool_alloc(op->device, (size_t)op->nblocks * op->nplanes * N * sizeof(cplx));
+    if (!op->d_dinv) op->d_dinv = (cplx *)helm_pool_alloc(op->device, (size_t)op->nblocks * N * sizeof(cplx));
+    if (!op->d_Cs || !op->d_dinv) HELM_FAIL(op, HELM_ERR_DEVICE, "hipMalloc of the scaled coefficient planes failed");
+    const int rc = helm_launch_scale_planes(op);
+    if (rc) return rc;
+    op->scaled_ok = true;
     return HELM_OK;
 }
 
@@ -641,6 +694,7 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
     }
     const long long NV = sys2 ? 2 * N : N;
     NvGuard guard(op, NV);
+    { const int rcs = helm_ensure_scaled(op); if (rcs) return rcs; }
     int Bmax = o.batch > 0 ? o.batch : 16;
     if (Bmax > nrhs) Bmax = nrhs;
     int rc = ensure_ws(op, (size_t)11 * Bmax * NV * sizeof(cplx));
@@ -851,9 +905,10 @@ extern "C" int helm_solve_device(helm_op *op, const void *dRHS, void *dU, int nr
     HIP_TRY(op, hipEventRecord(e0, op->stream));
 
     int result = 0;
-    cplx *dX = nullptr;
-    HIP_TRY(op, hipMalloc(&dX, (size_t)nrhs * N * sizeof(cplx)));
-    auto cleanup = [&]() { hipFree(dX); hipEventDestroy(e0); hipEventDestroy(e1); };
+    const size_t xbytes = (size_t)nrhs * N * sizeof(cplx);
+    cplx *dX = (cplx *)helm_pool_alloc(op->device, xbytes);
+    if (!dX) { hipEventDestroy(e0); hipEventDestroy(e1); HELM_FAIL(op, HELM_ERR_DEVICE, "hipMalloc failed"); }
+    auto cleanup = [&]() { hipStreamSynchronize(op->stream); helm_pool_free(op->device, dX, xbytes); hipEventDestroy(e0); hipEventDestroy(e1); };
 
     if (op->variant == HELM_EURUS && !op->block_zero[2]) {
         // eps != delta: M3 != 0, the two fields are coupled -> Jacobi-BiCGSTAB on the full 2N x 2N system

@@ -495,7 +495,7 @@ int nd_get_plan(helm_op *op, int leaf, std::shared_ptr<NdPlanDev> *out) {
 // ---- factorisation ---------------------------------------------------------------------------------------------
 void nd_free(NdFactor *f) {
     if (!f) return;
-    if (f->d_fac) hipFree(f->d_fac);
+    if (f->d_fac) helm_pool_free(f->pd ? f->pd->device : 0, f->d_fac, (size_t)f->pd->plan.fac_elems * sizeof(cplx));
     delete f;
 }
 
@@ -512,7 +512,10 @@ int nd_factor(helm_op *op, int block, NdFactor *f, cplx *ws) {
         return HELM_ERR_DEVICE;
     };
     hipError_t e;
-    if (!f->d_fac && (e = hipMalloc((void **)&f->d_fac, (size_t)P.fac_elems * sizeof(cplx))) != hipSuccess) return fail("hipMalloc(factors)", e);
+    if (!f->d_fac) {
+        f->d_fac = (cplx *)helm_pool_alloc(op->device, (size_t)P.fac_elems * sizeof(cplx));
+        if (!f->d_fac) return fail("hipMalloc(factors)", hipErrorOutOfMemory);
+    }
     const cplx *planes = op->d_C + (long long)block * op->nplanes * op->N;
     const cplx one = cmake(1, 0), mone = cmake(-1, 0), zero = cmake(0, 0);
     double flops = 0;

@@ -122,6 +122,7 @@ struct helm_op {
     cplx *d_S = nullptr;      // coupled Eurus system: the four blocks scaled by the inverse 2-norm of their system row (36N), on demand
     double *d_rs = nullptr;   // 2N inverse row norms of the 2N x 2N system
     bool assembled = false;
+    bool scaled_ok = false;       // d_Cs / d_dinv hold the current operator (made on demand: only the Krylov paths need them)
     bool block_zero[4] = {false, false, false, false};   // block is identically zero (e.g. Eurus M3 isotropic)
 
     // solver workspace (grown on demand)
@@ -146,6 +147,12 @@ struct helm_op {
     HELM_FAIL(op, HELM_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); } } while (0)
 
 void helm_set_error(helm_op *op, const char *msg);
+
+// Size-keyed cache of large device buffers (coefficient planes, factors, per-call temporaries): a job walks through many
+// operators of identical shape, and hipMalloc/hipFree of GB-sized buffers cost milliseconds each.  helm_trim() empties it.
+void *helm_pool_alloc(int device, size_t bytes);          // nullptr on failure
+void helm_pool_free(int device, void *p, size_t bytes);   // the buffer must no longer be in use by any stream
+int helm_ensure_scaled(helm_op *op);                      // d_Cs, d_dinv for the operator currently assembled
 
 // ---- multigrid preconditioner (mg.hip) ---------------------------------------------------------
 struct MgPrecond;
