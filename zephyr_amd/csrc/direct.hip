@@ -191,41 +191,81 @@ __global__ __launch_bounds__(256) void k_nd_extend_add(const NdDev *nodes, int f
 // ---- strided-batched complex GEMM: C = beta C + alpha A B, row-major ----------------------------------------------
 // 64x64 tile, K step 8, 256 threads each owning a 4x4 block; the next K slab is fetched into registers while the
 // current one is multiplied out of LDS.
-#define GB_M 64
-#define GB_N 64
+//
+// IDX variant (solve phase): rows of B, of the C that is read (beta != 0) and of the C that is written may be taken
+// through the plan's row table instead of a dense front buffer, i.e. straight from / to the node-major right-hand sides
+// Xt[cell][rhs]:   row r of batch item z  ->  X + tab[z * tab_stride + off + r].x * ldx   (negative: a zero row / not stored).
+// This removes the gather / scatter passes (and their HBM round trips) from the lower tree levels.
+struct GemmRows {
+    const int4 *tabB = nullptr, *tabCi = nullptr, *tabCo = nullptr;
+    int offB = 0, offCi = 0, offCo = 0, tab_stride = 0;
+    const cplx *Bx = nullptr, *Cix = nullptr; cplx *Cox = nullptr;
+    int ldx = 0;
+    int z0 = 0;           // batch index of blockIdx.z == 0 (launches are chunked along z)
+};
 #define GB_K 8
+#define GB_KIDX 512       // largest K with indexed B rows
+// next K slab of the A and B tiles into registers (shared by both GEMM kernels)
+template <int TM, int TN, int NA, int NB>
+__device__ __forceinline__ void zg_fetch(cplx (&ra)[NA], cplx (&rb)[NB], int tid, int k0, int m0, int n0, int M, int Nn, int K,
+                                         const cplx *A, int lda, const cplx *B, int ldb, bool idxB, const int *kidx, const cplx *Bx, int ldx) {
+    #pragma unroll
+    for (int e = 0; e < NA; ++e) {
+        const int idx = tid + e * 256;
+        const int ar = idx >> 3, ak = idx & 7;
+        cplx v = cmake(0.0, 0.0);
+        if (idx < TM * GB_K && m0 + ar < M && k0 + ak < K) v = A[(long long)(m0 + ar) * lda + k0 + ak];
+        ra[e] = v;
+    }
+    #pragma unroll
+    for (int e = 0; e < NB; ++e) {
+        const int idx = tid + e * 256;
+        const int bk = idx / TN, bc = idx % TN;
+        cplx v = cmake(0.0, 0.0);
+        if (idx < TN * GB_K && k0 + bk < K && n0 + bc < Nn) {
+            if (idxB) { const int r = kidx[k0 + bk]; if (r >= 0) v = Bx[(long long)r * ldx + n0 + bc]; }
+            else v = B[(long long)(k0 + bk) * ldb + n0 + bc];
+        }
+        rb[e] = v;
+    }
+}
+#define ZG_FETCH(k0_) zg_fetch<TM, TN, NA, NB>(ra, rb, tid, (k0_), m0, n0, M, Nn, K, A, lda, B, ldb, idxB, kidx, R.Bx, R.ldx);
+
+// TM x TN tile with TM * TN = 4096: 64 x 64, 32 x 128 or 16 x 256 -- the fronts of the lower tree levels have 36, 54, 72 ...
+// rows against 256 right-hand sides, and a 64-row tile would spend up to 44 % of its flops on padding
+template <int TM, bool IDX>
 __global__ __launch_bounds__(256) void k_zgemm(int M, int Nn, int K, cplx alpha, const cplx *A0, int lda, long long sa,
-                                               const cplx *B0, int ldb, long long sb, cplx beta, cplx *C0, int ldc, long long sc) {
-    __shared__ cplx As[GB_K][GB_M + 1];
-    __shared__ cplx Bs[GB_K][GB_N];
+                                               const cplx *B0, int ldb, long long sb, cplx beta, cplx *C0, int ldc, long long sc, GemmRows R) {
+    constexpr int TN = 4096 / TM, TXN = TN / 4;
+    constexpr int NA = (TM * GB_K + 255) / 256, NB = TN * GB_K / 256;
+    __shared__ cplx As[GB_K][TM + 1];
+    __shared__ cplx Bs[GB_K][TN];
+    __shared__ int kidx[IDX ? GB_KIDX : 1];
     const cplx *A = A0 + (long long)blockIdx.z * sa;
     const cplx *B = B0 + (long long)blockIdx.z * sb;
     cplx *C = C0 + (long long)blockIdx.z * sc;
-    const int m0 = blockIdx.y * GB_M, n0 = blockIdx.x * GB_N;
-    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    // loader roles: A slab 64 rows x 8 k (2 elements per thread), B slab 8 k x 64 cols (2 per thread)
-    const int ar = tid >> 3, ak = tid & 7;          // rows ar and ar+32
-    const int bk = tid >> 6, bc = tid & 63;         // k rows bk and bk+4
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    const int tid = threadIdx.x, ty = tid / TXN, tx = tid % TXN;
+    const long long trow = IDX ? (long long)(R.z0 + blockIdx.z) * R.tab_stride : 0;
+    const bool idxB = IDX && R.tabB != nullptr;
+    if (idxB) {
+        for (int k = tid; k < K; k += 256) kidx[k] = R.tabB[trow + R.offB + k].x;
+        __syncthreads();
+    }
     cplx acc[4][4];
     #pragma unroll
     for (int i = 0; i < 4; ++i)
         #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = cmake(0.0, 0.0);
-    cplx ra0, ra1, rb0, rb1;
-    const cplx zero = cmake(0.0, 0.0);
-    auto fetch = [&](int k0) {
-        const int kk = k0 + ak;
-        ra0 = (m0 + ar < M && kk < K) ? A[(long long)(m0 + ar) * lda + kk] : zero;
-        ra1 = (m0 + ar + 32 < M && kk < K) ? A[(long long)(m0 + ar + 32) * lda + kk] : zero;
-        rb0 = (k0 + bk < K && n0 + bc < Nn) ? B[(long long)(k0 + bk) * ldb + n0 + bc] : zero;
-        rb1 = (k0 + bk + 4 < K && n0 + bc < Nn) ? B[(long long)(k0 + bk + 4) * ldb + n0 + bc] : zero;
-    };
-    fetch(0);
+    cplx ra[NA], rb[NB];
+    ZG_FETCH(0)
     for (int k0 = 0; k0 < K; k0 += GB_K) {
-        As[ak][ar] = ra0; As[ak][ar + 32] = ra1;
-        Bs[bk][bc] = rb0; Bs[bk + 4][bc] = rb1;
+        #pragma unroll
+        for (int e = 0; e < NA; ++e) { const int idx = tid + e * 256; if (idx < TM * GB_K) As[idx & 7][idx >> 3] = ra[e]; }
+        #pragma unroll
+        for (int e = 0; e < NB; ++e) { const int idx = tid + e * 256; Bs[idx / TN][idx % TN] = rb[e]; }
         __syncthreads();
-        if (k0 + GB_K < K) fetch(k0 + GB_K);
+        if (k0 + GB_K < K) { ZG_FETCH(k0 + GB_K) }
         #pragma unroll
         for (int k = 0; k < GB_K; ++k) {
             cplx a[4], b[4];
@@ -245,15 +285,140 @@ __global__ __launch_bounds__(256) void k_zgemm(int M, int Nn, int K, cplx alpha,
     for (int i = 0; i < 4; ++i) {
         const int r = m0 + ty * 4 + i;
         if (r >= M) continue;
+        cplx *dst = C + (long long)r * ldc;
+        const cplx *cin = dst;
+        if (IDX && R.tabCo) {
+            const int ix = R.tabCo[trow + R.offCo + r].x;
+            if (ix < 0) continue;
+            dst = R.Cox + (long long)ix * R.ldx;
+        }
+        if (IDX && R.tabCi && !b0) {
+            const int ix = R.tabCi[trow + R.offCi + r].x;
+            cin = ix >= 0 ? R.Cix + (long long)ix * R.ldx : nullptr;
+        }
         #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int cc = n0 + tx * 4 + j;
             if (cc >= Nn) continue;
             cplx v = cmul(alpha, acc[i][j]);
-            if (!b0) v = cadd(v, cmul(beta, C[(long long)r * ldc + cc]));
-            C[(long long)r * ldc + cc] = v;
+            if (!b0 && cin) v = cadd(v, cmul(beta, cin[cc]));
+            dst[cc] = v;
         }
     }
+}
+
+template <int TM>
+void launch_vec(hipStream_t st, bool idx, int nb, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, long long sa, const cplx *B, int ldb, long long sb,
+                cplx beta, cplx *C, int ldc, long long sc, const GemmRows &R) {
+    constexpr int TN = 4096 / TM;
+    dim3 grid((Nn + TN - 1) / TN, (M + TM - 1) / TM, nb);
+    if (idx) hipLaunchKernelGGL((k_zgemm<TM, true>), grid, dim3(256), 0, st, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
+    else hipLaunchKernelGGL((k_zgemm<TM, false>), grid, dim3(256), 0, st, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
+}
+
+// ---- the same GEMM on the matrix cores -------------------------------------------------------------------------
+// v_mfma_f64_16x16x4_f64: lane l holds A[l & 15][l >> 4] and B[l >> 4][l & 15]; result register r of lane l is
+// C[(l >> 4) + 4 r][l & 15].  A complex product is four real MFMAs on the (re, im) planes of the same lane data:
+//   Cre += Are Bre - Aim Bim ;  Cim += Are Bim + Aim Bre.
+// fp64 MFMA issues at the same flop rate as the vector FMAs, but one LDS read of 16 B per lane feeds 1024 real
+// multiply-adds instead of 16, so the kernel is no longer bound by LDS bandwidth (the vector tile kernel is).
+// Block = 4 waves arranged WM x WN; each wave owns RA x RB blocks of 16 x 16; tile = (16 RA WM) x (16 RB WN).
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+template <int RA, int RB, int WM, int WN, bool IDX>
+__global__ __launch_bounds__(256) void k_zgemm_mfma(int M, int Nn, int K, cplx alpha, const cplx *A0, int lda, long long sa,
+                                                    const cplx *B0, int ldb, long long sb, cplx beta, cplx *C0, int ldc, long long sc, GemmRows R) {
+    constexpr int TM = 16 * RA * WM, TN = 16 * RB * WN;
+    constexpr int NA = (TM * GB_K + 255) / 256, NB = (TN * GB_K + 255) / 256;
+    __shared__ cplx As[GB_K][TM + 1];
+    __shared__ cplx Bs[GB_K][TN + 1];
+    __shared__ int kidx[IDX ? GB_KIDX : 1];
+    const cplx *A = A0 + (long long)blockIdx.z * sa;
+    const cplx *B = B0 + (long long)blockIdx.z * sb;
+    cplx *C = C0 + (long long)blockIdx.z * sc;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const long long trow = IDX ? (long long)(R.z0 + blockIdx.z) * R.tab_stride : 0;
+    const bool idxB = IDX && R.tabB != nullptr;
+    if (idxB) {
+        for (int k = tid; k < K; k += 256) kidx[k] = R.tabB[trow + R.offB + k].x;
+        __syncthreads();
+    }
+    v4f64 cre[RA][RB], cim[RA][RB];
+    #pragma unroll
+    for (int i = 0; i < RA; ++i)
+        #pragma unroll
+        for (int j = 0; j < RB; ++j) { cre[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0}; cim[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0}; }
+    cplx ra[NA], rb[NB];
+    ZG_FETCH(0)
+    const int lr = lane & 15, lk = lane >> 4;
+    for (int k0 = 0; k0 < K; k0 += GB_K) {
+        #pragma unroll
+        for (int e = 0; e < NA; ++e) { const int idx = tid + e * 256; if (idx < TM * GB_K) As[idx & 7][idx >> 3] = ra[e]; }
+        #pragma unroll
+        for (int e = 0; e < NB; ++e) { const int idx = tid + e * 256; if (idx < TN * GB_K) Bs[idx / TN][idx % TN] = rb[e]; }
+        __syncthreads();
+        if (k0 + GB_K < K) { ZG_FETCH(k0 + GB_K) }
+        #pragma unroll
+        for (int kk = 0; kk < GB_K; kk += 4) {
+            cplx a[RA], b[RB];
+            #pragma unroll
+            for (int i = 0; i < RA; ++i) a[i] = As[kk + lk][(wm * RA + i) * 16 + lr];
+            #pragma unroll
+            for (int j = 0; j < RB; ++j) b[j] = Bs[kk + lk][(wn * RB + j) * 16 + lr];
+            // four sweeps over the RA x RB accumulator blocks, so that two MFMAs on the same accumulator are 2 RA RB - 1
+            // instructions apart (back-to-back dependent MFMAs stall for the full pass latency)
+            #pragma unroll
+            for (int i = 0; i < RA; ++i)
+                #pragma unroll
+                for (int j = 0; j < RB; ++j) {
+                    cre[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, cre[i][j], 0, 0, 0);
+                    cim[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].y, cim[i][j], 0, 0, 0);
+                }
+            #pragma unroll
+            for (int i = 0; i < RA; ++i)
+                #pragma unroll
+                for (int j = 0; j < RB; ++j) {
+                    cre[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[i].y, b[j].y, cre[i][j], 0, 0, 0);
+                    cim[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].x, cim[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+    const bool b0 = (beta.x == 0.0 && beta.y == 0.0);
+    #pragma unroll
+    for (int i = 0; i < RA; ++i)
+        #pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + (wm * RA + i) * 16 + lk + 4 * r;
+            if (row >= M) continue;
+            cplx *dst = C + (long long)row * ldc;
+            const cplx *cin = dst;
+            if (IDX && R.tabCo) {
+                const int ix = R.tabCo[trow + R.offCo + row].x;
+                if (ix < 0) continue;
+                dst = R.Cox + (long long)ix * R.ldx;
+            }
+            if (IDX && R.tabCi && !b0) {
+                const int ix = R.tabCi[trow + R.offCi + row].x;
+                cin = ix >= 0 ? R.Cix + (long long)ix * R.ldx : nullptr;
+            }
+            #pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                const int cc = n0 + (wn * RB + j) * 16 + lr;
+                if (cc >= Nn) continue;
+                cplx v = cmul(alpha, cmake(cre[i][j][r], cim[i][j][r]));
+                if (!b0 && cin) v = cadd(v, cmul(beta, cin[cc]));
+                dst[cc] = v;
+            }
+        }
+}
+
+template <int RA, int RB, int WM, int WN>
+void launch_mfma(hipStream_t st, dim3 grid, bool idx, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, long long sa, const cplx *B, int ldb, long long sb,
+                 cplx beta, cplx *C, int ldc, long long sc, const GemmRows &R) {
+    if (idx) hipLaunchKernelGGL((k_zgemm_mfma<RA, RB, WM, WN, true>), grid, dim3(256), 0, st, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
+    else hipLaunchKernelGGL((k_zgemm_mfma<RA, RB, WM, WN, false>), grid, dim3(256), 0, st, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
 }
 
 // ---- in-place inverse of n x n blocks, n <= 32: Gauss-Jordan with row pivoting in LDS, one workgroup per matrix ----
@@ -397,7 +562,7 @@ __global__ void k_axpy_one(cplx *y, const cplx *x, long long n) {
 
 // op may be null (diagnostic entry points): default stream, no profiling
 int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, long long sa, const cplx *B, int ldb, long long sb,
-         cplx beta, cplx *C, int ldc, long long sc, int batch) {
+         cplx beta, cplx *C, int ldc, long long sc, int batch, const GemmRows *rows = nullptr) {
     if (M <= 0 || Nn <= 0 || batch <= 0) return 0;
     hipStream_t st = op ? op->stream : nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -407,10 +572,41 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
         if (op->ev_used + 2 <= op->ev_pool.size()) { e0 = op->ev_pool[op->ev_used]; e1 = op->ev_pool[op->ev_used + 1]; }
     }
     if (e0) hipEventRecord(e0, st);
+    static const int use_mfma = getenv("HELM_ND_MFMA") ? atoi(getenv("HELM_ND_MFMA")) : 0;
+    static const int fixed_tm = getenv("HELM_ND_TM") ? atoi(getenv("HELM_ND_TM")) : 0;
+    int vbest = 64; long long varea = -1;
+    for (int tm = 64; tm >= 16; tm >>= 1) {
+        const int tn = 4096 / tm;
+        const long long area = (long long)((M + tm - 1) / tm) * tm * ((Nn + tn - 1) / tn) * tn;
+        if (varea < 0 || area < varea) { vbest = tm; varea = area; }
+    }
+    if (fixed_tm == 64 || fixed_tm == 32 || fixed_tm == 16) vbest = fixed_tm;
+    // tile shapes of the MFMA kernel: pick the one that pads M x N the least (ties: the larger tile)
+    static const int cfg_tm[4] = {64, 48, 32, 16}, cfg_tn[4] = {64, 128, 128, 256};
+    int best = 0; long long best_area = -1;
+    for (int c = 0; c < 4; ++c) {
+        const long long area = (long long)((M + cfg_tm[c] - 1) / cfg_tm[c]) * cfg_tm[c] * ((Nn + cfg_tn[c] - 1) / cfg_tn[c]) * cfg_tn[c];
+        if (best_area < 0 || area < best_area) { best = c; best_area = area; }
+    }
     for (int b0 = 0; b0 < batch; b0 += 65535) {
         const int nb = std::min(65535, batch - b0);
-        dim3 grid((Nn + GB_N - 1) / GB_N, (M + GB_M - 1) / GB_M, nb);
-        hipLaunchKernelGGL(k_zgemm, grid, dim3(256), 0, st, M, Nn, K, alpha, A + b0 * sa, lda, sa, B + b0 * sb, ldb, sb, beta, C + b0 * sc, ldc, sc);
+        GemmRows R; if (rows) R = *rows;
+        R.z0 = b0;
+        const cplx *Ab = A + b0 * sa, *Bb = B ? B + b0 * sb : B;
+        cplx *Cb = C ? C + b0 * sc : C;
+        if (use_mfma) {
+            dim3 grid((Nn + cfg_tn[best] - 1) / cfg_tn[best], (M + cfg_tm[best] - 1) / cfg_tm[best], nb);
+            switch (best) {
+                case 0: launch_mfma<2, 2, 2, 2>(st, grid, rows != nullptr, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R); break;
+                case 1: launch_mfma<3, 2, 1, 4>(st, grid, rows != nullptr, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R); break;
+                case 2: launch_mfma<2, 2, 1, 4>(st, grid, rows != nullptr, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R); break;
+                default: launch_mfma<1, 4, 1, 4>(st, grid, rows != nullptr, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R); break;
+            }
+            continue;
+        }
+        if (vbest == 64) launch_vec<64>(st, rows != nullptr, nb, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R);
+        else if (vbest == 32) launch_vec<32>(st, rows != nullptr, nb, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R);
+        else launch_vec<16>(st, rows != nullptr, nb, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R);
     }
     if (e0) {
         hipEventRecord(e1, st);
@@ -577,6 +773,7 @@ int nd_solve(helm_op *op, NdFactor *f, const cplx *Xin, cplx *Xout, int nrhs, cp
     const long long N = (long long)P.nz * P.nx;
     cplx *Xt = ws, *arenaV = ws + N * nrhs;
     const cplx one = cmake(1, 0), mone = cmake(-1, 0), zero = cmake(0, 0);
+    static const int use_idx = getenv("HELM_ND_IDXGEMM") ? atoi(getenv("HELM_ND_IDXGEMM")) : 1;
     int lx = 1;
     while (lx < nrhs && lx < 256) lx <<= 1;
     const dim3 rb(lx, 256 / lx);
@@ -588,6 +785,13 @@ int nd_solve(helm_op *op, NdFactor *f, const cplx *Xin, cplx *Xout, int nrhs, cp
         const int nmax = g.smax + g.mmax;
         const long long rows = (long long)g.cnt * nmax;
         cplx *V = arenaV + g.voff * nrhs;
+        if (use_idx && g.leaf && g.mmax > 0 && g.smax <= GB_KIDX) {
+            // leaves have no children: the outgoing ring part is -G21 x_S with x_S read straight from Xt
+            GemmRows R; R.tabB = tab + g.roff; R.offB = 0; R.tab_stride = nmax; R.Bx = Xt; R.ldx = nrhs;
+            gemm(op, g.mmax, nrhs, g.smax, mone, f->d_fac + g.g21, g.smax, (long long)g.mmax * g.smax, nullptr, 0, 0, zero,
+                 V + (long long)g.smax * nrhs, nrhs, (long long)nmax * nrhs, g.cnt, &R);
+            continue;
+        }
         hipLaunchKernelGGL(k_nd_fwd_rows, rgrid(rows), rb, 0, st, tab + g.roff, V, arenaV, Xt, rows, nrhs, g.leaf ? 0 : 1);
         if (g.mmax > 0)     // outgoing ring part: V_B -= G21 V_S
             gemm(op, g.mmax, nrhs, g.smax, mone, f->d_fac + g.g21, g.smax, (long long)g.mmax * g.smax, V, nrhs, (long long)nmax * nrhs, one,
@@ -602,6 +806,18 @@ int nd_solve(helm_op *op, NdFactor *f, const cplx *Xin, cplx *Xout, int nrhs, cp
         // the other region is free in this pass: separator results go there
         const long long xs_off = g.voff + ((g.level & 1) ? -P.vregion : P.vregion);
         cplx *XS = arenaV + xs_off * nrhs;
+        if (use_idx && g.mmax > 0 && g.mmax <= GB_KIDX) {
+            // lower tree levels (almost all rows): T = y_S - F12 x_B and x_S = F11^-1 T with every Xt row addressed through
+            // the row table -- no gather / store pass
+            GemmRows R1; R1.tabB = tab + g.roff; R1.offB = g.smax; R1.tabCi = tab + g.roff; R1.offCi = 0; R1.tab_stride = nmax;
+            R1.Bx = Xt; R1.Cix = Xt; R1.ldx = nrhs;
+            gemm(op, g.smax, nrhs, g.mmax, mone, f->d_fac + g.f12, g.mmax, (long long)g.smax * g.mmax, nullptr, 0, 0, one,
+                 V, nrhs, (long long)g.smax * nrhs, g.cnt, &R1);
+            GemmRows R2; R2.tabCo = tab + g.roff; R2.offCo = 0; R2.tab_stride = nmax; R2.Cox = Xt; R2.ldx = nrhs;
+            gemm(op, g.smax, nrhs, g.smax, one, f->d_fac + g.finv, g.smax, (long long)g.smax * g.smax, V, nrhs, (long long)g.smax * nrhs, zero,
+                 nullptr, 0, 0, g.cnt, &R2);
+            continue;
+        }
         hipLaunchKernelGGL(k_nd_bwd_gather, rgrid(rows), rb, 0, st, tab + g.roff, V, Xt, rows, nrhs);
         if (g.mmax > 0)
             gemm(op, g.smax, nrhs, g.mmax, mone, f->d_fac + g.f12, g.mmax, (long long)g.smax * g.mmax, V + (long long)g.smax * nrhs, nrhs, (long long)nmax * nrhs,
