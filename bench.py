@@ -316,10 +316,14 @@ def main():
         # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same
         # command; bench.py cannot run the profiler on itself) -- only when it was collected for this workload
         try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_krylov_pmc_traffic.json')))
             if not direct and pmc.get('batch') == B and pmc.get('grid') == [n, n]:
                 out['roofline']['traffic'] = pmc['traffic_bytes_per_launch_outer_applies']
-                out['roofline']['traffic_source'] = 'profiles/r01_pmc_traffic.json'
+                out['roofline']['traffic_source'] = 'profiles/r01_krylov_pmc_traffic.json'
+            pmd = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_direct.json')))
+            if direct and pmd.get('batch') == B and pmd.get('grid') == [n, n]:
+                out['roofline']['traffic'] = pmd['traffic_bytes_per_launch']
+                out['roofline']['traffic_source'] = 'profiles/r01_pmc_traffic_direct.json (HBM bytes per k_zgemm launch, FETCH_SIZE x2 + WRITE_SIZE)'
         except Exception:
             pass
         if world == 1 and not args.no_cpu:
