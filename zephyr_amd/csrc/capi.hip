@@ -39,8 +39,10 @@ extern "C" int helm_device_count(void) {
 // Scratch of the direct path (fronts while factoring, front vectors while solving) is tens of GB at the bench size and
 // is only needed during a call, so all handles of a process share one buffer; a handle that finds it taken (another
 // host thread is inside a solve) falls back to its own.
-struct SharedWs { std::mutex mu; void *ptr = nullptr; size_t bytes = 0; int device = -1; bool busy = false; };
+struct WsSlot { void *ptr = nullptr; size_t bytes = 0; int device = -1; bool busy = false; };
+struct SharedWs { std::mutex mu; WsSlot slot[4]; };
 static SharedWs g_shared_ws;
+static int shared_ws_slots() { const char *e = getenv("HELM_WS_SLOTS"); const int n = e ? atoi(e) : 2; return n < 1 ? 1 : (n > 4 ? 4 : n); }
 static int g_live_handles = 0;     // guarded by g_shared_ws.mu
 
 struct DevPool { std::mutex mu; std::multimap<std::pair<int, size_t>, void *> idle; size_t held = 0; };
@@ -143,9 +145,12 @@ extern "C" void helm_destroy(helm_op *op) {
 // handles on purpose -- allocating tens of GB costs far more than a solve -- so a host that wants the memory back says so.
 extern "C" int helm_trim(void) {
     std::lock_guard<std::mutex> lk(g_shared_ws.mu);
-    if (g_shared_ws.busy) return HELM_ERR_STATE;
-    if (g_shared_ws.ptr) { hipSetDevice(g_shared_ws.device); hipFree(g_shared_ws.ptr); }
-    g_shared_ws.ptr = nullptr; g_shared_ws.bytes = 0; g_shared_ws.device = -1;
+    for (int i = 0; i < 4; ++i) if (g_shared_ws.slot[i].busy) return HELM_ERR_STATE;
+    for (int i = 0; i < 4; ++i) {
+        WsSlot &w = g_shared_ws.slot[i];
+        if (w.ptr) { hipSetDevice(w.device); hipFree(w.ptr); }
+        w.ptr = nullptr; w.bytes = 0; w.device = -1;
+    }
     std::lock_guard<std::mutex> lp(g_pool.mu);
     for (auto &kv : g_pool.idle) { hipSetDevice(kv.first.first); hipFree(kv.second); }
     g_pool.idle.clear(); g_pool.held = 0;
@@ -542,32 +547,38 @@ struct NvGuard {     // Krylov vector length of the handle for the duration of a
 };
 
 
-void *ws_checkout(helm_op *op, size_t bytes, bool *shared) {
+void *ws_checkout(helm_op *op, size_t bytes, int *slot_out) {
     {
         std::lock_guard<std::mutex> lk(g_shared_ws.mu);
-        if (!g_shared_ws.busy && (g_shared_ws.ptr == nullptr || g_shared_ws.device == op->device)) {
-            if (g_shared_ws.bytes < bytes) {
-                if (g_shared_ws.ptr) hipFree(g_shared_ws.ptr);
-                g_shared_ws.ptr = nullptr; g_shared_ws.bytes = 0;
-                if (hipMalloc(&g_shared_ws.ptr, bytes) != hipSuccess) { g_shared_ws.ptr = nullptr; (void)hipGetLastError(); }
-                else { g_shared_ws.bytes = bytes; g_shared_ws.device = op->device; }
+        const int ns = shared_ws_slots();
+        // prefer an idle slot that is already big enough, then any idle slot
+        int pick = -1;
+        for (int i = 0; i < ns; ++i) { WsSlot &w = g_shared_ws.slot[i]; if (!w.busy && w.ptr && w.device == op->device && w.bytes >= bytes) { pick = i; break; } }
+        if (pick < 0) for (int i = 0; i < ns; ++i) { WsSlot &w = g_shared_ws.slot[i]; if (!w.busy && (w.ptr == nullptr || w.device == op->device)) { pick = i; break; } }
+        if (pick >= 0) {
+            WsSlot &w = g_shared_ws.slot[pick];
+            if (w.bytes < bytes) {
+                if (w.ptr) hipFree(w.ptr);
+                w.ptr = nullptr; w.bytes = 0;
+                if (hipMalloc(&w.ptr, bytes) != hipSuccess) { w.ptr = nullptr; (void)hipGetLastError(); }
+                else { w.bytes = bytes; w.device = op->device; }
             }
-            if (g_shared_ws.ptr) { g_shared_ws.busy = true; *shared = true; return g_shared_ws.ptr; }
+            if (w.ptr) { w.busy = true; *slot_out = pick; return w.ptr; }
         }
     }
-    *shared = false;
+    *slot_out = -1;
     if (ensure_ws(op, bytes) != HELM_OK) return nullptr;
     return op->d_ws;
 }
-void ws_checkin(bool shared) {
-    if (!shared) return;
+void ws_checkin(int slot) {
+    if (slot < 0) return;
     std::lock_guard<std::mutex> lk(g_shared_ws.mu);
-    g_shared_ws.busy = false;
+    g_shared_ws.slot[slot].busy = false;
 }
 struct WsLease {
-    bool shared = false; void *ptr = nullptr;
-    WsLease(helm_op *op, size_t bytes) { ptr = ws_checkout(op, bytes, &shared); }
-    ~WsLease() { ws_checkin(shared); }
+    int slot = -1; void *ptr = nullptr;
+    WsLease(helm_op *op, size_t bytes) { ptr = ws_checkout(op, bytes, &slot); }
+    ~WsLease() { ws_checkin(slot); }
 };
 
 // Sparse direct path (direct.hip): factor once per assembled operator, then per batch q' -> x by the multifrontal

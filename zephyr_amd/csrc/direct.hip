@@ -163,12 +163,15 @@ __global__ __launch_bounds__(256) void k_nd_assemble(const NdDev *nodes, int fir
     }
 }
 
-// parent front += Schur complement of child `slot` (rows of the child's F22 spread over gridDim.x blocks)
+// parent front += Schur complement of child `slot`; the m x m entries of the child's F22 are spread over gridDim.x blocks
+#define EA_CHUNK 4096
 __global__ __launch_bounds__(256) void k_nd_extend_add(const NdDev *nodes, int first, int slot, cplx *arenaF, int nz, int nx) {
     extern __shared__ int map[];
     const NdDev p = nodes[first + blockIdx.y];
     if (p.kid[slot] < 0) return;
     const NdDev c = nodes[p.kid[slot]];
+    const long long total = (long long)c.m * c.m;
+    if ((long long)blockIdx.x * EA_CHUNK >= total) return;
     for (int a = threadIdx.x; a < c.m; a += blockDim.x) {
         int z, x;
         nd_cell(c, c.s + a, z, x);
@@ -178,12 +181,12 @@ __global__ __launch_bounds__(256) void k_nd_extend_add(const NdDev *nodes, int f
     const cplx *Fc = arenaF + c.foff;
     cplx *Fp = arenaF + p.foff;
     const int ldc = c.smax + c.mmax, ldp = p.smax + p.mmax;
-    for (int a = blockIdx.x; a < c.m; a += gridDim.x) {
-        const cplx *src = Fc + (long long)(c.smax + a) * ldc + c.smax;
-        cplx *dst = Fp + (long long)map[a] * ldp;
-        for (int b = threadIdx.x; b < c.m; b += blockDim.x) {
-            cplx v = dst[map[b]];
-            dst[map[b]] = cadd(v, src[b]);
+    for (long long e0 = (long long)blockIdx.x * EA_CHUNK; e0 < total; e0 += (long long)gridDim.x * EA_CHUNK) {
+        const long long e1 = e0 + EA_CHUNK < total ? e0 + EA_CHUNK : total;
+        for (long long e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+            const int a = (int)(e / c.m), b2 = (int)(e - (long long)a * c.m);
+            cplx *dst = Fp + (long long)map[a] * ldp + map[b2];
+            *dst = cadd(*dst, Fc[(long long)(c.smax + a) * ldc + c.smax + b2]);
         }
     }
 }
@@ -432,6 +435,8 @@ __global__ __launch_bounds__(256) void k_gj_inverse(cplx *A0, int ld, long long 
     for (int e = tid; e < n * n; e += 256) a[e / n][e % n] = A[(long long)(e / n) * ld + e % n];
     __syncthreads();
     for (int k = 0; k < n; ++k) {
+        // wave 0 (n <= 32 lanes, lock-step): pivot search in column k, row exchange, scaling of the pivot row, and the
+        // column that the elimination needs -- every read of the old values is issued before the writes
         if (tid < 64) {
             double val = (tid >= k && tid < n) ? cabs2(a[tid][k]) : -1.0;
             int idx = tid;
@@ -440,16 +445,17 @@ __global__ __launch_bounds__(256) void k_gj_inverse(cplx *A0, int ld, long long 
                 const int oi = __shfl_down(idx, off);
                 if (ov > val) { val = ov; idx = oi; }
             }
-            if (tid == 0) piv[k] = idx;
+            const int p = __shfl(idx, 0);
+            if (tid == 0) piv[k] = p;
+            if (tid < n) {
+                const cplx f = (tid == p) ? a[k][k] : a[tid][k];
+                const cplx rk = a[p][tid], rp = a[k][tid];
+                const cplx d = crecip(a[p][k]);
+                a[p][tid] = rp;
+                a[k][tid] = (tid == k) ? d : cmul(rk, d);
+                fcol[tid] = f;
+            }
         }
-        __syncthreads();
-        const int p = piv[k];
-        if (p != k && tid < n) { cplx t = a[k][tid]; a[k][tid] = a[p][tid]; a[p][tid] = t; }
-        __syncthreads();
-        const cplx d = crecip(a[k][k]);
-        if (tid < n) fcol[tid] = a[tid][k];
-        __syncthreads();
-        if (tid < n) a[k][tid] = (tid == k) ? d : cmul(a[k][tid], d);
         __syncthreads();
         for (int e = tid; e < n * n; e += 256) {
             const int i = e / n, j = e % n;
@@ -459,11 +465,13 @@ __global__ __launch_bounds__(256) void k_gj_inverse(cplx *A0, int ld, long long 
         }
         __syncthreads();
     }
-    for (int k = n - 1; k >= 0; --k) {
-        const int p = piv[k];
-        if (p != k && tid < n) { cplx t = a[tid][k]; a[tid][k] = a[tid][p]; a[tid][p] = t; }
-        __syncthreads();
+    if (tid < 64) {      // undo the row exchanges as column exchanges, last first (lock-step within the wave)
+        for (int k = n - 1; k >= 0; --k) {
+            const int p = piv[k];
+            if (p != k && tid < n) { cplx t = a[tid][k]; a[tid][k] = a[tid][p]; a[tid][p] = t; }
+        }
     }
+    __syncthreads();
     for (int e = tid; e < n * n; e += 256) A[(long long)(e / n) * ld + e % n] = a[e / n][e % n];
 }
 
@@ -731,8 +739,10 @@ int nd_factor(helm_op *op, int block, NdFactor *f, cplx *ws) {
             for (int slot = 0; slot < 2; ++slot)
                 for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
                     const int nb = std::min(65535, g.cnt - j0);
-                    const int rb = std::max(1, std::min(nmax, 16384 / std::max(1, nb)));
-                    hipLaunchKernelGGL(k_nd_extend_add, dim3(rb, nb), dim3(256), shm, st, d_nodes, g.first + j0, slot, arenaF, op->nz, op->nx);
+                    // children's rings are at most this group's front size: enough chunks for the largest, grid-stride otherwise
+                    const long long chunks = ((long long)nmax * nmax + EA_CHUNK - 1) / EA_CHUNK;
+                    const int gx = (int)std::max<long long>(1, std::min<long long>(chunks, std::max(1, 32768 / nb)));
+                    hipLaunchKernelGGL(k_nd_extend_add, dim3(gx, nb), dim3(256), shm, st, d_nodes, g.first + j0, slot, arenaF, op->nz, op->nx);
                 }
         }
         invert(op, F, nmax, fs, g.smax, g.cnt, work, (long long)g.smax * g.smax);
