@@ -177,13 +177,12 @@ extern "C" int helm_set_model(helm_op *op, const double *c, const double *rho, c
     HIP_TRY(op, hipSetDevice(op->device));
     const size_t N = (size_t)op->N;
     HIP_TRY(op, hipMemcpyAsync(op->d_c, c, N * sizeof(cplx), hipMemcpyHostToDevice, op->stream));
-    std::vector<double> gard;
-    if (!rho) {   // Gardner default 310 * Re(c)^0.25  (discretization.py:70)
-        gard.resize(N);
-        for (size_t i = 0; i < N; ++i) gard[i] = 310.0 * pow(c[2 * i], 0.25);
-        rho = gard.data();
+    if (!rho) {   // Gardner default 310 * Re(c)^0.25  (discretization.py:70), evaluated on the device
+        const int rcg = helm_launch_gardner_rho(op);
+        if (rcg) return rcg;
+    } else {
+        HIP_TRY(op, hipMemcpyAsync(op->d_rho, rho, N * sizeof(double), hipMemcpyHostToDevice, op->stream));
     }
-    HIP_TRY(op, hipMemcpyAsync(op->d_rho, rho, N * sizeof(double), hipMemcpyHostToDevice, op->stream));
     op->aniso = false;
     bool m3zero = true;
     if (op->variant == HELM_EURUS) {
@@ -201,18 +200,30 @@ extern "C" int helm_set_model(helm_op *op, const double *c, const double *rho, c
         }
     }
     HIP_TRY(op, hipStreamSynchronize(op->stream));
-    op->h_c.assign((const cplx *)c, (const cplx *)c + N);
-    op->h_rho.assign(rho, rho + N);
-    op->h_theta.clear(); op->h_eps.clear(); op->h_delta.clear();
-    if (op->variant == HELM_EURUS) {
-        if (theta) op->h_theta.assign(theta, theta + N);
-        if (eps) op->h_eps.assign(eps, eps + N);
-        if (delta) op->h_delta.assign(delta, delta + N);
-    }
+    // host copies are only needed to build the multigrid levels: fetched back from the device if that ever happens
+    op->h_c.clear(); op->h_rho.clear(); op->h_theta.clear(); op->h_eps.clear(); op->h_delta.clear();
     op->block_zero[0] = op->block_zero[1] = op->block_zero[3] = false;
     op->block_zero[2] = m3zero;
     op->has_model = true;
     op->assembled = false;
+    return HELM_OK;
+}
+
+int helm_ensure_host_model(helm_op *op) {
+    if (!op->has_model) HELM_FAIL(op, HELM_ERR_STATE, "model not set");
+    if (!op->h_c.empty()) return HELM_OK;
+    const size_t N = (size_t)op->N;
+    HIP_TRY(op, hipStreamSynchronize(op->stream));
+    op->h_c.resize(N); op->h_rho.resize(N);
+    HIP_TRY(op, hipMemcpy(op->h_c.data(), op->d_c, N * sizeof(cplx), hipMemcpyDeviceToHost));
+    HIP_TRY(op, hipMemcpy(op->h_rho.data(), op->d_rho, N * sizeof(double), hipMemcpyDeviceToHost));
+    auto down = [&](std::vector<double> &dst, const double *src) -> int {
+        dst.clear();
+        if (!src) return 0;
+        dst.resize(N);
+        return hipMemcpy(dst.data(), src, N * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+    };
+    if (down(op->h_theta, op->d_theta) || down(op->h_eps, op->d_eps) || down(op->h_delta, op->d_delta)) HELM_FAIL(op, HELM_ERR_DEVICE, "model download failed");
     return HELM_OK;
 }
 

@@ -104,7 +104,8 @@ struct helm_op {
     double *d_rho = nullptr, *d_theta = nullptr, *d_eps = nullptr, *d_delta = nullptr;
     bool has_model = false, aniso = false;
 
-    // host copies of the model (coarse levels of the multigrid preconditioner are built from them)
+    // host copies of the model (coarse levels of the multigrid preconditioner are built from them; filled on demand by
+    // helm_ensure_host_model)
     std::vector<cplx> h_c; std::vector<double> h_rho, h_theta, h_eps, h_delta;
 
     // operator
@@ -235,3 +236,5 @@ int helm_launch_prep_rhs_rs(helm_op *op, const cplx *dRHS, long long rhs_ld, lon
 int helm_launch_prep_rhs(helm_op *op, const cplx *dRHS, long long rhs_ld, long long row_off, cplx premul, const cplx *sub, cplx *out, int nrhs); // out = premul*rhs - sub
 int helm_launch_imaging(helm_op *op, const cplx *uf, const cplx *ub, int nsrc, const cplx *scaler, cplx *g);
 int helm_launch_zero(helm_op *op, cplx *p, long long n);
+int helm_launch_gardner_rho(helm_op *op);     // d_rho = 310 Re(d_c)^0.25
+int helm_ensure_host_model(helm_op *op);      // h_c, h_rho, ... (downloaded from the device on first use)

@@ -900,6 +900,17 @@ int helm_launch_prep_rhs_rs(helm_op *op, const cplx *dRHS, long long rhs_ld, lon
     return HELM_OK;
 }
 
+// Gardner's relation, the reference's density default: rho = 310 Re(c)^0.25 (discretization.py:70)
+__global__ __launch_bounds__(256) void k_gardner_rho(const cplx *__restrict__ c, double *__restrict__ rho, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        rho[i] = 310.0 * pow(c[i].x, 0.25);
+}
+int helm_launch_gardner_rho(helm_op *op) {
+    hipLaunchKernelGGL(k_gardner_rho, dim3(vec_blocks(op->N)), dim3(256), 0, op->stream, (const cplx *)op->d_c, op->d_rho, op->N);
+    HIP_TRY(op, hipGetLastError());
+    return HELM_OK;
+}
+
 int helm_launch_zero(helm_op *op, cplx *p, long long n) {
     hipLaunchKernelGGL(k_zero, dim3(vec_blocks(n)), dim3(256), 0, op->stream, p, n);
     return HELM_OK;

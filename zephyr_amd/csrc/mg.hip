@@ -455,7 +455,7 @@ int setup_typed(helm_op *op, MgPrecond *P) {
 int mg_setup(helm_op *op, int batch) {
     if (op->mg && op->mg->batch >= batch) return HELM_OK;
     if (op->mg) mg_destroy(op);
-    if (op->h_c.empty()) HELM_FAIL(op, HELM_ERR_STATE, "model not set");
+    { const int rch = helm_ensure_host_model(op); if (rch) return rch; }
     MgPrecond *P = new MgPrecond();
     op->mg = P;
     P->batch = batch;

@@ -100,7 +100,9 @@ class BaseDiscretization(BaseModelDependent):
     def _model_arrays(self):
         'returns (c, rho, theta, eps, delta) host arrays (None where not applicable)'
         dims = (int(self.nz), int(self.nx))
-        return _lib.c128(self.c.reshape(dims)), _lib.f64(self.rho.reshape(dims)), None, None, None
+        # no density given: the library evaluates the Gardner default on the device (same formula as the `rho` property)
+        rho = _lib.f64(self.rho.reshape(dims)) if hasattr(self, '_rho') else None
+        return _lib.c128(self.c.reshape(dims)), rho, None, None, None
 
     def _assemble_args(self):
         'returns (ky, cPML)'
