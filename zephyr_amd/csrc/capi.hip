@@ -47,6 +47,19 @@ static int g_live_handles = 0;     // guarded by g_shared_ws.mu
 
 struct DevPool { std::mutex mu; std::multimap<std::pair<int, size_t>, void *> idle; size_t held = 0; };
 static DevPool g_pool;
+static std::map<int, std::vector<hipEvent_t>> g_idle_events;      // per device, guarded by g_pool.mu
+
+int helm_events_grow(helm_op *op, int n) {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    for (int i = 0; i < n; ++i) {
+        hipEvent_t e;
+        std::vector<hipEvent_t> &idle = g_idle_events[op->device];
+        if (!idle.empty()) { e = idle.back(); idle.pop_back(); }
+        else if (hipEventCreate(&e) != hipSuccess) return -1;
+        op->ev_pool.push_back(e);
+    }
+    return 0;
+}
 static const size_t kPoolMinBytes = (size_t)16 << 20, kPoolCapBytes = (size_t)24 << 30;
 
 void *helm_pool_alloc(int device, size_t bytes) {
@@ -134,7 +147,11 @@ extern "C" void helm_destroy(helm_op *op) {
     for (int b = 0; b < 4; ++b) { nd_free(op->direct[b]); op->direct[b] = nullptr; }
     hipFree(op->d_ws); hipFree(op->d_part); hipFree(op->d_scal);
     if (op->h_scal) hipHostFree(op->h_scal);
-    for (hipEvent_t e : op->ev_pool) hipEventDestroy(e);
+    {   // timing events go back to the process-wide free list
+        std::lock_guard<std::mutex> lk(g_pool.mu);
+        std::vector<hipEvent_t> &idle = g_idle_events[op->device];
+        for (hipEvent_t e : op->ev_pool) { if (idle.size() < 65536) idle.push_back(e); else hipEventDestroy(e); }
+    }
     if (op->own_stream && op->stream) hipStreamDestroy(op->stream);
     delete op;
     std::lock_guard<std::mutex> lk(g_shared_ws.mu);

@@ -424,18 +424,21 @@ void launch_mfma(hipStream_t st, dim3 grid, bool idx, int M, int Nn, int K, cplx
     else hipLaunchKernelGGL((k_zgemm_mfma<RA, RB, WM, WN, false>), grid, dim3(256), 0, st, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
 }
 
-// ---- in-place inverse of n x n blocks, n <= 32: Gauss-Jordan with row pivoting in LDS, one workgroup per matrix ----
-#define GJ_MAX 32
+// ---- in-place inverse of n x n blocks, n <= 64: Gauss-Jordan with row pivoting in LDS, one workgroup per matrix ----
+// (bottom of the recursive block inversion: 32 by default; 64 (HELM_ND_GJ=64) halves the number of small GEMM launches
+// and gains a digit of accuracy, but its 64-step elimination is slower overall: 41.8 vs 35.9 ms per factorisation at 1024^2)
+#define GJ_MAX 64
+template <int NMAX>
 __global__ __launch_bounds__(256) void k_gj_inverse(cplx *A0, int ld, long long stride, int n) {
-    __shared__ cplx a[GJ_MAX][GJ_MAX + 1];
-    __shared__ cplx fcol[GJ_MAX];
-    __shared__ int piv[GJ_MAX];
+    __shared__ cplx a[NMAX][NMAX + 1];
+    __shared__ cplx fcol[NMAX];
+    __shared__ int piv[NMAX];
     cplx *A = A0 + (long long)blockIdx.x * stride;
     const int tid = threadIdx.x;
     for (int e = tid; e < n * n; e += 256) a[e / n][e % n] = A[(long long)(e / n) * ld + e % n];
     __syncthreads();
     for (int k = 0; k < n; ++k) {
-        // wave 0 (n <= 32 lanes, lock-step): pivot search in column k, row exchange, scaling of the pivot row, and the
+        // wave 0 (n <= 64 lanes, lock-step): pivot search in column k, row exchange, scaling of the pivot row, and the
         // column that the elimination needs -- every read of the old values is issued before the writes
         if (tid < 64) {
             double val = (tid >= k && tid < n) ? cabs2(a[tid][k]) : -1.0;
@@ -576,7 +579,7 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (op && op->profiling) {
         if (op->ev_used + 2 > op->ev_pool.size() && op->ev_pool.size() < 16384)
-            for (int i = 0; i < 64; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; op->ev_pool.push_back(e); }
+            (void)helm_events_grow(op, 64);
         if (op->ev_used + 2 <= op->ev_pool.size()) { e0 = op->ev_pool[op->ev_used]; e1 = op->ev_pool[op->ev_used + 1]; }
     }
     if (e0) hipEventRecord(e0, st);
@@ -628,10 +631,12 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
 // batch stride ws, at least n*n elements per matrix
 void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cplx *W, long long ws) {
     hipStream_t st = op ? op->stream : nullptr;
-    if (n <= GJ_MAX) {
+    static const int gj_base = (getenv("HELM_ND_GJ") && atoi(getenv("HELM_ND_GJ")) == 64) ? 64 : 32;
+    if (n <= gj_base) {
         for (int b0 = 0; b0 < batch; b0 += 1 << 20) {
             const int nb = std::min(1 << 20, batch - b0);
-            hipLaunchKernelGGL(k_gj_inverse, dim3(nb), dim3(256), 0, st, M + b0 * stride, ld, stride, n);
+            if (n <= 32) hipLaunchKernelGGL(k_gj_inverse<32>, dim3(nb), dim3(256), 0, st, M + b0 * stride, ld, stride, n);
+            else hipLaunchKernelGGL(k_gj_inverse<64>, dim3(nb), dim3(256), 0, st, M + b0 * stride, ld, stride, n);
         }
         return;
     }

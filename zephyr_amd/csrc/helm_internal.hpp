@@ -153,7 +153,8 @@ void helm_set_error(helm_op *op, const char *msg);
 // operators of identical shape, and hipMalloc/hipFree of GB-sized buffers cost milliseconds each.  helm_trim() empties it.
 void *helm_pool_alloc(int device, size_t bytes);          // nullptr on failure
 void helm_pool_free(int device, void *p, size_t bytes);   // the buffer must no longer be in use by any stream
-int helm_ensure_scaled(helm_op *op);                      // d_Cs, d_dinv for the operator currently assembled
+int helm_ensure_scaled(helm_op *op);
+int helm_events_grow(helm_op *op, int n);                 // n more timing events for the handle (recycled across handles)                      // d_Cs, d_dinv for the operator currently assembled
 
 // ---- multigrid preconditioner (mg.hip) ---------------------------------------------------------
 struct MgPrecond;

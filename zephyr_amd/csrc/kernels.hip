@@ -708,7 +708,7 @@ int helm_launch_apply(helm_op *op, const ApplyArgs &a) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (op->profiling && a.profile && op->ev_pool.size() < 8192) {
             if (op->ev_used + 2 > op->ev_pool.size())
-                for (int i = 0; i < 64; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) HELM_FAIL(op, HELM_ERR_DEVICE, "hipEventCreate failed"); op->ev_pool.push_back(e); }
+                if (helm_events_grow(op, 64)) HELM_FAIL(op, HELM_ERR_DEVICE, "hipEventCreate failed");
             e0 = op->ev_pool[op->ev_used]; e1 = op->ev_pool[op->ev_used + 1];
         }
         int rc = helm3d_launch_apply(op, a, e0, e1);
@@ -740,7 +740,7 @@ int helm_launch_apply(helm_op *op, const ApplyArgs &a) {
     if (prof) {
         if (op->ev_used + 2 > op->ev_pool.size() && op->ev_pool.size() >= 8192) { e0 = nullptr; }
         else if (op->ev_used + 2 > op->ev_pool.size()) {
-            for (int i = 0; i < 64; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) HELM_FAIL(op, HELM_ERR_DEVICE, "hipEventCreate failed"); op->ev_pool.push_back(e); }
+            if (helm_events_grow(op, 64)) HELM_FAIL(op, HELM_ERR_DEVICE, "hipEventCreate failed");
         }
         if (op->ev_used + 2 <= op->ev_pool.size()) {
             e0 = op->ev_pool[op->ev_used]; e1 = op->ev_pool[op->ev_used + 1];
