@@ -162,6 +162,17 @@ int helm_set_profiling(helm_op *op, int on);
 int helm_imaging_accumulate_device(helm_op *op, const void *dUF, const void *dUB, int nsrc,
                                    const void *dScaler, void *dG);
 
+/* --- device-resident callers: sparse sources in, receiver samples out ---------------------------------- */
+/* Dense right-hand sides from the COO triplets of the reference's sparse source matrix (survey.py:162-169,
+ * source.py:213-317): R (nrhs x rows, zeroed by the call), R[col[k]][row[k]] = val[k]; no duplicate entries.
+ * row: int64, col: int32, val: complex128, all device pointers. */
+int helm_rhs_from_coo_device(helm_op *op, const void *d_row, const void *d_col, const void *d_val, long long nnz,
+                             void *dR, int nrhs, long long rows);
+/* Receiver sampling data = R u (survey.py:152-160): out[r][s] = sum_k val[k] * U[s][col[k]] over the entries k of CSR
+ * row r (rowptr, col: int64; val: complex128; U: nsrc x ld; out: nrec x nsrc complex128; device pointers). */
+int helm_sample_device(helm_op *op, const void *dU, int nsrc, long long ld, const void *d_rowptr, const void *d_col,
+                       const void *d_val, int nrec, void *d_out);
+
 /* Free the scratch memory the library keeps between calls (the direct path's shared workspace, tens of GB at
  * 1024^2 x 256 right-hand sides).  HELM_ERR_STATE while a solve is using it. */
 int helm_trim(void);

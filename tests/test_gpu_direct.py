@@ -150,3 +150,29 @@ def test_direct_free_surface_and_viscous_configurations(helm_lib):
     u = op * q
     C = ho.minizephyr_coefficients(nz, nx, c, rho, 10., dx=8., dz=12., nPML=7, tau=0.6, freeSurf=(True, False, False, True))
     assert nrm(u, ho.DirectOperator(C) * q) <= 1e-9
+
+
+def test_sparse_rhs_upload_and_receiver_sampling(helm_lib):
+    'helm_rhs_from_coo_device / helm_sample_device against numpy'
+    import torch
+    import scipy.sparse as sp
+    import zephyr_amd as za
+    nz, nx = 30, 34
+    N = nz * nx
+    cfg = dict(nx=nx, nz=nz, dx=10., dz=10., c=2500., freq=6., nPML=5)
+    op = za.MiniZephyr(cfg)
+    q = za.SparseKaiserSource(cfg)(np.array([[55., 61.], [203., 148.], [12., 250.]]))       # (N, 3) sparse, clipped at the edge
+    dev = torch.device('cuda', op.device)
+    R = torch.full((3, N), float('nan'), dtype=torch.complex128, device=dev)
+    op.rhsFromSparseDevice(q, R.data_ptr())
+    assert np.array_equal(R.cpu().numpy(), q.toarray().T)
+    rng = np.random.default_rng(4)
+    U = rng.standard_normal((3, N)) + 1j * rng.standard_normal((3, N))
+    Rm = sp.csr_matrix((za.SparseKaiserSource(cfg)(np.array([[40., 40.], [100., 120.], [250., 33.], [170., 222.]])) * (0.5 + 0.25j)).T)
+    csr = (torch.from_numpy(Rm.indptr.astype(np.int64)).to(dev), torch.from_numpy(Rm.indices.astype(np.int64)).to(dev),
+           torch.from_numpy(Rm.data.astype(np.complex128)).to(dev), 4)
+    dU = torch.from_numpy(U).to(dev)
+    out = torch.empty((4, 3), dtype=torch.complex128, device=dev)
+    op.sampleDevice(dU.data_ptr(), 3, csr, out.data_ptr())
+    ref = Rm @ U.T
+    assert np.abs(out.cpu().numpy() - ref).max() <= 1e-13 * np.abs(ref).max()

@@ -71,6 +71,10 @@ _SIGNATURES = {
     'helm_imaging_accumulate_device': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                                       ctypes.c_void_p, ctypes.c_void_p]),
     'helm_trim': (ctypes.c_int, []),
+    'helm_rhs_from_coo_device': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong,
+                                                ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong]),
+    'helm_sample_device': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'helm_direct_plan': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]),
     'helm_direct_plan_front': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]),
     'helm_debug_zgemm': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,

@@ -1009,15 +1009,33 @@ extern "C" int helm_solve(helm_op *op, const double *RHS, double *U, int nrhs, l
     if (!op || !RHS || !U || nrhs < 1) return HELM_ERR_ARG;
     HIP_TRY(op, hipSetDevice(op->device));
     const size_t bytes = (size_t)nrhs * rows * sizeof(cplx);
-    void *dR = nullptr, *dU = nullptr;
-    HIP_TRY(op, hipMalloc(&dR, bytes));
-    if (hipMalloc(&dU, bytes) != hipSuccess) { hipFree(dR); HELM_FAIL(op, HELM_ERR_DEVICE, "hipMalloc failed"); }
+    void *dR = helm_pool_alloc(op->device, bytes), *dU = helm_pool_alloc(op->device, bytes);
+    if (!dR || !dU) { helm_pool_free(op->device, dR, bytes); helm_pool_free(op->device, dU, bytes); HELM_FAIL(op, HELM_ERR_DEVICE, "hipMalloc failed"); }
     int rc = HELM_OK;
     if (hipMemcpy(dR, RHS, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = HELM_ERR_DEVICE;
     if (!rc) rc = helm_solve_device(op, dR, dU, nrhs, rows, premul_re, premul_im, opts, info);
     if (rc >= 0 && hipMemcpy(U, dU, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = HELM_ERR_DEVICE;
-    hipFree(dR); hipFree(dU);
+    hipStreamSynchronize(op->stream);
+    helm_pool_free(op->device, dR, bytes); helm_pool_free(op->device, dU, bytes);
     return rc;
+}
+
+extern "C" int helm_rhs_from_coo_device(helm_op *op, const void *d_row, const void *d_col, const void *d_val, long long nnz, void *dR, int nrhs, long long rows) {
+    if (!op || !dR || nrhs < 1 || rows < 1 || nnz < 0 || (nnz > 0 && (!d_row || !d_col || !d_val))) return HELM_ERR_ARG;
+    HIP_TRY(op, hipSetDevice(op->device));
+    int rc = helm_launch_rhs_from_coo(op, (const long long *)d_row, (const int *)d_col, (const cplx *)d_val, nnz, (cplx *)dR, nrhs, rows);
+    if (rc) return rc;
+    HIP_TRY(op, hipStreamSynchronize(op->stream));
+    return HELM_OK;
+}
+
+extern "C" int helm_sample_device(helm_op *op, const void *dU, int nsrc, long long ld, const void *d_rowptr, const void *d_col, const void *d_val, int nrec, void *d_out) {
+    if (!op || !dU || !d_rowptr || !d_col || !d_val || !d_out || nsrc < 1 || nrec < 1) return HELM_ERR_ARG;
+    HIP_TRY(op, hipSetDevice(op->device));
+    int rc = helm_launch_sample(op, (const cplx *)dU, nsrc, ld, (const long long *)d_rowptr, (const long long *)d_col, (const cplx *)d_val, nrec, (cplx *)d_out);
+    if (rc) return rc;
+    HIP_TRY(op, hipStreamSynchronize(op->stream));
+    return HELM_OK;
 }
 
 extern "C" int helm_imaging_accumulate_device(helm_op *op, const void *dUF, const void *dUB, int nsrc, const void *dScaler, void *dG) {

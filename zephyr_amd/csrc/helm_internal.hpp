@@ -237,5 +237,7 @@ int helm_launch_prep_rhs_rs(helm_op *op, const cplx *dRHS, long long rhs_ld, lon
 int helm_launch_prep_rhs(helm_op *op, const cplx *dRHS, long long rhs_ld, long long row_off, cplx premul, const cplx *sub, cplx *out, int nrhs); // out = premul*rhs - sub
 int helm_launch_imaging(helm_op *op, const cplx *uf, const cplx *ub, int nsrc, const cplx *scaler, cplx *g);
 int helm_launch_zero(helm_op *op, cplx *p, long long n);
+int helm_launch_rhs_from_coo(helm_op *op, const long long *row, const int *col, const cplx *val, long long nnz, cplx *R, int nrhs, long long rows);
+int helm_launch_sample(helm_op *op, const cplx *U, int nsrc, long long ld, const long long *rowptr, const long long *col, const cplx *val, int nrec, cplx *out);
 int helm_launch_gardner_rho(helm_op *op);     // d_rho = 310 Re(d_c)^0.25
 int helm_ensure_host_model(helm_op *op);      // h_c, h_rho, ... (downloaded from the device on first use)

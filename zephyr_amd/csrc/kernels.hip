@@ -10,6 +10,7 @@
 // the design rules are 16-B-per-lane coalesced accesses, one pass per vector per kernel, and
 // an XCD-aware tile order so that halo rows are served by the XCD's own L2.
 #include "helm_internal.hpp"
+#include <algorithm>
 
 namespace {
 
@@ -896,6 +897,36 @@ int helm_launch_prep_rhs_rs(helm_op *op, const cplx *dRHS, long long rhs_ld, lon
                             cplx *out, long long out_ld, long long out_off, int nrhs) {
     dim3 grid(vec_blocks(op->N), nrhs);
     hipLaunchKernelGGL(k_prep_rhs_rs, grid, dim3(256), 0, op->stream, dRHS, rhs_ld, row_off, premul, rs, out, out_ld, out_off, op->N);
+    HIP_TRY(op, hipGetLastError());
+    return HELM_OK;
+}
+
+// dense right-hand sides from the triplets of a sparse matrix (no duplicate entries): R[col][row] = val
+__global__ __launch_bounds__(256) void k_rhs_from_coo(const long long *__restrict__ row, const int *__restrict__ col, const cplx *__restrict__ val,
+                                                      long long nnz, cplx *__restrict__ R, long long rows) {
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (long long)gridDim.x * blockDim.x)
+        R[(long long)col[k] * rows + row[k]] = val[k];
+}
+int helm_launch_rhs_from_coo(helm_op *op, const long long *row, const int *col, const cplx *val, long long nnz, cplx *R, int nrhs, long long rows) {
+    HIP_TRY(op, hipMemsetAsync(R, 0, (size_t)nrhs * rows * sizeof(cplx), op->stream));
+    if (nnz > 0) hipLaunchKernelGGL(k_rhs_from_coo, dim3((unsigned)std::min<long long>((nnz + 255) / 256, 65535)), dim3(256), 0, op->stream, row, col, val, nnz, R, rows);
+    HIP_TRY(op, hipGetLastError());
+    return HELM_OK;
+}
+
+// receiver sampling out[r][s] = sum_k val[k] U[s][col[k]] over the entries k of sparse row r (one thread per (r, s), fixed order)
+__global__ __launch_bounds__(256) void k_sample(const cplx *__restrict__ U, int nsrc, long long ld, const long long *__restrict__ rowptr,
+                                                const long long *__restrict__ col, const cplx *__restrict__ val, int nrec, cplx *__restrict__ out) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)nrec * nsrc) return;
+    const int r = (int)(t / nsrc), sidx = (int)(t % nsrc);
+    cplx acc = cmake(0.0, 0.0);
+    for (long long k = rowptr[r]; k < rowptr[r + 1]; ++k) cfma(acc, val[k], U[(long long)sidx * ld + col[k]]);
+    out[t] = acc;
+}
+int helm_launch_sample(helm_op *op, const cplx *U, int nsrc, long long ld, const long long *rowptr, const long long *col, const cplx *val, int nrec, cplx *out) {
+    const long long tot = (long long)nrec * nsrc;
+    hipLaunchKernelGGL(k_sample, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, op->stream, U, nsrc, ld, rowptr, col, val, nrec, out);
     HIP_TRY(op, hipGetLastError());
     return HELM_OK;
 }

@@ -243,6 +243,29 @@ class BaseDiscretization(BaseModelDependent):
         _lib.check(lib.helm_imaging_accumulate_device(self.handle, ctypes.c_void_p(d_uf), ctypes.c_void_p(d_ub), int(nsrc),
                                                       ctypes.c_void_p(d_scaler), ctypes.c_void_p(d_g)), self.handle)
 
+    def rhsFromSparseDevice(self, q, d_rhs):
+        '''Fill the device buffer d_rhs ([ncols][nrow] complex128) from the scipy-sparse right-hand-side matrix q (nrow x ncols)
+        without densifying it on the host: only the COO triplets cross PCIe.'''
+        import torch
+        lib = _lib.load()
+        coo = sp.coo_matrix(q)
+        coo.sum_duplicates()
+        dev = torch.device('cuda', self.device)
+        row = torch.from_numpy(np.ascontiguousarray(coo.row, dtype=np.int64)).to(dev)
+        col = torch.from_numpy(np.ascontiguousarray(coo.col, dtype=np.int32)).to(dev)
+        val = torch.from_numpy(np.ascontiguousarray(coo.data, dtype=np.complex128)).to(dev)
+        torch.cuda.synchronize(dev)
+        _lib.check(lib.helm_rhs_from_coo_device(self.handle, ctypes.c_void_p(row.data_ptr()), ctypes.c_void_p(col.data_ptr()),
+                                                ctypes.c_void_p(val.data_ptr()), int(coo.nnz), ctypes.c_void_p(d_rhs), int(coo.shape[1]),
+                                                int(coo.shape[0])), self.handle)
+
+    def sampleDevice(self, d_u, nsrc, csr_dev, d_out):
+        'd_out[nrec][nsrc] = R u for the CSR receiver matrix uploaded by the caller: csr_dev = (rowptr, col, val, nrec) device tensors'
+        rowptr, col, val, nrec = csr_dev
+        _lib.check(_lib.load().helm_sample_device(self.handle, ctypes.c_void_p(d_u), int(nsrc), int(self.nrow), ctypes.c_void_p(rowptr.data_ptr()),
+                                                  ctypes.c_void_p(col.data_ptr()), ctypes.c_void_p(val.data_ptr()), int(nrec),
+                                                  ctypes.c_void_p(d_out)), self.handle)
+
     def setProfiling(self, on=True):
         'time every stencil-apply launch of subsequent solves with HIP events on the solver stream'
         _lib.check(_lib.load().helm_set_profiling(self.handle, 1 if on else 0), self.handle)

@@ -198,6 +198,9 @@ class HelmBaseProblem(BaseModelDependent, BaseSCCache):
         subs = self.system.subProblems
         if not subs or not hasattr(subs[0], 'solveDevice'):
             return False
+        from .discretization import DiscretizationWrapper
+        if isinstance(subs[0], DiscretizationWrapper):        # composite sub-problems (2.5-D ky sums) own no single device operator
+            return False
         try:
             from . import _lib
             if _lib.load().helm_device_count() <= 0:
@@ -219,10 +222,10 @@ class HelmBaseProblem(BaseModelDependent, BaseSCCache):
         G = torch.zeros(N, dtype=torch.complex128, device=dev)
         qf = sv.getSources()
         U = torch.empty((2 * nsrc, N), dtype=torch.complex128, device=dev)
+        R = torch.empty((2 * nsrc, N), dtype=torch.complex128, device=dev)
         for ifreq in owned:
             sub = subs[ifreq]
-            qm = sp.hstack((qf[ifreq], qb[ifreq])).toarray()
-            R = torch.from_numpy(np.ascontiguousarray(qm.T)).to(dev)
+            sub.rhsFromSparseDevice(sp.hstack((qf[ifreq], qb[ifreq])), R.data_ptr())      # sparse triplets up, dense on the device
             scaler = torch.from_numpy(np.ascontiguousarray(self.gradientScaler(ifreq) * scale * scale)).to(dev)
             torch.cuda.synchronize(dev)
             sub.solveDevice(R.data_ptr(), U.data_ptr(), 2 * nsrc, N)
@@ -231,6 +234,37 @@ class HelmBaseProblem(BaseModelDependent, BaseSCCache):
             parallel.allreduce_sum_device(G)
         torch.cuda.synchronize(dev)
         return G.cpu().numpy()
+
+    def _dpredDevice(self, owned):
+        '''predicted data with the wavefields kept in HBM (fixed receiver array): per owned frequency the sparse sources are
+        expanded on the device, solved there, and only the receiver samples R u (nrec x nsrc) come back'''
+        import torch
+        sv = self.survey
+        nsrc, nrec, N = sv.nsrc, sv.nrec, self.nrow
+        subs = self.system.subProblems
+        scale = complex(self.system.scaleTerm)
+        data = np.zeros((nrec, nsrc, sv.nfreq), dtype=np.complex128)
+        if not owned:
+            return data
+        dev = torch.device('cuda', subs[owned[0]].device)
+        Rm = sp.csr_matrix(sv.rVec(0))
+        Rm.sum_duplicates()
+        csr = (torch.from_numpy(np.ascontiguousarray(Rm.indptr, dtype=np.int64)).to(dev),
+               torch.from_numpy(np.ascontiguousarray(Rm.indices, dtype=np.int64)).to(dev),
+               torch.from_numpy(np.ascontiguousarray(Rm.data, dtype=np.complex128)).to(dev), nrec)
+        qf = sv.getSources()
+        R = torch.empty((nsrc, N), dtype=torch.complex128, device=dev)
+        U = torch.empty((nsrc, N), dtype=torch.complex128, device=dev)
+        out = torch.empty((nrec, nsrc), dtype=torch.complex128, device=dev)
+        for ifreq in owned:
+            sub = subs[ifreq]
+            q = qf[ifreq] if isinstance(qf, (list, tuple)) else qf
+            sub.rhsFromSparseDevice(q, R.data_ptr())
+            sub.solveDevice(R.data_ptr(), U.data_ptr(), nsrc, N)
+            sub.sampleDevice(U.data_ptr(), nsrc, csr, out.data_ptr())
+            torch.cuda.synchronize(dev)
+            data[:, :, ifreq] = scale * out.cpu().numpy()
+        return data
 
     @property
     def factors(self):

@@ -142,7 +142,11 @@ class HelmBaseSurvey(BaseSCCache):
             raise Exception('%s instance is not paired to a problem' % (self.__class__.__name__,))
         if u is None:
             owned = self.prob.ownedFreqs
-            data = self._lazyProjectFields(self.prob.lazyFields(m), owned)
+            if self.mode == 'fixed' and sp.issparse(self.sVecs()) and self.prob._deviceGradientAvailable():
+                self.prob.updateModel(m)
+                data = self.prob._dpredDevice(owned)          # wavefields never leave HBM
+            else:
+                data = self._lazyProjectFields(self.prob.lazyFields(m), owned)
             if len(owned) != self.nfreq:
                 data = parallel.allreduce_sum(data)
             return data.ravel()
