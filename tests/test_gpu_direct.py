@@ -106,10 +106,35 @@ def test_direct_new_frequency_refactors_and_unsupported_cases(helm_lib):
     for f, u in zip((6., 11.), us):
         ref = ho.DirectOperator(ho.minizephyr_coefficients(nz, nx, c, ho.gardner_rho(c.astype(complex)), f, dx=10., dz=10., nPML=6)) * q
         assert nrm(u, ref) <= 1e-9
-    # coupled TTI system: not a single-block system
-    tti = dict(cfg, theta=np.full((nz, nx), 0.3), eps=np.full((nz, nx), 0.2), delta=np.full((nz, nx), 0.05))
+    # 3-D operators have no direct path
     with pytest.raises(Exception):
-        za.Eurus(tti) * q
+        za.Helm3D(dict(nx=12, ny=12, nz=12, dx=10., c=2000., freq=5., method='direct')) * np.ones(12 ** 3, complex)
+
+
+@pytest.mark.parametrize('nz,nx', [(44, 52), (96, 120)])
+def test_direct_coupled_tti_system(helm_lib, nz, nx):
+    """eps != delta: the 2N x 2N system [[M1, M2], [M3, M4]] (eurus.py:430-464) factored with two unknowns per cell; N-row and
+    stacked 2N-row right-hand sides against the sparse LU of the reference-identical matrix"""
+    import zephyr_amd as za
+    rng = np.random.default_rng(nz)
+    c = 1800. + 2200. * rng.random((nz, nx))
+    rho = 1000. + 600. * rng.random((nz, nx))
+    theta = 0.5 * rng.random((nz, nx)) - 0.25
+    eps = 0.25 * rng.random((nz, nx))
+    delta = 0.12 * rng.random((nz, nx))
+    cfg = dict(nx=nx, nz=nz, dx=10., dz=10., c=c, rho=rho, freq=9., nPML=6, theta=theta, eps=eps, delta=delta, rtol=1e-10)
+    C4 = ho.eurus_coefficients(nz, nx, c, rho, 9., dx=10., dz=10., nPML=6, theta=theta, eps=eps, delta=delta)
+    assert np.abs(C4[2]).max() > 0
+    lu = ho.DirectOperator(C4, eurus=True)
+    q = za.SimpleSource(cfg)(np.array([[250., 220.], [330., 150.], [120., 300.]]))
+    for method in ('direct', 'auto'):
+        op = za.Eurus(dict(cfg, method=method))
+        u = op * q
+        assert nrm(u, lu * q) <= 1e-8, op.lastInfo
+        assert all(i['method'] == 4 and i['relres'] <= 1e-10 and i['iterations'] <= 4 for i in op.lastInfo), op.lastInfo
+        q2 = np.vstack([q, 0.3j * q[::-1]])
+        u2 = op * q2
+        assert u2.shape == q2.shape and nrm(u2, lu * q2) <= 1e-8, op.lastInfo
 
 
 def test_auto_prefers_direct_and_falls_back_to_krylov(helm_lib, monkeypatch):

@@ -611,11 +611,19 @@ struct WsLease {
 
 // Sparse direct path (direct.hip): factor once per assembled operator, then per batch q' -> x by the multifrontal
 // triangular solves and iterative refinement on the true residual q' - A x (stencil kernel) until rtol is met.
+int launch_sys2_apply(helm_op *op, bool raw, int adjoint, const cplx *X, cplx *Y, const cplx *W, int nrhs, int epi, const RhsScal *scal);
+
+// sys2 != 0: the coupled two-field Eurus system [[M1, M2], [M3, M4]] on the stacked unknowns [u; v] (block ignored, two
+// unknowns per cell in the elimination tree, factors kept in slot 1); rows_in = N or 2N rows of right-hand side per source.
 int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long long row_off, cplx premul,
-                       const cplx *sub, cplx *dXout, int nrhs, const helm_solve_opts &o, helm_solve_info *info) {
+                       const cplx *sub, cplx *dXout, int nrhs, const helm_solve_opts &o, helm_solve_info *info,
+                       int sys2 = 0, long long rows_in = 0) {
     const long long N = op->N;
+    const long long NV = sys2 ? 2 * N : N;
+    struct NvScope { helm_op *op; long long old; NvScope(helm_op *o_, long long nv) : op(o_), old(o_->Nv) { o_->Nv = nv; } ~NvScope() { op->Nv = old; } } nvscope(op, NV);
+    const int slot = sys2 ? 1 : block;
     int rc;
-    NdFactor *f = op->direct[block];
+    NdFactor *f = op->direct[slot];
     const bool need_factor = (f == nullptr);
     {   // fault injection for the tests of the AUTO fallback
         const char *inj = getenv("HELM_ND_INJECT_FAILURE");
@@ -624,10 +632,10 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
     if (need_factor) {
         const char *e = getenv("HELM_ND_LEAF");
         f = new NdFactor();
-        rc = nd_get_plan(op, e ? std::max(2, atoi(e)) : 8, &f->pd);
+        rc = nd_get_plan(op, e ? std::max(2, atoi(e)) : 8, sys2 ? 2 : 1, &f->pd);
         if (rc) { nd_free(f); return rc; }
     }
-    const long long per_rhs = nd_solve_ws_elems(f->pd->plan, 1) + 2 * N;
+    const long long per_rhs = nd_solve_ws_elems(f->pd->plan, 1) + 2 * NV;
     int Bmax = o.batch > 0 ? o.batch : 256;
     if (Bmax > nrhs) Bmax = nrhs;
     const char *capenv = getenv("HELM_ND_WS_GB");
@@ -646,7 +654,7 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
         float ms = 0.f; hipEventElapsedTime(&ms, f0, f1);
         hipEventDestroy(f0); hipEventDestroy(f1);
         if (rc) { nd_free(f); return rc; }
-        op->direct[block] = f;
+        op->direct[slot] = f;
         op->timing.factor_ms += ms;
     }
     rc = ensure_part(op, Bmax);
@@ -660,12 +668,20 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
     int unconverged = 0;
     for (int first = 0; first < nrhs; first += Bmax) {
         const int n = std::min(Bmax, nrhs - first);
-        cplx *q = (cplx *)lease.ptr, *r = q + (long long)Bmax * N, *nws = q + 2LL * Bmax * N;
-        cplx *x = dXout + (long long)first * N;
+        cplx *q = (cplx *)lease.ptr, *r = q + (long long)Bmax * NV, *nws = q + 2LL * Bmax * NV;
+        cplx *x = dXout + (long long)first * NV;
         const cplx *rhs_b = dRHS + (long long)first * rhs_ld;
         const cplx *sub_b = sub ? sub + (long long)first * N : nullptr;
-        rc = helm_launch_prep_rhs(op, rhs_b, rhs_ld, row_off, premul, sub_b, q, n);
-        if (rc) return rc;
+        if (sys2) {
+            HIP_TRY(op, hipMemsetAsync(q, 0, (size_t)n * NV * sizeof(cplx), op->stream));
+            for (int half = 0; half < (rows_in == 2 * N ? 2 : 1); ++half) {
+                rc = helm_launch_prep_rhs_ex(op, rhs_b, rhs_ld, half * N, premul, nullptr, q, NV, half * N, n);
+                if (rc) return rc;
+            }
+        } else {
+            rc = helm_launch_prep_rhs(op, rhs_b, rhs_ld, row_off, premul, sub_b, q, n);
+            if (rc) return rc;
+        }
         helm_launch_norm2(op, q, n);
         helm_launch_fin_ex(op, FIN_NORM, n, helm_vec_num_blocks(op), nullptr, d_aux + n);
         rc = nd_solve(op, f, q, x, n, nws);
@@ -673,12 +689,18 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
         std::vector<double> relres(n, 0.0);
         int solves = 1;
         for (int round = 0; ; ++round) {
-            ApplyArgs a = ApplyArgs();
-            a.planes = op->d_C + (long long)block * op->nplanes * N; a.X = x; a.Y = r; a.W = q; a.ld = N; a.nrhs = n;
-            a.scaled = 0; a.adjoint = 0; a.epi = EPI_RESID; a.scal = nullptr; a.part = (double *)op->d_part;
-            rc = helm_launch_apply(op, a);
-            if (rc) return rc;
-            helm_launch_fin_ex(op, FIN_NORM, n, helm_apply_num_blocks(op), nullptr, d_aux);
+            if (sys2) {
+                rc = launch_sys2_apply(op, true, 0, x, r, q, n, EPI_RESID, nullptr);
+                if (rc) return rc;
+                helm_launch_fin_ex(op, FIN_NORM, n, 2 * helm_apply_num_blocks(op), nullptr, d_aux);
+            } else {
+                ApplyArgs a = ApplyArgs();
+                a.planes = op->d_C + (long long)block * op->nplanes * N; a.X = x; a.Y = r; a.W = q; a.ld = N; a.nrhs = n;
+                a.scaled = 0; a.adjoint = 0; a.epi = EPI_RESID; a.scal = nullptr; a.part = (double *)op->d_part;
+                rc = helm_launch_apply(op, a);
+                if (rc) return rc;
+                helm_launch_fin_ex(op, FIN_NORM, n, helm_apply_num_blocks(op), nullptr, d_aux);
+            }
             HIP_TRY(op, hipMemcpyAsync(h_aux, d_aux, 2 * n * sizeof(double), hipMemcpyDeviceToHost, op->stream));
             HIP_TRY(op, hipStreamSynchronize(op->stream));
             bool all_ok = true;
@@ -690,7 +712,7 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
             if (all_ok || round >= max_refine) break;
             rc = nd_solve(op, f, r, r, n, nws);       // dx = A^-1 r
             if (rc) return rc;
-            nd_axpy_one(op, x, r, (long long)n * N);
+            nd_axpy_one(op, x, r, (long long)n * NV);
             solves += 1;
         }
         for (int b = 0; b < n; ++b) {
@@ -715,17 +737,17 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
                 int sys2 = 0, long long rows_in = 0) {
     const long long N = op->N;
     if (o.method == HELM_DIRECT) {
-        if (sys2 || op->ny > 0) HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "the direct solver handles 2-D single-block systems only (not the coupled TTI system, not 3-D)");
-        return solve_block_direct(op, block, dRHS, rhs_ld, row_off, premul, sub, dXout, nrhs, o, info);
+        if (op->ny > 0) HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "the direct solver is 2-D only");
+        return solve_block_direct(op, block, dRHS, rhs_ld, row_off, premul, sub, dXout, nrhs, o, info, sys2, rows_in);
     }
     // AUTO: the sparse direct path wherever it applies (2-D single-block systems that fit), else / on failure the
     // multigrid-preconditioned Krylov path below
-    if (o.method == HELM_AUTO && !sys2 && op->ny == 0 && !op->direct_failed) {
+    if (o.method == HELM_AUTO && op->ny == 0 && !op->direct_failed) {
         const char *e = getenv("HELM_AUTO_DIRECT");
         if (!e || atoi(e) != 0) {
             std::vector<helm_solve_info> saved;
             if (info) saved.assign(info, info + nrhs);
-            const int rc = solve_block_direct(op, block, dRHS, rhs_ld, row_off, premul, sub, dXout, nrhs, o, info);
+            const int rc = solve_block_direct(op, block, dRHS, rhs_ld, row_off, premul, sub, dXout, nrhs, o, info, sys2, rows_in);
             if (rc == 0) return 0;
             op->direct_failed = true;
             if (info) std::copy(saved.begin(), saved.end(), info);

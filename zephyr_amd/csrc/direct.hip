@@ -31,15 +31,16 @@ namespace {
 
 // ---- plan ------------------------------------------------------------------------------------------------------
 struct Build {
-    int nz, nx, leaf;
+    int nz, nx, leaf, dof;
     std::vector<NdDev> nodes;      // creation order
     std::vector<int> level;
     std::vector<int> parent;
 };
 
-void fill_geometry(NdDev &n, int nz, int nx) {
+void fill_geometry(NdDev &n, int nz, int nx, int dof) {
     const int h = n.z1 - n.z0, w = n.x1 - n.x0;
-    n.s = n.cut < 0 ? h * w : (n.cut == 0 ? w : h);
+    n.dof = dof;
+    n.s = dof * (n.cut < 0 ? h * w : (n.cut == 0 ? w : h));
     n.xlo = std::max(n.x0 - 1, 0);
     const int xhi = std::min(n.x1, nx - 1);
     const int wrow = xhi - n.xlo + 1;
@@ -47,7 +48,7 @@ void fill_geometry(NdDev &n, int nz, int nx) {
     n.nbot = n.z1 < nz ? wrow : 0;
     n.nleft = n.x0 > 0 ? h : 0;
     n.nright = n.x1 < nx ? h : 0;
-    n.m = n.ntop + n.nbot + n.nleft + n.nright;
+    n.m = dof * (n.ntop + n.nbot + n.nleft + n.nright);
 }
 
 int build_rec(Build &B, int z0, int z1, int x0, int x1, int lev, int parent) {
@@ -58,7 +59,7 @@ int build_rec(Build &B, int z0, int z1, int x0, int x1, int lev, int parent) {
     if (h <= B.leaf && w <= B.leaf) { n.cut = -1; n.pos = -1; }
     else if (h >= w) { n.cut = 0; n.pos = z0 + h / 2; }
     else { n.cut = 1; n.pos = x0 + w / 2; }
-    fill_geometry(n, B.nz, B.nx);
+    fill_geometry(n, B.nz, B.nx, B.dof);
     B.nodes.push_back(n); B.level.push_back(lev); B.parent.push_back(parent);
     if (n.cut == 0) {
         int k = 0;
@@ -74,8 +75,8 @@ int build_rec(Build &B, int z0, int z1, int x0, int x1, int lev, int parent) {
 
 }  // namespace
 
-int nd_build_plan(NdPlan &P, int nz, int nx, int leaf) {
-    Build B; B.nz = nz; B.nx = nx; B.leaf = std::max(2, leaf);
+int nd_build_plan(NdPlan &P, int nz, int nx, int leaf, int dof) {
+    Build B; B.nz = nz; B.nx = nx; B.leaf = std::max(2, leaf); B.dof = dof;
     build_rec(B, 0, nz, 0, nx, 0, -1);
     const int nn = (int)B.nodes.size();
     int maxlev = 0;
@@ -102,7 +103,7 @@ int nd_build_plan(NdPlan &P, int nz, int nx, int leaf) {
         for (int c = 0; c < 2; ++c) if (n.kid[c] >= 0) n.kid[c] = newidx[n.kid[c]];
         P.nodes[k] = n;
     }
-    P.nz = nz; P.nx = nx; P.leaf = B.leaf; P.nlevels = maxlev + 1; P.total_rows = 0;
+    P.nz = nz; P.nx = nx; P.leaf = B.leaf; P.nlevels = maxlev + 1; P.total_rows = 0; P.dof = dof;
     // arenas: fronts (factor) and front vectors (solve) of level L live in region L % 2
     std::vector<long long> lev_f(maxlev + 1, 0), lev_v(maxlev + 1, 0);
     long long fac = 0;
@@ -149,16 +150,20 @@ __global__ __launch_bounds__(256) void k_nd_assemble(const NdDev *nodes, int fir
     for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < n.smax; a += gridDim.x * blockDim.x)
         if (a >= n.s) F[(long long)a * ld + a] = cmake(1.0, 0.0);     // padded separator slots: identity
     for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < tot; a += gridDim.x * blockDim.x) {
-        int z, x;
-        nd_cell(n, a, z, x);
+        int z, x, ca;
+        nd_cell(n, a, z, x, ca);
         const long long ra = nd_pos(n, a);
-        #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const int z2 = z + k / 3 - 1, x2 = x + k % 3 - 1;
-            if (z2 < 0 || z2 >= nz || x2 < 0 || x2 >= nx) continue;
-            const int b = nd_local(n, nz, nx, z2, x2);
-            if (b < 0 || (a >= n.s && b >= n.s)) continue;            // ring x ring entries belong to an ancestor
-            F[ra * ld + nd_pos(n, b)] = planes[(long long)k * N + (long long)z * nx + x];
+        for (int cb = 0; cb < n.dof; ++cb) {
+            // dof 2: row component ca, column component cb -> Eurus block 2 ca + cb (M1 M2 / M3 M4), nine planes each
+            const cplx *pl = planes + (long long)(n.dof == 2 ? 2 * ca + cb : 0) * 9 * N;
+            #pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int z2 = z + k / 3 - 1, x2 = x + k % 3 - 1;
+                if (z2 < 0 || z2 >= nz || x2 < 0 || x2 >= nx) continue;
+                const int b = nd_local(n, nz, nx, z2, x2, cb);
+                if (b < 0 || (a >= n.s && b >= n.s)) continue;            // ring x ring entries belong to an ancestor
+                F[ra * ld + nd_pos(n, b)] = pl[(long long)k * N + (long long)z * nx + x];
+            }
         }
     }
 }
@@ -173,9 +178,9 @@ __global__ __launch_bounds__(256) void k_nd_extend_add(const NdDev *nodes, int f
     const long long total = (long long)c.m * c.m;
     if ((long long)blockIdx.x * EA_CHUNK >= total) return;
     for (int a = threadIdx.x; a < c.m; a += blockDim.x) {
-        int z, x;
-        nd_cell(c, c.s + a, z, x);
-        map[a] = nd_pos(p, nd_local(p, nz, nx, z, x));
+        int z, x, comp;
+        nd_cell(c, c.s + a, z, x, comp);
+        map[a] = nd_pos(p, nd_local(p, nz, nx, z, x, comp));
     }
     __syncthreads();
     const cplx *Fc = arenaF + c.foff;
@@ -510,13 +515,13 @@ __global__ __launch_bounds__(256) void k_nd_build_tab(const NdDev *nodes, int fi
         else if (row >= n.smax && row - n.smax < n.m) a = n.s + row - n.smax;
         int4 e = make_int4(-1, -1, -1, row < n.s ? 1 : 0);
         if (a >= 0) {
-            int z, x;
-            nd_cell(n, a, z, x);
-            e.x = z * nx + x;
+            int z, x, comp;
+            nd_cell(n, a, z, x, comp);
+            e.x = comp * nz * nx + z * nx + x;            // row of Xt: the fields are stacked [u; v] like the right-hand sides
             for (int k = 0; k < 2; ++k) {
                 if (n.kid[k] < 0) continue;
                 const NdDev c = nodes[n.kid[k]];
-                const int la = nd_local(c, nz, nx, z, x);
+                const int la = nd_local(c, nz, nx, z, x, comp);
                 if (la >= c.s) { const int src = (int)(c.voff + c.smax + (la - c.s)); if (k == 0) e.y = src; else e.z = src; }
             }
         }
@@ -667,11 +672,11 @@ std::mutex g_plan_mu;
 std::vector<std::shared_ptr<NdPlanDev>> g_plans;     // most recently used last, at most 4 kept alive by the cache
 }
 
-int nd_get_plan(helm_op *op, int leaf, std::shared_ptr<NdPlanDev> *out) {
+int nd_get_plan(helm_op *op, int leaf, int dof, std::shared_ptr<NdPlanDev> *out) {
     std::lock_guard<std::mutex> lk(g_plan_mu);
     for (size_t i = 0; i < g_plans.size(); ++i) {
         const NdPlanDev &c = *g_plans[i];
-        if (c.device == op->device && c.plan.nz == op->nz && c.plan.nx == op->nx && c.plan.leaf == std::max(2, leaf)) {
+        if (c.device == op->device && c.plan.nz == op->nz && c.plan.nx == op->nx && c.plan.leaf == std::max(2, leaf) && c.plan.dof == dof) {
             std::shared_ptr<NdPlanDev> hit = g_plans[i];
             g_plans.erase(g_plans.begin() + i); g_plans.push_back(hit);
             *out = hit;
@@ -680,7 +685,7 @@ int nd_get_plan(helm_op *op, int leaf, std::shared_ptr<NdPlanDev> *out) {
     }
     std::shared_ptr<NdPlanDev> pd(new NdPlanDev());
     pd->device = op->device;
-    nd_build_plan(pd->plan, op->nz, op->nx, leaf);
+    nd_build_plan(pd->plan, op->nz, op->nx, leaf, dof);
     const NdPlan &P = pd->plan;
     if (2 * P.vregion >= (1LL << 31) || P.total_rows >= (1LL << 31)) HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "direct solver: grid too large for 32-bit row indices");
     HIP_TRY(op, hipMalloc((void **)&pd->d_nodes, P.nodes.size() * sizeof(NdDev)));
@@ -725,7 +730,7 @@ int nd_factor(helm_op *op, int block, NdFactor *f, cplx *ws) {
         f->d_fac = (cplx *)helm_pool_alloc(op->device, (size_t)P.fac_elems * sizeof(cplx));
         if (!f->d_fac) return fail("hipMalloc(factors)", hipErrorOutOfMemory);
     }
-    const cplx *planes = op->d_C + (long long)block * op->nplanes * op->N;
+    const cplx *planes = P.dof == 2 ? op->d_C : op->d_C + (long long)block * op->nplanes * op->N;
     const cplx one = cmake(1, 0), mone = cmake(-1, 0), zero = cmake(0, 0);
     double flops = 0;
     for (size_t gi = 0; gi < P.groups.size(); ++gi) {
@@ -779,13 +784,13 @@ int nd_factor(helm_op *op, int block, NdFactor *f, cplx *ws) {
 
 // ---- solve: Xin (nrhs x N, each right-hand side contiguous) -> Xout (may alias Xin) --------------------------------------
 // ws: workspace of nd_solve_ws_elems(plan, nrhs) elements
-long long nd_solve_ws_elems(const NdPlan &P, int nrhs) { return ((long long)P.nz * P.nx + 2 * P.vregion) * nrhs; }
+long long nd_solve_ws_elems(const NdPlan &P, int nrhs) { return ((long long)P.dof * P.nz * P.nx + 2 * P.vregion) * nrhs; }
 
 int nd_solve(helm_op *op, NdFactor *f, const cplx *Xin, cplx *Xout, int nrhs, cplx *ws) {
     const NdPlan &P = f->pd->plan;
     const int4 *tab = f->pd->d_tab;
     hipStream_t st = op->stream;
-    const long long N = (long long)P.nz * P.nx;
+    const long long N = (long long)P.dof * P.nz * P.nx;          // unknowns per right-hand side
     cplx *Xt = ws, *arenaV = ws + N * nrhs;
     const cplx one = cmake(1, 0), mone = cmake(-1, 0), zero = cmake(0, 0);
     static const int use_idx = getenv("HELM_ND_IDXGEMM") ? atoi(getenv("HELM_ND_IDXGEMM")) : 1;

@@ -6,7 +6,8 @@
 struct NdDev {                // one front = one node of the elimination tree
     int z0, z1, x0, x1;       // region of the subtree (half-open)
     int cut, pos;             // -1: leaf, all cells of the region are eliminated; 0: separator row z = pos; 1: separator column x = pos
-    int s, m;                 // separator cells, ring cells
+    int dof;                  // unknowns per cell: 1, or 2 for the coupled two-field Eurus system (u and v of a cell are adjacent)
+    int s, m;                 // separator / ring unknowns (cells x dof)
     int ntop, nbot, nleft, nright, xlo;   // ring segments clipped to the grid: row z0-1, row z1 (x from xlo), column x0-1, column x1 (z from z0)
     int kid[2];               // children (indices in processing order), -1: none
     int smax, mmax;           // padded sizes of the node's group
@@ -25,7 +26,7 @@ struct NdGroup {              // nodes of one tree level and kind: one strided b
 };
 
 struct NdPlan {
-    int nz = 0, nx = 0, leaf = 8, nlevels = 0;
+    int nz = 0, nx = 0, leaf = 8, nlevels = 0, dof = 1;
     std::vector<NdDev> nodes;                  // processing order: deepest level first
     std::vector<NdGroup> groups;
     long long fac_elems = 0, fregion = 0, vregion = 0, work_elems = 0, total_rows = 0;
@@ -51,29 +52,34 @@ struct NdFactor {
     double flops = 0;
 };
 
-// local index of cell (z, x) in the front: [0, s) separator, [s, s+m) ring; -1 when the cell is not in the front
-__host__ __device__ inline int nd_local(const NdDev &n, int nz, int nx, int z, int x) {
+// local index of unknown (cell (z, x), component comp) in the front: [0, s) separator, [s, s+m) ring; -1 when the cell
+// is not in the front.  Unknown = cell index * dof + comp within each part.
+__host__ __device__ inline int nd_local(const NdDev &n, int nz, int nx, int z, int x, int comp = 0) {
     (void)nz; (void)nx;
-    if (n.cut < 0) { if (z >= n.z0 && z < n.z1 && x >= n.x0 && x < n.x1) return (z - n.z0) * (n.x1 - n.x0) + (x - n.x0); }
-    else if (n.cut == 0) { if (z == n.pos && x >= n.x0 && x < n.x1) return x - n.x0; }
-    else { if (x == n.pos && z >= n.z0 && z < n.z1) return z - n.z0; }
+    const int d = n.dof;
+    if (n.cut < 0) { if (z >= n.z0 && z < n.z1 && x >= n.x0 && x < n.x1) return ((z - n.z0) * (n.x1 - n.x0) + (x - n.x0)) * d + comp; }
+    else if (n.cut == 0) { if (z == n.pos && x >= n.x0 && x < n.x1) return (x - n.x0) * d + comp; }
+    else { if (x == n.pos && z >= n.z0 && z < n.z1) return (z - n.z0) * d + comp; }
     const int wrow = n.ntop ? n.ntop : n.nbot;
-    if (n.ntop && z == n.z0 - 1 && x >= n.xlo && x < n.xlo + wrow) return n.s + (x - n.xlo);
-    if (n.nbot && z == n.z1 && x >= n.xlo && x < n.xlo + wrow) return n.s + n.ntop + (x - n.xlo);
-    if (n.nleft && x == n.x0 - 1 && z >= n.z0 && z < n.z1) return n.s + n.ntop + n.nbot + (z - n.z0);
-    if (n.nright && x == n.x1 && z >= n.z0 && z < n.z1) return n.s + n.ntop + n.nbot + n.nleft + (z - n.z0);
+    if (n.ntop && z == n.z0 - 1 && x >= n.xlo && x < n.xlo + wrow) return n.s + (x - n.xlo) * d + comp;
+    if (n.nbot && z == n.z1 && x >= n.xlo && x < n.xlo + wrow) return n.s + (n.ntop + (x - n.xlo)) * d + comp;
+    if (n.nleft && x == n.x0 - 1 && z >= n.z0 && z < n.z1) return n.s + (n.ntop + n.nbot + (z - n.z0)) * d + comp;
+    if (n.nright && x == n.x1 && z >= n.z0 && z < n.z1) return n.s + (n.ntop + n.nbot + n.nleft + (z - n.z0)) * d + comp;
     return -1;
 }
 
-// cell of local index a (0 <= a < s + m)
-__host__ __device__ inline void nd_cell(const NdDev &n, int a, int &z, int &x) {
+// cell and component of local index a (0 <= a < s + m)
+__host__ __device__ inline void nd_cell(const NdDev &n, int a, int &z, int &x, int &comp) {
+    const int d = n.dof;
     if (a < n.s) {
+        comp = a % d; a /= d;
         if (n.cut < 0) { const int w = n.x1 - n.x0; z = n.z0 + a / w; x = n.x0 + a % w; }
         else if (n.cut == 0) { z = n.pos; x = n.x0 + a; }
         else { z = n.z0 + a; x = n.pos; }
         return;
     }
     a -= n.s;
+    comp = a % d; a /= d;
     if (a < n.ntop) { z = n.z0 - 1; x = n.xlo + a; return; }
     a -= n.ntop;
     if (a < n.nbot) { z = n.z1; x = n.xlo + a; return; }
@@ -82,14 +88,15 @@ __host__ __device__ inline void nd_cell(const NdDev &n, int a, int &z, int &x) {
     a -= n.nleft;
     z = n.z0 + a; x = n.x1;
 }
+__host__ __device__ inline void nd_cell(const NdDev &n, int a, int &z, int &x) { int comp; nd_cell(n, a, z, x, comp); }
 
 // row / column of local index a in the padded front (separator block padded to smax)
 __host__ __device__ inline int nd_pos(const NdDev &n, int a) { return a < n.s ? a : n.smax + (a - n.s); }
 
-int nd_build_plan(NdPlan &P, int nz, int nx, int leaf);
+int nd_build_plan(NdPlan &P, int nz, int nx, int leaf, int dof = 1);
 long long nd_factor_ws_elems(const NdPlan &P);
-int nd_get_plan(helm_op *op, int leaf, std::shared_ptr<NdPlanDev> *out);    // cached per (device, grid, leaf)
-int nd_factor(helm_op *op, int block, NdFactor *f, cplx *ws);    // f->pd must be set
+int nd_get_plan(helm_op *op, int leaf, int dof, std::shared_ptr<NdPlanDev> *out);    // cached per (device, grid, leaf, dof)
+int nd_factor(helm_op *op, int block, NdFactor *f, cplx *ws);    // f->pd must be set; dof 2: block ignored, all four Eurus blocks
 void nd_free(NdFactor *f);
 long long nd_solve_ws_elems(const NdPlan &P, int nrhs);
 int nd_solve(helm_op *op, NdFactor *f, const cplx *Xin, cplx *Xout, int nrhs, cplx *ws);
