@@ -12,12 +12,16 @@ def main():
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--freqs', type=str, default='2.0,5.5,9.5')
     ap.add_argument('--rtol', type=float, default=1e-10)
+    ap.add_argument('--tti', action='store_true', help='coupled TTI system: smooth theta, eps != delta')
     args = ap.parse_args()
     import torch
     import bench
     import zephyr_amd as za
     cfg = bench.build_config(args.grid, args.dx)
     n = args.grid
+    if args.tti:
+        zz, xx = np.mgrid[0:n, 0:n] / float(n)
+        cfg.update(theta=0.3 * np.sin(2 * np.pi * xx) * np.cos(np.pi * zz), eps=0.15 + 0.1 * np.sin(3 * np.pi * zz), delta=0.05 + 0.05 * np.cos(2 * np.pi * xx))
     for f in [float(v) for v in args.freqs.split(',')]:
         sc = dict(cfg, freq=f, method='direct', rtol=args.rtol, batch=args.batch)
         op = za.Eurus(sc)

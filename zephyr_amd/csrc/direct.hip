@@ -634,9 +634,11 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
 
 // in-place inverse of `batch` n x n blocks (row-major, leading dimension ld, batch stride `stride`); W: workspace with
 // batch stride ws, at least n*n elements per matrix
-void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cplx *W, long long ws) {
+void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cplx *W, long long ws, int align = 1) {
     hipStream_t st = op ? op->stream : nullptr;
-    static const int gj_base = (getenv("HELM_ND_GJ") && atoi(getenv("HELM_ND_GJ")) == 64) ? 64 : 32;
+    // the coupled two-field system (align == 2) is far worse conditioned: it gets the wider pivoting window by default
+    static const int gj_env = getenv("HELM_ND_GJ") ? atoi(getenv("HELM_ND_GJ")) : 0;
+    const int gj_base = gj_env == 64 ? 64 : (gj_env == 32 ? 32 : (align == 2 ? 64 : 32));
     if (n <= gj_base) {
         for (int b0 = 0; b0 < batch; b0 += 1 << 20) {
             const int nb = std::min(1 << 20, batch - b0);
@@ -645,14 +647,17 @@ void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cp
         }
         return;
     }
-    const int s1 = n / 2, s2 = n - s1;
+    // halves split between cells, never between the two unknowns of one cell (their 2 x 2 coupling needs the pivoting of a base block)
+    int s1 = ((n / 2 + align - 1) / align) * align;
+    if (s1 >= n) s1 = n / 2;
+    const int s2 = n - s1;
     cplx *A = M, *B = M + s1, *C = M + (long long)s1 * ld, *D = M + (long long)s1 * ld + s1;
     cplx *T1 = W, *T2 = W + (long long)s1 * s2, *Wn = W + 2LL * s1 * s2;
     const cplx one = cmake(1, 0), mone = cmake(-1, 0), zero = cmake(0, 0);
-    invert(op, A, ld, stride, s1, batch, Wn, ws);
+    invert(op, A, ld, stride, s1, batch, Wn, ws, align);
     gemm(op, s2, s1, s1, one, C, ld, stride, A, ld, stride, zero, T1, s1, ws, batch);       // T1 = C A^-1
     gemm(op, s2, s2, s1, mone, T1, s1, ws, B, ld, stride, one, D, ld, stride, batch);       // D  = D - T1 B  (Schur)
-    invert(op, D, ld, stride, s2, batch, Wn, ws);
+    invert(op, D, ld, stride, s2, batch, Wn, ws, align);
     gemm(op, s1, s2, s1, one, A, ld, stride, B, ld, stride, zero, T2, s2, ws, batch);       // T2 = A^-1 B
     gemm(op, s1, s2, s2, mone, T2, s2, ws, D, ld, stride, zero, B, ld, stride, batch);      // B  = -T2 S^-1
     gemm(op, s2, s1, s2, mone, D, ld, stride, T1, s1, ws, zero, C, ld, stride, batch);      // C  = -S^-1 T1
@@ -716,7 +721,7 @@ void nd_free(NdFactor *f) {
 long long nd_factor_ws_elems(const NdPlan &P) { return 2 * P.fregion + P.work_elems; }
 
 // ws: nd_factor_ws_elems(plan) elements of scratch (fronts of two adjacent levels + inversion workspace)
-int nd_factor(helm_op *op, int block, NdFactor *f, cplx *ws) {
+int nd_factor(helm_op *op, int block, NdFactor *f, cplx *ws, const cplx *planes_in) {
     const NdPlan &P = f->pd->plan;
     const NdDev *d_nodes = f->pd->d_nodes;
     hipStream_t st = op->stream;
@@ -730,7 +735,7 @@ int nd_factor(helm_op *op, int block, NdFactor *f, cplx *ws) {
         f->d_fac = (cplx *)helm_pool_alloc(op->device, (size_t)P.fac_elems * sizeof(cplx));
         if (!f->d_fac) return fail("hipMalloc(factors)", hipErrorOutOfMemory);
     }
-    const cplx *planes = P.dof == 2 ? op->d_C : op->d_C + (long long)block * op->nplanes * op->N;
+    const cplx *planes = planes_in ? planes_in : (P.dof == 2 ? op->d_C : op->d_C + (long long)block * op->nplanes * op->N);
     const cplx one = cmake(1, 0), mone = cmake(-1, 0), zero = cmake(0, 0);
     double flops = 0;
     for (size_t gi = 0; gi < P.groups.size(); ++gi) {
@@ -755,7 +760,7 @@ int nd_factor(helm_op *op, int block, NdFactor *f, cplx *ws) {
                     hipLaunchKernelGGL(k_nd_extend_add, dim3(gx, nb), dim3(256), shm, st, d_nodes, g.first + j0, slot, arenaF, op->nz, op->nx);
                 }
         }
-        invert(op, F, nmax, fs, g.smax, g.cnt, work, (long long)g.smax * g.smax);
+        invert(op, F, nmax, fs, g.smax, g.cnt, work, (long long)g.smax * g.smax, P.dof);
         cplx *Finv = f->d_fac + g.finv, *G21 = f->d_fac + g.g21, *F12 = f->d_fac + g.f12;
         const int zb = std::min(g.cnt, 65535);
         for (int j0 = 0; j0 < g.cnt; j0 += 65535) {

@@ -901,6 +901,20 @@ int helm_launch_prep_rhs_rs(helm_op *op, const cplx *dRHS, long long rhs_ld, lon
     return HELM_OK;
 }
 
+// v[b][i] *= rs[i] in place (row equilibration of a residual before a refinement pass of the coupled system)
+__global__ __launch_bounds__(256) void k_rowscale_inplace(cplx *v, const double *__restrict__ rs, long long NV) {
+    const int b = blockIdx.y;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < NV; i += (long long)gridDim.x * blockDim.x) {
+        cplx *p = v + (long long)b * NV + i;
+        *p = cscale(*p, rs[i]);
+    }
+}
+int helm_launch_rowscale_inplace(helm_op *op, cplx *v, const double *rs, long long NV, int nrhs) {
+    hipLaunchKernelGGL(k_rowscale_inplace, dim3(vec_blocks(NV), nrhs), dim3(256), 0, op->stream, v, rs, NV);
+    HIP_TRY(op, hipGetLastError());
+    return HELM_OK;
+}
+
 // dense right-hand sides from the triplets of a sparse matrix (no duplicate entries): R[col][row] = val
 __global__ __launch_bounds__(256) void k_rhs_from_coo(const long long *__restrict__ row, const int *__restrict__ col, const cplx *__restrict__ val,
                                                       long long nnz, cplx *__restrict__ R, long long rows) {
