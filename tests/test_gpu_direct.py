@@ -201,3 +201,20 @@ def test_sparse_rhs_upload_and_receiver_sampling(helm_lib):
     op.sampleDevice(dU.data_ptr(), 3, csr, out.data_ptr())
     ref = Rm @ U.T
     assert np.abs(out.cpu().numpy() - ref).max() <= 1e-13 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize('nz,nx,nrhs', [(3, 3, 1), (3, 200, 2), (200, 3, 1), (5, 7, 7), (17, 33, 3), (129, 65, 1)])
+def test_direct_degenerate_shapes(helm_lib, nz, nx, nrhs):
+    'grids thinner than a leaf, single cells of interior, odd sizes, 1..7 right-hand sides'
+    import zephyr_amd as za
+    rng = np.random.default_rng(nz * 31 + nx)
+    c = 2000. + 1000. * rng.random((nz, nx))
+    cfg = dict(nx=nx, nz=nz, dx=10., dz=10., c=c, freq=7. + 0.3j, nPML=2, method='direct', rtol=1e-11, premul=0.5 - 2j)
+    q = rng.standard_normal((nz * nx, nrhs)) + 1j * rng.standard_normal((nz * nx, nrhs))
+    op = za.MiniZephyr(cfg)
+    u = op * q
+    C = ho.minizephyr_coefficients(nz, nx, c, ho.gardner_rho(c.astype(complex)), 7. + 0.3j, dx=10., dz=10., nPML=2)
+    ref = ho.DirectOperator(C, premul=0.5 - 2j) * q
+    assert nrm(u, ref) <= 1e-9, op.lastInfo
+    u1 = op * q[:, 0]                       # 1-D right-hand side keeps its shape
+    assert u1.shape == (nz * nx,) and nrm(u1, ref[:, 0]) <= 1e-9
