@@ -152,6 +152,7 @@ extern "C" void helm_destroy(helm_op *op) {
         std::vector<hipEvent_t> &idle = g_idle_events[op->device];
         for (hipEvent_t e : op->ev_pool) { if (idle.size() < 65536) idle.push_back(e); else hipEventDestroy(e); }
     }
+    if (op->side_stream) hipStreamDestroy(op->side_stream);
     if (op->own_stream && op->stream) hipStreamDestroy(op->stream);
     delete op;
     std::lock_guard<std::mutex> lk(g_shared_ws.mu);
@@ -641,18 +642,25 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
     const char *capenv = getenv("HELM_ND_WS_GB");
     const double cap = (capenv ? atof(capenv) : 32.0) * 1e9;
     while (Bmax > 1 && (double)per_rhs * Bmax * sizeof(cplx) > cap) Bmax = (Bmax + 1) / 2;
-    const long long ws_elems = std::max(per_rhs * Bmax, need_factor ? nd_factor_ws_elems(f->pd->plan) : 0LL);
+    // factorisation scratch sits behind the solve scratch (they are live together when HELM_ND_OVERLAP=1 runs the forward
+    // elimination of the first batch behind the factorisation on a second stream -- measured: no gain, the big forward GEMMs
+    // delay the factorisation's small launches by as much as they hide; off by default)
+    const long long fws = need_factor ? nd_factor_ws_elems(f->pd->plan) : 0LL;
+    const long long ws_elems = per_rhs * Bmax + fws;
     WsLease lease(op, (size_t)ws_elems * sizeof(cplx));
     if (!lease.ptr) { if (need_factor) nd_free(f); HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: cannot allocate %.1f GB of scratch", ws_elems * 16e-9); }
+    cplx *ws_factor = (cplx *)lease.ptr + per_rhs * Bmax;
     if (sys2) {     // the coupled system is factored row-equilibrated (its v rows are orders of magnitude smaller than its u rows,
         rc = helm_launch_rowscaled_system(op);      // which would mislead the magnitude-based pivoting): A_s = D A, A_s x = D q'
         if (rc) { if (need_factor) nd_free(f); return rc; }
     }
-    if (need_factor) {
+    static const int overlap = getenv("HELM_ND_OVERLAP") ? atoi(getenv("HELM_ND_OVERLAP")) : 0;
+    bool factor_pending = need_factor;
+    if (need_factor && !overlap) {
         hipEvent_t f0, f1;
         HIP_TRY(op, hipEventCreate(&f0)); HIP_TRY(op, hipEventCreate(&f1));
         hipEventRecord(f0, op->stream);
-        rc = nd_factor(op, block, f, (cplx *)lease.ptr, sys2 ? op->d_S : nullptr);
+        rc = nd_factor(op, block, f, ws_factor, sys2 ? op->d_S : nullptr);
         hipEventRecord(f1, op->stream);
         hipEventSynchronize(f1);
         float ms = 0.f; hipEventElapsedTime(&ms, f0, f1);
@@ -660,6 +668,10 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
         if (rc) { nd_free(f); return rc; }
         op->direct[slot] = f;
         op->timing.factor_ms += ms;
+        factor_pending = false;
+    }
+    if (factor_pending && !op->side_stream) {
+        if (hipStreamCreateWithFlags(&op->side_stream, hipStreamNonBlocking) != hipSuccess) { nd_free(f); HELM_FAIL(op, HELM_ERR_DEVICE, "hipStreamCreate failed"); }
     }
     rc = ensure_part(op, Bmax);
     if (rc) return rc;
@@ -689,16 +701,25 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
         }
         helm_launch_norm2(op, q, n);
         helm_launch_fin_ex(op, FIN_NORM, n, helm_vec_num_blocks(op), nullptr, d_aux + n);
+        const cplx *xin = q;
         if (sys2) {
             for (int half = 0; half < 2; ++half) {
                 rc = helm_launch_prep_rhs_rs(op, q, NV, half * N, cmake(1.0, 0.0), op->d_rs + half * N, x, NV, half * N, n);
-                if (rc) return rc;
+                if (rc) { if (factor_pending) nd_free(f); return rc; }
             }
-            rc = nd_solve(op, f, x, x, n, nws);
-        } else {
-            rc = nd_solve(op, f, q, x, n, nws);
+            xin = x;
         }
-        if (rc) return rc;
+        if (factor_pending) {       // factorisation with the forward elimination of this batch following it level by level
+            float fms = 0.f;
+            rc = nd_factor_solve(op, block, f, ws_factor, sys2 ? op->d_S : nullptr, xin, x, n, nws, op->side_stream, &fms);
+            if (rc) { nd_free(f); return rc; }
+            op->direct[slot] = f;
+            op->timing.factor_ms += fms;
+            factor_pending = false;
+        } else {
+            rc = nd_solve(op, f, xin, x, n, nws);
+            if (rc) return rc;
+        }
         std::vector<double> relres(n, 0.0);
         int solves = 1;
         double prev_worst = 0.0;

@@ -718,73 +718,158 @@ void nd_free(NdFactor *f) {
     delete f;
 }
 
+namespace {
+
+// factorisation of one group (tree level x kind) on op->stream
+int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, const cplx *planes) {
+    const NdPlan &P = f->pd->plan;
+    const NdDev *d_nodes = f->pd->d_nodes;
+    hipStream_t st = op->stream;
+    const cplx one = cmake(1, 0), mone = cmake(-1, 0), zero = cmake(0, 0);
+    const NdGroup &g = P.groups[gi];
+    const int nmax = g.smax + g.mmax;
+    const long long fs = (long long)nmax * nmax;
+    cplx *F = arenaF + g.foff;
+    HIP_TRY(op, hipMemsetAsync(F, 0, (size_t)g.cnt * fs * sizeof(cplx), st));
+    for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
+        const int nb = std::min(65535, g.cnt - j0);
+        hipLaunchKernelGGL(k_nd_assemble, dim3((nmax + 255) / 256, nb), dim3(256), 0, st, d_nodes, g.first + j0, arenaF, planes, op->nz, op->nx);
+    }
+    if (!g.leaf) {
+        // children's ring sizes are bounded by this group's front size
+        const size_t shm = (size_t)(2 * nmax + 8) * sizeof(int);
+        for (int slot = 0; slot < 2; ++slot)
+            for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
+                const int nb = std::min(65535, g.cnt - j0);
+                // enough chunks for the largest child ring, grid-stride otherwise
+                const long long chunks = ((long long)nmax * nmax + EA_CHUNK - 1) / EA_CHUNK;
+                const int gx = (int)std::max<long long>(1, std::min<long long>(chunks, std::max(1, 32768 / nb)));
+                hipLaunchKernelGGL(k_nd_extend_add, dim3(gx, nb), dim3(256), shm, st, d_nodes, g.first + j0, slot, arenaF, op->nz, op->nx);
+            }
+    }
+    invert(op, F, nmax, fs, g.smax, g.cnt, work, (long long)g.smax * g.smax, P.dof);
+    cplx *Finv = f->d_fac + g.finv, *G21 = f->d_fac + g.g21, *F12 = f->d_fac + g.f12;
+    for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
+        const int nb = std::min(65535, g.cnt - j0);
+        hipLaunchKernelGGL(k_copy2d, dim3((g.smax + 63) / 64, std::min(g.smax, 64), nb), dim3(64), 0, st,
+                           F + j0 * fs, nmax, fs, Finv + (long long)j0 * g.smax * g.smax, g.smax, (long long)g.smax * g.smax, g.smax, g.smax);
+        if (g.mmax > 0)
+            hipLaunchKernelGGL(k_copy2d, dim3((g.mmax + 63) / 64, std::min(g.smax, 64), nb), dim3(64), 0, st,
+                               F + j0 * fs + g.smax, nmax, fs, F12 + (long long)j0 * g.smax * g.mmax, g.mmax, (long long)g.smax * g.mmax, g.smax, g.mmax);
+    }
+    if (g.mmax > 0) {
+        // G21 = F21 F11^-1 ; F22 -= G21 F12
+        gemm(op, g.mmax, g.smax, g.smax, one, F + (long long)g.smax * nmax, nmax, fs, F, nmax, fs, zero, G21, g.smax, (long long)g.mmax * g.smax, g.cnt);
+        gemm(op, g.mmax, g.mmax, g.smax, mone, G21, g.smax, (long long)g.mmax * g.smax, F + g.smax, nmax, fs, one,
+             F + (long long)g.smax * nmax + g.smax, nmax, fs, g.cnt);
+    }
+    f->flops += (double)g.cnt * 8.0 * (2.0 * g.smax * g.smax * g.smax + (double)g.smax * g.smax * g.mmax + (double)g.smax * g.mmax * g.mmax);
+    return HELM_OK;
+}
+
+struct SolveCtx {
+    const int4 *tab; cplx *Xt, *arenaV; int nrhs; dim3 rb; int use_idx;
+    dim3 rgrid(long long rows) const { return dim3((unsigned)std::min<long long>((rows + rb.y - 1) / rb.y, 1 << 20)); }
+};
+
+SolveCtx solve_ctx(const NdFactor *f, cplx *ws, int nrhs) {
+    static const int use_idx = getenv("HELM_ND_IDXGEMM") ? atoi(getenv("HELM_ND_IDXGEMM")) : 1;
+    const NdPlan &P = f->pd->plan;
+    SolveCtx c;
+    c.tab = f->pd->d_tab; c.Xt = ws; c.arenaV = ws + (long long)P.dof * P.nz * P.nx * nrhs; c.nrhs = nrhs; c.use_idx = use_idx;
+    int lx = 1;
+    while (lx < nrhs && lx < 256) lx <<= 1;
+    c.rb = dim3(lx, 256 / lx);
+    return c;
+}
+
+// forward elimination of one group on op->stream
+void forward_group(helm_op *op, NdFactor *f, size_t gi, const SolveCtx &c) {
+    const NdPlan &P = f->pd->plan;
+    const cplx one = cmake(1, 0), mone = cmake(-1, 0), zero = cmake(0, 0);
+    const NdGroup &g = P.groups[gi];
+    const int nmax = g.smax + g.mmax, nrhs = c.nrhs;
+    const long long rows = (long long)g.cnt * nmax;
+    cplx *V = c.arenaV + g.voff * nrhs;
+    if (c.use_idx && g.leaf && g.mmax > 0 && g.smax <= GB_KIDX) {
+        // leaves have no children: the outgoing ring part is -G21 x_S with x_S read straight from Xt
+        GemmRows R; R.tabB = c.tab + g.roff; R.offB = 0; R.tab_stride = nmax; R.Bx = c.Xt; R.ldx = nrhs;
+        gemm(op, g.mmax, nrhs, g.smax, mone, f->d_fac + g.g21, g.smax, (long long)g.mmax * g.smax, nullptr, 0, 0, zero,
+             V + (long long)g.smax * nrhs, nrhs, (long long)nmax * nrhs, g.cnt, &R);
+        return;
+    }
+    hipLaunchKernelGGL(k_nd_fwd_rows, c.rgrid(rows), c.rb, 0, op->stream, c.tab + g.roff, V, c.arenaV, c.Xt, rows, nrhs, g.leaf ? 0 : 1);
+    if (g.mmax > 0)     // outgoing ring part: V_B -= G21 V_S
+        gemm(op, g.mmax, nrhs, g.smax, mone, f->d_fac + g.g21, g.smax, (long long)g.mmax * g.smax, V, nrhs, (long long)nmax * nrhs, one,
+             V + (long long)g.smax * nrhs, nrhs, (long long)nmax * nrhs, g.cnt);
+}
+
+// back substitution of one group on op->stream
+void backward_group(helm_op *op, NdFactor *f, size_t gk, const SolveCtx &c) {
+    const NdPlan &P = f->pd->plan;
+    const cplx one = cmake(1, 0), mone = cmake(-1, 0), zero = cmake(0, 0);
+    const NdGroup &g = P.groups[gk];
+    const int nmax = g.smax + g.mmax, nrhs = c.nrhs;
+    const long long rows = (long long)g.cnt * nmax;
+    cplx *V = c.arenaV + g.voff * nrhs;
+    // the other region is free in this pass: separator results go there
+    const long long xs_off = g.voff + ((g.level & 1) ? -P.vregion : P.vregion);
+    cplx *XS = c.arenaV + xs_off * nrhs;
+    if (c.use_idx && g.mmax > 0 && g.mmax <= GB_KIDX) {
+        // lower tree levels (almost all rows): T = y_S - F12 x_B and x_S = F11^-1 T with every Xt row addressed through
+        // the row table -- no gather / store pass
+        GemmRows R1; R1.tabB = c.tab + g.roff; R1.offB = g.smax; R1.tabCi = c.tab + g.roff; R1.offCi = 0; R1.tab_stride = nmax;
+        R1.Bx = c.Xt; R1.Cix = c.Xt; R1.ldx = nrhs;
+        gemm(op, g.smax, nrhs, g.mmax, mone, f->d_fac + g.f12, g.mmax, (long long)g.smax * g.mmax, nullptr, 0, 0, one,
+             V, nrhs, (long long)g.smax * nrhs, g.cnt, &R1);
+        GemmRows R2; R2.tabCo = c.tab + g.roff; R2.offCo = 0; R2.tab_stride = nmax; R2.Cox = c.Xt; R2.ldx = nrhs;
+        gemm(op, g.smax, nrhs, g.smax, one, f->d_fac + g.finv, g.smax, (long long)g.smax * g.smax, V, nrhs, (long long)g.smax * nrhs, zero,
+             nullptr, 0, 0, g.cnt, &R2);
+        return;
+    }
+    hipLaunchKernelGGL(k_nd_bwd_gather, c.rgrid(rows), c.rb, 0, op->stream, c.tab + g.roff, V, c.Xt, rows, nrhs);
+    if (g.mmax > 0)
+        gemm(op, g.smax, nrhs, g.mmax, mone, f->d_fac + g.f12, g.mmax, (long long)g.smax * g.mmax, V + (long long)g.smax * nrhs, nrhs, (long long)nmax * nrhs,
+             one, V, nrhs, (long long)nmax * nrhs, g.cnt);
+    gemm(op, g.smax, nrhs, g.smax, one, f->d_fac + g.finv, g.smax, (long long)g.smax * g.smax, V, nrhs, (long long)nmax * nrhs, zero,
+         XS, nrhs, (long long)g.smax * nrhs, g.cnt);
+    const long long srows = (long long)g.cnt * g.smax;
+    hipLaunchKernelGGL(k_nd_bwd_store, c.rgrid(srows), c.rb, 0, op->stream, c.tab + g.roff, XS, c.Xt, srows, g.smax, nmax, nrhs);
+}
+
+int factor_prologue(helm_op *op, int block, NdFactor *f, const cplx *planes_in, const cplx **planes) {
+    const NdPlan &P = f->pd->plan;
+    if (!f->d_fac) {
+        f->d_fac = (cplx *)helm_pool_alloc(op->device, (size_t)P.fac_elems * sizeof(cplx));
+        if (!f->d_fac) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: cannot allocate %.1f GB for the factors", P.fac_elems * 16e-9);
+    }
+    *planes = planes_in ? planes_in : (P.dof == 2 ? op->d_C : op->d_C + (long long)block * op->nplanes * op->N);
+    f->block = block; f->flops = 0;
+    return HELM_OK;
+}
+
+int check_kernels(helm_op *op, const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { char b[256]; snprintf(b, sizeof(b), "direct solver: %s failed: %s", what, hipGetErrorString(e)); helm_set_error(op, b); return HELM_ERR_DEVICE; }
+    return HELM_OK;
+}
+
+}  // namespace
+
 long long nd_factor_ws_elems(const NdPlan &P) { return 2 * P.fregion + P.work_elems; }
 
 // ws: nd_factor_ws_elems(plan) elements of scratch (fronts of two adjacent levels + inversion workspace)
 int nd_factor(helm_op *op, int block, NdFactor *f, cplx *ws, const cplx *planes_in) {
     const NdPlan &P = f->pd->plan;
-    const NdDev *d_nodes = f->pd->d_nodes;
-    hipStream_t st = op->stream;
-    cplx *arenaF = ws, *work = ws + 2 * P.fregion;
-    auto fail = [&](const char *what, hipError_t e) {
-        char b[256]; snprintf(b, sizeof(b), "direct solver: %s failed: %s", what, hipGetErrorString(e)); helm_set_error(op, b);
-        return HELM_ERR_DEVICE;
-    };
-    hipError_t e;
-    if (!f->d_fac) {
-        f->d_fac = (cplx *)helm_pool_alloc(op->device, (size_t)P.fac_elems * sizeof(cplx));
-        if (!f->d_fac) return fail("hipMalloc(factors)", hipErrorOutOfMemory);
-    }
-    const cplx *planes = planes_in ? planes_in : (P.dof == 2 ? op->d_C : op->d_C + (long long)block * op->nplanes * op->N);
-    const cplx one = cmake(1, 0), mone = cmake(-1, 0), zero = cmake(0, 0);
-    double flops = 0;
+    const cplx *planes = nullptr;
+    int rc = factor_prologue(op, block, f, planes_in, &planes);
+    if (rc) return rc;
     for (size_t gi = 0; gi < P.groups.size(); ++gi) {
-        const NdGroup &g = P.groups[gi];
-        const int nmax = g.smax + g.mmax;
-        const long long fs = (long long)nmax * nmax;
-        cplx *F = arenaF + g.foff;
-        if ((e = hipMemsetAsync(F, 0, (size_t)g.cnt * fs * sizeof(cplx), st)) != hipSuccess) return fail("memset", e);
-        for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
-            const int nb = std::min(65535, g.cnt - j0);
-            hipLaunchKernelGGL(k_nd_assemble, dim3((nmax + 255) / 256, nb), dim3(256), 0, st, d_nodes, g.first + j0, arenaF, planes, op->nz, op->nx);
-        }
-        if (!g.leaf) {
-            // children's ring sizes are bounded by this group's front size
-            const size_t shm = (size_t)(2 * nmax + 8) * sizeof(int);
-            for (int slot = 0; slot < 2; ++slot)
-                for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
-                    const int nb = std::min(65535, g.cnt - j0);
-                    // children's rings are at most this group's front size: enough chunks for the largest, grid-stride otherwise
-                    const long long chunks = ((long long)nmax * nmax + EA_CHUNK - 1) / EA_CHUNK;
-                    const int gx = (int)std::max<long long>(1, std::min<long long>(chunks, std::max(1, 32768 / nb)));
-                    hipLaunchKernelGGL(k_nd_extend_add, dim3(gx, nb), dim3(256), shm, st, d_nodes, g.first + j0, slot, arenaF, op->nz, op->nx);
-                }
-        }
-        invert(op, F, nmax, fs, g.smax, g.cnt, work, (long long)g.smax * g.smax, P.dof);
-        cplx *Finv = f->d_fac + g.finv, *G21 = f->d_fac + g.g21, *F12 = f->d_fac + g.f12;
-        const int zb = std::min(g.cnt, 65535);
-        for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
-            const int nb = std::min(65535, g.cnt - j0);
-            hipLaunchKernelGGL(k_copy2d, dim3((g.smax + 63) / 64, std::min(g.smax, 64), nb), dim3(64), 0, st,
-                               F + j0 * fs, nmax, fs, Finv + (long long)j0 * g.smax * g.smax, g.smax, (long long)g.smax * g.smax, g.smax, g.smax);
-            if (g.mmax > 0)
-                hipLaunchKernelGGL(k_copy2d, dim3((g.mmax + 63) / 64, std::min(g.smax, 64), nb), dim3(64), 0, st,
-                                   F + j0 * fs + g.smax, nmax, fs, F12 + (long long)j0 * g.smax * g.mmax, g.mmax, (long long)g.smax * g.mmax, g.smax, g.mmax);
-        }
-        (void)zb;
-        if (g.mmax > 0) {
-            // G21 = F21 F11^-1 ; F22 -= G21 F12
-            gemm(op, g.mmax, g.smax, g.smax, one, F + (long long)g.smax * nmax, nmax, fs, F, nmax, fs, zero, G21, g.smax, (long long)g.mmax * g.smax, g.cnt);
-            gemm(op, g.mmax, g.mmax, g.smax, mone, G21, g.smax, (long long)g.mmax * g.smax, F + g.smax, nmax, fs, one,
-                 F + (long long)g.smax * nmax + g.smax, nmax, fs, g.cnt);
-        }
-        flops += (double)g.cnt * 8.0 * (2.0 * g.smax * g.smax * g.smax + (double)g.smax * g.smax * g.mmax + (double)g.smax * g.mmax * g.mmax);
+        rc = factor_group(op, f, gi, ws, ws + 2 * P.fregion, planes);
+        if (rc) return rc;
     }
-    e = hipStreamSynchronize(st);
-    if (e == hipSuccess) e = hipGetLastError();
-    if (e != hipSuccess) return fail("factorisation kernels", e);
-    f->block = block; f->flops = flops;
-    return HELM_OK;
+    HIP_TRY(op, hipStreamSynchronize(op->stream));
+    return check_kernels(op, "factorisation kernels");
 }
 
 // ---- solve: Xin (nrhs x N, each right-hand side contiguous) -> Xout (may alias Xin) --------------------------------------
@@ -793,69 +878,61 @@ long long nd_solve_ws_elems(const NdPlan &P, int nrhs) { return ((long long)P.do
 
 int nd_solve(helm_op *op, NdFactor *f, const cplx *Xin, cplx *Xout, int nrhs, cplx *ws) {
     const NdPlan &P = f->pd->plan;
-    const int4 *tab = f->pd->d_tab;
     hipStream_t st = op->stream;
     const long long N = (long long)P.dof * P.nz * P.nx;          // unknowns per right-hand side
-    cplx *Xt = ws, *arenaV = ws + N * nrhs;
-    const cplx one = cmake(1, 0), mone = cmake(-1, 0), zero = cmake(0, 0);
-    static const int use_idx = getenv("HELM_ND_IDXGEMM") ? atoi(getenv("HELM_ND_IDXGEMM")) : 1;
-    int lx = 1;
-    while (lx < nrhs && lx < 256) lx <<= 1;
-    const dim3 rb(lx, 256 / lx);
-    auto rgrid = [&](long long rows) { return dim3((unsigned)std::min<long long>((rows + rb.y - 1) / rb.y, 1 << 20)); };
-    hipLaunchKernelGGL(k_transpose, dim3((unsigned)((N + 31) / 32), (nrhs + 31) / 32), dim3(256), 0, st, Xin, (long long)nrhs, N, Xt, 0);
-    // forward elimination, leaves to root
-    for (size_t gi = 0; gi < P.groups.size(); ++gi) {
-        const NdGroup &g = P.groups[gi];
-        const int nmax = g.smax + g.mmax;
-        const long long rows = (long long)g.cnt * nmax;
-        cplx *V = arenaV + g.voff * nrhs;
-        if (use_idx && g.leaf && g.mmax > 0 && g.smax <= GB_KIDX) {
-            // leaves have no children: the outgoing ring part is -G21 x_S with x_S read straight from Xt
-            GemmRows R; R.tabB = tab + g.roff; R.offB = 0; R.tab_stride = nmax; R.Bx = Xt; R.ldx = nrhs;
-            gemm(op, g.mmax, nrhs, g.smax, mone, f->d_fac + g.g21, g.smax, (long long)g.mmax * g.smax, nullptr, 0, 0, zero,
-                 V + (long long)g.smax * nrhs, nrhs, (long long)nmax * nrhs, g.cnt, &R);
-            continue;
-        }
-        hipLaunchKernelGGL(k_nd_fwd_rows, rgrid(rows), rb, 0, st, tab + g.roff, V, arenaV, Xt, rows, nrhs, g.leaf ? 0 : 1);
-        if (g.mmax > 0)     // outgoing ring part: V_B -= G21 V_S
-            gemm(op, g.mmax, nrhs, g.smax, mone, f->d_fac + g.g21, g.smax, (long long)g.mmax * g.smax, V, nrhs, (long long)nmax * nrhs, one,
-                 V + (long long)g.smax * nrhs, nrhs, (long long)nmax * nrhs, g.cnt);
+    const SolveCtx c = solve_ctx(f, ws, nrhs);
+    hipLaunchKernelGGL(k_transpose, dim3((unsigned)((N + 31) / 32), (nrhs + 31) / 32), dim3(256), 0, st, Xin, (long long)nrhs, N, c.Xt, 0);
+    for (size_t gi = 0; gi < P.groups.size(); ++gi) forward_group(op, f, gi, c);       // leaves to root
+    for (size_t gk = P.groups.size(); gk-- > 0;) backward_group(op, f, gk, c);          // root to leaves
+    hipLaunchKernelGGL(k_transpose, dim3((unsigned)((N + 31) / 32), (nrhs + 31) / 32), dim3(256), 0, st, c.Xt, N, (long long)nrhs, Xout, 1);
+    return check_kernels(op, "solve kernels");
+}
+
+// Factorisation and the first solve in one sweep: the forward elimination of a tree level only needs that level's factors,
+// so it follows the factorisation on a second stream, level by level.  The upper tree levels of the factorisation are a chain
+// of small latency-bound launches; the forward pass of the lower levels (big batched GEMMs) runs underneath it.
+// ws_factor / ws_solve as for nd_factor / nd_solve (disjoint); *factor_ms: time until the last front is factored.
+int nd_factor_solve(helm_op *op, int block, NdFactor *f, cplx *ws_factor, const cplx *planes_in, const cplx *Xin, cplx *Xout, int nrhs,
+                    cplx *ws_solve, hipStream_t side, float *factor_ms) {
+    const NdPlan &P = f->pd->plan;
+    hipStream_t main = op->stream;
+    const long long N = (long long)P.dof * P.nz * P.nx;
+    const cplx *planes = nullptr;
+    int rc = factor_prologue(op, block, f, planes_in, &planes);
+    if (rc) return rc;
+    const SolveCtx c = solve_ctx(f, ws_solve, nrhs);
+    const size_t ng = P.groups.size();
+    std::vector<hipEvent_t> ev(ng + 2);
+    for (auto &e : ev) HIP_TRY(op, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipEvent_t t0, t1;
+    HIP_TRY(op, hipEventCreate(&t0)); HIP_TRY(op, hipEventCreate(&t1));
+    // the right-hand sides were prepared on the main stream
+    hipEventRecord(ev[ng], main);
+    hipStreamWaitEvent(side, ev[ng], 0);
+    hipLaunchKernelGGL(k_transpose, dim3((unsigned)((N + 31) / 32), (nrhs + 31) / 32), dim3(256), 0, side, Xin, (long long)nrhs, N, c.Xt, 0);
+    hipEventRecord(t0, main);
+    for (size_t gi = 0; gi < ng && !rc; ++gi) {
+        rc = factor_group(op, f, gi, ws_factor, ws_factor + 2 * P.fregion, planes);
+        hipEventRecord(ev[gi], main);
+        hipStreamWaitEvent(side, ev[gi], 0);
+        op->stream = side;
+        forward_group(op, f, gi, c);
+        op->stream = main;
     }
-    // back substitution, root to leaves
-    for (size_t gk = P.groups.size(); gk-- > 0;) {
-        const NdGroup &g = P.groups[gk];
-        const int nmax = g.smax + g.mmax;
-        const long long rows = (long long)g.cnt * nmax;
-        cplx *V = arenaV + g.voff * nrhs;
-        // the other region is free in this pass: separator results go there
-        const long long xs_off = g.voff + ((g.level & 1) ? -P.vregion : P.vregion);
-        cplx *XS = arenaV + xs_off * nrhs;
-        if (use_idx && g.mmax > 0 && g.mmax <= GB_KIDX) {
-            // lower tree levels (almost all rows): T = y_S - F12 x_B and x_S = F11^-1 T with every Xt row addressed through
-            // the row table -- no gather / store pass
-            GemmRows R1; R1.tabB = tab + g.roff; R1.offB = g.smax; R1.tabCi = tab + g.roff; R1.offCi = 0; R1.tab_stride = nmax;
-            R1.Bx = Xt; R1.Cix = Xt; R1.ldx = nrhs;
-            gemm(op, g.smax, nrhs, g.mmax, mone, f->d_fac + g.f12, g.mmax, (long long)g.smax * g.mmax, nullptr, 0, 0, one,
-                 V, nrhs, (long long)g.smax * nrhs, g.cnt, &R1);
-            GemmRows R2; R2.tabCo = tab + g.roff; R2.offCo = 0; R2.tab_stride = nmax; R2.Cox = Xt; R2.ldx = nrhs;
-            gemm(op, g.smax, nrhs, g.smax, one, f->d_fac + g.finv, g.smax, (long long)g.smax * g.smax, V, nrhs, (long long)g.smax * nrhs, zero,
-                 nullptr, 0, 0, g.cnt, &R2);
-            continue;
-        }
-        hipLaunchKernelGGL(k_nd_bwd_gather, rgrid(rows), rb, 0, st, tab + g.roff, V, Xt, rows, nrhs);
-        if (g.mmax > 0)
-            gemm(op, g.smax, nrhs, g.mmax, mone, f->d_fac + g.f12, g.mmax, (long long)g.smax * g.mmax, V + (long long)g.smax * nrhs, nrhs, (long long)nmax * nrhs,
-                 one, V, nrhs, (long long)nmax * nrhs, g.cnt);
-        gemm(op, g.smax, nrhs, g.smax, one, f->d_fac + g.finv, g.smax, (long long)g.smax * g.smax, V, nrhs, (long long)nmax * nrhs, zero,
-             XS, nrhs, (long long)g.smax * nrhs, g.cnt);
-        const long long srows = (long long)g.cnt * g.smax;
-        hipLaunchKernelGGL(k_nd_bwd_store, rgrid(srows), rb, 0, st, tab + g.roff, XS, Xt, srows, g.smax, nmax, nrhs);
+    hipEventRecord(t1, main);
+    hipEventRecord(ev[ng + 1], side);
+    hipStreamWaitEvent(main, ev[ng + 1], 0);
+    if (!rc) {
+        for (size_t gk = ng; gk-- > 0;) backward_group(op, f, gk, c);
+        hipLaunchKernelGGL(k_transpose, dim3((unsigned)((N + 31) / 32), (nrhs + 31) / 32), dim3(256), 0, main, c.Xt, N, (long long)nrhs, Xout, 1);
     }
-    hipLaunchKernelGGL(k_transpose, dim3((unsigned)((N + 31) / 32), (nrhs + 31) / 32), dim3(256), 0, st, Xt, N, (long long)nrhs, Xout, 1);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { char b[256]; snprintf(b, sizeof(b), "direct solver: solve kernels failed: %s", hipGetErrorString(e)); helm_set_error(op, b); return HELM_ERR_DEVICE; }
-    return HELM_OK;
+    hipError_t e = hipStreamSynchronize(main);
+    if (factor_ms) { float ms = 0.f; if (hipEventElapsedTime(&ms, t0, t1) == hipSuccess) *factor_ms = ms; }
+    for (auto &x : ev) hipEventDestroy(x);
+    hipEventDestroy(t0); hipEventDestroy(t1);
+    if (rc) return rc;
+    if (e != hipSuccess) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: factor + solve failed: %s", hipGetErrorString(e));
+    return check_kernels(op, "factor + solve kernels");
 }
 
 int nd_axpy_one(helm_op *op, cplx *y, const cplx *x, long long n) {

@@ -100,4 +100,6 @@ int nd_factor(helm_op *op, int block, NdFactor *f, cplx *ws, const cplx *planes 
 void nd_free(NdFactor *f);
 long long nd_solve_ws_elems(const NdPlan &P, int nrhs);
 int nd_solve(helm_op *op, NdFactor *f, const cplx *Xin, cplx *Xout, int nrhs, cplx *ws);
+int nd_factor_solve(helm_op *op, int block, NdFactor *f, cplx *ws_factor, const cplx *planes, const cplx *Xin, cplx *Xout, int nrhs,
+                    cplx *ws_solve, hipStream_t side, float *factor_ms);
 int nd_axpy_one(helm_op *op, cplx *y, const cplx *x, long long n);

@@ -98,6 +98,7 @@ struct helm_op {
     int fs[4] = {0, 0, 0, 0};
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t side_stream = nullptr;    // second stream of the direct path (forward elimination behind the factorisation), on demand
 
     // model
     cplx *d_c = nullptr;
