@@ -241,10 +241,10 @@ __device__ __forceinline__ void zg_fetch(cplx (&ra)[NA], cplx (&rb)[NB], int tid
 
 // TM x TN tile with TM * TN = 4096: 64 x 64, 32 x 128 or 16 x 256 -- the fronts of the lower tree levels have 36, 54, 72 ...
 // rows against 256 right-hand sides, and a 64-row tile would spend up to 44 % of its flops on padding
-template <int TM, bool IDX>
+template <int TM, bool IDX, int RN = 4>
 __global__ __launch_bounds__(256) void k_zgemm(int M, int Nn, int K, cplx alpha, const cplx *A0, int lda, long long sa,
                                                const cplx *B0, int ldb, long long sb, cplx beta, cplx *C0, int ldc, long long sc, GemmRows R) {
-    constexpr int TN = 4096 / TM, TXN = TN / 4;
+    constexpr int TXN = 1024 / TM, TN = TXN * RN;      // 256 threads = (TM / 4) x TXN, each owning 4 x RN outputs
     constexpr int NA = (TM * GB_K + 255) / 256, NB = TN * GB_K / 256;
     __shared__ cplx As[GB_K][TM + 1];
     __shared__ cplx Bs[GB_K][TN];
@@ -260,11 +260,11 @@ __global__ __launch_bounds__(256) void k_zgemm(int M, int Nn, int K, cplx alpha,
         for (int k = tid; k < K; k += 256) kidx[k] = R.tabB[trow + R.offB + k].x;
         __syncthreads();
     }
-    cplx acc[4][4];
+    cplx acc[4][RN];
     #pragma unroll
     for (int i = 0; i < 4; ++i)
         #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = cmake(0.0, 0.0);
+        for (int j = 0; j < RN; ++j) acc[i][j] = cmake(0.0, 0.0);
     cplx ra[NA], rb[NB];
     ZG_FETCH(0)
     for (int k0 = 0; k0 < K; k0 += GB_K) {
@@ -276,15 +276,15 @@ __global__ __launch_bounds__(256) void k_zgemm(int M, int Nn, int K, cplx alpha,
         if (k0 + GB_K < K) { ZG_FETCH(k0 + GB_K) }
         #pragma unroll
         for (int k = 0; k < GB_K; ++k) {
-            cplx a[4], b[4];
+            cplx a[4], b[RN];
             #pragma unroll
             for (int i = 0; i < 4; ++i) a[i] = As[k][ty * 4 + i];
             #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = Bs[k][tx * 4 + j];
+            for (int j = 0; j < RN; ++j) b[j] = Bs[k][tx * RN + j];
             #pragma unroll
             for (int i = 0; i < 4; ++i)
                 #pragma unroll
-                for (int j = 0; j < 4; ++j) cfma(acc[i][j], a[i], b[j]);
+                for (int j = 0; j < RN; ++j) cfma(acc[i][j], a[i], b[j]);
         }
         __syncthreads();
     }
@@ -305,8 +305,8 @@ __global__ __launch_bounds__(256) void k_zgemm(int M, int Nn, int K, cplx alpha,
             cin = ix >= 0 ? R.Cix + (long long)ix * R.ldx : nullptr;
         }
         #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int cc = n0 + tx * 4 + j;
+        for (int j = 0; j < RN; ++j) {
+            const int cc = n0 + tx * RN + j;
             if (cc >= Nn) continue;
             cplx v = cmul(alpha, acc[i][j]);
             if (!b0 && cin) v = cadd(v, cmul(beta, cin[cc]));
@@ -315,13 +315,13 @@ __global__ __launch_bounds__(256) void k_zgemm(int M, int Nn, int K, cplx alpha,
     }
 }
 
-template <int TM>
+template <int TM, int RN = 4>
 void launch_vec(hipStream_t st, bool idx, int nb, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, long long sa, const cplx *B, int ldb, long long sb,
                 cplx beta, cplx *C, int ldc, long long sc, const GemmRows &R) {
-    constexpr int TN = 4096 / TM;
+    constexpr int TN = (1024 / TM) * RN;
     dim3 grid((Nn + TN - 1) / TN, (M + TM - 1) / TM, nb);
-    if (idx) hipLaunchKernelGGL((k_zgemm<TM, true>), grid, dim3(256), 0, st, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
-    else hipLaunchKernelGGL((k_zgemm<TM, false>), grid, dim3(256), 0, st, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
+    if (idx) hipLaunchKernelGGL((k_zgemm<TM, true, RN>), grid, dim3(256), 0, st, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
+    else hipLaunchKernelGGL((k_zgemm<TM, false, RN>), grid, dim3(256), 0, st, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
 }
 
 // ---- the same GEMM on the matrix cores -------------------------------------------------------------------------
@@ -620,6 +620,7 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
             }
             continue;
         }
+        // (a 4 x 8 register block per thread -- RN = 8, 64 x 128 tile -- was measured too: 230 VGPRs, occupancy 2, 38 % slower)
         if (vbest == 64) launch_vec<64>(st, rows != nullptr, nb, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R);
         else if (vbest == 32) launch_vec<32>(st, rows != nullptr, nb, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R);
         else launch_vec<16>(st, rows != nullptr, nb, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R);
