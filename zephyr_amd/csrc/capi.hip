@@ -630,11 +630,16 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
         const char *inj = getenv("HELM_ND_INJECT_FAILURE");
         if (inj && atoi(inj) != 0) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: injected failure (HELM_ND_INJECT_FAILURE)");
     }
+    struct FactorOwner {       // a factor under construction is released on every early return
+        NdFactor *p = nullptr;
+        ~FactorOwner() { if (p) nd_free(p); }
+    } fresh;
     if (need_factor) {
         const char *e = getenv("HELM_ND_LEAF");
         f = new NdFactor();
+        fresh.p = f;
         rc = nd_get_plan(op, e ? std::max(2, atoi(e)) : 8, sys2 ? 2 : 1, &f->pd);
-        if (rc) { nd_free(f); return rc; }
+        if (rc) return rc;
     }
     const long long per_rhs = nd_solve_ws_elems(f->pd->plan, 1) + 2 * NV;
     int Bmax = o.batch > 0 ? o.batch : 256;
@@ -648,11 +653,11 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
     const long long fws = need_factor ? nd_factor_ws_elems(f->pd->plan) : 0LL;
     const long long ws_elems = per_rhs * Bmax + fws;
     WsLease lease(op, (size_t)ws_elems * sizeof(cplx));
-    if (!lease.ptr) { if (need_factor) nd_free(f); HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: cannot allocate %.1f GB of scratch", ws_elems * 16e-9); }
+    if (!lease.ptr) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: cannot allocate %.1f GB of scratch", ws_elems * 16e-9);
     cplx *ws_factor = (cplx *)lease.ptr + per_rhs * Bmax;
     if (sys2) {     // the coupled system is factored row-equilibrated (its v rows are orders of magnitude smaller than its u rows,
         rc = helm_launch_rowscaled_system(op);      // which would mislead the magnitude-based pivoting): A_s = D A, A_s x = D q'
-        if (rc) { if (need_factor) nd_free(f); return rc; }
+        if (rc) return rc;
     }
     static const int overlap = getenv("HELM_ND_OVERLAP") ? atoi(getenv("HELM_ND_OVERLAP")) : 0;
     bool factor_pending = need_factor;
@@ -665,13 +670,13 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
         hipEventSynchronize(f1);
         float ms = 0.f; hipEventElapsedTime(&ms, f0, f1);
         hipEventDestroy(f0); hipEventDestroy(f1);
-        if (rc) { nd_free(f); return rc; }
-        op->direct[slot] = f;
+        if (rc) return rc;
+        op->direct[slot] = f; fresh.p = nullptr;
         op->timing.factor_ms += ms;
         factor_pending = false;
     }
     if (factor_pending && !op->side_stream) {
-        if (hipStreamCreateWithFlags(&op->side_stream, hipStreamNonBlocking) != hipSuccess) { nd_free(f); HELM_FAIL(op, HELM_ERR_DEVICE, "hipStreamCreate failed"); }
+        if (hipStreamCreateWithFlags(&op->side_stream, hipStreamNonBlocking) != hipSuccess) HELM_FAIL(op, HELM_ERR_DEVICE, "hipStreamCreate failed");
     }
     rc = ensure_part(op, Bmax);
     if (rc) return rc;
@@ -695,25 +700,25 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
                 rc = helm_launch_prep_rhs_ex(op, rhs_b, rhs_ld, half * N, premul, nullptr, q, NV, half * N, n);
                 if (rc) return rc;
             }
+            helm_launch_norm2(op, q, n);
         } else {
-            rc = helm_launch_prep_rhs(op, rhs_b, rhs_ld, row_off, premul, sub_b, q, n);
+            rc = helm_launch_prep_rhs_norm(op, rhs_b, rhs_ld, row_off, premul, sub_b, q, n);      // q' and the partials of ||q'||^2
             if (rc) return rc;
         }
-        helm_launch_norm2(op, q, n);
         helm_launch_fin_ex(op, FIN_NORM, n, helm_vec_num_blocks(op), nullptr, d_aux + n);
         const cplx *xin = q;
         if (sys2) {
             for (int half = 0; half < 2; ++half) {
                 rc = helm_launch_prep_rhs_rs(op, q, NV, half * N, cmake(1.0, 0.0), op->d_rs + half * N, x, NV, half * N, n);
-                if (rc) { if (factor_pending) nd_free(f); return rc; }
+                if (rc) return rc;
             }
             xin = x;
         }
         if (factor_pending) {       // factorisation with the forward elimination of this batch following it level by level
             float fms = 0.f;
             rc = nd_factor_solve(op, block, f, ws_factor, sys2 ? op->d_S : nullptr, xin, x, n, nws, op->side_stream, &fms);
-            if (rc) { nd_free(f); return rc; }
-            op->direct[slot] = f;
+            if (rc) return rc;
+            op->direct[slot] = f; fresh.p = nullptr;
             op->timing.factor_ms += fms;
             factor_pending = false;
         } else {

@@ -236,6 +236,7 @@ int helm_launch_rowscaled_system(helm_op *op);    // d_S, d_rs
 int helm_launch_prep_rhs_rs(helm_op *op, const cplx *dRHS, long long rhs_ld, long long row_off, cplx premul, const double *rs,
                             cplx *out, long long out_ld, long long out_off, int nrhs);
 int helm_launch_prep_rhs(helm_op *op, const cplx *dRHS, long long rhs_ld, long long row_off, cplx premul, const cplx *sub, cplx *out, int nrhs); // out = premul*rhs - sub
+int helm_launch_prep_rhs_norm(helm_op *op, const cplx *dRHS, long long rhs_ld, long long row_off, cplx premul, const cplx *sub, cplx *out, int nrhs);
 int helm_launch_imaging(helm_op *op, const cplx *uf, const cplx *ub, int nsrc, const cplx *scaler, cplx *g);
 int helm_launch_zero(helm_op *op, cplx *p, long long n);
 int helm_launch_rhs_from_coo(helm_op *op, const long long *row, const int *col, const cplx *val, long long nnz, cplx *R, int nrhs, long long rows);

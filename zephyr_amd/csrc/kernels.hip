@@ -307,6 +307,23 @@ __global__ __launch_bounds__(256) void k_prep_rhs(const cplx *__restrict__ rhs, 
     }
 }
 
+// k_prep_rhs with the partial (out, out) of k_norm2 folded in (direct path: one pass over the right-hand sides less)
+__global__ __launch_bounds__(256) void k_prep_rhs_norm(const cplx *__restrict__ rhs, long long rhs_ld, long long row_off, cplx premul,
+                                                       const cplx *__restrict__ sub, cplx *__restrict__ out, long long N,
+                                                       double *__restrict__ part, int nblk) {
+    __shared__ double red[4];
+    const int b = blockIdx.y;
+    double s[1] = {0.0};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x) {
+        cplx v = cmul(premul, rhs[(long long)b * rhs_ld + row_off + i]);
+        if (sub) v = csub(v, sub[(long long)b * N + i]);
+        out[(long long)b * N + i] = v;
+        s[0] += cabs2(v);
+    }
+    block_sum<1>(s, red);
+    if (threadIdx.x == 0) part[((long long)b * 4) * nblk + blockIdx.x] = s[0];
+}
+
 // BiCGSTAB / CGNR start: x = 0, r = r0 = bbar, p = v = 0, partial (r, r)
 __global__ __launch_bounds__(256) void k_krylov_init(const cplx *__restrict__ bbar, VecPtrs w, long long N,
                                                      double *__restrict__ part, int nblk) {
@@ -785,6 +802,14 @@ int helm_launch_prep_rhs(helm_op *op, const cplx *dRHS, long long rhs_ld, long l
                          const cplx *sub, cplx *out, int nrhs) {
     dim3 grid(vec_blocks(op->Nv), nrhs);
     hipLaunchKernelGGL(k_prep_rhs, grid, dim3(256), 0, op->stream, dRHS, rhs_ld, row_off, premul, sub, (const cplx *)nullptr, out, op->Nv);
+    HIP_TRY(op, hipGetLastError());
+    return HELM_OK;
+}
+
+// out = premul*rhs - sub and the partial sums of ||out||^2 (reduce with FIN_NORM over helm_vec_num_blocks partials)
+int helm_launch_prep_rhs_norm(helm_op *op, const cplx *dRHS, long long rhs_ld, long long row_off, cplx premul, const cplx *sub, cplx *out, int nrhs) {
+    dim3 grid(vec_blocks(op->Nv), nrhs);
+    hipLaunchKernelGGL(k_prep_rhs_norm, grid, dim3(256), 0, op->stream, dRHS, rhs_ld, row_off, premul, sub, out, op->Nv, (double *)op->d_part, (int)grid.x);
     HIP_TRY(op, hipGetLastError());
     return HELM_OK;
 }
