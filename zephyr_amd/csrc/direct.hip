@@ -635,11 +635,11 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
 
 // in-place inverse of `batch` n x n blocks (row-major, leading dimension ld, batch stride `stride`); W: workspace with
 // batch stride ws, at least n*n elements per matrix
-void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cplx *W, long long ws, int align = 1) {
+void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cplx *W, long long ws, int align = 1, int base = 0) {
     hipStream_t st = op ? op->stream : nullptr;
     // the coupled two-field system (align == 2) is far worse conditioned: it gets the wider pivoting window by default
     static const int gj_env = getenv("HELM_ND_GJ") ? atoi(getenv("HELM_ND_GJ")) : 0;
-    const int gj_base = gj_env == 64 ? 64 : (gj_env == 32 ? 32 : (align == 2 ? 64 : 32));
+    const int gj_base = base ? base : (gj_env == 64 ? 64 : (gj_env == 32 ? 32 : (align == 2 ? 64 : 32)));
     if (n <= gj_base) {
         for (int b0 = 0; b0 < batch; b0 += 1 << 20) {
             const int nb = std::min(1 << 20, batch - b0);
@@ -655,10 +655,10 @@ void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cp
     cplx *A = M, *B = M + s1, *C = M + (long long)s1 * ld, *D = M + (long long)s1 * ld + s1;
     cplx *T1 = W, *T2 = W + (long long)s1 * s2, *Wn = W + 2LL * s1 * s2;
     const cplx one = cmake(1, 0), mone = cmake(-1, 0), zero = cmake(0, 0);
-    invert(op, A, ld, stride, s1, batch, Wn, ws, align);
+    invert(op, A, ld, stride, s1, batch, Wn, ws, align, base);
     gemm(op, s2, s1, s1, one, C, ld, stride, A, ld, stride, zero, T1, s1, ws, batch);       // T1 = C A^-1
     gemm(op, s2, s2, s1, mone, T1, s1, ws, B, ld, stride, one, D, ld, stride, batch);       // D  = D - T1 B  (Schur)
-    invert(op, D, ld, stride, s2, batch, Wn, ws, align);
+    invert(op, D, ld, stride, s2, batch, Wn, ws, align, base);
     gemm(op, s1, s2, s1, one, A, ld, stride, B, ld, stride, zero, T2, s2, ws, batch);       // T2 = A^-1 B
     gemm(op, s1, s2, s2, mone, T2, s2, ws, D, ld, stride, zero, B, ld, stride, batch);      // B  = -T2 S^-1
     gemm(op, s2, s1, s2, mone, D, ld, stride, T1, s1, ws, zero, C, ld, stride, batch);      // C  = -S^-1 T1
@@ -748,7 +748,9 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
                 hipLaunchKernelGGL(k_nd_extend_add, dim3(gx, nb), dim3(256), shm, st, d_nodes, g.first + j0, slot, arenaF, op->nz, op->nx);
             }
     }
-    invert(op, F, nmax, fs, g.smax, g.cnt, work, (long long)g.smax * g.smax, P.dof);
+    static const int gj_leaf = getenv("HELM_ND_GJ_LEAF") ? atoi(getenv("HELM_ND_GJ_LEAF")) : 0;
+    static const int gj_upper = getenv("HELM_ND_GJ_UPPER") ? atoi(getenv("HELM_ND_GJ_UPPER")) : 0;
+    invert(op, F, nmax, fs, g.smax, g.cnt, work, (long long)g.smax * g.smax, P.dof, g.leaf ? gj_leaf : gj_upper);
     cplx *Finv = f->d_fac + g.finv, *G21 = f->d_fac + g.g21, *F12 = f->d_fac + g.f12;
     for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
         const int nb = std::min(65535, g.cnt - j0);
