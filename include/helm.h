@@ -50,13 +50,15 @@ enum { HELM_MINIZEPHYR = 0, HELM_EURUS = 1, HELM_3D = 2 /* 27-point 3-D operator
 enum {
     HELM_BICGSTAB = 0,   /* Jacobi-preconditioned BiCGSTAB */
     HELM_CGNR = 1,       /* Jacobi-scaled CGNR */
-    HELM_AUTO = 2,       /* HELM_MG where available, else BiCGSTAB; CGNR for right-hand sides that break down */
+    HELM_AUTO = 2,       /* HELM_DIRECT for every 2-D system; if that fails, and in 3-D: HELM_MG where available, else
+                            BiCGSTAB, with CGNR for right-hand sides that break down */
     HELM_MG = 3,         /* BiCGSTAB right-preconditioned by shifted-Laplacian multigrid (damped-Jacobi smoothing)
                             + PML strip line relaxation */
     HELM_DIRECT = 4      /* sparse direct: nested-dissection multifrontal factorisation kept on the handle until the next
                             helm_assemble and re-used for every right-hand side (what the reference's sparse LU does,
                             discretization.py:78-103), plus iterative refinement with the stencil kernel to rtol.
-                            2-D single-block systems only (MiniZephyr; Eurus with eps == delta) */
+                            2-D: MiniZephyr, Eurus with eps == delta (block-triangular) and the coupled TTI system
+                            (eps != delta, two unknowns per cell, row-equilibrated); not the 3-D operator */
 };
 
 /* hard errors */
