@@ -210,6 +210,7 @@ def main():
     t0 = time.perf_counter()
     iters, apply_ms, apply_launches, apply_bytes, solve_ms = [], 0.0, 0, 0.0, 0.0
     gemm_ms, gemm_launches, gemm_flops, factor_ms, methods = 0.0, 0, 0.0, 0.0, set()
+    big_ms, big_launches, big_flops = 0.0, 0, 0.0
     freq_used = []
     results = [None] * args.steps
     if args.streams <= 1:
@@ -237,6 +238,7 @@ def main():
         solve_ms += t['solve_ms']
         gemm_ms += t['gemm_ms']; gemm_launches += t['gemm_launches']; gemm_flops += t['gemm_flops']; factor_ms += t['factor_ms']
         methods.update(i['method'] for i in info)
+        big_ms += t['gemm_big_ms']; big_launches += t['gemm_big_launches']; big_flops += t['gemm_big_flops']
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -281,7 +283,10 @@ def main():
                                'achieved': tf, 'peak': F64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / F64_PEAK_TFLOPS, 'traffic': None,
                                'launches_timed': int(gemm_launches), 'avg_launch_us': 1e3 * gemm_ms / gemm_launches if gemm_launches else None,
                                'flops_per_launch_algorithmic': gemm_flops / gemm_launches if gemm_launches else None,
-                               'gemm_share_of_solve_time': gemm_ms / solve_ms if solve_ms > 0 else None}
+                               'gemm_share_of_solve_time': gemm_ms / solve_ms if solve_ms > 0 else None,
+                               'launches_of_at_least_1_GFLOP': {'launches': int(big_launches), 'share_of_gemm_time': big_ms / gemm_ms if gemm_ms > 0 else None,
+                                                                'achieved': big_flops / (big_ms * 1e-3) / 1e12 if big_ms > 0 else None, 'unit': 'TFLOP/s',
+                                                                'frac': big_flops / (big_ms * 1e-3) / 1e12 / F64_PEAK_TFLOPS if big_ms > 0 else None}}
             out['stencil_roofline'] = stencil
         else:
             out['roofline'] = stencil

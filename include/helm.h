@@ -153,6 +153,9 @@ typedef struct helm_timing {
     double gemm_ms;          /* HELM_DIRECT: ms / launches / flops (8 M N K per batch item) of the dense complex GEMM kernel */
     long long gemm_launches;
     double gemm_flops;
+    double gemm_big_ms;      /* the same over the launches of at least 1 GFLOP (throughput-bound ones) */
+    long long gemm_big_launches;
+    double gemm_big_flops;
 } helm_timing;
 int helm_last_timing(const helm_op *op, helm_timing *out);
 /* enable per-launch HIP-event timing of the stencil kernel inside solves (costs a little) */

@@ -315,6 +315,7 @@ static void timing_begin(helm_op *op) {
     op->ev_pending_gemm.clear();
     op->timing.apply_ms = 0; op->timing.apply_launches = 0; op->timing.apply_bytes = 0;
     op->timing.factor_ms = 0; op->timing.gemm_ms = 0; op->timing.gemm_launches = 0; op->timing.gemm_flops = 0;
+    op->timing.gemm_big_ms = 0; op->timing.gemm_big_launches = 0; op->timing.gemm_big_flops = 0;
 }
 static void timing_collect(helm_op *op) {
     for (auto &pr : op->ev_pending) {
@@ -328,6 +329,7 @@ static void timing_collect(helm_op *op) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, op->ev_pool[pr.first], op->ev_pool[pr.first + 1]) == hipSuccess) {
             op->timing.gemm_ms += ms; op->timing.gemm_launches += 1; op->timing.gemm_flops += pr.second;
+            if (pr.second >= 1e9) { op->timing.gemm_big_ms += ms; op->timing.gemm_big_launches += 1; op->timing.gemm_big_flops += pr.second; }
         }
     }
     op->ev_pending_gemm.clear();

@@ -134,7 +134,7 @@ struct helm_op {
 
     // timing / profiling
     bool profiling = false;
-    helm_timing timing = {0, 0, 0, 0, 0, 0, 0, 0};
+    helm_timing timing = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<hipEvent_t> ev_pool;
     std::vector<std::pair<int, double>> ev_pending;   // (event-pair index, bytes)
     std::vector<std::pair<int, double>> ev_pending_gemm;   // (event-pair index, flops) of the direct solver's GEMM launches

@@ -274,7 +274,8 @@ class BaseDiscretization(BaseModelDependent):
         t = _lib.Timing()
         _lib.check(_lib.load().helm_last_timing(self.handle, ctypes.byref(t)), self.handle)
         return dict(solve_ms=t.solve_ms, apply_ms=t.apply_ms, apply_launches=t.apply_launches, apply_bytes=t.apply_bytes,
-                    factor_ms=t.factor_ms, gemm_ms=t.gemm_ms, gemm_launches=t.gemm_launches, gemm_flops=t.gemm_flops)
+                    factor_ms=t.factor_ms, gemm_ms=t.gemm_ms, gemm_launches=t.gemm_launches, gemm_flops=t.gemm_flops,
+                    gemm_big_ms=t.gemm_big_ms, gemm_big_launches=t.gemm_big_launches, gemm_big_flops=t.gemm_big_flops)
 
     @staticmethod
     def _dense_rhs(rhs):
