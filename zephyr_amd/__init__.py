@@ -14,9 +14,15 @@ from .minizephyr import MiniZephyr, MiniZephyrHD, MiniZephyr25D
 from .source import (FakeSource, SimpleSource, StackedSimpleSource, SparseKaiserSource, KaiserSource,
                      AnisotropicKaiserSource)
 
+def trim():
+    'give the scratch memory libhelm caches between calls (tens of GB after large direct solves) back to the device'
+    from . import _lib
+    return _lib.load().helm_trim()
+
+
 __all__ = [
     'AnalyticalHelmholtz', 'BaseModelDependent', 'BaseAnisotropic', 'AttributeMapper', 'BaseSCCache', 'SCFilter',
     'BaseDiscretization', 'DiscretizationWrapper', 'BaseDist', 'BaseMPDist', 'MultiFreq', 'SerialMultiFreq',
     'ViscoMultiFreq', 'Eurus', 'EurusHD', 'Helm3D', 'MiniZephyr', 'MiniZephyrHD', 'MiniZephyr25D', 'FakeSource', 'SimpleSource',
-    'StackedSimpleSource', 'SparseKaiserSource', 'KaiserSource', 'AnisotropicKaiserSource',
+    'StackedSimpleSource', 'SparseKaiserSource', 'KaiserSource', 'AnisotropicKaiserSource', 'trim',
 ]
