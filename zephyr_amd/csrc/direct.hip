@@ -169,14 +169,14 @@ __global__ __launch_bounds__(256) void k_nd_assemble(const NdDev *nodes, int fir
 }
 
 // parent front += Schur complement of child `slot`; the m x m entries of the child's F22 are spread over gridDim.x blocks
-#define EA_CHUNK 4096
-__global__ __launch_bounds__(256) void k_nd_extend_add(const NdDev *nodes, int first, int slot, cplx *arenaF, int nz, int nx) {
+// (every block rebuilds the child-ring -> parent-row map in LDS, so a block takes `chunk` entries: large enough to amortise that)
+__global__ __launch_bounds__(256) void k_nd_extend_add(const NdDev *nodes, int first, int slot, cplx *arenaF, int nz, int nx, int chunk) {
     extern __shared__ int map[];
     const NdDev p = nodes[first + blockIdx.y];
     if (p.kid[slot] < 0) return;
     const NdDev c = nodes[p.kid[slot]];
     const long long total = (long long)c.m * c.m;
-    if ((long long)blockIdx.x * EA_CHUNK >= total) return;
+    if ((long long)blockIdx.x * chunk >= total) return;
     for (int a = threadIdx.x; a < c.m; a += blockDim.x) {
         int z, x, comp;
         nd_cell(c, c.s + a, z, x, comp);
@@ -186,8 +186,8 @@ __global__ __launch_bounds__(256) void k_nd_extend_add(const NdDev *nodes, int f
     const cplx *Fc = arenaF + c.foff;
     cplx *Fp = arenaF + p.foff;
     const int ldc = c.smax + c.mmax, ldp = p.smax + p.mmax;
-    for (long long e0 = (long long)blockIdx.x * EA_CHUNK; e0 < total; e0 += (long long)gridDim.x * EA_CHUNK) {
-        const long long e1 = e0 + EA_CHUNK < total ? e0 + EA_CHUNK : total;
+    for (long long e0 = (long long)blockIdx.x * chunk; e0 < total; e0 += (long long)gridDim.x * chunk) {
+        const long long e1 = e0 + chunk < total ? e0 + chunk : total;
         for (long long e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
             const int a = (int)(e / c.m), b2 = (int)(e - (long long)a * c.m);
             cplx *dst = Fp + (long long)map[a] * ldp + map[b2];
@@ -744,10 +744,11 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
         for (int slot = 0; slot < 2; ++slot)
             for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
                 const int nb = std::min(65535, g.cnt - j0);
-                // enough chunks for the largest child ring, grid-stride otherwise
-                const long long chunks = ((long long)nmax * nmax + EA_CHUNK - 1) / EA_CHUNK;
-                const int gx = (int)std::max<long long>(1, std::min<long long>(chunks, std::max(1, 32768 / nb)));
-                hipLaunchKernelGGL(k_nd_extend_add, dim3(gx, nb), dim3(256), shm, st, d_nodes, g.first + j0, slot, arenaF, op->nz, op->nx);
+                // a chunk is at least 16 entries per map entry the block has to build, and enough chunks to fill the chip
+                const long long total = (long long)nmax * nmax;
+                const int chunk = (int)std::max<long long>(4096, std::min<long long>(total, std::max<long long>(16LL * nmax, total / std::max(1, 2048 / nb))));
+                const int gx = (int)std::max<long long>(1, std::min<long long>((total + chunk - 1) / chunk, 65535));
+                hipLaunchKernelGGL(k_nd_extend_add, dim3(gx, nb), dim3(256), shm, st, d_nodes, g.first + j0, slot, arenaF, op->nz, op->nx, chunk);
             }
     }
     static const int gj_leaf = getenv("HELM_ND_GJ_LEAF") ? atoi(getenv("HELM_ND_GJ_LEAF")) : 0;
