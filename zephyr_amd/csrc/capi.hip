@@ -312,7 +312,7 @@ static int ensure_part(helm_op *op, int nrhs) {
 static void timing_begin(helm_op *op) {
     op->ev_used = 0;
     op->ev_pending.clear();
-    op->ev_pending_gemm.clear();
+    op->ev_pending_gemm.clear(); op->ev_pending_gemm_n.clear();
     op->timing.apply_ms = 0; op->timing.apply_launches = 0; op->timing.apply_bytes = 0;
     op->timing.factor_ms = 0; op->timing.gemm_ms = 0; op->timing.gemm_launches = 0; op->timing.gemm_flops = 0;
     op->timing.gemm_big_ms = 0; op->timing.gemm_big_launches = 0; op->timing.gemm_big_flops = 0;
@@ -325,14 +325,16 @@ static void timing_collect(helm_op *op) {
         }
     }
     op->ev_pending.clear();
-    for (auto &pr : op->ev_pending_gemm) {
+    for (size_t i = 0; i < op->ev_pending_gemm.size(); ++i) {
+        const std::pair<int, double> &pr = op->ev_pending_gemm[i];
+        const int nl = i < op->ev_pending_gemm_n.size() ? op->ev_pending_gemm_n[i] : 1;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, op->ev_pool[pr.first], op->ev_pool[pr.first + 1]) == hipSuccess) {
-            op->timing.gemm_ms += ms; op->timing.gemm_launches += 1; op->timing.gemm_flops += pr.second;
-            if (pr.second >= 1e9) { op->timing.gemm_big_ms += ms; op->timing.gemm_big_launches += 1; op->timing.gemm_big_flops += pr.second; }
+            op->timing.gemm_ms += ms; op->timing.gemm_launches += nl; op->timing.gemm_flops += pr.second;
+            if (pr.second >= 1e9 * nl) { op->timing.gemm_big_ms += ms; op->timing.gemm_big_launches += nl; op->timing.gemm_big_flops += pr.second; }
         }
     }
-    op->ev_pending_gemm.clear();
+    op->ev_pending_gemm.clear(); op->ev_pending_gemm_n.clear();
     op->ev_used = 0;
 }
 

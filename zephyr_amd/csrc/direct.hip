@@ -582,12 +582,14 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
     if (M <= 0 || Nn <= 0 || batch <= 0) return 0;
     hipStream_t st = op ? op->stream : nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (op && op->profiling) {
+    const bool in_run = op && op->gemm_run_depth > 0;
+    if (op && op->profiling && !(in_run && op->gemm_run_pair >= 0)) {
         if (op->ev_used + 2 > op->ev_pool.size() && op->ev_pool.size() < 16384)
             (void)helm_events_grow(op, 64);
         if (op->ev_used + 2 <= op->ev_pool.size()) { e0 = op->ev_pool[op->ev_used]; e1 = op->ev_pool[op->ev_used + 1]; }
     }
     if (e0) hipEventRecord(e0, st);
+    if (in_run && e0) { op->gemm_run_pair = (int)op->ev_used; op->ev_used += 2; }
     static const int use_mfma = getenv("HELM_ND_MFMA") ? atoi(getenv("HELM_ND_MFMA")) : 0;
     static const int fixed_tm = getenv("HELM_ND_TM") ? atoi(getenv("HELM_ND_TM")) : 0;
     int vbest = 64; long long varea = -1;
@@ -625,13 +627,33 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
         else if (vbest == 32) launch_vec<32>(st, rows != nullptr, nb, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R);
         else launch_vec<16>(st, rows != nullptr, nb, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R);
     }
-    if (e0) {
+    const double flops = 8.0 * M * (double)Nn * K * batch;
+    if (in_run) {                       // the run's end event is recorded by GemmRun's destructor
+        if (op->gemm_run_pair >= 0) { op->gemm_run_flops += flops; op->gemm_run_launches += 1; }
+    } else if (e0) {
         hipEventRecord(e1, st);
-        op->ev_pending_gemm.push_back(std::make_pair((int)op->ev_used, 8.0 * M * (double)Nn * K * batch));
+        op->ev_pending_gemm.push_back(std::make_pair((int)op->ev_used, flops));
+        op->ev_pending_gemm_n.push_back(1);
         op->ev_used += 2;
     }
     return 0;
 }
+
+// Consecutive GEMM launches with no other kernel between them (the recursion of the block inversion issues them in runs of
+// two and four) share one pair of timing events: the per-launch average stays exact, two thirds of the event traffic go away.
+struct GemmRun {
+    helm_op *op;
+    explicit GemmRun(helm_op *o) : op(o) { if (op && op->gemm_run_depth++ == 0) { op->gemm_run_pair = -1; op->gemm_run_flops = 0; op->gemm_run_launches = 0; } }
+    ~GemmRun() {
+        if (!op || --op->gemm_run_depth != 0) return;
+        if (op->gemm_run_pair >= 0 && op->gemm_run_launches > 0) {
+            hipEventRecord(op->ev_pool[op->gemm_run_pair + 1], op->stream);
+            op->ev_pending_gemm.push_back(std::make_pair(op->gemm_run_pair, op->gemm_run_flops));
+            op->ev_pending_gemm_n.push_back(op->gemm_run_launches);
+        }
+        op->gemm_run_pair = -1;
+    }
+};
 
 // in-place inverse of `batch` n x n blocks (row-major, leading dimension ld, batch stride `stride`); W: workspace with
 // batch stride ws, at least n*n elements per matrix
@@ -658,13 +680,19 @@ void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cp
     cplx *T1 = W, *T2 = W + (long long)s1 * s2, *Wn = W + 2LL * s1 * s2;
     const cplx one = cmake(1, 0), mone = cmake(-1, 0), zero = cmake(0, 0);
     invert(op, A, ld, stride, s1, batch, Wn, ws, align, base);
-    gemm(op, s2, s1, s1, one, C, ld, stride, A, ld, stride, zero, T1, s1, ws, batch);       // T1 = C A^-1
-    gemm(op, s2, s2, s1, mone, T1, s1, ws, B, ld, stride, one, D, ld, stride, batch);       // D  = D - T1 B  (Schur)
+    {
+        GemmRun run(op);
+        gemm(op, s2, s1, s1, one, C, ld, stride, A, ld, stride, zero, T1, s1, ws, batch);       // T1 = C A^-1
+        gemm(op, s2, s2, s1, mone, T1, s1, ws, B, ld, stride, one, D, ld, stride, batch);       // D  = D - T1 B  (Schur)
+    }
     invert(op, D, ld, stride, s2, batch, Wn, ws, align, base);
-    gemm(op, s1, s2, s1, one, A, ld, stride, B, ld, stride, zero, T2, s2, ws, batch);       // T2 = A^-1 B
-    gemm(op, s1, s2, s2, mone, T2, s2, ws, D, ld, stride, zero, B, ld, stride, batch);      // B  = -T2 S^-1
-    gemm(op, s2, s1, s2, mone, D, ld, stride, T1, s1, ws, zero, C, ld, stride, batch);      // C  = -S^-1 T1
-    gemm(op, s1, s1, s2, mone, B, ld, stride, T1, s1, ws, one, A, ld, stride, batch);       // A  = A^-1 - B T1
+    {
+        GemmRun run(op);
+        gemm(op, s1, s2, s1, one, A, ld, stride, B, ld, stride, zero, T2, s2, ws, batch);       // T2 = A^-1 B
+        gemm(op, s1, s2, s2, mone, T2, s2, ws, D, ld, stride, zero, B, ld, stride, batch);      // B  = -T2 S^-1
+        gemm(op, s2, s1, s2, mone, D, ld, stride, T1, s1, ws, zero, C, ld, stride, batch);      // C  = -S^-1 T1
+        gemm(op, s1, s1, s2, mone, B, ld, stride, T1, s1, ws, one, A, ld, stride, batch);       // A  = A^-1 - B T1
+    }
 }
 
 }  // namespace

@@ -137,7 +137,11 @@ struct helm_op {
     helm_timing timing = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<hipEvent_t> ev_pool;
     std::vector<std::pair<int, double>> ev_pending;   // (event-pair index, bytes)
-    std::vector<std::pair<int, double>> ev_pending_gemm;   // (event-pair index, flops) of the direct solver's GEMM launches
+    std::vector<std::pair<int, double>> ev_pending_gemm;   // (event-pair index, flops) of the direct solver's GEMM launches / runs of launches
+    std::vector<int> ev_pending_gemm_n;                    // launches covered by each pair
+    int gemm_run_depth = 0, gemm_run_launches = 0;         // back-to-back GEMM launches timed with ONE event pair (direct.hip)
+    double gemm_run_flops = 0;
+    int gemm_run_pair = -1;
     size_t ev_used = 0;
     int active_hint = -1;        // right-hand sides currently iterating (for the byte count of profiled launches)
 
