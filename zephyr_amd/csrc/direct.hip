@@ -112,7 +112,7 @@ int nd_build_plan(NdPlan &P, int nz, int nx, int leaf, int dof) {
         const long long nmax = g.smax + g.mmax;
         g.foff = lev_f[g.level]; g.voff = lev_v[g.level];
         g.roff = P.total_rows; P.total_rows += (long long)g.cnt * nmax;
-        lev_f[g.level] += (long long)g.cnt * nmax * nmax;
+        lev_f[g.level] += (long long)g.cnt * g.mmax * nmax;
         lev_v[g.level] += (long long)g.cnt * nmax;
         g.finv = fac; fac += (long long)g.cnt * g.smax * g.smax;
         g.g21 = fac; fac += (long long)g.cnt * g.mmax * g.smax;
@@ -130,7 +130,9 @@ int nd_build_plan(NdPlan &P, int nz, int nx, int leaf, int dof) {
             NdDev &n = P.nodes[g.first + j];
             const long long nmax = g.smax + g.mmax;
             n.smax = g.smax; n.mmax = g.mmax;
-            n.foff = g.foff + (long long)j * nmax * nmax;
+            n.foff = g.foff + (long long)j * g.mmax * nmax;
+            n.finv_off = g.finv + (long long)j * g.smax * g.smax;
+            n.f12_off = g.f12 + (long long)j * g.smax * g.mmax;
             n.voff = g.voff + (long long)j * nmax;
             n.roff = g.roff + (long long)j * nmax;
         }
@@ -141,18 +143,27 @@ int nd_build_plan(NdPlan &P, int nz, int nx, int leaf, int dof) {
 // ---- kernels ---------------------------------------------------------------------------------------------------
 namespace {
 
-__global__ __launch_bounds__(256) void k_nd_assemble(const NdDev *nodes, int first, cplx *arenaF, const cplx *planes, int nz, int nx) {
+// The front [[F11, F12], [F21, F22]] is assembled where each block is needed afterwards: F11 and F12 in the factor storage
+// (F11 is inverted in place, F12 is kept as it is), [F21 | F22] in the scratch arena (F21 feeds G21, F22 becomes the Schur
+// complement the parent picks up).  (r, c): padded front coordinates.
+__device__ __forceinline__ cplx *front_entry(const NdDev &n, cplx *arenaF, cplx *fac, int r, int c) {
+    if (r < n.smax) {
+        if (c < n.smax) return fac + n.finv_off + (long long)r * n.smax + c;
+        return fac + n.f12_off + (long long)r * n.mmax + (c - n.smax);
+    }
+    return arenaF + n.foff + (long long)(r - n.smax) * (n.smax + n.mmax) + c;
+}
+
+__global__ __launch_bounds__(256) void k_nd_assemble(const NdDev *nodes, int first, cplx *arenaF, cplx *fac, const cplx *planes, int nz, int nx) {
     const NdDev n = nodes[first + blockIdx.y];
-    cplx *F = arenaF + n.foff;
-    const int ld = n.smax + n.mmax;
     const long long N = (long long)nz * nx;
     const int tot = n.s + n.m;
     for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < n.smax; a += gridDim.x * blockDim.x)
-        if (a >= n.s) F[(long long)a * ld + a] = cmake(1.0, 0.0);     // padded separator slots: identity
+        if (a >= n.s) *front_entry(n, arenaF, fac, a, a) = cmake(1.0, 0.0);     // padded separator slots: identity
     for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < tot; a += gridDim.x * blockDim.x) {
         int z, x, ca;
         nd_cell(n, a, z, x, ca);
-        const long long ra = nd_pos(n, a);
+        const int ra = nd_pos(n, a);
         for (int cb = 0; cb < n.dof; ++cb) {
             // dof 2: row component ca, column component cb -> Eurus block 2 ca + cb (M1 M2 / M3 M4), nine planes each
             const cplx *pl = planes + (long long)(n.dof == 2 ? 2 * ca + cb : 0) * 9 * N;
@@ -162,7 +173,7 @@ __global__ __launch_bounds__(256) void k_nd_assemble(const NdDev *nodes, int fir
                 if (z2 < 0 || z2 >= nz || x2 < 0 || x2 >= nx) continue;
                 const int b = nd_local(n, nz, nx, z2, x2, cb);
                 if (b < 0 || (a >= n.s && b >= n.s)) continue;            // ring x ring entries belong to an ancestor
-                F[ra * ld + nd_pos(n, b)] = pl[(long long)k * N + (long long)z * nx + x];
+                *front_entry(n, arenaF, fac, ra, nd_pos(n, b)) = pl[(long long)k * N + (long long)z * nx + x];
             }
         }
     }
@@ -170,7 +181,7 @@ __global__ __launch_bounds__(256) void k_nd_assemble(const NdDev *nodes, int fir
 
 // parent front += Schur complement of child `slot`; the m x m entries of the child's F22 are spread over gridDim.x blocks
 // (every block rebuilds the child-ring -> parent-row map in LDS, so a block takes `chunk` entries: large enough to amortise that)
-__global__ __launch_bounds__(256) void k_nd_extend_add(const NdDev *nodes, int first, int slot, cplx *arenaF, int nz, int nx, int chunk) {
+__global__ __launch_bounds__(256) void k_nd_extend_add(const NdDev *nodes, int first, int slot, cplx *arenaF, cplx *fac, int nz, int nx, int chunk) {
     extern __shared__ int map[];
     const NdDev p = nodes[first + blockIdx.y];
     if (p.kid[slot] < 0) return;
@@ -183,15 +194,14 @@ __global__ __launch_bounds__(256) void k_nd_extend_add(const NdDev *nodes, int f
         map[a] = nd_pos(p, nd_local(p, nz, nx, z, x, comp));
     }
     __syncthreads();
-    const cplx *Fc = arenaF + c.foff;
-    cplx *Fp = arenaF + p.foff;
-    const int ldc = c.smax + c.mmax, ldp = p.smax + p.mmax;
+    const cplx *Sc = arenaF + c.foff + c.smax;          // child's F22: row a at Sc + a * ldc
+    const int ldc = c.smax + c.mmax;
     for (long long e0 = (long long)blockIdx.x * chunk; e0 < total; e0 += (long long)gridDim.x * chunk) {
         const long long e1 = e0 + chunk < total ? e0 + chunk : total;
         for (long long e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
             const int a = (int)(e / c.m), b2 = (int)(e - (long long)a * c.m);
-            cplx *dst = Fp + (long long)map[a] * ldp + map[b2];
-            *dst = cadd(*dst, Fc[(long long)(c.smax + a) * ldc + c.smax + b2]);
+            cplx *dst = front_entry(p, arenaF, fac, map[a], map[b2]);
+            *dst = cadd(*dst, Sc[(long long)a * ldc + b2]);
         }
     }
 }
@@ -483,14 +493,6 @@ __global__ __launch_bounds__(256) void k_gj_inverse(cplx *A0, int ld, long long 
     for (int e = tid; e < n * n; e += blockDim.x) A[(long long)(e / n) * ld + e % n] = a[e / n][e % n];
 }
 
-__global__ void k_copy2d(const cplx *src, int lds_, long long ss, cplx *dst, int ldd, long long sd, int rows, int cols) {
-    const cplx *s = src + (long long)blockIdx.z * ss;
-    cplx *d = dst + (long long)blockIdx.z * sd;
-    for (int r = blockIdx.y; r < rows; r += gridDim.y)
-        for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x)
-            d[(long long)r * ldd + c] = s[(long long)r * lds_ + c];
-}
-
 // ---- solve-phase data movement -----------------------------------------------------------------------------------
 // out[i][r] = in[r][i]   (in: rows x cols)
 // (the long dimension always rides on gridDim.x: `swap` exchanges the roles of blockIdx.x / blockIdx.y)
@@ -759,12 +761,16 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
     const cplx one = cmake(1, 0), mone = cmake(-1, 0), zero = cmake(0, 0);
     const NdGroup &g = P.groups[gi];
     const int nmax = g.smax + g.mmax;
-    const long long fs = (long long)nmax * nmax;
+    const long long fs = (long long)g.mmax * nmax;              // scratch per front: [F21 | F22]
+    const long long s11 = (long long)g.smax * g.smax, s12 = (long long)g.smax * g.mmax;
     cplx *F = arenaF + g.foff;
-    HIP_TRY(op, hipMemsetAsync(F, 0, (size_t)g.cnt * fs * sizeof(cplx), st));
+    cplx *Finv = f->d_fac + g.finv, *G21 = f->d_fac + g.g21, *F12 = f->d_fac + g.f12;
+    if (fs > 0) HIP_TRY(op, hipMemsetAsync(F, 0, (size_t)g.cnt * fs * sizeof(cplx), st));
+    HIP_TRY(op, hipMemsetAsync(Finv, 0, (size_t)g.cnt * s11 * sizeof(cplx), st));
+    if (s12 > 0) HIP_TRY(op, hipMemsetAsync(F12, 0, (size_t)g.cnt * s12 * sizeof(cplx), st));
     for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
         const int nb = std::min(65535, g.cnt - j0);
-        hipLaunchKernelGGL(k_nd_assemble, dim3((nmax + 255) / 256, nb), dim3(256), 0, st, d_nodes, g.first + j0, arenaF, planes, op->nz, op->nx);
+        hipLaunchKernelGGL(k_nd_assemble, dim3((nmax + 255) / 256, nb), dim3(256), 0, st, d_nodes, g.first + j0, arenaF, f->d_fac, planes, op->nz, op->nx);
     }
     if (!g.leaf) {
         // children's ring sizes are bounded by this group's front size
@@ -776,26 +782,16 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
                 const long long total = (long long)nmax * nmax;
                 const int chunk = (int)std::max<long long>(4096, std::min<long long>(total, std::max<long long>(16LL * nmax, total / std::max(1, 2048 / nb))));
                 const int gx = (int)std::max<long long>(1, std::min<long long>((total + chunk - 1) / chunk, 65535));
-                hipLaunchKernelGGL(k_nd_extend_add, dim3(gx, nb), dim3(256), shm, st, d_nodes, g.first + j0, slot, arenaF, op->nz, op->nx, chunk);
+                hipLaunchKernelGGL(k_nd_extend_add, dim3(gx, nb), dim3(256), shm, st, d_nodes, g.first + j0, slot, arenaF, f->d_fac, op->nz, op->nx, chunk);
             }
     }
     static const int gj_leaf = getenv("HELM_ND_GJ_LEAF") ? atoi(getenv("HELM_ND_GJ_LEAF")) : 0;
     static const int gj_upper = getenv("HELM_ND_GJ_UPPER") ? atoi(getenv("HELM_ND_GJ_UPPER")) : 0;
-    invert(op, F, nmax, fs, g.smax, g.cnt, work, (long long)g.smax * g.smax, P.dof, g.leaf ? gj_leaf : gj_upper);
-    cplx *Finv = f->d_fac + g.finv, *G21 = f->d_fac + g.g21, *F12 = f->d_fac + g.f12;
-    for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
-        const int nb = std::min(65535, g.cnt - j0);
-        hipLaunchKernelGGL(k_copy2d, dim3((g.smax + 63) / 64, std::min(g.smax, 64), nb), dim3(64), 0, st,
-                           F + j0 * fs, nmax, fs, Finv + (long long)j0 * g.smax * g.smax, g.smax, (long long)g.smax * g.smax, g.smax, g.smax);
-        if (g.mmax > 0)
-            hipLaunchKernelGGL(k_copy2d, dim3((g.mmax + 63) / 64, std::min(g.smax, 64), nb), dim3(64), 0, st,
-                               F + j0 * fs + g.smax, nmax, fs, F12 + (long long)j0 * g.smax * g.mmax, g.mmax, (long long)g.smax * g.mmax, g.smax, g.mmax);
-    }
+    invert(op, Finv, g.smax, s11, g.smax, g.cnt, work, s11, P.dof, g.leaf ? gj_leaf : gj_upper);      // F11 -> F11^-1 where it stays
     if (g.mmax > 0) {
         // G21 = F21 F11^-1 ; F22 -= G21 F12
-        gemm(op, g.mmax, g.smax, g.smax, one, F + (long long)g.smax * nmax, nmax, fs, F, nmax, fs, zero, G21, g.smax, (long long)g.mmax * g.smax, g.cnt);
-        gemm(op, g.mmax, g.mmax, g.smax, mone, G21, g.smax, (long long)g.mmax * g.smax, F + g.smax, nmax, fs, one,
-             F + (long long)g.smax * nmax + g.smax, nmax, fs, g.cnt);
+        gemm(op, g.mmax, g.smax, g.smax, one, F, nmax, fs, Finv, g.smax, s11, zero, G21, g.smax, (long long)g.mmax * g.smax, g.cnt);
+        gemm(op, g.mmax, g.mmax, g.smax, mone, G21, g.smax, (long long)g.mmax * g.smax, F12, g.mmax, s12, one, F + g.smax, nmax, fs, g.cnt);
     }
     f->flops += (double)g.cnt * 8.0 * (2.0 * g.smax * g.smax * g.smax + (double)g.smax * g.smax * g.mmax + (double)g.smax * g.mmax * g.mmax);
     return HELM_OK;

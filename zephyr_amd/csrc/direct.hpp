@@ -11,7 +11,8 @@ struct NdDev {                // one front = one node of the elimination tree
     int ntop, nbot, nleft, nright, xlo;   // ring segments clipped to the grid: row z0-1, row z1 (x from xlo), column x0-1, column x1 (z from z0)
     int kid[2];               // children (indices in processing order), -1: none
     int smax, mmax;           // padded sizes of the node's group
-    long long foff;           // front matrix offset in the factorisation arena (elements)
+    long long foff;           // [F21 | F22] (mmax x (smax + mmax)) of the front in the factorisation arena (elements)
+    long long finv_off, f12_off;   // F11 (smax x smax, inverted in place) and F12 (smax x mmax) of the front in the factor storage
     long long voff;           // front vector offset in the solve arena (rows; x nrhs elements)
     long long roff;           // first row of this front in the row table
 };
