@@ -622,9 +622,12 @@ int launch_sys2_apply(helm_op *op, bool raw, int adjoint, const cplx *X, cplx *Y
 // unknowns per cell in the elimination tree, factors kept in slot 1); rows_in = N or 2N rows of right-hand side per source.
 int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long long row_off, cplx premul,
                        const cplx *sub, cplx *dXout, int nrhs, const helm_solve_opts &o, helm_solve_info *info,
-                       int sys2 = 0, long long rows_in = 0) {
+                       int sys2 = 0, long long rows_in = 0, cplx *dUconj = nullptr) {
+    // dUconj (single-block systems, N rows per right-hand side): the result is left there already conjugated -- the last
+    // transpose of a pass writes conj(x), the residual kernel reads it conjugated -- and dXout is not written
     const long long N = op->N;
     const long long NV = sys2 ? 2 * N : N;
+    const int cj = (dUconj && !sys2) ? 1 : 0;
     struct NvScope { helm_op *op; long long old; NvScope(helm_op *o_, long long nv) : op(o_), old(o_->Nv) { o_->Nv = nv; } ~NvScope() { op->Nv = old; } } nvscope(op, NV);
     const int slot = sys2 ? 1 : block;
     int rc;
@@ -695,7 +698,7 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
     for (int first = 0; first < nrhs; first += Bmax) {
         const int n = std::min(Bmax, nrhs - first);
         cplx *q = (cplx *)lease.ptr, *r = q + (long long)Bmax * NV, *nws = q + 2LL * Bmax * NV;
-        cplx *x = dXout + (long long)first * NV;
+        cplx *x = cj ? dUconj + (long long)first * NV : dXout + (long long)first * NV;
         const cplx *rhs_b = dRHS + (long long)first * rhs_ld;
         const cplx *sub_b = sub ? sub + (long long)first * N : nullptr;
         if (sys2) {
@@ -720,13 +723,13 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
         }
         if (factor_pending) {       // factorisation with the forward elimination of this batch following it level by level
             float fms = 0.f;
-            rc = nd_factor_solve(op, block, f, ws_factor, sys2 ? op->d_S : nullptr, xin, x, n, nws, op->side_stream, &fms);
+            rc = nd_factor_solve(op, block, f, ws_factor, sys2 ? op->d_S : nullptr, xin, x, n, nws, op->side_stream, &fms, cj);
             if (rc) return rc;
             op->direct[slot] = f; fresh.p = nullptr;
             op->timing.factor_ms += fms;
             factor_pending = false;
         } else {
-            rc = nd_solve(op, f, xin, x, n, nws);
+            rc = nd_solve(op, f, xin, x, n, nws, cj);
             if (rc) return rc;
         }
         std::vector<double> relres(n, 0.0);
@@ -741,6 +744,7 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
                 ApplyArgs a = ApplyArgs();
                 a.planes = op->d_C + (long long)block * op->nplanes * N; a.X = x; a.Y = r; a.W = q; a.ld = N; a.nrhs = n;
                 a.scaled = 0; a.adjoint = 0; a.epi = EPI_RESID; a.scal = nullptr; a.part = (double *)op->d_part;
+                a.xmode = cj ? 3 : 0;
                 rc = helm_launch_apply(op, a);
                 if (rc) return rc;
                 helm_launch_fin_ex(op, FIN_NORM, n, helm_apply_num_blocks(op), nullptr, d_aux);
@@ -763,7 +767,7 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
             if (sys2) { rc = helm_launch_rowscale_inplace(op, r, op->d_rs, NV, n); if (rc) return rc; }
             rc = nd_solve(op, f, r, r, n, nws);       // dx = A^-1 r
             if (rc) return rc;
-            nd_axpy_one(op, x, r, (long long)n * NV);
+            nd_axpy_one(op, x, r, (long long)n * NV, cj);
             solves += 1;
         }
         for (int b = 0; b < n; ++b) {
@@ -785,11 +789,16 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
 // right-hand side per source; sub unused); dXout then holds 2N values per right-hand side.
 int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long long row_off, cplx premul,
                 const cplx *sub, cplx *dXout, int nrhs, const helm_solve_opts &o, helm_solve_info *info,
-                int sys2 = 0, long long rows_in = 0) {
+                int sys2 = 0, long long rows_in = 0, cplx *dUconj = nullptr, bool *wrote_u = nullptr) {
+    // dUconj / wrote_u: the direct path can leave conj(x) straight in the caller's output (then *wrote_u = true and dXout is
+    // untouched); every other path fills dXout
     const long long N = op->N;
+    if (wrote_u) *wrote_u = false;
     if (o.method == HELM_DIRECT) {
         if (op->ny > 0) HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "the direct solver is 2-D only");
-        return solve_block_direct(op, block, dRHS, rhs_ld, row_off, premul, sub, dXout, nrhs, o, info, sys2, rows_in);
+        const int rcd = solve_block_direct(op, block, dRHS, rhs_ld, row_off, premul, sub, dXout, nrhs, o, info, sys2, rows_in, dUconj);
+        if (rcd >= 0 && wrote_u && dUconj && !sys2) *wrote_u = true;
+        return rcd;
     }
     // AUTO: the sparse direct path wherever it applies (2-D single-block systems that fit), else / on failure the
     // multigrid-preconditioned Krylov path below
@@ -798,8 +807,8 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
         if (!e || atoi(e) != 0) {
             std::vector<helm_solve_info> saved;
             if (info) saved.assign(info, info + nrhs);
-            const int rc = solve_block_direct(op, block, dRHS, rhs_ld, row_off, premul, sub, dXout, nrhs, o, info, sys2, rows_in);
-            if (rc == 0) return 0;
+            const int rc = solve_block_direct(op, block, dRHS, rhs_ld, row_off, premul, sub, dXout, nrhs, o, info, sys2, rows_in, dUconj);
+            if (rc == 0) { if (wrote_u && dUconj && !sys2) *wrote_u = true; return 0; }
             // the coupled system has no better fallback: row-equilibrated CGNR needs 10^4-10^5 iterations and meets the same
             // fp64 floor of the true residual, so right-hand sides that stalled above rtol are reported as such
             if (rc > 0 && sys2) return rc;
@@ -1042,11 +1051,14 @@ extern "C" int helm_solve_device(helm_op *op, const void *dRHS, void *dU, int nr
     } else if (op->variant == HELM_MINIZEPHYR || !stacked) {
         // Eurus with an N-row right-hand side: zero-padded second field => v = 0 and M1 u = q
         // when M3 == 0 (eurus.py:512-533)
-        int rc = solve_block(op, 0, (const cplx *)dRHS, rows, 0, premul, nullptr, dX, nrhs, o, info);
+        bool wrote_u = false;        // rows == N here: the direct path writes conj(x) into dU itself
+        int rc = solve_block(op, 0, (const cplx *)dRHS, rows, 0, premul, nullptr, dX, nrhs, o, info, 0, 0, (cplx *)dU, &wrote_u);
         if (rc < 0) { cleanup(); return rc; }
         result = rc;
-        rc = helm_launch_finish(op, dX, (cplx *)dU, rows, nrhs, 0);
-        if (rc) { cleanup(); return rc; }
+        if (!wrote_u) {
+            rc = helm_launch_finish(op, dX, (cplx *)dU, rows, nrhs, 0);
+            if (rc) { cleanup(); return rc; }
+        }
     } else {
         // block-triangular: v = M4^-1 q2 ; u = M1^-1 (q1 - M2 v)
         cplx *dV = nullptr, *dT = nullptr;

@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void k_gj_inverse(cplx *A0, int ld, long long 
 // ---- solve-phase data movement -----------------------------------------------------------------------------------
 // out[i][r] = in[r][i]   (in: rows x cols)
 // (the long dimension always rides on gridDim.x: `swap` exchanges the roles of blockIdx.x / blockIdx.y)
-__global__ __launch_bounds__(256) void k_transpose(const cplx *in, long long rows, long long cols, cplx *out, int swap) {
+__global__ __launch_bounds__(256) void k_transpose(const cplx *in, long long rows, long long cols, cplx *out, int swap, int conj = 0) {
     __shared__ cplx t[32][33];
     const long long c0 = (long long)(swap ? blockIdx.y : blockIdx.x) * 32, r0 = (long long)(swap ? blockIdx.x : blockIdx.y) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256) void k_transpose(const cplx *in, long long row
         if (r0 + j < rows && c0 + tx < cols) t[j][tx] = in[(r0 + j) * cols + c0 + tx];
     __syncthreads();
     for (int j = ty; j < 32; j += 8)
-        if (c0 + j < cols && r0 + tx < rows) out[(c0 + j) * rows + r0 + tx] = t[tx][j];
+        if (c0 + j < cols && r0 + tx < rows) out[(c0 + j) * rows + r0 + tx] = conj ? cconj(t[tx][j]) : t[tx][j];
 }
 
 // row table (see NdPlanDev): one thread per padded row of the group's fronts
@@ -573,9 +573,10 @@ __global__ __launch_bounds__(256) void k_nd_bwd_store(const int4 *tab, const cpl
     }
 }
 
-// y += x  (refinement update), n elements
-__global__ void k_axpy_one(cplx *y, const cplx *x, long long n) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] = cadd(y[i], x[i]);
+// y += x, or y += conj(x) when y holds the conjugated wavefield  (refinement update), n elements
+__global__ void k_axpy_one(cplx *y, const cplx *x, long long n, int conj) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        y[i] = cadd(y[i], conj ? cconj(x[i]) : x[i]);
 }
 
 // op may be null (diagnostic entry points): default stream, no profiling
@@ -906,7 +907,7 @@ int nd_factor(helm_op *op, int block, NdFactor *f, cplx *ws, const cplx *planes_
 // ws: workspace of nd_solve_ws_elems(plan, nrhs) elements
 long long nd_solve_ws_elems(const NdPlan &P, int nrhs) { return ((long long)P.dof * P.nz * P.nx + 2 * P.vregion) * nrhs; }
 
-int nd_solve(helm_op *op, NdFactor *f, const cplx *Xin, cplx *Xout, int nrhs, cplx *ws) {
+int nd_solve(helm_op *op, NdFactor *f, const cplx *Xin, cplx *Xout, int nrhs, cplx *ws, int conj_out) {
     const NdPlan &P = f->pd->plan;
     hipStream_t st = op->stream;
     const long long N = (long long)P.dof * P.nz * P.nx;          // unknowns per right-hand side
@@ -914,7 +915,7 @@ int nd_solve(helm_op *op, NdFactor *f, const cplx *Xin, cplx *Xout, int nrhs, cp
     hipLaunchKernelGGL(k_transpose, dim3((unsigned)((N + 31) / 32), (nrhs + 31) / 32), dim3(256), 0, st, Xin, (long long)nrhs, N, c.Xt, 0);
     for (size_t gi = 0; gi < P.groups.size(); ++gi) forward_group(op, f, gi, c);       // leaves to root
     for (size_t gk = P.groups.size(); gk-- > 0;) backward_group(op, f, gk, c);          // root to leaves
-    hipLaunchKernelGGL(k_transpose, dim3((unsigned)((N + 31) / 32), (nrhs + 31) / 32), dim3(256), 0, st, c.Xt, N, (long long)nrhs, Xout, 1);
+    hipLaunchKernelGGL(k_transpose, dim3((unsigned)((N + 31) / 32), (nrhs + 31) / 32), dim3(256), 0, st, c.Xt, N, (long long)nrhs, Xout, 1, conj_out);
     return check_kernels(op, "solve kernels");
 }
 
@@ -923,7 +924,7 @@ int nd_solve(helm_op *op, NdFactor *f, const cplx *Xin, cplx *Xout, int nrhs, cp
 // of small latency-bound launches; the forward pass of the lower levels (big batched GEMMs) runs underneath it.
 // ws_factor / ws_solve as for nd_factor / nd_solve (disjoint); *factor_ms: time until the last front is factored.
 int nd_factor_solve(helm_op *op, int block, NdFactor *f, cplx *ws_factor, const cplx *planes_in, const cplx *Xin, cplx *Xout, int nrhs,
-                    cplx *ws_solve, hipStream_t side, float *factor_ms) {
+                    cplx *ws_solve, hipStream_t side, float *factor_ms, int conj_out) {
     const NdPlan &P = f->pd->plan;
     hipStream_t main = op->stream;
     const long long N = (long long)P.dof * P.nz * P.nx;
@@ -954,7 +955,7 @@ int nd_factor_solve(helm_op *op, int block, NdFactor *f, cplx *ws_factor, const 
     hipStreamWaitEvent(main, ev[ng + 1], 0);
     if (!rc) {
         for (size_t gk = ng; gk-- > 0;) backward_group(op, f, gk, c);
-        hipLaunchKernelGGL(k_transpose, dim3((unsigned)((N + 31) / 32), (nrhs + 31) / 32), dim3(256), 0, main, c.Xt, N, (long long)nrhs, Xout, 1);
+        hipLaunchKernelGGL(k_transpose, dim3((unsigned)((N + 31) / 32), (nrhs + 31) / 32), dim3(256), 0, main, c.Xt, N, (long long)nrhs, Xout, 1, conj_out);
     }
     hipError_t e = hipStreamSynchronize(main);
     if (factor_ms) { float ms = 0.f; if (hipEventElapsedTime(&ms, t0, t1) == hipSuccess) *factor_ms = ms; }
@@ -965,8 +966,8 @@ int nd_factor_solve(helm_op *op, int block, NdFactor *f, cplx *ws_factor, const 
     return check_kernels(op, "factor + solve kernels");
 }
 
-int nd_axpy_one(helm_op *op, cplx *y, const cplx *x, long long n) {
-    hipLaunchKernelGGL(k_axpy_one, dim3((unsigned)std::min<long long>((n + 255) / 256, 65535)), dim3(256), 0, op->stream, y, x, n);
+int nd_axpy_one(helm_op *op, cplx *y, const cplx *x, long long n, int conj) {
+    hipLaunchKernelGGL(k_axpy_one, dim3((unsigned)std::min<long long>((n + 255) / 256, 65535)), dim3(256), 0, op->stream, y, x, n, conj);
     return HELM_OK;
 }
 

@@ -100,7 +100,7 @@ int nd_get_plan(helm_op *op, int leaf, int dof, std::shared_ptr<NdPlanDev> *out)
 int nd_factor(helm_op *op, int block, NdFactor *f, cplx *ws, const cplx *planes = nullptr);    // f->pd must be set; dof 2: block ignored, all four Eurus blocks
 void nd_free(NdFactor *f);
 long long nd_solve_ws_elems(const NdPlan &P, int nrhs);
-int nd_solve(helm_op *op, NdFactor *f, const cplx *Xin, cplx *Xout, int nrhs, cplx *ws);
+int nd_solve(helm_op *op, NdFactor *f, const cplx *Xin, cplx *Xout, int nrhs, cplx *ws, int conj_out = 0);   // conj_out: Xout = conj(x)
 int nd_factor_solve(helm_op *op, int block, NdFactor *f, cplx *ws_factor, const cplx *planes, const cplx *Xin, cplx *Xout, int nrhs,
-                    cplx *ws_solve, hipStream_t side, float *factor_ms);
-int nd_axpy_one(helm_op *op, cplx *y, const cplx *x, long long n);
+                    cplx *ws_solve, hipStream_t side, float *factor_ms, int conj_out = 0);
+int nd_axpy_one(helm_op *op, cplx *y, const cplx *x, long long n, int conj = 0);

@@ -83,6 +83,7 @@ constexpr int TX = 64;
 //   0  X is read                                                       (everything else)
 //   1  X = omega_j * dinv (.) W, also stored to U        [multigrid: first Jacobi sweep fused into the residual]
 //   2  X = X + P E (bilinear prolongation of E)          [multigrid: coarse correction fused into the post-smoothing sweep]
+//   3  X is read conjugated                               [direct path: residual of a wavefield already stored as conj(x)]
 template <class V, int P, bool SCALED, bool ADJ, int EPI, int XMODE = 0>
 __global__ __launch_bounds__(256) void k_stencil_t(StencilParamsT<V> q) {
     constexpr int TZ = 4 * P;
@@ -148,6 +149,8 @@ __global__ __launch_bounds__(256) void k_stencil_t(StencilParamsT<V> q) {
                 if (oj && J + 1 < q.nxc) { const V c3 = e[(long long)(I + 1) * q.nxc + J + 1]; a.x += 0.25 * c3.x; a.y += 0.25 * c3.y; }
             }
             return cadd(v, a);
+        } else if (XMODE == 3) {
+            return cconj(q.X[(long long)b * q.ld + idx]);
         } else {
             return q.X[(long long)b * q.ld + idx];
         }
@@ -769,6 +772,8 @@ int helm_launch_apply(helm_op *op, const ApplyArgs &a) {
         hipLaunchKernelGGL((k_stencil_t<cplx, STENCIL_P, false, false, EPI_RESID, 1>), grid, dim3(256), 0, op->stream, q);
     } else if (a.xmode == 2 && a.epi == EPI_JACOBI && !a.scaled && !a.adjoint) {
         hipLaunchKernelGGL((k_stencil_t<cplx, STENCIL_P, false, false, EPI_JACOBI, 2>), grid, dim3(256), 0, op->stream, q);
+    } else if (a.xmode == 3 && a.epi == EPI_RESID && !a.scaled && !a.adjoint) {
+        hipLaunchKernelGGL((k_stencil_t<cplx, STENCIL_P, false, false, EPI_RESID, 3>), grid, dim3(256), 0, op->stream, q);
     } else if (a.xmode != 0) {
         HELM_FAIL(op, HELM_ERR_ARG, "unsupported fused stencil mode");
     } else if (a.scaled) {
