@@ -733,6 +733,7 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
             if (rc) return rc;
         }
         std::vector<double> relres(n, 0.0);
+        std::vector<int> extra_solves(n, 0);
         int solves = 1;
         double prev_worst = 0.0;
         for (int round = 0; ; ++round) {
@@ -764,10 +765,26 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
             const bool stalled = round > 0 && !(worst < 0.5 * prev_worst);
             prev_worst = worst;
             if (all_ok || round >= max_refine || stalled) break;
-            if (sys2) { rc = helm_launch_rowscale_inplace(op, r, op->d_rs, NV, n); if (rc) return rc; }
-            rc = nd_solve(op, f, r, r, n, nws);       // dx = A^-1 r
-            if (rc) return rc;
-            nd_axpy_one(op, x, r, (long long)n * NV, cj);
+            // refine only the right-hand sides that missed rtol when they are a minority: their residual columns are packed to
+            // the front of r (whole 16 MB rows), solved as a narrower batch and added back
+            std::vector<int> bad;
+            for (int b = 0; b < n; ++b) if (!(relres[b] <= o.rtol)) bad.push_back(b);
+            const int k = (int)bad.size();
+            if (k < n / 2) {
+                for (int j = 0; j < k; ++j)
+                    if (bad[j] != j) HIP_TRY(op, hipMemcpyAsync(r + (long long)j * NV, r + (long long)bad[j] * NV, (size_t)NV * sizeof(cplx), hipMemcpyDeviceToDevice, op->stream));
+                if (sys2) { rc = helm_launch_rowscale_inplace(op, r, op->d_rs, NV, k); if (rc) return rc; }
+                rc = nd_solve(op, f, r, r, k, nws);
+                if (rc) return rc;
+                for (int j = 0; j < k; ++j) nd_axpy_one(op, x + (long long)bad[j] * NV, r + (long long)j * NV, NV, cj);
+                for (int j = 0; j < k; ++j) extra_solves[bad[j]] += 1;
+            } else {
+                if (sys2) { rc = helm_launch_rowscale_inplace(op, r, op->d_rs, NV, n); if (rc) return rc; }
+                rc = nd_solve(op, f, r, r, n, nws);       // dx = A^-1 r
+                if (rc) return rc;
+                nd_axpy_one(op, x, r, (long long)n * NV, cj);
+                for (int b = 0; b < n; ++b) extra_solves[b] += 1;
+            }
             solves += 1;
         }
         for (int b = 0; b < n; ++b) {
@@ -775,7 +792,7 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
             if (!ok) unconverged += 1;
             if (info) {
                 helm_solve_info &I = info[first + b];
-                I.iterations += solves; I.method = HELM_DIRECT;
+                I.iterations += 1 + extra_solves[b]; I.method = HELM_DIRECT;
                 I.relres = std::max(I.relres, relres[b]);
                 I.status = std::max(I.status, ok ? 0 : 1);
             }
