@@ -734,7 +734,6 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
         }
         std::vector<double> relres(n, 0.0);
         std::vector<int> extra_solves(n, 0);
-        int solves = 1;
         double prev_worst = 0.0;
         for (int round = 0; ; ++round) {
             if (sys2) {
@@ -785,7 +784,6 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
                 nd_axpy_one(op, x, r, (long long)n * NV, cj);
                 for (int b = 0; b < n; ++b) extra_solves[b] += 1;
             }
-            solves += 1;
         }
         for (int b = 0; b < n; ++b) {
             const bool ok = relres[b] <= o.rtol * 1.0000001;
