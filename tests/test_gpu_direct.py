@@ -288,3 +288,19 @@ def test_direct_randomised_coupled_tti(helm_lib, seed):
     u = op * q
     assert nrm(u, ho.DirectOperator(C4, eurus=True) * q) <= 1e-6, (seed, op.lastInfo)
     assert all(i['method'] == 4 and i['status'] == 0 for i in op.lastInfo), op.lastInfo
+
+
+def test_direct_many_right_hand_sides_in_batches(helm_lib):
+    'more right-hand sides than one batch holds: 300 sources with batch=128 go through three passes of the same factors'
+    import zephyr_amd as za
+    nz, nx = 48, 40
+    rng = np.random.default_rng(8)
+    c = 2000. + 1500. * rng.random((nz, nx))
+    cfg = dict(nx=nx, nz=nz, dx=10., dz=10., c=c, freq=9., nPML=6, method='direct', rtol=1e-11, batch=128)
+    q = rng.standard_normal((nz * nx, 300)) + 1j * rng.standard_normal((nz * nx, 300))
+    op = za.MiniZephyr(cfg)
+    u = op * q
+    ref = ho.DirectOperator(ho.minizephyr_coefficients(nz, nx, c, ho.gardner_rho(c.astype(complex)), 9., dx=10., dz=10., nPML=6)) * q
+    assert nrm(u, ref) <= 1e-9
+    assert len(op.lastInfo) == 300 and all(i['status'] == 0 for i in op.lastInfo)
+    assert op.lastTiming()['factor_ms'] > 0            # one factorisation for all three batches
