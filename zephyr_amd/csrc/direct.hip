@@ -595,13 +595,20 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
     if (in_run && e0) { op->gemm_run_pair = (int)op->ev_used; op->ev_used += 2; }
     static const int use_mfma = getenv("HELM_ND_MFMA") ? atoi(getenv("HELM_ND_MFMA")) : 0;
     static const int fixed_tm = getenv("HELM_ND_TM") ? atoi(getenv("HELM_ND_TM")) : 0;
-    int vbest = 64; long long varea = -1;
-    for (int tm = 64; tm >= 16; tm >>= 1) {
-        const int tn = 4096 / tm;
-        const long long area = (long long)((M + tm - 1) / tm) * tm * ((Nn + tn - 1) / tn) * tn;
-        if (varea < 0 || area < varea) { vbest = tm; varea = area; }
+    // tile of the vector kernel: 4 x RN outputs per thread, TM x TN = TM x (1024 / TM * RN).  The padded area is weighed by how
+    // well a register block re-uses its LDS reads (4 x 4: 1, 4 x 2: 0.7, 4 x 1: 0.45): narrow tiles only win on small outputs
+    // (the 32 x 32 blocks at the bottom of the inversion recursion, 17- and 35-wide separators of the middle tree levels)
+    static const int vc_tm[8] = {64, 32, 16, 64, 32, 16, 32, 16}, vc_rn[8] = {4, 4, 4, 2, 2, 2, 1, 1};
+    static const double w2 = getenv("HELM_ND_EFF2") ? atof(getenv("HELM_ND_EFF2")) : 0.7, w1 = getenv("HELM_ND_EFF1") ? atof(getenv("HELM_ND_EFF1")) : 0.45;
+    static const double vc_eff[8] = {1.0, 1.0, 1.0, w2, w2, w2, w1, w1};
+    static const int narrow = getenv("HELM_ND_NARROW") ? atoi(getenv("HELM_ND_NARROW")) : 1;
+    int vsel = 0; double vcost = -1;
+    for (int c = 0; c < (narrow ? 8 : 3); ++c) {
+        const int tm = vc_tm[c], tn = 1024 / tm * vc_rn[c];
+        const double cost = (double)((M + tm - 1) / tm) * tm * ((Nn + tn - 1) / tn) * tn / vc_eff[c];
+        if (vcost < 0 || cost < vcost * 0.999) { vsel = c; vcost = cost; }
     }
-    if (fixed_tm == 64 || fixed_tm == 32 || fixed_tm == 16) vbest = fixed_tm;
+    if (fixed_tm == 64) vsel = 0; else if (fixed_tm == 32) vsel = 1; else if (fixed_tm == 16) vsel = 2;
     // tile shapes of the MFMA kernel: pick the one that pads M x N the least (ties: the larger tile)
     static const int cfg_tm[4] = {64, 48, 32, 16}, cfg_tn[4] = {64, 128, 128, 256};
     int best = 0; long long best_area = -1;
@@ -626,9 +633,18 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
             continue;
         }
         // (a 4 x 8 register block per thread -- RN = 8, 64 x 128 tile -- was measured too: 230 VGPRs, occupancy 2, 38 % slower)
-        if (vbest == 64) launch_vec<64>(st, rows != nullptr, nb, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R);
-        else if (vbest == 32) launch_vec<32>(st, rows != nullptr, nb, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R);
-        else launch_vec<16>(st, rows != nullptr, nb, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R);
+#define ZG_VEC(TM_, RN_) launch_vec<TM_, RN_>(st, rows != nullptr, nb, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R)
+        switch (vsel) {
+            case 0: ZG_VEC(64, 4); break;
+            case 1: ZG_VEC(32, 4); break;
+            case 2: ZG_VEC(16, 4); break;
+            case 3: ZG_VEC(64, 2); break;
+            case 4: ZG_VEC(32, 2); break;
+            case 5: ZG_VEC(16, 2); break;
+            case 6: ZG_VEC(32, 1); break;
+            default: ZG_VEC(16, 1); break;
+        }
+#undef ZG_VEC
     }
     const double flops = 8.0 * M * (double)Nn * K * batch;
     if (in_run) {                       // the run's end event is recorded by GemmRun's destructor
