@@ -443,8 +443,8 @@ void launch_mfma(hipStream_t st, dim3 grid, bool idx, int M, int Nn, int K, cplx
 // (bottom of the recursive block inversion: 32 by default; 64 (HELM_ND_GJ=64) halves the number of small GEMM launches
 // and gains a digit of accuracy, but its 64-step elimination is slower overall: 41.8 vs 35.9 ms per factorisation at 1024^2)
 #define GJ_MAX 64
-template <int NMAX>
-__global__ __launch_bounds__(256) void k_gj_inverse(cplx *A0, int ld, long long stride, int n) {
+template <int NMAX, int NT = 256>
+__global__ __launch_bounds__(NT) void k_gj_inverse(cplx *A0, int ld, long long stride, int n) {
     __shared__ cplx a[NMAX][NMAX + 1];
     __shared__ cplx fcol[NMAX];
     __shared__ int piv[NMAX];
@@ -686,7 +686,8 @@ void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cp
             const int nb = std::min(1 << 20, batch - b0);
             // (one wave per matrix -- 64 threads, free barriers, four times the matrices in flight -- was measured: 20 % slower factorisation)
             static const int gj_threads = getenv("HELM_ND_GJ_THREADS") ? atoi(getenv("HELM_ND_GJ_THREADS")) : 256;
-            if (n <= 32) hipLaunchKernelGGL(k_gj_inverse<32>, dim3(nb), dim3(gj_threads), 0, st, M + b0 * stride, ld, stride, n);
+            if (n <= 32 && gj_threads == 1024) hipLaunchKernelGGL((k_gj_inverse<32, 1024>), dim3(nb), dim3(1024), 0, st, M + b0 * stride, ld, stride, n);
+            else if (n <= 32) hipLaunchKernelGGL(k_gj_inverse<32>, dim3(nb), dim3(gj_threads), 0, st, M + b0 * stride, ld, stride, n);
             else hipLaunchKernelGGL(k_gj_inverse<64>, dim3(nb), dim3(256), 0, st, M + b0 * stride, ld, stride, n);
         }
         return;
@@ -804,7 +805,10 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
     }
     static const int gj_leaf = getenv("HELM_ND_GJ_LEAF") ? atoi(getenv("HELM_ND_GJ_LEAF")) : 0;
     static const int gj_upper = getenv("HELM_ND_GJ_UPPER") ? atoi(getenv("HELM_ND_GJ_UPPER")) : 0;
-    invert(op, Finv, g.smax, s11, g.smax, g.cnt, work, s11, P.dof, g.leaf ? gj_leaf : gj_upper);      // F11 -> F11^-1 where it stays
+    // the few huge fronts at the top of the tree are one long chain of single-matrix launches: the wider base block halves it
+    static const int gj_top = getenv("HELM_ND_GJ_TOP") ? atoi(getenv("HELM_ND_GJ_TOP")) : 0;
+    const int base = g.leaf ? gj_leaf : (g.cnt <= gj_top ? 64 : gj_upper);
+    invert(op, Finv, g.smax, s11, g.smax, g.cnt, work, s11, P.dof, base);      // F11 -> F11^-1 where it stays
     if (g.mmax > 0) {
         // G21 = F21 F11^-1 ; F22 -= G21 F12
         gemm(op, g.mmax, g.smax, g.smax, one, F, nmax, fs, Finv, g.smax, s11, zero, G21, g.smax, (long long)g.mmax * g.smax, g.cnt);
