@@ -34,7 +34,7 @@ text = '''## Default path
 
 | file | what |
 |---|---|
-| `r01_bench_n1.json` | `python bench.py --cpu-pool`: **%.0f wavefields/s**, %.1f ms per 256-source work item (device: %.1f ms in the solve call, of which %.1f ms factorisation); `roofline` = all `k_zgemm` launches of the timed items, HIP events on the solver stream: %.1f TFLOP/s = **%.0f %% of the 78.6 TFLOP/s fp64 peak** (%d launches, avg %.1f us); `stencil_roofline` = the residual launches of the stencil kernel (%.0f GB/s) + the SURVEY 8(d) apply microbenchmark; CPU baselines on the same box: 1 core %.2f wavefields/s, 16 processes (one per frequency, the reference's pool mode) %.1f wavefields/s |
+| `r01_bench_n1.json` | `python bench.py`: **%.0f wavefields/s**, %.1f ms per 256-source work item (device: %.1f ms in the solve call, of which %.1f ms factorisation); `roofline` = all `k_zgemm` launches of the timed items, HIP events on the solver stream: %.1f TFLOP/s = **%.0f %% of the 78.6 TFLOP/s fp64 peak** (%d launches, avg %.1f us); `stencil_roofline` = the residual launches of the stencil kernel (%.0f GB/s) + the SURVEY 8(d) apply microbenchmark; CPU baselines on the same box: 1 core %.2f wavefields/s, 16 processes (one per frequency, the reference's pool mode) %.1f wavefields/s |
 | `r01_bench_n1_rocprofv3_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu` (summary only) |
 | `r01_bench_n1_under_rocprofv3.json` | the bench line printed by that profiled run (%.0f wavefields/s) |
 | `r01_pmc_traffic_direct.json` | `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (two separate passes) of `python3 bench.py --steps 1 --warmup 0 --no-cpu`, reduced over all `k_zgemm` dispatches by `tools/pmc_reduce.py` (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): %.0f MB of HBM traffic per launch |
