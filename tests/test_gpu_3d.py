@@ -60,3 +60,30 @@ def test_3d_analytic_green_function(helm_lib):
     m = (r > 3 * dx) & (iz > 12) & (iz < n - 13) & (iy > 12) & (iy < n - 13) & (ix > 12) & (ix < n - 13)
     g = h3.green3d(2 * np.pi * f / c0, r[m], 1.0, dx ** 3)
     assert np.linalg.norm(u[m] - g) / np.linalg.norm(g) < 5e-2
+
+
+def test_3d_multigrid_preconditioner(helm_lib):
+    """method='mg' on the 3-D operator (mg3d.hip): same wavefield as the sparse LU, far fewer iterations than Jacobi-BiCGSTAB"""
+    import zephyr_amd as za
+    from oracle import helm3d_oracle as h3
+    import scipy.sparse.linalg as spla
+    nz, ny, nx = 30, 26, 28          # (the sparse LU of a 3-D grid is the slow part of this test)
+    rng = np.random.default_rng(3)
+    c = 1900. + 400. * rng.random((nz, ny, nx))
+    rho = 1000. + 100. * rng.random((nz, ny, nx))
+    cfg = dict(nx=nx, ny=ny, nz=nz, dx=10., c=c, rho=rho, freq=6., nPML=6, rtol=1e-9, maxit=20000)
+    N = nz * ny * nx
+    q = np.zeros((N, 2), complex)
+    q[(15 * ny + 12) * nx + 14, 0] = 1.0
+    q[(9 * ny + 18) * nx + 20, 1] = 1.0 - 0.5j
+    A = h3.coefficients_to_csr3(h3.helm3d_coefficients(nz, ny, nx, c, rho, 6., dx=10., nPML=6)).tocsc()
+    ref = np.conj(spla.splu(A).solve(q))
+    op_j = za.Helm3D(dict(cfg, method='bicgstab'))
+    uj = op_j * q
+    op_m = za.Helm3D(dict(cfg, method='mg'))
+    um = op_m * q
+    assert np.linalg.norm(um - ref) / np.linalg.norm(ref) <= 1e-6, op_m.lastInfo
+    its_j = max(i['iterations'] for i in op_j.lastInfo); its_m = max(i['iterations'] for i in op_m.lastInfo)
+    assert all(i['status'] == 0 and i['method'] == 3 for i in op_m.lastInfo)
+    assert its_m * 2 < its_j, (its_m, its_j)
+    print('3-D iterations: multigrid %d, Jacobi %d' % (its_m, its_j))

@@ -143,7 +143,7 @@ extern "C" void helm_destroy(helm_op *op) {
         helm_pool_free(op->device, op->d_dinv, (size_t)op->nblocks * (size_t)op->N * sizeof(cplx));
     }
     hipFree(op->d_S); hipFree(op->d_rs);
-    if (op->mg) mg_destroy(op);
+    if (op->mg || op->mg3) mg_destroy(op);
     for (int b = 0; b < 4; ++b) { nd_free(op->direct[b]); op->direct[b] = nullptr; }
     hipFree(op->d_ws); hipFree(op->d_part); hipFree(op->d_scal);
     if (op->h_scal) hipHostFree(op->h_scal);
@@ -256,7 +256,7 @@ extern "C" int helm_assemble(helm_op *op, double freq_re, double freq_im, double
     HIP_TRY(op, hipStreamSynchronize(op->stream));
     op->assembled = true;
     op->a_freq_re = freq_re; op->a_freq_im = freq_im; op->a_tau = tau; op->a_ky = ky; op->a_cpml = cPML;
-    if (op->mg) mg_destroy(op);      // preconditioner belongs to the previous frequency
+    if (op->mg || op->mg3) mg_destroy(op);      // preconditioner belongs to the previous frequency
     for (int b = 0; b < 4; ++b) { nd_free(op->direct[b]); op->direct[b] = nullptr; }   // and so do the direct factors
     op->direct_failed = false;
     return HELM_OK;
@@ -848,8 +848,9 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
     if (rc) return rc;
     // preconditioner choice: multigrid for the main block when asked for (or AUTO on Eurus, where it is validated)
     bool use_mg = false;
-    if (op->ny > 0 && o.method == HELM_MG) HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "the multigrid preconditioner is 2-D only");
-    if (!sys2 && op->ny == 0 && block == 0 && (o.method == HELM_MG || (o.method == HELM_AUTO && std::min(op->nz, op->nx) >= 32))) {
+    static const int auto_mg3 = getenv("HELM_AUTO_MG3") ? atoi(getenv("HELM_AUTO_MG3")) : 0;
+    const bool mg3_ok = op->ny > 0 && (o.method == HELM_MG || (o.method == HELM_AUTO && auto_mg3 && std::min(op->nz, std::min(op->ny, op->nx)) >= 24));
+    if (!sys2 && block == 0 && (mg3_ok || (op->ny == 0 && (o.method == HELM_MG || (o.method == HELM_AUTO && std::min(op->nz, op->nx) >= 32))))) {
         rc = mg_setup(op, Bmax);
         if (rc == HELM_OK) use_mg = true;
         else if (o.method == HELM_MG) return rc;

@@ -986,6 +986,16 @@ int nd_factor_solve(helm_op *op, int block, NdFactor *f, cplx *ws_factor, const 
     return check_kernels(op, "factor + solve kernels");
 }
 
+// dense helpers for other translation units (3-D multigrid: coarsest-level inverse and its application)
+int nd_dense_gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, const cplx *B, int ldb, cplx beta, cplx *C, int ldc) {
+    gemm(op, M, Nn, K, alpha, A, lda, 0, B, ldb, 0, beta, C, ldc, 0, 1);
+    return check_kernels(op, "dense GEMM");
+}
+int nd_dense_inverse(helm_op *op, cplx *M, int n, cplx *W) {
+    invert(op, M, n, (long long)n * n, n, 1, W, (long long)n * n);
+    return check_kernels(op, "dense inverse");
+}
+
 int nd_axpy_one(helm_op *op, cplx *y, const cplx *x, long long n, int conj) {
     hipLaunchKernelGGL(k_axpy_one, dim3((unsigned)std::min<long long>((n + 255) / 256, 65535)), dim3(256), 0, op->stream, y, x, n, conj);
     return HELM_OK;

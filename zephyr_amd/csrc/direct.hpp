@@ -104,3 +104,7 @@ int nd_solve(helm_op *op, NdFactor *f, const cplx *Xin, cplx *Xout, int nrhs, cp
 int nd_factor_solve(helm_op *op, int block, NdFactor *f, cplx *ws_factor, const cplx *planes, const cplx *Xin, cplx *Xout, int nrhs,
                     cplx *ws_solve, hipStream_t side, float *factor_ms, int conj_out = 0);
 int nd_axpy_one(helm_op *op, cplx *y, const cplx *x, long long n, int conj = 0);
+
+// dense kernels for other translation units (row-major, single matrices)
+int nd_dense_gemm(helm_op *op, int M, int N, int K, cplx alpha, const cplx *A, int lda, const cplx *B, int ldb, cplx beta, cplx *C, int ldc);
+int nd_dense_inverse(helm_op *op, cplx *M, int n, cplx *W);     // in place; W: n*n elements of scratch

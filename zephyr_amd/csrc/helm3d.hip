@@ -72,6 +72,8 @@ struct Stencil3Params {
     int nz, ny, nx, nrhs, ntx, nty, nblk;
     const RhsScal *scal;
     double *part;
+    const cplx *dinv;        // EPI_JACOBI: 1 / diagonal
+    double omega_j;
 };
 
 __device__ inline double wave_sum3(double v) {
@@ -173,9 +175,11 @@ __global__ __launch_bounds__(256) void k_stencil3(Stencil3Params q) {
             else if (EPI == EPI_DOT_W) { const cplx w = q.W[g]; dsum[0] += w.x * y.x + w.y * y.y; dsum[1] += w.x * y.y - w.y * y.x; }
             else if (EPI == EPI_DOT_XY) { dsum[0] += y.x * xc.x + y.y * xc.y; dsum[1] += y.x * xc.y - y.y * xc.x; dsum[2] += cabs2(y); }
             else if (EPI == EPI_DOT_YY) { dsum[0] += cabs2(y); }
+            else if (EPI == EPI_DOT_WY) { const cplx w = q.W[g]; dsum[0] += y.x * w.x + y.y * w.y; dsum[1] += y.x * w.y - y.y * w.x; dsum[2] += cabs2(y); }
+            else if (EPI == EPI_JACOBI) { const cplx res = csub(q.W[g], y); y = xc; cfma(y, cscale(q.dinv[idx], q.omega_j), res); }
             q.Y[g] = y;
         }
-        if (EPI != EPI_NONE) {
+        if (EPI != EPI_NONE && EPI != EPI_JACOBI) {
             const int wave = tid >> 6;
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) dsum[qq] = wave_sum3(dsum[qq]);
@@ -255,18 +259,19 @@ static void launch3_epi(hipStream_t st, dim3 grid, const Stencil3Params &q, int 
     case EPI_DOT_XY: hipLaunchKernelGGL((k_stencil3<SCALED, EPI_DOT_XY>), grid, dim3(256), 0, st, q); break;
     case EPI_DOT_YY: hipLaunchKernelGGL((k_stencil3<SCALED, EPI_DOT_YY>), grid, dim3(256), 0, st, q); break;
     case EPI_RESID: hipLaunchKernelGGL((k_stencil3<SCALED, EPI_RESID>), grid, dim3(256), 0, st, q); break;
+    case EPI_DOT_WY: hipLaunchKernelGGL((k_stencil3<SCALED, EPI_DOT_WY>), grid, dim3(256), 0, st, q); break;
+    case EPI_JACOBI: hipLaunchKernelGGL((k_stencil3<SCALED, EPI_JACOBI>), grid, dim3(256), 0, st, q); break;
     default: break;
     }
 }
 
 int helm3d_launch_apply(helm_op *op, const ApplyArgs &a, hipEvent_t e0, hipEvent_t e1) {
     if (a.adjoint) HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "adjoint apply is not available for the 3-D operator");
-    if (a.epi == EPI_JACOBI || a.epi == EPI_DOT_WY) HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "epilogue not available for the 3-D operator");
     Stencil3Params q;
     q.planes = a.planes; q.X = a.X; q.Y = a.Y; q.W = a.W; q.ld = a.ld; q.N = op->N;
     q.nz = op->nz; q.ny = op->ny; q.nx = op->nx; q.nrhs = a.nrhs;
     q.ntx = (op->nx + T3X - 1) / T3X; q.nty = (op->ny + T3Y - 1) / T3Y; q.nblk = q.ntx * q.nty * op->nz;
-    q.scal = a.scal; q.part = a.part;
+    q.scal = a.scal; q.part = a.part; q.dinv = a.dinv; q.omega_j = a.omega_j;
     int split = 1;
     if (q.nblk < 2048) { split = (2048 + q.nblk - 1) / q.nblk; if (split > a.nrhs) split = a.nrhs; if (split < 1) split = 1; }
     dim3 grid(q.nblk, split);

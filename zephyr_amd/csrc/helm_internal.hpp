@@ -115,6 +115,7 @@ struct helm_op {
     double diag_floor = 0.0;      // preconditioner levels: floor on |diag| as a fraction of the row's absolute sum (smoother safeguard)
     double a_freq_re = 0, a_freq_im = 0, a_tau = 0, a_ky = 0, a_cpml = 0;   // parameters of the last assemble
     struct MgPrecond *mg = nullptr;
+    struct Mg3Precond *mg3 = nullptr;    // 3-D multigrid preconditioner (mg3d.hip)
     struct NdFactor *direct[4] = {nullptr, nullptr, nullptr, nullptr};   // sparse direct factors per block, valid until the next assemble
     bool direct_failed = false;
     int nblocks = 1;
@@ -167,6 +168,11 @@ int mg_setup(helm_op *op, int batch);                       // (re)build for the
 void mg_destroy(helm_op *op);
 // out[b] = M^-1 in[b] for the active right-hand sides (scal may be null = all)
 int mg_apply(helm_op *op, const cplx *in, cplx *out, int nrhs, const RhsScal *scal);
+
+// 3-D counterpart (mg3d.hip): shifted-Laplacian V-cycle with damped-Jacobi smoothing, weak absorbing layer, no line relaxation
+int mg3_setup(helm_op *op, int batch);
+void mg3_destroy(helm_op *op);
+int mg3_apply(helm_op *op, const cplx *in, cplx *out, int nrhs);
 
 // ---- launchers implemented in assemble.hip ----------------------------------------------------
 int helm_launch_assemble(helm_op *op, double freq_re, double freq_im, double tau, double ky, double cPML);

@@ -364,6 +364,7 @@ void destroy_child(helm_op *&c) {
 }  // namespace
 
 void mg_destroy(helm_op *op) {
+    if (op->mg3) mg3_destroy(op);
     MgPrecond *P = op->mg;
     if (!P) return;
     hipSetDevice(op->device);
@@ -453,6 +454,7 @@ int setup_typed(helm_op *op, MgPrecond *P) {
 }  // namespace
 
 int mg_setup(helm_op *op, int batch) {
+    if (op->ny > 0) return mg3_setup(op, batch);
     if (op->mg && op->mg->batch >= batch) return HELM_OK;
     if (op->mg) mg_destroy(op);
     { const int rch = helm_ensure_host_model(op); if (rch) return rch; }
@@ -635,6 +637,7 @@ int apply_typed(helm_op *op, MgPrecond *P, const cplx *in, cplx *out, int nrhs, 
 }  // namespace
 
 int mg_apply(helm_op *op, const cplx *in, cplx *out, int nrhs, const RhsScal *scal) {
+    if (op->ny > 0) return mg3_apply(op, in, out, nrhs);      // (the 3-D cycle runs on every right-hand side of the batch)
     MgPrecond *P = op->mg;
     if (!P) HELM_FAIL(op, HELM_ERR_STATE, "preconditioner not built");
     if (nrhs > P->batch) HELM_FAIL(op, HELM_ERR_ARG, "preconditioner batch too small");
