@@ -102,7 +102,7 @@ helm_op *helm_create(int device, int variant, int nz, int nx, double dx, double 
  * zephyr/backend/base.py:20,36-40, source.py:43-44); definition in oracle/helm3d_oracle.py.  All other entry
  * points (set_model with theta/eps/delta NULL, assemble with ky ignored and cPML the layer amplitude,
  * get_diagonals, apply, solve with rows = N) work on the returned handle; solves use the Jacobi-preconditioned
- * BiCGSTAB / CGNR; HELM_MG selects an experimental 3-D multigrid preconditioner (not chosen by HELM_AUTO). */
+ * BiCGSTAB / CGNR, right-preconditioned by a 3-D shifted-Laplacian multigrid under HELM_MG / HELM_AUTO. */
 helm_op *helm_create3d(int device, int nz, int ny, int nx, double dx, double dy, double dz, int nPML);
 void helm_destroy(helm_op *op);
 const char *helm_last_error(const helm_op *op);

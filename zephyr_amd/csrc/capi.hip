@@ -848,7 +848,7 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
     if (rc) return rc;
     // preconditioner choice: multigrid for the main block when asked for (or AUTO on Eurus, where it is validated)
     bool use_mg = false;
-    static const int auto_mg3 = getenv("HELM_AUTO_MG3") ? atoi(getenv("HELM_AUTO_MG3")) : 0;
+    static const int auto_mg3 = getenv("HELM_AUTO_MG3") ? atoi(getenv("HELM_AUTO_MG3")) : 1;
     const bool mg3_ok = op->ny > 0 && (o.method == HELM_MG || (o.method == HELM_AUTO && auto_mg3 && std::min(op->nz, std::min(op->ny, op->nx)) >= 24));
     if (!sys2 && block == 0 && (mg3_ok || (op->ny == 0 && (o.method == HELM_MG || (o.method == HELM_AUTO && std::min(op->nz, op->nx) >= 32))))) {
         rc = mg_setup(op, Bmax);
