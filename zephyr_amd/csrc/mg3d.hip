@@ -170,9 +170,10 @@ int mg3_setup(helm_op *op, int batch) {
     double inv_tau = omega * P->beta / 2.0;
     if (std::isfinite(op->a_tau) && op->a_tau != 0.0) inv_tau += 1.0 / op->a_tau;
     const double tauM = 1.0 / inv_tau;
-    // weak layer of the preconditioner: gamma / omega = 0.2 (measured at 256 x 256 x 128: a fixed amplitude of 30 diverges at 3 Hz
-    // and stalls at 2 Hz, 0.2 omega converges from 2 to 5 Hz; 0.4 omega is as good at 5 Hz but stalls at 2 Hz)
-    P->cpml_m = envd("HELM_MG3_CPML", std::min(30.0, 0.2 * omega));
+    // layer of the preconditioner: gamma / omega = 2 (measured at 256 x 256 x 128 with the shift above: 0.2 omega -> 26 / 14 / 8.8 s
+    // per 4 sources at 2 / 3 / 5 Hz, 2 omega -> 22 / 10.5 / 7.4 s, 5 omega worse again, the true layer (300) does not converge;
+    // with the small shift beta = 0.6 only gamma / omega <= 0.4 was stable)
+    P->cpml_m = envd("HELM_MG3_CPML", 2.0 * omega);
     const double cpml = std::min(P->cpml_m, op->a_cpml > 0 ? op->a_cpml : P->cpml_m);
     std::vector<cplx> c = op->h_c;
     std::vector<double> rho = op->h_rho;
