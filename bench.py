@@ -69,9 +69,42 @@ def cpu_baseline(cfg, freqs, q_host, sample_rhs=8):
     t_rhs = (t3 - t2) / sample_rhs
     wps = NSRC / ((t1 - t0) + (t2 - t1) + NSRC * t_rhs)
     return dict(value=wps, unit='wavefields/s', cores=1, kind='port',
+                system='M1-only (isotropic-equivalent N x N block; the reference factors the 2N x 2N system, see cpu_baseline_2n)',
+                freq_hz=f, assemble_s=t1 - t0, factor_s=t2 - t1, per_rhs_s=t_rhs, sample_rhs=sample_rhs,
                 sample='1 of 16 freqs (%.2f Hz) of the 1024^2 job: numpy assembly %.1fs + SciPy SuperLU factor %.1fs + %d back-substitutions %.3fs each, '
                        'extrapolated to 256 sources/frequency; single thread; host has %d logical CPUs'
                        % (f, t1 - t0, t2 - t1, sample_rhs, t_rhs, os.cpu_count())), u
+
+
+def cpu_baseline_2n(n=512, dx=10.0, f=6.0, sample_rhs=4):
+    """The FAITHFUL reference system: Eurus' 2N x 2N block matrix [[M1, M2], [M3, M4]] handed to the sparse LU
+    (eurus.py:430-464,512-533), on the 512^2 configuration (config 2: ~11 GB of factors; the 1024^2 one needs ~45 GB and
+    minutes).  Quoted per 64 sources per frequency, config 2's batch."""
+    from oracle import helm_oracle as ho
+    from zephyr_amd.models import marmousi_like
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=1)
+    except Exception:
+        limiter = None
+    c = marmousi_like(n, n, dx)
+    t0 = time.perf_counter()
+    C4 = ho.eurus_coefficients(n, n, c, ho.gardner_rho(c), f, dx=dx, dz=dx, nPML=10, cPML=1e3)
+    op = ho.DirectOperator(C4, eurus=True)
+    t1 = time.perf_counter()
+    op.factor()
+    t2 = time.perf_counter()
+    q = np.zeros((n * n, sample_rhs), complex)
+    q[2 * n + n // 2 + np.arange(sample_rhs) * 7, np.arange(sample_rhs)] = 1.
+    op * q
+    t3 = time.perf_counter()
+    t_rhs = (t3 - t2) / sample_rhs
+    nsrc = 64
+    return dict(value=nsrc / ((t2 - t0) + nsrc * t_rhs), unit='wavefields/s', cores=1, kind='port',
+                system='2N x 2N (faithful: the block system the reference factors, eurus.py:430-464)',
+                grid=[n, n], freq_hz=f, assemble_s=t1 - t0, factor_s=t2 - t1, per_rhs_s=t_rhs, sample_rhs=sample_rhs,
+                sample='1 frequency (%.1f Hz) of the %d^2 config-2 model: assemble %.1fs + SuperLU of the 2N system %.1fs + %d back-substitutions %.3fs each, '
+                       'extrapolated to 64 sources/frequency; single thread' % (f, n, t1 - t0, t2 - t1, sample_rhs, t_rhs))
 
 
 def _pool_worker(job):
@@ -123,10 +156,37 @@ def cpu_baseline_pool(cfg, freqs, nproc=16, nsolve=4):
     wall = time.perf_counter() - t0
     setup = max(r[0] for r in res); per_rhs = max(r[1] for r in res)
     wps = len(jobs) * NSRC / (setup + NSRC * per_rhs)
-    return dict(value=wps, unit='wavefields/s', cores=len(jobs), kind='port',
+    return dict(value=wps, unit='wavefields/s', cores=len(jobs), kind='port', system='M1-only (isotropic-equivalent)',
+                slowest_assemble_plus_factor_s=setup, slowest_per_rhs_s=per_rhs,
                 sample='%d frequencies of the %d^2 job in %d concurrent single-thread processes (the reference MultiFreq pool mode): slowest assemble+factor %.1fs, '
                        'slowest back-substitution %.3fs per source (%d measured), extrapolated to 256 sources per frequency; wall of the sample %.1fs'
                        % (len(jobs), cfg['nx'], len(jobs), setup, per_rhs, nsolve, wall))
+
+
+def spawn_ranks(ngpus, argv):
+    """`python bench.py --gpus N` without a launcher: start N rank processes (one per GPU, RCCL rendezvous on 127.0.0.1) BEFORE
+    anything in this process touches the GPU, relay rank 0's JSON line, fail if any rank fails.  (The driver's
+    `torch.distributed.run` launch sets WORLD_SIZE and never comes here.)"""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(ngpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    procs = []
+    for r in range(ngpus):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        sys.stderr.write('bench.py: ranks failed (rank, exit code): %s\n' % bad)
+        return 1
+    return 0
 
 
 def main():
@@ -142,8 +202,13 @@ def main():
     ap.add_argument('--cpu-pool', action='store_true', help='(default now) kept for compatibility')
     ap.add_argument('--no-cpu-pool', action='store_true', help='skip the 16-process CPU pool baseline (it adds ~35 s)')
     ap.add_argument('--method', default='auto')
+    ap.add_argument('--no-plain-pass', action='store_true', help='skip the extra un-profiled pass over the same work items')
+    ap.add_argument('--no-cpu-2n', action='store_true', help='skip the faithful 2N x 2N Eurus LU baseline at 512^2 (~1 min, ~11 GB)')
     ap.add_argument('--streams', type=int, default=1, help='work items in flight per GPU (host threads, one operator handle / HIP stream each)')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -242,10 +307,24 @@ def main():
         big_ms += t['gemm_big_ms']; big_launches += t['gemm_big_launches']; big_flops += t['gemm_big_flops']
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        return float(tt.item())
+    elapsed = max_over_ranks(elapsed)
+
+    # the same K work items once more with the per-launch HIP events off: what the event traffic of the roofline measurement costs
+    elapsed_plain = None
+    if args.streams <= 1 and not args.no_plain_pass:
+        barrier()
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            run_item(rank + world * (args.warmup + k), False)
+        barrier()
+        elapsed_plain = max_over_ranks(time.perf_counter() - t1)
 
     wavefields = world * args.steps * B
     value = wavefields / elapsed
@@ -269,6 +348,8 @@ def main():
             'value': value, 'unit': 'wavefields/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'timed_region': 'K work items with per-launch HIP events on (they feed `roofline`); `unprofiled` repeats the same K items with the events off',
+            'unprofiled': None if elapsed_plain is None else {'value': wavefields / elapsed_plain, 'ms_per_step': 1e3 * elapsed_plain / args.steps},
             'config': {'workload': 'Eurus 2D isotropic %dx%d synthetic-Marmousi (seed 20240512, dx=%g m), 16 freqs 2-9.5 Hz x 256 Kaiser sources; '
                                    'step = create + assemble 1 frequency + solve %d sources to true relres<=%g (method=%s: %s)' % (n, n, dx, B, args.rtol, args.method, how),
                        'grid': [n, n], 'sources_per_step': B, 'work_items_in_flight': args.streams, 'freqs_hz_this_run': freq_used, 'sharding': 'work items (freq, source batch) round-robin over ranks',
@@ -278,8 +359,8 @@ def main():
         }
         if direct:
             tf = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-            out['roofline'] = {'bound': 'mfma', 'kernel': 'k_zgemm (strided-batched complex128 GEMM of the multifrontal factorisation and triangular solves; fp64 FMAs on the vector '
-                                                           'ALUs, whose rate equals the fp64 MFMA rate on MI355X)',
+            out['roofline'] = {'bound': 'fp64-valu', 'kernel': 'k_zgemm2 (strided-batched complex128 GEMM of the multifrontal factorisation and triangular solves; fp64 FMAs on the vector '
+                                                                'ALUs -- no MFMA is issued; the peak quoted is the fp64 vector-FMA rate, which equals the fp64 MFMA rate on MI355X)',
                                'flops_formula': '8*M*N*K per batch item (4 real multiply-adds per complex one)',
                                'achieved': tf, 'peak': F64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / F64_PEAK_TFLOPS, 'traffic': None,
                                'launches_timed': int(gemm_launches), 'avg_launch_us': 1e3 * gemm_ms / gemm_launches if gemm_launches else None,
@@ -291,6 +372,7 @@ def main():
             out['stencil_roofline'] = stencil
         else:
             out['roofline'] = stencil
+        out['roofline_northstar'] = stencil        # the kernel BASELINE.json's north_star names: the 9-point stencil apply against the HBM roofline
         micro_target = out['stencil_roofline'] if direct else out['roofline']
         # stencil-apply microbenchmark of SURVEY.md 8(d) (outside the timed region): Y = A X on random X, B right-hand sides,
         # algorithmic bytes N*(32*B + 144), HIP events on the solver stream
@@ -333,8 +415,29 @@ def main():
         except Exception:
             pass
         if world == 1 and not args.no_cpu:
-            cb, _ = cpu_baseline(cfg, freqs, q_all)
+            cb, u_lu = cpu_baseline(cfg, freqs, q_all)
             out['cpu_baseline'] = cb
+            # parity gate of the bench itself: the LU wavefields the CPU leg just computed against the GPU path on the same frequency / sources
+            try:
+                ns = min(u_lu.shape[1], B)
+                u_lu = u_lu[:, :ns]
+                sc = dict(cfg); sc.update(freq=cb['freq_hz'], rtol=args.rtol, maxit=400000, method=args.method, batch=B, device=local)
+                opp = Eurus(sc)
+                opp.solveDevice(d_rhs.data_ptr(), d_u.data_ptr(), ns, N)
+                u_gpu = d_u[:ns].cpu().numpy().T
+                rel = np.linalg.norm(u_gpu - u_lu, axis=0) / np.linalg.norm(u_lu, axis=0)
+                out['parity_vs_lu_max_rel'] = float(rel.max())
+                out['parity_vs_lu'] = {'freq_hz': cb['freq_hz'], 'sources': int(ns), 'grid': [n, n], 'tolerance': 1e-7, 'ok': bool(rel.max() <= 1e-7),
+                                       'what': 'max over sources of ||u_gpu - u_lu|| / ||u_lu||, u_lu = SciPy SuperLU solve of the oracle matrix (the cpu_baseline leg)'}
+                del opp.factors
+            except Exception as exc:
+                out['parity_vs_lu_max_rel'] = None
+                out['parity_vs_lu'] = 'failed: %s' % exc
+            if not args.no_cpu_2n and n == 1024:
+                try:
+                    out['cpu_baseline_2n'] = cpu_baseline_2n()
+                except Exception as exc:
+                    out['cpu_baseline_2n'] = 'failed: %s' % exc
             if not args.no_cpu_pool and (os.cpu_count() or 1) >= 32:
                 try:
                     out['cpu_baseline_pool'] = cpu_baseline_pool(cfg, freqs)

@@ -193,6 +193,9 @@ int helm_direct_plan_front(int nz, int nx, int leaf, int node, long long *cells,
 int helm_debug_zgemm(int device, int M, int N, int K, const double *alpha, const double *A, const double *B,
                      const double *beta, double *C, int batch);
 int helm_debug_inverse(int device, int n, double *A, int batch);
+/* average milliseconds per launch of one strided-batched GEMM shape (random operands, `reps` timed launches) with tile-kernel
+ * variant `variant` (-1: default; 0: first-generation tile kernel; 1 / 2: conflict-free double-buffered kernel, K slab 8 / 16) */
+int helm_debug_zgemm_bench(int device, int M, int N, int K, int batch, int variant, int reps, double *ms_out);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,142 @@
+"""GPU: parity against the sparse LU at the BASELINE sizes (VERDICT r1 "full-size parity gate").
+
+The HIP path (through the C ABI, the operator / dispatcher / survey classes) is compared with the oracle's SciPy SuperLU
+solve of the reference-identical matrix (zephyr/backend/discretization.py:78-103) on the configurations BASELINE.json names:
+
+    config 2   Eurus 512^2 synthetic-Marmousi, 8 frequencies 3-10 Hz x 64 Kaiser sources through MultiFreq + Helm2DSurvey.dpred
+    config 3   Eurus 1024^2, dx = 9 m: 5.0 / 9.0 / 9.5 Hz (9.0 and 9.5 Hz are the frequencies where the direct path needs a
+               second refinement pass), 8 sources
+    config 4   FWI gradient (forward + adjoint + imaging condition, problem.py:124-164) on the 512^2 model
+
+Tolerances: wavefield rel-L2 vs LU <= 1e-7, gradient rel-L2 <= 1e-6.  The LU factorisations run in
+spawned host processes (tests/lu_worker.py) while the GPU results wait in /dev/shm.
+"""
+import os
+import shutil
+import tempfile
+
+import numpy as np
+import pytest
+
+from tests import lu_worker
+
+pytestmark = pytest.mark.gpu
+
+
+def nrm(a, b):
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+@pytest.fixture()
+def shm_dir():
+    base = '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else None
+    d = tempfile.mkdtemp(prefix='helm_fullsize_', dir=base)
+    yield d
+    shutil.rmtree(d, ignore_errors=True)
+
+
+def cfg2_geometry(n=512, dx=10.):
+    src = np.stack([np.linspace(200., 4920., 64), np.full(64, 20.)], 1)
+    rec = np.stack([np.linspace(100., dx * n - 100., 128), np.full(128, 20.)], 1)
+    return src, rec
+
+
+def test_config2_eurus_512_multifreq_dpred_matches_sparse_lu(helm_lib, shm_dir):
+    import zephyr_amd as za
+    from zephyr_amd.models import marmousi_like
+    from zephyr_amd.problem import Helm2DProblem
+    from zephyr_amd.survey import Helm2DSurvey
+    n, dx = 512, 10.
+    freqs = [float(f) for f in np.linspace(3., 10., 8)]
+    src, rec = cfg2_geometry(n, dx)
+    c = marmousi_like(n, n, dx)
+    sc = dict(nx=n, nz=n, dx=dx, dz=dx, c=c, nPML=10, cPML=1e3, freqs=freqs, Disc=za.Eurus, geom=dict(src=src, rec=rec, mode='fixed'), rtol=1e-10)
+    prob, surv = Helm2DProblem(sc), Helm2DSurvey(sc)
+    prob.pair(surv)
+    assert isinstance(prob.system, za.MultiFreq)
+    d_gpu = surv.dpred().reshape((128, 64, 8))
+    # the same wavefields once more through the dispatcher's `*` (host arrays out), kept for the workers
+    q = surv.getSources()
+    jobs = []
+    for i, u in enumerate(prob.system * q):
+        assert u.shape == (n * n, 64)
+        path = os.path.join(shm_dir, 'u%d.npy' % i)
+        np.save(path, u)
+        jobs.append(dict(n=n, dx=dx, model=('marmousi', 0), freq=freqs[i], system='eurus_m1', src=src, rec=rec, ufile=path))
+        del u
+    for sub in prob.system.subProblems:
+        assert all(it['status'] == 0 and it['relres'] <= 1e-10 for it in sub.lastInfo)
+    # one frequency additionally against the faithful 2N x 2N system the reference factors (eurus.py:430-464)
+    jobs.append(dict(jobs[3], system='eurus_2n'))
+    res = lu_worker.run_jobs(jobs)
+    for i in range(8):
+        assert max(res[i]['err']) <= 1e-7, (freqs[i], max(res[i]['err']))
+        assert nrm(d_gpu[:, :, i], res[i]['data']) <= 1e-7
+    assert max(res[8]['err']) <= 1e-7, ('2N system', max(res[8]['err']))
+    print('config 2: worst rel-L2 vs LU %.2e (M1), %.2e (2N system at %.1f Hz)' % (max(max(r['err']) for r in res[:8]), max(res[8]['err']), freqs[3]))
+
+
+def test_config4_gradient_512_matches_oracle_gradient(helm_lib):
+    import zephyr_amd as za
+    from zephyr_amd.models import marmousi_like, box_smooth
+    from zephyr_amd.problem import Helm2DProblem
+    from zephyr_amd.survey import Helm2DSurvey
+    n, dx = 512, 10.
+    freqs = [float(f) for f in np.linspace(3., 10., 8)]
+    src, rec = cfg2_geometry(n, dx)
+    ctrue = marmousi_like(n, n, dx)
+    ccur = box_smooth(ctrue, 12)                     # "3-pt -> 25-pt smoothed" current model
+    base = dict(nx=n, nz=n, dx=dx, dz=dx, nPML=10, cPML=1e3, freqs=freqs, Disc=za.Eurus, geom=dict(src=src, rec=rec, mode='fixed'), rtol=1e-10)
+
+    def make(c, **kw):
+        sc = dict(base, c=c, **kw)
+        p, s = Helm2DProblem(sc), Helm2DSurvey(sc)
+        p.pair(s)
+        return p, s
+
+    ptrue, strue = make(ctrue)
+    dobs = strue.dpred()
+    del ptrue.factors
+    pcur, scur = make(ccur)
+    dcur = scur.dpred()
+    resid = (dcur - dobs).reshape((128, 64, 8))
+    g_dev = pcur.Jtvec(None, resid.ravel())                        # wavefields stay in HBM, imaging kernel
+    assert pcur._deviceGradientAvailable()
+    jobs = [dict(n=n, dx=dx, model=('marmousi', 12), freq=freqs[i], system='eurus_m1', src=src, rec=rec, resid=np.ascontiguousarray(resid[:, :, i]))
+            for i in range(8)]
+    res = lu_worker.run_jobs(jobs)
+    g_ref = sum(r['grad'] for r in res)
+    d_ref = np.stack([r['data'] for r in res], axis=2)
+    assert nrm(dcur.reshape((128, 64, 8)), d_ref) <= 1e-7
+    err = nrm(g_dev, g_ref)
+    print('config 4: gradient rel-L2 vs oracle %.2e' % err)
+    assert err <= 1e-6
+    # the host imaging path (numpy) on the same GPU wavefields
+    ph, sh = make(ccur, hostGradient=True)
+    assert nrm(ph.Jtvec(None, resid.ravel()), g_ref) <= 1e-6
+
+
+def test_config3_eurus_1024_two_pass_frequencies_match_sparse_lu(helm_lib, shm_dir):
+    import zephyr_amd as za
+    from zephyr_amd.models import marmousi_like
+    n, dx = 1024, 9.
+    freqs = [5.0, 9.0, 9.5]
+    c = marmousi_like(n, n, dx)
+    xs = np.linspace(0.04 * n * dx, 0.96 * n * dx, 256)[::32]                    # 8 of the bench's 256 source positions
+    src = np.stack([xs, np.full(xs.size, 20.)], 1)
+    cfg = dict(nx=n, nz=n, dx=dx, dz=dx, c=c, nPML=10, cPML=1e3, rtol=1e-10)
+    q = za.SparseKaiserSource(cfg)(src)
+    jobs, passes = [], []
+    for i, f in enumerate(freqs):
+        op = za.Eurus(dict(cfg, freq=f))
+        u = op * q
+        assert all(it['status'] == 0 and it['relres'] <= 1e-10 and it['method'] == 4 for it in op.lastInfo), op.lastInfo
+        passes.append(max(it['iterations'] for it in op.lastInfo))
+        path = os.path.join(shm_dir, 'u%d.npy' % i)
+        np.save(path, u)
+        del op.factors
+        jobs.append(dict(n=n, dx=dx, model=('marmousi', 0), freq=f, system='eurus_m1', src=src, ufile=path))
+    res = lu_worker.run_jobs(jobs, nproc=3)
+    worst = [max(r['err']) for r in res]
+    print('config 3: rel-L2 vs LU %s, direct passes %s' % (['%.2e' % w for w in worst], passes))
+    assert max(worst) <= 1e-7, worst

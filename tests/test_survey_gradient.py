@@ -95,3 +95,43 @@ def test_frequency_sharding_world_size_2_gloo(tmp_path):
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and ('RANK %d OK' % r) in o, o
+
+
+WORKER_ONE_FREQ = r'''
+import os, sys, numpy as np
+sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+dist.init_process_group('gloo', rank=int(os.environ['RANK']), world_size=int(os.environ['WORLD_SIZE']))
+from tests.test_survey_gradient import make, nrm, GOLD
+g = dict(np.load(os.path.join(GOLD, 'g6_survey.npz')))
+ref_prob, ref_surv = make(g, shardFreqs=False, freqs=[float(g['freqs'][1])], sterms=g['sterms'][1:2])
+d_ref = ref_surv.dpred()
+resid = np.ascontiguousarray(g['resid'].reshape((ref_surv.nrec, ref_surv.nsrc, 3))[:, :, 1:2])
+g_ref = ref_prob.Jtvec(None, resid)
+j_ref = ref_prob.Jvec(None, np.linspace(1., 2., g_ref.size))
+prob, surv = make(g, freqs=[float(g['freqs'][1])], sterms=g['sterms'][1:2])
+assert prob.ownedFreqs == ([0] if dist.get_rank() == 0 else [])      # rank 1 owns nothing and must still enter the all-reduce
+ok = nrm(surv.dpred(), d_ref) < 1e-12 and nrm(prob.Jtvec(None, resid), g_ref) < 1e-12
+ok = ok and nrm(prob.Jvec(None, np.linspace(1., 2., g_ref.size)), j_ref) < 1e-12
+print('RANK', dist.get_rank(), 'OK' if ok else 'FAIL', flush=True)
+dist.barrier(); dist.destroy_process_group()
+sys.exit(0 if ok else 1)
+'''
+
+
+def test_single_frequency_on_two_ranks_does_not_hang(tmp_path):
+    """nfreq = 1, world_size = 2: rank 0 owns every frequency, rank 1 none.  The all-reduce decision must not depend on the
+    rank (ADVICE r1: `len(owned) != nfreq` let rank 0 skip the collective rank 1 was waiting in)."""
+    script = tmp_path / 'worker1.py'
+    script.write_text(WORKER_ONE_FREQ % dict(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29619', WORLD_SIZE='2', PYTHONPATH=ROOT)
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    try:
+        outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ('RANK %d OK' % r) in o, o

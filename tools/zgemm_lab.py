@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Tile-kernel lab: TFLOP/s of the strided-batched complex GEMM variants (HELM_ND_GEMMV) on the shapes the 1024^2 plan issues."""
+import ctypes, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as g
+g.build()
+from zephyr_amd import _lib
+lib = _lib.load()
+
+SHAPES = [  # (label, M, N, K, batch)
+    ('leaf fwd   G21 x', 32, 256, 64, 16384), ('leaf bwd   F12 x', 64, 256, 32, 16384), ('leaf bwd   F11i t', 64, 256, 64, 16384),
+    ('s8  fwd', 48, 256, 8, 8192), ('s8  bwd', 8, 256, 48, 8192),
+    ('s16 fwd', 64, 256, 16, 4096), ('s16 bwd', 16, 256, 64, 4096),
+    ('s32 fwd', 128, 256, 32, 1024), ('s32 bwd', 32, 256, 128, 1024),
+    ('s128 fwd', 512, 256, 128, 64), ('s128 bwd', 128, 256, 512, 64),
+    ('s512 fwd', 1025, 256, 512, 4), ('s512 bwd', 512, 256, 1025, 4),
+    ('leaf G21 = F21 F11i', 32, 64, 64, 16384), ('leaf Schur', 32, 32, 64, 16384), ('leaf inv 32^3', 32, 32, 32, 16384),
+    ('s256 Schur', 1024, 1024, 256, 16), ('s256 G21', 1024, 256, 256, 16),
+    ('top inv 512^3 x1', 512, 512, 512, 1), ('top inv 256^3 x2', 256, 256, 256, 2), ('inv 128^3 x8', 128, 128, 128, 8),
+    ('inv 64^3 x16', 64, 64, 64, 16), ('inv 32^3 x4', 32, 32, 32, 4),
+]
+variants = [int(v) for v in (sys.argv[1].split(',') if len(sys.argv) > 1 else '0,1,2,3,4,5'.split(','))]
+rows = []
+print('%-22s %6s %5s %5s %6s | ' % ('shape', 'M', 'N', 'K', 'batch') + ' '.join('v%d TF/s (us)   ' % v for v in variants))
+for label, M, N, K, b in SHAPES:
+    fl = 8.0 * M * N * K * b
+    reps = max(3, min(50, int(2e11 / fl)))
+    cells = []
+    for v in variants:
+        ms = ctypes.c_double(0)
+        rc = lib.helm_debug_zgemm_bench(0, M, N, K, b, v, reps, ctypes.byref(ms))
+        assert rc == 0, rc
+        cells.append((fl / ms.value / 1e9, ms.value * 1e3))
+    rows.append(dict(label=label, M=M, N=N, K=K, batch=b, tflops={str(v): c[0] for v, c in zip(variants, cells)}, us={str(v): c[1] for v, c in zip(variants, cells)}))
+    print('%-22s %6d %5d %5d %6d | ' % (label, M, N, K, b) + ' '.join('%6.1f (%7.1f)' % c for c in cells), flush=True)
+print(json.dumps(rows))

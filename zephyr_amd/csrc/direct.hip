@@ -334,6 +334,123 @@ void launch_vec(hipStream_t st, bool idx, int nb, int M, int Nn, int K, cplx alp
     else hipLaunchKernelGGL((k_zgemm<TM, false, RN>), grid, dim3(256), 0, st, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
 }
 
+// ---- second-generation tile kernel ------------------------------------------------------------------------------------
+// Same tile shapes and the same IDX addressing as k_zgemm, with the two LDS problems of that kernel removed:
+//   * a thread's RN output columns are interleaved (column j * TXN + tx instead of tx * RN + j): the 16-byte Bs reads of
+//     consecutive lanes are consecutive in LDS (conflict-free: 16 lanes x 16 B = all 64 banks once), where the blocked
+//     layout put lanes 64 B apart -- a 4-way bank conflict on every B operand read, which is what held the big launches at
+//     45 TFLOP/s; global stores of C become 256-byte contiguous runs per wave row as well;
+//   * the LDS tiles are double-buffered: the next K slab goes from registers into the other buffer while the current one is
+//     multiplied, ONE barrier per slab instead of two.
+template <int TM, bool IDX, int RN, int KS, int UNR, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_zgemm2(int M, int Nn, int K, cplx alpha, const cplx *A0, int lda, long long sa,
+                                                const cplx *B0, int ldb, long long sb, cplx beta, cplx *C0, int ldc, long long sc, GemmRows R) {
+    constexpr int TXN = 1024 / TM, TN = TXN * RN;
+    constexpr int NA = (TM * KS + 255) / 256, NB = (TN * KS + 255) / 256;
+    __shared__ cplx As[2][KS][TM + 1];
+    __shared__ cplx Bs[2][KS][TN];
+    __shared__ int kidx[IDX ? GB_KIDX : 1];
+    const cplx *A = A0 + (long long)blockIdx.z * sa;
+    const cplx *B = B0 + (long long)blockIdx.z * sb;
+    cplx *C = C0 + (long long)blockIdx.z * sc;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    const int tid = threadIdx.x, ty = tid / TXN, tx = tid % TXN;
+    const long long trow = IDX ? (long long)(R.z0 + blockIdx.z) * R.tab_stride : 0;
+    const bool idxB = IDX && R.tabB != nullptr;
+    if (idxB) {
+        for (int k = tid; k < K; k += 256) kidx[k] = R.tabB[trow + R.offB + k].x;
+        __syncthreads();
+    }
+    cplx acc[4][RN];
+    #pragma unroll
+    for (int i = 0; i < 4; ++i)
+        #pragma unroll
+        for (int j = 0; j < RN; ++j) acc[i][j] = cmake(0.0, 0.0);
+    cplx ra[NA], rb[NB];
+    auto fetch = [&](int k0) {
+        #pragma unroll
+        for (int e = 0; e < NA; ++e) {
+            const int idx = tid + e * 256;
+            const int ar = idx / KS, ak = idx % KS;
+            cplx v = cmake(0.0, 0.0);
+            if (idx < TM * KS && m0 + ar < M && k0 + ak < K) v = A[(long long)(m0 + ar) * lda + k0 + ak];
+            ra[e] = v;
+        }
+        #pragma unroll
+        for (int e = 0; e < NB; ++e) {
+            const int idx = tid + e * 256;
+            const int bk = idx / TN, bc = idx % TN;
+            cplx v = cmake(0.0, 0.0);
+            if (idx < TN * KS && k0 + bk < K && n0 + bc < Nn) {
+                if (idxB) { const int r = kidx[k0 + bk]; if (r >= 0) v = R.Bx[(long long)r * R.ldx + n0 + bc]; }
+                else v = B[(long long)(k0 + bk) * ldb + n0 + bc];
+            }
+            rb[e] = v;
+        }
+    };
+    auto stash = [&](int buf) {
+        #pragma unroll
+        for (int e = 0; e < NA; ++e) { const int idx = tid + e * 256; if (idx < TM * KS) As[buf][idx % KS][idx / KS] = ra[e]; }
+        #pragma unroll
+        for (int e = 0; e < NB; ++e) { const int idx = tid + e * 256; if (idx < TN * KS) Bs[buf][idx / TN][idx % TN] = rb[e]; }
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = 0; k0 < K; k0 += KS) {
+        const bool more = k0 + KS < K;
+        if (more) fetch(k0 + KS);
+        #pragma unroll UNR
+        for (int k = 0; k < KS; ++k) {
+            cplx a[4], b[RN];
+            #pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[cur][k][ty * 4 + i];
+            #pragma unroll
+            for (int j = 0; j < RN; ++j) b[j] = Bs[cur][k][j * TXN + tx];
+            #pragma unroll
+            for (int i = 0; i < 4; ++i)
+                #pragma unroll
+                for (int j = 0; j < RN; ++j) cfma(acc[i][j], a[i], b[j]);
+        }
+        if (more) { stash(cur ^ 1); __syncthreads(); cur ^= 1; }
+    }
+    const bool b0 = (beta.x == 0.0 && beta.y == 0.0);
+    #pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = m0 + ty * 4 + i;
+        if (r >= M) continue;
+        cplx *dst = C + (long long)r * ldc;
+        const cplx *cin = dst;
+        if (IDX && R.tabCo) {
+            const int ix = R.tabCo[trow + R.offCo + r].x;
+            if (ix < 0) continue;
+            dst = R.Cox + (long long)ix * R.ldx;
+        }
+        if (IDX && R.tabCi && !b0) {
+            const int ix = R.tabCi[trow + R.offCi + r].x;
+            cin = ix >= 0 ? R.Cix + (long long)ix * R.ldx : nullptr;
+        }
+        #pragma unroll
+        for (int j = 0; j < RN; ++j) {
+            const int cc = n0 + j * TXN + tx;
+            if (cc >= Nn) continue;
+            cplx v = cmul(alpha, acc[i][j]);
+            if (!b0 && cin) v = cadd(v, cmul(beta, cin[cc]));
+            dst[cc] = v;
+        }
+    }
+}
+
+template <int TM, int RN, int KS, int UNR = 1, int OCC = 1>
+void launch_vec2(hipStream_t st, bool idx, int nb, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, long long sa, const cplx *B, int ldb, long long sb,
+                 cplx beta, cplx *C, int ldc, long long sc, const GemmRows &R) {
+    constexpr int TN = (1024 / TM) * RN;
+    dim3 grid((Nn + TN - 1) / TN, (M + TM - 1) / TM, nb);
+    if (idx) hipLaunchKernelGGL((k_zgemm2<TM, true, RN, KS, UNR, OCC>), grid, dim3(256), 0, st, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
+    else hipLaunchKernelGGL((k_zgemm2<TM, false, RN, KS, UNR, OCC>), grid, dim3(256), 0, st, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
+}
+
 // ---- the same GEMM on the matrix cores -------------------------------------------------------------------------
 // v_mfma_f64_16x16x4_f64: lane l holds A[l & 15][l >> 4] and B[l >> 4][l & 15]; result register r of lane l is
 // C[(l >> 4) + 4 r][l & 15].  A complex product is four real MFMAs on the (re, im) planes of the same lane data:
@@ -579,6 +696,8 @@ __global__ void k_axpy_one(cplx *y, const cplx *x, long long n, int conj) {
         y[i] = cadd(y[i], conj ? cconj(x[i]) : x[i]);
 }
 
+int g_gemm_variant = -1;        // >= 0: overrides HELM_ND_GEMMV (helm_debug_zgemm_bench)
+
 // op may be null (diagnostic entry points): default stream, no profiling
 int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, long long sa, const cplx *B, int ldb, long long sb,
          cplx beta, cplx *C, int ldc, long long sc, int batch, const GemmRows *rows = nullptr) {
@@ -633,7 +752,18 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
             continue;
         }
         // (a 4 x 8 register block per thread -- RN = 8, 64 x 128 tile -- was measured too: 230 VGPRs, occupancy 2, 38 % slower)
-#define ZG_VEC(TM_, RN_) launch_vec<TM_, RN_>(st, rows != nullptr, nb, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R)
+        // 0: first-generation kernel; v2 kernel: 1: K slab 8, 2: K slab 16, 3: K slab 8 + k loop unrolled twice, 4: K slab 16 unrolled twice,
+        // 5: K slab 8 with the register budget of 4 waves per SIMD
+        static const int gemm_v = getenv("HELM_ND_GEMMV") ? atoi(getenv("HELM_ND_GEMMV")) : 1;
+        const int gv = g_gemm_variant >= 0 ? g_gemm_variant : gemm_v;
+#define ZG_ARGS st, rows != nullptr, nb, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R
+#define ZG_VEC(TM_, RN_) do { switch (gv) { \
+            case 0: launch_vec<TM_, RN_>(ZG_ARGS); break; \
+            case 2: launch_vec2<TM_, RN_, 16, 1, 1>(ZG_ARGS); break; \
+            case 3: launch_vec2<TM_, RN_, 8, 2, 1>(ZG_ARGS); break; \
+            case 4: launch_vec2<TM_, RN_, 16, 2, 1>(ZG_ARGS); break; \
+            case 5: launch_vec2<TM_, RN_, 8, 1, 4>(ZG_ARGS); break; \
+            default: launch_vec2<TM_, RN_, 8, 1, 1>(ZG_ARGS); break; } } while (0)
         switch (vsel) {
             case 0: ZG_VEC(64, 4); break;
             case 1: ZG_VEC(32, 4); break;
@@ -909,16 +1039,44 @@ int check_kernels(helm_op *op, const char *what) {
 
 long long nd_factor_ws_elems(const NdPlan &P) { return 2 * P.fregion + P.work_elems; }
 
+namespace {
+// HELM_ND_TRACE=1: per-group device time of the factorisation / forward / backward sweeps on stderr (diagnostics only)
+struct GroupTrace {
+    bool on; hipStream_t st; std::vector<hipEvent_t> ev; const char *what;
+    GroupTrace(hipStream_t s, const char *w) : st(s), what(w) { static const int t = getenv("HELM_ND_TRACE") ? atoi(getenv("HELM_ND_TRACE")) : 0; on = t != 0; mark(); }
+    void mark() { if (!on) return; hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, st); ev.push_back(e); }
+    void report(const NdPlan &P, bool reverse) {
+        if (!on) return;
+        hipStreamSynchronize(st);
+        double tot = 0;
+        for (size_t i = 0; i + 1 < ev.size(); ++i) {
+            float ms = 0.f; hipEventElapsedTime(&ms, ev[i], ev[i + 1]); tot += ms;
+            const size_t gi = reverse ? P.groups.size() - 1 - i : i;
+            if (gi < P.groups.size()) {
+                const NdGroup &g = P.groups[gi];
+                fprintf(stderr, "[nd trace] %-8s level %2d %s cnt %6d s %5d m %5d : %8.3f ms\n", what, g.level, g.leaf ? "leaf" : "sep ", g.cnt, g.smax, g.mmax, ms);
+            } else fprintf(stderr, "[nd trace] %-8s extra : %8.3f ms\n", what, ms);
+        }
+        fprintf(stderr, "[nd trace] %-8s total %8.3f ms\n", what, tot);
+        for (hipEvent_t e : ev) hipEventDestroy(e);
+        ev.clear();
+    }
+};
+}  // namespace
+
 // ws: nd_factor_ws_elems(plan) elements of scratch (fronts of two adjacent levels + inversion workspace)
 int nd_factor(helm_op *op, int block, NdFactor *f, cplx *ws, const cplx *planes_in) {
     const NdPlan &P = f->pd->plan;
     const cplx *planes = nullptr;
     int rc = factor_prologue(op, block, f, planes_in, &planes);
     if (rc) return rc;
+    GroupTrace tr(op->stream, "factor");
     for (size_t gi = 0; gi < P.groups.size(); ++gi) {
         rc = factor_group(op, f, gi, ws, ws + 2 * P.fregion, planes);
         if (rc) return rc;
+        tr.mark();
     }
+    tr.report(P, false);
     HIP_TRY(op, hipStreamSynchronize(op->stream));
     return check_kernels(op, "factorisation kernels");
 }
@@ -932,10 +1090,18 @@ int nd_solve(helm_op *op, NdFactor *f, const cplx *Xin, cplx *Xout, int nrhs, cp
     hipStream_t st = op->stream;
     const long long N = (long long)P.dof * P.nz * P.nx;          // unknowns per right-hand side
     const SolveCtx c = solve_ctx(f, ws, nrhs);
+    GroupTrace t0(st, "transpose");
     hipLaunchKernelGGL(k_transpose, dim3((unsigned)((N + 31) / 32), (nrhs + 31) / 32), dim3(256), 0, st, Xin, (long long)nrhs, N, c.Xt, 0);
-    for (size_t gi = 0; gi < P.groups.size(); ++gi) forward_group(op, f, gi, c);       // leaves to root
-    for (size_t gk = P.groups.size(); gk-- > 0;) backward_group(op, f, gk, c);          // root to leaves
+    t0.mark(); t0.report(P, false);
+    GroupTrace tf(st, "forward");
+    for (size_t gi = 0; gi < P.groups.size(); ++gi) { forward_group(op, f, gi, c); tf.mark(); }       // leaves to root
+    tf.report(P, false);
+    GroupTrace tb(st, "backward");
+    for (size_t gk = P.groups.size(); gk-- > 0;) { backward_group(op, f, gk, c); tb.mark(); }          // root to leaves
+    tb.report(P, true);
+    GroupTrace t1(st, "transpose");
     hipLaunchKernelGGL(k_transpose, dim3((unsigned)((N + 31) / 32), (nrhs + 31) / 32), dim3(256), 0, st, c.Xt, N, (long long)nrhs, Xout, 1, conj_out);
+    t1.mark(); t1.report(P, false);
     return check_kernels(op, "solve kernels");
 }
 
@@ -1056,5 +1222,32 @@ extern "C" int helm_debug_inverse(int device, int n, double *A, int batch) {
     hipError_t e = hipDeviceSynchronize();
     hipMemcpy(A, dA, na * 16, hipMemcpyDeviceToHost);
     hipFree(dA); hipFree(dW);
+    return e == hipSuccess ? HELM_OK : HELM_ERR_DEVICE;
+}
+
+// times `reps` launches of one strided-batched GEMM shape on random operands with kernel variant `variant` (see HELM_ND_GEMMV;
+// -1: the default); returns the average milliseconds per launch in *ms
+extern "C" int helm_debug_zgemm_bench(int device, int M, int Nn, int K, int batch, int variant, int reps, double *ms_out) {
+    if (hipSetDevice(device) != hipSuccess) return HELM_ERR_DEVICE;
+    cplx *dA, *dB, *dC;
+    const size_t na = (size_t)batch * M * K, nb = (size_t)batch * K * Nn, nc = (size_t)batch * M * Nn;
+    if (hipMalloc((void **)&dA, na * 16) != hipSuccess || hipMalloc((void **)&dB, nb * 16) != hipSuccess || hipMalloc((void **)&dC, nc * 16) != hipSuccess) return HELM_ERR_DEVICE;
+    std::vector<cplx> h(std::max(na, nb));
+    unsigned long long st = 88172645463325252ULL;
+    for (size_t i = 0; i < h.size(); ++i) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; h[i] = cmake((double)(st & 0xffff) / 65536.0 - 0.5, (double)((st >> 16) & 0xffff) / 65536.0 - 0.5); }
+    hipMemcpy(dA, h.data(), na * 16, hipMemcpyHostToDevice); hipMemcpy(dB, h.data(), nb * 16, hipMemcpyHostToDevice);
+    hipMemset(dC, 0, nc * 16);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    g_gemm_variant = variant;
+    for (int w = 0; w < 2; ++w) gemm((helm_op *)nullptr, M, Nn, K, cmake(1, 0), dA, K, (long long)M * K, dB, Nn, (long long)K * Nn, cmake(0, 0), dC, Nn, (long long)M * Nn, batch);
+    hipEventRecord(e0, nullptr);
+    for (int r = 0; r < reps; ++r) gemm((helm_op *)nullptr, M, Nn, K, cmake(1, 0), dA, K, (long long)M * K, dB, Nn, (long long)K * Nn, cmake(0, 0), dC, Nn, (long long)M * Nn, batch);
+    hipEventRecord(e1, nullptr);
+    hipError_t e = hipEventSynchronize(e1);
+    g_gemm_variant = -1;
+    float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+    if (ms_out) *ms_out = ms / std::max(1, reps);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(dA); hipFree(dB); hipFree(dC);
     return e == hipSuccess ? HELM_OK : HELM_ERR_DEVICE;
 }

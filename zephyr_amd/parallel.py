@@ -43,7 +43,9 @@ def allreduce_sum(arr):
     flat = arr.view(np.float64) if is_complex else arr.astype(np.float64, copy=False)
     t = torch.from_numpy(np.array(flat, copy=True))
     if d.get_backend() == 'nccl':
-        t = t.cuda()
+        # the rank's own GPU (LOCAL_RANK / HELM_DEVICE, the one its operator handles live on), not torch's current device
+        from .discretization import default_device
+        t = t.cuda(default_device())
     d.all_reduce(t, op=d.ReduceOp.SUM)
     out = t.cpu().numpy()
     return out.view(np.complex128).reshape(arr.shape) if is_complex else out.reshape(arr.shape)

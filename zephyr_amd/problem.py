@@ -86,6 +86,13 @@ class HelmBaseProblem(BaseModelDependent, BaseSCCache):
             return parallel.owned_indices(nf)
         return list(range(nf))
 
+    @property
+    def _sharded(self):
+        '''True when the frequencies are split over ranks.  The decision is the same on every rank (it must be: it
+        guards a collective -- a rank that owns every frequency of a short list still has to enter the all-reduce
+        the ranks that own none are waiting in).'''
+        return bool(getattr(self, '_shard', True)) and parallel.rank_and_size()[1] > 1
+
     def _solveOwned(self, rhs_list):
         'generator of (ifreq, scaleTerm * sub * rhs) over the owned frequencies'
         subs = self.system.subProblems
@@ -149,7 +156,7 @@ class HelmBaseProblem(BaseModelDependent, BaseSCCache):
             srcTerms = qf[ifreq].T * uFreq
             recTerms = sv.rVec(0) * uFreq
             dpert[:, :, ifreq] = np.asarray(recTerms).reshape((sv.nrec, 1)) * np.asarray(srcTerms).reshape((1, sv.nsrc))
-        if len(owned) != sv.nfreq:
+        if self._sharded:
             dpert = parallel.allreduce_sum(dpert)
         return dpert.ravel()
 
@@ -186,7 +193,7 @@ class HelmBaseProblem(BaseModelDependent, BaseSCCache):
             for ifreq, uB in self._solveOwned(qb):
                 pp = sv.postProcessors[ifreq]
                 g += self.gradientScaler(ifreq) * (np.asarray(uF[ifreq]) * pp(uB)).sum(axis=1)
-        if len(owned) != sv.nfreq:
+        if self._sharded:
             g = parallel.allreduce_sum(g)
         return g if u is None else g.real
 
@@ -218,7 +225,8 @@ class HelmBaseProblem(BaseModelDependent, BaseSCCache):
         nsrc, N = sv.nsrc, self.nrow
         subs = self.system.subProblems
         scale = complex(self.system.scaleTerm)
-        dev = torch.device('cuda', subs[owned[0]].device if owned else torch.cuda.current_device())
+        from .discretization import default_device
+        dev = torch.device('cuda', subs[owned[0]].device if owned else default_device())
         G = torch.zeros(N, dtype=torch.complex128, device=dev)
         qf = sv.getSources()
         U = torch.empty((2 * nsrc, N), dtype=torch.complex128, device=dev)
@@ -230,7 +238,7 @@ class HelmBaseProblem(BaseModelDependent, BaseSCCache):
             torch.cuda.synchronize(dev)
             sub.solveDevice(R.data_ptr(), U.data_ptr(), 2 * nsrc, N)
             sub.imagingAccumulateDevice(U.data_ptr(), U.data_ptr() + nsrc * N * 16, nsrc, scaler.data_ptr(), G.data_ptr())
-        if len(owned) != sv.nfreq:
+        if self._sharded:
             parallel.allreduce_sum_device(G)
         torch.cuda.synchronize(dev)
         return G.cpu().numpy()

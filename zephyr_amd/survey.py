@@ -147,7 +147,7 @@ class HelmBaseSurvey(BaseSCCache):
                 data = self.prob._dpredDevice(owned)          # wavefields never leave HBM
             else:
                 data = self._lazyProjectFields(self.prob.lazyFields(m), owned)
-            if len(owned) != self.nfreq:
+            if self.prob._sharded:
                 data = parallel.allreduce_sum(data)
             return data.ravel()
         return self._lazyProjectFields(u).ravel()
