@@ -701,7 +701,99 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
     const int max_refine = sys2 ? 40 : 10;      // passes stop earlier when the residual stalls
     static const int nd_debug = getenv("HELM_ND_DEBUG") ? atoi(getenv("HELM_ND_DEBUG")) : 0;
     int unconverged = 0;
-    for (int first = 0; first < nrhs; first += Bmax) {
+    // Node-major pipeline (single-block systems): the right-hand sides are transposed once on the way in (fused with premul /
+    // the norm), stay [cell][rhs] through solve, true residual and refinement, and are transposed once on the way out.
+    static const int use_nm = getenv("HELM_ND_NM") ? atoi(getenv("HELM_ND_NM")) : 1;
+    const bool nm = use_nm && !sys2 && !factor_pending;
+    for (int first = 0; nm && first < nrhs; first += Bmax) {
+        const int n = std::min(Bmax, nrhs - first);
+        const NdPlan &P = f->pd->plan;
+        cplx *Qt = (cplx *)lease.ptr, *Xt = Qt + (long long)Bmax * N, *dXt = Xt + (long long)Bmax * N, *arenaV = dXt + (long long)Bmax * N;
+        (void)P;
+        cplx *xout = cj ? dUconj + (long long)first * N : dXout + (long long)first * N;
+        const cplx *rhs_b = dRHS + (long long)first * rhs_ld;
+        const cplx *sub_b = sub ? sub + (long long)first * N : nullptr;
+        const cplx *planes = op->d_C + (long long)block * op->nplanes * N;
+        int *d_cols = (int *)(ptail + (size_t)Bmax * 2 * sizeof(double));
+        int *h_cols = (int *)(htail + (size_t)op->scal_cap * 2 * sizeof(double));
+        int nb_part = 0;
+        rc = nd_prep_transpose_norm(op, rhs_b, rhs_ld, row_off, premul, sub_b, Qt, N, n, (double *)op->d_part, nblk, &nb_part);
+        if (rc) return rc;
+        helm_launch_fin_ex(op, FIN_NORM, n, nb_part, nullptr, d_aux + n);           // ||q'||^2
+        rc = nd_solve_nm(op, f, Qt, Xt, n, arenaV);
+        if (rc) return rc;
+        std::vector<double> relres(n, 0.0), qq(n, 0.0);
+        std::vector<int> extra_solves(n, 0);
+        double prev_worst = 0.0;
+        bool q_is_resid = false;          // Qt holds q' until the first refinement needs the residual stored
+        rc = nd_resid_nm(op, planes, Xt, n, Qt, n, nullptr, n, 0, nullptr, (double *)op->d_part, nblk, &nb_part);
+        if (rc) return rc;
+        helm_launch_fin_ex(op, FIN_NORM, n, nb_part, nullptr, d_aux);
+        HIP_TRY(op, hipMemcpyAsync(h_aux, d_aux, 2 * n * sizeof(double), hipMemcpyDeviceToHost, op->stream));
+        HIP_TRY(op, hipStreamSynchronize(op->stream));
+        for (int b = 0; b < n; ++b) { qq[b] = h_aux[n + b]; relres[b] = qq[b] > 0 ? sqrt(h_aux[b] / qq[b]) : 0.0; }
+        for (int round = 0; ; ++round) {
+            bool all_ok = true;
+            double worst = 0.0;
+            for (int b = 0; b < n; ++b) {
+                if (!(relres[b] <= o.rtol)) all_ok = false;
+                if (!(relres[b] <= worst)) worst = relres[b];       // NaN-propagating max
+            }
+            if (nd_debug) fprintf(stderr, "[helm direct] pass %d: worst true relres %.3e\n", round + 1, worst);
+            const bool stalled = round > 0 && !(worst < 0.5 * prev_worst);
+            prev_worst = worst;
+            if (all_ok || round >= max_refine || stalled) break;
+            if (!q_is_resid) {            // r = q' - A x, stored over q' this time
+                rc = nd_resid_nm(op, planes, Xt, n, Qt, n, nullptr, n, 1, nullptr, (double *)op->d_part, nblk, &nb_part);
+                if (rc) return rc;
+                q_is_resid = true;
+            }
+            std::vector<int> bad;
+            for (int b = 0; b < n; ++b) if (!(relres[b] <= o.rtol)) bad.push_back(b);
+            const int k = (int)bad.size();
+            if (k < n / 2) {
+                // a minority missed rtol: their residual columns are packed to a narrower batch, solved in place, and the
+                // correction is folded back (x += dx, r -= A dx) by the residual kernel through the column map
+                for (int j = 0; j < k; ++j) h_cols[j] = bad[j];
+                HIP_TRY(op, hipMemcpyAsync(d_cols, h_cols, k * sizeof(int), hipMemcpyHostToDevice, op->stream));
+                rc = nd_pack_cols(op, Qt, n, d_cols, k, dXt, N);
+                if (rc) return rc;
+                cplx *dXp = dXt + N * k;                      // k < n / 2: packed residuals and their corrections share the dXt buffer
+                rc = nd_solve_nm(op, f, dXt, dXp, k, arenaV);
+                if (rc) return rc;
+                rc = nd_resid_nm(op, planes, dXp, k, Qt, n, d_cols, k, 1, Xt, (double *)op->d_part, nblk, &nb_part);
+                if (rc) return rc;
+                helm_launch_fin_ex(op, FIN_NORM, k, nb_part, nullptr, d_aux);
+                HIP_TRY(op, hipMemcpyAsync(h_aux, d_aux, k * sizeof(double), hipMemcpyDeviceToHost, op->stream));
+                HIP_TRY(op, hipStreamSynchronize(op->stream));
+                for (int j = 0; j < k; ++j) { const int b = bad[j]; relres[b] = qq[b] > 0 ? sqrt(h_aux[j] / qq[b]) : 0.0; extra_solves[b] += 1; }
+            } else {
+                rc = nd_solve_nm(op, f, Qt, dXt, n, arenaV);          // dx = A^-1 r
+                if (rc) return rc;
+                rc = nd_resid_nm(op, planes, dXt, n, Qt, n, nullptr, n, 1, Xt, (double *)op->d_part, nblk, &nb_part);
+                if (rc) return rc;
+                helm_launch_fin_ex(op, FIN_NORM, n, nb_part, nullptr, d_aux);
+                HIP_TRY(op, hipMemcpyAsync(h_aux, d_aux, n * sizeof(double), hipMemcpyDeviceToHost, op->stream));
+                HIP_TRY(op, hipStreamSynchronize(op->stream));
+                for (int b = 0; b < n; ++b) { relres[b] = qq[b] > 0 ? sqrt(h_aux[b] / qq[b]) : 0.0; extra_solves[b] += 1; }
+            }
+        }
+        rc = nd_transpose_out(op, Xt, N, n, xout, cj);
+        if (rc) return rc;
+        const int inject_stall = getenv("HELM_ND_INJECT_STALL") ? atoi(getenv("HELM_ND_INJECT_STALL")) : 0;
+        for (int b = 0; b < n; ++b) {
+            const bool ok = relres[b] <= o.rtol * 1.0000001 && !(first + b < inject_stall);
+            if (!ok) unconverged += 1;
+            if (info) {
+                helm_solve_info &I = info[first + b];
+                I.iterations += 1 + extra_solves[b]; I.method = HELM_DIRECT;
+                I.relres = std::max(I.relres, relres[b]);
+                I.status = std::max(I.status, ok ? 0 : 1);
+            }
+        }
+        HIP_TRY(op, hipStreamSynchronize(op->stream));
+    }
+    for (int first = 0; !nm && first < nrhs; first += Bmax) {
         const int n = std::min(Bmax, nrhs - first);
         cplx *q = (cplx *)lease.ptr, *r = q + (long long)Bmax * NV, *nws = q + 2LL * Bmax * NV;
         cplx *x = cj ? dUconj + (long long)first * NV : dXout + (long long)first * NV;

@@ -206,6 +206,70 @@ __global__ __launch_bounds__(256) void k_nd_extend_add(const NdDev *nodes, int f
     }
 }
 
+// One pass that WRITES every entry of a front exactly once (gather form of k_nd_assemble + the two k_nd_extend_add + the three
+// memsets they needed):  entry (r, c) = [stencil coefficient of the two cells, unless both lie on the ring]
+//                                       + child 0's Schur complement entry + child 1's, where both cells lie on that child's ring
+// (child 0 first: same summation order as the scatter form, bit for bit), identity on the padded separator diagonal, zero on
+// every other padded slot.  The inverse maps are the same closed-form nd_cell / nd_local; a workgroup tabulates them for the
+// front's rows once in LDS and then streams `rb` rows.  Traffic per level: children's F22 read once, the fronts written once
+// (the scatter form read-modify-wrote the parents twice on top of the memsets).
+__global__ __launch_bounds__(256) void k_nd_build_front(const NdDev *nodes, int first, cplx *arenaF, cplx *fac, const cplx *planes, int nz, int nx, int rb) {
+    extern __shared__ int2 finfo[];        // per padded row: x = z | x << 16 (-1: padding), y = (k0 + 1) | (k1 + 1) << 14 | comp << 28
+    const NdDev n = nodes[first + blockIdx.y];
+    const int nmax = n.smax + n.mmax;
+    const int r0 = blockIdx.x * rb;
+    if (r0 >= nmax) return;
+    const bool h0 = n.kid[0] >= 0, h1 = n.kid[1] >= 0;
+    NdDev c0 = NdDev(), c1 = NdDev();
+    if (h0) c0 = nodes[n.kid[0]];
+    if (h1) c1 = nodes[n.kid[1]];
+    const int tid = threadIdx.x;
+    for (int r = tid; r < nmax; r += 256) {
+        int a = -1;
+        if (r < n.s) a = r;
+        else if (r >= n.smax && r - n.smax < n.m) a = n.s + r - n.smax;
+        int2 e = make_int2(-1, 0);
+        if (a >= 0) {
+            int z, x, comp;
+            nd_cell(n, a, z, x, comp);
+            int k0 = 0, k1 = 0;
+            if (h0) { const int la = nd_local(c0, nz, nx, z, x, comp); if (la >= c0.s) k0 = la - c0.s + 1; }
+            if (h1) { const int la = nd_local(c1, nz, nx, z, x, comp); if (la >= c1.s) k1 = la - c1.s + 1; }
+            e.x = z | (x << 16);
+            e.y = k0 | (k1 << 14) | (comp << 28);
+        }
+        finfo[r] = e;
+    }
+    __syncthreads();
+    const long long N = (long long)nz * nx;
+    const cplx *S0 = h0 ? arenaF + c0.foff + c0.smax : nullptr, *S1 = h1 ? arenaF + c1.foff + c1.smax : nullptr;
+    const int ld0 = c0.smax + c0.mmax, ld1 = c1.smax + c1.mmax;
+    const int r1 = r0 + rb < nmax ? r0 + rb : nmax;
+    const int tx = tid & 63, ty = tid >> 6;
+    for (int r = r0 + ty; r < r1; r += 4) {
+        const int2 ia = finfo[r];
+        const int za = ia.x & 0xffff, xa = ia.x >> 16, ca = (ia.y >> 28) & 1, a0 = (ia.y & 0x3fff) - 1, a1 = ((ia.y >> 14) & 0x3fff) - 1;
+        for (int c = tx; c < nmax; c += 64) {
+            const int2 ib = finfo[c];
+            cplx v = cmake(0.0, 0.0);
+            if (ia.x < 0 || ib.x < 0) { if (r == c && r < n.smax) v = cmake(1.0, 0.0); }
+            else {
+                if (r < n.smax || c < n.smax) {              // ring x ring entries belong to an ancestor
+                    const int dz = (ib.x & 0xffff) - za, dx = (ib.x >> 16) - xa;
+                    if (dz >= -1 && dz <= 1 && dx >= -1 && dx <= 1) {
+                        const int blk = n.dof == 2 ? 2 * ca + ((ib.y >> 28) & 1) : 0;
+                        v = planes[((long long)blk * 9 + (dz + 1) * 3 + dx + 1) * N + (long long)za * nx + xa];
+                    }
+                }
+                const int b0 = (ib.y & 0x3fff) - 1, b1 = ((ib.y >> 14) & 0x3fff) - 1;
+                if (a0 >= 0 && b0 >= 0) v = cadd(v, S0[(long long)a0 * ld0 + b0]);
+                if (a1 >= 0 && b1 >= 0) v = cadd(v, S1[(long long)a1 * ld1 + b1]);
+            }
+            *front_entry(n, arenaF, fac, r, c) = v;
+        }
+    }
+}
+
 // ---- strided-batched complex GEMM: C = beta C + alpha A B, row-major ----------------------------------------------
 // 64x64 tile, K step 8, 256 threads each owning a 4x4 block; the next K slab is fetched into registers while the
 // current one is multiplied out of LDS.
@@ -220,6 +284,8 @@ struct GemmRows {
     const cplx *Bx = nullptr, *Cix = nullptr; cplx *Cox = nullptr;
     int ldx = 0;
     int z0 = 0;           // batch index of blockIdx.z == 0 (launches are chunked along z)
+    int fwd3 = 0;         // forward-gather mode (k_zgemm2<.., 2, ..>): Bx = right-hand sides, Cix = front-vector arena, Cox = where y_S goes
+    int zr0 = 0, zr1 = 0, zc0 = 0, zc1 = 0;   // rows [zr0, zr1) and columns [zc0, zc1) of C are taken as zero on input (beta masked): blocked Gauss-Jordan
 };
 #define GB_K 8
 #define GB_KIDX 512       // largest K with indexed B rows
@@ -342,23 +408,32 @@ void launch_vec(hipStream_t st, bool idx, int nb, int M, int Nn, int K, cplx alp
 //     45 TFLOP/s; global stores of C become 256-byte contiguous runs per wave row as well;
 //   * the LDS tiles are double-buffered: the next K slab goes from registers into the other buffer while the current one is
 //     multiplied, ONE barrier per slab instead of two.
-template <int TM, bool IDX, int RN, int KS, int UNR, int OCC>
+// IDX: 0 dense operands; 1 rows of B / C through the row table (GemmRows); 2 "forward gather": a row of B is the SUM the forward pass
+// needs -- the right-hand side of a separator cell plus the children's outgoing rows that land on it (table entries x / y, z) -- and
+// the C that is read is the sum of the children's rows of a ring row; the first row-tile also stores the gathered separator rows
+// (y_S) where the back substitution expects them.  Same additions in the same order as k_nd_fwd_rows + the dense GEMM.
+template <int TM, int IDX, int RN, int KS, int UNR, int OCC>
 __global__ __launch_bounds__(256, OCC) void k_zgemm2(int M, int Nn, int K, cplx alpha, const cplx *A0, int lda, long long sa,
                                                 const cplx *B0, int ldb, long long sb, cplx beta, cplx *C0, int ldc, long long sc, GemmRows R) {
     constexpr int TXN = 1024 / TM, TN = TXN * RN;
     constexpr int NA = (TM * KS + 255) / 256, NB = (TN * KS + 255) / 256;
     __shared__ cplx As[2][KS][TM + 1];
     __shared__ cplx Bs[2][KS][TN];
-    __shared__ int kidx[IDX ? GB_KIDX : 1];
+    __shared__ int kidx[IDX == 1 ? GB_KIDX : 1];
+    __shared__ int4 kidx4[IDX == 2 ? GB_KIDX : 1];
     const cplx *A = A0 + (long long)blockIdx.z * sa;
     const cplx *B = B0 + (long long)blockIdx.z * sb;
     cplx *C = C0 + (long long)blockIdx.z * sc;
     const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
     const int tid = threadIdx.x, ty = tid / TXN, tx = tid % TXN;
     const long long trow = IDX ? (long long)(R.z0 + blockIdx.z) * R.tab_stride : 0;
-    const bool idxB = IDX && R.tabB != nullptr;
+    const bool idxB = IDX == 1 && R.tabB != nullptr;
     if (idxB) {
         for (int k = tid; k < K; k += 256) kidx[k] = R.tabB[trow + R.offB + k].x;
+        __syncthreads();
+    }
+    if (IDX == 2) {
+        for (int k = tid; k < K; k += 256) kidx4[k] = R.tabB[trow + R.offB + k];
         __syncthreads();
     }
     cplx acc[4][RN];
@@ -382,7 +457,14 @@ __global__ __launch_bounds__(256, OCC) void k_zgemm2(int M, int Nn, int K, cplx 
             const int bk = idx / TN, bc = idx % TN;
             cplx v = cmake(0.0, 0.0);
             if (idx < TN * KS && k0 + bk < K && n0 + bc < Nn) {
-                if (idxB) { const int r = kidx[k0 + bk]; if (r >= 0) v = R.Bx[(long long)r * R.ldx + n0 + bc]; }
+                if (IDX == 2) {
+                    const int4 t4 = kidx4[k0 + bk];
+                    if (t4.w) v = R.Bx[(long long)t4.x * R.ldx + n0 + bc];
+                    if (t4.y >= 0) v = cadd(v, R.Cix[(long long)t4.y * R.ldx + n0 + bc]);
+                    if (t4.z >= 0) v = cadd(v, R.Cix[(long long)t4.z * R.ldx + n0 + bc]);
+                    if (blockIdx.y == 0 && t4.w && R.Cox) R.Cox[(long long)t4.x * R.ldx + n0 + bc] = v;      // y_S
+                }
+                else if (idxB) { const int r = kidx[k0 + bk]; if (r >= 0) v = R.Bx[(long long)r * R.ldx + n0 + bc]; }
                 else v = B[(long long)(k0 + bk) * ldb + n0 + bc];
             }
             rb[e] = v;
@@ -422,33 +504,46 @@ __global__ __launch_bounds__(256, OCC) void k_zgemm2(int M, int Nn, int K, cplx 
         if (r >= M) continue;
         cplx *dst = C + (long long)r * ldc;
         const cplx *cin = dst;
-        if (IDX && R.tabCo) {
+        const cplx *cin2 = nullptr;
+        if (IDX == 2) {
+            const int4 t4 = R.tabCi[trow + R.offCi + r];
+            cin = t4.y >= 0 ? R.Cix + (long long)t4.y * R.ldx : nullptr;
+            cin2 = t4.z >= 0 ? R.Cix + (long long)t4.z * R.ldx : nullptr;
+        }
+        if (IDX == 1 && R.tabCo) {
             const int ix = R.tabCo[trow + R.offCo + r].x;
             if (ix < 0) continue;
             dst = R.Cox + (long long)ix * R.ldx;
         }
-        if (IDX && R.tabCi && !b0) {
+        if (IDX == 1 && R.tabCi && !b0) {
             const int ix = R.tabCi[trow + R.offCi + r].x;
             cin = ix >= 0 ? R.Cix + (long long)ix * R.ldx : nullptr;
         }
+        const bool zrow = r >= R.zr0 && r < R.zr1;
         #pragma unroll
         for (int j = 0; j < RN; ++j) {
             const int cc = n0 + j * TXN + tx;
             if (cc >= Nn) continue;
             cplx v = cmul(alpha, acc[i][j]);
-            if (!b0 && cin) v = cadd(v, cmul(beta, cin[cc]));
+            if (IDX == 2) {
+                cplx c = cin ? cin[cc] : cmake(0.0, 0.0);
+                if (cin2) c = cadd(c, cin2[cc]);
+                v = cadd(v, cmul(beta, c));
+            }
+            else if (!b0 && cin && !zrow && !(cc >= R.zc0 && cc < R.zc1)) v = cadd(v, cmul(beta, cin[cc]));
             dst[cc] = v;
         }
     }
 }
 
 template <int TM, int RN, int KS, int UNR = 1, int OCC = 1>
-void launch_vec2(hipStream_t st, bool idx, int nb, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, long long sa, const cplx *B, int ldb, long long sb,
+void launch_vec2(hipStream_t st, int idx, int nb, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, long long sa, const cplx *B, int ldb, long long sb,
                  cplx beta, cplx *C, int ldc, long long sc, const GemmRows &R) {
     constexpr int TN = (1024 / TM) * RN;
     dim3 grid((Nn + TN - 1) / TN, (M + TM - 1) / TM, nb);
-    if (idx) hipLaunchKernelGGL((k_zgemm2<TM, true, RN, KS, UNR, OCC>), grid, dim3(256), 0, st, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
-    else hipLaunchKernelGGL((k_zgemm2<TM, false, RN, KS, UNR, OCC>), grid, dim3(256), 0, st, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
+    if (idx == 2) hipLaunchKernelGGL((k_zgemm2<TM, 2, RN, KS, UNR, OCC>), grid, dim3(256), 0, st, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
+    else if (idx) hipLaunchKernelGGL((k_zgemm2<TM, 1, RN, KS, UNR, OCC>), grid, dim3(256), 0, st, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
+    else hipLaunchKernelGGL((k_zgemm2<TM, 0, RN, KS, UNR, OCC>), grid, dim3(256), 0, st, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
 }
 
 // ---- the same GEMM on the matrix cores -------------------------------------------------------------------------
@@ -560,15 +655,10 @@ void launch_mfma(hipStream_t st, dim3 grid, bool idx, int M, int Nn, int K, cplx
 // (bottom of the recursive block inversion: 32 by default; 64 (HELM_ND_GJ=64) halves the number of small GEMM launches
 // and gains a digit of accuracy, but its 64-step elimination is slower overall: 41.8 vs 35.9 ms per factorisation at 1024^2)
 #define GJ_MAX 64
-template <int NMAX, int NT = 256>
-__global__ __launch_bounds__(NT) void k_gj_inverse(cplx *A0, int ld, long long stride, int n) {
-    __shared__ cplx a[NMAX][NMAX + 1];
-    __shared__ cplx fcol[NMAX];
-    __shared__ int piv[NMAX];
-    cplx *A = A0 + (long long)blockIdx.x * stride;
-    const int tid = threadIdx.x;
-    for (int e = tid; e < n * n; e += blockDim.x) a[e / n][e % n] = A[(long long)(e / n) * ld + e % n];
-    __syncthreads();
+// Gauss-Jordan with row pivoting on an n x n matrix held in LDS (all threads of the workgroup call it; a is valid on return
+// after the trailing barrier)
+template <int NMAX>
+__device__ __forceinline__ void gj_lds(cplx (*a)[NMAX + 1], cplx *fcol, int *piv, int n, int tid, int nthreads) {
     for (int k = 0; k < n; ++k) {
         // wave 0 (n <= 64 lanes, lock-step): pivot search in column k, row exchange, scaling of the pivot row, and the
         // column that the elimination needs -- every read of the old values is issued before the writes
@@ -592,7 +682,7 @@ __global__ __launch_bounds__(NT) void k_gj_inverse(cplx *A0, int ld, long long s
             }
         }
         __syncthreads();
-        for (int e = tid; e < n * n; e += blockDim.x) {
+        for (int e = tid; e < n * n; e += nthreads) {
             const int i = e / n, j = e % n;
             if (i == k) continue;
             cplx base = (j == k) ? cmake(0.0, 0.0) : a[i][j];
@@ -607,7 +697,178 @@ __global__ __launch_bounds__(NT) void k_gj_inverse(cplx *A0, int ld, long long s
         }
     }
     __syncthreads();
+}
+
+// ---- fast path for blocks of at most 32 x 32: 256 threads, no serial phase ------------------------------------------------
+// The generic routine above spends ~1.7 us per elimination step (4000 cycles: a one-wave pivot search through shuffles, two
+// fp64 divisions, integer divisions in the update loop); this one needs two barriers and ~500 cycles:
+//   * thread (i = tid / 8, columns 4 (tid % 8) .. +3) owns four entries of row i for the whole elimination;
+//   * the pivot of the next column is chosen by EVERY thread from 32 keys in LDS -- float(max(|re|, |im|)) with the row index in
+//     the low five bits, so the search is one v_max_u32 reduction over eight 16-byte broadcast reads; the keys are written by
+//     the threads that produce that column in the previous step;
+//   * the row exchange is folded into the update (a thread of row p reads old row k and vice versa), all old values are read
+//     before the barrier and all new ones written after it;
+//   * the reciprocal of the pivot is v_rcp_f64 + two Newton steps.
+// On return a holds the inverse with its COLUMNS still permuted: column j belongs at column colperm(j) (gj32_colperm).
+struct Gj32 {
+    cplx a[32][33];
+    unsigned cand[32];
+    int piv[32];
+};
+__device__ __forceinline__ double gj_rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(fma(-x, y, 1.0), y, y);
+    return fma(fma(-x, y, 1.0), y, y);
+}
+__device__ __forceinline__ unsigned gj_key(cplx v, int i) {
+    const float m = (float)fmax(fabs(v.x), fabs(v.y));
+    return (__float_as_uint(m) & ~31u) | (unsigned)i;
+}
+// S.a must hold the matrix padded with the identity to 32 x 32; all 256 threads call
+__device__ __forceinline__ void gj32(Gj32 &S, int n, int tid) {
+    const int i = tid >> 3, jc = tid & 7, j0 = jc * 4;
+    if (jc == 0) S.cand[i] = i < n ? gj_key(S.a[i][0], i) : (unsigned)i;
+    __syncthreads();
+    for (int k = 0; k < n; ++k) {
+        const uint4 *c4 = reinterpret_cast<const uint4 *>(S.cand);
+        unsigned m = 0;
+        #pragma unroll
+        for (int q = 0; q < 8; ++q) { const uint4 v = c4[q]; m = max(m, max(max(v.x, v.y), max(v.z, v.w))); }
+        const int p = (int)(m & 31u);
+        if (tid == 0) S.piv[k] = p;
+        const int si = (i == p) ? k : ((i == k) ? p : i);          // row i of the matrix after exchanging rows p and k
+        const cplx d = S.a[p][k];
+        cplx pr[4], mine[4];
+        #pragma unroll
+        for (int q = 0; q < 4; ++q) { pr[q] = S.a[p][j0 + q]; mine[q] = S.a[si][j0 + q]; }
+        const cplx fi = S.a[si][k];
+        const double r = gj_rcp(d.x * d.x + d.y * d.y);
+        const cplx dinv = cmake(d.x * r, -d.y * r);
+        cplx out[4];
+        #pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = j0 + q;
+            const cplx t = (j == k) ? dinv : cmul(pr[q], dinv);     // entry j of the scaled pivot row
+            if (i == k) out[q] = t;
+            else out[q] = csub((j == k) ? cmake(0.0, 0.0) : mine[q], cmul(fi, t));
+        }
+        __syncthreads();
+        #pragma unroll
+        for (int q = 0; q < 4; ++q) S.a[i][j0 + q] = out[q];
+        if (k + 1 < n && jc == ((k + 1) >> 2)) {
+            cplx v = out[0];
+            #pragma unroll
+            for (int q = 1; q < 4; ++q) if (((k + 1) & 3) == q) v = out[q];
+            S.cand[i] = (i > k && i < n) ? gj_key(v, i) : (unsigned)i;
+        }
+        __syncthreads();
+    }
+}
+// where column j of the permuted inverse belongs: the row exchanges undone as column exchanges, last first
+__device__ __forceinline__ int gj32_colperm(const Gj32 &S, int n, int j) {
+    int pv[32];
+    const int4 *p4 = reinterpret_cast<const int4 *>(S.piv);
+    #pragma unroll
+    for (int q = 0; q < 8; ++q) { const int4 v = p4[q]; pv[4 * q] = v.x; pv[4 * q + 1] = v.y; pv[4 * q + 2] = v.z; pv[4 * q + 3] = v.w; }
+    int col = j;
+    #pragma unroll
+    for (int k = 31; k >= 0; --k) {
+        if (k < n) { const int pk = pv[k]; col = (col == k) ? pk : ((col == pk) ? k : col); }
+    }
+    return col;
+}
+
+__global__ __launch_bounds__(256) void k_gj32_inverse(cplx *A0, int ld, long long stride, int n) {
+    __shared__ Gj32 S;
+    cplx *A = A0 + (long long)blockIdx.x * stride;
+    const int tid = threadIdx.x, i = tid >> 3, j0 = (tid & 7) * 4;
+    #pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = j0 + q;
+        S.a[i][j] = (i < n && j < n) ? A[(long long)i * ld + j] : cmake(i == j ? 1.0 : 0.0, 0.0);
+    }
+    __syncthreads();
+    gj32(S, n, tid);
+    #pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = j0 + q;
+        if (i < n && j < n) A[(long long)i * ld + gj32_colperm(S, n, j)] = S.a[i][j];
+    }
+}
+
+// ---- in-place inverse of n x n blocks, n <= 64: one workgroup per matrix -------------------------------------------------
+// (bottom of the block inversions: 32 by default; 64 (HELM_ND_GJ=64) gains a digit of accuracy, but its 64-step elimination
+// is slower overall: 41.8 vs 35.9 ms per factorisation at 1024^2)
+template <int NMAX, int NT = 256>
+__global__ __launch_bounds__(NT) void k_gj_inverse(cplx *A0, int ld, long long stride, int n) {
+    __shared__ cplx a[NMAX][NMAX + 1];
+    __shared__ cplx fcol[NMAX];
+    __shared__ int piv[NMAX];
+    cplx *A = A0 + (long long)blockIdx.x * stride;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < n * n; e += blockDim.x) a[e / n][e % n] = A[(long long)(e / n) * ld + e % n];
+    __syncthreads();
+    gj_lds<NMAX>(a, fcol, piv, n, tid, blockDim.x);
     for (int e = tid; e < n * n; e += blockDim.x) A[(long long)(e / n) * ld + e % n] = a[e / n][e % n];
+}
+
+// ---- blocked Gauss-Jordan inversion: panel kernel ----------------------------------------------------------------------
+// In-place inverse of T (n x n) by block steps of nb <= 32 columns.  Step k with pivot block T_kk (rows / columns [k0, k0+nb)):
+//     P = T_kk^-1 ;  R = P T[k, :] with R_k := P ;  C = T[:, k] with C_k := -I ;  T <- Z(T) - C R
+// where Z zeroes block row k and block column k (the GEMM's masked beta).  This kernel makes R (nb x n) and C (n x nb) in
+// scratch; every workgroup inverts the pivot block for itself (25 us, redundant but parallel) and then produces a 64-wide
+// slice of R and a 64-tall slice of C.  Compared with the recursive 2 x 2 block inversion the chain of dependent launches is
+// n / nb steps of two fat launches instead of ~6.8 n / 32 thin ones, which is what the upper tree levels were spending
+// their time on.  Same pivots (the block-LU Schur complements), same accuracy class.
+#define PNB 32
+__global__ __launch_bounds__(256) void k_gj_panel(cplx *T0, int ld, long long stride, int n, int k0, int nb, cplx *Wc0, cplx *Wr0, long long wstride) {
+    __shared__ Gj32 S;
+    __shared__ cplx t[PNB][64 + 1];
+    __shared__ int cperm[PNB];
+    cplx *T = T0 + (long long)blockIdx.y * stride;
+    cplx *Wc = Wc0 + (long long)blockIdx.y * wstride, *Wr = Wr0 + (long long)blockIdx.y * wstride;
+    const int tid = threadIdx.x;
+    const int s0 = blockIdx.x * 64;                     // this workgroup's slice [s0, s0 + 64) of the columns of R / rows of C
+    {
+        const int i = tid >> 3, j0 = (tid & 7) * 4;
+        #pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = j0 + q;
+            S.a[i][j] = (i < nb && j < nb) ? T[(long long)(k0 + i) * ld + k0 + j] : cmake(i == j ? 1.0 : 0.0, 0.0);
+        }
+    }
+    // row-panel slice T[k-rows, s0 .. s0+63] -> LDS ; column-panel slice copied out (C_k = -I)
+    for (int e = tid; e < PNB * 64; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        t[r][c] = (r < nb && s0 + c < n) ? T[(long long)(k0 + r) * ld + s0 + c] : cmake(0.0, 0.0);
+    }
+    for (int e = tid; e < 64 * PNB; e += 256) {
+        const int r = e >> 5, c = e & 31;
+        if (s0 + r >= n || c >= nb) continue;
+        const int gr = s0 + r;
+        cplx v = T[(long long)gr * ld + k0 + c];
+        if (gr >= k0 && gr < k0 + nb) v = (gr - k0 == c) ? cmake(-1.0, 0.0) : cmake(0.0, 0.0);
+        Wc[(long long)gr * PNB + c] = v;
+    }
+    __syncthreads();
+    gj32(S, nb, tid);
+    if (tid < PNB) cperm[tid] = gj32_colperm(S, nb, tid);
+    __syncthreads();
+    // R slice = P * t  (nb x 64) with P[r][cperm[j]] = S.a[r][j]; columns inside the pivot block get P itself
+    for (int e = tid; e < PNB * 64; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        const int gc = s0 + c;
+        if (r >= nb || gc >= n || (gc >= k0 && gc < k0 + nb)) continue;
+        cplx acc = cmake(0.0, 0.0);
+        for (int j = 0; j < nb; ++j) cfma(acc, S.a[r][j], t[cperm[j]][c]);
+        Wr[(long long)r * n + gc] = acc;
+    }
+    if (s0 < k0 + nb && s0 + 64 > k0)                    // the slice that holds the pivot block's columns
+        for (int e = tid; e < nb * nb; e += 256) {
+            const int r = e / nb, j = e % nb;
+            const int gc = k0 + cperm[j];
+            if (gc >= s0 && gc < s0 + 64) Wr[(long long)r * n + gc] = S.a[r][j];
+        }
 }
 
 // ---- solve-phase data movement -----------------------------------------------------------------------------------
@@ -622,6 +883,120 @@ __global__ __launch_bounds__(256) void k_transpose(const cplx *in, long long row
     __syncthreads();
     for (int j = ty; j < 32; j += 8)
         if (c0 + j < cols && r0 + tx < rows) out[(c0 + j) * rows + r0 + tx] = conj ? cconj(t[tx][j]) : t[tx][j];
+}
+
+// ---- node-major pipeline around the solve --------------------------------------------------------------------------------
+// The triangular solves want the right-hand sides node-major, Xt[cell][rhs].  Everything between the caller's rhs-major
+// buffers and the solves stays in that layout: the right-hand-side preparation is fused into the transpose-in, the true
+// residual q - A x is evaluated node-major (one lane per right-hand side, the nine coefficients of a cell are uniform
+// across the lanes), refinement passes solve on the residual where it lies, and only the final result is transposed out.
+//
+// Qt[i][r] = premul * rhs[r][row_off + i] - sub[r][i]   and the partials of ||q_r||^2: part[(r * 4) * nblk + block]
+__global__ __launch_bounds__(256) void k_prep_transpose_norm(const cplx *__restrict__ rhs, long long rhs_ld, long long row_off, cplx premul,
+                                                             const cplx *__restrict__ sub, cplx *__restrict__ Qt, long long N, int nrhs,
+                                                             double *__restrict__ part, int nblk) {
+    __shared__ cplx t[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = blockIdx.y * 32;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    const long long ntile = (N + 31) / 32;
+    for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const long long c0 = tile * 32;
+        #pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = ty + 8 * q;
+            if (r0 + j < nrhs && c0 + tx < N) {
+                cplx v = cmul(premul, rhs[(long long)(r0 + j) * rhs_ld + row_off + c0 + tx]);
+                if (sub) v = csub(v, sub[(long long)(r0 + j) * N + c0 + tx]);
+                t[j][tx] = v;
+                s[q] += cabs2(v);
+            }
+        }
+        __syncthreads();
+        #pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = ty + 8 * q;
+            if (c0 + j < N && r0 + tx < nrhs) Qt[(c0 + j) * nrhs + r0 + tx] = t[tx][j];
+        }
+        __syncthreads();
+    }
+    #pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double v = s[q];
+        for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);       // over the 32 cells of the tile row (half a wave)
+        const int j = ty + 8 * q;
+        if (tx == 0 && r0 + j < nrhs) part[((long long)(r0 + j) * 4) * nblk + blockIdx.x] = v;
+    }
+}
+
+// Node-major stencil with residual epilogue.  Lane = right-hand side j (blockDim.x lanes), blockDim.y row segments per workgroup;
+// a thread marches along x over `seg` cells of one grid row with a 3 x 3 register window of the input columns.
+//   in  : Xin[cell * ldin + j]                                  (the solution, or a refinement correction)
+//   q   : Q[cell * ldq + map(j)]   (map = qmap[j] or j)           r = q - A xin
+//   store != 0: r written back over q;  Xacc != null: Xacc[cell * ldq + map(j)] += xin  (refinement update folded in)
+//   part[(j * 4) * nblk + block] = partial ||r_j||^2
+__global__ __launch_bounds__(256) void k_resid_nm(const cplx *__restrict__ planes, int nz, int nx, const cplx *__restrict__ Xin, int ldin,
+                                                  cplx *__restrict__ Q, int ldq, const int *__restrict__ qmap, int ncol, int store,
+                                                  cplx *__restrict__ Xacc, double *__restrict__ part, int nblk, int seg, int ntiles) {
+    __shared__ double red[256];
+    const int j = threadIdx.x, ly = threadIdx.y;
+    const bool act = j < ncol;
+    const int col = act ? (qmap ? qmap[j] : j) : 0;
+    const long long N = (long long)nz * nx;
+    const int nseg = (nx + seg - 1) / seg;
+    double acc = 0.0;
+    // tile order: workgroup b serves band (b % 8) of the tile list, so that the workgroups of one XCD (b, b + 8, ...) walk
+    // z-adjacent row segments together and the halo rows are served by that XCD's L2
+    const int per = (ntiles + 7) / 8;
+    for (int w = blockIdx.x * blockDim.y + ly; w < per * 8; w += gridDim.x * blockDim.y) {
+        const int t = (w & 7) * per + (w >> 3);
+        if (t >= ntiles || !act) continue;
+        const int sgi = t / nz, z = t - sgi * nz;         // z fastest: consecutive tiles are vertically adjacent
+        const int x0 = sgi * seg, x1 = min(nx, x0 + seg);
+        cplx win[3][3];                                   // win[dz][.] = columns x-1, x, x+1 of row z-1+dz
+        #pragma unroll
+        for (int dz = 0; dz < 3; ++dz) {
+            const int zz = z - 1 + dz;
+            const bool zin = zz >= 0 && zz < nz;
+            win[dz][0] = cmake(0.0, 0.0);
+            win[dz][1] = (zin && x0 - 1 >= 0) ? Xin[((long long)zz * nx + x0 - 1) * ldin + j] : cmake(0.0, 0.0);
+            win[dz][2] = zin ? Xin[((long long)zz * nx + x0) * ldin + j] : cmake(0.0, 0.0);
+        }
+        for (int x = x0; x < x1; ++x) {
+            #pragma unroll
+            for (int dz = 0; dz < 3; ++dz) {
+                const int zz = z - 1 + dz;
+                win[dz][0] = win[dz][1]; win[dz][1] = win[dz][2];
+                win[dz][2] = (zz >= 0 && zz < nz && x + 1 < nx) ? Xin[((long long)zz * nx + x + 1) * ldin + j] : cmake(0.0, 0.0);
+            }
+            const long long cell = (long long)z * nx + x;
+            cplx r = Q[cell * ldq + col];
+            #pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const cplx c = planes[(long long)k * N + cell];
+                const cplx xv = win[k / 3][k % 3];
+                r.x = fma(-c.x, xv.x, r.x); r.x = fma(c.y, xv.y, r.x);
+                r.y = fma(-c.x, xv.y, r.y); r.y = fma(-c.y, xv.x, r.y);
+            }
+            if (store) Q[cell * ldq + col] = r;
+            if (Xacc) { cplx *xa = Xacc + cell * ldq + col; *xa = cadd(*xa, win[1][1]); }
+            acc += cabs2(r);
+        }
+    }
+    if (blockDim.y > 1) {
+        red[ly * blockDim.x + j] = acc;
+        __syncthreads();
+        if (ly == 0) for (int q = 1; q < (int)blockDim.y; ++q) acc += red[q * blockDim.x + j];
+    }
+    if (ly == 0 && act) part[((long long)j * 4) * nblk + blockIdx.x] = acc;
+}
+
+// Rp[cell][j] = Qt[cell][cols[j]]  (the right-hand sides that need another pass, packed to a narrower batch)
+__global__ __launch_bounds__(256) void k_pack_cols(const cplx *__restrict__ Qt, int ldq, const int *__restrict__ cols, int k, cplx *__restrict__ Rp, long long N) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < N * k; e += (long long)gridDim.x * blockDim.x) {
+        const long long cell = e / k; const int j = (int)(e - cell * k);
+        Rp[e] = Qt[cell * ldq + cols[j]];
+    }
 }
 
 // row table (see NdPlanDev): one thread per padded row of the group's fronts
@@ -650,11 +1025,11 @@ __global__ __launch_bounds__(256) void k_nd_build_tab(const NdDev *nodes, int fi
 
 // forward pass, one group: V[row] = [separator row: Xt[cell]] + outgoing rows of the children; separator rows of
 // non-leaf fronts are final (y_S) and written back to Xt.  blockDim = (LX, 256 / LX), LX lanes over the right-hand sides.
-__global__ __launch_bounds__(256) void k_nd_fwd_rows(const int4 *tab, cplx *V, const cplx *arenaV, cplx *Xt, long long rows, int nrhs, int write_back) {
+__global__ __launch_bounds__(256) void k_nd_fwd_rows(const int4 *tab, cplx *V, const cplx *arenaV, const cplx *Qt, cplx *Xt, long long rows, int nrhs, int write_back) {
     for (long long row = (long long)blockIdx.x * blockDim.y + threadIdx.y; row < rows; row += (long long)gridDim.x * blockDim.y) {
         const int4 e = tab[row];
         cplx *dst = V + row * nrhs;
-        const cplx *s0 = e.w ? Xt + (long long)e.x * nrhs : nullptr;
+        const cplx *s0 = e.w ? Qt + (long long)e.x * nrhs : nullptr;
         const cplx *s1 = e.y >= 0 ? arenaV + (long long)e.y * nrhs : nullptr;
         const cplx *s2 = e.z >= 0 ? arenaV + (long long)e.z * nrhs : nullptr;
         for (int r = threadIdx.x; r < nrhs; r += blockDim.x) {
@@ -668,11 +1043,12 @@ __global__ __launch_bounds__(256) void k_nd_fwd_rows(const int4 *tab, cplx *V, c
 }
 
 // backward pass: V[row] = Xt[cell of the row] (separator and ring rows), 0 for padding
-__global__ __launch_bounds__(256) void k_nd_bwd_gather(const int4 *tab, cplx *V, const cplx *Xt, long long rows, int nrhs) {
+__global__ __launch_bounds__(256) void k_nd_bwd_gather(const int4 *tab, cplx *V, const cplx *XS, const cplx *Xt, long long rows, int nrhs) {
+    // XS: where the separator rows' y_S lives (the right-hand sides themselves for leaves, Xt otherwise)
     for (long long row = (long long)blockIdx.x * blockDim.y + threadIdx.y; row < rows; row += (long long)gridDim.x * blockDim.y) {
         const int4 e = tab[row];
         cplx *dst = V + row * nrhs;
-        const cplx *src = e.x >= 0 ? Xt + (long long)e.x * nrhs : nullptr;
+        const cplx *src = e.x >= 0 ? (e.w ? XS : Xt) + (long long)e.x * nrhs : nullptr;
         for (int r = threadIdx.x; r < nrhs; r += blockDim.x) dst[r] = src ? src[r] : cmake(0.0, 0.0);
     }
 }
@@ -697,6 +1073,13 @@ __global__ void k_axpy_one(cplx *y, const cplx *x, long long n, int conj) {
 }
 
 int g_gemm_variant = -1;        // >= 0: overrides HELM_ND_GEMMV (helm_debug_zgemm_bench)
+int g_gemm_tile = -1;           // >= 0: forces the tile configuration (helm_debug_zgemm_bench)
+int gemm_variant() {
+    // 0: first-generation kernel; v2 kernel: 1: K slab 8, 2: K slab 16, 3: K slab 8 + k loop unrolled twice, 4: K slab 16 unrolled twice,
+    // 5: K slab 8 with the register budget of 4 waves per SIMD
+    static const int gemm_v = getenv("HELM_ND_GEMMV") ? atoi(getenv("HELM_ND_GEMMV")) : 1;
+    return g_gemm_variant >= 0 ? g_gemm_variant : gemm_v;
+}
 
 // op may be null (diagnostic entry points): default stream, no profiling
 int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, long long sa, const cplx *B, int ldb, long long sb,
@@ -728,6 +1111,17 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
         if (vcost < 0 || cost < vcost * 0.999) { vsel = c; vcost = cost; }
     }
     if (fixed_tm == 64) vsel = 0; else if (fixed_tm == 32) vsel = 1; else if (fixed_tm == 16) vsel = 2;
+    // under-filled launches (the few big fronts at the top of the tree: fewer 64 x 64 tiles than compute units): 32 x 32 or 16 x 64
+    // tiles quadruple the number of workgroups; their kernels take a K slab of 32 with the k loop unrolled, because with one wave per
+    // SIMD nothing else hides the LDS and HBM latencies (measured on 1024 x 256 x 1024: 240 -> 118 us)
+    static const int latency_tiles = getenv("HELM_ND_LATTILES") ? atoi(getenv("HELM_ND_LATTILES")) : 1;
+    bool latency_mode = false;
+    if (latency_tiles && (long long)batch * ((M + 63) / 64) * ((Nn + 63) / 64) < 256) {
+        const long long a6 = (long long)((M + 31) / 32) * 32 * ((Nn + 31) / 32) * 32, a7 = (long long)((M + 15) / 16) * 16 * ((Nn + 63) / 64) * 64;
+        vsel = a7 < a6 ? 7 : 6;
+        latency_mode = true;
+    }
+    if (g_gemm_tile >= 0) { vsel = g_gemm_tile & 7; latency_mode = false; }
     // tile shapes of the MFMA kernel: pick the one that pads M x N the least (ties: the larger tile)
     static const int cfg_tm[4] = {64, 48, 32, 16}, cfg_tn[4] = {64, 128, 128, 256};
     int best = 0; long long best_area = -1;
@@ -752,18 +1146,20 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
             continue;
         }
         // (a 4 x 8 register block per thread -- RN = 8, 64 x 128 tile -- was measured too: 230 VGPRs, occupancy 2, 38 % slower)
-        // 0: first-generation kernel; v2 kernel: 1: K slab 8, 2: K slab 16, 3: K slab 8 + k loop unrolled twice, 4: K slab 16 unrolled twice,
-        // 5: K slab 8 with the register budget of 4 waves per SIMD
-        static const int gemm_v = getenv("HELM_ND_GEMMV") ? atoi(getenv("HELM_ND_GEMMV")) : 1;
-        const int gv = g_gemm_variant >= 0 ? g_gemm_variant : gemm_v;
-#define ZG_ARGS st, rows != nullptr, nb, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R
+        const int gv = gemm_variant();
+#define ZG_ARGS st, (rows ? (rows->fwd3 ? 2 : 1) : 0), nb, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R
 #define ZG_VEC(TM_, RN_) do { switch (gv) { \
             case 0: launch_vec<TM_, RN_>(ZG_ARGS); break; \
             case 2: launch_vec2<TM_, RN_, 16, 1, 1>(ZG_ARGS); break; \
             case 3: launch_vec2<TM_, RN_, 8, 2, 1>(ZG_ARGS); break; \
             case 4: launch_vec2<TM_, RN_, 16, 2, 1>(ZG_ARGS); break; \
             case 5: launch_vec2<TM_, RN_, 8, 1, 4>(ZG_ARGS); break; \
+            case 6: launch_vec2<TM_, RN_, (RN_ == 1 ? 32 : (RN_ == 2 ? 16 : 8)), 1, 1>(ZG_ARGS); break; \
             default: launch_vec2<TM_, RN_, 8, 1, 1>(ZG_ARGS); break; } } while (0)
+        if (latency_mode && gv != 0) {
+            if (vsel == 6) launch_vec2<32, 1, 32, 4, 1>(ZG_ARGS); else launch_vec2<16, 1, 32, 4, 1>(ZG_ARGS);
+            continue;
+        }
         switch (vsel) {
             case 0: ZG_VEC(64, 4); break;
             case 1: ZG_VEC(32, 4); break;
@@ -811,12 +1207,31 @@ void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cp
     // the coupled two-field system (align == 2) is far worse conditioned: it gets the wider pivoting window by default
     static const int gj_env = getenv("HELM_ND_GJ") ? atoi(getenv("HELM_ND_GJ")) : 0;
     const int gj_base = base ? base : (gj_env == 64 ? 64 : (gj_env == 32 ? 32 : (align == 2 ? 64 : 32)));
+    // blocked Gauss-Jordan (k_gj_panel + one masked GEMM per 32 columns) for everything above the base size; the recursive 2 x 2
+    // block inversion below is kept for the coupled two-field system (64-wide pivot windows) and as HELM_ND_BLOCKED=0
+    static const int blocked = getenv("HELM_ND_BLOCKED") ? atoi(getenv("HELM_ND_BLOCKED")) : 1;
+    static const int blocked_max_batch = getenv("HELM_ND_BLOCKED_BATCH") ? atoi(getenv("HELM_ND_BLOCKED_BATCH")) : 1024;
+    if (blocked && batch <= blocked_max_batch && gemm_variant() != 0 && n > gj_base && gj_base == 32 && (long long)2 * PNB * n <= ws) {
+        cplx *Wc = W, *Wr = W + (long long)PNB * n;
+        for (int k0 = 0; k0 < n; k0 += PNB) {
+            const int nb = std::min(PNB, n - k0);
+            for (int b0 = 0; b0 < batch; b0 += 65535) {
+                const int nbt = std::min(65535, batch - b0);
+                hipLaunchKernelGGL(k_gj_panel, dim3((n + 63) / 64, nbt), dim3(256), 0, st, M + b0 * stride, ld, stride, n, k0, nb, Wc + b0 * ws, Wr + b0 * ws, ws);
+            }
+            GemmRows R; R.zr0 = k0; R.zr1 = k0 + nb; R.zc0 = k0; R.zc1 = k0 + nb;
+            gemm(op, n, n, nb, cmake(-1, 0), Wc, PNB, ws, Wr, n, ws, cmake(1, 0), M, ld, stride, batch, &R);
+        }
+        return;
+    }
     if (n <= gj_base) {
         for (int b0 = 0; b0 < batch; b0 += 1 << 20) {
             const int nb = std::min(1 << 20, batch - b0);
             // (one wave per matrix -- 64 threads, free barriers, four times the matrices in flight -- was measured: 20 % slower factorisation)
             static const int gj_threads = getenv("HELM_ND_GJ_THREADS") ? atoi(getenv("HELM_ND_GJ_THREADS")) : 256;
-            if (n <= 32 && gj_threads == 1024) hipLaunchKernelGGL((k_gj_inverse<32, 1024>), dim3(nb), dim3(1024), 0, st, M + b0 * stride, ld, stride, n);
+            static const int gj_fast = getenv("HELM_ND_GJFAST") ? atoi(getenv("HELM_ND_GJFAST")) : 1;
+            if (n <= 32 && gj_fast) hipLaunchKernelGGL(k_gj32_inverse, dim3(nb), dim3(256), 0, st, M + b0 * stride, ld, stride, n);
+            else if (n <= 32 && gj_threads == 1024) hipLaunchKernelGGL((k_gj_inverse<32, 1024>), dim3(nb), dim3(1024), 0, st, M + b0 * stride, ld, stride, n);
             else if (n <= 32) hipLaunchKernelGGL(k_gj_inverse<32>, dim3(nb), dim3(gj_threads), 0, st, M + b0 * stride, ld, stride, n);
             else hipLaunchKernelGGL(k_gj_inverse<64>, dim3(nb), dim3(256), 0, st, M + b0 * stride, ld, stride, n);
         }
@@ -913,25 +1328,37 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
     const long long s11 = (long long)g.smax * g.smax, s12 = (long long)g.smax * g.mmax;
     cplx *F = arenaF + g.foff;
     cplx *Finv = f->d_fac + g.finv, *G21 = f->d_fac + g.g21, *F12 = f->d_fac + g.f12;
-    if (fs > 0) HIP_TRY(op, hipMemsetAsync(F, 0, (size_t)g.cnt * fs * sizeof(cplx), st));
-    HIP_TRY(op, hipMemsetAsync(Finv, 0, (size_t)g.cnt * s11 * sizeof(cplx), st));
-    if (s12 > 0) HIP_TRY(op, hipMemsetAsync(F12, 0, (size_t)g.cnt * s12 * sizeof(cplx), st));
-    for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
-        const int nb = std::min(65535, g.cnt - j0);
-        hipLaunchKernelGGL(k_nd_assemble, dim3((nmax + 255) / 256, nb), dim3(256), 0, st, d_nodes, g.first + j0, arenaF, f->d_fac, planes, op->nz, op->nx);
-    }
-    if (!g.leaf) {
-        // children's ring sizes are bounded by this group's front size
-        const size_t shm = (size_t)(2 * nmax + 8) * sizeof(int);
-        for (int slot = 0; slot < 2; ++slot)
-            for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
-                const int nb = std::min(65535, g.cnt - j0);
-                // a chunk is at least 16 entries per map entry the block has to build, and enough chunks to fill the chip
-                const long long total = (long long)nmax * nmax;
-                const int chunk = (int)std::max<long long>(4096, std::min<long long>(total, std::max<long long>(16LL * nmax, total / std::max(1, 2048 / nb))));
-                const int gx = (int)std::max<long long>(1, std::min<long long>((total + chunk - 1) / chunk, 65535));
-                hipLaunchKernelGGL(k_nd_extend_add, dim3(gx, nb), dim3(256), shm, st, d_nodes, g.first + j0, slot, arenaF, f->d_fac, op->nz, op->nx, chunk);
-            }
+    static const int fused_build = getenv("HELM_ND_FUSEDBUILD") ? atoi(getenv("HELM_ND_FUSEDBUILD")) : 1;
+    if (fused_build && nmax < (1 << 14) && op->nz < 65536 && op->nx < 32768) {
+        // rows per workgroup: whole fronts while there are thousands of them, a few rows each for the handful of big ones at the top
+        const int want = std::max(1, 2048 / g.cnt);
+        const int rb = std::max(std::min(nmax, 4), (nmax + want - 1) / want);
+        for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
+            const int nb = std::min(65535, g.cnt - j0);
+            hipLaunchKernelGGL(k_nd_build_front, dim3((nmax + rb - 1) / rb, nb), dim3(256), (size_t)nmax * sizeof(int2), st, d_nodes, g.first + j0, arenaF, f->d_fac, planes,
+                               op->nz, op->nx, rb);
+        }
+    } else {
+        if (fs > 0) HIP_TRY(op, hipMemsetAsync(F, 0, (size_t)g.cnt * fs * sizeof(cplx), st));
+        HIP_TRY(op, hipMemsetAsync(Finv, 0, (size_t)g.cnt * s11 * sizeof(cplx), st));
+        if (s12 > 0) HIP_TRY(op, hipMemsetAsync(F12, 0, (size_t)g.cnt * s12 * sizeof(cplx), st));
+        for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
+            const int nb = std::min(65535, g.cnt - j0);
+            hipLaunchKernelGGL(k_nd_assemble, dim3((nmax + 255) / 256, nb), dim3(256), 0, st, d_nodes, g.first + j0, arenaF, f->d_fac, planes, op->nz, op->nx);
+        }
+        if (!g.leaf) {
+            // children's ring sizes are bounded by this group's front size
+            const size_t shm = (size_t)(2 * nmax + 8) * sizeof(int);
+            for (int slot = 0; slot < 2; ++slot)
+                for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
+                    const int nb = std::min(65535, g.cnt - j0);
+                    // a chunk is at least 16 entries per map entry the block has to build, and enough chunks to fill the chip
+                    const long long total = (long long)nmax * nmax;
+                    const int chunk = (int)std::max<long long>(4096, std::min<long long>(total, std::max<long long>(16LL * nmax, total / std::max(1, 2048 / nb))));
+                    const int gx = (int)std::max<long long>(1, std::min<long long>((total + chunk - 1) / chunk, 65535));
+                    hipLaunchKernelGGL(k_nd_extend_add, dim3(gx, nb), dim3(256), shm, st, d_nodes, g.first + j0, slot, arenaF, f->d_fac, op->nz, op->nx, chunk);
+                }
+        }
     }
     static const int gj_leaf = getenv("HELM_ND_GJ_LEAF") ? atoi(getenv("HELM_ND_GJ_LEAF")) : 0;
     static const int gj_upper = getenv("HELM_ND_GJ_UPPER") ? atoi(getenv("HELM_ND_GJ_UPPER")) : 0;
@@ -950,6 +1377,7 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
 
 struct SolveCtx {
     const int4 *tab; cplx *Xt, *arenaV; int nrhs; dim3 rb; int use_idx;
+    const cplx *Qt;       // node-major right-hand sides (read only); == Xt for an in-place solve
     dim3 rgrid(long long rows) const { return dim3((unsigned)std::min<long long>((rows + rb.y - 1) / rb.y, 1 << 20)); }
 };
 
@@ -958,6 +1386,7 @@ SolveCtx solve_ctx(const NdFactor *f, cplx *ws, int nrhs) {
     const NdPlan &P = f->pd->plan;
     SolveCtx c;
     c.tab = f->pd->d_tab; c.Xt = ws; c.arenaV = ws + (long long)P.dof * P.nz * P.nx * nrhs; c.nrhs = nrhs; c.use_idx = use_idx;
+    c.Qt = c.Xt;
     int lx = 1;
     while (lx < nrhs && lx < 256) lx <<= 1;
     c.rb = dim3(lx, 256 / lx);
@@ -974,12 +1403,23 @@ void forward_group(helm_op *op, NdFactor *f, size_t gi, const SolveCtx &c) {
     cplx *V = c.arenaV + g.voff * nrhs;
     if (c.use_idx && g.leaf && g.mmax > 0 && g.smax <= GB_KIDX) {
         // leaves have no children: the outgoing ring part is -G21 x_S with x_S read straight from Xt
-        GemmRows R; R.tabB = c.tab + g.roff; R.offB = 0; R.tab_stride = nmax; R.Bx = c.Xt; R.ldx = nrhs;
+        GemmRows R; R.tabB = c.tab + g.roff; R.offB = 0; R.tab_stride = nmax; R.Bx = c.Qt; R.ldx = nrhs;
         gemm(op, g.mmax, nrhs, g.smax, mone, f->d_fac + g.g21, g.smax, (long long)g.mmax * g.smax, nullptr, 0, 0, zero,
              V + (long long)g.smax * nrhs, nrhs, (long long)nmax * nrhs, g.cnt, &R);
         return;
     }
-    hipLaunchKernelGGL(k_nd_fwd_rows, c.rgrid(rows), c.rb, 0, op->stream, c.tab + g.roff, V, c.arenaV, c.Xt, rows, nrhs, g.leaf ? 0 : 1);
+    static const int fuse_fwd = getenv("HELM_ND_FUSEFWD") ? atoi(getenv("HELM_ND_FUSEFWD")) : 1;
+    if (fuse_fwd && c.use_idx && c.Qt != c.Xt && !g.leaf && g.mmax > 0 && g.smax <= GB_KIDX && gemm_variant() != 0) {
+        // (out-of-place solves only: in place, the y_S store of the first row-tile would race with the other row-tiles' reads of q_S)
+        // the gather of k_nd_fwd_rows happens inside the GEMM's operand loads: V_B = (children's rows) - G21 (q_S + children's rows),
+        // y_S stored to Xt on the way
+        GemmRows R; R.fwd3 = 1; R.tabB = c.tab + g.roff; R.offB = 0; R.tabCi = c.tab + g.roff; R.offCi = g.smax; R.tab_stride = nmax;
+        R.Bx = c.Qt; R.Cix = c.arenaV; R.Cox = c.Xt; R.ldx = nrhs;
+        gemm(op, g.mmax, nrhs, g.smax, mone, f->d_fac + g.g21, g.smax, (long long)g.mmax * g.smax, nullptr, 0, 0, one,
+             V + (long long)g.smax * nrhs, nrhs, (long long)nmax * nrhs, g.cnt, &R);
+        return;
+    }
+    hipLaunchKernelGGL(k_nd_fwd_rows, c.rgrid(rows), c.rb, 0, op->stream, c.tab + g.roff, V, c.arenaV, c.Qt, c.Xt, rows, nrhs, g.leaf ? 0 : 1);
     if (g.mmax > 0)     // outgoing ring part: V_B -= G21 V_S
         gemm(op, g.mmax, nrhs, g.smax, mone, f->d_fac + g.g21, g.smax, (long long)g.mmax * g.smax, V, nrhs, (long long)nmax * nrhs, one,
              V + (long long)g.smax * nrhs, nrhs, (long long)nmax * nrhs, g.cnt);
@@ -1000,7 +1440,7 @@ void backward_group(helm_op *op, NdFactor *f, size_t gk, const SolveCtx &c) {
         // lower tree levels (almost all rows): T = y_S - F12 x_B and x_S = F11^-1 T with every Xt row addressed through
         // the row table -- no gather / store pass
         GemmRows R1; R1.tabB = c.tab + g.roff; R1.offB = g.smax; R1.tabCi = c.tab + g.roff; R1.offCi = 0; R1.tab_stride = nmax;
-        R1.Bx = c.Xt; R1.Cix = c.Xt; R1.ldx = nrhs;
+        R1.Bx = c.Xt; R1.Cix = g.leaf ? c.Qt : c.Xt; R1.ldx = nrhs;      // a leaf's y_S is still the right-hand side itself
         gemm(op, g.smax, nrhs, g.mmax, mone, f->d_fac + g.f12, g.mmax, (long long)g.smax * g.mmax, nullptr, 0, 0, one,
              V, nrhs, (long long)g.smax * nrhs, g.cnt, &R1);
         GemmRows R2; R2.tabCo = c.tab + g.roff; R2.offCo = 0; R2.tab_stride = nmax; R2.Cox = c.Xt; R2.ldx = nrhs;
@@ -1008,7 +1448,7 @@ void backward_group(helm_op *op, NdFactor *f, size_t gk, const SolveCtx &c) {
              nullptr, 0, 0, g.cnt, &R2);
         return;
     }
-    hipLaunchKernelGGL(k_nd_bwd_gather, c.rgrid(rows), c.rb, 0, op->stream, c.tab + g.roff, V, c.Xt, rows, nrhs);
+    hipLaunchKernelGGL(k_nd_bwd_gather, c.rgrid(rows), c.rb, 0, op->stream, c.tab + g.roff, V, g.leaf ? c.Qt : c.Xt, c.Xt, rows, nrhs);
     if (g.mmax > 0)
         gemm(op, g.smax, nrhs, g.mmax, mone, f->d_fac + g.f12, g.mmax, (long long)g.smax * g.mmax, V + (long long)g.smax * nrhs, nrhs, (long long)nmax * nrhs,
              one, V, nrhs, (long long)nmax * nrhs, g.cnt);
@@ -1103,6 +1543,69 @@ int nd_solve(helm_op *op, NdFactor *f, const cplx *Xin, cplx *Xout, int nrhs, cp
     hipLaunchKernelGGL(k_transpose, dim3((unsigned)((N + 31) / 32), (nrhs + 31) / 32), dim3(256), 0, st, c.Xt, N, (long long)nrhs, Xout, 1, conj_out);
     t1.mark(); t1.report(P, false);
     return check_kernels(op, "solve kernels");
+}
+
+// node-major solve: Qt (cells x nrhs, read only) -> Xt (may alias Qt); arenaV: 2 * vregion * nrhs elements
+int nd_solve_nm(helm_op *op, NdFactor *f, const cplx *Qt, cplx *Xt, int nrhs, cplx *arenaV) {
+    const NdPlan &P = f->pd->plan;
+    SolveCtx c = solve_ctx(f, Xt, nrhs);
+    c.Qt = Qt; c.Xt = Xt; c.arenaV = arenaV;
+    GroupTrace tf(op->stream, "forward");
+    for (size_t gi = 0; gi < P.groups.size(); ++gi) { forward_group(op, f, gi, c); tf.mark(); }
+    tf.report(P, false);
+    GroupTrace tb(op->stream, "backward");
+    for (size_t gk = P.groups.size(); gk-- > 0;) { backward_group(op, f, gk, c); tb.mark(); }
+    tb.report(P, true);
+    return check_kernels(op, "solve kernels");
+}
+
+int nd_prep_transpose_norm(helm_op *op, const cplx *rhs, long long rhs_ld, long long row_off, cplx premul, const cplx *sub, cplx *Qt, long long N, int nrhs,
+                           double *part, int nblk_cap, int *nblk_out) {
+    const int nblk = (int)std::max<long long>(1, std::min<long long>((N + 31) / 32, std::min(nblk_cap, 1024)));
+    hipLaunchKernelGGL(k_prep_transpose_norm, dim3(nblk, (nrhs + 31) / 32), dim3(256), 0, op->stream, rhs, rhs_ld, row_off, premul, sub, Qt, N, nrhs, part, nblk);
+    *nblk_out = nblk;
+    return check_kernels(op, "right-hand-side transpose");
+}
+
+// r = q - A xin node-major (see k_resid_nm); ncol columns of Xin (leading dimension ldin); returns the partial count per column
+int nd_resid_nm(helm_op *op, const cplx *planes, const cplx *Xin, int ldin, cplx *Q, int ldq, const int *qmap, int ncol, int store, cplx *Xacc,
+                double *part, int nblk_cap, int *nblk_out) {
+    int lx = 64;
+    while (lx < ncol && lx < 256) lx <<= 1;
+    const int ly = 256 / lx;
+    const int seg = 32;
+    const int ntiles = op->nz * ((op->nx + seg - 1) / seg);
+    const int nblk = std::max(1, std::min((ntiles + ly - 1) / ly, std::min(nblk_cap, 2048)));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (op->profiling) {
+        if (op->ev_used + 2 > op->ev_pool.size() && op->ev_pool.size() < 16384) (void)helm_events_grow(op, 64);
+        if (op->ev_used + 2 <= op->ev_pool.size()) { e0 = op->ev_pool[op->ev_used]; e1 = op->ev_pool[op->ev_used + 1]; }
+    }
+    if (e0) hipEventRecord(e0, op->stream);
+    for (int c0 = 0; c0 < ncol; c0 += 256) {          // more than 256 columns: one launch per 256 (partials of later chunks follow the first)
+        const int nc = std::min(256, ncol - c0);
+        hipLaunchKernelGGL(k_resid_nm, dim3(nblk), dim3(lx, ly), 0, op->stream, planes, op->nz, op->nx, Xin + c0, ldin, Q + (qmap ? 0 : c0), ldq, qmap ? qmap + c0 : nullptr, nc, store,
+                           Xacc ? Xacc + (qmap ? 0 : c0) : nullptr, part + (long long)c0 * 4 * nblk, nblk, seg, ntiles);
+    }
+    if (e0) {
+        hipEventRecord(e1, op->stream);
+        // algorithmic bytes: the stencil apply N (32 B + 144) plus the operand q it must read (16 N B)
+        op->ev_pending.push_back(std::make_pair((int)op->ev_used, (double)op->N * (32.0 * ncol + 144.0 + 16.0 * ncol)));
+        op->ev_used += 2;
+    }
+    *nblk_out = nblk;
+    return check_kernels(op, "node-major residual");
+}
+
+int nd_pack_cols(helm_op *op, const cplx *Qt, int ldq, const int *d_cols, int k, cplx *Rp, long long N) {
+    hipLaunchKernelGGL(k_pack_cols, dim3((unsigned)std::min<long long>((N * k + 255) / 256, 1 << 20)), dim3(256), 0, op->stream, Qt, ldq, d_cols, k, Rp, N);
+    return check_kernels(op, "column packing");
+}
+
+// Xt (cells x nrhs) -> U (nrhs x N), conjugated on request
+int nd_transpose_out(helm_op *op, const cplx *Xt, long long N, int nrhs, cplx *U, int conj) {
+    hipLaunchKernelGGL(k_transpose, dim3((unsigned)((N + 31) / 32), (nrhs + 31) / 32), dim3(256), 0, op->stream, Xt, N, (long long)nrhs, U, 1, conj);
+    return check_kernels(op, "transpose out");
 }
 
 // Factorisation and the first solve in one sweep: the forward elimination of a tree level only needs that level's factors,
@@ -1238,13 +1741,14 @@ extern "C" int helm_debug_zgemm_bench(int device, int M, int Nn, int K, int batc
     hipMemcpy(dA, h.data(), na * 16, hipMemcpyHostToDevice); hipMemcpy(dB, h.data(), nb * 16, hipMemcpyHostToDevice);
     hipMemset(dC, 0, nc * 16);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    g_gemm_variant = variant;
+    g_gemm_variant = variant < 0 ? -1 : (variant & 15);          // variant = kernel generation + 16 * (tile + 1)
+    g_gemm_tile = variant >= 16 ? (variant >> 4) - 1 : -1;
     for (int w = 0; w < 2; ++w) gemm((helm_op *)nullptr, M, Nn, K, cmake(1, 0), dA, K, (long long)M * K, dB, Nn, (long long)K * Nn, cmake(0, 0), dC, Nn, (long long)M * Nn, batch);
     hipEventRecord(e0, nullptr);
     for (int r = 0; r < reps; ++r) gemm((helm_op *)nullptr, M, Nn, K, cmake(1, 0), dA, K, (long long)M * K, dB, Nn, (long long)K * Nn, cmake(0, 0), dC, Nn, (long long)M * Nn, batch);
     hipEventRecord(e1, nullptr);
     hipError_t e = hipEventSynchronize(e1);
-    g_gemm_variant = -1;
+    g_gemm_variant = -1; g_gemm_tile = -1;
     float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
     if (ms_out) *ms_out = ms / std::max(1, reps);
     hipEventDestroy(e0); hipEventDestroy(e1);
