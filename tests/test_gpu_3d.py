@@ -87,3 +87,30 @@ def test_3d_multigrid_preconditioner(helm_lib):
     assert all(i['status'] == 0 and i['method'] == 3 for i in op_m.lastInfo)
     assert its_m * 2 < its_j, (its_m, its_j)
     print('3-D iterations: multigrid %d, Jacobi %d' % (its_m, its_j))
+
+
+def test_3d_mid_size_properties_128x128x64(helm_lib):
+    """Config-5 geometry at one eighth of its size (c = 2000 m/s, h = 10 m, 5 Hz): size-independent properties of the solve --
+    residual of the returned field through the independent apply entry point, conj-linearity, agreement with the analytic
+    3-D Green's function on an interior window (zephyr/backend/analytical.py:55-59 is the reference's own analytic pin)."""
+    import zephyr_amd as za
+    nz, ny, nx, dx, f, c0 = 64, 128, 128, 10., 5., 2000.
+    cfg = dict(nx=nx, ny=ny, nz=nz, dx=dx, c=c0, rho=1., freq=f, nPML=10, rtol=1e-8, maxit=60000, method='auto', batch=2)
+    N = nz * ny * nx
+    sz, sy, sx = 30, 64, 60
+    q = np.zeros((N, 2), complex)
+    q[(sz * ny + sy) * nx + sx, 0] = 1.
+    q[((sz + 6) * ny + sy - 20) * nx + sx + 25, 1] = 1j
+    op = za.Helm3D(cfg)
+    u = op * q
+    assert all(i['status'] == 0 and i['relres'] <= 1e-8 for i in op.lastInfo), op.lastInfo
+    r = op.applyForward(u.conj()) - q                              # A conj(u) = q
+    assert np.linalg.norm(r, axis=0).max() <= 2e-8 * np.linalg.norm(q, axis=0).min()
+    usum = op * (q[:, 0] - 2j * q[:, 1])
+    assert nrm(usum, u[:, 0] + 2j * u[:, 1]) <= 1e-6               # conj-linear
+    iz, iy, ix = np.mgrid[0:nz, 0:ny, 0:nx]
+    rr = dx * np.sqrt((iz - sz) ** 2 + (iy - sy) ** 2 + (ix - sx) ** 2)
+    m = (rr > 3 * dx) & (iz > 12) & (iz < nz - 13) & (iy > 12) & (iy < ny - 13) & (ix > 12) & (ix < nx - 13)
+    g = h3.green3d(2 * np.pi * f / c0, rr[m], 1.0, dx ** 3)
+    assert np.linalg.norm(u[:, 0].reshape((nz, ny, nx))[m] - g) / np.linalg.norm(g) < 5e-2
+    print('3-D 128x128x64 @ 5 Hz: iterations %s' % [i['iterations'] for i in op.lastInfo])

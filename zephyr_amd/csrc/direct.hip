@@ -854,14 +854,26 @@ __global__ __launch_bounds__(256) void k_gj_panel(cplx *T0, int ld, long long st
     gj32(S, nb, tid);
     if (tid < PNB) cperm[tid] = gj32_colperm(S, nb, tid);
     __syncthreads();
-    // R slice = P * t  (nb x 64) with P[r][cperm[j]] = S.a[r][j]; columns inside the pivot block get P itself
-    for (int e = tid; e < PNB * 64; e += 256) {
-        const int r = e >> 6, c = e & 63;
-        const int gc = s0 + c;
-        if (r >= nb || gc >= n || (gc >= k0 && gc < k0 + nb)) continue;
-        cplx acc = cmake(0.0, 0.0);
-        for (int j = 0; j < nb; ++j) cfma(acc, S.a[r][j], t[cperm[j]][c]);
-        Wr[(long long)r * n + gc] = acc;
+    // R slice = P * t  (nb x 64) with P[r][cperm[j]] = S.a[r][j]; columns inside the pivot block get P itself.
+    // Thread (r = tid / 8, eight consecutive columns): ten LDS reads per eight complex multiply-adds.
+    {
+        const int r = tid >> 3, c0 = (tid & 7) * 8;
+        cplx acc[8];
+        #pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = cmake(0.0, 0.0);
+        for (int j = 0; j < nb; ++j) {
+            const cplx a = S.a[r][j];
+            const int tj = cperm[j];
+            #pragma unroll
+            for (int i = 0; i < 8; ++i) cfma(acc[i], a, t[tj][c0 + i]);
+        }
+        if (r < nb) {
+            #pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int gc = s0 + c0 + i;
+                if (gc < n && !(gc >= k0 && gc < k0 + nb)) Wr[(long long)r * n + gc] = acc[i];
+            }
+        }
     }
     if (s0 < k0 + nb && s0 + 64 > k0)                    // the slice that holds the pivot block's columns
         for (int e = tid; e < nb * nb; e += 256) {
@@ -1230,7 +1242,9 @@ void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cp
             // (one wave per matrix -- 64 threads, free barriers, four times the matrices in flight -- was measured: 20 % slower factorisation)
             static const int gj_threads = getenv("HELM_ND_GJ_THREADS") ? atoi(getenv("HELM_ND_GJ_THREADS")) : 256;
             static const int gj_fast = getenv("HELM_ND_GJFAST") ? atoi(getenv("HELM_ND_GJFAST")) : 1;
-            if (n <= 32 && gj_fast) hipLaunchKernelGGL(k_gj32_inverse, dim3(nb), dim3(256), 0, st, M + b0 * stride, ld, stride, n);
+            // the fast kernel is built for latency (every thread repeats the pivot search): with thousands of matrices in flight the
+            // chip is issue-bound and the plain kernel is as fast or faster (8192 blocks of 8 x 8: 54 vs 139 us)
+            if (n <= 32 && gj_fast && batch < 2048) hipLaunchKernelGGL(k_gj32_inverse, dim3(nb), dim3(256), 0, st, M + b0 * stride, ld, stride, n);
             else if (n <= 32 && gj_threads == 1024) hipLaunchKernelGGL((k_gj_inverse<32, 1024>), dim3(nb), dim3(1024), 0, st, M + b0 * stride, ld, stride, n);
             else if (n <= 32) hipLaunchKernelGGL(k_gj_inverse<32>, dim3(nb), dim3(gj_threads), 0, st, M + b0 * stride, ld, stride, n);
             else hipLaunchKernelGGL(k_gj_inverse<64>, dim3(nb), dim3(256), 0, st, M + b0 * stride, ld, stride, n);
@@ -1409,7 +1423,8 @@ void forward_group(helm_op *op, NdFactor *f, size_t gi, const SolveCtx &c) {
         return;
     }
     static const int fuse_fwd = getenv("HELM_ND_FUSEFWD") ? atoi(getenv("HELM_ND_FUSEFWD")) : 1;
-    if (fuse_fwd && c.use_idx && c.Qt != c.Xt && !g.leaf && g.mmax > 0 && g.smax <= GB_KIDX && gemm_variant() != 0) {
+    if (fuse_fwd && c.use_idx && c.Qt != c.Xt && !g.leaf && g.mmax > 0 && g.mmax <= 256 && g.smax <= GB_KIDX && gemm_variant() != 0) {
+        // (lower levels only: with many row-tiles per front every one of them repeats the three-source gather -- measured slower from m = 1025 up)
         // (out-of-place solves only: in place, the y_S store of the first row-tile would race with the other row-tiles' reads of q_S)
         // the gather of k_nd_fwd_rows happens inside the GEMM's operand loads: V_B = (children's rows) - G21 (q_S + children's rows),
         // y_S stored to Xt on the way

@@ -70,6 +70,7 @@ struct Stencil3Params {
     const cplx *W;
     long long ld, N;
     int nz, ny, nx, nrhs, ntx, nty, nblk;
+    int zfast;               // tile order: 1 = z fastest (workgroups that run together share their z-halo planes in the XCD's L2)
     const RhsScal *scal;
     double *part;
     const cplx *dinv;        // EPI_JACOBI: 1 / diagonal
@@ -101,7 +102,13 @@ __global__ __launch_bounds__(256) void k_stencil3(Stencil3Params q) {
 
     const int tid = threadIdx.x, lane = tid & 63, wy = tid >> 6;
     const int t = xcd_swizzle3(blockIdx.x, q.nblk);
-    const int tx = t % q.ntx, ty = (t / q.ntx) % q.nty, iz = t / (q.ntx * q.nty);
+    // Tile order.  Every workgroup loops over the right-hand sides of its tile, so the three z-planes it stages are shared with the
+    // tiles above and below only if THOSE run at the same time: with x fastest the same (x, y) tile of the next plane comes a whole
+    // plane of tiles later and, at 8-16 right-hand sides, its halo planes have long left the 4 MB L2 (HBM traffic up to 3x the
+    // input); with z fastest the ~100 workgroups an XCD has in flight are consecutive planes of one (x, y) column.
+    int tx, ty, iz;
+    if (q.zfast) { iz = t % q.nz; tx = (t / q.nz) % q.ntx; ty = t / (q.nz * q.ntx); }
+    else { tx = t % q.ntx; ty = (t / q.ntx) % q.nty; iz = t / (q.ntx * q.nty); }
     const int x0 = tx * T3X, y0 = ty * T3Y;
     const int nz = q.nz, ny = q.ny, nx = q.nx;
     const long long N = q.N;
@@ -272,6 +279,8 @@ int helm3d_launch_apply(helm_op *op, const ApplyArgs &a, hipEvent_t e0, hipEvent
     q.nz = op->nz; q.ny = op->ny; q.nx = op->nx; q.nrhs = a.nrhs;
     q.ntx = (op->nx + T3X - 1) / T3X; q.nty = (op->ny + T3Y - 1) / T3Y; q.nblk = q.ntx * q.nty * op->nz;
     q.scal = a.scal; q.part = a.part; q.dinv = a.dinv; q.omega_j = a.omega_j;
+    static const int zfast = getenv("HELM_3D_ZFAST") ? atoi(getenv("HELM_3D_ZFAST")) : 1;
+    q.zfast = zfast;
     int split = 1;
     if (q.nblk < 2048) { split = (2048 + q.nblk - 1) / q.nblk; if (split > a.nrhs) split = a.nrhs; if (split < 1) split = 1; }
     dim3 grid(q.nblk, split);
