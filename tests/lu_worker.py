@@ -10,6 +10,7 @@ A job is a plain dict (picklable):
                            'eurus_2n'  the faithful 2N x 2N system the reference factors (eurus.py:430-464,512-533)
                            'minizephyr'
     src                    (nsrc, 2) source locations (x, z); sources are SparseKaiserSource columns
+    tti                    optional True: smooth tilted-transverse-isotropy fields (tti_fields) -> the coupled system, eps != delta
     ufile                  .npy with the GPU wavefields (N, ncols), or None
     rec                    optional (nrec, 2): also return the projected data R u_lu
     resid                  optional (nrec, nsrc): back-propagate it and return this frequency's gradient term
@@ -35,6 +36,12 @@ def model_of(job):
     return box_smooth(c, passes) if passes else c
 
 
+def tti_fields(n):
+    """Smooth theta / eps / delta with eps != delta everywhere (the coupled two-field Eurus system, eurus.py:279-295)."""
+    zz, xx = np.mgrid[0:n, 0:n] / float(n)
+    return dict(theta=0.3 * np.sin(2 * np.pi * xx) * np.cos(np.pi * zz), eps=0.15 + 0.1 * np.sin(3 * np.pi * zz), delta=0.05 + 0.05 * np.cos(2 * np.pi * xx))
+
+
 def lu_job(job):
     try:
         from threadpoolctl import threadpool_limits
@@ -54,7 +61,8 @@ def lu_job(job):
         C = ho.minizephyr_coefficients(n, n, c, rho, f, dx=dx, dz=dx, nPML=nPML)
         op = ho.DirectOperator(C)
     else:
-        C4 = ho.eurus_coefficients(n, n, c, rho, f, dx=dx, dz=dx, nPML=nPML, cPML=cPML)
+        aniso = tti_fields(n) if job.get('tti') else {}
+        C4 = ho.eurus_coefficients(n, n, c, rho, f, dx=dx, dz=dx, nPML=nPML, cPML=cPML, **aniso)
         op = ho.DirectOperator(C4, eurus=True) if job['system'] == 'eurus_2n' else ho.DirectOperator(C4[0])
     t1 = time.perf_counter()
     op.factor()

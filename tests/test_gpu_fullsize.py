@@ -140,3 +140,28 @@ def test_config3_eurus_1024_two_pass_frequencies_match_sparse_lu(helm_lib, shm_d
     worst = [max(r['err']) for r in res]
     print('config 3: rel-L2 vs LU %s, direct passes %s' % (['%.2e' % w for w in worst], passes))
     assert max(worst) <= 1e-7, worst
+
+
+def test_coupled_tti_512_matches_2n_sparse_lu(helm_lib, shm_dir):
+    """Row f1 at scale: the coupled two-field Eurus system (eps != delta, eurus.py:279-295,430-464) on the 512^2 model against the
+    sparse LU of the reference-identical 2N x 2N matrix.  The true residual of this ill-conditioned system has an fp64 floor above
+    1e-10 (status 3, see include/helm.h); what must hold is the wavefield itself."""
+    import zephyr_amd as za
+    from zephyr_amd.models import marmousi_like
+    n, dx, f = 512, 10., 6.0
+    c = marmousi_like(n, n, dx)
+    src = np.stack([np.linspace(600., 4500., 4), np.full(4, 20.)], 1)
+    cfg = dict(nx=n, nz=n, dx=dx, dz=dx, c=c, nPML=10, cPML=1e3, freq=f, rtol=1e-10, **lu_worker.tti_fields(n))
+    q = za.SparseKaiserSource(cfg)(src)
+    op = za.Eurus(cfg)
+    u = op * q
+    assert u.shape == (n * n, 4)
+    info = op.lastInfo
+    assert all(i['status'] in (0, 3) and i['method'] == 4 for i in info), info
+    path = os.path.join(shm_dir, 'utti.npy')
+    np.save(path, u)
+    res = lu_worker.run_jobs([dict(n=n, dx=dx, model=('marmousi', 0), freq=f, system='eurus_2n', tti=True, src=src, ufile=path)], nproc=1)
+    worst = max(res[0]['err'])
+    print('coupled TTI 512^2: rel-L2 vs 2N LU %.2e, passes %s, relres %s, status %s'
+          % (worst, [i['iterations'] for i in info], ['%.1e' % i['relres'] for i in info], [i['status'] for i in info]))
+    assert worst <= 1e-7

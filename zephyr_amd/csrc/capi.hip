@@ -417,13 +417,15 @@ ApplyArgs batch_apply(helm_op *op, const Batch &B, const cplx *X, cplx *Y, const
     return a;
 }
 
+int launch_sys2_apply(helm_op *op, bool raw, int adjoint, const cplx *X, cplx *Y, const cplx *W, int nrhs, int epi, const RhsScal *scal, const cplx *planes_override = nullptr);
+
 // Apply of the coupled Eurus system [[M1, M2], [M3, M4]] (or its conjugate transpose) to vectors [u; v] of length 2N:
 // four stencil launches, the second of each output half accumulating into the first and carrying the fused epilogue.
 // raw = unscaled planes (true residual), otherwise the row-equilibrated system d_S.
-int launch_sys2_apply(helm_op *op, bool raw, int adjoint, const cplx *X, cplx *Y, const cplx *W, int nrhs, int epi, const RhsScal *scal) {
+int launch_sys2_apply(helm_op *op, bool raw, int adjoint, const cplx *X, cplx *Y, const cplx *W, int nrhs, int epi, const RhsScal *scal, const cplx *planes_override) {
     const long long N = op->N;
     const int nblk = helm_apply_num_blocks(op);
-    const cplx *P = raw ? op->d_C : op->d_S;
+    const cplx *P = planes_override ? planes_override : (raw ? op->d_C : op->d_S);
     if (epi == EPI_DOT_XY) { epi = EPI_DOT_WY; W = X; }
     for (int half = 0; half < 2; ++half) {
         // forward: out_half = M[half][0] in0 + M[half][1] in1 ; adjoint: out_half = M[0][half]^H in0 + M[1][half]^H in1
@@ -622,8 +624,6 @@ struct WsLease {
 
 // Sparse direct path (direct.hip): factor once per assembled operator, then per batch q' -> x by the multifrontal
 // triangular solves and iterative refinement on the true residual q' - A x (stencil kernel) until rtol is met.
-int launch_sys2_apply(helm_op *op, bool raw, int adjoint, const cplx *X, cplx *Y, const cplx *W, int nrhs, int epi, const RhsScal *scal);
-
 // sys2 != 0: the coupled two-field Eurus system [[M1, M2], [M3, M4]] on the stacked unknowns [u; v] (block ignored, two
 // unknowns per cell in the elimination tree, factors kept in slot 1); rows_in = N or 2N rows of right-hand side per source.
 int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long long row_off, cplx premul,
@@ -883,16 +883,47 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
                 for (int b = 0; b < n; ++b) extra_solves[b] += 1;
             }
         }
+        // Coupled system: where refinement has stalled above rtol, is that the floor of fp64 itself?  The residual of ANY fp64 vector x
+        // near the solution carries rounding of size eps (|A||x| + |q|) componentwise, so ||r|| / ||q|| cannot be pushed below
+        // ~ eps || |A||x| + |q| || / ||q||, whatever the solver (a backward-stable sparse LU lands there too).  Evaluated with the
+        // stencil kernel on |planes| and |x|; right-hand sides within 8x of it are reported as status 3, not as failures.
+        std::vector<int> at_floor(n, 0);
+        if (sys2) {
+            bool any = false;
+            for (int b = 0; b < n; ++b) if (!(relres[b] <= o.rtol)) any = true;
+            const size_t pbytes = (size_t)36 * N * sizeof(cplx);
+            cplx *absP = any ? (cplx *)helm_pool_alloc(op->device, pbytes) : nullptr;
+            if (any && absP) {
+                cplx *absx = r, *negq = nws, *yy = nws + (long long)n * NV;
+                rc = helm_launch_abs(op, op->d_C, absP, 36LL * N, 1.0);
+                if (!rc) rc = helm_launch_abs(op, x, absx, (long long)n * NV, 1.0);
+                if (!rc) rc = helm_launch_abs(op, q, negq, (long long)n * NV, -1.0);
+                if (!rc) rc = launch_sys2_apply(op, true, 0, absx, yy, negq, n, EPI_RESID, nullptr, absP);      // -(|q| + |A||x|)
+                if (!rc) {
+                    helm_launch_fin_ex(op, FIN_NORM, n, 2 * helm_apply_num_blocks(op), nullptr, d_aux);
+                    if (hipMemcpyAsync(h_aux, d_aux, n * sizeof(double), hipMemcpyDeviceToHost, op->stream) != hipSuccess || hipStreamSynchronize(op->stream) != hipSuccess) rc = HELM_ERR_DEVICE;
+                }
+                helm_pool_free(op->device, absP, pbytes);
+                if (rc) return rc;
+                for (int b = 0; b < n; ++b) {
+                    // ||q||^2 was left in h_aux[n + b] by the residual rounds
+                    const double qq = h_aux[n + b];
+                    const double fl = qq > 0 ? 1.1102230246251565e-16 * sqrt(h_aux[b] / qq) : 0.0;
+                    if (!(relres[b] <= o.rtol) && relres[b] <= 8.0 * fl) at_floor[b] = 1;
+                    if (nd_debug) fprintf(stderr, "[helm direct] rhs %d: relres %.3e, fp64 floor %.3e\n", first + b, relres[b], fl);
+                }
+            }
+        }
         // fault injection for the tests of the partial fallback: report the first k right-hand sides as stalled
         const int inject_stall = getenv("HELM_ND_INJECT_STALL") ? atoi(getenv("HELM_ND_INJECT_STALL")) : 0;      // read per call: the tests flip it
         for (int b = 0; b < n; ++b) {
-            const bool ok = relres[b] <= o.rtol * 1.0000001 && !(first + b < inject_stall);
+            const bool ok = (relres[b] <= o.rtol * 1.0000001 || at_floor[b]) && !(first + b < inject_stall);
             if (!ok) unconverged += 1;
             if (info) {
                 helm_solve_info &I = info[first + b];
                 I.iterations += 1 + extra_solves[b]; I.method = HELM_DIRECT;
                 I.relres = std::max(I.relres, relres[b]);
-                I.status = std::max(I.status, ok ? 0 : 1);
+                I.status = std::max(I.status, ok ? (at_floor[b] ? 3 : 0) : 1);
             }
         }
         HIP_TRY(op, hipStreamSynchronize(op->stream));

@@ -252,5 +252,6 @@ int helm_launch_zero(helm_op *op, cplx *p, long long n);
 int helm_launch_rhs_from_coo(helm_op *op, const long long *row, const int *col, const cplx *val, long long nnz, cplx *R, int nrhs, long long rows);
 int helm_launch_sample(helm_op *op, const cplx *U, int nsrc, long long ld, const long long *rowptr, const long long *col, const cplx *val, int nrec, cplx *out);
 int helm_launch_rowscale_inplace(helm_op *op, cplx *v, const double *rs, long long NV, int nrhs);
+int helm_launch_abs(helm_op *op, const cplx *in, cplx *out, long long n, double sign);      // out = sign |in|
 int helm_launch_gardner_rho(helm_op *op);     // d_rho = 310 Re(d_c)^0.25
 int helm_ensure_host_model(helm_op *op);      // h_c, h_rho, ... (downloaded from the device on first use)

@@ -455,6 +455,14 @@ __global__ __launch_bounds__(256) void k_norm2(const cplx *__restrict__ a, long 
     if (threadIdx.x == 0) part[((long long)b * 4) * nblk + blockIdx.x] = s[0];
 }
 
+// out = sign * |in| as a complex number with zero imaginary part (attainable-accuracy estimate of the coupled system)
+__global__ __launch_bounds__(256) void k_abs_cplx(const cplx *__restrict__ in, cplx *__restrict__ out, long long n, double sign) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const cplx v = in[i];
+        out[i] = cmake(sign * hypot(v.x, v.y), 0.0);
+    }
+}
+
 // U = conj(x) into a (possibly strided / offset) output
 __global__ __launch_bounds__(256) void k_finish(const cplx *__restrict__ x, cplx *__restrict__ U, long long u_ld,
                                                 long long row_off, long long N) {
@@ -896,6 +904,12 @@ int helm_launch_norm2(helm_op *op, const cplx *a, int nrhs) {
 int helm_launch_finish(helm_op *op, const cplx *x, cplx *dU, long long u_ld, int nrhs, long long row_off) {
     dim3 grid(vec_blocks(op->Nv), nrhs);
     hipLaunchKernelGGL(k_finish, grid, dim3(256), 0, op->stream, x, dU, u_ld, row_off, op->Nv);
+    HIP_TRY(op, hipGetLastError());
+    return HELM_OK;
+}
+
+int helm_launch_abs(helm_op *op, const cplx *in, cplx *out, long long n, double sign) {
+    hipLaunchKernelGGL(k_abs_cplx, dim3((unsigned)std::min<long long>((n + 255) / 256, 1 << 20)), dim3(256), 0, op->stream, in, out, n, sign);
     HIP_TRY(op, hipGetLastError());
     return HELM_OK;
 }
