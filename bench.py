@@ -29,7 +29,9 @@ F64_PEAK_TFLOPS = 78.6    # MI355X fp64 dense peak, vector FMA = MFMA f64 rate (
 
 def build_config(n, dx):
     from zephyr_amd.models import marmousi_like
-    c = marmousi_like(n, n, dx)
+    # complex128 once, here: the discretisation classes cast `c` to complex128 at construction (discretization.py:23-31), which for a
+    # float array is a 16 MB conversion per operator -- a job builds one operator per frequency from the same model
+    c = marmousi_like(n, n, dx).astype(np.complex128)
     return dict(nx=n, nz=n, dx=dx, dz=dx, c=c, nPML=10, cPML=1e3, freeSurf=(False, False, False, False))
 
 
@@ -58,8 +60,9 @@ def cpu_baseline(cfg, freqs, q_host, sample_rhs=8):
     n = cfg['nx']
     f = float(freqs[len(freqs) // 2])
     t0 = time.perf_counter()
-    rho = ho.gardner_rho(cfg['c'])
-    C4 = ho.eurus_coefficients(n, n, cfg['c'], rho, f, dx=cfg['dx'], dz=cfg['dz'], nPML=cfg['nPML'], cPML=cfg['cPML'])
+    c_real = np.ascontiguousarray(cfg['c'].real)
+    rho = ho.gardner_rho(c_real)
+    C4 = ho.eurus_coefficients(n, n, c_real, rho, f, dx=cfg['dx'], dz=cfg['dz'], nPML=cfg['nPML'], cPML=cfg['cPML'])
     op = ho.DirectOperator(C4[0])
     t1 = time.perf_counter()
     op.factor()

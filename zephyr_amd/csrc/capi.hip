@@ -63,7 +63,7 @@ int helm_events_grow(helm_op *op, int n) {
     }
     return 0;
 }
-static const size_t kPoolMinBytes = (size_t)16 << 20, kPoolCapBytes = (size_t)24 << 30;
+static const size_t kPoolMinBytes = (size_t)1 << 20, kPoolCapBytes = (size_t)24 << 30;
 
 void *helm_pool_alloc(int device, size_t bytes) {
     {
@@ -128,8 +128,10 @@ static helm_op *create_common(helm_op *op) {
     op->own_stream = true;
     const size_t N = (size_t)op->N;
     op->Nv = op->N;
-    HIP_TRY_NULL(hipMalloc(&op->d_c, N * sizeof(cplx)));
-    HIP_TRY_NULL(hipMalloc(&op->d_rho, N * sizeof(double)));
+    // model arrays come from the size-keyed pool as well: hipMalloc / hipFree of a few MB per operator is a device synchronisation each
+    op->d_c = (cplx *)helm_pool_alloc(device, N * sizeof(cplx));
+    op->d_rho = (double *)helm_pool_alloc(device, N * sizeof(double));
+    if (!op->d_c || !op->d_rho) { helm_destroy(op); helm_set_error(nullptr, "hipMalloc of the model arrays failed"); return nullptr; }
     op->d_C = (cplx *)helm_pool_alloc(device, (size_t)op->nblocks * op->nplanes * N * sizeof(cplx));
     if (!op->d_C) { helm_destroy(op); helm_set_error(nullptr, "hipMalloc of the coefficient planes failed"); return nullptr; }
     return op;
@@ -139,7 +141,8 @@ extern "C" void helm_destroy(helm_op *op) {
     if (!op) return;
     hipSetDevice(op->device);
     if (op->stream) hipStreamSynchronize(op->stream);
-    hipFree(op->d_c); hipFree(op->d_rho); hipFree(op->d_theta); hipFree(op->d_eps); hipFree(op->d_delta);
+    helm_pool_free(op->device, op->d_c, (size_t)op->N * sizeof(cplx)); helm_pool_free(op->device, op->d_rho, (size_t)op->N * sizeof(double));
+    hipFree(op->d_theta); hipFree(op->d_eps); hipFree(op->d_delta);
     {
         const size_t pb = (size_t)op->nblocks * op->nplanes * (size_t)op->N * sizeof(cplx);
         helm_pool_free(op->device, op->d_C, pb); helm_pool_free(op->device, op->d_Cs, pb);

@@ -947,15 +947,19 @@ __global__ __launch_bounds__(256) void k_prep_transpose_norm(const cplx *__restr
 //   q   : Q[cell * ldq + map(j)]   (map = qmap[j] or j)           r = q - A xin
 //   store != 0: r written back over q;  Xacc != null: Xacc[cell * ldq + map(j)] += xin  (refinement update folded in)
 //   part[(j * 4) * nblk + block] = partial ||r_j||^2
+template <int RPT>
 __global__ __launch_bounds__(256) void k_resid_nm(const cplx *__restrict__ planes, int nz, int nx, const cplx *__restrict__ Xin, int ldin,
                                                   cplx *__restrict__ Q, int ldq, const int *__restrict__ qmap, int ncol, int store,
                                                   cplx *__restrict__ Xacc, double *__restrict__ part, int nblk, int seg, int ntiles) {
+    // RPT grid rows per thread: the window is (RPT + 2) x 3, so a step along x loads RPT + 2 values for RPT outputs and the rows a tile
+    // shares with the tiles above and below (the only HBM re-reads of this kernel: 1.7 x the input at RPT = 1 by the PMC counters) shrink
+    // from 2 per output row to 2 / RPT
     __shared__ double red[256];
     const int j = threadIdx.x, ly = threadIdx.y;
     const bool act = j < ncol;
     const int col = act ? (qmap ? qmap[j] : j) : 0;
     const long long N = (long long)nz * nx;
-    const int nseg = (nx + seg - 1) / seg;
+    const int nzt = (nz + RPT - 1) / RPT;
     double acc = 0.0;
     // tile order: workgroup b serves band (b % 8) of the tile list, so that the workgroups of one XCD (b, b + 8, ...) walk
     // z-adjacent row segments together and the halo rows are served by that XCD's L2
@@ -963,36 +967,41 @@ __global__ __launch_bounds__(256) void k_resid_nm(const cplx *__restrict__ plane
     for (int w = blockIdx.x * blockDim.y + ly; w < per * 8; w += gridDim.x * blockDim.y) {
         const int t = (w & 7) * per + (w >> 3);
         if (t >= ntiles || !act) continue;
-        const int sgi = t / nz, z = t - sgi * nz;         // z fastest: consecutive tiles are vertically adjacent
+        const int sgi = t / nzt, z0 = (t - sgi * nzt) * RPT;      // z fastest: consecutive tiles are vertically adjacent
         const int x0 = sgi * seg, x1 = min(nx, x0 + seg);
-        cplx win[3][3];                                   // win[dz][.] = columns x-1, x, x+1 of row z-1+dz
+        cplx win[RPT + 2][3];                                     // win[d][.] = columns x-1, x, x+1 of row z0-1+d
         #pragma unroll
-        for (int dz = 0; dz < 3; ++dz) {
-            const int zz = z - 1 + dz;
+        for (int d = 0; d < RPT + 2; ++d) {
+            const int zz = z0 - 1 + d;
             const bool zin = zz >= 0 && zz < nz;
-            win[dz][0] = cmake(0.0, 0.0);
-            win[dz][1] = (zin && x0 - 1 >= 0) ? Xin[((long long)zz * nx + x0 - 1) * ldin + j] : cmake(0.0, 0.0);
-            win[dz][2] = zin ? Xin[((long long)zz * nx + x0) * ldin + j] : cmake(0.0, 0.0);
+            win[d][0] = cmake(0.0, 0.0);
+            win[d][1] = (zin && x0 - 1 >= 0) ? Xin[((long long)zz * nx + x0 - 1) * ldin + j] : cmake(0.0, 0.0);
+            win[d][2] = zin ? Xin[((long long)zz * nx + x0) * ldin + j] : cmake(0.0, 0.0);
         }
         for (int x = x0; x < x1; ++x) {
             #pragma unroll
-            for (int dz = 0; dz < 3; ++dz) {
-                const int zz = z - 1 + dz;
-                win[dz][0] = win[dz][1]; win[dz][1] = win[dz][2];
-                win[dz][2] = (zz >= 0 && zz < nz && x + 1 < nx) ? Xin[((long long)zz * nx + x + 1) * ldin + j] : cmake(0.0, 0.0);
+            for (int d = 0; d < RPT + 2; ++d) {
+                const int zz = z0 - 1 + d;
+                win[d][0] = win[d][1]; win[d][1] = win[d][2];
+                win[d][2] = (zz >= 0 && zz < nz && x + 1 < nx) ? Xin[((long long)zz * nx + x + 1) * ldin + j] : cmake(0.0, 0.0);
             }
-            const long long cell = (long long)z * nx + x;
-            cplx r = Q[cell * ldq + col];
             #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const cplx c = planes[(long long)k * N + cell];
-                const cplx xv = win[k / 3][k % 3];
-                r.x = fma(-c.x, xv.x, r.x); r.x = fma(c.y, xv.y, r.x);
-                r.y = fma(-c.x, xv.y, r.y); r.y = fma(-c.y, xv.x, r.y);
+            for (int o = 0; o < RPT; ++o) {
+                const int z = z0 + o;
+                if (z >= nz) break;
+                const long long cell = (long long)z * nx + x;
+                cplx r = Q[cell * ldq + col];
+                #pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const cplx c = planes[(long long)k * N + cell];
+                    const cplx xv = win[o + k / 3][k % 3];
+                    r.x = fma(-c.x, xv.x, r.x); r.x = fma(c.y, xv.y, r.x);
+                    r.y = fma(-c.x, xv.y, r.y); r.y = fma(-c.y, xv.x, r.y);
+                }
+                if (store) Q[cell * ldq + col] = r;
+                if (Xacc) { cplx *xa = Xacc + cell * ldq + col; *xa = cadd(*xa, win[o + 1][1]); }
+                acc += cabs2(r);
             }
-            if (store) Q[cell * ldq + col] = r;
-            if (Xacc) { cplx *xa = Xacc + cell * ldq + col; *xa = cadd(*xa, win[1][1]); }
-            acc += cabs2(r);
         }
     }
     if (blockDim.y > 1) {
@@ -1133,6 +1142,9 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
         vsel = a7 < a6 ? 7 : 6;
         latency_mode = true;
     }
+    // forward-gather launches are HBM-bound and every row-tile repeats the three-source gather of the B rows: one row-tile per front
+    // wherever the front has at most 64 rows, whatever the padding costs in flops
+    if (rows && rows->fwd3 && M <= 64 && !latency_mode) vsel = 0;
     if (g_gemm_tile >= 0) { vsel = g_gemm_tile & 7; latency_mode = false; }
     // tile shapes of the MFMA kernel: pick the one that pads M x N the least (ties: the larger tile)
     static const int cfg_tm[4] = {64, 48, 32, 16}, cfg_tn[4] = {64, 128, 128, 256};
@@ -1589,7 +1601,10 @@ int nd_resid_nm(helm_op *op, const cplx *planes, const cplx *Xin, int ldin, cplx
     while (lx < ncol && lx < 256) lx <<= 1;
     const int ly = 256 / lx;
     const int seg = 32;
-    const int ntiles = op->nz * ((op->nx + seg - 1) / seg);
+    // rows per thread: measured on 1024^2 x 256 (norm-only launch): 1 -> 2.52 ms, 2 -> 3.71 ms, 4 -> 2.23 ms
+    static const int rpt_env = getenv("HELM_ND_RESID_RPT") ? atoi(getenv("HELM_ND_RESID_RPT")) : 4;
+    const int rpt = (rpt_env == 1 || rpt_env == 2 || rpt_env == 8) ? rpt_env : 4;
+    const int ntiles = ((op->nz + rpt - 1) / rpt) * ((op->nx + seg - 1) / seg);
     const int nblk = std::max(1, std::min((ntiles + ly - 1) / ly, std::min(nblk_cap, 2048)));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (op->profiling) {
@@ -1599,13 +1614,17 @@ int nd_resid_nm(helm_op *op, const cplx *planes, const cplx *Xin, int ldin, cplx
     if (e0) hipEventRecord(e0, op->stream);
     for (int c0 = 0; c0 < ncol; c0 += 256) {          // more than 256 columns: one launch per 256 (partials of later chunks follow the first)
         const int nc = std::min(256, ncol - c0);
-        hipLaunchKernelGGL(k_resid_nm, dim3(nblk), dim3(lx, ly), 0, op->stream, planes, op->nz, op->nx, Xin + c0, ldin, Q + (qmap ? 0 : c0), ldq, qmap ? qmap + c0 : nullptr, nc, store,
-                           Xacc ? Xacc + (qmap ? 0 : c0) : nullptr, part + (long long)c0 * 4 * nblk, nblk, seg, ntiles);
+#define RESID_LAUNCH(RPT_) hipLaunchKernelGGL(k_resid_nm<RPT_>, dim3(nblk), dim3(lx, ly), 0, op->stream, planes, op->nz, op->nx, Xin + c0, ldin, Q + (qmap ? 0 : c0), ldq, \
+                           qmap ? qmap + c0 : nullptr, nc, store, Xacc ? Xacc + (qmap ? 0 : c0) : nullptr, part + (long long)c0 * 4 * nblk, nblk, seg, ntiles)
+        if (rpt == 1) RESID_LAUNCH(1); else if (rpt == 2) RESID_LAUNCH(2); else if (rpt == 8) RESID_LAUNCH(8); else RESID_LAUNCH(4);
+#undef RESID_LAUNCH
     }
     if (e0) {
         hipEventRecord(e1, op->stream);
-        // algorithmic bytes: the stencil apply N (32 B + 144) plus the operand q it must read (16 N B)
-        op->ev_pending.push_back(std::make_pair((int)op->ev_used, (double)op->N * (32.0 * ncol + 144.0 + 16.0 * ncol)));
+        // algorithmic bytes of what this launch has to move (SURVEY.md 8(d) convention: operands once, halo re-reads not counted):
+        // the input columns and q (16 B each per point and column), the nine coefficients (144 B per point); r written only when it
+        // is stored (+16), the refinement update reads and writes x (+32)
+        op->ev_pending.push_back(std::make_pair((int)op->ev_used, (double)op->N * ((32.0 + (store ? 16.0 : 0.0) + (Xacc ? 32.0 : 0.0)) * ncol + 144.0)));
         op->ev_used += 2;
     }
     *nblk_out = nblk;
