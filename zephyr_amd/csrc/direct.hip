@@ -20,8 +20,9 @@
 //   accuracy  pivoting is confined to the 32x32 base blocks, so one or two steps of iterative refinement with
 //             the stencil kernel (capi.hip) bring the residual to the requested tolerance.
 //
-// All dense arithmetic is fp64 complex on the vector ALUs (MI355X: fp64 MFMA rate == fp64 vector FMA rate, so
-// MFMA buys nothing here); the solve phase is bound by reading the factors and the right-hand sides from HBM.
+// All dense arithmetic is fp64 complex on the vector ALUs.  Measured (tools/fp64_rate.hip): the fp64 MFMA and the vector FMAs share one
+// throughput on MI355X (46-50 against 45-49 TFLOP/s for this instruction mix, and they do not add up when mixed), so an MFMA kernel buys
+// nothing -- the one round 1 carried was 10 % slower and is gone.  The lower solve levels are bound by moving ring rows through HBM.
 #include "helm_internal.hpp"
 #include "direct.hpp"
 #include <algorithm>
@@ -546,114 +547,6 @@ void launch_vec2(hipStream_t st, int idx, int nb, int M, int Nn, int K, cplx alp
     else hipLaunchKernelGGL((k_zgemm2<TM, 0, RN, KS, UNR, OCC>), grid, dim3(256), 0, st, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
 }
 
-// ---- the same GEMM on the matrix cores -------------------------------------------------------------------------
-// v_mfma_f64_16x16x4_f64: lane l holds A[l & 15][l >> 4] and B[l >> 4][l & 15]; result register r of lane l is
-// C[(l >> 4) + 4 r][l & 15].  A complex product is four real MFMAs on the (re, im) planes of the same lane data:
-//   Cre += Are Bre - Aim Bim ;  Cim += Are Bim + Aim Bre.
-// fp64 MFMA issues at the same flop rate as the vector FMAs, but one LDS read of 16 B per lane feeds 1024 real
-// multiply-adds instead of 16, so the kernel is no longer bound by LDS bandwidth (the vector tile kernel is).
-// Block = 4 waves arranged WM x WN; each wave owns RA x RB blocks of 16 x 16; tile = (16 RA WM) x (16 RB WN).
-typedef double v4f64 __attribute__((ext_vector_type(4)));
-template <int RA, int RB, int WM, int WN, bool IDX>
-__global__ __launch_bounds__(256) void k_zgemm_mfma(int M, int Nn, int K, cplx alpha, const cplx *A0, int lda, long long sa,
-                                                    const cplx *B0, int ldb, long long sb, cplx beta, cplx *C0, int ldc, long long sc, GemmRows R) {
-    constexpr int TM = 16 * RA * WM, TN = 16 * RB * WN;
-    constexpr int NA = (TM * GB_K + 255) / 256, NB = (TN * GB_K + 255) / 256;
-    __shared__ cplx As[GB_K][TM + 1];
-    __shared__ cplx Bs[GB_K][TN + 1];
-    __shared__ int kidx[IDX ? GB_KIDX : 1];
-    const cplx *A = A0 + (long long)blockIdx.z * sa;
-    const cplx *B = B0 + (long long)blockIdx.z * sb;
-    cplx *C = C0 + (long long)blockIdx.z * sc;
-    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const long long trow = IDX ? (long long)(R.z0 + blockIdx.z) * R.tab_stride : 0;
-    const bool idxB = IDX && R.tabB != nullptr;
-    if (idxB) {
-        for (int k = tid; k < K; k += 256) kidx[k] = R.tabB[trow + R.offB + k].x;
-        __syncthreads();
-    }
-    v4f64 cre[RA][RB], cim[RA][RB];
-    #pragma unroll
-    for (int i = 0; i < RA; ++i)
-        #pragma unroll
-        for (int j = 0; j < RB; ++j) { cre[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0}; cim[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0}; }
-    cplx ra[NA], rb[NB];
-    ZG_FETCH(0)
-    const int lr = lane & 15, lk = lane >> 4;
-    for (int k0 = 0; k0 < K; k0 += GB_K) {
-        #pragma unroll
-        for (int e = 0; e < NA; ++e) { const int idx = tid + e * 256; if (idx < TM * GB_K) As[idx & 7][idx >> 3] = ra[e]; }
-        #pragma unroll
-        for (int e = 0; e < NB; ++e) { const int idx = tid + e * 256; if (idx < TN * GB_K) Bs[idx / TN][idx % TN] = rb[e]; }
-        __syncthreads();
-        if (k0 + GB_K < K) { ZG_FETCH(k0 + GB_K) }
-        #pragma unroll
-        for (int kk = 0; kk < GB_K; kk += 4) {
-            cplx a[RA], b[RB];
-            #pragma unroll
-            for (int i = 0; i < RA; ++i) a[i] = As[kk + lk][(wm * RA + i) * 16 + lr];
-            #pragma unroll
-            for (int j = 0; j < RB; ++j) b[j] = Bs[kk + lk][(wn * RB + j) * 16 + lr];
-            // four sweeps over the RA x RB accumulator blocks, so that two MFMAs on the same accumulator are 2 RA RB - 1
-            // instructions apart (back-to-back dependent MFMAs stall for the full pass latency)
-            #pragma unroll
-            for (int i = 0; i < RA; ++i)
-                #pragma unroll
-                for (int j = 0; j < RB; ++j) {
-                    cre[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, cre[i][j], 0, 0, 0);
-                    cim[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].y, cim[i][j], 0, 0, 0);
-                }
-            #pragma unroll
-            for (int i = 0; i < RA; ++i)
-                #pragma unroll
-                for (int j = 0; j < RB; ++j) {
-                    cre[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[i].y, b[j].y, cre[i][j], 0, 0, 0);
-                    cim[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].x, cim[i][j], 0, 0, 0);
-                }
-        }
-        __syncthreads();
-    }
-    const bool b0 = (beta.x == 0.0 && beta.y == 0.0);
-    #pragma unroll
-    for (int i = 0; i < RA; ++i)
-        #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = m0 + (wm * RA + i) * 16 + lk + 4 * r;
-            if (row >= M) continue;
-            cplx *dst = C + (long long)row * ldc;
-            const cplx *cin = dst;
-            if (IDX && R.tabCo) {
-                const int ix = R.tabCo[trow + R.offCo + row].x;
-                if (ix < 0) continue;
-                dst = R.Cox + (long long)ix * R.ldx;
-            }
-            if (IDX && R.tabCi && !b0) {
-                const int ix = R.tabCi[trow + R.offCi + row].x;
-                cin = ix >= 0 ? R.Cix + (long long)ix * R.ldx : nullptr;
-            }
-            #pragma unroll
-            for (int j = 0; j < RB; ++j) {
-                const int cc = n0 + (wn * RB + j) * 16 + lr;
-                if (cc >= Nn) continue;
-                cplx v = cmul(alpha, cmake(cre[i][j][r], cim[i][j][r]));
-                if (!b0 && cin) v = cadd(v, cmul(beta, cin[cc]));
-                dst[cc] = v;
-            }
-        }
-}
-
-template <int RA, int RB, int WM, int WN>
-void launch_mfma(hipStream_t st, dim3 grid, bool idx, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, long long sa, const cplx *B, int ldb, long long sb,
-                 cplx beta, cplx *C, int ldc, long long sc, const GemmRows &R) {
-    if (idx) hipLaunchKernelGGL((k_zgemm_mfma<RA, RB, WM, WN, true>), grid, dim3(256), 0, st, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
-    else hipLaunchKernelGGL((k_zgemm_mfma<RA, RB, WM, WN, false>), grid, dim3(256), 0, st, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
-}
-
-// ---- in-place inverse of n x n blocks, n <= 64: Gauss-Jordan with row pivoting in LDS, one workgroup per matrix ----
-// (bottom of the recursive block inversion: 32 by default; 64 (HELM_ND_GJ=64) halves the number of small GEMM launches
-// and gains a digit of accuracy, but its 64-step elimination is slower overall: 41.8 vs 35.9 ms per factorisation at 1024^2)
 #define GJ_MAX 64
 // Gauss-Jordan with row pivoting on an n x n matrix held in LDS (all threads of the workgroup call it; a is valid on return
 // after the trailing barrier)
@@ -1096,8 +989,10 @@ __global__ void k_axpy_one(cplx *y, const cplx *x, long long n, int conj) {
 int g_gemm_variant = -1;        // >= 0: overrides HELM_ND_GEMMV (helm_debug_zgemm_bench)
 int g_gemm_tile = -1;           // >= 0: forces the tile configuration (helm_debug_zgemm_bench)
 int gemm_variant() {
-    // 0: first-generation kernel; v2 kernel: 1: K slab 8, 2: K slab 16, 3: K slab 8 + k loop unrolled twice, 4: K slab 16 unrolled twice,
-    // 5: K slab 8 with the register budget of 4 waves per SIMD
+    // 0: first-generation kernel (kept for before / after comparisons); 1: second-generation kernel, K slab 8; 6: K slab 32 on the 1-column
+    // tiles.  Measured and dropped (profiles/r02_zgemm_lab_variants.txt): K slab 16 (occupancy 2), k loop unrolled twice (+1-2 %, 166 VGPRs),
+    // a 4-waves-per-SIMD register budget (spills), and a 3M complex product (48 FMAs for 64 per k step but 192 VGPRs and twelve more LDS
+    // reads: 3 % SLOWER on the large shapes, and its rounding pushed two more of the 16 bench frequencies over rtol into a second pass)
     static const int gemm_v = getenv("HELM_ND_GEMMV") ? atoi(getenv("HELM_ND_GEMMV")) : 1;
     return g_gemm_variant >= 0 ? g_gemm_variant : gemm_v;
 }
@@ -1116,7 +1011,6 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
     }
     if (e0) hipEventRecord(e0, st);
     if (in_run && e0) { op->gemm_run_pair = (int)op->ev_used; op->ev_used += 2; }
-    static const int use_mfma = getenv("HELM_ND_MFMA") ? atoi(getenv("HELM_ND_MFMA")) : 0;
     static const int fixed_tm = getenv("HELM_ND_TM") ? atoi(getenv("HELM_ND_TM")) : 0;
     // tile of the vector kernel: 4 x RN outputs per thread, TM x TN = TM x (1024 / TM * RN).  The padded area is weighed by how
     // well a register block re-uses its LDS reads (4 x 4: 1, 4 x 2: 0.7, 4 x 1: 0.45): narrow tiles only win on small outputs
@@ -1146,38 +1040,17 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
     // wherever the front has at most 64 rows, whatever the padding costs in flops
     if (rows && rows->fwd3 && M <= 64 && !latency_mode) vsel = 0;
     if (g_gemm_tile >= 0) { vsel = g_gemm_tile & 7; latency_mode = false; }
-    // tile shapes of the MFMA kernel: pick the one that pads M x N the least (ties: the larger tile)
-    static const int cfg_tm[4] = {64, 48, 32, 16}, cfg_tn[4] = {64, 128, 128, 256};
-    int best = 0; long long best_area = -1;
-    for (int c = 0; c < 4; ++c) {
-        const long long area = (long long)((M + cfg_tm[c] - 1) / cfg_tm[c]) * cfg_tm[c] * ((Nn + cfg_tn[c] - 1) / cfg_tn[c]) * cfg_tn[c];
-        if (best_area < 0 || area < best_area) { best = c; best_area = area; }
-    }
     for (int b0 = 0; b0 < batch; b0 += 65535) {
         const int nb = std::min(65535, batch - b0);
         GemmRows R; if (rows) R = *rows;
         R.z0 = b0;
         const cplx *Ab = A + b0 * sa, *Bb = B ? B + b0 * sb : B;
         cplx *Cb = C ? C + b0 * sc : C;
-        if (use_mfma) {
-            dim3 grid((Nn + cfg_tn[best] - 1) / cfg_tn[best], (M + cfg_tm[best] - 1) / cfg_tm[best], nb);
-            switch (best) {
-                case 0: launch_mfma<2, 2, 2, 2>(st, grid, rows != nullptr, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R); break;
-                case 1: launch_mfma<3, 2, 1, 4>(st, grid, rows != nullptr, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R); break;
-                case 2: launch_mfma<2, 2, 1, 4>(st, grid, rows != nullptr, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R); break;
-                default: launch_mfma<1, 4, 1, 4>(st, grid, rows != nullptr, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R); break;
-            }
-            continue;
-        }
         // (a 4 x 8 register block per thread -- RN = 8, 64 x 128 tile -- was measured too: 230 VGPRs, occupancy 2, 38 % slower)
         const int gv = gemm_variant();
 #define ZG_ARGS st, (rows ? (rows->fwd3 ? 2 : 1) : 0), nb, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R
 #define ZG_VEC(TM_, RN_) do { switch (gv) { \
             case 0: launch_vec<TM_, RN_>(ZG_ARGS); break; \
-            case 2: launch_vec2<TM_, RN_, 16, 1, 1>(ZG_ARGS); break; \
-            case 3: launch_vec2<TM_, RN_, 8, 2, 1>(ZG_ARGS); break; \
-            case 4: launch_vec2<TM_, RN_, 16, 2, 1>(ZG_ARGS); break; \
-            case 5: launch_vec2<TM_, RN_, 8, 1, 4>(ZG_ARGS); break; \
             case 6: launch_vec2<TM_, RN_, (RN_ == 1 ? 32 : (RN_ == 2 ? 16 : 8)), 1, 1>(ZG_ARGS); break; \
             default: launch_vec2<TM_, RN_, 8, 1, 1>(ZG_ARGS); break; } } while (0)
         if (latency_mode && gv != 0) {
