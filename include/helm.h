@@ -82,7 +82,7 @@ typedef struct helm_solve_opts {
 
 typedef struct helm_solve_info {
     int iterations;    /* iterations used by this right-hand side (HELM_DIRECT: triangular solves incl. refinement) */
-    int status;        /* 0 converged, 1 iteration cap / stalled above rtol, 2 breakdown (not recovered), 3 coupled TTI system only:
+    int status;        /* 0 converged, 1 iteration cap / stalled above rtol, 2 breakdown (not recovered), 3 direct path (in practice the coupled TTI system):
                         * the true residual has reached the floor fp64 allows for this right-hand side, relres <= 8 eps || |A||x| + |q| || / ||q||,
                         * which lies above rtol -- no fp64 vector does better (a backward-stable LU lands on the same floor); counted as solved */
     int restarts;      /* BiCGSTAB restarts taken */

@@ -329,3 +329,20 @@ def test_direct_many_right_hand_sides_in_batches(helm_lib):
     assert nrm(u, ref) <= 1e-9
     assert len(op.lastInfo) == 300 and all(i['status'] == 0 for i in op.lastInfo)
     assert op.lastTiming()['factor_ms'] > 0            # one factorisation for all three batches
+
+
+def test_unreachable_rtol_reports_fp64_floor(helm_lib):
+    """rtol below what fp64 can represent: refinement stalls, the library evaluates the floor eps (|| |A||x| || + ||q||) / ||q|| of the true
+    residual and reports the right-hand sides that sit on it as status 3 (solved to the precision the arithmetic has), not as failures."""
+    import zephyr_amd as za
+    nz, nx = 96, 120
+    rng = np.random.default_rng(21)
+    c = 1800. + 2200. * rng.random((nz, nx))
+    cfg = dict(nx=nx, nz=nz, dx=10., dz=10., c=c, freq=9., nPML=8, rtol=1e-17, method='direct')
+    q = za.SimpleSource(cfg)(np.array([[300., 320.], [800., 500.]]))
+    op = za.Eurus(cfg)
+    u = op * q                                   # does not raise
+    assert [i['status'] for i in op.lastInfo] == [3, 3], op.lastInfo
+    assert all(1e-17 < i['relres'] < 1e-12 for i in op.lastInfo), op.lastInfo
+    ref = ho.DirectOperator(ho.eurus_coefficients(nz, nx, c, ho.gardner_rho(c.astype(complex)), 9., dx=10., dz=10., nPML=8), eurus=True) * q
+    assert nrm(u, ref) <= 1e-9

@@ -838,12 +838,12 @@ __global__ __launch_bounds__(256) void k_prep_transpose_norm(const cplx *__restr
 // a thread marches along x over `seg` cells of one grid row with a 3 x 3 register window of the input columns.
 //   in  : Xin[cell * ldin + j]                                  (the solution, or a refinement correction)
 //   q   : Q[cell * ldq + map(j)]   (map = qmap[j] or j)           r = q - A xin
-//   store != 0: r written back over q;  Xacc != null: Xacc[cell * ldq + map(j)] += xin  (refinement update folded in)
+//   store != 0: r written to Rout (same indexing as q; Rout == null: over q)
 //   part[(j * 4) * nblk + block] = partial ||r_j||^2
 template <int RPT>
 __global__ __launch_bounds__(256) void k_resid_nm(const cplx *__restrict__ planes, int nz, int nx, const cplx *__restrict__ Xin, int ldin,
                                                   cplx *__restrict__ Q, int ldq, const int *__restrict__ qmap, int ncol, int store,
-                                                  cplx *__restrict__ Xacc, double *__restrict__ part, int nblk, int seg, int ntiles) {
+                                                  cplx *__restrict__ Rout, double *__restrict__ part, int nblk, int seg, int ntiles) {
     // RPT grid rows per thread: the window is (RPT + 2) x 3, so a step along x loads RPT + 2 values for RPT outputs and the rows a tile
     // shares with the tiles above and below (the only HBM re-reads of this kernel: 1.7 x the input at RPT = 1 by the PMC counters) shrink
     // from 2 per output row to 2 / RPT
@@ -891,8 +891,7 @@ __global__ __launch_bounds__(256) void k_resid_nm(const cplx *__restrict__ plane
                     r.x = fma(-c.x, xv.x, r.x); r.x = fma(c.y, xv.y, r.x);
                     r.y = fma(-c.x, xv.y, r.y); r.y = fma(-c.y, xv.x, r.y);
                 }
-                if (store) Q[cell * ldq + col] = r;
-                if (Xacc) { cplx *xa = Xacc + cell * ldq + col; *xa = cadd(*xa, win[o + 1][1]); }
+                if (store) (Rout ? Rout : Q)[cell * ldq + col] = r;
                 acc += cabs2(r);
             }
         }
@@ -903,6 +902,15 @@ __global__ __launch_bounds__(256) void k_resid_nm(const cplx *__restrict__ plane
         if (ly == 0) for (int q = 1; q < (int)blockDim.y; ++q) acc += red[q * blockDim.x + j];
     }
     if (ly == 0 && act) part[((long long)j * 4) * nblk + blockIdx.x] = acc;
+}
+
+// Xt[cell][cols[j]] += Dp[cell][j]  (corrections of the packed minority batch back into the full batch)
+__global__ __launch_bounds__(256) void k_scatter_add_cols(cplx *__restrict__ Xt, int ldq, const int *__restrict__ cols, int k, const cplx *__restrict__ Dp, long long N) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < N * k; e += (long long)gridDim.x * blockDim.x) {
+        const long long cell = e / k; const int j = (int)(e - cell * k);
+        cplx *x = Xt + cell * ldq + cols[j];
+        *x = cadd(*x, Dp[e]);
+    }
 }
 
 // Rp[cell][j] = Qt[cell][cols[j]]  (the right-hand sides that need another pass, packed to a narrower batch)
@@ -1468,7 +1476,7 @@ int nd_prep_transpose_norm(helm_op *op, const cplx *rhs, long long rhs_ld, long 
 }
 
 // r = q - A xin node-major (see k_resid_nm); ncol columns of Xin (leading dimension ldin); returns the partial count per column
-int nd_resid_nm(helm_op *op, const cplx *planes, const cplx *Xin, int ldin, cplx *Q, int ldq, const int *qmap, int ncol, int store, cplx *Xacc,
+int nd_resid_nm(helm_op *op, const cplx *planes, const cplx *Xin, int ldin, cplx *Q, int ldq, const int *qmap, int ncol, int store, cplx *Rout,
                 double *part, int nblk_cap, int *nblk_out) {
     int lx = 64;
     while (lx < ncol && lx < 256) lx <<= 1;
@@ -1488,7 +1496,7 @@ int nd_resid_nm(helm_op *op, const cplx *planes, const cplx *Xin, int ldin, cplx
     for (int c0 = 0; c0 < ncol; c0 += 256) {          // more than 256 columns: one launch per 256 (partials of later chunks follow the first)
         const int nc = std::min(256, ncol - c0);
 #define RESID_LAUNCH(RPT_) hipLaunchKernelGGL(k_resid_nm<RPT_>, dim3(nblk), dim3(lx, ly), 0, op->stream, planes, op->nz, op->nx, Xin + c0, ldin, Q + (qmap ? 0 : c0), ldq, \
-                           qmap ? qmap + c0 : nullptr, nc, store, Xacc ? Xacc + (qmap ? 0 : c0) : nullptr, part + (long long)c0 * 4 * nblk, nblk, seg, ntiles)
+                           qmap ? qmap + c0 : nullptr, nc, store, Rout ? Rout + (qmap ? 0 : c0) : nullptr, part + (long long)c0 * 4 * nblk, nblk, seg, ntiles)
         if (rpt == 1) RESID_LAUNCH(1); else if (rpt == 2) RESID_LAUNCH(2); else if (rpt == 8) RESID_LAUNCH(8); else RESID_LAUNCH(4);
 #undef RESID_LAUNCH
     }
@@ -1496,12 +1504,17 @@ int nd_resid_nm(helm_op *op, const cplx *planes, const cplx *Xin, int ldin, cplx
         hipEventRecord(e1, op->stream);
         // algorithmic bytes of what this launch has to move (SURVEY.md 8(d) convention: operands once, halo re-reads not counted):
         // the input columns and q (16 B each per point and column), the nine coefficients (144 B per point); r written only when it
-        // is stored (+16), the refinement update reads and writes x (+32)
-        op->ev_pending.push_back(std::make_pair((int)op->ev_used, (double)op->N * ((32.0 + (store ? 16.0 : 0.0) + (Xacc ? 32.0 : 0.0)) * ncol + 144.0)));
+        // is stored (+16)
+        op->ev_pending.push_back(std::make_pair((int)op->ev_used, (double)op->N * ((32.0 + (store ? 16.0 : 0.0)) * ncol + 144.0)));
         op->ev_used += 2;
     }
     *nblk_out = nblk;
     return check_kernels(op, "node-major residual");
+}
+
+int nd_scatter_add_cols(helm_op *op, cplx *Xt, int ldq, const int *d_cols, int k, const cplx *Dp, long long N) {
+    hipLaunchKernelGGL(k_scatter_add_cols, dim3((unsigned)std::min<long long>((N * k + 255) / 256, 1 << 20)), dim3(256), 0, op->stream, Xt, ldq, d_cols, k, Dp, N);
+    return check_kernels(op, "column scatter");
 }
 
 int nd_pack_cols(helm_op *op, const cplx *Qt, int ldq, const int *d_cols, int k, cplx *Rp, long long N) {

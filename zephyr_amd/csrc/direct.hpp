@@ -108,8 +108,9 @@ int nd_axpy_one(helm_op *op, cplx *y, const cplx *x, long long n, int conj = 0);
 int nd_solve_nm(helm_op *op, NdFactor *f, const cplx *Qt, cplx *Xt, int nrhs, cplx *arenaV);
 int nd_prep_transpose_norm(helm_op *op, const cplx *rhs, long long rhs_ld, long long row_off, cplx premul, const cplx *sub, cplx *Qt, long long N, int nrhs,
                            double *part, int nblk_cap, int *nblk_out);     // nblk_cap: partials per right-hand side the buffer has room for
-int nd_resid_nm(helm_op *op, const cplx *planes, const cplx *Xin, int ldin, cplx *Q, int ldq, const int *qmap, int ncol, int store, cplx *Xacc,
-                double *part, int nblk_cap, int *nblk_out);
+int nd_resid_nm(helm_op *op, const cplx *planes, const cplx *Xin, int ldin, cplx *Q, int ldq, const int *qmap, int ncol, int store, cplx *Rout,
+                double *part, int nblk_cap, int *nblk_out);      // r = q - A xin; store: r -> Rout (null: over q)
+int nd_scatter_add_cols(helm_op *op, cplx *Xt, int ldq, const int *d_cols, int k, const cplx *Dp, long long N);
 int nd_pack_cols(helm_op *op, const cplx *Qt, int ldq, const int *d_cols, int k, cplx *Rp, long long N);
 int nd_transpose_out(helm_op *op, const cplx *Xt, long long N, int nrhs, cplx *U, int conj);
 
