@@ -678,8 +678,15 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
         if (rc) return rc;
     }
     static const int overlap = getenv("HELM_ND_OVERLAP") ? atoi(getenv("HELM_ND_OVERLAP")) : 0;
+    static const int use_nm = getenv("HELM_ND_NM") ? atoi(getenv("HELM_ND_NM")) : 1;
+    // node-major pipeline: the forward elimination of the first batch may run beside the factorisation (HELM_ND_OVERLAP_NM)
+    // -- measured on the 16-frequency job: 44.9 -> 43.8 ms per work item; the factorisation itself stretches from 17.6 to 22.2 ms under
+    // the competing launches but 5 ms of forward pass disappear behind it.  Not while per-launch profiling is on: HIP events around
+    // kernels that share the chip with another stream measure the sharing, not the kernel (HELM_ND_OVERLAP_NM=2 forces it anyway).
+    static const int overlap_nm = getenv("HELM_ND_OVERLAP_NM") ? atoi(getenv("HELM_ND_OVERLAP_NM")) : 1;
+    const bool nm_overlap = need_factor && (overlap_nm == 2 || (overlap_nm == 1 && !op->profiling)) && use_nm && !sys2 && !overlap;
     bool factor_pending = need_factor;
-    if (need_factor && !overlap) {
+    if (need_factor && !overlap && !nm_overlap) {
         hipEvent_t f0, f1;
         HIP_TRY(op, hipEventCreate(&f0)); HIP_TRY(op, hipEventCreate(&f1));
         hipEventRecord(f0, op->stream);
@@ -694,7 +701,10 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
         factor_pending = false;
     }
     if (factor_pending && !op->side_stream) {
-        if (hipStreamCreateWithFlags(&op->side_stream, hipStreamNonBlocking) != hipSuccess) HELM_FAIL(op, HELM_ERR_DEVICE, "hipStreamCreate failed");
+        // lowest priority: the forward pass that runs beside the factorisation must not delay the factorisation's chain of small launches
+        int plo = 0, phi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
+        if (hipStreamCreateWithPriority(&op->side_stream, hipStreamNonBlocking, plo) != hipSuccess) HELM_FAIL(op, HELM_ERR_DEVICE, "hipStreamCreate failed");
     }
     rc = ensure_part(op, Bmax);
     if (rc) return rc;
@@ -708,8 +718,7 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
     int unconverged = 0;
     // Node-major pipeline (single-block systems): the right-hand sides are transposed once on the way in (fused with premul /
     // the norm), stay [cell][rhs] through solve, true residual and refinement, and are transposed once on the way out.
-    static const int use_nm = getenv("HELM_ND_NM") ? atoi(getenv("HELM_ND_NM")) : 1;
-    const bool nm = use_nm && !sys2 && !factor_pending;
+    const bool nm = use_nm && !sys2 && (!factor_pending || nm_overlap);
     for (int first = 0; nm && first < nrhs; first += Bmax) {
         const int n = std::min(Bmax, nrhs - first);
         const NdPlan &P = f->pd->plan;
@@ -725,8 +734,17 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
         rc = nd_prep_transpose_norm(op, rhs_b, rhs_ld, row_off, premul, sub_b, Qt, N, n, (double *)op->d_part, nblk, &nb_part);
         if (rc) return rc;
         helm_launch_fin_ex(op, FIN_NORM, n, nb_part, nullptr, d_aux + n);           // ||q'||^2
-        rc = nd_solve_nm(op, f, Qt, Xt, n, arenaV);
-        if (rc) return rc;
+        if (factor_pending) {
+            float fms = 0.f;
+            rc = nd_factor_solve_nm(op, block, f, ws_factor, nullptr, Qt, Xt, n, arenaV, op->side_stream, &fms);
+            if (rc) return rc;
+            op->direct[slot] = f; fresh.p = nullptr;
+            op->timing.factor_ms += fms;
+            factor_pending = false;
+        } else {
+            rc = nd_solve_nm(op, f, Qt, Xt, n, arenaV);
+            if (rc) return rc;
+        }
         std::vector<double> relres(n, 0.0), qq(n, 0.0);
         std::vector<int> extra_solves(n, 0);
         double prev_worst = 0.0;

@@ -1467,6 +1467,48 @@ int nd_solve_nm(helm_op *op, NdFactor *f, const cplx *Qt, cplx *Xt, int nrhs, cp
     return check_kernels(op, "solve kernels");
 }
 
+// Factorisation with the forward elimination of one batch running beside it: the forward pass of a tree level only needs that
+// level's factors, so it follows the factorisation level by level on a second, LOW-priority stream.  The top of the tree is a chain of
+// small dependent launches (80 block steps of a 16-workgroup panel kernel + one update each) that leaves most of the chip idle; the
+// forward pass of the lower levels (big HBM-bound launches) fills it, and the priorities keep it from delaying the chain.
+int nd_factor_solve_nm(helm_op *op, int block, NdFactor *f, cplx *ws_factor, const cplx *planes_in, const cplx *Qt, cplx *Xt, int nrhs, cplx *arenaV,
+                       hipStream_t side, float *factor_ms) {
+    const NdPlan &P = f->pd->plan;
+    hipStream_t main = op->stream;
+    const cplx *planes = nullptr;
+    int rc = factor_prologue(op, block, f, planes_in, &planes);
+    if (rc) return rc;
+    SolveCtx c = solve_ctx(f, Xt, nrhs);
+    c.Qt = Qt; c.Xt = Xt; c.arenaV = arenaV;
+    const size_t ng = P.groups.size();
+    std::vector<hipEvent_t> ev(ng + 2);
+    for (auto &e : ev) HIP_TRY(op, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipEvent_t t0, t1;
+    HIP_TRY(op, hipEventCreate(&t0)); HIP_TRY(op, hipEventCreate(&t1));
+    hipEventRecord(ev[ng], main);                 // the right-hand sides were prepared on the main stream
+    hipStreamWaitEvent(side, ev[ng], 0);
+    hipEventRecord(t0, main);
+    for (size_t gi = 0; gi < ng && !rc; ++gi) {
+        rc = factor_group(op, f, gi, ws_factor, ws_factor + 2 * P.fregion, planes);
+        hipEventRecord(ev[gi], main);
+        hipStreamWaitEvent(side, ev[gi], 0);
+        op->stream = side;
+        forward_group(op, f, gi, c);
+        op->stream = main;
+    }
+    hipEventRecord(t1, main);
+    hipEventRecord(ev[ng + 1], side);
+    hipStreamWaitEvent(main, ev[ng + 1], 0);
+    if (!rc) for (size_t gk = ng; gk-- > 0;) backward_group(op, f, gk, c);
+    hipError_t e = hipStreamSynchronize(main);
+    if (factor_ms) { float ms = 0.f; if (hipEventElapsedTime(&ms, t0, t1) == hipSuccess) *factor_ms = ms; }
+    for (auto &x : ev) hipEventDestroy(x);
+    hipEventDestroy(t0); hipEventDestroy(t1);
+    if (rc) return rc;
+    if (e != hipSuccess) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: factor + solve failed: %s", hipGetErrorString(e));
+    return check_kernels(op, "factor + solve kernels");
+}
+
 int nd_prep_transpose_norm(helm_op *op, const cplx *rhs, long long rhs_ld, long long row_off, cplx premul, const cplx *sub, cplx *Qt, long long N, int nrhs,
                            double *part, int nblk_cap, int *nblk_out) {
     const int nblk = (int)std::max<long long>(1, std::min<long long>((N + 31) / 32, std::min(nblk_cap, 1024)));

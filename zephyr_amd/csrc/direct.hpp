@@ -106,6 +106,8 @@ int nd_factor_solve(helm_op *op, int block, NdFactor *f, cplx *ws_factor, const 
 int nd_axpy_one(helm_op *op, cplx *y, const cplx *x, long long n, int conj = 0);
 // node-major pipeline (direct.hip): right-hand sides and solutions as [cell][rhs] between one transpose in and one out
 int nd_solve_nm(helm_op *op, NdFactor *f, const cplx *Qt, cplx *Xt, int nrhs, cplx *arenaV);
+int nd_factor_solve_nm(helm_op *op, int block, NdFactor *f, cplx *ws_factor, const cplx *planes, const cplx *Qt, cplx *Xt, int nrhs, cplx *arenaV,
+                       hipStream_t side, float *factor_ms);
 int nd_prep_transpose_norm(helm_op *op, const cplx *rhs, long long rhs_ld, long long row_off, cplx premul, const cplx *sub, cplx *Qt, long long N, int nrhs,
                            double *part, int nblk_cap, int *nblk_out);     // nblk_cap: partials per right-hand side the buffer has room for
 int nd_resid_nm(helm_op *op, const cplx *planes, const cplx *Xin, int ldin, cplx *Q, int ldq, const int *qmap, int ncol, int store, cplx *Rout,
