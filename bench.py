@@ -339,8 +339,12 @@ def main():
         how = ('sparse direct: nested-dissection multifrontal factorisation of A(f) on the GPU, kept for all sources of the frequency, '
                'triangular solves as batched complex GEMMs + iterative refinement with the stencil kernel' if direct else
                'BiCGSTAB right-preconditioned by shifted-Laplacian multigrid with damped-Jacobi smoothing + PML line relaxation')
-        stencil = {'bound': 'hbm', 'kernel': 'k_stencil (batched 9-pt complex128 apply with fused dot-product / residual epilogue), launches inside the timed solves',
-                   'bytes_formula': 'N*(32*B_active + 144) for the apply + N*16*B_active for the epilogue operand it must read',
+        stencil = {'bound': 'hbm',
+                   'kernel': ('k_resid_nm (9-pt complex128 stencil apply in the node-major layout of the direct path with the residual q - A x and its norms fused), '
+                              'launches inside the timed solves; apply_microbench = the rhs-major batched apply k_stencil' if direct else
+                              'k_stencil (batched 9-pt complex128 apply with fused dot-product / residual epilogue), launches inside the timed solves'),
+                   'bytes_formula': ('N*(32*B + 144) per norm-only launch (x and q in, nine coefficients once, nothing out), + N*16*B when r is stored' if direct else
+                                     'N*(32*B_active + 144) for the apply + N*16*B_active for the epilogue operand it must read'),
                    'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                    'traffic': None, 'launches_timed': int(apply_launches),
                    'avg_launch_us': 1e3 * apply_ms / apply_launches if apply_launches else None,
@@ -411,10 +415,14 @@ def main():
             if not direct and pmc.get('batch') == B and pmc.get('grid') == [n, n]:
                 out['roofline']['traffic'] = pmc['traffic_bytes_per_launch_outer_applies']
                 out['roofline']['traffic_source'] = 'profiles/r01_krylov_pmc_traffic.json'
-            pmd = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_direct.json')))
+            pmd = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic_zgemm.json')))
             if direct and pmd.get('batch') == B and pmd.get('grid') == [n, n]:
                 out['roofline']['traffic'] = pmd['traffic_bytes_per_launch']
-                out['roofline']['traffic_source'] = 'profiles/r01_pmc_traffic_direct.json (HBM bytes per k_zgemm launch, FETCH_SIZE x2 + WRITE_SIZE)'
+                out['roofline']['traffic_source'] = 'profiles/r02_pmc_traffic_zgemm.json (HBM bytes per k_zgemm2 launch, FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes)'
+            pmr = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic_resid_nm.json')))
+            if direct and pmr.get('batch') == B and pmr.get('grid') == [n, n]:
+                out['stencil_roofline']['traffic'] = pmr['traffic_bytes_per_launch']
+                out['stencil_roofline']['traffic_source'] = 'profiles/r02_pmc_traffic_resid_nm.json (HBM bytes per k_resid_nm launch)'
         except Exception:
             pass
         if world == 1 and not args.no_cpu:
