@@ -35,12 +35,15 @@ def test_batched_zgemm(helm_lib, M, N, K, batch):
         assert np.abs(out - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()) * K
 
 
-@pytest.mark.parametrize('n,batch', [(1, 2), (5, 3), (32, 4), (33, 2), (64, 5), (100, 2), (257, 1)])
+@pytest.mark.parametrize('n,batch', [(1, 2), (5, 3), (32, 4), (33, 2), (64, 5), (100, 2), (257, 1),
+                                     (32, 2100), (8, 2048), (20, 2300), (64, 2050)])     # >= 2048 blocks: the wave-per-matrix kernel
 def test_batched_inverse(helm_lib, n, batch):
     rng = np.random.default_rng(n)
     A = crand(rng, batch, n, n) + 2.0 * np.sqrt(n) * np.eye(n)        # leading blocks comfortably invertible
-    if n == 5:
+    if n == 5 or batch > 2000:
         A[0, 0, 0] = 0.0                                              # forces a row exchange in the base block
+        if batch > 2000 and n >= 8:
+            A[-1, :4, :4] = np.fliplr(np.eye(4)) * 3.0               # and a permutation-like leading block in the last matrix
     out = np.ascontiguousarray(A.copy())
     assert helm_lib.helm_debug_inverse(0, n, out.ctypes.data_as(ctypes.c_void_p), batch) == 0
     for b in range(batch):

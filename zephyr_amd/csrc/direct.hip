@@ -603,6 +603,9 @@ __device__ __forceinline__ void gj_lds(cplx (*a)[NMAX + 1], cplx *fcol, int *piv
 //     before the barrier and all new ones written after it;
 //   * the reciprocal of the pivot is v_rcp_f64 + two Newton steps.
 // On return a holds the inverse with its COLUMNS still permuted: column j belongs at column colperm(j) (gj32_colperm).
+// (Measured and reverted: the same elimination with the four entries of a thread kept in registers, implicit pivoting and the deferred
+// scaling of k_gj32w_inverse -- fewer instructions, but pivot row and multiplier column then go write -> barrier -> read through LDS in
+// every step, three dependent LDS round trips instead of two: 65 -> 88 us per block step of the 1024-wide top front.)
 struct Gj32 {
     cplx a[32][33];
     unsigned cand[32];
@@ -686,6 +689,95 @@ __global__ __launch_bounds__(256) void k_gj32_inverse(cplx *A0, int ld, long lon
     for (int q = 0; q < 4; ++q) {
         const int j = j0 + q;
         if (i < n && j < n) A[(long long)i * ld + gj32_colperm(S, n, j)] = S.a[i][j];
+    }
+}
+
+// ---- throughput variant for thousands of small blocks: one WAVE per matrix, the matrix in registers -------------------------------
+// Lane l holds half a row: row r = l & 31, columns 16 h .. 16 h + 15 with h = l >> 5 (16 complex = 64 VGPRs).  The 32 elimination steps
+// are unrolled so that every register index is static.  Per step the wave exchanges three things through its own 1.5 KB of LDS (LDS
+// operations of one wave execute in order, no barrier): the pivot keys of column k, the pivot row (written by its two owner lanes, read
+// as broadcasts), and the multipliers a[r][k] for the half that does not hold column k.  Pivoting is implicit -- rows stay where they
+// are, sigma(k) records the pivot row of step k -- and is undone when the result is stored: inv[i][sigma(k)] = R[sigma(i)][k].
+// ~220 wave-instructions per step against ~840 for the four-wave kernel above: the leaf level's two launches of 16 384 blocks are
+// issue-bound, so this is what they cost.
+struct Gj32w {
+    cplx prow[32];
+    cplx fcol[32];
+    unsigned cand[32];
+    int sigma[32];       // pivot row of step k
+    int sinv[32];        // step at which row r was the pivot
+};
+__global__ __launch_bounds__(256) void k_gj32w_inverse(cplx *A0, int ld, long long stride, int n, int nmat) {
+    __shared__ Gj32w SW[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int mat = blockIdx.x * 4 + w;
+    if (mat >= nmat) return;                       // whole waves leave together (no block-level barrier below)
+    Gj32w &S = SW[w];
+    cplx *A = A0 + (long long)mat * stride;
+    const int r = lane & 31, h = lane >> 5;
+    cplx a[16];
+    #pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int j = 16 * h + c;
+        a[c] = (r < n && j < n) ? A[(long long)r * ld + j] : cmake(r == j ? 1.0 : 0.0, 0.0);
+    }
+    bool used = r >= n;                            // padding rows never pivot
+    if (h == 0) { S.sigma[r] = r; S.sinv[r] = r; }  // (a singular block may leave entries unset: keep every index in range)
+    // The pivot row is NOT scaled when it is chosen: the other rows are eliminated with the multiplier f / d against the unscaled row,
+    // and the factor 1 / d of the pivot row rides along in `srow` until the end (every later operation on that row is linear in it).
+    // That leaves 16 complex multiply-adds per lane and step -- scaling the row at once would double the fp64 work of a step.
+    cplx srow = cmake(1.0, 0.0);
+    #pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        if (k < n) {
+            const int kc = k & 15, kh = k >> 4;
+            // pivot keys and multipliers of column k, from the half that holds it (candidates are unused rows: their scale is still 1)
+            if (h == kh) {
+                S.cand[r] = used ? (unsigned)r : gj_key(a[kc], r);
+                S.fcol[r] = a[kc];
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint4 *c4 = reinterpret_cast<const uint4 *>(S.cand);
+            unsigned m = 0;
+            #pragma unroll
+            for (int q = 0; q < 8; ++q) { const uint4 v = c4[q]; m = max(m, max(max(v.x, v.y), max(v.z, v.w))); }
+            const int p = (int)(m & 31u);
+            const cplx f = S.fcol[r];
+            __builtin_amdgcn_wave_barrier();
+            // the pivot row, written by its two owner lanes
+            if (r == p) {
+                #pragma unroll
+                for (int c = 0; c < 16; ++c) S.prow[16 * h + c] = a[c];
+                if (h == 0) { S.sigma[k] = p; S.sinv[p] = k; }
+                used = true;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const cplx d = S.prow[k];
+            const double rr = gj_rcp(d.x * d.x + d.y * d.y);
+            const cplx dinv = cmake(d.x * rr, -d.y * rr);
+            const cplx fp = (r == p) ? cmake(0.0, 0.0) : cmul(f, dinv);
+            #pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const cplx pr = S.prow[16 * h + c];
+                a[c].x = fma(-fp.x, pr.x, a[c].x); a[c].x = fma(fp.y, pr.y, a[c].x);
+                a[c].y = fma(-fp.x, pr.y, a[c].y); a[c].y = fma(-fp.y, pr.x, a[c].y);
+            }
+            if (h == kh) a[kc] = (r == p) ? cmake(1.0, 0.0) : cneg(fp);        // column k of the running inverse
+            if (r == p) srow = dinv;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    #pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = cmul(a[c], srow);
+    // inv[i][sigma(kcol)] = R[sigma(i)][kcol]: this lane holds storage row r = sigma(i), i.e. output row i = sinv[r]
+    if (r < n) {
+        const int i = S.sinv[r] & 31;
+        #pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int kcol = 16 * h + c;
+            const int col = S.sigma[kcol & 31] & 31;
+            if (kcol < n && i < n && col < n) A[(long long)i * ld + col] = a[c];
+        }
     }
 }
 
@@ -1137,7 +1229,9 @@ void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cp
             static const int gj_fast = getenv("HELM_ND_GJFAST") ? atoi(getenv("HELM_ND_GJFAST")) : 1;
             // the fast kernel is built for latency (every thread repeats the pivot search): with thousands of matrices in flight the
             // chip is issue-bound and the plain kernel is as fast or faster (8192 blocks of 8 x 8: 54 vs 139 us)
-            if (n <= 32 && gj_fast && batch < 2048) hipLaunchKernelGGL(k_gj32_inverse, dim3(nb), dim3(256), 0, st, M + b0 * stride, ld, stride, n);
+            static const int gj_wave = getenv("HELM_ND_GJWAVE") ? atoi(getenv("HELM_ND_GJWAVE")) : 1;
+            if (n <= 32 && gj_wave && batch >= 2048) hipLaunchKernelGGL(k_gj32w_inverse, dim3((nb + 3) / 4), dim3(256), 0, st, M + b0 * stride, ld, stride, n, nb);
+            else if (n <= 32 && gj_fast && batch < 2048) hipLaunchKernelGGL(k_gj32_inverse, dim3(nb), dim3(256), 0, st, M + b0 * stride, ld, stride, n);
             else if (n <= 32 && gj_threads == 1024) hipLaunchKernelGGL((k_gj_inverse<32, 1024>), dim3(nb), dim3(1024), 0, st, M + b0 * stride, ld, stride, n);
             else if (n <= 32) hipLaunchKernelGGL(k_gj_inverse<32>, dim3(nb), dim3(gj_threads), 0, st, M + b0 * stride, ld, stride, n);
             else hipLaunchKernelGGL(k_gj_inverse<64>, dim3(nb), dim3(256), 0, st, M + b0 * stride, ld, stride, n);
