@@ -599,17 +599,16 @@ __device__ __forceinline__ void gj_lds(cplx (*a)[NMAX + 1], cplx *fcol, int *piv
 //   * the pivot of the next column is chosen by EVERY thread from 32 keys in LDS -- float(max(|re|, |im|)) with the row index in
 //     the low five bits, so the search is one v_max_u32 reduction over eight 16-byte broadcast reads; the keys are written by
 //     the threads that produce that column in the previous step;
-//   * the row exchange is folded into the update (a thread of row p reads old row k and vice versa), all old values are read
+//   * no row exchange (implicit pivoting) and no scaling of the pivot row (its 1 / d is applied once at the end); all old values are read
 //     before the barrier and all new ones written after it;
 //   * the reciprocal of the pivot is v_rcp_f64 + two Newton steps.
-// On return a holds the inverse with its COLUMNS still permuted: column j belongs at column colperm(j) (gj32_colperm).
-// (Measured and reverted: the same elimination with the four entries of a thread kept in registers, implicit pivoting and the deferred
-// scaling of k_gj32w_inverse -- fewer instructions, but pivot row and multiplier column then go write -> barrier -> read through LDS in
-// every step, three dependent LDS round trips instead of two: 65 -> 88 us per block step of the 1024-wide top front.)
+// (Measured and reverted: exchanging the pivot row and the multiplier column through small LDS buffers instead of the full matrix --
+// fewer LDS bytes, but write -> barrier -> read makes three dependent LDS round trips per step instead of two: 65 -> 88 us per block step.)
 struct Gj32 {
     cplx a[32][33];
     unsigned cand[32];
-    int piv[32];
+    int piv[32];          // sigma: pivot row of step k
+    int sinv[32];         // step at which row r was the pivot
 };
 __device__ __forceinline__ double gj_rcp(double x) {
     double y = __builtin_amdgcn_rcp(x);
@@ -620,10 +619,15 @@ __device__ __forceinline__ unsigned gj_key(cplx v, int i) {
     const float m = (float)fmax(fabs(v.x), fabs(v.y));
     return (__float_as_uint(m) & ~31u) | (unsigned)i;
 }
-// S.a must hold the matrix padded with the identity to 32 x 32; all 256 threads call
+// S.a must hold the matrix padded with the identity to 32 x 32; all 256 threads call.
+// Implicit pivoting (rows stay where they are, S.piv[k] = sigma(k) = pivot row of step k, S.sinv its inverse) and deferred scaling of the
+// pivot rows (see k_gj32w_inverse): a step is   read keys -> p;  read row p, column k (old values);  barrier;  write own entries + next
+// keys;  barrier.  On return S.a holds the storage rows R with   inverse[i][sigma(k)] = R[sigma(i)][k].
 __device__ __forceinline__ void gj32(Gj32 &S, int n, int tid) {
     const int i = tid >> 3, jc = tid & 7, j0 = jc * 4;
-    if (jc == 0) S.cand[i] = i < n ? gj_key(S.a[i][0], i) : (unsigned)i;
+    bool used = i >= n;
+    cplx srow = cmake(1.0, 0.0);
+    if (jc == 0) { S.cand[i] = used ? (unsigned)i : gj_key(S.a[i][0], i); S.piv[i] = i; S.sinv[i] = i; }
     __syncthreads();
     for (int k = 0; k < n; ++k) {
         const uint4 *c4 = reinterpret_cast<const uint4 *>(S.cand);
@@ -631,47 +635,36 @@ __device__ __forceinline__ void gj32(Gj32 &S, int n, int tid) {
         #pragma unroll
         for (int q = 0; q < 8; ++q) { const uint4 v = c4[q]; m = max(m, max(max(v.x, v.y), max(v.z, v.w))); }
         const int p = (int)(m & 31u);
-        if (tid == 0) S.piv[k] = p;
-        const int si = (i == p) ? k : ((i == k) ? p : i);          // row i of the matrix after exchanging rows p and k
-        const cplx d = S.a[p][k];
-        cplx pr[4], mine[4];
+        const cplx d = S.a[p][k], f = S.a[i][k];
+        cplx pr[4], out[4];
         #pragma unroll
-        for (int q = 0; q < 4; ++q) { pr[q] = S.a[p][j0 + q]; mine[q] = S.a[si][j0 + q]; }
-        const cplx fi = S.a[si][k];
-        const double r = gj_rcp(d.x * d.x + d.y * d.y);
-        const cplx dinv = cmake(d.x * r, -d.y * r);
-        cplx out[4];
+        for (int q = 0; q < 4; ++q) { pr[q] = S.a[p][j0 + q]; out[q] = S.a[i][j0 + q]; }
+        if (tid == 0) { S.piv[k] = p; S.sinv[p] = k; }
+        const double rr = gj_rcp(d.x * d.x + d.y * d.y);
+        const cplx dinv = cmake(d.x * rr, -d.y * rr);
+        const cplx fp = (i == p) ? cmake(0.0, 0.0) : cmul(f, dinv);
+        const cplx vk = (i == p) ? cmake(1.0, 0.0) : cneg(fp);          // column k of the running inverse
         #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int j = j0 + q;
-            const cplx t = (j == k) ? dinv : cmul(pr[q], dinv);     // entry j of the scaled pivot row
-            if (i == k) out[q] = t;
-            else out[q] = csub((j == k) ? cmake(0.0, 0.0) : mine[q], cmul(fi, t));
+        for (int q = 0; q < 4; ++q) {                 // (static register indices only: an `a[k & 3] = ...` sends the array to scratch memory)
+            out[q].x = fma(-fp.x, pr[q].x, out[q].x); out[q].x = fma(fp.y, pr[q].y, out[q].x);
+            out[q].y = fma(-fp.x, pr[q].y, out[q].y); out[q].y = fma(-fp.y, pr[q].x, out[q].y);
+            if (j0 + q == k) out[q] = vk;
         }
+        if (i == p) { srow = dinv; used = true; }
         __syncthreads();
         #pragma unroll
         for (int q = 0; q < 4; ++q) S.a[i][j0 + q] = out[q];
-        if (k + 1 < n && jc == ((k + 1) >> 2)) {
+        if (k + 1 < n && jc == ((k + 1) >> 2)) {    // pivot keys of the next column (unused rows only: their scale is still 1)
             cplx v = out[0];
             #pragma unroll
             for (int q = 1; q < 4; ++q) if (((k + 1) & 3) == q) v = out[q];
-            S.cand[i] = (i > k && i < n) ? gj_key(v, i) : (unsigned)i;
+            S.cand[i] = used ? (unsigned)i : gj_key(v, i);
         }
         __syncthreads();
     }
-}
-// where column j of the permuted inverse belongs: the row exchanges undone as column exchanges, last first
-__device__ __forceinline__ int gj32_colperm(const Gj32 &S, int n, int j) {
-    int pv[32];
-    const int4 *p4 = reinterpret_cast<const int4 *>(S.piv);
     #pragma unroll
-    for (int q = 0; q < 8; ++q) { const int4 v = p4[q]; pv[4 * q] = v.x; pv[4 * q + 1] = v.y; pv[4 * q + 2] = v.z; pv[4 * q + 3] = v.w; }
-    int col = j;
-    #pragma unroll
-    for (int k = 31; k >= 0; --k) {
-        if (k < n) { const int pk = pv[k]; col = (col == k) ? pk : ((col == pk) ? k : col); }
-    }
-    return col;
+    for (int q = 0; q < 4; ++q) S.a[i][j0 + q] = cmul(S.a[i][j0 + q], srow);
+    __syncthreads();
 }
 
 __global__ __launch_bounds__(256) void k_gj32_inverse(cplx *A0, int ld, long long stride, int n) {
@@ -685,10 +678,13 @@ __global__ __launch_bounds__(256) void k_gj32_inverse(cplx *A0, int ld, long lon
     }
     __syncthreads();
     gj32(S, n, tid);
+    // inverse[row][sigma(j)] = R[sigma(row)][j]: this thread holds storage row i = sigma(row), i.e. row = sinv[i]
+    const int row = S.sinv[i] & 31;
     #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int j = j0 + q;
-        if (i < n && j < n) A[(long long)i * ld + gj32_colperm(S, n, j)] = S.a[i][j];
+        const int col = S.piv[j] & 31;
+        if (i < n && j < n && row < n && col < n) A[(long long)row * ld + col] = S.a[i][j];
     }
 }
 
@@ -837,7 +833,7 @@ __global__ __launch_bounds__(256) void k_gj_panel(cplx *T0, int ld, long long st
     }
     __syncthreads();
     gj32(S, nb, tid);
-    if (tid < PNB) cperm[tid] = gj32_colperm(S, nb, tid);
+    if (tid < PNB) cperm[tid] = S.piv[tid] & 31;            // P[r][sigma(j)] = S.a[sigma(r)][j]
     __syncthreads();
     // R slice = P * t  (nb x 64) with P[r][cperm[j]] = S.a[r][j]; columns inside the pivot block get P itself.
     // Thread (r = tid / 8, eight consecutive columns): ten LDS reads per eight complex multiply-adds.
@@ -846,8 +842,9 @@ __global__ __launch_bounds__(256) void k_gj_panel(cplx *T0, int ld, long long st
         cplx acc[8];
         #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = cmake(0.0, 0.0);
+        const int sr = cperm[r];                             // storage row of output row r
         for (int j = 0; j < nb; ++j) {
-            const cplx a = S.a[r][j];
+            const cplx a = S.a[sr][j];
             const int tj = cperm[j];
             #pragma unroll
             for (int i = 0; i < 8; ++i) cfma(acc[i], a, t[tj][c0 + i]);
@@ -864,7 +861,7 @@ __global__ __launch_bounds__(256) void k_gj_panel(cplx *T0, int ld, long long st
         for (int e = tid; e < nb * nb; e += 256) {
             const int r = e / nb, j = e % nb;
             const int gc = k0 + cperm[j];
-            if (gc >= s0 && gc < s0 + 64) Wr[(long long)r * n + gc] = S.a[r][j];
+            if (gc >= s0 && gc < s0 + 64) Wr[(long long)r * n + gc] = S.a[cperm[r]][j];
         }
 }
 
