@@ -159,7 +159,9 @@ int mg3_setup(helm_op *op, int batch) {
     Mg3Precond *P = new Mg3Precond();
     op->mg3 = P;
     P->batch = batch;
-    P->omega_j = envd("HELM_MG3_OMEGA", 0.8);
+    // Jacobi damping: measured at 256 x 256 x 128, 4 sources (tools/sweep3d.sh): 0.8 / 0.9 / 1.0 / 1.1 -> 10.9 / 9.6 / 10.0 / 16.4 s at 3 Hz and
+    // 7.4 / 7.0 / 6.6 / 8.9 s at 5 Hz
+    P->omega_j = envd("HELM_MG3_OMEGA", 0.9);
     P->nu1 = envi("HELM_MG3_NU1", 1); P->nu2 = envi("HELM_MG3_NU2", 1); P->min_n = envi("HELM_MG3_MIN_N", 8);
     const double omega = 2.0 * M_PI * std::abs(std::complex<double>(op->a_freq_re, op->a_freq_im));
     // shift: 0.6 at 10 grid points per wavelength, growing with the square of the oversampling up to 8 -- measured at
