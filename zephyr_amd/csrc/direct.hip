@@ -25,6 +25,7 @@
 // nothing -- the one round 1 carried was 10 % slower and is gone.  The lower solve levels are bound by moving ring rows through HBM.
 #include "helm_internal.hpp"
 #include "direct.hpp"
+#include <hip/hip_ext.h>
 #include <algorithm>
 #include <mutex>
 
@@ -551,14 +552,20 @@ __global__ __launch_bounds__(256, OCC) void k_zgemm2(int M, int Nn, int K, cplx 
     }
 }
 
+// Per-launch timing without extra packets: when gemm() has armed a pair of events, the dispatch itself carries them
+// (hipExtLaunchKernelGGL: start / stop timestamps of that kernel), instead of two hipEventRecord markers around it.
+thread_local hipEvent_t tl_ev0 = nullptr, tl_ev1 = nullptr;
+#define ZG_LAUNCH(KERNEL, GRID, ...) do { if (tl_ev0) hipExtLaunchKernelGGL(KERNEL, GRID, dim3(256), 0, st, tl_ev0, tl_ev1, 0, __VA_ARGS__); \
+                                          else hipLaunchKernelGGL(KERNEL, GRID, dim3(256), 0, st, __VA_ARGS__); } while (0)
+
 template <int TM, int RN, int KS, int UNR = 1, int OCC = 1>
 void launch_vec2(hipStream_t st, int idx, int nb, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, long long sa, const cplx *B, int ldb, long long sb,
                  cplx beta, cplx *C, int ldc, long long sc, const GemmRows &R) {
     constexpr int TN = (1024 / TM) * RN;
     dim3 grid((Nn + TN - 1) / TN, (M + TM - 1) / TM, nb);
-    if (idx == 2) hipLaunchKernelGGL((k_zgemm2<TM, 2, RN, KS, UNR, OCC>), grid, dim3(256), 0, st, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
-    else if (idx) hipLaunchKernelGGL((k_zgemm2<TM, 1, RN, KS, UNR, OCC>), grid, dim3(256), 0, st, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
-    else hipLaunchKernelGGL((k_zgemm2<TM, 0, RN, KS, UNR, OCC>), grid, dim3(256), 0, st, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
+    if (idx == 2) ZG_LAUNCH((k_zgemm2<TM, 2, RN, KS, UNR, OCC>), grid, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
+    else if (idx) ZG_LAUNCH((k_zgemm2<TM, 1, RN, KS, UNR, OCC>), grid, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
+    else ZG_LAUNCH((k_zgemm2<TM, 0, RN, KS, UNR, OCC>), grid, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
 }
 
 #define GJ_MAX 64
@@ -1114,8 +1121,12 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
     if (M <= 0 || Nn <= 0 || batch <= 0) return 0;
     hipStream_t st = op ? op->stream : nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    const bool in_run = op && op->gemm_run_depth > 0;
-    if (op && op->profiling && !(in_run && op->gemm_run_pair >= 0)) {
+    // profiling mode 1 (default): every launch carries its own start / stop events (ext launch, see ZG_LAUNCH); 0: hipEventRecord markers
+    // around launches / runs of launches (round 1)
+    static const int prof_ext = getenv("HELM_PROF_EXT") ? atoi(getenv("HELM_PROF_EXT")) : 1;
+    const bool ext = prof_ext && op && op->profiling && gemm_variant() != 0;
+    const bool in_run = !ext && op && op->gemm_run_depth > 0;
+    if (!ext && op && op->profiling && !(in_run && op->gemm_run_pair >= 0)) {
         if (op->ev_used + 2 > op->ev_pool.size() && op->ev_pool.size() < 16384)
             (void)helm_events_grow(op, 64);
         if (op->ev_used + 2 <= op->ev_pool.size()) { e0 = op->ev_pool[op->ev_used]; e1 = op->ev_pool[op->ev_used + 1]; }
@@ -1159,6 +1170,21 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
         cplx *Cb = C ? C + b0 * sc : C;
         // (a 4 x 8 register block per thread -- RN = 8, 64 x 128 tile -- was measured too: 230 VGPRs, occupancy 2, 38 % slower)
         const int gv = gemm_variant();
+        struct ExtArm {            // arms the per-launch event pair for the launchers below, books it when the launch is out
+            helm_op *op; bool on; double fl;
+            ExtArm(helm_op *o, bool e, double f) : op(o), on(false), fl(f) {
+                if (!e) return;
+                if (op->ev_used + 2 > op->ev_pool.size() && op->ev_pool.size() < 16384) (void)helm_events_grow(op, 64);
+                if (op->ev_used + 2 <= op->ev_pool.size()) { tl_ev0 = op->ev_pool[op->ev_used]; tl_ev1 = op->ev_pool[op->ev_used + 1]; on = true; }
+            }
+            ~ExtArm() {
+                if (!on) return;
+                op->ev_pending_gemm.push_back(std::make_pair((int)op->ev_used, fl));
+                op->ev_pending_gemm_n.push_back(1);
+                op->ev_used += 2;
+                tl_ev0 = tl_ev1 = nullptr;
+            }
+        } arm(op, ext, 8.0 * M * (double)Nn * K * nb);
 #define ZG_ARGS st, (rows ? (rows->fwd3 ? 2 : 1) : 0), nb, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R
 #define ZG_VEC(TM_, RN_) do { switch (gv) { \
             case 0: launch_vec<TM_, RN_>(ZG_ARGS); break; \
@@ -1181,6 +1207,7 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
 #undef ZG_VEC
     }
     const double flops = 8.0 * M * (double)Nn * K * batch;
+    if (ext) return 0;
     if (in_run) {                       // the run's end event is recorded by GemmRun's destructor
         if (op->gemm_run_pair >= 0) { op->gemm_run_flops += flops; op->gemm_run_launches += 1; }
     } else if (e0) {
