@@ -1754,6 +1754,11 @@ int nd_dense_gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, 
     gemm(op, M, Nn, K, alpha, A, lda, 0, B, ldb, 0, beta, C, ldc, 0, 1);
     return check_kernels(op, "dense GEMM");
 }
+int nd_dense_gemm_batched(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, long long sa, const cplx *B, int ldb, long long sb,
+                          cplx beta, cplx *C, int ldc, long long sc, int batch) {
+    gemm(op, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, batch);
+    return check_kernels(op, "dense GEMM");
+}
 int nd_dense_inverse(helm_op *op, cplx *M, int n, cplx *W) {
     invert(op, M, n, (long long)n * n, n, 1, W, (long long)n * n);
     return check_kernels(op, "dense inverse");

@@ -118,4 +118,7 @@ int nd_transpose_out(helm_op *op, const cplx *Xt, long long N, int nrhs, cplx *U
 
 // dense kernels for other translation units (row-major, single matrices)
 int nd_dense_gemm(helm_op *op, int M, int N, int K, cplx alpha, const cplx *A, int lda, const cplx *B, int ldb, cplx beta, cplx *C, int ldc);
+// `batch` products C_b = alpha A_b B_b + beta C_b with element strides sa / sb / sc between them (e.g. the K chunks of a split-K product)
+int nd_dense_gemm_batched(helm_op *op, int M, int N, int K, cplx alpha, const cplx *A, int lda, long long sa, const cplx *B, int ldb, long long sb,
+                          cplx beta, cplx *C, int ldc, long long sc, int batch);
 int nd_dense_inverse(helm_op *op, cplx *M, int n, cplx *W);     // in place; W: n*n elements of scratch

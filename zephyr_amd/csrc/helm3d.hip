@@ -239,11 +239,15 @@ int helm3d_launch_assemble(helm_op *op, double freq_re, double freq_im, double t
     std::vector<cplx> all(Lx);
     all.insert(all.end(), Ly.begin(), Ly.end());
     all.insert(all.end(), Lz.begin(), Lz.end());
+    // levels of the layer-preserving multigrid hierarchy (mg3d.hip) bring their own factors: non-uniform node spacing, 1/h^2 included
+    const bool over = op->lap_override.size() == all.size();
+    if (over) all = op->lap_override;
     cplx *d_L = nullptr;
     HIP_TRY(op, hipMalloc(&d_L, all.size() * sizeof(cplx)));
     HIP_TRY(op, hipMemcpyAsync(d_L, all.data(), all.size() * sizeof(cplx), hipMemcpyHostToDevice, op->stream));
     Asm3Params P;
     P.nz = op->nz; P.ny = op->ny; P.nx = op->nx; P.dx = op->dx; P.dy = op->dy; P.dz = op->dz;
+    if (over) P.dx = P.dy = P.dz = 1.0;
     P.om = cmake(om.real(), om.imag()); P.blend = 0.5;
     const int blocks = (int)((op->N + 255) / 256);
     hipLaunchKernelGGL(k_assemble_3d, dim3(blocks), dim3(256), 0, op->stream, P, (const cplx *)op->d_c, (const double *)op->d_rho,

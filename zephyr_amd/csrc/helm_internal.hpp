@@ -112,6 +112,7 @@ struct helm_op {
     // operator
     bool block0_only = false;     // Eurus preconditioner levels: assemble/keep only M1
     double pml_scale = 1.0;       // MiniZephyr preconditioner levels: scales the PML factors (1 = reference)
+    std::vector<cplx> lap_override;   // 3-D preconditioner levels on stretched grids: Lx(-1,0,+1)[nx] | Ly[ny] | Lz[nz] including 1/h^2 (helm3d.hip)
     double diag_floor = 0.0;      // preconditioner levels: floor on |diag| as a fraction of the row's absolute sum (smoother safeguard)
     double a_freq_re = 0, a_freq_im = 0, a_tau = 0, a_ky = 0, a_cpml = 0;   // parameters of the last assemble
     struct MgPrecond *mg = nullptr;
