@@ -14,15 +14,17 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--nx', type=int, default=256); ap.add_argument('--ny', type=int, default=256); ap.add_argument('--nz', type=int, default=128)
 ap.add_argument('--freqs', type=float, nargs='+', default=[2., 5.]); ap.add_argument('--nsrc', type=int, default=4)
 ap.add_argument('--maxit', type=int, default=60000); ap.add_argument('--rtol', type=float, default=1e-8)
-ap.add_argument('--no-solve', action='store_true'); ap.add_argument('--method', default='auto'); ap.add_argument('--no-apply', action='store_true')
+ap.add_argument('--no-solve', action='store_true'); ap.add_argument('--standard-cycle', action='store_true', help='HELM_MG3_KEEP=0: the shifted cycle with standard coarsening (round-2 baseline)'); ap.add_argument('--method', default='auto'); ap.add_argument('--no-apply', action='store_true')
 a = ap.parse_args()
 nx, ny, nz = a.nx, a.ny, a.nz
+if a.standard_cycle:
+    os.environ['HELM_MG3_KEEP'] = '0'
 N = nx * ny * nz
 cfg = dict(nx=nx, ny=ny, nz=nz, dx=10., c=2000., rho=1., freq=a.freqs[0], nPML=10, rtol=a.rtol, maxit=a.maxit, batch=a.nsrc, method=a.method)
 op = Helm3D(cfg)
 lib = _lib.load()
 dev = torch.device('cuda', 0)
-out = {'grid': [nz, ny, nx], 'apply': []}
+out = {'grid': [nz, ny, nx], 'preconditioner': 'standard shifted cycle' if a.standard_cycle else 'layer-preserving hierarchy + block-tridiagonal coarse solve', 'apply': []}
 for B in (() if a.no_apply else (1, 4, 8, 16)):
     X = torch.randn((B, N), dtype=torch.complex128, device=dev)
     Y = torch.empty_like(X)
@@ -46,7 +48,7 @@ if not a.no_solve:
         # right-hand sides kept source-major in memory: the (N, nsrc) view the operator takes is then free of copies
         q = np.zeros((a.nsrc, N), complex).T
         for s in range(a.nsrc):
-            q[((20 + 5 * s) * ny + ny // 2) * nx + nx // 4 + 30 * s, s] = 1.
+            q[((20 + 5 * s) * ny + ny // 2) * nx + nx // 4 + (30 * s) % (nx // 2), s] = 1.     # all inside the physical domain
         t0 = time.time()
         try:
             u = op * q

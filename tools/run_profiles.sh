@@ -23,6 +23,8 @@ python3 tools/pmc_reduce.py --fetch $OUT/pmc_FETCH_SIZE --write $OUT/pmc_WRITE_S
 find $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE -name "*.csv" -size +2M -delete
 HELM_ND_TRACE=1 python3 tools/bench_direct.py --freqs 5.5 > $OUT/trace.txt 2>&1
 python3 tools/bench3d.py --freqs 2 3 4 5 --nsrc 16 > $OUT/bench3d.txt 2> $OUT/bench3d.err
+# the cycle it replaced on oversampled grids (standard coarsening, weak layer, large shift), 4 sources at the two end frequencies
+python3 tools/bench3d.py --no-apply --standard-cycle --freqs 2 5 --nsrc 4 > $OUT/bench3d_standard.txt 2> $OUT/bench3d_standard.err
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats3d -o s -- python3 $GRAFT_REPO_ROOT/tools/bench3d.py --freqs 5 --nsrc 16 > $OUT/bench3d_under_rocprof.txt 2> $OUT/stats3d.err
 find $OUT/stats $OUT/stats3d -name "*kernel_trace.csv" -size +8M -delete

@@ -24,6 +24,8 @@ cp('pmc_traffic_stencil_micro.json', 'r02_pmc_traffic_stencil_apply.json')
 cp('bench3d.txt', 'r02_config5_bench3d.txt')
 open(P + 'r02_config5_bench3d.json', 'w').write(open(os.path.join(S, 'bench3d.txt')).read().strip().split('\n')[-1] + '\n')
 cp('stats3d/s_kernel_stats.csv', 'r02_config5_rocprofv3_kernel_stats.csv')
+if os.path.exists(os.path.join(S, 'bench3d_standard.txt')):
+    open(P + 'r02_config5_standard_cycle_4src.json', 'w').write(open(os.path.join(S, 'bench3d_standard.txt')).read().strip().split('\n')[-1] + '\n')
 open(P + 'r02_config5_under_rocprofv3.json', 'w').write(open(os.path.join(S, 'bench3d_under_rocprof.txt')).read().strip().split('\n')[-1] + '\n')
 if os.path.exists(os.path.join(S, 'trace.txt')):
     open(P + 'r02_direct_per_level_trace.txt', 'w').write(''.join(l for l in open(os.path.join(S, 'trace.txt')) if l.startswith('[nd trace]')))
@@ -49,6 +51,10 @@ def table_of(rs, k):
 R = d['roofline']; St = d['stencil_roofline']; cb = d['cpu_baseline']; c2 = d['cpu_baseline_2n']; cpool = d['cpu_baseline_pool']
 rows3 = list(csv.DictReader(open(P + 'r02_config5_rocprofv3_kernel_stats.csv')))
 b3 = json.load(open(P + 'r02_config5_bench3d.json'))
+std_note = ''
+if os.path.exists(P + 'r02_config5_standard_cycle_4src.json'):
+    b3s = json.load(open(P + 'r02_config5_standard_cycle_4src.json'))
+    std_note = ': ' + ', '.join('%g Hz %.1f s, %d iterations' % (x['freq'], x['seconds_device_resident'], max(x['iterations'])) for x in b3s['solve'])
 nB = d['config']['sources_per_step']; N = d['config']['grid'][0] * d['config']['grid'][1]
 alg_norm_only = N * (32.0 * nB + 144.0)
 text = f'''# profiles/ -- round 2 (MI355X, 1 GPU)
@@ -96,8 +102,9 @@ measured too: 3 % slower and two more frequencies pushed into a second pass (DES
 
 | file | what |
 |---|---|
-| `r02_config5_bench3d.json` / `.txt` | batched apply {', '.join('%.0f' % a['GBps_algorithmic'] for a in b3['apply'])} GB/s at B = 1 / 4 / 8 / 16 against N(32B + 432) ({', '.join('%.0f' % (a['GBps_algorithmic'] / 80) for a in b3['apply'])} % of 8 TB/s); the whole job: {' + '.join('%.1f' % s['seconds'] for s in b3['solve'])} s = **{sum(s['seconds'] for s in b3['solve']):.0f} s** for the 64 wavefields at 2 / 3 / 4 / 5 Hz to rtol 1e-8 ({', '.join('%d' % (sum(s['iterations']) / len(s['iterations'])) for s in b3['solve'])} BiCGSTAB iterations per source on average) |
+| `r02_config5_bench3d.json` / `.txt` | batched apply {', '.join('%.0f' % a['GBps_algorithmic'] for a in b3['apply'])} GB/s at B = 1 / 4 / 8 / 16 against N(32B + 432) ({', '.join('%.0f' % (a['GBps_algorithmic'] / 80) for a in b3['apply'])} % of 8 TB/s); the whole job through host buffers: {' + '.join('%.1f' % s['seconds'] for s in b3['solve'])} s = **{sum(s['seconds'] for s in b3['solve']):.1f} s** for the 64 wavefields at 2 / 3 / 4 / 5 Hz to rtol 1e-8 ({', '.join('%d' % (sum(s['iterations']) / len(s['iterations'])) for s in b3['solve'])} BiCGSTAB iterations per source on average); with right-hand sides and wavefields resident in HBM {' + '.join('%.1f' % s['seconds_device_resident'] for s in b3['solve'])} s = **{sum(s['seconds_device_resident'] for s in b3['solve']):.1f} s**, of which {sum(s['seconds_device_resident'] - s['seconds_device_resident_reusing_setup'] for s in b3['solve']):.1f} s are the preconditioner set-ups (plane inverses of the coarsest level) |
 | `r02_config5_rocprofv3_kernel_stats.csv`, `r02_config5_under_rocprofv3.json` | `rocprofv3 --kernel-trace --stats -- python3 tools/bench3d.py --freqs 5 --nsrc 16` |
+| `r02_config5_standard_cycle_*` | the same job with the cycle this round started with (standard coarsening, weak layer, shift 6-8; collected before the layer-preserving hierarchy existed): 134 s, 500-1500 iterations per source; `r02_config5_standard_cycle_4src.json`: that cycle again on the final code (`--standard-cycle`, 4 sources at 2 and 5 Hz){std_note} |
 
 Top rows of the 3-D stats file (5 Hz, 16 sources):
 
@@ -105,7 +112,7 @@ Top rows of the 3-D stats file (5 Hz, 16 sources):
 |---|---|---|---|
 {table_of(rows3, 10)}
 
-(`k_stencil3<false, EPI>`: 4 = residual, 5 = damped-Jacobi sweep of the multigrid levels, 1 / 6 = the outer BiCGSTAB applies with fused dot
+(`k_stencil3<false, EPI>`: 4 = residual, 5 = l1-Jacobi sweep of the multigrid levels; `k_zgemm2<64, 1, 4, 8>` + `k_gj_panel` + `k_bt_schur_t`: the plane inverses of the set-up; `k_bt_apply` / `k_bt_rhs` / `k_bt_reduce`: the block-tridiagonal solve of the coarsest level, 1 / 6 = the outer BiCGSTAB applies with fused dot
 products.)
 
 ## Round 1 files

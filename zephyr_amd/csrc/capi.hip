@@ -63,7 +63,7 @@ int helm_events_grow(helm_op *op, int n) {
     }
     return 0;
 }
-static const size_t kPoolMinBytes = (size_t)1 << 20, kPoolCapBytes = (size_t)24 << 30;
+static const size_t kPoolMinBytes = (size_t)1 << 20, kPoolCapBytes = (size_t)64 << 30;
 
 void *helm_pool_alloc(int device, size_t bytes) {
     {

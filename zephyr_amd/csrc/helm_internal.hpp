@@ -170,7 +170,8 @@ void mg_destroy(helm_op *op);
 // out[b] = M^-1 in[b] for the active right-hand sides (scal may be null = all)
 int mg_apply(helm_op *op, const cplx *in, cplx *out, int nrhs, const RhsScal *scal);
 
-// 3-D counterpart (mg3d.hip): shifted-Laplacian V-cycle with damped-Jacobi smoothing, weak absorbing layer, no line relaxation
+// 3-D counterpart (mg3d.hip): layer-preserving hierarchy with a direct coarse solve on oversampled grids, otherwise a
+// shifted-Laplacian V-cycle with damped-Jacobi smoothing and a weak absorbing layer
 int mg3_setup(helm_op *op, int batch);
 void mg3_destroy(helm_op *op);
 int mg3_apply(helm_op *op, const cplx *in, cplx *out, int nrhs);

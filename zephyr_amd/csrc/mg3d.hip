@@ -1,11 +1,12 @@
-// Multigrid preconditioner for the 3-D 27-point operator: one V(1,1) cycle on the complex-shifted operator
-// (1/tau_M = 1/tau + omega beta / 2) with a weak absorbing layer (cPML_M), rediscretised on coarser grids (model by
-// injection, spacing doubled, layer thickness halved), damped Jacobi smoothing through the 3-D stencil kernel, full-weighting
-// restriction / trilinear prolongation, dense inverse on the coarsest grid (dense kernels of direct.hip).
+// Multigrid preconditioners for the 3-D 27-point operator (right-preconditioned BiCGSTAB of capi.hip).
 //
-// Why this recipe: numpy experiments on the oracle's 3-D matrices -- unlike in 2-D, the mismatch
-// between the weak layer of the preconditioner and the true layer of the operator costs little in 3-D, so no line
-// relaxation is needed; the cycle right-preconditions the same BiCGSTAB as in 2-D (capi.hip).
+// 1. Standard cycle (first half of this file; grids below 20 points per wavelength, fallback): one V(1,1) cycle on the
+//    complex-shifted operator (1/tau_M = 1/tau + omega beta / 2) with a weak absorbing layer (cPML_M), rediscretised on coarser
+//    grids (model by injection, spacing doubled, layer thickness halved), damped Jacobi smoothing through the 3-D stencil
+//    kernel, full-weighting restriction / trilinear prolongation, dense inverse on the coarsest grid (dense kernels of direct.hip).
+// 2. Layer-preserving hierarchy (second half; oversampled grids such as BASELINE config 5): coarse grids keep every node of the
+//    absorbing layers, l1-Jacobi, true layer with a small shift, block-tridiagonal direct solve of the level that still has
+//    ~10 points per wavelength.  DESIGN.md section 5.3 has the measurements behind each of these choices.
 #include "helm_internal.hpp"
 #include "direct.hpp"
 #include <algorithm>
@@ -168,7 +169,9 @@ struct PTab { int c0, c1; double w0, w1; };         // fine node -> its two coar
 struct RTab { int f; double wl, wc, wr; };          // coarse node -> fine nodes f-1, f, f+1 with normalised weights
 
 struct Bt3 {                        // direct solver of the coarsest level
-    int axis = 0, np = 0, na = 0, nb = 0, m = 0, mpad = 0, ksplit = 1, kc = 0, batch = 0;
+    int axis = 0, np = 0, na = 0, nb = 0, m = 0, mpad = 0, ksplit = 1, kc = 0, batch = 0, nparts = 1;
+    bool own = true;                // k_bt_apply (memory-bound product) instead of the generic batched GEMM
+    int device = 0; size_t tbytes = 0;   // Tinv comes from the size-keyed buffer pool (the next frequency takes it over without a hipMalloc)
     long long ss = 0, sa = 0, sb = 0, N = 0;      // node strides of the sweep axis / the two in-plane axes
     cplx *Tinv = nullptr;           // np x (mpad x m): inverse of the transposed Schur complement of plane k (rows >= m are zero)
     cplx *Y = nullptr;              // batch x mpad: packed right-hand side of one plane (columns >= m stay zero)
@@ -356,6 +359,51 @@ __global__ __launch_bounds__(256) void k_bt_rhs(const cplx *__restrict__ planes,
     Y[(long long)r * mpad + i] = v;
 }
 
+// parts[(ks * 4 + w)][r][c] = sum over the k rows of chunk ks handled by wave w of Y[r][k] T[k][c]   (r < 16 right-hand sides).
+// The plane inverses are read once per solve and nothing else is: a memory-bound product (8 flop per byte at 16 right-hand sides), so
+// one lane per column streams T row by row (1 KB per wave and row, coalesced) against right-hand sides broadcast from LDS.
+#define BTA_KS 128
+template <int NR>
+__global__ __launch_bounds__(256) void k_bt_apply(const cplx *__restrict__ Y, int ldy, const cplx *__restrict__ T, int m, int kc, int nrhs,
+                                                  cplx *__restrict__ parts) {
+    __shared__ cplx ys[BTA_KS][NR];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int kbeg = blockIdx.y * kc, kend = min(m, kbeg + kc);
+    cplx acc[NR];
+    #pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] = cmake(0.0, 0.0);
+    const bool live = c < m;
+    for (int k0 = kbeg; k0 < kend; k0 += BTA_KS) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < BTA_KS * NR; e += 256) {
+            const int kk = e % BTA_KS, r = e / BTA_KS;
+            ys[kk][r] = (r < nrhs && k0 + kk < kend) ? Y[(long long)r * ldy + k0 + kk] : cmake(0.0, 0.0);
+        }
+        __syncthreads();
+        const int kn = min(BTA_KS, kend - k0);
+        // wave w takes rows w, w + 4, ... of the slab, eight loads in flight
+        for (int kk = w; kk < kn; kk += 32) {
+            cplx t[8];
+            #pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = kk + 4 * u;
+                t[u] = (live && k < kn) ? T[(long long)(k0 + k) * m + c] : cmake(0.0, 0.0);
+            }
+            #pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = min(kk + 4 * u, BTA_KS - 1);
+                #pragma unroll
+                for (int r = 0; r < NR; ++r) cfma(acc[r], ys[k][r], t[u]);
+            }
+        }
+    }
+    if (!live) return;
+    cplx *out = parts + ((long long)(blockIdx.y * 4 + w) * nrhs) * m + c;
+    #pragma unroll
+    for (int r = 0; r < NR; ++r) if (r < nrhs) out[(long long)r * m] = acc[r];
+}
+
 // Z (+)= sum of the split-K partial products: sub = 0: Z = sum, 1: Z -= sum
 __global__ void k_bt_reduce(const cplx *__restrict__ parts, int nparts, long long n, cplx *__restrict__ Z, int sub) {
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
@@ -378,7 +426,8 @@ __global__ void k_bt_scatter(const cplx *__restrict__ Z, BtGeom g, int nrhs, cpl
 BtGeom bt_geom(const Bt3 &B) { BtGeom g; g.axis = B.axis; g.np = B.np; g.na = B.na; g.nb = B.nb; g.m = B.m; g.ss = B.ss; g.sa = B.sa; g.sb = B.sb; g.N = B.N; return g; }
 
 void bt_free(Bt3 &B) {
-    hipFree(B.Tinv); hipFree(B.Y); hipFree(B.Z); hipFree(B.parts);
+    if (B.Tinv) helm_pool_free(B.device, B.Tinv, B.tbytes);
+    hipFree(B.Y); hipFree(B.Z); hipFree(B.parts);
     B = Bt3();
 }
 
@@ -392,24 +441,29 @@ int bt_setup(helm_op *op, Bt3 &B, const Mg3Level &L, int batch) {
     B.axis = axis; B.np = dims[axis]; B.na = dims[ia]; B.nb = dims[ib]; B.m = B.na * B.nb;
     B.ss = strides[axis]; B.sa = strides[ia]; B.sb = strides[ib]; B.N = L.N; B.batch = batch;
     // split-K so that the 16 x 64 tiles of the (batch x m x m) products come to ~250 workgroups
-    B.ksplit = std::max(1, std::min(16, 255 / ((B.m + 63) / 64)));
+    // split-K: ~512 workgroups of 64 columns each (k_bt_apply); HELM_MG3_BT_GEMM=1 goes through the generic batched GEMM instead
+    B.own = envi("HELM_MG3_BT_GEMM", 0) == 0 && batch <= 16;
+    B.ksplit = B.own ? std::max(1, std::min(16, 512 / ((B.m + 63) / 64))) : std::max(1, std::min(16, 255 / ((B.m + 63) / 64)));
     B.ksplit = envi("HELM_MG3_BT_KSPLIT", B.ksplit);
     B.kc = (B.m + B.ksplit - 1) / B.ksplit;
-    B.mpad = B.kc * B.ksplit;
+    B.mpad = B.own ? B.m : B.kc * B.ksplit;          // (the generic GEMM wants equal K chunks: zero rows / columns up to mpad)
+    B.nparts = B.own ? 4 * B.ksplit : B.ksplit;
+    B.device = op->device;
     const size_t tb = (size_t)B.np * B.mpad * B.m * sizeof(cplx);
-    size_t freeb = 0, totb = 0;
-    hipMemGetInfo(&freeb, &totb);
     const size_t wbytes = (size_t)B.m * B.m * sizeof(cplx);
-    if (tb + wbytes + (1ull << 30) > freeb) HELM_FAIL(op, HELM_ERR_DEVICE, "3-D multigrid: the plane inverses of the coarsest level (%.1f GB) do not fit", tb / 1e9);
-    cplx *W = nullptr;
-    if (hipMalloc((void **)&B.Tinv, tb) != hipSuccess || hipMalloc((void **)&B.Y, (size_t)batch * B.mpad * sizeof(cplx)) != hipSuccess ||
-        hipMalloc((void **)&B.Z, (size_t)B.np * batch * B.m * sizeof(cplx)) != hipSuccess ||
-        hipMalloc((void **)&B.parts, (size_t)B.ksplit * batch * B.m * sizeof(cplx)) != hipSuccess || hipMalloc((void **)&W, wbytes) != hipSuccess) {
-        hipFree(W); bt_free(B);
-        HELM_FAIL(op, HELM_ERR_DEVICE, "3-D multigrid: coarsest-level solver does not fit");
-    }
+    B.tbytes = tb;
     hipStream_t st = op->stream;
-    hipMemsetAsync(B.Tinv, 0, tb, st);
+    hipStreamSynchronize(st);          // (buffers of the previous frequency go back to the pool only when their work is done)
+    B.Tinv = (cplx *)helm_pool_alloc(op->device, tb);
+    cplx *W = (cplx *)helm_pool_alloc(op->device, wbytes);
+    if (!B.Tinv || !W || hipMalloc((void **)&B.Y, (size_t)batch * B.mpad * sizeof(cplx)) != hipSuccess ||
+        hipMalloc((void **)&B.Z, (size_t)B.np * batch * B.m * sizeof(cplx)) != hipSuccess ||
+        hipMalloc((void **)&B.parts, (size_t)B.nparts * batch * B.m * sizeof(cplx)) != hipSuccess) {
+        if (W) helm_pool_free(op->device, W, wbytes);
+        bt_free(B);
+        HELM_FAIL(op, HELM_ERR_DEVICE, "3-D multigrid: the plane inverses of the coarsest level (%.1f GB) do not fit", tb / 1e9);
+    }
+    if (B.mpad != B.m) hipMemsetAsync(B.Tinv, 0, tb, st);
     hipMemsetAsync(B.Y, 0, (size_t)batch * B.mpad * sizeof(cplx), st);
     const BtGeom g = bt_geom(B);
     const long long mm = (long long)B.m * B.m;
@@ -421,7 +475,7 @@ int bt_setup(helm_op *op, Bt3 &B, const Mg3Level &L, int batch) {
         rc = nd_dense_inverse(op, Tk, B.m, W);
     }
     hipStreamSynchronize(st);
-    hipFree(W);
+    helm_pool_free(op->device, W, wbytes);
     if (rc) { bt_free(B); return rc; }
     return HELM_OK;
 }
@@ -436,6 +490,11 @@ int bt_solve(helm_op *op, Bt3 &B, const Mg3Level &L, const cplx *f, cplx *u, int
     const unsigned redg = (unsigned)std::min<long long>((pz + 255) / 256, 4096);
     auto apply_inverse = [&](int k, cplx *Zk, int sub) -> int {
         const cplx *Tk = B.Tinv + (long long)k * B.mpad * B.m;
+        if (B.own) {
+            hipLaunchKernelGGL(k_bt_apply<16>, dim3((B.m + 63) / 64, B.ksplit), dim3(256), 0, st, (const cplx *)B.Y, B.mpad, Tk, B.m, B.kc, nrhs, B.parts);
+            hipLaunchKernelGGL(k_bt_reduce, dim3(redg), dim3(256), 0, st, (const cplx *)B.parts, B.nparts, pz, Zk, sub);
+            return HELM_OK;
+        }
         const int rc = nd_dense_gemm_batched(op, nrhs, B.m, B.kc, cmake(1, 0), B.Y, B.mpad, B.kc, Tk, B.m, (long long)B.kc * B.m, cmake(0, 0),
                                              B.parts, B.m, pz, B.ksplit);
         if (rc) return rc;
