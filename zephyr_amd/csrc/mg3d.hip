@@ -359,21 +359,23 @@ __global__ __launch_bounds__(256) void k_bt_rhs(const cplx *__restrict__ planes,
     Y[(long long)r * mpad + i] = v;
 }
 
-// parts[(ks * 4 + w)][r][c] = sum over the k rows of chunk ks handled by wave w of Y[r][k] T[k][c]   (r < 16 right-hand sides).
-// The plane inverses are read once per solve and nothing else is: a memory-bound product (8 flop per byte at 16 right-hand sides), so
-// one lane per column streams T row by row (1 KB per wave and row, coalesced) against right-hand sides broadcast from LDS.
+// parts[ks][r][c] = sum over the k rows of chunk ks of Y[r][k] T[k][c]   (r < 16 right-hand sides).
+// The plane inverses are read once per solve and nothing else is: a memory-bound product (8 flop per byte at 16 right-hand sides).
+// A workgroup takes 128 columns and one K chunk; every lane owns two columns (c, c + 64) so that one LDS broadcast of a right-hand-side
+// value feeds two multiply-adds (with one column per lane the 16 broadcasts per row bound the kernel at 2.8 TB/s); wave w streams rows
+// w, w + 4, ... of T (two coalesced 1-KB segments per row) and the four waves add their partial sums through LDS at the end.
 #define BTA_KS 128
 template <int NR>
-__global__ __launch_bounds__(256) void k_bt_apply(const cplx *__restrict__ Y, int ldy, const cplx *__restrict__ T, int m, int kc, int nrhs,
-                                                  cplx *__restrict__ parts) {
-    __shared__ cplx ys[BTA_KS][NR];
+__global__ __launch_bounds__(256, 2) void k_bt_apply(const cplx *__restrict__ Y, int ldy, const cplx *__restrict__ T, int m, int kc, int nrhs,
+                                                     cplx *__restrict__ parts) {
+    __shared__ cplx ys[BTA_KS][NR];                      // 32 KB; doubles as the reduction buffer (3 waves x 8 values x 64 lanes = 24 KB)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
+    const int c0 = blockIdx.x * 128 + lane, c1 = c0 + 64;
     const int kbeg = blockIdx.y * kc, kend = min(m, kbeg + kc);
-    cplx acc[NR];
+    cplx acc0[NR], acc1[NR];
     #pragma unroll
-    for (int r = 0; r < NR; ++r) acc[r] = cmake(0.0, 0.0);
-    const bool live = c < m;
+    for (int r = 0; r < NR; ++r) { acc0[r] = cmake(0.0, 0.0); acc1[r] = cmake(0.0, 0.0); }
+    const bool live0 = c0 < m, live1 = c1 < m;
     for (int k0 = kbeg; k0 < kend; k0 += BTA_KS) {
         __syncthreads();
         for (int e = threadIdx.x; e < BTA_KS * NR; e += 256) {
@@ -382,26 +384,53 @@ __global__ __launch_bounds__(256) void k_bt_apply(const cplx *__restrict__ Y, in
         }
         __syncthreads();
         const int kn = min(BTA_KS, kend - k0);
-        // wave w takes rows w, w + 4, ... of the slab, eight loads in flight
-        for (int kk = w; kk < kn; kk += 32) {
-            cplx t[8];
+        for (int kk = w; kk < kn; kk += 16) {            // four rows of this wave per step: eight 16-byte loads in flight per lane
+            cplx t0[4], t1[4];
             #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 4; ++u) {
                 const int k = kk + 4 * u;
-                t[u] = (live && k < kn) ? T[(long long)(k0 + k) * m + c] : cmake(0.0, 0.0);
+                const cplx *row = T + (long long)(k0 + k) * m;
+                t0[u] = (live0 && k < kn) ? row[c0] : cmake(0.0, 0.0);
+                t1[u] = (live1 && k < kn) ? row[c1] : cmake(0.0, 0.0);
             }
             #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 4; ++u) {
                 const int k = min(kk + 4 * u, BTA_KS - 1);
                 #pragma unroll
-                for (int r = 0; r < NR; ++r) cfma(acc[r], ys[k][r], t[u]);
+                for (int r = 0; r < NR; ++r) { const cplx y = ys[k][r]; cfma(acc0[r], y, t0[u]); cfma(acc1[r], y, t1[u]); }
             }
         }
     }
-    if (!live) return;
-    cplx *out = parts + ((long long)(blockIdx.y * 4 + w) * nrhs) * m + c;
+    // waves 1-3 hand their sums to wave 0, eight values per lane and round
+    cplx *red = &ys[0][0];
     #pragma unroll
-    for (int r = 0; r < NR; ++r) if (r < nrhs) out[(long long)r * m] = acc[r];
+    for (int half = 0; half < 2; ++half) {
+        #pragma unroll
+        for (int g = 0; g < NR; g += 8) {
+            __syncthreads();
+            if (w > 0) {
+                #pragma unroll
+                for (int r = 0; r < 8; ++r) red[((w - 1) * 8 + r) * 64 + lane] = half ? acc1[g + r] : acc0[g + r];
+            }
+            __syncthreads();
+            if (w == 0) {
+                #pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    cplx v = half ? acc1[g + r] : acc0[g + r];
+                    #pragma unroll
+                    for (int q = 0; q < 3; ++q) v = cadd(v, red[(q * 8 + r) * 64 + lane]);
+                    if (half) acc1[g + r] = v; else acc0[g + r] = v;
+                }
+            }
+        }
+    }
+    if (w != 0) return;
+    cplx *out = parts + ((long long)blockIdx.y * nrhs) * m;
+    #pragma unroll
+    for (int r = 0; r < NR; ++r) if (r < nrhs) {
+        if (live0) out[(long long)r * m + c0] = acc0[r];
+        if (live1) out[(long long)r * m + c1] = acc1[r];
+    }
 }
 
 // Z (+)= sum of the split-K partial products: sub = 0: Z = sum, 1: Z -= sum
@@ -441,13 +470,13 @@ int bt_setup(helm_op *op, Bt3 &B, const Mg3Level &L, int batch) {
     B.axis = axis; B.np = dims[axis]; B.na = dims[ia]; B.nb = dims[ib]; B.m = B.na * B.nb;
     B.ss = strides[axis]; B.sa = strides[ia]; B.sb = strides[ib]; B.N = L.N; B.batch = batch;
     // split-K so that the 16 x 64 tiles of the (batch x m x m) products come to ~250 workgroups
-    // split-K: ~512 workgroups of 64 columns each (k_bt_apply); HELM_MG3_BT_GEMM=1 goes through the generic batched GEMM instead
+    // split-K: ~512 workgroups of 128 columns each (k_bt_apply); HELM_MG3_BT_GEMM=1 goes through the generic batched GEMM instead
     B.own = envi("HELM_MG3_BT_GEMM", 0) == 0 && batch <= 16;
-    B.ksplit = B.own ? std::max(1, std::min(16, 512 / ((B.m + 63) / 64))) : std::max(1, std::min(16, 255 / ((B.m + 63) / 64)));
+    B.ksplit = B.own ? std::max(1, std::min(16, 512 / ((B.m + 127) / 128))) : std::max(1, std::min(16, 255 / ((B.m + 63) / 64)));
     B.ksplit = envi("HELM_MG3_BT_KSPLIT", B.ksplit);
     B.kc = (B.m + B.ksplit - 1) / B.ksplit;
     B.mpad = B.own ? B.m : B.kc * B.ksplit;          // (the generic GEMM wants equal K chunks: zero rows / columns up to mpad)
-    B.nparts = B.own ? 4 * B.ksplit : B.ksplit;
+    B.nparts = B.ksplit;
     B.device = op->device;
     const size_t tb = (size_t)B.np * B.mpad * B.m * sizeof(cplx);
     const size_t wbytes = (size_t)B.m * B.m * sizeof(cplx);
@@ -491,7 +520,7 @@ int bt_solve(helm_op *op, Bt3 &B, const Mg3Level &L, const cplx *f, cplx *u, int
     auto apply_inverse = [&](int k, cplx *Zk, int sub) -> int {
         const cplx *Tk = B.Tinv + (long long)k * B.mpad * B.m;
         if (B.own) {
-            hipLaunchKernelGGL(k_bt_apply<16>, dim3((B.m + 63) / 64, B.ksplit), dim3(256), 0, st, (const cplx *)B.Y, B.mpad, Tk, B.m, B.kc, nrhs, B.parts);
+            hipLaunchKernelGGL(k_bt_apply<16>, dim3((B.m + 127) / 128, B.ksplit), dim3(256), 0, st, (const cplx *)B.Y, B.mpad, Tk, B.m, B.kc, nrhs, B.parts);
             hipLaunchKernelGGL(k_bt_reduce, dim3(redg), dim3(256), 0, st, (const cplx *)B.parts, B.nparts, pz, Zk, sub);
             return HELM_OK;
         }
