@@ -151,7 +151,7 @@ extern "C" void helm_destroy(helm_op *op) {
     hipFree(op->d_S); hipFree(op->d_rs);
     if (op->mg || op->mg3) mg_destroy(op);
     for (int b = 0; b < 4; ++b) { nd_free(op->direct[b]); op->direct[b] = nullptr; }
-    hipFree(op->d_ws); hipFree(op->d_part); hipFree(op->d_scal);
+    helm_pool_free(op->device, op->d_ws, op->ws_bytes); hipFree(op->d_part); hipFree(op->d_scal);
     if (op->h_scal) hipHostFree(op->h_scal);
     {   // timing events go back to the process-wide free list
         std::lock_guard<std::mutex> lk(g_pool.mu);
@@ -294,8 +294,10 @@ extern "C" int helm_get_diagonals(helm_op *op, double *out) {
 // ---- workspace ------------------------------------------------------------------------------
 static int ensure_ws(helm_op *op, size_t bytes) {
     if (op->ws_bytes >= bytes) return HELM_OK;
-    if (op->d_ws) { hipFree(op->d_ws); op->d_ws = nullptr; op->ws_bytes = 0; }
-    HIP_TRY(op, hipMalloc(&op->d_ws, bytes));
+    // from the size-keyed pool: a job makes one operator per frequency and the Krylov workspace of a 3-D batch is tens of GB
+    if (op->d_ws) { hipStreamSynchronize(op->stream); helm_pool_free(op->device, op->d_ws, op->ws_bytes); op->d_ws = nullptr; op->ws_bytes = 0; }
+    op->d_ws = helm_pool_alloc(op->device, bytes);
+    if (!op->d_ws) HELM_FAIL(op, HELM_ERR_DEVICE, "hipMalloc of the solver workspace (%.1f GB) failed", bytes / 1e9);
     op->ws_bytes = bytes;
     return HELM_OK;
 }

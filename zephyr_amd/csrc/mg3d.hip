@@ -17,6 +17,7 @@ struct Mg3Level {
     int nz = 0, ny = 0, nx = 0;
     long long N = 0;
     cplx *u = nullptr, *f = nullptr, *r = nullptr, *t = nullptr;      // [batch][N]
+    size_t vbytes = 0;
 };
 
 struct Mg3Keep;
@@ -30,6 +31,18 @@ struct Mg3Precond {
 };
 
 namespace {
+
+// the four work vectors of a level ([batch][N] each) come from the size-keyed buffer pool: the next frequency's hierarchy has the same shapes
+bool level_vectors(helm_op *op, Mg3Level &L, int batch) {
+    L.vbytes = (size_t)batch * L.N * sizeof(cplx);
+    cplx **v[4] = {&L.u, &L.f, &L.r, &L.t};
+    for (int i = 0; i < 4; ++i) { *v[i] = (cplx *)helm_pool_alloc(op->device, L.vbytes); if (!*v[i]) return false; }
+    return true;
+}
+void level_vectors_free(helm_op *op, Mg3Level &L) {
+    cplx **v[4] = {&L.u, &L.f, &L.r, &L.t};
+    for (int i = 0; i < 4; ++i) { if (*v[i]) helm_pool_free(op->device, *v[i], L.vbytes); *v[i] = nullptr; }
+}
 
 double envd(const char *n, double d) { const char *v = getenv(n); return v ? atof(v) : d; }
 int envi(const char *n, int d) { const char *v = getenv(n); return v ? atoi(v) : d; }
@@ -174,6 +187,8 @@ struct Bt3 {                        // direct solver of the coarsest level
     int device = 0; size_t tbytes = 0;   // Tinv comes from the size-keyed buffer pool (the next frequency takes it over without a hipMalloc)
     long long ss = 0, sa = 0, sb = 0, N = 0;      // node strides of the sweep axis / the two in-plane axes
     cplx *Tinv = nullptr;           // np x (mpad x m): inverse of the transposed Schur complement of plane k (rows >= m are zero)
+    float2 *Tinv32 = nullptr;       // single-precision copy, np x (m x ld32), used INSTEAD of Tinv (f32 = true: Tinv is then not kept)
+    bool f32 = false; int ld32 = 0; size_t tbytes32 = 0;
     cplx *Y = nullptr;              // batch x mpad: packed right-hand side of one plane (columns >= m stay zero)
     cplx *Z = nullptr;              // np x batch x m: forward-substituted planes, then the solution
     cplx *parts = nullptr;          // ksplit x batch x m: partial products of the split-K GEMM
@@ -433,6 +448,89 @@ __global__ __launch_bounds__(256, 2) void k_bt_apply(const cplx *__restrict__ Y,
     }
 }
 
+// Single-precision variant: the plane inverses are stored as float2 (half the bytes, half the 17 GB) and the products run in fp32 --
+// the cycle is a preconditioner, its coarse solve does not need more than ~1e-5.  A lane owns two ADJACENT columns (one 16-byte load).
+template <int NR>
+__global__ __launch_bounds__(256, 2) void k_bt_apply32(const cplx *__restrict__ Y, int ldy, const float2 *__restrict__ T, int m, int ld, int kc, int nrhs,
+                                                       cplx *__restrict__ parts) {
+    __shared__ float2 ys[BTA_KS][NR];                    // 16 KB; doubles as the reduction buffer (3 waves x 8 values x 64 lanes = 12 KB)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * 128 + 2 * lane, c1 = c0 + 1;
+    const int kbeg = blockIdx.y * kc, kend = min(m, kbeg + kc);
+    float2 acc0[NR], acc1[NR];
+    #pragma unroll
+    for (int r = 0; r < NR; ++r) { acc0[r] = make_float2(0.f, 0.f); acc1[r] = make_float2(0.f, 0.f); }
+    const bool live0 = c0 < m, live1 = c1 < m;
+    for (int k0 = kbeg; k0 < kend; k0 += BTA_KS) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < BTA_KS * NR; e += 256) {
+            const int kk = e % BTA_KS, r = e / BTA_KS;
+            const cplx v = (r < nrhs && k0 + kk < kend) ? Y[(long long)r * ldy + k0 + kk] : cmake(0.0, 0.0);
+            ys[kk][r] = make_float2((float)v.x, (float)v.y);
+        }
+        __syncthreads();
+        const int kn = min(BTA_KS, kend - k0);
+        for (int kk = w; kk < kn; kk += 32) {            // eight rows of this wave per step
+            float4 t[8];
+            #pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = kk + 4 * u;
+                t[u] = (live0 && k < kn) ? *reinterpret_cast<const float4 *>(T + (long long)(k0 + k) * ld + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            #pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = min(kk + 4 * u, BTA_KS - 1);
+                #pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const float2 y = ys[k][r];
+                    acc0[r].x = fmaf(y.x, t[u].x, acc0[r].x); acc0[r].x = fmaf(-y.y, t[u].y, acc0[r].x);
+                    acc0[r].y = fmaf(y.x, t[u].y, acc0[r].y); acc0[r].y = fmaf(y.y, t[u].x, acc0[r].y);
+                    acc1[r].x = fmaf(y.x, t[u].z, acc1[r].x); acc1[r].x = fmaf(-y.y, t[u].w, acc1[r].x);
+                    acc1[r].y = fmaf(y.x, t[u].w, acc1[r].y); acc1[r].y = fmaf(y.y, t[u].z, acc1[r].y);
+                }
+            }
+        }
+    }
+    float2 *red = &ys[0][0];
+    #pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        #pragma unroll
+        for (int g = 0; g < NR; g += 8) {
+            __syncthreads();
+            if (w > 0) {
+                #pragma unroll
+                for (int r = 0; r < 8; ++r) red[((w - 1) * 8 + r) * 64 + lane] = half ? acc1[g + r] : acc0[g + r];
+            }
+            __syncthreads();
+            if (w == 0) {
+                #pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    float2 v = half ? acc1[g + r] : acc0[g + r];
+                    #pragma unroll
+                    for (int q = 0; q < 3; ++q) { const float2 o = red[(q * 8 + r) * 64 + lane]; v.x += o.x; v.y += o.y; }
+                    if (half) acc1[g + r] = v; else acc0[g + r] = v;
+                }
+            }
+        }
+    }
+    if (w != 0) return;
+    cplx *out = parts + ((long long)blockIdx.y * nrhs) * m;
+    #pragma unroll
+    for (int r = 0; r < NR; ++r) if (r < nrhs) {
+        if (live0) out[(long long)r * m + c0] = cmake((double)acc0[r].x, (double)acc0[r].y);
+        if (live1) out[(long long)r * m + c1] = cmake((double)acc1[r].x, (double)acc1[r].y);
+    }
+}
+
+__global__ void k_bt_to_f32(const cplx *__restrict__ T, float2 *__restrict__ T32, int m, int ld) {
+    const long long n = (long long)m * ld;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(e / ld), c = (int)(e % ld);
+        const cplx v = c < m ? T[(long long)r * m + c] : cmake(0.0, 0.0);
+        T32[e] = make_float2((float)v.x, (float)v.y);
+    }
+}
+
 // Z (+)= sum of the split-K partial products: sub = 0: Z = sum, 1: Z -= sum
 __global__ void k_bt_reduce(const cplx *__restrict__ parts, int nparts, long long n, cplx *__restrict__ Z, int sub) {
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
@@ -456,6 +554,7 @@ BtGeom bt_geom(const Bt3 &B) { BtGeom g; g.axis = B.axis; g.np = B.np; g.na = B.
 
 void bt_free(Bt3 &B) {
     if (B.Tinv) helm_pool_free(B.device, B.Tinv, B.tbytes);
+    if (B.Tinv32) helm_pool_free(B.device, B.Tinv32, B.tbytes32);
     hipFree(B.Y); hipFree(B.Z); hipFree(B.parts);
     B = Bt3();
 }
@@ -469,7 +568,6 @@ int bt_setup(helm_op *op, Bt3 &B, const Mg3Level &L, int batch) {
     const int ia = axis == 0 ? 1 : 0, ib = axis == 2 ? 1 : 2;
     B.axis = axis; B.np = dims[axis]; B.na = dims[ia]; B.nb = dims[ib]; B.m = B.na * B.nb;
     B.ss = strides[axis]; B.sa = strides[ia]; B.sb = strides[ib]; B.N = L.N; B.batch = batch;
-    // split-K so that the 16 x 64 tiles of the (batch x m x m) products come to ~250 workgroups
     // split-K: ~512 workgroups of 128 columns each (k_bt_apply); HELM_MG3_BT_GEMM=1 goes through the generic batched GEMM instead
     B.own = envi("HELM_MG3_BT_GEMM", 0) == 0 && batch <= 16;
     B.ksplit = B.own ? std::max(1, std::min(16, 512 / ((B.m + 127) / 128))) : std::max(1, std::min(16, 255 / ((B.m + 63) / 64)));
@@ -478,33 +576,40 @@ int bt_setup(helm_op *op, Bt3 &B, const Mg3Level &L, int batch) {
     B.mpad = B.own ? B.m : B.kc * B.ksplit;          // (the generic GEMM wants equal K chunks: zero rows / columns up to mpad)
     B.nparts = B.ksplit;
     B.device = op->device;
-    const size_t tb = (size_t)B.np * B.mpad * B.m * sizeof(cplx);
+    // single-precision plane inverses (default): only two double-precision planes exist at a time during the set-up
+    B.f32 = B.own && envi("HELM_MG3_BT_F32", 1) != 0;
+    B.ld32 = (B.m + 1) & ~1;
     const size_t wbytes = (size_t)B.m * B.m * sizeof(cplx);
+    const size_t tb = B.f32 ? 2 * wbytes : (size_t)B.np * B.mpad * B.m * sizeof(cplx);
     B.tbytes = tb;
+    B.tbytes32 = B.f32 ? (size_t)B.np * B.m * B.ld32 * sizeof(float2) : 0;
     hipStream_t st = op->stream;
     hipStreamSynchronize(st);          // (buffers of the previous frequency go back to the pool only when their work is done)
     B.Tinv = (cplx *)helm_pool_alloc(op->device, tb);
+    if (B.f32) B.Tinv32 = (float2 *)helm_pool_alloc(op->device, B.tbytes32);
     cplx *W = (cplx *)helm_pool_alloc(op->device, wbytes);
-    if (!B.Tinv || !W || hipMalloc((void **)&B.Y, (size_t)batch * B.mpad * sizeof(cplx)) != hipSuccess ||
+    if (!B.Tinv || !W || (B.f32 && !B.Tinv32) || hipMalloc((void **)&B.Y, (size_t)batch * B.mpad * sizeof(cplx)) != hipSuccess ||
         hipMalloc((void **)&B.Z, (size_t)B.np * batch * B.m * sizeof(cplx)) != hipSuccess ||
         hipMalloc((void **)&B.parts, (size_t)B.nparts * batch * B.m * sizeof(cplx)) != hipSuccess) {
         if (W) helm_pool_free(op->device, W, wbytes);
         bt_free(B);
-        HELM_FAIL(op, HELM_ERR_DEVICE, "3-D multigrid: the plane inverses of the coarsest level (%.1f GB) do not fit", tb / 1e9);
+        HELM_FAIL(op, HELM_ERR_DEVICE, "3-D multigrid: the plane inverses of the coarsest level (%.1f GB) do not fit", (tb + B.tbytes32) / 1e9);
     }
-    if (B.mpad != B.m) hipMemsetAsync(B.Tinv, 0, tb, st);
+    if (!B.f32 && B.mpad != B.m) hipMemsetAsync(B.Tinv, 0, tb, st);
     hipMemsetAsync(B.Y, 0, (size_t)batch * B.mpad * sizeof(cplx), st);
     const BtGeom g = bt_geom(B);
     const long long mm = (long long)B.m * B.m;
     int rc = HELM_OK;
     for (int k = 0; k < B.np && !rc; ++k) {
-        cplx *Tk = B.Tinv + (long long)k * B.mpad * B.m;
-        hipLaunchKernelGGL(k_bt_schur_t, dim3((unsigned)((mm + 255) / 256)), dim3(256), 0, st, (const cplx *)L.op->d_C, g, k,
-                           (const cplx *)(k ? Tk - (long long)B.mpad * B.m : nullptr), Tk);
+        cplx *Tk = B.f32 ? B.Tinv + (long long)(k & 1) * mm : B.Tinv + (long long)k * B.mpad * B.m;
+        const cplx *Tprev = !k ? nullptr : (B.f32 ? B.Tinv + (long long)((k - 1) & 1) * mm : Tk - (long long)B.mpad * B.m);
+        hipLaunchKernelGGL(k_bt_schur_t, dim3((unsigned)((mm + 255) / 256)), dim3(256), 0, st, (const cplx *)L.op->d_C, g, k, Tprev, Tk);
         rc = nd_dense_inverse(op, Tk, B.m, W);
+        if (B.f32 && !rc) hipLaunchKernelGGL(k_bt_to_f32, dim3(4096), dim3(256), 0, st, (const cplx *)Tk, B.Tinv32 + (long long)k * B.m * B.ld32, B.m, B.ld32);
     }
     hipStreamSynchronize(st);
     helm_pool_free(op->device, W, wbytes);
+    if (B.f32 && B.Tinv) { helm_pool_free(op->device, B.Tinv, B.tbytes); B.Tinv = nullptr; }
     if (rc) { bt_free(B); return rc; }
     return HELM_OK;
 }
@@ -518,6 +623,12 @@ int bt_solve(helm_op *op, Bt3 &B, const Mg3Level &L, const cplx *f, cplx *u, int
     const long long pz = (long long)nrhs * B.m;              // one packed plane of Z
     const unsigned redg = (unsigned)std::min<long long>((pz + 255) / 256, 4096);
     auto apply_inverse = [&](int k, cplx *Zk, int sub) -> int {
+        if (B.f32) {
+            hipLaunchKernelGGL(k_bt_apply32<16>, dim3((B.m + 127) / 128, B.ksplit), dim3(256), 0, st, (const cplx *)B.Y, B.mpad,
+                               (const float2 *)(B.Tinv32 + (long long)k * B.m * B.ld32), B.m, B.ld32, B.kc, nrhs, B.parts);
+            hipLaunchKernelGGL(k_bt_reduce, dim3(redg), dim3(256), 0, st, (const cplx *)B.parts, B.nparts, pz, Zk, sub);
+            return HELM_OK;
+        }
         const cplx *Tk = B.Tinv + (long long)k * B.mpad * B.m;
         if (B.own) {
             hipLaunchKernelGGL(k_bt_apply<16>, dim3((B.m + 127) / 128, B.ksplit), dim3(256), 0, st, (const cplx *)B.Y, B.mpad, Tk, B.m, B.kc, nrhs, B.parts);
@@ -635,10 +746,7 @@ int setup_keep(helm_op *op, Mg3Precond *P, int batch, int ncoarsen, double tauM)
         int rc = helm_set_model(Lr.op, (const double *)c.data(), rho.data(), nullptr, nullptr, nullptr);
         if (!rc) rc = helm_assemble(Lr.op, op->a_freq_re, op->a_freq_im, tauM, 0.0, cpml);
         if (rc) HELM_FAIL(op, rc, "%s", helm_last_error(Lr.op));
-        const size_t vb = (size_t)batch * Lr.N * sizeof(cplx);
-        if (hipMalloc((void **)&Lr.u, vb) != hipSuccess || hipMalloc((void **)&Lr.f, vb) != hipSuccess ||
-            hipMalloc((void **)&Lr.r, vb) != hipSuccess || hipMalloc((void **)&Lr.t, vb) != hipSuccess)
-            HELM_FAIL(op, HELM_ERR_DEVICE, "3-D multigrid: level vectors do not fit");
+        if (!level_vectors(op, Lr, batch)) HELM_FAIL(op, HELM_ERR_DEVICE, "3-D multigrid: level vectors do not fit");
         if (l == ncoarsen) break;
         cplx *dl1 = nullptr;
         if (hipMalloc((void **)&dl1, (size_t)Lr.N * sizeof(cplx)) != hipSuccess) HELM_FAIL(op, HELM_ERR_DEVICE, "3-D multigrid: level vectors do not fit");
@@ -672,7 +780,7 @@ void mg3_destroy(helm_op *op) {
     if (!P) return;
     keep_free(P);
     for (Mg3Level &L : P->lv) {
-        hipFree(L.u); hipFree(L.f); hipFree(L.r); hipFree(L.t);
+        level_vectors_free(op, L);
         if (L.op) { L.op->own_stream = false; L.op->stream = nullptr; helm_destroy(L.op); }
     }
     hipFree(P->cinvT);
@@ -720,7 +828,7 @@ int mg3_setup(helm_op *op, int batch) {
             // not this time: release what was built and go on with the standard hierarchy
             keep_free(P);
             for (Mg3Level &L : P->lv) {
-                hipFree(L.u); hipFree(L.f); hipFree(L.r); hipFree(L.t);
+                level_vectors_free(op, L);
                 if (L.op) { L.op->own_stream = false; L.op->stream = nullptr; helm_destroy(L.op); }
             }
             P->lv.clear();
@@ -751,10 +859,7 @@ int mg3_setup(helm_op *op, int batch) {
         if (!rc) rc = helm_assemble(Lr.op, op->a_freq_re, op->a_freq_im, tauM, 0.0, cpml);
         if (!rc) rc = helm_ensure_scaled(Lr.op);
         if (rc) return fail(rc, helm_last_error(Lr.op));
-        const size_t vb = (size_t)batch * Lr.N * sizeof(cplx);
-        if (hipMalloc((void **)&Lr.u, vb) != hipSuccess || hipMalloc((void **)&Lr.f, vb) != hipSuccess ||
-            hipMalloc((void **)&Lr.r, vb) != hipSuccess || hipMalloc((void **)&Lr.t, vb) != hipSuccess)
-            return fail(HELM_ERR_DEVICE, "3-D multigrid: level vectors do not fit");
+        if (!level_vectors(op, Lr, batch)) return fail(HELM_ERR_DEVICE, "3-D multigrid: level vectors do not fit");
         const int nzc = (nz + 1) / 2, nyc = (ny + 1) / 2, nxc = (nx + 1) / 2;
         const int npmlc = std::max((npml - 1) / 2 + 1, 2);
         const long long Nc = (long long)nzc * nyc * nxc;
