@@ -302,6 +302,7 @@ struct GemmRows {
     int z0 = 0;           // batch index of blockIdx.z == 0 (launches are chunked along z)
     int fwd3 = 0;         // forward-gather mode (k_zgemm2<.., 2, ..>): Bx = right-hand sides, Cix = front-vector arena, Cox = where y_S goes
     int zr0 = 0, zr1 = 0, zc0 = 0, zc1 = 0;   // rows [zr0, zr1) and columns [zc0, zc1) of C are taken as zero on input (beta masked): blocked Gauss-Jordan
+    int sk0 = 0, sk1 = 0;                     // the diagonal block [sk0, sk1)^2 of C is neither read nor written (the next pivot block, owned by k_gj_pivot)
 };
 #define GB_K 8
 #define GB_KIDX 512       // largest K with indexed B rows
@@ -536,10 +537,12 @@ __global__ __launch_bounds__(256, OCC) void k_zgemm2(int M, int Nn, int K, cplx 
             cin = ix >= 0 ? R.Cix + (long long)ix * R.ldx : nullptr;
         }
         const bool zrow = r >= R.zr0 && r < R.zr1;
+        const bool srow = r >= R.sk0 && r < R.sk1;
         #pragma unroll
         for (int j = 0; j < RN; ++j) {
             const int cc = n0 + j * TXN + tx;
             if (cc >= Nn) continue;
+            if (srow && cc >= R.sk0 && cc < R.sk1) continue;
             cplx v = cmul(alpha, acc[i][j]);
             if (IDX == 2) {
                 cplx c = cin ? cin[cc] : cmake(0.0, 0.0);
@@ -884,6 +887,108 @@ __global__ __launch_bounds__(256) void k_gj_panel(cplx *T0, int ld, long long st
             const int gc = k0 + cperm[j];
             if (gc >= s0 && gc < s0 + 64) Wr[(long long)r * n + gc] = S.a[cperm[r]][j];
         }
+}
+
+// Look-ahead form of the panel step.  The Gauss-Jordan sweep of the next pivot block only needs that 32 x 32 block, so
+// it runs on a second stream beside the rank-32 update of the whole front: k_gj_pivot applies the pending update to its
+// block privately (the GEMM skips it, GemmRows::sk0/sk1), inverts it and leaves P in Pb; k_gj_slices then forms the
+// panels R_k = P T[k-rows, :], C_k = T[:, k-cols] from the updated front.
+__global__ __launch_bounds__(256) void k_gj_pivot(const cplx *T0, int ld, long long stride, int n, int k0, int nb, const cplx *Wc0, const cplx *Wr0, long long wstride,
+                                                  cplx *Pb0, long long pstride) {
+    __shared__ Gj32 S;
+    __shared__ cplx wc[PNB][PNB + 1], wr[PNB][PNB + 1];
+    __shared__ int cperm[PNB];
+    const cplx *T = T0 + (long long)blockIdx.x * stride;
+    const cplx *Wc = Wc0 + (long long)blockIdx.x * wstride, *Wr = Wr0 + (long long)blockIdx.x * wstride;
+    cplx *Pb = Pb0 + (long long)blockIdx.x * pstride;
+    const int tid = threadIdx.x;
+    const int i = tid >> 3, j0 = (tid & 7) * 4;
+    const bool pending = k0 > 0;                          // the update of step k-1 (full width PNB) has not touched this block
+    if (pending) {
+        #pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = j0 + q;
+            wc[i][j] = i < nb ? Wc[(long long)(k0 + i) * PNB + j] : cmake(0.0, 0.0);
+            wr[i][j] = j < nb ? Wr[(long long)i * n + k0 + j] : cmake(0.0, 0.0);
+        }
+        __syncthreads();
+    }
+    {
+        cplx v[4];
+        #pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = j0 + q;
+            v[q] = (i < nb && j < nb) ? T[(long long)(k0 + i) * ld + k0 + j] : cmake(i == j ? 1.0 : 0.0, 0.0);
+        }
+        if (pending) {
+            cplx acc[4];
+            #pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = cmake(0.0, 0.0);
+            for (int p = 0; p < PNB; ++p) {
+                const cplx a = wc[i][p];
+                #pragma unroll
+                for (int q = 0; q < 4; ++q) cfma(acc[q], a, wr[p][j0 + q]);
+            }
+            #pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = csub(v[q], acc[q]);
+        }
+        #pragma unroll
+        for (int q = 0; q < 4; ++q) S.a[i][j0 + q] = v[q];
+    }
+    __syncthreads();
+    gj32(S, nb, tid);
+    if (tid < PNB) cperm[tid] = S.piv[tid] & 31;            // P[r][sigma(j)] = S.a[sigma(r)][j]
+    __syncthreads();
+    #pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = j0 + q;
+        if (i < nb && j < nb) Pb[i * PNB + cperm[j]] = S.a[cperm[i]][j];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gj_slices(const cplx *T0, int ld, long long stride, int n, int k0, int nb, cplx *Wc0, cplx *Wr0, long long wstride,
+                                                   const cplx *Pb0, long long pstride) {
+    __shared__ cplx P[PNB][PNB + 1];
+    __shared__ cplx t[PNB][64 + 1];
+    const cplx *T = T0 + (long long)blockIdx.y * stride;
+    cplx *Wc = Wc0 + (long long)blockIdx.y * wstride, *Wr = Wr0 + (long long)blockIdx.y * wstride;
+    const cplx *Pb = Pb0 + (long long)blockIdx.y * pstride;
+    const int tid = threadIdx.x;
+    const int s0 = blockIdx.x * 64;
+    for (int e = tid; e < PNB * PNB; e += 256) {
+        const int r = e >> 5, c = e & 31;
+        P[r][c] = (r < nb && c < nb) ? Pb[e] : cmake(0.0, 0.0);
+    }
+    for (int e = tid; e < PNB * 64; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        t[r][c] = (r < nb && s0 + c < n) ? T[(long long)(k0 + r) * ld + s0 + c] : cmake(0.0, 0.0);
+    }
+    for (int e = tid; e < 64 * PNB; e += 256) {
+        const int r = e >> 5, c = e & 31;
+        if (s0 + r >= n || c >= nb) continue;
+        const int gr = s0 + r;
+        cplx v = T[(long long)gr * ld + k0 + c];
+        if (gr >= k0 && gr < k0 + nb) v = (gr - k0 == c) ? cmake(-1.0, 0.0) : cmake(0.0, 0.0);
+        Wc[(long long)gr * PNB + c] = v;
+    }
+    __syncthreads();
+    const int r = tid >> 3, c0 = (tid & 7) * 8;
+    cplx acc[8];
+    #pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = cmake(0.0, 0.0);
+    for (int j = 0; j < nb; ++j) {
+        const cplx a = P[r][j];
+        #pragma unroll
+        for (int i = 0; i < 8; ++i) cfma(acc[i], a, t[j][c0 + i]);
+    }
+    if (r < nb) {
+        #pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int gc = s0 + c0 + i;
+            if (gc >= n) continue;
+            Wr[(long long)r * n + gc] = (gc >= k0 && gc < k0 + nb) ? P[r][gc - k0] : acc[i];
+        }
+    }
 }
 
 // ---- solve-phase data movement -----------------------------------------------------------------------------------
@@ -1235,6 +1340,17 @@ struct GemmRun {
     }
 };
 
+// second stream + two events of the look-ahead Gauss-Jordan, created on first use (released in helm_destroy)
+static bool nd_pivot_stream(helm_op *op) {
+    if (op->pivot_stream) return true;
+    int plo = 0, phi = 0;
+    hipDeviceGetStreamPriorityRange(&plo, &phi);
+    if (hipStreamCreateWithPriority(&op->pivot_stream, hipStreamNonBlocking, phi) != hipSuccess) { op->pivot_stream = nullptr; return false; }
+    for (int i = 0; i < 2; ++i)
+        if (hipEventCreateWithFlags(&op->ev_la[i], hipEventDisableTiming) != hipSuccess) return false;
+    return true;
+}
+
 // in-place inverse of `batch` n x n blocks (row-major, leading dimension ld, batch stride `stride`); W: workspace with
 // batch stride ws, at least n*n elements per matrix
 void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cplx *W, long long ws, int align = 1, int base = 0) {
@@ -1248,6 +1364,38 @@ void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cp
     static const int blocked_max_batch = getenv("HELM_ND_BLOCKED_BATCH") ? atoi(getenv("HELM_ND_BLOCKED_BATCH")) : 1024;
     if (blocked && batch <= blocked_max_batch && gemm_variant() != 0 && n > gj_base && gj_base == 32 && (long long)2 * PNB * n <= ws) {
         cplx *Wc = W, *Wr = W + (long long)PNB * n;
+        // look-ahead: the pivot block of step k+1 is inverted on a second (high-priority) stream beside the update of step k
+        // (only where the update is long enough to hide the sweep and the two cross-stream hops a step costs: the dense plane inverses of the
+        // 3-D coarse solve, n = 3713: 148 -> ~130 us per block step; on the 2-D fronts, n <= 1024, it LOSES 5 %)
+        static const int lookahead = getenv("HELM_ND_LOOKAHEAD") ? atoi(getenv("HELM_ND_LOOKAHEAD")) : 1;
+        static const int lookahead_min_n = getenv("HELM_ND_LOOKAHEAD_N") ? atoi(getenv("HELM_ND_LOOKAHEAD_N")) : 2048;
+        if (lookahead && op && batch == 1 && n >= lookahead_min_n && (long long)2 * PNB * n + PNB * PNB <= ws && nd_pivot_stream(op)) {
+            hipStream_t sp = op->pivot_stream;
+            cplx *Pb = W + (long long)2 * PNB * n;
+            hipEventRecord(op->ev_la[0], st);                              // the front is assembled
+            hipStreamWaitEvent(sp, op->ev_la[0], 0);
+            for (int k0 = 0; k0 < n; k0 += PNB) {
+                const int nb = std::min(PNB, n - k0);
+                hipLaunchKernelGGL(k_gj_pivot, dim3(batch), dim3(256), 0, sp, M, ld, stride, n, k0, nb, Wc, Wr, ws, Pb, ws);
+                hipEventRecord(op->ev_la[1], sp);
+                if (k0 > 0) {                                              // update of step k-1, beside the pivot kernel
+                    const int kp = k0 - PNB;
+                    GemmRows R; R.zr0 = kp; R.zr1 = k0; R.zc0 = kp; R.zc1 = k0; R.sk0 = k0; R.sk1 = k0 + nb;
+                    gemm(op, n, n, PNB, cmake(-1, 0), Wc, PNB, ws, Wr, n, ws, cmake(1, 0), M, ld, stride, batch, &R);
+                }
+                hipStreamWaitEvent(st, op->ev_la[1], 0);
+                hipLaunchKernelGGL(k_gj_slices, dim3((n + 63) / 64, batch), dim3(256), 0, st, M, ld, stride, n, k0, nb, Wc, Wr, ws, Pb, ws);
+                if (k0 + PNB < n) {
+                    hipEventRecord(op->ev_la[0], st);
+                    hipStreamWaitEvent(sp, op->ev_la[0], 0);
+                }
+                else {
+                    GemmRows R; R.zr0 = k0; R.zr1 = k0 + nb; R.zc0 = k0; R.zc1 = k0 + nb;
+                    gemm(op, n, n, nb, cmake(-1, 0), Wc, PNB, ws, Wr, n, ws, cmake(1, 0), M, ld, stride, batch, &R);
+                }
+            }
+            return;
+        }
         for (int k0 = 0; k0 < n; k0 += PNB) {
             const int nb = std::min(PNB, n - k0);
             for (int b0 = 0; b0 < batch; b0 += 65535) {

@@ -583,6 +583,13 @@ int bt_setup(helm_op *op, Bt3 &B, const Mg3Level &L, int batch) {
     const size_t tb = B.f32 ? 2 * wbytes : (size_t)B.np * B.mpad * B.m * sizeof(cplx);
     B.tbytes = tb;
     B.tbytes32 = B.f32 ? (size_t)B.np * B.m * B.ld32 * sizeof(float2) : 0;
+    {   // leave room for the Krylov workspace: the plane inverses may take a third of the device memory (HELM_MG3_BT_MAXGB overrides)
+        size_t freeb = 0, totb = 0;
+        hipMemGetInfo(&freeb, &totb);
+        const double cap = envd("HELM_MG3_BT_MAXGB", totb / 3.0e9) * 1e9;
+        if ((double)(tb + B.tbytes32) > cap)
+            HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "3-D multigrid: the plane inverses of the directly solved level (%.1f GB) exceed the budget of %.1f GB", (tb + B.tbytes32) / 1e9, cap / 1e9);
+    }
     hipStream_t st = op->stream;
     hipStreamSynchronize(st);          // (buffers of the previous frequency go back to the pool only when their work is done)
     B.Tinv = (cplx *)helm_pool_alloc(op->device, tb);
