@@ -199,6 +199,16 @@ int helm_debug_inverse(int device, int n, double *A, int batch);
  * variant `variant` (-1: default; 0: first-generation tile kernel; 1 / 2: conflict-free double-buffered kernel, K slab 8 / 16) */
 int helm_debug_zgemm_bench(int device, int M, int N, int K, int batch, int variant, int reps, double *ms_out);
 
+/* --- diagnostics of the 3-D multigrid hierarchy (host only, no GPU needed; zephyr_amd/csrc/mg3d.hip) ------------------ */
+/* One axis of n nodes (spacing h, npml absorbing-layer nodes at each end, damping amplitude cpml) coarsened `level` times by the
+ * layer-preserving rule (all layer nodes kept, the interior halved).  Returns the node count nc of that level (< 0: bad arguments)
+ * and fills whichever outputs are not NULL: x[nc] coordinates, lay[nc] layer flags, lap[3 nc] complex factors L(-1), L(0), L(+1)
+ * of (1/xi) d/dx (1/xi) d/dx on the non-uniform axis for omega = om_re + i om_im; the transfer to the next level: pc / pw [2 nc]
+ * coarse nodes and weights every node interpolates from, *n_next its size, rf[n_next] / rw[3 n_next] centre node and weights of
+ * the normalised transposed interpolation. */
+int helm_mg3_axis(int n, int npml, double h, double cpml, double om_re, double om_im, int level, double *x, int *lay, double *lap,
+                  int *pc, double *pw, int *n_next, int *rf, double *rw);
+
 #ifdef __cplusplus
 }
 #endif

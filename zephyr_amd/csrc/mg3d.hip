@@ -170,7 +170,7 @@ int cycle(helm_op *op, Mg3Precond *P, size_t l, int nrhs, cplx *final_out = null
 //   * the preconditioner is the operator itself with its TRUE layer and a small shift (beta = 0.1);
 //   * coarsening stops while the interior still has >= 10 points per wavelength and that level is solved directly:
 //     block-tridiagonal elimination over the planes normal to the longest axis, dense plane inverses in HBM
-//     (17 GB for the 79 x 79 x 47 level of config 5), applied as split-K batched GEMMs.
+//     (8.7 GB in single precision for the 79 x 79 x 47 level of config 5), applied as split-K batched GEMMs.
 // numpy prototype (96 x 96 x 64, 40 / 100 points per wavelength): 9 / 7 BiCGSTAB iterations against 219 / 811 for the recipe above.
 // ================================================================================================================
 struct Ax3 {
@@ -908,4 +908,46 @@ int mg3_apply(helm_op *op, const cplx *in, cplx *out, int nrhs) {
     if (rc) return rc;
     if (P->lv.size() == 1) HIP_TRY(op, hipMemcpyAsync(out, L0.u, (size_t)nrhs * L0.N * sizeof(cplx), hipMemcpyDeviceToDevice, op->stream));
     return HELM_OK;
+}
+
+// ---- diagnostics exported through the C ABI (host side of the layer-preserving hierarchy, no GPU needed) ----------------
+// One axis of n nodes (spacing h, npml layer nodes at each end, damping amplitude cpml), coarsened `level` times.  Returns the number of
+// nodes nc of that level and writes, if the pointers are not null: x[nc] node coordinates, lay[nc] layer flags, lap[3 * nc] the factors
+// L(-1), L(0), L(+1) (complex, interleaved re / im) for omega = (om_re, om_im); and for the transfer from this level to the next one:
+// pc[2 * nc] / pw[2 * nc] the two coarse nodes and weights each node interpolates from, rf[ncn] / rw[3 * ncn] the centre node and the
+// three weights of every node of the next level (ncn through *n_next).
+extern "C" int helm_mg3_axis(int n, int npml, double h, double cpml, double om_re, double om_im, int level, double *x, int *lay, double *lap,
+                             int *pc, double *pw, int *n_next, int *rf, double *rw) {
+    if (n < 3 || npml < 2 || 2 * npml > n || level < 0) return -1;
+    Ax3 a;
+    a.x.resize(n); a.gam.assign(n, 0.0); a.lay.assign(n, 0);
+    const double Lh = h * (npml - 1);
+    for (int i = 0; i < n; ++i) a.x[i] = i * h;
+    for (int k = 0; k < npml; ++k) {
+        a.gam[k] = cpml * cos((M_PI / 2) * (k * h / Lh)); a.lay[k] = 1;
+        a.gam[n - npml + k] = cpml * cos((M_PI / 2) * ((npml - 1 - k) * h / Lh)); a.lay[n - npml + k] = 1;
+    }
+    Ax3 c; std::vector<int> kept; std::vector<PTab> pt; std::vector<RTab> rt;
+    for (int l = 0; l < level; ++l) { coarsen_axis(a, true, c, kept, pt, rt); a = c; }
+    const int nc = a.n();
+    if (x) for (int i = 0; i < nc; ++i) x[i] = a.x[i];
+    if (lay) for (int i = 0; i < nc; ++i) lay[i] = a.lay[i];
+    if (lap) {
+        std::vector<cplx> Lt;
+        lap_from_axis(a, std::complex<double>(om_re, om_im), Lt);
+        for (size_t i = 0; i < Lt.size(); ++i) { lap[2 * i] = Lt[i].x; lap[2 * i + 1] = Lt[i].y; }
+    }
+    if (pc || pw || n_next || rf || rw) {
+        coarsen_axis(a, true, c, kept, pt, rt);
+        if (n_next) *n_next = c.n();
+        for (int i = 0; i < nc; ++i) {
+            if (pc) { pc[2 * i] = pt[i].c0; pc[2 * i + 1] = pt[i].c1; }
+            if (pw) { pw[2 * i] = pt[i].w0; pw[2 * i + 1] = pt[i].w1; }
+        }
+        for (int i = 0; i < c.n(); ++i) {
+            if (rf) rf[i] = rt[i].f;
+            if (rw) { rw[3 * i] = rt[i].wl; rw[3 * i + 1] = rt[i].wc; rw[3 * i + 2] = rt[i].wr; }
+        }
+    }
+    return nc;
 }
