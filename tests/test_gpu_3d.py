@@ -122,6 +122,41 @@ def test_3d_layer_preserving_hierarchy(helm_lib, monkeypatch):
     assert its_keep <= 30 and its_keep * 4 < its_std, (its_keep, its_std)
 
 
+def test_3d_layer_preserving_hierarchy_anisotropic_spacing_and_attenuation(helm_lib):
+    """The same hierarchy with dx != dy != dz and a finite tau (complex omega in the mass term and in the layer stretch): parity with the
+    sparse LU of the oracle's matrix; more than 16 right-hand sides in one batch go through the generic batched GEMM of the coarse solve."""
+    import zephyr_amd as za
+    from oracle import helm3d_oracle as h3
+    import scipy.sparse.linalg as spla
+    nz, ny, nx, f, tau = 30, 32, 34, 4., 0.8
+    dx, dy, dz = 10., 9., 11.
+    rng = np.random.default_rng(11)
+    c = 1900. + 300. * rng.random((nz, ny, nx))
+    cfg = dict(nx=nx, ny=ny, nz=nz, dx=dx, dy=dy, dz=dz, c=c, rho=1000., freq=f, tau=tau, nPML=6, rtol=1e-9, maxit=5000, method='mg')
+    N = nz * ny * nx
+    q = np.zeros((N, 2), complex)
+    q[(14 * ny + 12) * nx + 14, 0] = 1.0
+    q[(9 * ny + 18) * nx + 20, 1] = 1.0 - 0.5j
+    A = h3.coefficients_to_csr3(h3.helm3d_coefficients(nz, ny, nx, c, 1000., f, dx=dx, dy=dy, dz=dz, tau=tau, nPML=6)).tocsc()
+    lu = spla.splu(A)
+    ref = np.conj(lu.solve(q))
+    op = za.Helm3D(cfg)
+    u = op * q
+    assert all(i['status'] == 0 and i['method'] == 3 for i in op.lastInfo), op.lastInfo
+    assert np.linalg.norm(u - ref) / np.linalg.norm(ref) <= 1e-6
+    assert max(i['iterations'] for i in op.lastInfo) <= 30, op.lastInfo
+    # a batch of 20: the plane products of the coarse solve leave k_bt_apply (16 right-hand sides) for the batched GEMM
+    q20 = np.zeros((N, 20), complex)
+    for s in range(20):
+        q20[((8 + s) * ny + 10 + s) * nx + 9 + s, s] = 1.0 + 0.1j * s
+    op20 = za.Helm3D(dict(cfg, batch=20))
+    u20 = op20 * q20
+    assert all(i['status'] == 0 for i in op20.lastInfo), op20.lastInfo
+    ref20 = np.conj(lu.solve(q20))
+    assert np.linalg.norm(u20 - ref20) / np.linalg.norm(ref20) <= 1e-6
+    assert max(i['iterations'] for i in op20.lastInfo) <= 30, op20.lastInfo
+
+
 def test_3d_mid_size_properties_128x128x64(helm_lib):
     """Config-5 geometry at one eighth of its size (c = 2000 m/s, h = 10 m, 5 Hz): size-independent properties of the solve --
     residual of the returned field through the independent apply entry point, conj-linearity, agreement with the analytic
