@@ -157,6 +157,33 @@ def test_3d_layer_preserving_hierarchy_anisotropic_spacing_and_attenuation(helm_
     assert max(i['iterations'] for i in op20.lastInfo) <= 30, op20.lastInfo
 
 
+def test_3d_retreat_to_the_standard_cycle(helm_lib, monkeypatch):
+    """If the layer-preserving hierarchy has not converged within its iteration cap (forced here: 3), the frequency retreats to the
+    standard cycle and goes on from the iterates reached: same wavefield, status 0."""
+    import zephyr_amd as za
+    nz, ny, nx = 30, 26, 28
+    rng = np.random.default_rng(3)
+    c = 1900. + 400. * rng.random((nz, ny, nx))
+    cfg = dict(nx=nx, ny=ny, nz=nz, dx=10., c=c, rho=1000., freq=6., nPML=6, rtol=1e-9, maxit=20000, method='auto')
+    N = nz * ny * nx
+    q = np.zeros((N, 2), complex)
+    q[(15 * ny + 12) * nx + 14, 0] = 1.0
+    q[(9 * ny + 18) * nx + 20, 1] = 1.0 - 0.5j
+    op = za.Helm3D(cfg)
+    u = op * q
+    its = max(i['iterations'] for i in op.lastInfo)
+    monkeypatch.setenv('HELM_MG3_KEEP_CAP', '3')
+    op2 = za.Helm3D(cfg)
+    u2 = op2 * q
+    assert all(i['status'] == 0 and i['relres'] <= 1e-9 for i in op2.lastInfo), op2.lastInfo
+    its2 = max(i['iterations'] for i in op2.lastInfo)
+    assert its2 > 3 * its, (its, its2)                     # it did go on with the slower cycle
+    assert np.linalg.norm(u2 - u) / np.linalg.norm(u) <= 1e-7
+    u3 = op2 * q                                           # the retreat holds for the rest of this frequency
+    assert all(i['status'] == 0 for i in op2.lastInfo)
+    assert np.linalg.norm(u3 - u) / np.linalg.norm(u) <= 1e-7
+
+
 def test_3d_mid_size_properties_128x128x64(helm_lib):
     """Config-5 geometry at one eighth of its size (c = 2000 m/s, h = 10 m, 5 Hz): size-independent properties of the solve --
     residual of the returned field through the independent apply entry point, conj-linearity, agreement with the analytic

@@ -268,6 +268,7 @@ extern "C" int helm_assemble(helm_op *op, double freq_re, double freq_im, double
     op->assembled = true;
     op->a_freq_re = freq_re; op->a_freq_im = freq_im; op->a_tau = tau; op->a_ky = ky; op->a_cpml = cPML;
     if (op->mg || op->mg3) mg_destroy(op);      // preconditioner belongs to the previous frequency
+    op->mg3_no_keep = false;
     for (int b = 0; b < 4; ++b) { nd_free(op->direct[b]); op->direct[b] = nullptr; }   // and so do the direct factors
     op->direct_failed = false;
     return HELM_OK;
@@ -1138,10 +1139,32 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
                 if (any) { rc = run_cgnr(op, block, B, o.maxit, check_every); if (rc) return rc; }
             } else {
                 // in AUTO mode a preconditioned run that has not converged after 5000 iterations is handed to CGNR
-                const int cap = (use_mg && o.method == HELM_AUTO) ? std::min(o.maxit, 5000) : o.maxit;
+                int cap = (use_mg && o.method == HELM_AUTO) ? std::min(o.maxit, 5000) : o.maxit;
+                // the layer-preserving 3-D hierarchy needs tens of iterations; if it has not converged after HELM_MG3_KEEP_CAP (300) the
+                // frequency retreats to the standard cycle and goes on from the iterates reached
+                const bool keep3 = use_mg && op->ny > 0 && mg3_is_layer_preserving(op);
+                if (keep3) cap = std::min(cap, getenv("HELM_MG3_KEEP_CAP") ? std::max(1, atoi(getenv("HELM_MG3_KEEP_CAP"))) : 300);
                 rc = run_bicgstab(op, block, B, cap, check_every, 25, restarts);
                 if (rc) return rc;
-                if (o.method == HELM_AUTO && use_mg && round == 0) {
+                if (keep3 && round == 0) {
+                    rc = download_scal(op, n);
+                    if (rc) return rc;
+                    bool any = false;
+                    for (int b = 0; b < n; ++b) {
+                        const int st = op->h_scal[b].status;
+                        B.h_mask[b] = (st == ST_BREAKDOWN || st == ST_FROZEN);
+                        any = any || B.h_mask[b];
+                    }
+                    if (any) {
+                        rc = mg3_retreat(op, Bmax);
+                        if (rc) return rc;
+                        rc = restart_masked(op, block, B);
+                        if (rc) return rc;
+                        rc = run_bicgstab(op, block, B, o.method == HELM_AUTO ? std::min(o.maxit, 5000) : o.maxit, check_every, 25, restarts);
+                        if (rc) return rc;
+                    }
+                }
+                if (o.method == HELM_AUTO && use_mg && round == 0 && op->ny == 0) {      // (no adjoint apply, hence no CGNR, in 3-D)
                     rc = download_scal(op, n);
                     if (rc) return rc;
                     bool any = false;

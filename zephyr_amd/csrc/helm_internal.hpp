@@ -119,6 +119,7 @@ struct helm_op {
     double a_freq_re = 0, a_freq_im = 0, a_tau = 0, a_ky = 0, a_cpml = 0;   // parameters of the last assemble
     struct MgPrecond *mg = nullptr;
     struct Mg3Precond *mg3 = nullptr;    // 3-D multigrid preconditioner (mg3d.hip)
+    bool mg3_no_keep = false;            // this frequency retreated from the layer-preserving hierarchy to the standard cycle (capi.hip)
     struct NdFactor *direct[4] = {nullptr, nullptr, nullptr, nullptr};   // sparse direct factors per block, valid until the next assemble
     bool direct_failed = false;
     int nblocks = 1;
@@ -177,6 +178,8 @@ int mg_apply(helm_op *op, const cplx *in, cplx *out, int nrhs, const RhsScal *sc
 int mg3_setup(helm_op *op, int batch);
 void mg3_destroy(helm_op *op);
 int mg3_apply(helm_op *op, const cplx *in, cplx *out, int nrhs);
+bool mg3_is_layer_preserving(const helm_op *op);           // the hierarchy in use is the layer-preserving one
+int mg3_retreat(helm_op *op, int batch);                   // rebuild as the standard cycle for the rest of this frequency
 
 // ---- launchers implemented in assemble.hip ----------------------------------------------------
 int helm_launch_assemble(helm_op *op, double freq_re, double freq_im, double tau, double ky, double cPML);

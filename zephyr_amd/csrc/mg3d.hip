@@ -825,7 +825,7 @@ int mg3_setup(helm_op *op, int batch) {
         const int interior = std::min(op->nz, std::min(op->ny, op->nx)) - 2 * op->nPML;
         while (ncoarsen > 0 && (interior >> ncoarsen) < 3) --ncoarsen;
         ncoarsen = envi("HELM_MG3_KEEP_LEVELS", ncoarsen);
-        if (envi("HELM_MG3_KEEP", 1) && ncoarsen > 0 && op->a_cpml > 0 && omega > 0) {
+        if (envi("HELM_MG3_KEEP", 1) && !op->mg3_no_keep && ncoarsen > 0 && op->a_cpml > 0 && omega > 0) {
             const double betak = envd("HELM_MG3_BETA", 0.1);
             double inv_tau_k = omega * betak / 2.0;
             if (std::isfinite(op->a_tau) && op->a_tau != 0.0) inv_tau_k += 1.0 / op->a_tau;
@@ -891,6 +891,14 @@ int mg3_setup(helm_op *op, int batch) {
     hipFree(A); hipFree(W);
     if (rc) return fail(rc, "3-D multigrid: coarsest inverse failed");
     return HELM_OK;
+}
+
+bool mg3_is_layer_preserving(const helm_op *op) { return op->mg3 && op->mg3->keep; }
+
+int mg3_retreat(helm_op *op, int batch) {
+    op->mg3_no_keep = true;
+    mg3_destroy(op);
+    return mg3_setup(op, batch);
 }
 
 // out[b] = M^-1 in[b]
