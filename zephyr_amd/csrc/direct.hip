@@ -303,6 +303,7 @@ struct GemmRows {
     int fwd3 = 0;         // forward-gather mode (k_zgemm2<.., 2, ..>): Bx = right-hand sides, Cix = front-vector arena, Cox = where y_S goes
     int zr0 = 0, zr1 = 0, zc0 = 0, zc1 = 0;   // rows [zr0, zr1) and columns [zc0, zc1) of C are taken as zero on input (beta masked): blocked Gauss-Jordan
     int sk0 = 0, sk1 = 0;                     // the diagonal block [sk0, sk1)^2 of C is neither read nor written (the next pivot block, owned by k_gj_pivot)
+    int dense = 0;                            // only the masks above are in use: launch the plain (un-indexed) kernel
 };
 #define GB_K 8
 #define GB_KIDX 512       // largest K with indexed B rows
@@ -1266,6 +1267,9 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
     // forward-gather launches are HBM-bound and every row-tile repeats the three-source gather of the B rows: one row-tile per front
     // wherever the front has at most 64 rows, whatever the padding costs in flops
     if (rows && rows->fwd3 && M <= 64 && !latency_mode) vsel = 0;
+    // rank-32 updates of one large matrix (blocked Gauss-Jordan of the 3-D plane inverses): HBM-bound, the 64 x 32 tile is the fastest
+    // (3713^2 x 32: 87 us against 93 for 64 x 64, tools/zgemm_tiles.py)
+    if (rows && rows->dense && K <= 32 && !latency_mode && batch == 1) vsel = 3;
     if (g_gemm_tile >= 0) { vsel = g_gemm_tile & 7; latency_mode = false; }
     for (int b0 = 0; b0 < batch; b0 += 65535) {
         const int nb = std::min(65535, batch - b0);
@@ -1290,7 +1294,7 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
                 tl_ev0 = tl_ev1 = nullptr;
             }
         } arm(op, ext, 8.0 * M * (double)Nn * K * nb);
-#define ZG_ARGS st, (rows ? (rows->fwd3 ? 2 : 1) : 0), nb, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R
+#define ZG_ARGS st, (rows && !rows->dense ? (rows->fwd3 ? 2 : 1) : 0), nb, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R
 #define ZG_VEC(TM_, RN_) do { switch (gv) { \
             case 0: launch_vec<TM_, RN_>(ZG_ARGS); break; \
             case 6: launch_vec2<TM_, RN_, (RN_ == 1 ? 32 : (RN_ == 2 ? 16 : 8)), 1, 1>(ZG_ARGS); break; \
@@ -1380,7 +1384,7 @@ void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cp
                 hipEventRecord(op->ev_la[1], sp);
                 if (k0 > 0) {                                              // update of step k-1, beside the pivot kernel
                     const int kp = k0 - PNB;
-                    GemmRows R; R.zr0 = kp; R.zr1 = k0; R.zc0 = kp; R.zc1 = k0; R.sk0 = k0; R.sk1 = k0 + nb;
+                    GemmRows R; R.dense = 1; R.zr0 = kp; R.zr1 = k0; R.zc0 = kp; R.zc1 = k0; R.sk0 = k0; R.sk1 = k0 + nb;
                     gemm(op, n, n, PNB, cmake(-1, 0), Wc, PNB, ws, Wr, n, ws, cmake(1, 0), M, ld, stride, batch, &R);
                 }
                 hipStreamWaitEvent(st, op->ev_la[1], 0);
@@ -1390,7 +1394,7 @@ void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cp
                     hipStreamWaitEvent(sp, op->ev_la[0], 0);
                 }
                 else {
-                    GemmRows R; R.zr0 = k0; R.zr1 = k0 + nb; R.zc0 = k0; R.zc1 = k0 + nb;
+                    GemmRows R; R.dense = 1; R.zr0 = k0; R.zr1 = k0 + nb; R.zc0 = k0; R.zc1 = k0 + nb;
                     gemm(op, n, n, nb, cmake(-1, 0), Wc, PNB, ws, Wr, n, ws, cmake(1, 0), M, ld, stride, batch, &R);
                 }
             }
@@ -1402,7 +1406,7 @@ void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cp
                 const int nbt = std::min(65535, batch - b0);
                 hipLaunchKernelGGL(k_gj_panel, dim3((n + 63) / 64, nbt), dim3(256), 0, st, M + b0 * stride, ld, stride, n, k0, nb, Wc + b0 * ws, Wr + b0 * ws, ws);
             }
-            GemmRows R; R.zr0 = k0; R.zr1 = k0 + nb; R.zc0 = k0; R.zc1 = k0 + nb;
+            GemmRows R; R.dense = 1; R.zr0 = k0; R.zr1 = k0 + nb; R.zc0 = k0; R.zc1 = k0 + nb;
             gemm(op, n, n, nb, cmake(-1, 0), Wc, PNB, ws, Wr, n, ws, cmake(1, 0), M, ld, stride, batch, &R);
         }
         return;
