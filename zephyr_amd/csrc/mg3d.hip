@@ -183,15 +183,18 @@ struct RTab { int f; double wl, wc, wr; };          // coarse node -> fine nodes
 
 struct Bt3 {                        // direct solver of the coarsest level
     int axis = 0, np = 0, na = 0, nb = 0, m = 0, mpad = 0, ksplit = 1, kc = 0, batch = 0, nparts = 1;
+    int mid = 0;                    // twisted elimination: planes 0 .. mid-1 from the left, np-1 .. mid+1 from the right, plane mid last
     bool own = true;                // k_bt_apply (memory-bound product) instead of the generic batched GEMM
     int device = 0; size_t tbytes = 0;   // Tinv comes from the size-keyed buffer pool (the next frequency takes it over without a hipMalloc)
     long long ss = 0, sa = 0, sb = 0, N = 0;      // node strides of the sweep axis / the two in-plane axes
     cplx *Tinv = nullptr;           // np x (mpad x m): inverse of the transposed Schur complement of plane k (rows >= m are zero)
     float2 *Tinv32 = nullptr;       // single-precision copy, np x (m x ld32), used INSTEAD of Tinv (f32 = true: Tinv is then not kept)
     bool f32 = false; int ld32 = 0; size_t tbytes32 = 0;
-    cplx *Y = nullptr;              // batch x mpad: packed right-hand side of one plane (columns >= m stay zero)
-    cplx *Z = nullptr;              // np x batch x m: forward-substituted planes, then the solution
-    cplx *parts = nullptr;          // ksplit x batch x m: partial products of the split-K GEMM
+    cplx *Y[2] = {nullptr, nullptr};      // per chain: batch x mpad, packed right-hand side of one plane (columns >= m stay zero)
+    cplx *Z = nullptr;                    // np x batch x m: forward-substituted planes, then the solution
+    cplx *parts[2] = {nullptr, nullptr};  // per chain: ksplit x batch x m partial products of the split-K product
+    helm_op *aux = nullptr;         // carries the stream (and the look-ahead stream) of the right-hand chain
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
 };
 
 struct Mg3Keep {
@@ -322,9 +325,11 @@ __device__ __forceinline__ int bt_slot(int axis, int os, int da, int db) {
 
 struct BtGeom { int axis, np, na, nb, m; long long ss, sa, sb, N; };
 
-// T_k = S_k^T with S_k = A_kk - A_{k,k-1} S_{k-1}^{-1} A_{k-1,k}; TinvPrev = T_{k-1}^{-1} (element [b][a] = S_{k-1}^{-1}[a][b]).
-// One thread per entry, i (the row of S) fastest: coalesced writes of T[j][i] and reads of TinvPrev[b][a ~ i].
-__global__ __launch_bounds__(256) void k_bt_schur_t(const cplx *__restrict__ planes, BtGeom g, int k, const cplx *__restrict__ TinvPrev, cplx *__restrict__ T) {
+// T_k = S_k^T with S_k = A_kk - sum over the eliminated neighbour planes k + d (d = -1 and / or +1) of A_{k,k+d} S_{k+d}^{-1} A_{k+d,k};
+// Tm / Tp = T_{k-1}^{-1} / T_{k+1}^{-1} or null (element [b][a] of T^{-1} is S^{-1}[a][b]).
+// One thread per entry, i (the row of S) fastest: coalesced writes of T[j][i] and reads of T^{-1}[b][a ~ i].
+__global__ __launch_bounds__(256) void k_bt_schur_t(const cplx *__restrict__ planes, BtGeom g, int k, const cplx *__restrict__ Tm, const cplx *__restrict__ Tp,
+                                                    cplx *__restrict__ T) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (long long)g.m * g.m) return;
     const int i = (int)(e % g.m), j = (int)(e / g.m);
@@ -332,20 +337,23 @@ __global__ __launch_bounds__(256) void k_bt_schur_t(const cplx *__restrict__ pla
     const long long node_i = (long long)k * g.ss + ia * g.sa + ib * g.sb;
     cplx v = cmake(0.0, 0.0);
     if (abs(ja - ia) <= 1 && abs(jb - ib) <= 1) v = planes[(long long)bt_slot(g.axis, 0, ja - ia, jb - ib) * g.N + node_i];
-    if (k > 0) {
-        // the nine entries of row i of A_{k,k-1} and of column j of A_{k-1,k}
+    for (int side = 0; side < 2; ++side) {
+        const cplx *Tn = side ? Tp : Tm;
+        if (!Tn) continue;
+        const int d = side ? 1 : -1;
+        // the nine entries of row i of A_{k,k+d} and of column j of A_{k+d,k}
         for (int d2 = 0; d2 < 9; ++d2) {
             const int ba = ja - (d2 / 3 - 1), bb = jb - (d2 % 3 - 1);
             if (ba < 0 || ba >= g.na || bb < 0 || bb >= g.nb) continue;
-            const long long node_b = (long long)(k - 1) * g.ss + ba * g.sa + bb * g.sb;
-            const cplx ap = planes[(long long)bt_slot(g.axis, 1, d2 / 3 - 1, d2 % 3 - 1) * g.N + node_b];
+            const long long node_b = (long long)(k + d) * g.ss + ba * g.sa + bb * g.sb;
+            const cplx ap = planes[(long long)bt_slot(g.axis, -d, d2 / 3 - 1, d2 % 3 - 1) * g.N + node_b];
             if (ap.x == 0.0 && ap.y == 0.0) continue;
-            const cplx *trow = TinvPrev + (long long)(ba * g.nb + bb) * g.m;
+            const cplx *trow = Tn + (long long)(ba * g.nb + bb) * g.m;
             cplx acc = cmake(0.0, 0.0);
             for (int d1 = 0; d1 < 9; ++d1) {
                 const int aa = ia + (d1 / 3 - 1), ab = ib + (d1 % 3 - 1);
                 if (aa < 0 || aa >= g.na || ab < 0 || ab >= g.nb) continue;
-                const cplx am = planes[(long long)bt_slot(g.axis, -1, d1 / 3 - 1, d1 % 3 - 1) * g.N + node_i];
+                const cplx am = planes[(long long)bt_slot(g.axis, d, d1 / 3 - 1, d1 % 3 - 1) * g.N + node_i];
                 cfma(acc, am, trow[aa * g.nb + ab]);
             }
             v = csub(v, cmul(acc, ap));
@@ -354,20 +362,23 @@ __global__ __launch_bounds__(256) void k_bt_schur_t(const cplx *__restrict__ pla
     T[(long long)j * g.m + i] = v;
 }
 
-// packed right-hand side of plane k.  os = -1 (forward): Y = f_k - A_{k,k-1} z_{k-1};  os = +1 (backward): Y = A_{k,k+1} x_{k+1}
-__global__ __launch_bounds__(256) void k_bt_rhs(const cplx *__restrict__ planes, BtGeom g, int k, int os, const cplx *__restrict__ f, const cplx *__restrict__ Zn,
-                                                cplx *__restrict__ Y, int mpad) {
+// packed right-hand side of plane k:  Y = [f_k] - A_{k,k-1} Zm - A_{k,k+1} Zp  (each neighbour optional; without f the sign is +:
+// Y = A_{k,k-1} Zm + A_{k,k+1} Zp, the back-substitution term)
+__global__ __launch_bounds__(256) void k_bt_rhs(const cplx *__restrict__ planes, BtGeom g, int k, const cplx *__restrict__ f, const cplx *__restrict__ Zm,
+                                                const cplx *__restrict__ Zp, cplx *__restrict__ Y, int mpad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
     if (i >= g.m) return;
     const int ia = i / g.nb, ib = i % g.nb;
     const long long node = (long long)k * g.ss + ia * g.sa + ib * g.sb;
     cplx v = cmake(0.0, 0.0);
-    if (Zn) {
+    for (int side = 0; side < 2; ++side) {
+        const cplx *Zn = side ? Zp : Zm;
+        if (!Zn) continue;
         const cplx *zr = Zn + (long long)r * g.m;
         for (int d = 0; d < 9; ++d) {
             const int aa = ia + (d / 3 - 1), ab = ib + (d % 3 - 1);
             if (aa < 0 || aa >= g.na || ab < 0 || ab >= g.nb) continue;
-            cfma(v, planes[(long long)bt_slot(g.axis, os, d / 3 - 1, d % 3 - 1) * g.N + node], zr[aa * g.nb + ab]);
+            cfma(v, planes[(long long)bt_slot(g.axis, side ? 1 : -1, d / 3 - 1, d % 3 - 1) * g.N + node], zr[aa * g.nb + ab]);
         }
     }
     if (f) v = csub(f[(long long)r * g.N + node], v);
@@ -555,10 +566,16 @@ BtGeom bt_geom(const Bt3 &B) { BtGeom g; g.axis = B.axis; g.np = B.np; g.na = B.
 void bt_free(Bt3 &B) {
     if (B.Tinv) helm_pool_free(B.device, B.Tinv, B.tbytes);
     if (B.Tinv32) helm_pool_free(B.device, B.Tinv32, B.tbytes32);
-    hipFree(B.Y); hipFree(B.Z); hipFree(B.parts);
+    for (int c = 0; c < 2; ++c) { hipFree(B.Y[c]); hipFree(B.parts[c]); }
+    hipFree(B.Z);
+    for (int e = 0; e < 3; ++e) if (B.ev[e]) hipEventDestroy(B.ev[e]);
+    if (B.aux) helm_destroy(B.aux);
     B = Bt3();
 }
 
+// Twisted block elimination: the planes left of `mid` are eliminated left to right, those right of it right to left, plane mid last.
+// The two chains are independent, so they run on two streams (set-up: two dense inversions in flight, whose latency-bound pivot and
+// panel steps fill each other's gaps; solve: two half-length chains of small launches).
 int bt_setup(helm_op *op, Bt3 &B, const Mg3Level &L, int batch) {
     const int dims[3] = {L.nz, L.ny, L.nx};
     const long long strides[3] = {(long long)L.ny * L.nx, L.nx, 1};
@@ -568,6 +585,7 @@ int bt_setup(helm_op *op, Bt3 &B, const Mg3Level &L, int batch) {
     const int ia = axis == 0 ? 1 : 0, ib = axis == 2 ? 1 : 2;
     B.axis = axis; B.np = dims[axis]; B.na = dims[ia]; B.nb = dims[ib]; B.m = B.na * B.nb;
     B.ss = strides[axis]; B.sa = strides[ia]; B.sb = strides[ib]; B.N = L.N; B.batch = batch;
+    B.mid = envi("HELM_MG3_BT_TWIST", 1) ? B.np / 2 : B.np - 1;
     // split-K: ~512 workgroups of 128 columns each (k_bt_apply); HELM_MG3_BT_GEMM=1 goes through the generic batched GEMM instead
     B.own = envi("HELM_MG3_BT_GEMM", 0) == 0 && batch <= 16;
     B.ksplit = B.own ? std::max(1, std::min(16, 512 / ((B.m + 127) / 128))) : std::max(1, std::min(16, 255 / ((B.m + 63) / 64)));
@@ -576,11 +594,12 @@ int bt_setup(helm_op *op, Bt3 &B, const Mg3Level &L, int batch) {
     B.mpad = B.own ? B.m : B.kc * B.ksplit;          // (the generic GEMM wants equal K chunks: zero rows / columns up to mpad)
     B.nparts = B.ksplit;
     B.device = op->device;
-    // single-precision plane inverses (default): only two double-precision planes exist at a time during the set-up
+    // single-precision plane inverses (default): only two double-precision planes per chain exist at a time during the set-up
     B.f32 = B.own && envi("HELM_MG3_BT_F32", 1) != 0;
     B.ld32 = (B.m + 1) & ~1;
-    const size_t wbytes = (size_t)B.m * B.m * sizeof(cplx);
-    const size_t tb = B.f32 ? 2 * wbytes : (size_t)B.np * B.mpad * B.m * sizeof(cplx);
+    const long long mm = (long long)B.m * B.m;
+    const size_t wbytes = (size_t)mm * sizeof(cplx);
+    const size_t tb = B.f32 ? 4 * wbytes : (size_t)B.np * B.mpad * B.m * sizeof(cplx);
     B.tbytes = tb;
     B.tbytes32 = B.f32 ? (size_t)B.np * B.m * B.ld32 * sizeof(float2) : 0;
     {   // leave room for the Krylov workspace: the plane inverses may take a third of the device memory (HELM_MG3_BT_MAXGB overrides)
@@ -590,32 +609,69 @@ int bt_setup(helm_op *op, Bt3 &B, const Mg3Level &L, int batch) {
         if ((double)(tb + B.tbytes32) > cap)
             HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "3-D multigrid: the plane inverses of the directly solved level (%.1f GB) exceed the budget of %.1f GB", (tb + B.tbytes32) / 1e9, cap / 1e9);
     }
-    hipStream_t st = op->stream;
-    hipStreamSynchronize(st);          // (buffers of the previous frequency go back to the pool only when their work is done)
+    hipStreamSynchronize(op->stream);          // (buffers of the previous frequency go back to the pool only when their work is done)
+    B.aux = helm_create3d(op->device, 3, 3, 3, 1.0, 1.0, 1.0, 2);
+    if (!B.aux) HELM_FAIL(op, HELM_ERR_DEVICE, "%s", helm_last_error(nullptr));
+    // set-up: two inversions in flight pay while they are latency-bound (m = 1617 at 2 Hz: 0.37 -> 0.30 s); two saturating ones only get in each
+    // other's way (m = 3713: 1.49 -> 1.93 s), so from the size at which the look-ahead Gauss-Jordan takes over both chains share one stream
+    const bool conc = B.m < envi("HELM_MG3_BT_CONC_N", 2048);
+    hipStream_t sts[2] = {op->stream, conc ? B.aux->stream : op->stream};
+    helm_op *ctx[2] = {op, conc ? B.aux : op};
     B.Tinv = (cplx *)helm_pool_alloc(op->device, tb);
     if (B.f32) B.Tinv32 = (float2 *)helm_pool_alloc(op->device, B.tbytes32);
-    cplx *W = (cplx *)helm_pool_alloc(op->device, wbytes);
-    if (!B.Tinv || !W || (B.f32 && !B.Tinv32) || hipMalloc((void **)&B.Y, (size_t)batch * B.mpad * sizeof(cplx)) != hipSuccess ||
-        hipMalloc((void **)&B.Z, (size_t)B.np * batch * B.m * sizeof(cplx)) != hipSuccess ||
-        hipMalloc((void **)&B.parts, (size_t)B.nparts * batch * B.m * sizeof(cplx)) != hipSuccess) {
-        if (W) helm_pool_free(op->device, W, wbytes);
+    cplx *W[2] = {(cplx *)helm_pool_alloc(op->device, wbytes), (cplx *)helm_pool_alloc(op->device, wbytes)};
+    bool ok = B.Tinv && W[0] && W[1] && (!B.f32 || B.Tinv32) && hipMalloc((void **)&B.Z, (size_t)B.np * batch * B.m * sizeof(cplx)) == hipSuccess;
+    for (int c = 0; c < 2 && ok; ++c)
+        ok = hipMalloc((void **)&B.Y[c], (size_t)batch * B.mpad * sizeof(cplx)) == hipSuccess &&
+             hipMalloc((void **)&B.parts[c], (size_t)B.nparts * batch * B.m * sizeof(cplx)) == hipSuccess;
+    for (int e = 0; e < 3 && ok; ++e) ok = hipEventCreateWithFlags(&B.ev[e], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        for (int c = 0; c < 2; ++c) if (W[c]) helm_pool_free(op->device, W[c], wbytes);
         bt_free(B);
         HELM_FAIL(op, HELM_ERR_DEVICE, "3-D multigrid: the plane inverses of the coarsest level (%.1f GB) do not fit", (tb + B.tbytes32) / 1e9);
     }
-    if (!B.f32 && B.mpad != B.m) hipMemsetAsync(B.Tinv, 0, tb, st);
-    hipMemsetAsync(B.Y, 0, (size_t)batch * B.mpad * sizeof(cplx), st);
+    if (!B.f32 && B.mpad != B.m) hipMemsetAsync(B.Tinv, 0, tb, op->stream);
+    for (int c = 0; c < 2; ++c) hipMemsetAsync(B.Y[c], 0, (size_t)batch * B.mpad * sizeof(cplx), op->stream);
+    hipEventRecord(B.ev[0], op->stream);
+    hipStreamWaitEvent(sts[1], B.ev[0], 0);
     const BtGeom g = bt_geom(B);
-    const long long mm = (long long)B.m * B.m;
+    const cplx *planes = L.op->d_C;
+    const unsigned sg = (unsigned)((mm + 255) / 256);
+    // where the (transposed, double-precision) Schur complement of plane k lives: its own slot, or a ping-pong pair per chain (f32)
+    auto slot = [&](int chain, int step, int k) { return B.f32 ? B.Tinv + ((long long)chain * 2 + (step & 1)) * mm : B.Tinv + (long long)k * B.mpad * B.m; };
+    auto finish = [&](int chain, cplx *Tk, int k) -> int {
+        const int rc = nd_dense_inverse(ctx[chain], Tk, B.m, W[chain]);
+        if (rc) { helm_set_error(op, helm_last_error(ctx[chain])); return rc; }
+        if (B.f32) hipLaunchKernelGGL(k_bt_to_f32, dim3(4096), dim3(256), 0, sts[chain], (const cplx *)Tk, B.Tinv32 + (long long)k * B.m * B.ld32, B.m, B.ld32);
+        return HELM_OK;
+    };
     int rc = HELM_OK;
-    for (int k = 0; k < B.np && !rc; ++k) {
-        cplx *Tk = B.f32 ? B.Tinv + (long long)(k & 1) * mm : B.Tinv + (long long)k * B.mpad * B.m;
-        const cplx *Tprev = !k ? nullptr : (B.f32 ? B.Tinv + (long long)((k - 1) & 1) * mm : Tk - (long long)B.mpad * B.m);
-        hipLaunchKernelGGL(k_bt_schur_t, dim3((unsigned)((mm + 255) / 256)), dim3(256), 0, st, (const cplx *)L.op->d_C, g, k, Tprev, Tk);
-        rc = nd_dense_inverse(op, Tk, B.m, W);
-        if (B.f32 && !rc) hipLaunchKernelGGL(k_bt_to_f32, dim3(4096), dim3(256), 0, st, (const cplx *)Tk, B.Tinv32 + (long long)k * B.m * B.ld32, B.m, B.ld32);
+    const int nl = B.mid, nr = B.np - 1 - B.mid;
+    const cplx *lastL = nullptr, *lastR = nullptr;
+    for (int step = 0; step < std::max(nl, nr) && !rc; ++step) {        // launches of the two chains interleaved
+        if (step < nl) {
+            const int k = step;
+            cplx *Tk = slot(0, step, k);
+            hipLaunchKernelGGL(k_bt_schur_t, dim3(sg), dim3(256), 0, sts[0], planes, g, k, lastL, (const cplx *)nullptr, Tk);
+            rc = finish(0, Tk, k); lastL = Tk;
+        }
+        if (step < nr && !rc) {
+            const int k = B.np - 1 - step;
+            cplx *Tk = slot(1, step, k);
+            hipLaunchKernelGGL(k_bt_schur_t, dim3(sg), dim3(256), 0, sts[1], planes, g, k, (const cplx *)nullptr, lastR, Tk);
+            rc = finish(1, Tk, k); lastR = Tk;
+        }
     }
-    hipStreamSynchronize(st);
-    helm_pool_free(op->device, W, wbytes);
+    if (!rc) {                                                           // the plane where the chains meet
+        hipEventRecord(B.ev[1], sts[1]);
+        hipStreamWaitEvent(sts[0], B.ev[1], 0);
+        cplx *Tk = slot(0, nl, B.mid);
+        hipLaunchKernelGGL(k_bt_schur_t, dim3(sg), dim3(256), 0, sts[0], planes, g, B.mid, lastL, lastR, Tk);
+        rc = finish(0, Tk, B.mid);
+    }
+    hipStreamSynchronize(sts[1]);
+    hipStreamSynchronize(sts[0]);
+    for (int c = 0; c < 2; ++c) helm_pool_free(op->device, W[c], wbytes);
     if (B.f32 && B.Tinv) { helm_pool_free(op->device, B.Tinv, B.tbytes); B.Tinv = nullptr; }
     if (rc) { bt_free(B); return rc; }
     return HELM_OK;
@@ -623,40 +679,59 @@ int bt_setup(helm_op *op, Bt3 &B, const Mg3Level &L, int batch) {
 
 // u = A^-1 f on the coarsest level (f, u: [nrhs][N])
 int bt_solve(helm_op *op, Bt3 &B, const Mg3Level &L, const cplx *f, cplx *u, int nrhs) {
-    hipStream_t st = op->stream;
+    hipStream_t sts[2] = {op->stream, B.aux->stream};
     const BtGeom g = bt_geom(B);
     const cplx *planes = L.op->d_C;
     const dim3 rg((B.m + 255) / 256, nrhs);
     const long long pz = (long long)nrhs * B.m;              // one packed plane of Z
     const unsigned redg = (unsigned)std::min<long long>((pz + 255) / 256, 4096);
-    auto apply_inverse = [&](int k, cplx *Zk, int sub) -> int {
+    // Z_k (-)= Y S_k^-T on the stream of `chain`
+    auto apply_inverse = [&](int chain, int k, int sub) -> int {
+        hipStream_t st = sts[chain];
+        cplx *Zk = B.Z + k * pz;
         if (B.f32) {
-            hipLaunchKernelGGL(k_bt_apply32<16>, dim3((B.m + 127) / 128, B.ksplit), dim3(256), 0, st, (const cplx *)B.Y, B.mpad,
-                               (const float2 *)(B.Tinv32 + (long long)k * B.m * B.ld32), B.m, B.ld32, B.kc, nrhs, B.parts);
-            hipLaunchKernelGGL(k_bt_reduce, dim3(redg), dim3(256), 0, st, (const cplx *)B.parts, B.nparts, pz, Zk, sub);
+            hipLaunchKernelGGL(k_bt_apply32<16>, dim3((B.m + 127) / 128, B.ksplit), dim3(256), 0, st, (const cplx *)B.Y[chain], B.mpad,
+                               (const float2 *)(B.Tinv32 + (long long)k * B.m * B.ld32), B.m, B.ld32, B.kc, nrhs, B.parts[chain]);
+            hipLaunchKernelGGL(k_bt_reduce, dim3(redg), dim3(256), 0, st, (const cplx *)B.parts[chain], B.nparts, pz, Zk, sub);
             return HELM_OK;
         }
         const cplx *Tk = B.Tinv + (long long)k * B.mpad * B.m;
         if (B.own) {
-            hipLaunchKernelGGL(k_bt_apply<16>, dim3((B.m + 127) / 128, B.ksplit), dim3(256), 0, st, (const cplx *)B.Y, B.mpad, Tk, B.m, B.kc, nrhs, B.parts);
-            hipLaunchKernelGGL(k_bt_reduce, dim3(redg), dim3(256), 0, st, (const cplx *)B.parts, B.nparts, pz, Zk, sub);
+            hipLaunchKernelGGL(k_bt_apply<16>, dim3((B.m + 127) / 128, B.ksplit), dim3(256), 0, st, (const cplx *)B.Y[chain], B.mpad, Tk, B.m, B.kc, nrhs, B.parts[chain]);
+            hipLaunchKernelGGL(k_bt_reduce, dim3(redg), dim3(256), 0, st, (const cplx *)B.parts[chain], B.nparts, pz, Zk, sub);
             return HELM_OK;
         }
-        const int rc = nd_dense_gemm_batched(op, nrhs, B.m, B.kc, cmake(1, 0), B.Y, B.mpad, B.kc, Tk, B.m, (long long)B.kc * B.m, cmake(0, 0),
-                                             B.parts, B.m, pz, B.ksplit);
+        // generic batched GEMM (more than 16 right-hand sides): it launches on the handle's own stream, so this path keeps to one chain order
+        const int rc = nd_dense_gemm_batched(chain ? B.aux : op, nrhs, B.m, B.kc, cmake(1, 0), B.Y[chain], B.mpad, B.kc, Tk, B.m, (long long)B.kc * B.m, cmake(0, 0),
+                                             B.parts[chain], B.m, pz, B.ksplit);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_bt_reduce, dim3(redg), dim3(256), 0, st, (const cplx *)B.parts, B.ksplit, pz, Zk, sub);
+        hipLaunchKernelGGL(k_bt_reduce, dim3(redg), dim3(256), 0, st, (const cplx *)B.parts[chain], B.ksplit, pz, Zk, sub);
         return HELM_OK;
     };
-    for (int k = 0; k < B.np; ++k) {                       // z_k = S_k^-1 (f_k - A_{k,k-1} z_{k-1})
-        hipLaunchKernelGGL(k_bt_rhs, rg, dim3(256), 0, st, planes, g, k, -1, f, (const cplx *)(k ? B.Z + (k - 1) * pz : nullptr), B.Y, B.mpad);
-        const int rc = apply_inverse(k, B.Z + k * pz, 0); if (rc) return rc;
+    auto rhs = [&](int chain, int k, const cplx *fk, const cplx *Zm, const cplx *Zp) {
+        hipLaunchKernelGGL(k_bt_rhs, rg, dim3(256), 0, sts[chain], planes, g, k, fk, Zm, Zp, B.Y[chain], B.mpad);
+    };
+    const int nl = B.mid, nr = B.np - 1 - B.mid;
+    int rc = HELM_OK;
+    hipEventRecord(B.ev[0], sts[0]);                       // f is ready
+    hipStreamWaitEvent(sts[1], B.ev[0], 0);
+    for (int step = 0; step < std::max(nl, nr); ++step) {  // forward: z_k = S_k^-1 (f_k - A_{k,k-+1} z_{k-+1}), both chains
+        if (step < nl) { const int k = step; rhs(0, k, f, k ? B.Z + (k - 1) * pz : nullptr, nullptr); rc = apply_inverse(0, k, 0); if (rc) return rc; }
+        if (step < nr) { const int k = B.np - 1 - step; rhs(1, k, f, nullptr, step ? B.Z + (k + 1) * pz : nullptr); rc = apply_inverse(1, k, 0); if (rc) return rc; }
     }
-    for (int k = B.np - 2; k >= 0; --k) {                  // x_k = z_k - S_k^-1 A_{k,k+1} x_{k+1}
-        hipLaunchKernelGGL(k_bt_rhs, rg, dim3(256), 0, st, planes, g, k, 1, (const cplx *)nullptr, (const cplx *)(B.Z + (k + 1) * pz), B.Y, B.mpad);
-        const int rc = apply_inverse(k, B.Z + k * pz, 1); if (rc) return rc;
+    hipEventRecord(B.ev[1], sts[1]);
+    hipStreamWaitEvent(sts[0], B.ev[1], 0);
+    rhs(0, B.mid, f, nl ? B.Z + (B.mid - 1) * pz : nullptr, nr ? B.Z + (B.mid + 1) * pz : nullptr);     // the plane where the chains meet: x_mid
+    rc = apply_inverse(0, B.mid, 0); if (rc) return rc;
+    hipEventRecord(B.ev[2], sts[0]);
+    hipStreamWaitEvent(sts[1], B.ev[2], 0);
+    for (int step = 0; step < std::max(nl, nr); ++step) {  // back substitution outwards: x_k = z_k - S_k^-1 A_{k,k+-1} x_{k+-1}
+        if (step < nl) { const int k = B.mid - 1 - step; rhs(0, k, nullptr, nullptr, B.Z + (k + 1) * pz); rc = apply_inverse(0, k, 1); if (rc) return rc; }
+        if (step < nr) { const int k = B.mid + 1 + step; rhs(1, k, nullptr, B.Z + (k - 1) * pz, nullptr); rc = apply_inverse(1, k, 1); if (rc) return rc; }
     }
-    hipLaunchKernelGGL(k_bt_scatter, dim3((unsigned)std::min<long long>(((long long)B.np * B.m + 255) / 256, 4096), nrhs), dim3(256), 0, st,
+    hipEventRecord(B.ev[1], sts[1]);
+    hipStreamWaitEvent(sts[0], B.ev[1], 0);
+    hipLaunchKernelGGL(k_bt_scatter, dim3((unsigned)std::min<long long>(((long long)B.np * B.m + 255) / 256, 4096), nrhs), dim3(256), 0, sts[0],
                        (const cplx *)B.Z, g, nrhs, u);
     return HELM_OK;
 }
