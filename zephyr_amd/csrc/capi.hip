@@ -159,8 +159,6 @@ extern "C" void helm_destroy(helm_op *op) {
         for (hipEvent_t e : op->ev_pool) { if (idle.size() < 65536) idle.push_back(e); else hipEventDestroy(e); }
     }
     if (op->side_stream) hipStreamDestroy(op->side_stream);
-    if (op->pivot_stream) hipStreamDestroy(op->pivot_stream);
-    for (int i = 0; i < 2; ++i) if (op->ev_la[i]) hipEventDestroy(op->ev_la[i]);
     if (op->own_stream && op->stream) hipStreamDestroy(op->stream);
     delete op;
     std::lock_guard<std::mutex> lk(g_shared_ws.mu);

@@ -294,6 +294,8 @@ __global__ __launch_bounds__(256) void k_nd_build_front(const NdDev *nodes, int 
 // through the plan's row table instead of a dense front buffer, i.e. straight from / to the node-major right-hand sides
 // Xt[cell][rhs]:   row r of batch item z  ->  X + tab[z * tab_stride + off + r].x * ldx   (negative: a zero row / not stored).
 // This removes the gather / scatter passes (and their HBM round trips) from the lower tree levels.
+// arguments of the Gauss-Jordan sweep that rides along with a blocked-inversion update (k_zgemm2_la)
+struct GjPivotArgs { const cplx *T0; int ld; long long stride; int n, k0, nb; const cplx *Wc0, *Wr0; long long wstride; cplx *Pb0; long long pstride; int batch; };
 struct GemmRows {
     const int4 *tabB = nullptr, *tabCi = nullptr, *tabCo = nullptr;
     int offB = 0, offCi = 0, offCo = 0, tab_stride = 0;
@@ -304,6 +306,7 @@ struct GemmRows {
     int zr0 = 0, zr1 = 0, zc0 = 0, zc1 = 0;   // rows [zr0, zr1) and columns [zc0, zc1) of C are taken as zero on input (beta masked): blocked Gauss-Jordan
     int sk0 = 0, sk1 = 0;                     // the diagonal block [sk0, sk1)^2 of C is neither read nor written (the next pivot block, owned by k_gj_pivot)
     int dense = 0;                            // only the masks above are in use: launch the plain (un-indexed) kernel
+    const GjPivotArgs *la = nullptr;          // (host pointer) fuse this pivot sweep into the launch: 64 x 32 tiles, one extra z-slice
 };
 #define GB_K 8
 #define GB_KIDX 512       // largest K with indexed B rows
@@ -430,13 +433,14 @@ void launch_vec(hipStream_t st, bool idx, int nb, int M, int Nn, int K, cplx alp
 // needs -- the right-hand side of a separator cell plus the children's outgoing rows that land on it (table entries x / y, z) -- and
 // the C that is read is the sum of the children's rows of a ring row; the first row-tile also stores the gathered separator rows
 // (y_S) where the back substitution expects them.  Same additions in the same order as k_nd_fwd_rows + the dense GEMM.
-template <int TM, int IDX, int RN, int KS, int UNR, int OCC>
-__global__ __launch_bounds__(256, OCC) void k_zgemm2(int M, int Nn, int K, cplx alpha, const cplx *A0, int lda, long long sa,
-                                                const cplx *B0, int ldb, long long sb, cplx beta, cplx *C0, int ldc, long long sc, GemmRows R) {
+template <int TM, int IDX, int RN, int KS, int UNR>
+__device__ __forceinline__ void zgemm2_body(int M, int Nn, int K, cplx alpha, const cplx *A0, int lda, long long sa,
+                                            const cplx *B0, int ldb, long long sb, cplx beta, cplx *C0, int ldc, long long sc, const GemmRows &R,
+                                            cplx *lds_a, cplx *lds_b) {
     constexpr int TXN = 1024 / TM, TN = TXN * RN;
     constexpr int NA = (TM * KS + 255) / 256, NB = (TN * KS + 255) / 256;
-    __shared__ cplx As[2][KS][TM + 1];
-    __shared__ cplx Bs[2][KS][TN];
+    cplx (&As)[2][KS][TM + 1] = *reinterpret_cast<cplx (*)[2][KS][TM + 1]>(lds_a);      // the two operand tiles live in the caller's LDS
+    cplx (&Bs)[2][KS][TN] = *reinterpret_cast<cplx (*)[2][KS][TN]>(lds_b);
     __shared__ int kidx[IDX == 1 ? GB_KIDX : 1];
     __shared__ int4 kidx4[IDX == 2 ? GB_KIDX : 1];
     const cplx *A = A0 + (long long)blockIdx.z * sa;
@@ -554,6 +558,14 @@ __global__ __launch_bounds__(256, OCC) void k_zgemm2(int M, int Nn, int K, cplx 
             dst[cc] = v;
         }
     }
+}
+
+template <int TM, int IDX, int RN, int KS, int UNR, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_zgemm2(int M, int Nn, int K, cplx alpha, const cplx *A0, int lda, long long sa,
+                                                const cplx *B0, int ldb, long long sb, cplx beta, cplx *C0, int ldc, long long sc, GemmRows R) {
+    __shared__ cplx As[2][KS][TM + 1];
+    __shared__ cplx Bs[2][KS][1024 / TM * RN];
+    zgemm2_body<TM, IDX, RN, KS, UNR>(M, Nn, K, alpha, A0, lda, sa, B0, ldb, sb, beta, C0, ldc, sc, R, &As[0][0][0], &Bs[0][0][0]);
 }
 
 // Per-launch timing without extra packets: when gemm() has armed a pair of events, the dispatch itself carries them
@@ -894,14 +906,19 @@ __global__ __launch_bounds__(256) void k_gj_panel(cplx *T0, int ld, long long st
 // it runs on a second stream beside the rank-32 update of the whole front: k_gj_pivot applies the pending update to its
 // block privately (the GEMM skips it, GemmRows::sk0/sk1), inverts it and leaves P in Pb; k_gj_slices then forms the
 // panels R_k = P T[k-rows, :], C_k = T[:, k-cols] from the updated front.
-__global__ __launch_bounds__(256) void k_gj_pivot(const cplx *T0, int ld, long long stride, int n, int k0, int nb, const cplx *Wc0, const cplx *Wr0, long long wstride,
-                                                  cplx *Pb0, long long pstride) {
-    __shared__ Gj32 S;
-    __shared__ cplx wc[PNB][PNB + 1], wr[PNB][PNB + 1];
-    __shared__ int cperm[PNB];
-    const cplx *T = T0 + (long long)blockIdx.x * stride;
-    const cplx *Wc = Wc0 + (long long)blockIdx.x * wstride, *Wr = Wr0 + (long long)blockIdx.x * wstride;
-    cplx *Pb = Pb0 + (long long)blockIdx.x * pstride;
+// LDS of the sweep: wc | wr (2 x 32 x 33 complex) while the pending update is applied to the block, then the Gj32 state in the same place
+constexpr int GJ_PIVOT_LDS = 2 * PNB * (PNB + 1) * (int)sizeof(cplx) + PNB * (int)sizeof(int);
+static_assert(sizeof(Gj32) <= 2 * PNB * (PNB + 1) * sizeof(cplx), "Gj32 must fit over the two panels");
+
+__device__ __forceinline__ void gj_pivot_body(const cplx *T0, int ld, long long stride, int n, int k0, int nb, const cplx *Wc0, const cplx *Wr0, long long wstride,
+                                              cplx *Pb0, long long pstride, int mat, char *lds) {
+    cplx (&wc)[PNB][PNB + 1] = *reinterpret_cast<cplx (*)[PNB][PNB + 1]>(lds);
+    cplx (&wr)[PNB][PNB + 1] = *reinterpret_cast<cplx (*)[PNB][PNB + 1]>(lds + PNB * (PNB + 1) * sizeof(cplx));
+    Gj32 &S = *reinterpret_cast<Gj32 *>(lds);
+    int *cperm = reinterpret_cast<int *>(lds + 2 * PNB * (PNB + 1) * sizeof(cplx));
+    const cplx *T = T0 + (long long)mat * stride;
+    const cplx *Wc = Wc0 + (long long)mat * wstride, *Wr = Wr0 + (long long)mat * wstride;
+    cplx *Pb = Pb0 + (long long)mat * pstride;
     const int tid = threadIdx.x;
     const int i = tid >> 3, j0 = (tid & 7) * 4;
     const bool pending = k0 > 0;                          // the update of step k-1 (full width PNB) has not touched this block
@@ -932,6 +949,7 @@ __global__ __launch_bounds__(256) void k_gj_pivot(const cplx *T0, int ld, long l
             }
             #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = csub(v[q], acc[q]);
+            __syncthreads();                              // the panels are read: S may take their place
         }
         #pragma unroll
         for (int q = 0; q < 4; ++q) S.a[i][j0 + q] = v[q];
@@ -945,6 +963,31 @@ __global__ __launch_bounds__(256) void k_gj_pivot(const cplx *T0, int ld, long l
         const int j = j0 + q;
         if (i < nb && j < nb) Pb[i * PNB + cperm[j]] = S.a[cperm[i]][j];
     }
+}
+
+__global__ __launch_bounds__(256) void k_gj_pivot(const cplx *T0, int ld, long long stride, int n, int k0, int nb, const cplx *Wc0, const cplx *Wr0, long long wstride,
+                                                  cplx *Pb0, long long pstride) {
+    __shared__ __attribute__((aligned(16))) char lds[GJ_PIVOT_LDS];
+    gj_pivot_body(T0, ld, stride, n, k0, nb, Wc0, Wr0, wstride, Pb0, pstride, blockIdx.x, lds);
+}
+
+// Rank-32 update of step k and the Gauss-Jordan sweep of pivot block k+1 in ONE launch: the workgroups of one extra z-slice of the grid
+// do the sweeps (one per matrix, the rest of that slice leaves at once), all others are tiles of the masked update, which skips the pivot
+// block.  The sweep (31 us, one workgroup) hides behind the update without a second stream: cross-stream event hops cost 15-20 us apiece.
+template <int TM, int RN, int KS>
+__global__ __launch_bounds__(256) void k_zgemm2_la(int M, int Nn, int K, cplx alpha, const cplx *A0, int lda, long long sa,
+                                                   const cplx *B0, int ldb, long long sb, cplx beta, cplx *C0, int ldc, long long sc, GemmRows R, GjPivotArgs pv) {
+    constexpr int TN = 1024 / TM * RN;
+    constexpr int ABYTES = 2 * KS * (TM + 1) * (int)sizeof(cplx), BBYTES = 2 * KS * TN * (int)sizeof(cplx);
+    constexpr int LDS = ABYTES + BBYTES > GJ_PIVOT_LDS ? ABYTES + BBYTES : GJ_PIVOT_LDS;
+    __shared__ __attribute__((aligned(16))) char lds[LDS];               // one buffer: a workgroup is either a tile or a sweep
+    if (blockIdx.z == 0) {                                                 // the sweeps go out first (dispatch order is x, y, z)
+        const int mat = blockIdx.y * gridDim.x + blockIdx.x;
+        if (mat < pv.batch) gj_pivot_body(pv.T0, pv.ld, pv.stride, pv.n, pv.k0, pv.nb, pv.Wc0, pv.Wr0, pv.wstride, pv.Pb0, pv.pstride, mat, lds);
+        return;
+    }
+    zgemm2_body<TM, 0, RN, KS, 1>(M, Nn, K, alpha, A0 - sa, lda, sa, B0 - sb, ldb, sb, beta, C0 - sc, ldc, sc, R,
+                                  reinterpret_cast<cplx *>(lds), reinterpret_cast<cplx *>(lds + ABYTES));     // (its batch index is blockIdx.z - 1)
 }
 
 __global__ __launch_bounds__(256) void k_gj_slices(const cplx *T0, int ld, long long stride, int n, int k0, int nb, cplx *Wc0, cplx *Wr0, long long wstride,
@@ -1271,6 +1314,7 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
     // (3713^2 x 32: 87 us against 93 for 64 x 64, tools/zgemm_tiles.py)
     if (rows && rows->dense && K <= 32 && !latency_mode && batch == 1) vsel = 3;
     if (g_gemm_tile >= 0) { vsel = g_gemm_tile & 7; latency_mode = false; }
+    if (rows && rows->la) { vsel = 3; latency_mode = false; }
     for (int b0 = 0; b0 < batch; b0 += 65535) {
         const int nb = std::min(65535, batch - b0);
         GemmRows R; if (rows) R = *rows;
@@ -1301,6 +1345,11 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
             default: launch_vec2<TM_, RN_, 8, 1, 1>(ZG_ARGS); break; } } while (0)
         if (latency_mode && gv != 0) {
             if (vsel == 6) launch_vec2<32, 1, 32, 4, 1>(ZG_ARGS); else launch_vec2<16, 1, 32, 4, 1>(ZG_ARGS);
+            continue;
+        }
+        if (rows && rows->la) {           // update + pivot sweep of the next block in one launch (64 x 32 tiles)
+            dim3 grid((Nn + 31) / 32, (M + 63) / 64, nb + 1);
+            ZG_LAUNCH((k_zgemm2_la<64, 2, 8>), grid, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R, *rows->la);
             continue;
         }
         switch (vsel) {
@@ -1344,17 +1393,6 @@ struct GemmRun {
     }
 };
 
-// second stream + two events of the look-ahead Gauss-Jordan, created on first use (released in helm_destroy)
-static bool nd_pivot_stream(helm_op *op) {
-    if (op->pivot_stream) return true;
-    int plo = 0, phi = 0;
-    hipDeviceGetStreamPriorityRange(&plo, &phi);
-    if (hipStreamCreateWithPriority(&op->pivot_stream, hipStreamNonBlocking, phi) != hipSuccess) { op->pivot_stream = nullptr; return false; }
-    for (int i = 0; i < 2; ++i)
-        if (hipEventCreateWithFlags(&op->ev_la[i], hipEventDisableTiming) != hipSuccess) return false;
-    return true;
-}
-
 // in-place inverse of `batch` n x n blocks (row-major, leading dimension ld, batch stride `stride`); W: workspace with
 // batch stride ws, at least n*n elements per matrix
 void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cplx *W, long long ws, int align = 1, int base = 0) {
@@ -1368,35 +1406,28 @@ void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cp
     static const int blocked_max_batch = getenv("HELM_ND_BLOCKED_BATCH") ? atoi(getenv("HELM_ND_BLOCKED_BATCH")) : 1024;
     if (blocked && batch <= blocked_max_batch && gemm_variant() != 0 && n > gj_base && gj_base == 32 && (long long)2 * PNB * n <= ws) {
         cplx *Wc = W, *Wr = W + (long long)PNB * n;
-        // look-ahead: the pivot block of step k+1 is inverted on a second (high-priority) stream beside the update of step k
-        // (only where the update is long enough to hide the sweep and the two cross-stream hops a step costs: the dense plane inverses of the
-        // 3-D coarse solve, n = 3713: 148 -> ~130 us per block step; on the 2-D fronts, n <= 1024, it LOSES 5 %)
+        // look-ahead: the pivot block of step k+1 is inverted beside the update of step k, in the same launch (k_zgemm2_la)
+        // (only for large matrices -- the dense plane inverses of the 3-D coarse solve, n = 3713: -7 % -- where the update is long enough to hide the
+        // sweep; on the 2-D fronts, n <= 1024, the update is shorter than the sweep and the split panel kernels cost more than is hidden: -1 %.
+        // A first version ran the sweep on a second stream: same gain at n = 3713, but two cross-stream event hops per step, -5 % in 2-D)
         static const int lookahead = getenv("HELM_ND_LOOKAHEAD") ? atoi(getenv("HELM_ND_LOOKAHEAD")) : 1;
         static const int lookahead_min_n = getenv("HELM_ND_LOOKAHEAD_N") ? atoi(getenv("HELM_ND_LOOKAHEAD_N")) : 2048;
-        if (lookahead && op && batch == 1 && n >= lookahead_min_n && (long long)2 * PNB * n + PNB * PNB <= ws && nd_pivot_stream(op)) {
-            hipStream_t sp = op->pivot_stream;
+        if (lookahead && batch <= 65535 && n >= lookahead_min_n && (long long)2 * PNB * n + PNB * PNB <= ws) {
             cplx *Pb = W + (long long)2 * PNB * n;
-            hipEventRecord(op->ev_la[0], st);                              // the front is assembled
-            hipStreamWaitEvent(sp, op->ev_la[0], 0);
+            hipLaunchKernelGGL(k_gj_pivot, dim3(batch), dim3(256), 0, st, M, ld, stride, n, 0, std::min(PNB, n), Wc, Wr, ws, Pb, ws);
             for (int k0 = 0; k0 < n; k0 += PNB) {
                 const int nb = std::min(PNB, n - k0);
-                hipLaunchKernelGGL(k_gj_pivot, dim3(batch), dim3(256), 0, sp, M, ld, stride, n, k0, nb, Wc, Wr, ws, Pb, ws);
-                hipEventRecord(op->ev_la[1], sp);
-                if (k0 > 0) {                                              // update of step k-1, beside the pivot kernel
-                    const int kp = k0 - PNB;
-                    GemmRows R; R.dense = 1; R.zr0 = kp; R.zr1 = k0; R.zc0 = kp; R.zc1 = k0; R.sk0 = k0; R.sk1 = k0 + nb;
-                    gemm(op, n, n, PNB, cmake(-1, 0), Wc, PNB, ws, Wr, n, ws, cmake(1, 0), M, ld, stride, batch, &R);
-                }
-                hipStreamWaitEvent(st, op->ev_la[1], 0);
                 hipLaunchKernelGGL(k_gj_slices, dim3((n + 63) / 64, batch), dim3(256), 0, st, M, ld, stride, n, k0, nb, Wc, Wr, ws, Pb, ws);
-                if (k0 + PNB < n) {
-                    hipEventRecord(op->ev_la[0], st);
-                    hipStreamWaitEvent(sp, op->ev_la[0], 0);
+                GemmRows R; R.dense = 1; R.zr0 = k0; R.zr1 = k0 + nb; R.zc0 = k0; R.zc1 = k0 + nb;
+                GjPivotArgs pv;
+                if (k0 + PNB < n) {                                      // the sweep of the next pivot block rides along; the update leaves that block alone
+                    const int k1 = k0 + PNB, nb1 = std::min(PNB, n - k1);
+                    R.sk0 = k1; R.sk1 = k1 + nb1;
+                    pv.T0 = M; pv.ld = ld; pv.stride = stride; pv.n = n; pv.k0 = k1; pv.nb = nb1; pv.Wc0 = Wc; pv.Wr0 = Wr; pv.wstride = ws;
+                    pv.Pb0 = Pb; pv.pstride = ws; pv.batch = batch;
+                    R.la = &pv;
                 }
-                else {
-                    GemmRows R; R.dense = 1; R.zr0 = k0; R.zr1 = k0 + nb; R.zc0 = k0; R.zc1 = k0 + nb;
-                    gemm(op, n, n, nb, cmake(-1, 0), Wc, PNB, ws, Wr, n, ws, cmake(1, 0), M, ld, stride, batch, &R);
-                }
+                gemm(op, n, n, nb, cmake(-1, 0), Wc, PNB, ws, Wr, n, ws, cmake(1, 0), M, ld, stride, batch, &R);
             }
             return;
         }

@@ -99,8 +99,6 @@ struct helm_op {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t side_stream = nullptr;    // second stream of the direct path (forward elimination behind the factorisation), on demand
-    hipStream_t pivot_stream = nullptr;   // high-priority stream of the look-ahead Gauss-Jordan (direct.hip invert()), on demand
-    hipEvent_t ev_la[2] = {nullptr, nullptr};
 
     // model
     cplx *d_c = nullptr;
