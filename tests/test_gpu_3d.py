@@ -184,6 +184,27 @@ def test_3d_retreat_to_the_standard_cycle(helm_lib, monkeypatch):
     assert np.linalg.norm(u3 - u) / np.linalg.norm(u) <= 1e-7
 
 
+def test_3d_multifreq_dispatcher(helm_lib):
+    """The multi-frequency dispatcher (zephyr/backend/dispatcher.py:160-187 contract) over the 3-D operator: one sub-problem per frequency,
+    every wavefield satisfies its own operator."""
+    import zephyr_amd as za
+    nz, ny, nx = 30, 32, 28
+    c = 2000. * np.ones((nz, ny, nx))
+    cfg = dict(nx=nx, ny=ny, nz=nz, dx=10., c=c, rho=1000., freqs=[3., 4.], nPML=6, rtol=1e-8, Disc=za.Helm3D, method='auto')
+    mf = za.MultiFreq(cfg)
+    N = nz * ny * nx
+    q = np.zeros((N, 2), complex)
+    q[(15 * ny + 12) * nx + 14, 0] = 1.
+    q[(9 * ny + 18) * nx + 20, 1] = 1j
+    us = list(mf * q)
+    assert len(us) == 2 and all(u.shape == (N, 2) for u in us)
+    for f, u, sub in zip(cfg['freqs'], us, mf.subProblems):
+        assert all(i['status'] == 0 for i in sub.lastInfo), sub.lastInfo
+        op = za.Helm3D(dict(cfg, freq=f))
+        r = op.applyForward(u.conj()) - q
+        assert np.linalg.norm(r) <= 2e-8 * np.linalg.norm(q)
+
+
 def test_3d_mid_size_properties_128x128x64(helm_lib):
     """Config-5 geometry at one eighth of its size (c = 2000 m/s, h = 10 m, 5 Hz): size-independent properties of the solve --
     residual of the returned field through the independent apply entry point, conj-linearity, agreement with the analytic
