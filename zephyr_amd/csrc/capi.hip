@@ -1067,7 +1067,8 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
         if (rc == HELM_OK) use_mg = true;
         else if (o.method == HELM_MG) return rc;
     }
-    const int check_every = o.check_every > 0 ? o.check_every : (use_mg ? 10 : 50);
+    // (an iteration of the layer-preserving 3-D cycle costs tens of milliseconds and ten of them are a whole solve: poll after every one)
+    const int check_every = o.check_every > 0 ? o.check_every : (use_mg && op->ny > 0 && mg3_is_layer_preserving(op) ? 1 : (use_mg ? 10 : 50));
     int unconverged = 0;
     for (int first = 0; first < nrhs; first += Bmax) {
         const int n = std::min(Bmax, nrhs - first);
