@@ -130,9 +130,8 @@ int nd_build_plan(NdPlan &P, int nz, int nx, int leaf, int dof) {
         g.roff = P.total_rows; P.total_rows += (long long)g.cnt * nmax;
         lev_f[g.level] += (long long)g.cnt * g.mmax * nmax;
         lev_v[g.level] += (long long)g.cnt * nmax;
-        g.finv = fac; fac += (long long)g.cnt * g.smax * g.smax;
+        g.finv = fac; g.f12 = fac + g.smax; fac += (long long)g.cnt * g.smax * nmax;       // [F11^-1 | F12] rows of nmax per front
         g.g21 = fac; fac += (long long)g.cnt * g.mmax * g.smax;
-        g.f12 = fac; fac += (long long)g.cnt * g.smax * g.mmax;
     }
     P.fac_elems = fac;
     P.fregion = 0; P.vregion = 0; P.work_elems = 0;
@@ -147,8 +146,8 @@ int nd_build_plan(NdPlan &P, int nz, int nx, int leaf, int dof) {
             const long long nmax = g.smax + g.mmax;
             n.smax = g.smax; n.mmax = g.mmax;
             n.foff = g.foff + (long long)j * g.mmax * nmax;
-            n.finv_off = g.finv + (long long)j * g.smax * g.smax;
-            n.f12_off = g.f12 + (long long)j * g.smax * g.mmax;
+            n.finv_off = g.finv + (long long)j * g.smax * nmax;
+            n.f12_off = n.finv_off + g.smax;
             n.voff = g.voff + (long long)j * nmax;
             n.roff = g.roff + (long long)j * nmax;
         }
@@ -159,13 +158,13 @@ int nd_build_plan(NdPlan &P, int nz, int nx, int leaf, int dof) {
 // ---- kernels ---------------------------------------------------------------------------------------------------
 namespace {
 
-// The front [[F11, F12], [F21, F22]] is assembled where each block is needed afterwards: F11 and F12 in the factor storage
-// (F11 is inverted in place, F12 is kept as it is), [F21 | F22] in the scratch arena (F21 feeds G21, F22 becomes the Schur
+// The front [[F11, F12], [F21, F22]] is assembled where each block is needed afterwards: [F11 | F12] side by side in the factor
+// storage (rows of smax + mmax; F11 is inverted in place, F12 is kept -- for leaves it becomes -F11^-1 F12 after the Schur complement, so
+// that the back substitution of a leaf is ONE product [F11^-1 | -F11^-1 F12] [y_S; x_B]), [F21 | F22] in the scratch arena (F21 feeds G21, F22 becomes the Schur
 // complement the parent picks up).  (r, c): padded front coordinates.
 __device__ __forceinline__ cplx *front_entry(const NdDev &n, cplx *arenaF, cplx *fac, int r, int c) {
     if (r < n.smax) {
-        if (c < n.smax) return fac + n.finv_off + (long long)r * n.smax + c;
-        return fac + n.f12_off + (long long)r * n.mmax + (c - n.smax);
+        return fac + n.finv_off + (long long)r * (n.smax + n.mmax) + c;        // [F11 | F12] share their rows
     }
     return arenaF + n.foff + (long long)(r - n.smax) * (n.smax + n.mmax) + c;
 }
@@ -306,6 +305,9 @@ struct GemmRows {
     int zr0 = 0, zr1 = 0, zc0 = 0, zc1 = 0;   // rows [zr0, zr1) and columns [zc0, zc1) of C are taken as zero on input (beta masked): blocked Gauss-Jordan
     int sk0 = 0, sk1 = 0;                     // the diagonal block [sk0, sk1)^2 of C is neither read nor written (the next pivot block, owned by k_gj_pivot)
     int dense = 0;                            // only the masks above are in use: launch the plain (un-indexed) kernel
+    const cplx *Bx2 = nullptr; int k2 = 0;    // rows k < k2 of an indexed B come from Bx2 instead of Bx (a leaf's y_S is still in the right-hand sides)
+    int tm64 = 0;                             // one 64-row tile per matrix (M <= 64): C may then overwrite B (every workgroup has read all of its B columns
+                                              // before it stores, and no other workgroup reads them)
     const GjPivotArgs *la = nullptr;          // (host pointer) fuse this pivot sweep into the launch: 64 x 32 tiles, one extra z-slice
 };
 #define GB_K 8
@@ -486,7 +488,7 @@ __device__ __forceinline__ void zgemm2_body(int M, int Nn, int K, cplx alpha, co
                     if (t4.z >= 0) v = cadd(v, R.Cix[(long long)t4.z * R.ldx + n0 + bc]);
                     if (blockIdx.y == 0 && t4.w && R.Cox) R.Cox[(long long)t4.x * R.ldx + n0 + bc] = v;      // y_S
                 }
-                else if (idxB) { const int r = kidx[k0 + bk]; if (r >= 0) v = R.Bx[(long long)r * R.ldx + n0 + bc]; }
+                else if (idxB) { const int r = kidx[k0 + bk]; if (r >= 0) v = (k0 + bk < R.k2 ? R.Bx2 : R.Bx)[(long long)r * R.ldx + n0 + bc]; }
                 else v = B[(long long)(k0 + bk) * ldb + n0 + bc];
             }
             rb[e] = v;
@@ -1315,6 +1317,7 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
     if (rows && rows->dense && K <= 32 && !latency_mode && batch == 1) vsel = 3;
     if (g_gemm_tile >= 0) { vsel = g_gemm_tile & 7; latency_mode = false; }
     if (rows && rows->la) { vsel = 3; latency_mode = false; }
+    if (rows && rows->tm64 && M <= 64) { vsel = Nn <= 32 ? 3 : 0; latency_mode = false; }
     for (int b0 = 0; b0 < batch; b0 += 65535) {
         const int nb = std::min(65535, batch - b0);
         GemmRows R; if (rows) R = *rows;
@@ -1538,6 +1541,12 @@ void nd_free(NdFactor *f) {
 
 namespace {
 
+// HELM_ND_MERGED_LEAF=0: keep F12 and back-substitute the leaves with two products through an intermediate (round-2 first half)
+bool merged_leaf_backward() {
+    static const int v = getenv("HELM_ND_MERGED_LEAF") ? atoi(getenv("HELM_ND_MERGED_LEAF")) : 1;
+    return v != 0 && gemm_variant() != 0;
+}
+
 // factorisation of one group (tree level x kind) on op->stream
 int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, const cplx *planes) {
     const NdPlan &P = f->pd->plan;
@@ -1547,7 +1556,7 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
     const NdGroup &g = P.groups[gi];
     const int nmax = g.smax + g.mmax;
     const long long fs = (long long)g.mmax * nmax;              // scratch per front: [F21 | F22]
-    const long long s11 = (long long)g.smax * g.smax, s12 = (long long)g.smax * g.mmax;
+    const long long s11 = (long long)g.smax * g.smax, s12 = (long long)g.smax * g.mmax, s1 = (long long)g.smax * nmax;   // s1: stride of [F11 | F12]
     cplx *F = arenaF + g.foff;
     cplx *Finv = f->d_fac + g.finv, *G21 = f->d_fac + g.g21, *F12 = f->d_fac + g.f12;
     static const int fused_build = getenv("HELM_ND_FUSEDBUILD") ? atoi(getenv("HELM_ND_FUSEDBUILD")) : 1;
@@ -1562,8 +1571,7 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
         }
     } else {
         if (fs > 0) HIP_TRY(op, hipMemsetAsync(F, 0, (size_t)g.cnt * fs * sizeof(cplx), st));
-        HIP_TRY(op, hipMemsetAsync(Finv, 0, (size_t)g.cnt * s11 * sizeof(cplx), st));
-        if (s12 > 0) HIP_TRY(op, hipMemsetAsync(F12, 0, (size_t)g.cnt * s12 * sizeof(cplx), st));
+        HIP_TRY(op, hipMemsetAsync(Finv, 0, (size_t)g.cnt * s1 * sizeof(cplx), st));
         for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
             const int nb = std::min(65535, g.cnt - j0);
             hipLaunchKernelGGL(k_nd_assemble, dim3((nmax + 255) / 256, nb), dim3(256), 0, st, d_nodes, g.first + j0, arenaF, f->d_fac, planes, op->nz, op->nx);
@@ -1587,11 +1595,22 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
     // the few huge fronts at the top of the tree are one long chain of single-matrix launches: the wider base block halves it
     static const int gj_top = getenv("HELM_ND_GJ_TOP") ? atoi(getenv("HELM_ND_GJ_TOP")) : 0;
     const int base = g.leaf ? gj_leaf : (g.cnt <= gj_top ? 64 : gj_upper);
-    invert(op, Finv, g.smax, s11, g.smax, g.cnt, work, s11, P.dof, base);      // F11 -> F11^-1 where it stays
+    invert(op, Finv, nmax, s1, g.smax, g.cnt, work, s11, P.dof, base);      // F11 -> F11^-1 where it stays
     if (g.mmax > 0) {
         // G21 = F21 F11^-1 ; F22 -= G21 F12
-        gemm(op, g.mmax, g.smax, g.smax, one, F, nmax, fs, Finv, g.smax, s11, zero, G21, g.smax, (long long)g.mmax * g.smax, g.cnt);
-        gemm(op, g.mmax, g.mmax, g.smax, mone, G21, g.smax, (long long)g.mmax * g.smax, F12, g.mmax, s12, one, F + g.smax, nmax, fs, g.cnt);
+        gemm(op, g.mmax, g.smax, g.smax, one, F, nmax, fs, Finv, nmax, s1, zero, G21, g.smax, (long long)g.mmax * g.smax, g.cnt);
+        gemm(op, g.mmax, g.mmax, g.smax, mone, G21, g.smax, (long long)g.mmax * g.smax, F12, nmax, s1, one, F + g.smax, nmax, fs, g.cnt);
+        if (g.leaf && merged_leaf_backward()) {
+            // leaves: F12 <- -F11^-1 F12, in place where a front is one 64-row tile (GemmRows::tm64), else through the inversion workspace
+            if (g.smax <= 64) {
+                GemmRows R; R.dense = 1; R.tm64 = 1;
+                gemm(op, g.smax, g.mmax, g.smax, mone, Finv, nmax, s1, F12, nmax, s1, zero, F12, nmax, s1, g.cnt, &R);
+            } else {
+                gemm(op, g.smax, g.mmax, g.smax, mone, Finv, nmax, s1, F12, nmax, s1, zero, work, g.mmax, s12, g.cnt);
+                HIP_TRY(op, hipMemcpy2DAsync(F12, (size_t)nmax * sizeof(cplx), work, (size_t)g.mmax * sizeof(cplx), (size_t)g.mmax * sizeof(cplx),
+                                             (size_t)g.cnt * g.smax, hipMemcpyDeviceToDevice, st));
+            }
+        }
     }
     f->flops += (double)g.cnt * 8.0 * (2.0 * g.smax * g.smax * g.smax + (double)g.smax * g.smax * g.mmax + (double)g.smax * g.mmax * g.mmax);
     return HELM_OK;
@@ -1655,28 +1674,49 @@ void backward_group(helm_op *op, NdFactor *f, size_t gk, const SolveCtx &c) {
     const NdGroup &g = P.groups[gk];
     const int nmax = g.smax + g.mmax, nrhs = c.nrhs;
     const long long rows = (long long)g.cnt * nmax;
+    const long long s1 = (long long)g.smax * nmax;                 // stride of a front's [F11^-1 | F12] rows
+    const cplx *Finv = f->d_fac + g.finv, *F12 = f->d_fac + g.f12;
+    // leaves under HELM_ND_MERGED_LEAF hold G = -F11^-1 F12 in place of F12: x_S = F11^-1 y_S + G x_B
+    const bool gform = g.leaf && g.mmax > 0 && merged_leaf_backward();
     cplx *V = c.arenaV + g.voff * nrhs;
     // the other region is free in this pass: separator results go there
     const long long xs_off = g.voff + ((g.level & 1) ? -P.vregion : P.vregion);
     cplx *XS = c.arenaV + xs_off * nrhs;
     if (c.use_idx && g.mmax > 0 && g.mmax <= GB_KIDX) {
-        // lower tree levels (almost all rows): T = y_S - F12 x_B and x_S = F11^-1 T with every Xt row addressed through
-        // the row table -- no gather / store pass
+        // lower tree levels (almost all rows): every Xt row addressed through the row table -- no gather / store pass
+        if (gform && c.Qt != c.Xt && nmax <= GB_KIDX) {
+            // leaves: x_S = [F11^-1 | G] [y_S; x_B] in ONE product -- y_S rows from the right-hand sides, x_B rows from Xt; the result goes
+            // straight to the Xt rows (no intermediate: 2 x 3.2 GB less per pass at 1024^2 x 256)
+            GemmRows R; R.tabB = c.tab + g.roff; R.offB = 0; R.tabCo = c.tab + g.roff; R.offCo = 0; R.tab_stride = nmax;
+            R.Bx = c.Xt; R.Bx2 = c.Qt; R.k2 = g.smax; R.Cox = c.Xt; R.ldx = nrhs;
+            gemm(op, g.smax, nrhs, nmax, one, Finv, nmax, s1, nullptr, 0, 0, zero, nullptr, 0, 0, g.cnt, &R);
+            return;
+        }
+        if (gform) {        // right-hand sides and wavefields share their rows (Qt == Xt): V = F11^-1 y_S first, then x_S = V + G x_B
+            GemmRows R1; R1.tabB = c.tab + g.roff; R1.offB = 0; R1.tab_stride = nmax; R1.Bx = c.Qt; R1.ldx = nrhs;
+            gemm(op, g.smax, nrhs, g.smax, one, Finv, nmax, s1, nullptr, 0, 0, zero, V, nrhs, (long long)g.smax * nrhs, g.cnt, &R1);
+            GemmRows R2; R2.tabB = c.tab + g.roff; R2.offB = g.smax; R2.tabCo = c.tab + g.roff; R2.offCo = 0; R2.tab_stride = nmax;
+            R2.Bx = c.Xt; R2.Cox = c.Xt; R2.ldx = nrhs;
+            gemm(op, g.smax, nrhs, g.mmax, one, F12, nmax, s1, nullptr, 0, 0, one, V, nrhs, (long long)g.smax * nrhs, g.cnt, &R2);
+            return;
+        }
+        // T = y_S - F12 x_B and x_S = F11^-1 T
         GemmRows R1; R1.tabB = c.tab + g.roff; R1.offB = g.smax; R1.tabCi = c.tab + g.roff; R1.offCi = 0; R1.tab_stride = nmax;
         R1.Bx = c.Xt; R1.Cix = g.leaf ? c.Qt : c.Xt; R1.ldx = nrhs;      // a leaf's y_S is still the right-hand side itself
-        gemm(op, g.smax, nrhs, g.mmax, mone, f->d_fac + g.f12, g.mmax, (long long)g.smax * g.mmax, nullptr, 0, 0, one,
-             V, nrhs, (long long)g.smax * nrhs, g.cnt, &R1);
+        gemm(op, g.smax, nrhs, g.mmax, mone, F12, nmax, s1, nullptr, 0, 0, one, V, nrhs, (long long)g.smax * nrhs, g.cnt, &R1);
         GemmRows R2; R2.tabCo = c.tab + g.roff; R2.offCo = 0; R2.tab_stride = nmax; R2.Cox = c.Xt; R2.ldx = nrhs;
-        gemm(op, g.smax, nrhs, g.smax, one, f->d_fac + g.finv, g.smax, (long long)g.smax * g.smax, V, nrhs, (long long)g.smax * nrhs, zero,
-             nullptr, 0, 0, g.cnt, &R2);
+        gemm(op, g.smax, nrhs, g.smax, one, Finv, nmax, s1, V, nrhs, (long long)g.smax * nrhs, zero, nullptr, 0, 0, g.cnt, &R2);
         return;
     }
     hipLaunchKernelGGL(k_nd_bwd_gather, c.rgrid(rows), c.rb, 0, op->stream, c.tab + g.roff, V, g.leaf ? c.Qt : c.Xt, c.Xt, rows, nrhs);
-    if (g.mmax > 0)
-        gemm(op, g.smax, nrhs, g.mmax, mone, f->d_fac + g.f12, g.mmax, (long long)g.smax * g.mmax, V + (long long)g.smax * nrhs, nrhs, (long long)nmax * nrhs,
-             one, V, nrhs, (long long)nmax * nrhs, g.cnt);
-    gemm(op, g.smax, nrhs, g.smax, one, f->d_fac + g.finv, g.smax, (long long)g.smax * g.smax, V, nrhs, (long long)nmax * nrhs, zero,
-         XS, nrhs, (long long)g.smax * nrhs, g.cnt);
+    if (gform) {            // the gathered front vector is [y_S; x_B]: one dense product with [F11^-1 | G]
+        gemm(op, g.smax, nrhs, nmax, one, Finv, nmax, s1, V, nrhs, (long long)nmax * nrhs, zero, XS, nrhs, (long long)g.smax * nrhs, g.cnt);
+    } else {
+        if (g.mmax > 0)
+            gemm(op, g.smax, nrhs, g.mmax, mone, F12, nmax, s1, V + (long long)g.smax * nrhs, nrhs, (long long)nmax * nrhs,
+                 one, V, nrhs, (long long)nmax * nrhs, g.cnt);
+        gemm(op, g.smax, nrhs, g.smax, one, Finv, nmax, s1, V, nrhs, (long long)nmax * nrhs, zero, XS, nrhs, (long long)g.smax * nrhs, g.cnt);
+    }
     const long long srows = (long long)g.cnt * g.smax;
     hipLaunchKernelGGL(k_nd_bwd_store, c.rgrid(srows), c.rb, 0, op->stream, c.tab + g.roff, XS, c.Xt, srows, g.smax, nmax, nrhs);
 }
