@@ -976,7 +976,7 @@ __global__ __launch_bounds__(256) void k_gj_pivot(const cplx *T0, int ld, long l
 // Rank-32 update of step k and the Gauss-Jordan sweep of pivot block k+1 in ONE launch: the workgroups of one extra z-slice of the grid
 // do the sweeps (one per matrix, the rest of that slice leaves at once), all others are tiles of the masked update, which skips the pivot
 // block.  The sweep (31 us, one workgroup) hides behind the update without a second stream: cross-stream event hops cost 15-20 us apiece.
-template <int TM, int RN, int KS>
+template <int TM, int RN, int KS, int UNR>
 __global__ __launch_bounds__(256) void k_zgemm2_la(int M, int Nn, int K, cplx alpha, const cplx *A0, int lda, long long sa,
                                                    const cplx *B0, int ldb, long long sb, cplx beta, cplx *C0, int ldc, long long sc, GemmRows R, GjPivotArgs pv) {
     constexpr int TN = 1024 / TM * RN;
@@ -988,7 +988,7 @@ __global__ __launch_bounds__(256) void k_zgemm2_la(int M, int Nn, int K, cplx al
         if (mat < pv.batch) gj_pivot_body(pv.T0, pv.ld, pv.stride, pv.n, pv.k0, pv.nb, pv.Wc0, pv.Wr0, pv.wstride, pv.Pb0, pv.pstride, mat, lds);
         return;
     }
-    zgemm2_body<TM, 0, RN, KS, 1>(M, Nn, K, alpha, A0 - sa, lda, sa, B0 - sb, ldb, sb, beta, C0 - sc, ldc, sc, R,
+    zgemm2_body<TM, 0, RN, KS, UNR>(M, Nn, K, alpha, A0 - sa, lda, sa, B0 - sb, ldb, sb, beta, C0 - sc, ldc, sc, R,
                                   reinterpret_cast<cplx *>(lds), reinterpret_cast<cplx *>(lds + ABYTES));     // (its batch index is blockIdx.z - 1)
 }
 
@@ -1316,7 +1316,8 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
     // (3713^2 x 32: 87 us against 93 for 64 x 64, tools/zgemm_tiles.py)
     if (rows && rows->dense && K <= 32 && !latency_mode && batch == 1) vsel = 3;
     if (g_gemm_tile >= 0) { vsel = g_gemm_tile & 7; latency_mode = false; }
-    if (rows && rows->la) { vsel = 3; latency_mode = false; }
+    // the fused update + sweep launch exists for two tiles: 64 x 32 (large matrices) and the 32 x 32 latency tile (under-filled launches)
+    if (rows && rows->la) { vsel = latency_mode ? 6 : 3; }
     if (rows && rows->tm64 && M <= 64) { vsel = Nn <= 32 ? 3 : 0; latency_mode = false; }
     for (int b0 = 0; b0 < batch; b0 += 65535) {
         const int nb = std::min(65535, batch - b0);
@@ -1346,13 +1347,18 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
             case 0: launch_vec<TM_, RN_>(ZG_ARGS); break; \
             case 6: launch_vec2<TM_, RN_, (RN_ == 1 ? 32 : (RN_ == 2 ? 16 : 8)), 1, 1>(ZG_ARGS); break; \
             default: launch_vec2<TM_, RN_, 8, 1, 1>(ZG_ARGS); break; } } while (0)
-        if (latency_mode && gv != 0) {
-            if (vsel == 6) launch_vec2<32, 1, 32, 4, 1>(ZG_ARGS); else launch_vec2<16, 1, 32, 4, 1>(ZG_ARGS);
+        if (rows && rows->la && gv != 0) {           // update + pivot sweep of the next block in one launch
+            if (latency_mode) {
+                dim3 grid((Nn + 31) / 32, (M + 31) / 32, nb + 1);
+                ZG_LAUNCH((k_zgemm2_la<32, 1, 32, 4>), grid, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R, *rows->la);
+            } else {
+                dim3 grid((Nn + 31) / 32, (M + 63) / 64, nb + 1);
+                ZG_LAUNCH((k_zgemm2_la<64, 2, 8, 1>), grid, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R, *rows->la);
+            }
             continue;
         }
-        if (rows && rows->la) {           // update + pivot sweep of the next block in one launch (64 x 32 tiles)
-            dim3 grid((Nn + 31) / 32, (M + 63) / 64, nb + 1);
-            ZG_LAUNCH((k_zgemm2_la<64, 2, 8>), grid, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R, *rows->la);
+        if (latency_mode && gv != 0) {
+            if (vsel == 6) launch_vec2<32, 1, 32, 4, 1>(ZG_ARGS); else launch_vec2<16, 1, 32, 4, 1>(ZG_ARGS);
             continue;
         }
         switch (vsel) {
@@ -1410,12 +1416,13 @@ void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cp
     if (blocked && batch <= blocked_max_batch && gemm_variant() != 0 && n > gj_base && gj_base == 32 && (long long)2 * PNB * n <= ws) {
         cplx *Wc = W, *Wr = W + (long long)PNB * n;
         // look-ahead: the pivot block of step k+1 is inverted beside the update of step k, in the same launch (k_zgemm2_la)
-        // (only for large matrices -- the dense plane inverses of the 3-D coarse solve, n = 3713: -7 % -- where the update is long enough to hide the
-        // sweep; on the 2-D fronts, n <= 1024, the update is shorter than the sweep and the split panel kernels cost more than is hidden: -1 %.
+        // (the dense plane inverses of the 3-D coarse solve, n = 3713: -7 %; the 2-D fronts of 512 and 1024 unknowns at the top of the tree, with the
+        // 32 x 32 latency tile: +0.6 % on the bench; below that the split panel kernels cost more than the sweep hides.
         // A first version ran the sweep on a second stream: same gain at n = 3713, but two cross-stream event hops per step, -5 % in 2-D)
         static const int lookahead = getenv("HELM_ND_LOOKAHEAD") ? atoi(getenv("HELM_ND_LOOKAHEAD")) : 1;
-        static const int lookahead_min_n = getenv("HELM_ND_LOOKAHEAD_N") ? atoi(getenv("HELM_ND_LOOKAHEAD_N")) : 2048;
-        if (lookahead && batch <= 65535 && n >= lookahead_min_n && (long long)2 * PNB * n + PNB * PNB <= ws) {
+        static const int lookahead_min_n = getenv("HELM_ND_LOOKAHEAD_N") ? atoi(getenv("HELM_ND_LOOKAHEAD_N")) : 512;
+        // (one sweep per matrix rides in the first z-slice of the update's grid: that slice must have a workgroup for each)
+        if (lookahead && n >= lookahead_min_n && (long long)((n + 63) / 64) * ((n + 31) / 32) >= batch && (long long)2 * PNB * n + PNB * PNB <= ws) {
             cplx *Pb = W + (long long)2 * PNB * n;
             hipLaunchKernelGGL(k_gj_pivot, dim3(batch), dim3(256), 0, st, M, ld, stride, n, 0, std::min(PNB, n), Wc, Wr, ws, Pb, ws);
             for (int k0 = 0; k0 < n; k0 += PNB) {
