@@ -341,7 +341,15 @@ __global__ __launch_bounds__(256) void k_bt_schur_t(const cplx *__restrict__ pla
         const cplx *Tn = side ? Tp : Tm;
         if (!Tn) continue;
         const int d = side ? 1 : -1;
-        // the nine entries of row i of A_{k,k+d} and of column j of A_{k+d,k}
+        // the nine entries of row i of A_{k,k+d} (kept in registers) and of column j of A_{k+d,k}
+        cplx am9[9]; int off9[9];
+        #pragma unroll
+        for (int d1 = 0; d1 < 9; ++d1) {
+            const int aa = ia + (d1 / 3 - 1), ab = ib + (d1 % 3 - 1);
+            const bool in = aa >= 0 && aa < g.na && ab >= 0 && ab < g.nb;
+            off9[d1] = in ? aa * g.nb + ab : -1;
+            am9[d1] = in ? planes[(long long)bt_slot(g.axis, d, d1 / 3 - 1, d1 % 3 - 1) * g.N + node_i] : cmake(0.0, 0.0);
+        }
         for (int d2 = 0; d2 < 9; ++d2) {
             const int ba = ja - (d2 / 3 - 1), bb = jb - (d2 % 3 - 1);
             if (ba < 0 || ba >= g.na || bb < 0 || bb >= g.nb) continue;
@@ -350,12 +358,8 @@ __global__ __launch_bounds__(256) void k_bt_schur_t(const cplx *__restrict__ pla
             if (ap.x == 0.0 && ap.y == 0.0) continue;
             const cplx *trow = Tn + (long long)(ba * g.nb + bb) * g.m;
             cplx acc = cmake(0.0, 0.0);
-            for (int d1 = 0; d1 < 9; ++d1) {
-                const int aa = ia + (d1 / 3 - 1), ab = ib + (d1 % 3 - 1);
-                if (aa < 0 || aa >= g.na || ab < 0 || ab >= g.nb) continue;
-                const cplx am = planes[(long long)bt_slot(g.axis, d, d1 / 3 - 1, d1 % 3 - 1) * g.N + node_i];
-                cfma(acc, am, trow[aa * g.nb + ab]);
-            }
+            #pragma unroll
+            for (int d1 = 0; d1 < 9; ++d1) if (off9[d1] >= 0) cfma(acc, am9[d1], trow[off9[d1]]);
             v = csub(v, cmul(acc, ap));
         }
     }
