@@ -1063,6 +1063,7 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
     static const int auto_mg3 = getenv("HELM_AUTO_MG3") ? atoi(getenv("HELM_AUTO_MG3")) : 1;
     const bool mg3_ok = op->ny > 0 && (o.method == HELM_MG || (o.method == HELM_AUTO && auto_mg3 && std::min(op->nz, std::min(op->ny, op->nx)) >= 24));
     if (!sys2 && block == 0 && (mg3_ok || (op->ny == 0 && (o.method == HELM_MG || (o.method == HELM_AUTO && std::min(op->nz, op->nx) >= 32))))) {
+        op->mg3_rhs_hint = nrhs;
         rc = mg_setup(op, Bmax);
         if (rc == HELM_OK) use_mg = true;
         else if (o.method == HELM_MG) return rc;

@@ -118,6 +118,7 @@ struct helm_op {
     struct MgPrecond *mg = nullptr;
     struct Mg3Precond *mg3 = nullptr;    // 3-D multigrid preconditioner (mg3d.hip)
     bool mg3_no_keep = false;            // this frequency retreated from the layer-preserving hierarchy to the standard cycle (capi.hip)
+    int mg3_rhs_hint = 0;                // right-hand sides of the solve call that builds the preconditioner (0: unknown): few of them favour a cheap set-up
     struct NdFactor *direct[4] = {nullptr, nullptr, nullptr, nullptr};   // sparse direct factors per block, valid until the next assemble
     bool direct_failed = false;
     int nblocks = 1;

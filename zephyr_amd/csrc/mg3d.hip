@@ -317,6 +317,46 @@ __global__ void k3_prolong_add_t(const cplx *__restrict__ coarse, cplx *__restri
     }
 }
 
+// Galerkin coarse operator A_c = R A_f P of a 27-point fine operator with the tensor-product transfers of the tables: again 27-point.
+// One thread per coarse node (a set-up kernel: the 27 accumulators are indexed dynamically and live in scratch).  Used for the directly
+// solved level only: at 5-8 points per wavelength the rediscretised operator carries waves of a different length than the level above
+// (numpy prototype, 5 points: 38 instead of 87 iterations).
+__global__ __launch_bounds__(256) void k3_galerkin(const cplx *__restrict__ pf, int nzf, int nyf, int nxf, cplx *__restrict__ pc, int nzc, int nyc, int nxc,
+                                                   const RTab *__restrict__ rz_, const RTab *__restrict__ ry_, const RTab *__restrict__ rx_,
+                                                   const PTab *__restrict__ pz_, const PTab *__restrict__ py_, const PTab *__restrict__ px_) {
+    const long long Nc = (long long)nzc * nyc * nxc, Nf = (long long)nzf * nyf * nxf;
+    const long long I = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= Nc) return;
+    const int X = (int)(I % nxc), Y = (int)((I / nxc) % nyc), Z = (int)(I / ((long long)nxc * nyc));
+    cplx acc[27];
+    for (int k = 0; k < 27; ++k) acc[k] = cmake(0.0, 0.0);
+    const RTab rz = rz_[Z], ry = ry_[Y], rx = rx_[X];
+    const double wz[3] = {rz.wl, rz.wc, rz.wr}, wy[3] = {ry.wl, ry.wc, ry.wr}, wx[3] = {rx.wl, rx.wc, rx.wr};
+    for (int a = 0; a < 3; ++a) { if (wz[a] == 0.0) continue; const int iz = rz.f + a - 1;
+        for (int b = 0; b < 3; ++b) { if (wy[b] == 0.0) continue; const int iy = ry.f + b - 1;
+            for (int c = 0; c < 3; ++c) { if (wx[c] == 0.0) continue; const int ix = rx.f + c - 1;
+                const double wr = wz[a] * wy[b] * wx[c];
+                const long long i = ((long long)iz * nyf + iy) * nxf + ix;
+                for (int k = 0; k < 27; ++k) {
+                    const cplx cf = pf[(long long)k * Nf + i];
+                    if (cf.x == 0.0 && cf.y == 0.0) continue;
+                    const int jz = iz + k / 9 - 1, jy = iy + (k / 3) % 3 - 1, jx = ix + k % 3 - 1;
+                    if (jz < 0 || jz >= nzf || jy < 0 || jy >= nyf || jx < 0 || jx >= nxf) continue;
+                    const PTab qz = pz_[jz], qy = py_[jy], qx = px_[jx];
+                    const int cz[2] = {qz.c0, qz.c1}, cy[2] = {qy.c0, qy.c1}, cx[2] = {qx.c0, qx.c1};
+                    const double vz[2] = {qz.w0, qz.w1}, vy[2] = {qy.w0, qy.w1}, vx[2] = {qx.w0, qx.w1};
+                    for (int ua = 0; ua < 2; ++ua) { if (vz[ua] == 0.0) continue; const int dz = cz[ua] - Z; if (dz < -1 || dz > 1) continue;
+                        for (int ub = 0; ub < 2; ++ub) { if (vy[ub] == 0.0) continue; const int dy = cy[ub] - Y; if (dy < -1 || dy > 1) continue;
+                            for (int uc = 0; uc < 2; ++uc) { if (vx[uc] == 0.0) continue; const int dx = cx[uc] - X; if (dx < -1 || dx > 1) continue;
+                                const double w = wr * vz[ua] * vy[ub] * vx[uc];
+                                cplx &t = acc[9 * (dz + 1) + 3 * (dy + 1) + (dx + 1)];
+                                t.x += w * cf.x; t.y += w * cf.y;
+                            } } }
+                }
+            } } }
+    for (int k = 0; k < 27; ++k) pc[(long long)k * Nc + I] = acc[k];
+}
+
 // ---- block-tridiagonal direct solver of the coarsest level ------------------------------------------------------------
 __device__ __forceinline__ int bt_slot(int axis, int os, int da, int db) {
     const int oz = axis == 0 ? os : da, oy = axis == 0 ? da : (axis == 1 ? os : db), ox = axis == 2 ? os : db;
@@ -875,6 +915,14 @@ int setup_keep(helm_op *op, Mg3Precond *P, int batch, int ncoarsen, double tauM)
         c.swap(cc); rho.swap(rc2);
         for (int a = 0; a < 3; ++a) ax[a] = cx[a];
     }
+    if (ncoarsen > 0 && envi("HELM_MG3_GALERKIN", 1)) {        // the directly solved level carries the Galerkin product of the level above it
+        const Mg3Level &Lf = P->lv[ncoarsen - 1]; Mg3Level &Lc = P->lv[ncoarsen];
+        const int t = ncoarsen - 1;
+        hipLaunchKernelGGL(k3_galerkin, dim3((unsigned)((Lc.N + 255) / 256)), dim3(256), 0, op->stream, (const cplx *)Lf.op->d_C, Lf.nz, Lf.ny, Lf.nx,
+                           Lc.op->d_C, Lc.nz, Lc.ny, Lc.nx, (const RTab *)K->rt[0][t], (const RTab *)K->rt[1][t], (const RTab *)K->rt[2][t],
+                           (const PTab *)K->pt[0][t], (const PTab *)K->pt[1][t], (const PTab *)K->pt[2][t]);
+        HIP_TRY(op, hipGetLastError());
+    }
     return bt_setup(op, K->bt, P->lv.back(), batch);
 }
 
@@ -927,7 +975,12 @@ int mg3_setup(helm_op *op, int batch) {
         if (ncoarsen > 0) {
             size_t freeb = 0, totb = 0;
             hipMemGetInfo(&freeb, &totb);
-            const double cap = envd("HELM_MG3_BT_MAXGB", totb / 3.0e9) * 1e9, ppwf = envd("HELM_MG3_PPWF", 6.0);
+            double cap = envd("HELM_MG3_BT_MAXGB", totb / 3.0e9) * 1e9;
+            const double ppwf = envd("HELM_MG3_PPWF", 6.0);
+            // ... and likewise when the call that builds the preconditioner brings few right-hand sides (<= HELM_MG3_FEW_RHS = 32) and the plane
+            // inverses of the 10-point level are large (> HELM_MG3_DEEPER_GB = 4): config 5 at 3 / 4 Hz, 16 sources: set-up 1.5 -> 0.27 s for 17 / 29
+            // iterations instead of 6 / 7 (the Galerkin operator of that level is what keeps it at that; 5 Hz would need 46 and stays)
+            if (op->mg3_rhs_hint > 0 && op->mg3_rhs_hint <= envi("HELM_MG3_FEW_RHS", 32)) cap = std::min(cap, envd("HELM_MG3_DEEPER_GB", 4.0) * 1e9);
             while (ncoarsen < 5 && keep_direct_bytes(op, ncoarsen) > cap && ppw / (double)(2 << ncoarsen) >= ppwf && (interior >> (ncoarsen + 1)) >= 3) ++ncoarsen;
         }
         ncoarsen = envi("HELM_MG3_KEEP_LEVELS", ncoarsen);
