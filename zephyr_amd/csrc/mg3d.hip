@@ -833,8 +833,9 @@ template <typename T> T *upload(const std::vector<T> &v) {
     return d;
 }
 
-// bytes of the (single-precision) plane inverses if the level reached after `l` layer-preserving coarsenings is the directly solved one
-double keep_direct_bytes(const helm_op *op, int l) {
+// bytes of the (single-precision) plane inverses if the level reached after `l` layer-preserving coarsenings is the directly solved one;
+// *setup_s (optional): the time its plane inversions take, 8 np m^3 flop at the ~21 TFLOP/s the blocked Gauss-Jordan sustains end to end
+double keep_direct_bytes(const helm_op *op, int l, double *setup_s = nullptr) {
     const int dims[3] = {op->nz, op->ny, op->nx};
     int out[3];
     for (int a = 0; a < 3; ++a) {
@@ -849,6 +850,7 @@ double keep_direct_bytes(const helm_op *op, int l) {
     int s = 0;
     for (int a = 1; a < 3; ++a) if (out[a] > out[s]) s = a;
     const double m = (double)out[(s + 1) % 3] * out[(s + 2) % 3];
+    if (setup_s) *setup_s = (double)out[s] * m * m * m * 8.0 / 21e12;
     return (double)out[s] * m * m * sizeof(float2);
 }
 
@@ -975,13 +977,23 @@ int mg3_setup(helm_op *op, int batch) {
         if (ncoarsen > 0) {
             size_t freeb = 0, totb = 0;
             hipMemGetInfo(&freeb, &totb);
-            double cap = envd("HELM_MG3_BT_MAXGB", totb / 3.0e9) * 1e9;
+            const double cap = envd("HELM_MG3_BT_MAXGB", totb / 3.0e9) * 1e9;
             const double ppwf = envd("HELM_MG3_PPWF", 6.0);
-            // ... and likewise when the call that builds the preconditioner brings few right-hand sides (<= HELM_MG3_FEW_RHS = 32) and the plane
-            // inverses of the 10-point level are large (> HELM_MG3_DEEPER_GB = 4): config 5 at 3 / 4 Hz, 16 sources: set-up 1.5 -> 0.27 s for 17 / 29
-            // iterations instead of 6 / 7 (the Galerkin operator of that level is what keeps it at that; 5 Hz would need 46 and stays)
-            if (op->mg3_rhs_hint > 0 && op->mg3_rhs_hint <= envi("HELM_MG3_FEW_RHS", 32)) cap = std::min(cap, envd("HELM_MG3_DEEPER_GB", 4.0) * 1e9);
             while (ncoarsen < 5 && keep_direct_bytes(op, ncoarsen) > cap && ppw / (double)(2 << ncoarsen) >= ppwf && (interior >> (ncoarsen + 1)) >= 3) ++ncoarsen;
+            // ... and one level deeper (down to 5 points) when that SAVES time for the right-hand sides of the call that builds the preconditioner:
+            // the set-up of the deeper level is cheaper (8 np m^3 flop of plane inversions) but every right-hand side pays more iterations --
+            // measured on config 5 with the Galerkin direct level: +11 / +22 / +38 iterations at >= 8 / 6 / 5 points per wavelength, 2.6 ms per
+            // right-hand side and iteration at 8.4 M unknowns.  16 sources: 3 and 4 Hz go deeper (1.88 -> 0.95 / 1.38 s), 5 Hz does not.
+            if (op->mg3_rhs_hint > 0 && envi("HELM_MG3_DEPTH_MODEL", 1) && ncoarsen < 5 && (interior >> (ncoarsen + 1)) >= 3) {
+                const double ppwd = ppw / (double)(2 << ncoarsen);
+                if (ppwd >= 5.0) {
+                    double t0 = 0, t1 = 0;
+                    keep_direct_bytes(op, ncoarsen, &t0); keep_direct_bytes(op, ncoarsen + 1, &t1);
+                    const double extra_its = ppwd >= 8.0 ? 11.0 : (ppwd >= 6.0 ? 22.0 : 38.0);
+                    const double per_rhs_it = 2.6e-3 * (double)op->N / 8.4e6;
+                    if (t0 - t1 > op->mg3_rhs_hint * extra_its * per_rhs_it) ++ncoarsen;
+                }
+            }
         }
         ncoarsen = envi("HELM_MG3_KEEP_LEVELS", ncoarsen);
         if (envi("HELM_MG3_KEEP", 1) && !op->mg3_no_keep && ncoarsen > 0 && op->a_cpml > 0 && omega > 0) {
