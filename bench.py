@@ -207,6 +207,8 @@ def main():
     ap.add_argument('--method', default='auto')
     ap.add_argument('--no-plain-pass', action='store_true', help='skip the extra un-profiled pass over the same work items')
     ap.add_argument('--no-cpu-2n', action='store_true', help='skip the faithful 2N x 2N Eurus LU baseline at 512^2 (~1 min, ~11 GB)')
+    ap.add_argument('--no-pipeline', dest='pipeline', action='store_false',
+                    help='work items strictly one after the other (no prepare-ahead thread, no helm_prefactor)')
     ap.add_argument('--streams', type=int, default=1, help='work items in flight per GPU (host threads, one operator handle / HIP stream each)')
     args = ap.parse_args()
 
@@ -253,18 +255,37 @@ def main():
 
     ops = {}
 
-    def run_item(w, profile, ubuf=None):
-        ubuf = d_u if ubuf is None else ubuf
+    def prepare_item(w, profile):
+        'create the operator of work item w, assemble it on the GPU (inside the timed region) and start its factorisation'
         fi, bi = work_item(w, nb)
         sc = dict(cfg)
         sc.update(freq=float(freqs[fi]), rtol=args.rtol, maxit=400000, method=args.method, batch=B, device=local)
-        op = Eurus(sc)                   # assembly on the GPU happens inside the timed region
+        op = Eurus(sc)
         op.setProfiling(profile and os.environ.get('HELM_BENCH_NOPROFILE', '0') != '1')
+        if args.pipeline:
+            op.prefactor()               # launches only: the factorisation runs beside the solves of the previous item
+        return op
+
+    def solve_item(w, op, ubuf=None):
+        ubuf = d_u if ubuf is None else ubuf
+        fi, bi = work_item(w, nb)
         rhs_ptr = d_rhs.data_ptr() + bi * B * N * 16
         info = op.solveDevice(rhs_ptr, ubuf.data_ptr(), B, N)
         t = op.lastTiming()
-        del op.factors
+        del op.factors                   # nothing is carried over between steps
         return fi, info, t
+
+    def run_item(w, profile, ubuf=None):
+        return solve_item(w, prepare_item(w, profile), ubuf)
+
+    def run_items(ws, profile):
+        """the K work items of a timed region.  Default: through the dispatcher's device pipeline (zephyr_amd.dispatch, what
+        MultiFreq's parallel mode uses): a prepare thread builds / assembles / pre-factors item k+1 while item k is being solved."""
+        if not args.pipeline:
+            return [run_item(w, profile) for w in ws]
+        from zephyr_amd import dispatch
+        items = [dispatch.WorkItem((lambda op, w=w: solve_item(w, op)), (lambda w=w: prepare_item(w, profile))) for w in ws]
+        return list(dispatch.pipelined(items, device=local, lookahead=1))
 
     def barrier():
         torch.cuda.synchronize()
@@ -272,8 +293,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        run_item(rank + world * k, False)
+    run_items([rank + world * k for k in range(args.warmup)], False)
 
     barrier()
     t0 = time.perf_counter()
@@ -283,8 +303,7 @@ def main():
     freq_used = []
     results = [None] * args.steps
     if args.streams <= 1:
-        for k in range(args.steps):
-            results[k] = run_item(rank + world * (args.warmup + k), True)
+        results = run_items([rank + world * (args.warmup + k) for k in range(args.steps)], True)
     else:
         # several work items in flight: each host thread drives its own operator handle (own HIP stream); ctypes
         # releases the GIL, so the latency-bound coarse multigrid levels of one item overlap the fine levels of another
@@ -324,8 +343,7 @@ def main():
     if args.streams <= 1 and not args.no_plain_pass:
         barrier()
         t1 = time.perf_counter()
-        for k in range(args.steps):
-            run_item(rank + world * (args.warmup + k), False)
+        run_items([rank + world * (args.warmup + k) for k in range(args.steps)], False)
         barrier()
         elapsed_plain = max_over_ranks(time.perf_counter() - t1)
 
@@ -356,6 +374,8 @@ def main():
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'timed_region': 'K work items with per-launch HIP events on (they feed `roofline`); `unprofiled` repeats the same K items with the events off',
+            'pipeline': ('device pipeline of zephyr_amd.dispatch (MultiFreq parallel mode): item k+1 is created, assembled and its factorisation enqueued '
+                         '(helm_prefactor, high-priority stream) while item k is being solved' if args.pipeline else 'off: items strictly one after the other'),
             'unprofiled': None if elapsed_plain is None else {'value': wavefields / elapsed_plain, 'ms_per_step': 1e3 * elapsed_plain / args.steps},
             'config': {'workload': 'Eurus 2D isotropic %dx%d synthetic-Marmousi (seed 20240512, dx=%g m), 16 freqs 2-9.5 Hz x 256 Kaiser sources; '
                                    'step = create + assemble 1 frequency + solve %d sources to true relres<=%g (method=%s: %s)' % (n, n, dx, B, args.rtol, args.method, how),

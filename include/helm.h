@@ -1,7 +1,10 @@
 /*
  * helm.h -- C ABI of libhelm: MI355X-native frequency-domain Helmholtz operator
- *           (assemble the 9-point PML-damped complex stencil, apply it, and solve
- *           A(w) u = q for many right-hand sides with matrix-free Krylov on the GPU).
+ *           (assemble the 9-point 2-D / 27-point 3-D PML-damped complex stencil on the GPU, apply it,
+ *           and solve A(w) u = q for many right-hand sides: in 2-D by a sparse direct factorisation
+ *           kept per frequency -- nested dissection, multifrontal, batched dense kernels -- with the
+ *           stencil kernel checking the true residual; in 3-D and as fallback by multigrid-
+ *           preconditioned / Jacobi-preconditioned BiCGSTAB and CGNR built on the same stencil kernel).
  *
  * This is the drop-in boundary for the hot path of uwoseis/zephyr's backend.  Each entry
  * point names the reference interface it replaces (paths relative to the reference tree):
@@ -15,6 +18,8 @@
  *   helm_solve[_device]            <- BaseDiscretization.__mul__          discretization.py:78-106
  *                                     (problemo.BestSolver LU + premul + conjugate),
  *                                     Eurus.__mul__ pad/clip              eurus.py:512-533
+ *   helm_prefactor                 <- the worker pool of BaseMPDist.__mul__ (distributors.py:80-96,161-168): the LU of the
+ *                                     NEXT frequency is built while the current one is being solved
  *   helm_imaging_accumulate_device <- zero-lag imaging condition in HelmBaseProblem.Jtvec
  *                                     zephyr/middleware/problem.py:152,162
  *   helm_destroy                   <- `del obj.factors` / __del__         discretization.py:86-99
@@ -143,6 +148,15 @@ int helm_solve(helm_op *op, const double *RHS, double *U, int nrhs, long long ro
 int helm_solve_device(helm_op *op, const void *dRHS, void *dU, int nrhs, long long rows,
                       double premul_re, double premul_im,
                       const helm_solve_opts *opts, helm_solve_info *info);
+
+/* Start the factorisation the next helm_solve[_device] on this handle will need, without waiting for it: the launches go to
+ * a high-priority stream of the handle and run beside whatever other handles are doing on the GPU (a dispatcher solving
+ * frequency k calls this for frequency k+1: the latency-bound top of the elimination tree then hides under the
+ * bandwidth-bound triangular solves of the previous frequency).  A hint: returns HELM_OK without doing anything where the
+ * direct path does not apply (3-D, coupled TTI) or factors already exist.  Requires helm_assemble.  The reference builds its
+ * LU lazily inside the first `Disc * rhs` (discretization.py:78-85) and overlaps frequencies with a process pool
+ * (distributors.py:161-168). */
+int helm_prefactor(helm_op *op);
 
 /* Timing of the last solve/apply on this handle, measured with HIP events on the handle's
  * stream: total ms, and ms / launches / algorithmic bytes of the stencil-apply kernel. */

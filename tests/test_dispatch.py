@@ -1,0 +1,142 @@
+"""CPU: the in-process dispatcher (zephyr_amd.dispatch) behind MultiFreq's parallel mode -- the counterpart of the
+reference's multiprocessing.Pool in BaseMPDist.__mul__ (zephyr/backend/distributors.py:127-173).  A test double stands in
+for the GPU operator: same config ingestion, arithmetic by the CPU oracle, and it records which thread / "device" ran what."""
+import os
+import threading
+import time
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import zephyr_amd as za
+from zephyr_amd import dispatch
+from oracle import helm_oracle as ho
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+LOG = []
+LOCK = threading.Lock()
+
+
+class RecordingDisc(za.MiniZephyr):
+
+    def prefactor(self):
+        with LOCK:
+            LOG.append(('prefactor', complex(self.freq).real, self.device, threading.current_thread().name))
+
+    def __mul__(self, rhs):
+        with LOCK:
+            LOG.append(('solve', complex(self.freq).real, self.device, threading.current_thread().name))
+        C = ho.minizephyr_coefficients(int(self.nz), int(self.nx), self.c, self.rho, complex(self.freq), dx=self.dx, dz=self.dz,
+                                       nPML=int(self.nPML), tau=self.tau, ky=self.ky, freeSurf=self.freeSurf)
+        if sp.issparse(rhs):
+            rhs = rhs.toarray()
+        return ho.DirectOperator(C, premul=self.premul) * rhs
+
+
+class FailingDisc(RecordingDisc):
+
+    def __mul__(self, rhs):
+        if abs(complex(self.freq).real - 6.) < 1e-12:
+            raise ArithmeticError('frequency 6 does not converge')
+        return RecordingDisc.__mul__(self, rhs)
+
+
+def config(**extra):
+    g = np.load(os.path.join(GOLD, 'g4_multifreq.npz'))
+    nz, nx = g['c'].shape
+    sc = dict(nx=nx, nz=nz, dx=10., dz=10., c=g['c'], rho=g['rho'], nPML=6, freqs=list(g['freqs']), Disc=RecordingDisc)
+    sc.update(extra)
+    return g, sc
+
+
+def test_parallel_mode_matches_serial_bit_for_bit_and_keeps_order(monkeypatch):
+    monkeypatch.setenv('HELM_DEVICES', '0,1')
+    g, sc = config(scaleTerm=0.5 - 0.25j)
+    serial = list(za.MultiFreq(dict(sc, parallel=False)) * g['q'])
+    del LOG[:]
+    mf = za.MultiFreq(sc)
+    assert mf.parallel and mf.nWorkers == 2 and mf.devices == [0, 1]
+    out = mf * g['q']
+    assert hasattr(out, '__next__')
+    par = list(out)
+    assert len(par) == len(serial) == 3
+    for a, b in zip(par, serial):
+        assert np.array_equal(a, b)                              # same arithmetic, same order of the results
+    assert np.linalg.norm(np.stack(par) - g['shared']) / np.linalg.norm(g['shared']) < 1e-10
+    # frequency-major dealing: frequencies 0 and 2 on device 0, frequency 1 on device 1; every solve was prefactored first,
+    # on the prepare thread of its device
+    freqs = list(g['freqs'])
+    assert [s.device for s in mf.subProblems] == [0, 1, 0]
+    for f, d in zip(freqs, (0, 1, 0)):
+        ev = [e for e in LOG if e[1] == f]
+        assert [e[0] for e in ev] == ['prefactor', 'solve'] and all(e[2] == d for e in ev)
+        assert ev[0][3] == 'helm-prep%d' % d and ev[1][3] == 'helm-solve%d' % d
+    # list and generator right-hand sides are consumed in order at submission, like the reference's apply_async loop
+    qlist = [g['q'] * (1 + i) for i in range(3)]
+    assert np.linalg.norm(np.stack(list(mf * qlist)) - g['list']) / np.linalg.norm(g['list']) < 1e-10
+    assert np.linalg.norm(np.stack(list(mf * (qq for qq in qlist))) - g['gen']) / np.linalg.norm(g['gen']) < 1e-10
+    del mf.factors
+
+
+def test_fewer_frequencies_than_devices_splits_the_sources(monkeypatch):
+    monkeypatch.setenv('HELM_DEVICES', '0,1,2,3')
+    g, sc = config()
+    sc['freqs'] = sc['freqs'][:2]
+    ref = list(za.MultiFreq(dict(sc, parallel=False)) * g['q'])
+    del LOG[:]
+    mf = za.MultiFreq(sc)
+    out = list(mf * g['q'])
+    assert np.allclose(np.stack(out), np.stack(ref), rtol=1e-13, atol=0)
+    solves = sorted((e[1], e[2]) for e in LOG if e[0] == 'solve')
+    f0, f1 = sc['freqs']
+    assert solves == [(f0, 0), (f0, 1), (f1, 2), (f1, 3)]        # two GPUs per frequency, each with half of the sources
+    assert mf.factors is False                                   # (doubles hold no device handle)
+    # nWorkers caps the GPUs used (reference: pool size, distributors.py:92-96)
+    mf2 = za.MultiFreq(dict(sc, nWorkers=1))
+    assert mf2.devices == [0] and mf2.nWorkers == 1
+
+
+def test_failure_surfaces_at_the_failing_frequency(monkeypatch):
+    monkeypatch.setenv('HELM_DEVICES', '0,1')
+    g, sc = config(Disc=FailingDisc)
+    sc['freqs'] = [5., 6., 7.]
+    it = za.MultiFreq(sc) * g['q']
+    assert next(it).shape == g['q'].shape
+    with pytest.raises(ArithmeticError):
+        next(it)
+
+
+def test_pipeline_overlaps_prepare_with_solve():
+    'the prepare step of item k+1 runs while item k is being solved, and never more than `lookahead` items ahead'
+    log = []
+
+    def make(k):
+        def prep():
+            log.append(('p0', k, time.perf_counter()))
+            time.sleep(0.05)
+            return k
+
+        def solve(p):
+            assert p == k
+            log.append(('s0', k, time.perf_counter()))
+            time.sleep(0.1)
+            log.append(('s1', k, time.perf_counter()))
+            return k * k
+        return dispatch.WorkItem(solve, prep)
+    t0 = time.perf_counter()
+    res = list(dispatch.pipelined([make(k) for k in range(5)], device=0, lookahead=1))
+    wall = time.perf_counter() - t0
+    assert res == [0, 1, 4, 9, 16]
+    assert wall < 5 * 0.15 - 0.1                                   # serial would take 0.75 s
+    t = dict(((a, k), v) for a, k, v in log)
+    for k in range(1, 5):
+        assert t[('p0', k)] < t[('s1', k - 1)]                     # prepared during the previous solve
+    for k in range(3, 5):
+        assert t[('p0', k)] >= t[('s0', k - 2)] - 1e-3             # but not before item k-2 has left the queue
+
+
+def test_single_device_under_a_launcher(monkeypatch):
+    monkeypatch.delenv('HELM_DEVICES', raising=False)
+    monkeypatch.setenv('LOCAL_RANK', '3')
+    assert dispatch.visible_devices() == [3]

@@ -67,6 +67,7 @@ _SIGNATURES = {
                                   ctypes.c_double, ctypes.c_double, ctypes.POINTER(SolveOpts), ctypes.POINTER(SolveInfo)]),
     'helm_solve_device': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong,
                                          ctypes.c_double, ctypes.c_double, ctypes.POINTER(SolveOpts), ctypes.POINTER(SolveInfo)]),
+    'helm_prefactor': (ctypes.c_int, [ctypes.c_void_p]),
     'helm_last_timing': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Timing)]),
     'helm_set_profiling': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'helm_imaging_accumulate_device': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,

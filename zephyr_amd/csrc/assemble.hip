@@ -305,7 +305,8 @@ int helm_launch_assemble(helm_op *op, double freq_re, double freq_im, double tau
         mz_profiles(nz, op->nPML, op->dz, op->fs[0], op->fs[2], distz, sgnz);
         double *d_prof = nullptr;
         const size_t bytes = sizeof(double) * (2 * (size_t)nx + 2 * (size_t)nz);
-        HIP_TRY(op, hipMalloc(&d_prof, bytes));
+        d_prof = (double *)helm_pool_alloc(op->device, bytes);          // (pool: hipMalloc / hipFree per assembly would wait for every stream of the device)
+        if (!d_prof) HELM_FAIL(op, HELM_ERR_DEVICE, "hipMalloc of the PML profiles failed");
         std::vector<double> h(2 * (size_t)nx + 2 * (size_t)nz);
         std::copy(distx.begin(), distx.end(), h.begin());
         std::copy(sgnx.begin(), sgnx.end(), h.begin() + nx);
@@ -322,7 +323,7 @@ int helm_launch_assemble(helm_op *op, double freq_re, double freq_im, double tau
                            d_prof, d_prof + nx, d_prof + 2 * nx, d_prof + 2 * nx + nz, op->d_C);
         HIP_TRY(op, hipGetLastError());
         HIP_TRY(op, hipStreamSynchronize(op->stream));
-        HIP_TRY(op, hipFree(d_prof));
+        helm_pool_free(op->device, d_prof, bytes);
         op->block_zero[0] = false;
     } else {
         if (op->nPML < 2) HELM_FAIL(op, HELM_ERR_ARG, "nPML must be >= 2");
@@ -350,7 +351,8 @@ int helm_launch_assemble(helm_op *op, double freq_re, double freq_im, double tau
             HELM_FAIL(op, HELM_ERR_PML, "np.arange(0, L+h, h) length != nPML for this dx/dz/nPML (reference raises ValueError, eurus.py:84-91)");
         cplx *d_xi = nullptr;
         const size_t bytes = sizeof(cplx) * ((size_t)nx + nz + 4);
-        HIP_TRY(op, hipMalloc(&d_xi, bytes));
+        d_xi = (cplx *)helm_pool_alloc(op->device, bytes);
+        if (!d_xi) HELM_FAIL(op, HELM_ERR_DEVICE, "hipMalloc of the PML profiles failed");
         std::vector<cplx> h(xix);
         h.insert(h.end(), xiz.begin(), xiz.end());
         HIP_TRY(op, hipMemcpyAsync(d_xi, h.data(), bytes, hipMemcpyHostToDevice, op->stream));
@@ -361,7 +363,7 @@ int helm_launch_assemble(helm_op *op, double freq_re, double freq_im, double tau
                            op->d_theta, op->d_eps, op->d_delta, d_xi, d_xi + nx + 2, op->d_C);
         HIP_TRY(op, hipGetLastError());
         HIP_TRY(op, hipStreamSynchronize(op->stream));
-        HIP_TRY(op, hipFree(d_xi));
+        helm_pool_free(op->device, d_xi, bytes);
     }
     return HELM_OK;
 }

@@ -63,7 +63,52 @@ int helm_events_grow(helm_op *op, int n) {
     }
     return 0;
 }
-static const size_t kPoolMinBytes = (size_t)1 << 20, kPoolCapBytes = (size_t)64 << 30;
+// (small buffers too: hipFree waits for every stream of the device, which would stall a host thread that prepares the next operator
+// while another one is solving -- the per-operator scratch of a few KB goes through the pool like the GB-sized buffers)
+static const size_t kPoolMinBytes = (size_t)64, kPoolCapBytes = (size_t)64 << 30;
+
+// pinned host buffers (per-handle scalar records) and HIP streams are recycled the same way: a job creates one operator per frequency
+struct HostPool { std::mutex mu; std::multimap<size_t, void *> idle; };
+static HostPool g_hostpool;
+void *helm_hostpool_alloc(size_t bytes) {
+    {
+        std::lock_guard<std::mutex> lk(g_hostpool.mu);
+        auto it = g_hostpool.idle.find(bytes);
+        if (it != g_hostpool.idle.end()) { void *p = it->second; g_hostpool.idle.erase(it); return p; }
+    }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void helm_hostpool_free(void *p, size_t bytes) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_hostpool.mu);
+    if (g_hostpool.idle.size() < 256) { g_hostpool.idle.insert(std::make_pair(bytes, p)); return; }
+    hipHostFree(p);
+}
+struct StreamPool { std::mutex mu; std::multimap<std::pair<int, int>, hipStream_t> idle; };     // (device, priority class) -> idle streams
+static StreamPool g_streams;
+// prio: 0 normal, 1 highest, -1 lowest priority the device offers; the stream comes back idle (synchronised by helm_stream_release)
+hipStream_t helm_stream_acquire(int device, int prio) {
+    {
+        std::lock_guard<std::mutex> lk(g_streams.mu);
+        auto it = g_streams.idle.find(std::make_pair(device, prio));
+        if (it != g_streams.idle.end()) { hipStream_t s = it->second; g_streams.idle.erase(it); return s; }
+    }
+    hipStream_t s = nullptr;
+    if (prio == 0) { if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr; return s; }
+    int plo = 0, phi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio > 0 ? phi : plo) != hipSuccess) return nullptr;
+    return s;
+}
+void helm_stream_release(int device, int prio, hipStream_t s) {
+    if (!s) return;
+    hipStreamSynchronize(s);
+    std::lock_guard<std::mutex> lk(g_streams.mu);
+    if (g_streams.idle.size() < 64) { g_streams.idle.insert(std::make_pair(std::make_pair(device, prio), s)); return; }
+    hipStreamDestroy(s);
+}
 
 void *helm_pool_alloc(int device, size_t bytes) {
     {
@@ -124,7 +169,8 @@ static helm_op *create_common(helm_op *op) {
     const int device = op->device;
     { std::lock_guard<std::mutex> lk(g_shared_ws.mu); g_live_handles += 1; }      // helm_destroy takes it back on every exit
     HIP_TRY_NULL(hipSetDevice(device));
-    HIP_TRY_NULL(hipStreamCreateWithFlags(&op->stream, hipStreamNonBlocking));
+    op->stream = helm_stream_acquire(device, 0);
+    if (!op->stream) { helm_destroy(op); helm_set_error(nullptr, "hipStreamCreate failed"); return nullptr; }
     op->own_stream = true;
     const size_t N = (size_t)op->N;
     op->Nv = op->N;
@@ -140,6 +186,7 @@ static helm_op *create_common(helm_op *op) {
 extern "C" void helm_destroy(helm_op *op) {
     if (!op) return;
     hipSetDevice(op->device);
+    helm_pf_retire(op);
     if (op->stream) hipStreamSynchronize(op->stream);
     helm_pool_free(op->device, op->d_c, (size_t)op->N * sizeof(cplx)); helm_pool_free(op->device, op->d_rho, (size_t)op->N * sizeof(double));
     hipFree(op->d_theta); hipFree(op->d_eps); hipFree(op->d_delta);
@@ -151,15 +198,20 @@ extern "C" void helm_destroy(helm_op *op) {
     hipFree(op->d_S); hipFree(op->d_rs);
     if (op->mg || op->mg3) mg_destroy(op);
     for (int b = 0; b < 4; ++b) { nd_free(op->direct[b]); op->direct[b] = nullptr; }
-    helm_pool_free(op->device, op->d_ws, op->ws_bytes); hipFree(op->d_part); hipFree(op->d_scal);
-    if (op->h_scal) hipHostFree(op->h_scal);
+    helm_pool_free(op->device, op->d_ws, op->ws_bytes); helm_pool_free(op->device, op->d_part, op->part_bytes);
+    helm_pool_free(op->device, op->d_scal, (size_t)op->scal_cap * sizeof(RhsScal));
+    helm_hostpool_free(op->h_scal, op->h_scal_bytes);
+    if (op->pf_done) hipEventDestroy(op->pf_done);
+    if (op->pf_t0) hipEventDestroy(op->pf_t0);
+    if (op->pf_t1) hipEventDestroy(op->pf_t1);
+    if (op->fstream) helm_stream_release(op->device, 1, op->fstream);
     {   // timing events go back to the process-wide free list
         std::lock_guard<std::mutex> lk(g_pool.mu);
         std::vector<hipEvent_t> &idle = g_idle_events[op->device];
         for (hipEvent_t e : op->ev_pool) { if (idle.size() < 65536) idle.push_back(e); else hipEventDestroy(e); }
     }
-    if (op->side_stream) hipStreamDestroy(op->side_stream);
-    if (op->own_stream && op->stream) hipStreamDestroy(op->stream);
+    if (op->side_stream) helm_stream_release(op->device, -1, op->side_stream);
+    if (op->own_stream && op->stream) helm_stream_release(op->device, 0, op->stream);
     delete op;
     std::lock_guard<std::mutex> lk(g_shared_ws.mu);
     g_live_handles -= 1;
@@ -184,13 +236,14 @@ extern "C" int helm_trim(void) {
 extern "C" int helm_set_stream(helm_op *op, void *hip_stream) {
     if (!op) return HELM_ERR_ARG;
     HIP_TRY(op, hipSetDevice(op->device));
+    helm_pf_retire(op);
     if (op->stream) HIP_TRY(op, hipStreamSynchronize(op->stream));
     // the multigrid level operators launch on the stream they were given at setup (mg.hip assemble_child): they are rebuilt on
     // the new stream by the next solve that needs them
     if (op->mg || op->mg3) mg_destroy(op);
-    if (op->own_stream && op->stream) { hipStreamDestroy(op->stream); op->own_stream = false; }
+    if (op->own_stream && op->stream) { helm_stream_release(op->device, 0, op->stream); op->own_stream = false; }
     if (hip_stream) { op->stream = (hipStream_t)hip_stream; op->own_stream = false; }
-    else { HIP_TRY(op, hipStreamCreateWithFlags(&op->stream, hipStreamNonBlocking)); op->own_stream = true; }
+    else { op->stream = helm_stream_acquire(op->device, 0); if (!op->stream) HELM_FAIL(op, HELM_ERR_DEVICE, "hipStreamCreate failed"); op->own_stream = true; }
     return HELM_OK;
 }
 
@@ -258,6 +311,7 @@ extern "C" int helm_assemble(helm_op *op, double freq_re, double freq_im, double
     if (!op) return HELM_ERR_ARG;
     if (!op->has_model) HELM_FAIL(op, HELM_ERR_STATE, "helm_set_model must be called before helm_assemble");
     HIP_TRY(op, hipSetDevice(op->device));
+    helm_pf_retire(op);                          // a factorisation still in flight belongs to the operator that is being replaced
     int rc = op->ny > 0 ? helm3d_launch_assemble(op, freq_re, freq_im, tau, cPML) : helm_launch_assemble(op, freq_re, freq_im, tau, ky, cPML);
     if (rc) return rc;
     op->scaled_ok = false;
@@ -306,25 +360,32 @@ static int ensure_part(helm_op *op, int nrhs) {
     const int nblk = std::max(2 * helm_apply_num_blocks(op), helm_vec_num_blocks(op));
     const size_t bytes = (size_t)nrhs * 4 * nblk * sizeof(double) + (size_t)nrhs * (2 * sizeof(double) + sizeof(int)) + 256;
     if (op->part_bytes < bytes) {
-        if (op->d_part) { hipFree(op->d_part); op->d_part = nullptr; op->part_bytes = 0; }
-        HIP_TRY(op, hipMalloc(&op->d_part, bytes));
+        if (op->d_part) { hipStreamSynchronize(op->stream); helm_pool_free(op->device, op->d_part, op->part_bytes); op->d_part = nullptr; op->part_bytes = 0; }
+        op->d_part = helm_pool_alloc(op->device, bytes);
+        if (!op->d_part) HELM_FAIL(op, HELM_ERR_DEVICE, "hipMalloc of the partial-sum buffer failed");
         op->part_bytes = bytes;
     }
     if (op->scal_cap < nrhs) {
-        if (op->d_scal) hipFree(op->d_scal);
-        if (op->h_scal) hipHostFree(op->h_scal);
-        op->d_scal = nullptr; op->h_scal = nullptr; op->scal_cap = 0;
-        HIP_TRY(op, hipMalloc(&op->d_scal, (size_t)nrhs * sizeof(RhsScal)));
-        HIP_TRY(op, hipHostMalloc((void **)&op->h_scal, (size_t)nrhs * sizeof(RhsScal) + (size_t)nrhs * (2 * sizeof(double) + sizeof(int)) + 64, hipHostMallocDefault));
+        if (op->d_scal || op->h_scal) hipStreamSynchronize(op->stream);
+        helm_pool_free(op->device, op->d_scal, (size_t)op->scal_cap * sizeof(RhsScal));
+        helm_hostpool_free(op->h_scal, op->h_scal_bytes);
+        op->d_scal = nullptr; op->h_scal = nullptr; op->scal_cap = 0; op->h_scal_bytes = 0;
+        op->d_scal = (RhsScal *)helm_pool_alloc(op->device, (size_t)nrhs * sizeof(RhsScal));
+        const size_t hb = (size_t)nrhs * sizeof(RhsScal) + (size_t)nrhs * (2 * sizeof(double) + sizeof(int)) + 64;
+        op->h_scal = (RhsScal *)helm_hostpool_alloc(hb);
+        if (!op->d_scal || !op->h_scal) HELM_FAIL(op, HELM_ERR_DEVICE, "allocation of the per-right-hand-side records failed");
+        op->h_scal_bytes = hb;
         op->scal_cap = nrhs;
     }
     return HELM_OK;
 }
 
 static void timing_begin(helm_op *op) {
-    op->ev_used = 0;
-    op->ev_pending.clear();
-    op->ev_pending_gemm.clear(); op->ev_pending_gemm_n.clear();
+    if (!op->pf_pending) {       // (the launches of a factorisation started by helm_prefactor are booked with the solve that uses it)
+        op->ev_used = 0;
+        op->ev_pending.clear();
+        op->ev_pending_gemm.clear(); op->ev_pending_gemm_n.clear();
+    }
     op->timing.apply_ms = 0; op->timing.apply_launches = 0; op->timing.apply_bytes = 0;
     op->timing.factor_ms = 0; op->timing.gemm_ms = 0; op->timing.gemm_launches = 0; op->timing.gemm_flops = 0;
     op->timing.gemm_big_ms = 0; op->timing.gemm_big_launches = 0; op->timing.gemm_big_flops = 0;
@@ -645,6 +706,8 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
     int rc;
     NdFactor *f = op->direct[slot];
     const bool need_factor = (f == nullptr);
+    // factors enqueued by helm_prefactor on the handle's factor stream: everything this call launches comes after them
+    if (op->pf_pending && f && op->pf_done) HIP_TRY(op, hipStreamWaitEvent(op->stream, op->pf_done, 0));
     {   // fault injection for the tests of the AUTO fallback
         const char *inj = getenv("HELM_ND_INJECT_FAILURE");
         if (inj && atoi(inj) != 0) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: injected failure (HELM_ND_INJECT_FAILURE)");
@@ -705,9 +768,8 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
     }
     if (factor_pending && !op->side_stream) {
         // lowest priority: the forward pass that runs beside the factorisation must not delay the factorisation's chain of small launches
-        int plo = 0, phi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
-        if (hipStreamCreateWithPriority(&op->side_stream, hipStreamNonBlocking, plo) != hipSuccess) HELM_FAIL(op, HELM_ERR_DEVICE, "hipStreamCreate failed");
+        op->side_stream = helm_stream_acquire(op->device, -1);
+        if (!op->side_stream) HELM_FAIL(op, HELM_ERR_DEVICE, "hipStreamCreate failed");
     }
     rc = ensure_part(op, Bmax);
     if (rc) return rc;
@@ -1258,6 +1320,55 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
 
 }  // namespace
 
+// A factorisation started by helm_prefactor is complete (or abandoned): wait for it, book its time, give its scratch back.
+void helm_pf_retire(helm_op *op) {
+    if (!op || !op->pf_pending) return;
+    hipSetDevice(op->device);
+    if (op->pf_done) hipEventSynchronize(op->pf_done);
+    float ms = 0.f;
+    if (op->pf_t0 && op->pf_t1 && hipEventElapsedTime(&ms, op->pf_t0, op->pf_t1) == hipSuccess) op->timing.factor_ms += ms;
+    helm_pool_free(op->device, op->pf_ws, op->pf_ws_bytes);
+    op->pf_ws = nullptr; op->pf_ws_bytes = 0;
+    op->pf_pending = false;
+}
+
+extern "C" int helm_prefactor(helm_op *op) {
+    if (!op) return HELM_ERR_ARG;
+    if (!op->assembled) HELM_FAIL(op, HELM_ERR_STATE, "operator not assembled");
+    // a hint: only the single-block 2-D systems the direct path of HELM_AUTO / HELM_DIRECT factors once per frequency
+    if (op->ny > 0 || op->direct_failed || op->direct[0] || op->pf_pending) return HELM_OK;
+    if (op->variant == HELM_EURUS && !op->block_zero[2]) return HELM_OK;          // coupled TTI: row-equilibrated inside the solve
+    { const char *e = getenv("HELM_AUTO_DIRECT"); if (e && atoi(e) == 0) return HELM_OK; }
+    { const char *e = getenv("HELM_ND_INJECT_FAILURE"); if (e && atoi(e) != 0) return HELM_OK; }
+    HIP_TRY(op, hipSetDevice(op->device));
+    if (!op->fstream) {
+        op->fstream = helm_stream_acquire(op->device, 1);
+        if (!op->fstream) HELM_FAIL(op, HELM_ERR_DEVICE, "hipStreamCreate failed");
+    }
+    if (!op->pf_done) HIP_TRY(op, hipEventCreateWithFlags(&op->pf_done, hipEventDisableTiming));
+    if (!op->pf_t0) HIP_TRY(op, hipEventCreate(&op->pf_t0));
+    if (!op->pf_t1) HIP_TRY(op, hipEventCreate(&op->pf_t1));
+    NdFactor *f = new NdFactor();
+    const char *e = getenv("HELM_ND_LEAF");
+    int rc = nd_get_plan(op, e ? std::max(2, atoi(e)) : 8, 1, &f->pd);
+    if (rc) { nd_free(f); return rc; }
+    const size_t wsb = (size_t)nd_factor_ws_elems(f->pd->plan) * sizeof(cplx);
+    void *ws = helm_pool_alloc(op->device, wsb);
+    if (!ws) { nd_free(f); HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: cannot allocate %.1f GB of factorisation scratch", wsb / 1e9); }
+    { op->ev_used = 0; op->ev_pending.clear(); op->ev_pending_gemm.clear(); op->ev_pending_gemm_n.clear(); }
+    hipStream_t main = op->stream;
+    op->stream = op->fstream;                    // (the assembled planes are complete: helm_assemble synchronises)
+    hipEventRecord(op->pf_t0, op->fstream);
+    rc = nd_factor_enqueue(op, 0, f, (cplx *)ws, nullptr);
+    hipEventRecord(op->pf_t1, op->fstream);
+    hipEventRecord(op->pf_done, op->fstream);
+    op->stream = main;
+    if (rc) { hipStreamSynchronize(op->fstream); helm_pool_free(op->device, ws, wsb); nd_free(f); return rc; }
+    op->direct[0] = f;
+    op->pf_ws = ws; op->pf_ws_bytes = wsb; op->pf_pending = true;
+    return HELM_OK;
+}
+
 extern "C" int helm_solve_device(helm_op *op, const void *dRHS, void *dU, int nrhs, long long rows,
                                  double premul_re, double premul_im, const helm_solve_opts *opts, helm_solve_info *info) {
     if (!op || !dRHS || !dU || nrhs < 1) return HELM_ERR_ARG;
@@ -1339,6 +1450,7 @@ extern "C" int helm_solve_device(helm_op *op, const void *dRHS, void *dU, int nr
     float ms = 0.f;
     hipEventElapsedTime(&ms, e0, e1);
     op->timing.solve_ms = ms;
+    helm_pf_retire(op);
     timing_collect(op);
     cleanup();
     return result;

@@ -1791,6 +1791,19 @@ int nd_factor(helm_op *op, int block, NdFactor *f, cplx *ws, const cplx *planes_
     return check_kernels(op, "factorisation kernels");
 }
 
+// Launches of the factorisation on op->stream without waiting for them (helm_prefactor): the caller orders later work behind an event
+int nd_factor_enqueue(helm_op *op, int block, NdFactor *f, cplx *ws, const cplx *planes_in) {
+    const NdPlan &P = f->pd->plan;
+    const cplx *planes = nullptr;
+    int rc = factor_prologue(op, block, f, planes_in, &planes);
+    if (rc) return rc;
+    for (size_t gi = 0; gi < P.groups.size(); ++gi) {
+        rc = factor_group(op, f, gi, ws, ws + 2 * P.fregion, planes);
+        if (rc) return rc;
+    }
+    return check_kernels(op, "factorisation kernels");
+}
+
 // ---- solve: Xin (nrhs x N, each right-hand side contiguous) -> Xout (may alias Xin) --------------------------------------
 // ws: workspace of nd_solve_ws_elems(plan, nrhs) elements
 long long nd_solve_ws_elems(const NdPlan &P, int nrhs) { return ((long long)P.dof * P.nz * P.nx + 2 * P.vregion) * nrhs; }

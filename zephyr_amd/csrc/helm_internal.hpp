@@ -99,6 +99,12 @@ struct helm_op {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t side_stream = nullptr;    // second stream of the direct path (forward elimination behind the factorisation), on demand
+    // helm_prefactor: the factorisation of the assembled operator enqueued on a high-priority stream of its own, so that it runs beside
+    // the solves of ANOTHER handle (the previous frequency of a job); the next solve on this handle waits for pf_done on the device
+    hipStream_t fstream = nullptr;
+    bool pf_pending = false;
+    hipEvent_t pf_done = nullptr, pf_t0 = nullptr, pf_t1 = nullptr;
+    void *pf_ws = nullptr; size_t pf_ws_bytes = 0;
 
     // model
     cplx *d_c = nullptr;
@@ -134,7 +140,7 @@ struct helm_op {
     // solver workspace (grown on demand)
     void *d_ws = nullptr; size_t ws_bytes = 0;
     void *d_part = nullptr; size_t part_bytes = 0;     // partial sums of the fused dot products
-    RhsScal *d_scal = nullptr; RhsScal *h_scal = nullptr; int scal_cap = 0;
+    RhsScal *d_scal = nullptr; RhsScal *h_scal = nullptr; int scal_cap = 0; size_t h_scal_bytes = 0;
 
     // timing / profiling
     bool profiling = false;
@@ -162,6 +168,11 @@ void helm_set_error(helm_op *op, const char *msg);
 // operators of identical shape, and hipMalloc/hipFree of GB-sized buffers cost milliseconds each.  helm_trim() empties it.
 void *helm_pool_alloc(int device, size_t bytes);          // nullptr on failure
 void helm_pool_free(int device, void *p, size_t bytes);   // the buffer must no longer be in use by any stream
+void *helm_hostpool_alloc(size_t bytes);                  // pinned host memory, recycled by size
+void helm_hostpool_free(void *p, size_t bytes);
+hipStream_t helm_stream_acquire(int device, int prio);    // prio 0 normal, 1 highest, -1 lowest; recycled across handles
+void helm_stream_release(int device, int prio, hipStream_t s);
+void helm_pf_retire(helm_op *op);                         // wait for / book / clean up a factorisation started by helm_prefactor
 int helm_ensure_scaled(helm_op *op);
 int helm_events_grow(helm_op *op, int n);                 // n more timing events for the handle (recycled across handles)                      // d_Cs, d_dinv for the operator currently assembled
 

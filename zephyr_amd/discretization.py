@@ -2,8 +2,9 @@
 
 Interface of zephyr/backend/discretization.py:18-169: an object built from a `systemConfig`
 dict that supports `obj * rhs` -> conj(A^-1 (premul * rhs)).  The sparse LU behind the
-reference's `Ainv` (external problemo.BestSolver, discretization.py:78-85) is replaced by the
-matrix-free Krylov solve of libhelm on the MI355X; assembly also happens on the device.
+reference's `Ainv` (external problemo.BestSolver, discretization.py:78-85) is replaced by libhelm on
+the MI355X: assembly on the device, a sparse direct factorisation kept per assembled operator in 2-D
+(Krylov methods in 3-D and as fallback), the stencil kernel checking the true residual.
 """
 import copy
 import ctypes
@@ -134,6 +135,14 @@ class BaseDiscretization(BaseModelDependent):
     @property
     def Ainv(self):
         return self.handle
+
+    def prefactor(self):
+        """Start the factorisation the next solve on this operator needs and return at once (helm_prefactor): the launches go
+        to a high-priority stream of the handle and run beside the solves of other operators.  The reference builds its LU
+        lazily inside the first `Disc * rhs` (discretization.py:78-85); its dispatcher overlaps frequencies with a process
+        pool (distributors.py:161-168) -- `zephyr_amd.dispatch` does it with this call."""
+        if str(self.method).lower() in ('auto', 'direct'):
+            _lib.check(_lib.load().helm_prefactor(self.handle), self.handle)
 
     @Ainv.deleter
     def Ainv(self):

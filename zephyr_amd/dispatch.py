@@ -1,0 +1,139 @@
+"""In-process dispatch of independent work items (frequencies, source batches) over the GPUs of a node.
+
+The reference's `BaseMPDist.__mul__` hands one sub-problem per frequency to a `multiprocessing.Pool`
+(zephyr/backend/distributors.py:80-96,161-168) and yields the results in submission order.  The GPU
+counterpart keeps everything in one process:
+
+  * one SOLVE thread per device works through that device's items in order (ctypes releases the GIL
+    inside libhelm, so the threads of different devices run concurrently);
+  * one PREPARE thread per device stays `lookahead` items ahead of it: it builds the next operator
+    (model upload, assembly on the GPU) and starts its factorisation with `helm_prefactor`, which only
+    enqueues launches on a high-priority stream -- the latency-bound top of the elimination tree of
+    frequency k+1 then runs underneath the bandwidth-bound triangular solves of frequency k;
+  * results come back as futures, consumed in submission order by the caller's generator.
+
+Nothing here touches device memory itself; an item is two callables supplied by the caller.
+"""
+import os
+import queue
+import threading
+from concurrent.futures import Future
+
+
+def visible_devices():
+    """Devices an in-process dispatcher may use.  `HELM_DEVICES=0,2,3` restricts the list; under a
+    one-process-per-GPU launcher (torch.distributed initialised, or LOCAL_RANK set) a process keeps to its own GPU."""
+    from . import _lib
+    from .discretization import default_device
+    env = os.environ.get('HELM_DEVICES')
+    if env:
+        return [int(t) for t in env.replace(' ', '').split(',') if t != '']
+    from . import parallel
+    if parallel.rank_and_size()[1] > 1 or 'LOCAL_RANK' in os.environ or 'HELM_DEVICE' in os.environ:
+        return [default_device()]
+    n = _lib.load().helm_device_count()
+    return list(range(max(1, n)))
+
+
+class WorkItem(object):
+    """prepare() runs on the device's prepare thread (may be None), solve(prepared) on its solve thread;
+    `future` receives solve's return value or the first exception of either step."""
+
+    __slots__ = ('prepare', 'solve', 'future', '_prepared', '_error')
+
+    def __init__(self, solve, prepare=None):
+        self.prepare = prepare
+        self.solve = solve
+        self.future = Future()
+        self._prepared = None
+        self._error = None
+
+
+class DevicePipeline(object):
+    """Two threads for one GPU: items are prepared up to `lookahead` ahead of the one being solved."""
+
+    def __init__(self, device, lookahead=1):
+        self.device = device
+        self.lookahead = max(0, int(lookahead))
+        self._threads = []
+
+    def start(self, items):
+        items = list(items)
+        if not items:
+            return
+        if self.lookahead == 0:
+            t = threading.Thread(target=self._serial, args=(items,), name='helm-dev%d' % self.device)
+            t.daemon = True
+            t.start()
+            self._threads = [t]
+            return
+        ready = queue.Queue(maxsize=self.lookahead)
+        tp = threading.Thread(target=self._prepare_loop, args=(items, ready), name='helm-prep%d' % self.device)
+        ts = threading.Thread(target=self._solve_loop, args=(len(items), ready), name='helm-solve%d' % self.device)
+        for t in (tp, ts):
+            t.daemon = True
+            t.start()
+        self._threads = [tp, ts]
+
+    def join(self):
+        for t in self._threads:
+            t.join()
+        self._threads = []
+
+    @staticmethod
+    def _run_prepare(item):
+        if item.prepare is not None:
+            try:
+                item._prepared = item.prepare()
+            except BaseException as exc:       # delivered through the future by the solve thread
+                item._error = exc
+
+    @staticmethod
+    def _run_solve(item):
+        if not item.future.set_running_or_notify_cancel():
+            return
+        if item._error is not None:
+            item.future.set_exception(item._error)
+            return
+        try:
+            item.future.set_result(item.solve(item._prepared))
+        except BaseException as exc:
+            item.future.set_exception(exc)
+
+    def _serial(self, items):
+        for item in items:
+            self._run_prepare(item)
+            self._run_solve(item)
+
+    def _prepare_loop(self, items, ready):
+        for item in items:
+            self._run_prepare(item)
+            ready.put(item)             # blocks while `lookahead` prepared items are waiting
+
+    def _solve_loop(self, n, ready):
+        for _ in range(n):
+            self._run_solve(ready.get())
+
+
+def dispatch(items_by_device, lookahead=1):
+    """Start one DevicePipeline per device.  items_by_device: {device: [WorkItem, ...]} (each list in the order it
+    should run).  Returns the pipelines (join() them, or just wait on the items' futures)."""
+    pipes = []
+    for dev, items in items_by_device.items():
+        p = DevicePipeline(dev, lookahead)
+        p.start(items)
+        pipes.append(p)
+    return pipes
+
+
+def pipelined(items, device=0, lookahead=1):
+    """Run `items` on one device with prepare-ahead and yield their results in order (exceptions surface where the
+    failing item's result is consumed)."""
+    items = list(items)
+    pipe = DevicePipeline(device, lookahead)
+    pipe.start(items)
+    try:
+        for item in items:
+            yield item.future.result()
+    finally:
+        pipe.join()

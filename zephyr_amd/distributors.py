@@ -1,17 +1,22 @@
 """Frequency dispatchers (interface of zephyr/backend/distributors.py:26-381).
 
 The reference farms one sub-problem per frequency out to a multiprocessing.Pool
-(distributors.py:127-173).  Here every sub-problem owns a device operator on this process's
-GPU and frequencies are solved back to back on it; across GPUs the frequencies (and source
-batches) are sharded over ranks, one process per GPU (`zephyr_amd.parallel`), with no
-data-path collective.  The result contract is unchanged: an iterable, in `freqs` order, of
-`scaleTerm * (sub * rhs_i)` arrays of shape (N, nrhs).
+(distributors.py:127-173).  Here every sub-problem owns a device operator; with `parallel` (the
+default) the frequencies are dealt over the GPUs this process can see, one solve thread and one
+prepare-ahead thread per GPU (`zephyr_amd.dispatch`: the factorisation of the next frequency is
+started while the current one is being solved), and when there are fewer frequencies than GPUs the
+sources of a frequency are split over the spare ones.  Under a one-process-per-GPU launcher
+(`zephyr_amd.parallel`) a process keeps to its own GPU.  No data-path collective either way.  The
+result contract is unchanged: an iterable, in `freqs` order, of `scaleTerm * (sub * rhs_i)` arrays
+of shape (N, nrhs).
 """
 import types
 import numpy as np
+import scipy.sparse as sp
 
 from .base import BaseModelDependent
 from .discretization import DiscretizationWrapper
+from . import dispatch
 
 
 class BaseDist(DiscretizationWrapper):
@@ -46,9 +51,11 @@ class BaseDist(DiscretizationWrapper):
 
 
 class BaseMPDist(BaseDist):
-    """Per-frequency dispatch (distributors.py:70-193).  `parallel`/`nWorkers` are accepted for
-    compatibility; concurrency comes from the GPU batch (all sources of a frequency iterate
-    together) and from rank-level sharding, not from a process pool."""
+    """Per-frequency dispatch (distributors.py:70-193).
+
+    `parallel` (default True): work items (frequency, source batch) are dealt frequency-major over the visible GPUs and run
+    by `zephyr_amd.dispatch` -- the counterpart of the reference's `multiprocessing.Pool`; `nWorkers` caps the number of
+    GPUs used (reference: pool size).  `parallel=False`: frequencies back to back on the default device."""
 
     maskKeys = {'parallel'}
 
@@ -57,8 +64,43 @@ class BaseMPDist(BaseDist):
         return bool(getattr(self, '_parallel', True))
 
     @property
+    def devices(self):
+        'GPUs of the parallel mode (HELM_DEVICES / all visible ones; a single one under a per-GPU launcher), at most nWorkers of them'
+        if not self.parallel:
+            return [self.systemConfig['device']] if 'device' in self.systemConfig else dispatch.visible_devices()[:1]
+        if 'device' in self.systemConfig:                      # the caller pinned the operators to one GPU
+            return [int(self.systemConfig['device'])]
+        devs = dispatch.visible_devices()
+        cap = int(getattr(self, '_nWorkers', len(devs)))
+        return devs[:max(1, cap)]
+
+    @property
     def nWorkers(self):
-        return 1
+        return len(self.devices)
+
+    @property
+    def subProblems(self):
+        'sub-problem i lives on device i mod (number of devices): a GPU keeps the operators (and factors) of its frequencies'
+        if getattr(self, '_subProblems', None) is None:
+            devs = self.devices
+            subs = []
+            for i, cfg in enumerate(self._spConfigs):
+                if self.parallel and 'device' not in cfg:
+                    cfg['device'] = devs[i % len(devs)]
+                subs.append(self.Disc(cfg))
+            self._subProblems = subs
+            self._replicas = {}
+        return self._subProblems
+
+    def _replica(self, i, r, device):
+        'copy r >= 1 of sub-problem i on another GPU (fewer frequencies than GPUs: its sources are split)'
+        key = (i, r)
+        reps = self.__dict__.setdefault('_replicas', {})
+        if key not in reps:
+            cfg = list(self._spConfigs)[i]
+            cfg['device'] = device
+            reps[key] = self.Disc(cfg)
+        return reps[key]
 
     @staticmethod
     def _rhs_getter(rhs):
@@ -77,9 +119,65 @@ class BaseMPDist(BaseDist):
                 return shared
         return get
 
+    @staticmethod
+    def _item(sub, r):
+        prep = None
+        if hasattr(sub, 'prefactor'):
+            def prep():
+                sub.prefactor()           # builds the handle (assembly on the GPU) and enqueues the factorisation
+        return dispatch.WorkItem(lambda _prepared: sub * r, prep)
+
     def __mul__(self, rhs):
         get = self._rhs_getter(rhs)
-        return (self.scaleTerm * (sub * get(i)) for i, sub in enumerate(self.subProblems))
+        subs = self.subProblems
+        if not self.parallel:
+            return (self.scaleTerm * (sub * get(i)) for i, sub in enumerate(subs))
+        # every right-hand side is taken now, in order, like the reference's apply_async loop (distributors.py:161-166)
+        devs = self.devices
+        split = max(1, len(devs) // max(1, len(subs)))           # GPUs per frequency when there are spare ones
+        queues = dict((d, []) for d in devs)
+        parts = []
+        for i, sub in enumerate(subs):
+            r = get(i)
+            ncol = r.shape[1] if getattr(r, 'ndim', 1) > 1 else 1
+            k = min(split, ncol) if hasattr(sub, 'prefactor') else 1
+            if k <= 1:
+                it = self._item(sub, r)
+                queues[devs[i % len(devs)]].append(it)
+                parts.append([it])
+                continue
+            rc = r.tocsc() if sp.issparse(r) else r
+            bounds = [ncol * j // k for j in range(k + 1)]
+            row = []
+            for j in range(k):
+                dev = devs[(i * k + j) % len(devs)]
+                owner = sub if dev == getattr(sub, 'device', None) else self._replica(i, j + 1, dev)
+                it = self._item(owner, rc[:, bounds[j]:bounds[j + 1]])
+                queues[dev].append(it)
+                row.append(it)
+            parts.append(row)
+        self._pipes = dispatch.dispatch(queues, lookahead=1)
+
+        def results():
+            for row in parts:
+                cols = [it.future.result() for it in row]
+                yield self.scaleTerm * (cols[0] if len(cols) == 1 else np.hstack(cols))
+        return results()
+
+    @property
+    def factors(self):
+        if DiscretizationWrapper.factors.fget(self):
+            return True
+        return any(rep.factors for rep in self.__dict__.get('_replicas', {}).values())
+
+    @factors.deleter
+    def factors(self):
+        for p in self.__dict__.get('_pipes', []):
+            p.join()
+        self._pipes = []
+        DiscretizationWrapper.factors.fdel(self)
+        for rep in self.__dict__.get('_replicas', {}).values():
+            del rep.factors
 
     def __del__(self):
         try:
