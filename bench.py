@@ -166,6 +166,78 @@ def cpu_baseline_pool(cfg, freqs, nproc=16, nsolve=4):
                        % (len(jobs), cfg['nx'], len(jobs), setup, per_rhs, nsolve, wall))
 
 
+def config5_leg(local, rtol=1e-8, nsrc=16, freqs=(2., 3., 4., 5.), grid=(128, 256, 256)):
+    """BASELINE configs[4]: the 3-D 27-point operator on 256 x 256 x 128 (nz = 128), homogeneous c = 2000 m/s, rho = 1, h = 10 m, nPML = 10,
+    4 frequencies x 16 point sources, right-hand sides and wavefields resident in HBM; one GPU does the whole job here (under N ranks the
+    dispatcher deals (frequency, source-batch) items).  Per frequency: seconds including the preconditioner set-up, seconds of a second
+    solve that re-uses it (their difference = the set-up), BiCGSTAB iterations per source; plus the 27-point apply against the HBM roofline."""
+    import ctypes
+    import torch
+    from zephyr_amd import Helm3D, _lib
+    lib = _lib.load()
+    lib.helm_trim()                                    # the 2-D leg's scratch (tens of GB) goes back first
+    nz, ny, nx = grid
+    N = nx * ny * nz
+    dev = torch.device('cuda', local)
+    cfg = dict(nx=nx, ny=ny, nz=nz, dx=10., c=2000., rho=1., freq=freqs[0], nPML=10, rtol=rtol, maxit=60000, batch=nsrc, method='auto', device=local)
+    out = {'workload': '3D 27-pt Helmholtz %dx%dx%d (nx, ny, nz) homogeneous c=2000 m/s, rho=1, h=10 m, nPML=10; %d freqs x %d sources, rtol %g, fp64; '
+                       'BiCGSTAB right-preconditioned by the layer-preserving 3-D multigrid with a block-tridiagonal direct coarse solve'
+                       % (nx, ny, nz, len(freqs), nsrc, rtol),
+           'grid_nz_ny_nx': [nz, ny, nx], 'rtol': rtol, 'per_frequency': [], 'apply': []}
+    q = np.zeros((nsrc, N), complex)
+    for s_ in range(nsrc):
+        q[s_, ((20 + 5 * s_) * ny + ny // 2) * nx + nx // 4 + (30 * s_) % (nx // 2)] = 1.     # all inside the physical domain
+    Q = torch.from_numpy(q).to(dev)
+    U = torch.empty_like(Q)
+    total = 0.0
+    for f in freqs:
+        cfg['freq'] = float(f)
+        op = Helm3D(cfg)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        status = 'ok'
+        try:
+            op.solveDevice(Q.data_ptr(), U.data_ptr(), nsrc)       # builds the operator and the preconditioner of this frequency, then solves
+        except ArithmeticError as e:
+            status = str(e)
+        torch.cuda.synchronize()
+        t_all = time.perf_counter() - t0
+        its = [i['iterations'] for i in op.lastInfo]
+        worst = max(i['relres'] for i in op.lastInfo)
+        t0 = time.perf_counter()
+        try:
+            op.solveDevice(Q.data_ptr(), U.data_ptr(), nsrc)       # the same solves with the preconditioner already built
+        except ArithmeticError:
+            pass
+        torch.cuda.synchronize()
+        t_re = time.perf_counter() - t0
+        total += t_all
+        out['per_frequency'].append({'freq_hz': float(f), 'seconds': t_all, 'seconds_reusing_setup': t_re, 'setup_seconds': max(0.0, t_all - t_re),
+                                     'setup_share': max(0.0, t_all - t_re) / t_all, 'iterations': its, 'worst_relres': worst, 'status': status})
+        del op.factors
+    out['job_seconds'] = total
+    out['wavefields_per_s'] = len(freqs) * nsrc / total
+    del Q, U
+    # 27-point apply (k_stencil3): algorithmic bytes N*(32*B + 432) (SURVEY.md 8(d)), HIP events on the solver stream
+    op = Helm3D(cfg)
+    op.setProfiling(True)
+    for Bm in (1, 4, 8, 16):
+        X = torch.randn((Bm, N), dtype=torch.complex128, device=dev)
+        Y = torch.empty_like(X)
+        torch.cuda.synchronize()
+        ms = by = 0.0
+        for rep in range(6):
+            _lib.check(lib.helm_apply_device(op.handle, 0, 0, ctypes.c_void_p(X.data_ptr()), ctypes.c_void_p(Y.data_ptr()), Bm), op.handle)
+            tm = op.lastTiming()
+            if rep:
+                ms += tm['apply_ms']; by += tm['apply_bytes']
+        out['apply'].append({'B': Bm, 'us': 1e3 * ms / 5, 'GBps': by / (ms * 1e-3) / 1e9, 'frac_of_peak': by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        del X, Y
+    del op.factors
+    lib.helm_trim()
+    return out
+
+
 def spawn_ranks(ngpus, argv):
     """`python bench.py --gpus N` without a launcher: start N rank processes (one per GPU, RCCL rendezvous on 127.0.0.1) BEFORE
     anything in this process touches the GPU, relay rank 0's JSON line, fail if any rank fails.  (The driver's
@@ -209,6 +281,8 @@ def main():
     ap.add_argument('--no-cpu-2n', action='store_true', help='skip the faithful 2N x 2N Eurus LU baseline at 512^2 (~1 min, ~11 GB)')
     ap.add_argument('--no-pipeline', dest='pipeline', action='store_false',
                     help='work items strictly one after the other (no prepare-ahead thread, no helm_prefactor)')
+    ap.add_argument('--no-config5', action='store_true', help='skip the 3-D leg (BASELINE configs[4]: 256x256x128, 4 freqs x 16 sources; ~15 s)')
+    ap.add_argument('--config5-rtol', type=float, default=1e-8)
     ap.add_argument('--streams', type=int, default=1, help='work items in flight per GPU (host threads, one operator handle / HIP stream each)')
     args = ap.parse_args()
 
@@ -297,10 +371,6 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    iters, apply_ms, apply_launches, apply_bytes, solve_ms = [], 0.0, 0, 0.0, 0.0
-    gemm_ms, gemm_launches, gemm_flops, factor_ms, methods = 0.0, 0, 0.0, 0.0, set()
-    big_ms, big_launches, big_flops = 0.0, 0, 0.0
-    freq_used = []
     results = [None] * args.steps
     if args.streams <= 1:
         results = run_items([rank + world * (args.warmup + k) for k in range(args.steps)], True)
@@ -319,14 +389,19 @@ def main():
             th.start()
         for th in threads:
             th.join()
-    for fi, info, t in results:
-        iters += [i['iterations'] for i in info]
-        freq_used.append(float(freqs[fi]))
-        apply_ms += t['apply_ms']; apply_launches += t['apply_launches']; apply_bytes += t['apply_bytes']
-        solve_ms += t['solve_ms']
-        gemm_ms += t['gemm_ms']; gemm_launches += t['gemm_launches']; gemm_flops += t['gemm_flops']; factor_ms += t['factor_ms']
-        methods.update(i['method'] for i in info)
-        big_ms += t['gemm_big_ms']; big_launches += t['gemm_big_launches']; big_flops += t['gemm_big_flops']
+    def aggregate(res):
+        a = dict(iters=[], freqs=[], apply_ms=0.0, apply_launches=0, apply_bytes=0.0, solve_ms=0.0, gemm_ms=0.0, gemm_launches=0, gemm_flops=0.0,
+                 factor_ms=0.0, methods=set(), big_ms=0.0, big_launches=0, big_flops=0.0)
+        for fi, info, t in res:
+            a['iters'] += [i['iterations'] for i in info]
+            a['freqs'].append(float(freqs[fi]))
+            a['methods'].update(i['method'] for i in info)
+            for k_, t_ in (('apply_ms', 'apply_ms'), ('apply_launches', 'apply_launches'), ('apply_bytes', 'apply_bytes'), ('solve_ms', 'solve_ms'),
+                           ('gemm_ms', 'gemm_ms'), ('gemm_launches', 'gemm_launches'), ('gemm_flops', 'gemm_flops'), ('factor_ms', 'factor_ms'),
+                           ('big_ms', 'gemm_big_ms'), ('big_launches', 'gemm_big_launches'), ('big_flops', 'gemm_big_flops')):
+                a[k_] += t[t_]
+        return a
+    agg = aggregate(results)
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -337,6 +412,15 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
     elapsed = max_over_ranks(elapsed)
+
+    # Kernel-level roofline: in the pipelined region the factorisation of item k+1 shares the CUs with the solves of item k, so the
+    # per-launch durations there measure the sharing (both kernels stretch).  The same K items therefore run once more strictly one after
+    # the other with the events on; `roofline` quotes that pass, `roofline.in_pipeline` the stretched figures of the timed region itself.
+    agg_k = agg
+    if args.pipeline and args.streams <= 1:
+        barrier()
+        agg_k = aggregate([run_item(rank + world * (args.warmup + k), True) for k in range(args.steps)])
+        barrier()
 
     # the same K work items once more with the per-launch HIP events off: what the event traffic of the roofline measurement costs
     elapsed_plain = None
@@ -352,50 +436,65 @@ def main():
 
     out = None
     if rank == 0:
-        achieved = (apply_bytes / (apply_ms * 1e-3)) / 1e9 if apply_ms > 0 else 0.0
-        direct = methods == {4}
+        direct = agg['methods'] == {4}
         how = ('sparse direct: nested-dissection multifrontal factorisation of A(f) on the GPU, kept for all sources of the frequency, '
                'triangular solves as batched complex GEMMs + iterative refinement with the stencil kernel' if direct else
                'BiCGSTAB right-preconditioned by shifted-Laplacian multigrid with damped-Jacobi smoothing + PML line relaxation')
+        where = ('a pass over the same K work items strictly one after the other (no other kernel on the GPU), events on; in_pipeline = the same '
+                 'quantities from the timed, pipelined region, where concurrent kernels share the CUs' if (args.pipeline and args.streams <= 1) else 'the timed region')
+
+        def stencil_block(a):
+            ach = (a['apply_bytes'] / (a['apply_ms'] * 1e-3)) / 1e9 if a['apply_ms'] > 0 else 0.0
+            return {'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'launches_timed': int(a['apply_launches']),
+                    'avg_launch_us': 1e3 * a['apply_ms'] / a['apply_launches'] if a['apply_launches'] else None,
+                    'bytes_per_launch_algorithmic': a['apply_bytes'] / a['apply_launches'] if a['apply_launches'] else None,
+                    'apply_share_of_solve_time': a['apply_ms'] / a['solve_ms'] if a['solve_ms'] > 0 else None}
+
+        def gemm_block(a):
+            tf = a['gemm_flops'] / (a['gemm_ms'] * 1e-3) / 1e12 if a['gemm_ms'] > 0 else 0.0
+            return {'achieved': tf, 'peak': F64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / F64_PEAK_TFLOPS,
+                    'launches_timed': int(a['gemm_launches']), 'avg_launch_us': 1e3 * a['gemm_ms'] / a['gemm_launches'] if a['gemm_launches'] else None,
+                    'flops_per_launch_algorithmic': a['gemm_flops'] / a['gemm_launches'] if a['gemm_launches'] else None,
+                    'gemm_share_of_solve_time': a['gemm_ms'] / a['solve_ms'] if a['solve_ms'] > 0 else None,
+                    'launches_of_at_least_1_GFLOP': {'launches': int(a['big_launches']), 'share_of_gemm_time': a['big_ms'] / a['gemm_ms'] if a['gemm_ms'] > 0 else None,
+                                                     'achieved': a['big_flops'] / (a['big_ms'] * 1e-3) / 1e12 if a['big_ms'] > 0 else None, 'unit': 'TFLOP/s',
+                                                     'frac': a['big_flops'] / (a['big_ms'] * 1e-3) / 1e12 / F64_PEAK_TFLOPS if a['big_ms'] > 0 else None}}
         stencil = {'bound': 'hbm',
                    'kernel': ('k_resid_nm (9-pt complex128 stencil apply in the node-major layout of the direct path with the residual q - A x and its norms fused), '
-                              'launches inside the timed solves; apply_microbench = the rhs-major batched apply k_stencil' if direct else
+                              'launches inside the solves; apply_microbench = the rhs-major batched apply k_stencil' if direct else
                               'k_stencil (batched 9-pt complex128 apply with fused dot-product / residual epilogue), launches inside the timed solves'),
                    'bytes_formula': ('N*(32*B + 144) per norm-only launch (x and q in, nine coefficients once, nothing out), + N*16*B when r is stored' if direct else
                                      'N*(32*B_active + 144) for the apply + N*16*B_active for the epilogue operand it must read'),
-                   'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                   'traffic': None, 'launches_timed': int(apply_launches),
-                   'avg_launch_us': 1e3 * apply_ms / apply_launches if apply_launches else None,
-                   'bytes_per_launch_algorithmic': apply_bytes / apply_launches if apply_launches else None,
-                   'apply_share_of_solve_time': apply_ms / solve_ms if solve_ms > 0 else None}
+                   'measured_on': where, 'traffic': None}
+        stencil.update(stencil_block(agg_k))
+        if agg_k is not agg:
+            stencil['in_pipeline'] = stencil_block(agg)
+        iters = agg['iters']
         out = {
             'metric': 'wavefields/sec (freq x source solves/s) on 1024^2 grid',
             'value': value, 'unit': 'wavefields/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'timed_region': 'K work items with per-launch HIP events on (they feed `roofline`); `unprofiled` repeats the same K items with the events off',
+            'timed_region': 'K work items through the device pipeline with per-launch HIP events on; `unprofiled` repeats the same K items with the events off',
             'pipeline': ('device pipeline of zephyr_amd.dispatch (MultiFreq parallel mode): item k+1 is created, assembled and its factorisation enqueued '
                          '(helm_prefactor, high-priority stream) while item k is being solved' if args.pipeline else 'off: items strictly one after the other'),
             'unprofiled': None if elapsed_plain is None else {'value': wavefields / elapsed_plain, 'ms_per_step': 1e3 * elapsed_plain / args.steps},
             'config': {'workload': 'Eurus 2D isotropic %dx%d synthetic-Marmousi (seed 20240512, dx=%g m), 16 freqs 2-9.5 Hz x 256 Kaiser sources; '
                                    'step = create + assemble 1 frequency + solve %d sources to true relres<=%g (method=%s: %s)' % (n, n, dx, B, args.rtol, args.method, how),
-                       'grid': [n, n], 'sources_per_step': B, 'work_items_in_flight': args.streams, 'freqs_hz_this_run': freq_used, 'sharding': 'work items (freq, source batch) round-robin over ranks',
+                       'grid': [n, n], 'sources_per_step': B, 'work_items_in_flight': args.streams, 'freqs_hz_this_run': agg['freqs'], 'sharding': 'work items (freq, source batch) round-robin over ranks',
                        'solves_or_iterations_per_rhs_mean': float(np.mean(iters)) if iters else None,
                        'solves_or_iterations_per_rhs_max': int(np.max(iters)) if iters else None,
-                       'device_ms_per_step': {'solve_call': solve_ms / args.steps, 'of_which_factorisation': factor_ms / args.steps}},
+                       'device_ms_per_step': {'solve_call': agg['solve_ms'] / args.steps, 'of_which_factorisation': agg['factor_ms'] / args.steps,
+                                              'note': 'pipelined: solve_call covers the triangular solves + residual checks of an item, the factorisation (of_which_factorisation: its span on its own '
+                                                      'stream, beside the previous item) is no longer inside it' if args.pipeline else 'serial: the factorisation is inside solve_call'}},
         }
         if direct:
-            tf = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
             out['roofline'] = {'bound': 'fp64-valu', 'kernel': 'k_zgemm2 (strided-batched complex128 GEMM of the multifrontal factorisation and triangular solves; fp64 FMAs on the vector '
                                                                 'ALUs -- no MFMA is issued; the peak quoted is the fp64 vector-FMA rate, which equals the fp64 MFMA rate on MI355X)',
-                               'flops_formula': '8*M*N*K per batch item (4 real multiply-adds per complex one)',
-                               'achieved': tf, 'peak': F64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / F64_PEAK_TFLOPS, 'traffic': None,
-                               'launches_timed': int(gemm_launches), 'avg_launch_us': 1e3 * gemm_ms / gemm_launches if gemm_launches else None,
-                               'flops_per_launch_algorithmic': gemm_flops / gemm_launches if gemm_launches else None,
-                               'gemm_share_of_solve_time': gemm_ms / solve_ms if solve_ms > 0 else None,
-                               'launches_of_at_least_1_GFLOP': {'launches': int(big_launches), 'share_of_gemm_time': big_ms / gemm_ms if gemm_ms > 0 else None,
-                                                                'achieved': big_flops / (big_ms * 1e-3) / 1e12 if big_ms > 0 else None, 'unit': 'TFLOP/s',
-                                                                'frac': big_flops / (big_ms * 1e-3) / 1e12 / F64_PEAK_TFLOPS if big_ms > 0 else None}}
+                               'flops_formula': '8*M*N*K per batch item (4 real multiply-adds per complex one)', 'measured_on': where, 'traffic': None}
+            out['roofline'].update(gemm_block(agg_k))
+            if agg_k is not agg:
+                out['roofline']['in_pipeline'] = gemm_block(agg)
             out['stencil_roofline'] = stencil
         else:
             out['roofline'] = stencil
@@ -445,6 +544,14 @@ def main():
                 out['stencil_roofline']['traffic_source'] = 'profiles/r02_pmc_traffic_resid_nm.json (HBM bytes per k_resid_nm launch)'
         except Exception:
             pass
+        if world == 1 and not args.no_config5 and n == 1024:
+            try:
+                del d_u
+                torch.cuda.empty_cache()
+                out['config5'] = config5_leg(local, rtol=args.config5_rtol)
+            except Exception as exc:
+                out['config5'] = 'failed: %s' % exc
+            d_u = torch.empty((B, N), dtype=torch.complex128, device=dev)
         if world == 1 and not args.no_cpu:
             cb, u_lu = cpu_baseline(cfg, freqs, q_all)
             out['cpu_baseline'] = cb

@@ -151,6 +151,7 @@ def test_auto_prefers_direct_and_falls_back_to_krylov(helm_lib, monkeypatch):
     op = za.Eurus(cfg)                       # method defaults to 'auto'
     u = op * q
     assert all(i['method'] == 4 for i in op.lastInfo) and nrm(u, ref) <= 1e-8
+    monkeypatch.setenv('HELM_TESTING', '1')                 # the fault-injection hooks are inert without it
     monkeypatch.setenv('HELM_ND_INJECT_FAILURE', '1')
     op2 = za.Eurus(cfg)
     u2 = op2 * q
@@ -173,6 +174,7 @@ def test_auto_partial_fallback_resolves_only_the_stalled_sources(helm_lib, monke
     cfg = dict(nx=nx, nz=nz, dx=10., dz=10., c=c, freq=7., nPML=8, rtol=1e-10)
     q = za.SimpleSource(cfg)(np.array([[300., 320.], [500., 200.], [120., 400.], [610., 510.], [333., 111.]]))
     ref = ho.DirectOperator(ho.eurus_coefficients(nz, nx, c, ho.gardner_rho(c.astype(complex)), 7., dx=10., dz=10., nPML=8), eurus=True) * q
+    monkeypatch.setenv('HELM_TESTING', '1')
     monkeypatch.setenv('HELM_ND_INJECT_STALL', '2')
     for cls, r in ((za.Eurus, ref), (za.MiniZephyr, None)):
         op = cls(cfg)

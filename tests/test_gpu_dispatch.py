@@ -1,0 +1,80 @@
+"""GPU: MultiFreq's parallel mode (in-process dispatcher, zephyr_amd/dispatch.py) on real operators -- the counterpart of the
+reference's pool in BaseMPDist.__mul__ (zephyr/backend/distributors.py:127-173).  One GPU is enough: two workers on device 0
+(HELM_DEVICES=0,0) exercise the concurrent handles, the prepare-ahead thread and helm_prefactor."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def config(**extra):
+    import zephyr_amd as za
+    from zephyr_amd.models import marmousi_like
+    n = 160
+    sc = dict(nx=n, nz=n, dx=12., dz=12., c=marmousi_like(n, n, 12.), nPML=10, freqs=[3., 4., 5.5, 7., 8.5], Disc=za.Eurus, rtol=1e-10)
+    sc.update(extra)
+    locs = np.stack([np.linspace(200., 1700., 12), np.full(12, 24.)], axis=1)
+    q = za.SparseKaiserSource(sc)(locs)
+    return sc, q
+
+
+def test_two_workers_on_one_gpu_match_the_serial_dispatch_bit_for_bit(helm_lib, monkeypatch):
+    import zephyr_amd as za
+    sc, q = config()
+    serial = list(za.MultiFreq(dict(sc, parallel=False)) * q)
+    monkeypatch.setenv('HELM_DEVICES', '0,0')
+    mf = za.MultiFreq(sc)
+    assert mf.parallel and mf.nWorkers == 2
+    par = list(mf * q)
+    assert len(par) == len(serial) == 5
+    for a, b in zip(par, serial):
+        assert np.array_equal(a, b)                 # the direct path is bit-reproducible; the dispatcher must not change a bit or the order
+    assert mf.factors
+    for sub in mf.subProblems:
+        assert all(i['status'] == 0 and i['relres'] <= 1e-10 for i in sub.lastInfo), sub.lastInfo
+    again = list(mf * q)                            # second call: factors are resident, prefactor is a no-op
+    for a, b in zip(again, serial):
+        assert np.array_equal(a, b)
+    del mf.factors
+    assert not mf.factors
+
+
+def test_fewer_frequencies_than_workers_splits_the_sources(helm_lib, monkeypatch):
+    import zephyr_amd as za
+    sc, q = config(freqs=[4., 7.])
+    serial = list(za.MultiFreq(dict(sc, parallel=False)) * q)
+    monkeypatch.setenv('HELM_DEVICES', '0,0,0,0')
+    mf = za.MultiFreq(sc)
+    par = list(mf * q)
+    for a, b in zip(par, serial):
+        assert a.shape == b.shape and np.array_equal(a, b)      # each half of the sources on its own handle: same columns
+    assert len(mf.__dict__['_replicas']) == 2
+    del mf.factors
+
+
+def test_a_failing_frequency_raises_where_its_result_is_consumed(helm_lib, monkeypatch):
+    import zephyr_amd as za
+    sc, q = config(freqs=[4., 5., 6.], method='bicgstab', maxit=3)     # three Jacobi-BiCGSTAB iterations converge nowhere
+    monkeypatch.setenv('HELM_DEVICES', '0,0')
+    it = za.MultiFreq(sc) * q
+    with pytest.raises(ArithmeticError):
+        next(it)
+
+
+def test_prefactor_then_solve_equals_lazy_factorisation(helm_lib):
+    import zephyr_amd as za
+    sc, q = config()
+    cfg = dict(sc); cfg.pop('freqs'); cfg.pop('Disc'); cfg['freq'] = 6.
+    a = za.Eurus(cfg)
+    ua = a * q
+    b = za.Eurus(cfg)
+    b.prefactor()
+    b.prefactor()                                   # idempotent
+    ub = b * q
+    assert np.array_equal(ua, ub)
+    c = za.Eurus(cfg)
+    c.prefactor()
+    del c.factors                                   # destroying a handle with a factorisation in flight is safe

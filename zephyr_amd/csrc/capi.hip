@@ -689,6 +689,18 @@ struct WsLease {
     ~WsLease() { ws_checkin(slot); }
 };
 
+// statuses of one right-hand side across the blocks / passes of a call, by severity: 0 converged < 3 at the fp64 floor (counted as solved)
+// < 1 cap / stalled < 2 breakdown
+// fault-injection hooks of the test-suite: honoured only when the process runs with HELM_TESTING=1 (read per call: the tests flip them)
+inline int testing_hook(const char *name) {
+    const char *t = getenv("HELM_TESTING");
+    if (!t || atoi(t) == 0) return 0;
+    const char *v = getenv(name);
+    return v ? atoi(v) : 0;
+}
+inline int status_rank(int st) { return st == 0 ? 0 : (st == 3 ? 1 : (st == 1 ? 2 : 3)); }
+inline int merge_status(int a, int b) { return status_rank(a) >= status_rank(b) ? a : b; }
+
 // Sparse direct path (direct.hip): factor once per assembled operator, then per batch q' -> x by the multifrontal
 // triangular solves and iterative refinement on the true residual q' - A x (stencil kernel) until rtol is met.
 // sys2 != 0: the coupled two-field Eurus system [[M1, M2], [M3, M4]] on the stacked unknowns [u; v] (block ignored, two
@@ -708,10 +720,8 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
     const bool need_factor = (f == nullptr);
     // factors enqueued by helm_prefactor on the handle's factor stream: everything this call launches comes after them
     if (op->pf_pending && f && op->pf_done) HIP_TRY(op, hipStreamWaitEvent(op->stream, op->pf_done, 0));
-    {   // fault injection for the tests of the AUTO fallback
-        const char *inj = getenv("HELM_ND_INJECT_FAILURE");
-        if (inj && atoi(inj) != 0) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: injected failure (HELM_ND_INJECT_FAILURE)");
-    }
+    // fault injection for the tests of the AUTO fallback
+    if (testing_hook("HELM_ND_INJECT_FAILURE")) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: injected failure (HELM_ND_INJECT_FAILURE)");
     struct FactorOwner {       // a factor under construction is released on every early return
         NdFactor *p = nullptr;
         ~FactorOwner() { if (p) nd_free(p); }
@@ -891,7 +901,7 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
                 }
             }
         }
-        const int inject_stall = getenv("HELM_ND_INJECT_STALL") ? atoi(getenv("HELM_ND_INJECT_STALL")) : 0;
+        const int inject_stall = testing_hook("HELM_ND_INJECT_STALL");
         for (int b = 0; b < n; ++b) {
             const bool ok = (relres[b] <= o.rtol * 1.0000001 || at_floor[b]) && !(first + b < inject_stall);
             if (!ok) unconverged += 1;
@@ -899,7 +909,7 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
                 helm_solve_info &I = info[first + b];
                 I.iterations += 1 + extra_solves[b]; I.method = HELM_DIRECT;
                 I.relres = std::max(I.relres, relres[b]);
-                I.status = std::max(I.status, ok ? (at_floor[b] ? 3 : 0) : 1);
+                I.status = merge_status(I.status, ok ? (at_floor[b] ? 3 : 0) : 1);
             }
         }
         HIP_TRY(op, hipStreamSynchronize(op->stream));
@@ -1026,7 +1036,7 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
             }
         }
         // fault injection for the tests of the partial fallback: report the first k right-hand sides as stalled
-        const int inject_stall = getenv("HELM_ND_INJECT_STALL") ? atoi(getenv("HELM_ND_INJECT_STALL")) : 0;      // read per call: the tests flip it
+        const int inject_stall = testing_hook("HELM_ND_INJECT_STALL");
         for (int b = 0; b < n; ++b) {
             const bool ok = (relres[b] <= o.rtol * 1.0000001 || at_floor[b]) && !(first + b < inject_stall);
             if (!ok) unconverged += 1;
@@ -1034,7 +1044,7 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
                 helm_solve_info &I = info[first + b];
                 I.iterations += 1 + extra_solves[b]; I.method = HELM_DIRECT;
                 I.relres = std::max(I.relres, relres[b]);
-                I.status = std::max(I.status, ok ? (at_floor[b] ? 3 : 0) : 1);
+                I.status = merge_status(I.status, ok ? (at_floor[b] ? 3 : 0) : 1);
             }
         }
         HIP_TRY(op, hipStreamSynchronize(op->stream));
@@ -1064,7 +1074,17 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
         if (!e || atoi(e) != 0) {
             std::vector<helm_solve_info> saved;
             if (info) saved.assign(info, info + nrhs);
-            const int rc = solve_block_direct(op, block, dRHS, rhs_ld, row_off, premul, sub, dXout, nrhs, o, info, sys2, rows_in, dUconj);
+            // what THIS call's direct pass found, apart from what earlier blocks of the same solve left in `info` (stacked Eurus: block 3, then 0)
+            std::vector<helm_solve_info> cur(nrhs);
+            for (helm_solve_info &c : cur) { c.iterations = 0; c.status = 0; c.restarts = 0; c.method = HELM_DIRECT; c.relres = 0.0; }
+            const int rc = solve_block_direct(op, block, dRHS, rhs_ld, row_off, premul, sub, dXout, nrhs, o, cur.data(), sys2, rows_in, dUconj);
+            auto merge_cur = [&](int b) {
+                helm_solve_info &I = info[b];
+                I.iterations += cur[b].iterations; I.method = cur[b].method;
+                I.relres = std::max(I.relres, cur[b].relres);
+                I.status = merge_status(I.status, cur[b].status);
+            };
+            if (rc >= 0 && info && !(rc > 0 && !sys2 && rc < nrhs)) for (int b = 0; b < nrhs; ++b) merge_cur(b);
             if (rc == 0) { if (wrote_u && dUconj && !sys2) *wrote_u = true; return 0; }
             // the coupled system has no better fallback: row-equilibrated CGNR needs 10^4-10^5 iterations and meets the same
             // fp64 floor of the true residual, so right-hand sides that stalled above rtol are reported as such
@@ -1075,8 +1095,9 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
             if (rc > 0 && info && !sys2 && rc < nrhs) {
                 // some right-hand sides stalled above rtol: only those go to the Krylov path (packed into a narrower batch);
                 // the converged ones keep the direct result
+                // (status 1 or 2 of the direct pass; those at the fp64 floor -- status 3 -- are solved: no Krylov method gets below it either)
                 std::vector<int> bad;
-                for (int b = 0; b < nrhs; ++b) if (info[b].status != 0) bad.push_back(b);
+                for (int b = 0; b < nrhs; ++b) { if (cur[b].status == 1 || cur[b].status == 2) bad.push_back(b); else merge_cur(b); }
                 const int k = (int)bad.size();
                 const size_t colb = (size_t)N * sizeof(cplx);
                 cplx *tR = (cplx *)helm_pool_alloc(op->device, (size_t)k * colb), *tX = (cplx *)helm_pool_alloc(op->device, (size_t)k * colb);
@@ -1131,7 +1152,8 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
         else if (o.method == HELM_MG) return rc;
     }
     // (an iteration of the layer-preserving 3-D cycle costs tens of milliseconds and ten of them are a whole solve: poll after every one)
-    const int check_every = o.check_every > 0 ? o.check_every : (use_mg && op->ny > 0 && mg3_is_layer_preserving(op) ? 1 : (use_mg ? 10 : 50));
+    auto pick_check_every = [&]() { return o.check_every > 0 ? o.check_every : (use_mg && op->ny > 0 && mg3_is_layer_preserving(op) ? 1 : (use_mg ? 10 : 50)); };
+    int check_every = pick_check_every();
     int unconverged = 0;
     for (int first = 0; first < nrhs; first += Bmax) {
         const int n = std::min(Bmax, nrhs - first);
@@ -1205,7 +1227,8 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
                 // the layer-preserving 3-D hierarchy needs tens of iterations; if it has not converged after HELM_MG3_KEEP_CAP (300) the
                 // frequency retreats to the standard cycle and goes on from the iterates reached
                 const bool keep3 = use_mg && op->ny > 0 && mg3_is_layer_preserving(op);
-                if (keep3) cap = std::min(cap, getenv("HELM_MG3_KEEP_CAP") ? std::max(1, atoi(getenv("HELM_MG3_KEEP_CAP"))) : 300);
+                // (first round only: the retreat below is what the cap is for, and it is taken there)
+                if (keep3 && round == 0) cap = std::min(cap, getenv("HELM_MG3_KEEP_CAP") ? std::max(1, atoi(getenv("HELM_MG3_KEEP_CAP"))) : 300);
                 rc = run_bicgstab(op, block, B, cap, check_every, 25, restarts);
                 if (rc) return rc;
                 if (keep3 && round == 0) {
@@ -1220,6 +1243,7 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
                     if (any) {
                         rc = mg3_retreat(op, Bmax);
                         if (rc) return rc;
+                        check_every = pick_check_every();          // the standard cycle needs hundreds of iterations: poll every 10, not every one
                         rc = restart_masked(op, block, B);
                         if (rc) return rc;
                         rc = run_bicgstab(op, block, B, o.method == HELM_AUTO ? std::min(o.maxit, 5000) : o.maxit, check_every, 25, restarts);
@@ -1308,7 +1332,7 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
                 I.method = method_used[b];
                 I.relres = std::max(I.relres, relres[b]);
                 const int st = (relres[b] <= o.rtol * 1.0000001) ? 0 : (S.status == ST_BREAKDOWN ? 2 : 1);
-                I.status = std::max(I.status, st);
+                I.status = merge_status(I.status, st);
             }
             (void)ok;
         }
@@ -1339,7 +1363,7 @@ extern "C" int helm_prefactor(helm_op *op) {
     if (op->ny > 0 || op->direct_failed || op->direct[0] || op->pf_pending) return HELM_OK;
     if (op->variant == HELM_EURUS && !op->block_zero[2]) return HELM_OK;          // coupled TTI: row-equilibrated inside the solve
     { const char *e = getenv("HELM_AUTO_DIRECT"); if (e && atoi(e) == 0) return HELM_OK; }
-    { const char *e = getenv("HELM_ND_INJECT_FAILURE"); if (e && atoi(e) != 0) return HELM_OK; }
+    if (testing_hook("HELM_ND_INJECT_FAILURE")) return HELM_OK;
     HIP_TRY(op, hipSetDevice(op->device));
     if (!op->fstream) {
         op->fstream = helm_stream_acquire(op->device, 1);

@@ -1567,7 +1567,7 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
     cplx *F = arenaF + g.foff;
     cplx *Finv = f->d_fac + g.finv, *G21 = f->d_fac + g.g21, *F12 = f->d_fac + g.f12;
     static const int fused_build = getenv("HELM_ND_FUSEDBUILD") ? atoi(getenv("HELM_ND_FUSEDBUILD")) : 1;
-    if (fused_build && nmax < (1 << 14) && op->nz < 65536 && op->nx < 32768) {
+    if (fused_build && (size_t)nmax * sizeof(int2) <= 64 * 1024 && nmax < (1 << 14) && op->nz < 65536 && op->nx < 32768) {      // (its row table must fit the 64 KB of LDS a launch gets by default: larger fronts take the unfused path)
         // rows per workgroup: whole fronts while there are thousands of them, a few rows each for the handful of big ones at the top
         const int want = std::max(1, 2048 / g.cnt);
         const int rb = std::max(std::min(nmax, 4), (nmax + want - 1) / want);
@@ -1842,6 +1842,19 @@ int nd_solve_nm(helm_op *op, NdFactor *f, const cplx *Qt, cplx *Xt, int nrhs, cp
     return check_kernels(op, "solve kernels");
 }
 
+// events of a factor + solve sweep, destroyed on every exit (an early error return must not leak the ones already created)
+namespace {
+struct EventSet {
+    std::vector<hipEvent_t> plain, timed;
+    bool create(size_t nplain, size_t ntimed) {
+        for (size_t i = 0; i < nplain; ++i) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false; plain.push_back(e); }
+        for (size_t i = 0; i < ntimed; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return false; timed.push_back(e); }
+        return true;
+    }
+    ~EventSet() { for (hipEvent_t e : plain) hipEventDestroy(e); for (hipEvent_t e : timed) hipEventDestroy(e); }
+};
+}  // namespace
+
 // Factorisation with the forward elimination of one batch running beside it: the forward pass of a tree level only needs that
 // level's factors, so it follows the factorisation level by level on a second, LOW-priority stream.  The top of the tree is a chain of
 // small dependent launches (80 block steps of a 16-workgroup panel kernel + one update each) that leaves most of the chip idle; the
@@ -1856,10 +1869,10 @@ int nd_factor_solve_nm(helm_op *op, int block, NdFactor *f, cplx *ws_factor, con
     SolveCtx c = solve_ctx(f, Xt, nrhs);
     c.Qt = Qt; c.Xt = Xt; c.arenaV = arenaV;
     const size_t ng = P.groups.size();
-    std::vector<hipEvent_t> ev(ng + 2);
-    for (auto &e : ev) HIP_TRY(op, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    hipEvent_t t0, t1;
-    HIP_TRY(op, hipEventCreate(&t0)); HIP_TRY(op, hipEventCreate(&t1));
+    EventSet evs;
+    if (!evs.create(ng + 2, 2)) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: hipEventCreate failed");
+    std::vector<hipEvent_t> &ev = evs.plain;
+    hipEvent_t t0 = evs.timed[0], t1 = evs.timed[1];
     hipEventRecord(ev[ng], main);                 // the right-hand sides were prepared on the main stream
     hipStreamWaitEvent(side, ev[ng], 0);
     hipEventRecord(t0, main);
@@ -1877,8 +1890,6 @@ int nd_factor_solve_nm(helm_op *op, int block, NdFactor *f, cplx *ws_factor, con
     if (!rc) for (size_t gk = ng; gk-- > 0;) backward_group(op, f, gk, c);
     hipError_t e = hipStreamSynchronize(main);
     if (factor_ms) { float ms = 0.f; if (hipEventElapsedTime(&ms, t0, t1) == hipSuccess) *factor_ms = ms; }
-    for (auto &x : ev) hipEventDestroy(x);
-    hipEventDestroy(t0); hipEventDestroy(t1);
     if (rc) return rc;
     if (e != hipSuccess) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: factor + solve failed: %s", hipGetErrorString(e));
     return check_kernels(op, "factor + solve kernels");
@@ -1959,10 +1970,10 @@ int nd_factor_solve(helm_op *op, int block, NdFactor *f, cplx *ws_factor, const 
     if (rc) return rc;
     const SolveCtx c = solve_ctx(f, ws_solve, nrhs);
     const size_t ng = P.groups.size();
-    std::vector<hipEvent_t> ev(ng + 2);
-    for (auto &e : ev) HIP_TRY(op, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    hipEvent_t t0, t1;
-    HIP_TRY(op, hipEventCreate(&t0)); HIP_TRY(op, hipEventCreate(&t1));
+    EventSet evs;
+    if (!evs.create(ng + 2, 2)) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: hipEventCreate failed");
+    std::vector<hipEvent_t> &ev = evs.plain;
+    hipEvent_t t0 = evs.timed[0], t1 = evs.timed[1];
     // the right-hand sides were prepared on the main stream
     hipEventRecord(ev[ng], main);
     hipStreamWaitEvent(side, ev[ng], 0);
@@ -1985,8 +1996,6 @@ int nd_factor_solve(helm_op *op, int block, NdFactor *f, cplx *ws_factor, const 
     }
     hipError_t e = hipStreamSynchronize(main);
     if (factor_ms) { float ms = 0.f; if (hipEventElapsedTime(&ms, t0, t1) == hipSuccess) *factor_ms = ms; }
-    for (auto &x : ev) hipEventDestroy(x);
-    hipEventDestroy(t0); hipEventDestroy(t1);
     if (rc) return rc;
     if (e != hipSuccess) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: factor + solve failed: %s", hipGetErrorString(e));
     return check_kernels(op, "factor + solve kernels");

@@ -8,6 +8,8 @@
 //    absorbing layers, l1-Jacobi, true layer with a small shift, block-tridiagonal direct solve of the level that still has
 //    ~10 points per wavelength.  DESIGN.md section 5.3 has the measurements behind each of these choices.
 #include "helm_internal.hpp"
+#include <map>
+#include <mutex>
 #include "direct.hpp"
 #include <algorithm>
 #include <complex>
@@ -649,7 +651,7 @@ int bt_setup(helm_op *op, Bt3 &B, const Mg3Level &L, int batch) {
     {   // leave room for the Krylov workspace: the plane inverses may take a third of the device memory (HELM_MG3_BT_MAXGB overrides)
         size_t freeb = 0, totb = 0;
         hipMemGetInfo(&freeb, &totb);
-        const double cap = envd("HELM_MG3_BT_MAXGB", totb / 3.0e9) * 1e9;
+        const double cap = std::min(envd("HELM_MG3_BT_MAXGB", totb / 3.0e9) * 1e9, 0.95 * (double)freeb);     // (free memory: several 3-D handles may be alive)
         if ((double)(tb + B.tbytes32) > cap)
             HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "3-D multigrid: the plane inverses of the directly solved level (%.1f GB) exceed the budget of %.1f GB", (tb + B.tbytes32) / 1e9, cap / 1e9);
     }
@@ -833,9 +835,10 @@ template <typename T> T *upload(const std::vector<T> &v) {
     return d;
 }
 
-// bytes of the (single-precision) plane inverses if the level reached after `l` layer-preserving coarsenings is the directly solved one;
-// *setup_s (optional): the time its plane inversions take, 8 np m^3 flop at the ~21 TFLOP/s the blocked Gauss-Jordan sustains end to end
-double keep_direct_bytes(const helm_op *op, int l, double *setup_s = nullptr) {
+// geometry of the directly solved level if it is the one reached after `l` layer-preserving coarsenings: np planes of m x m;
+// returns the bytes of its plane inverses as bt_setup will store them for `batch` right-hand sides (single precision for up to 16
+// with the library's own plane product, double precision -- padded for the generic batched GEMM -- beyond that or on request)
+double keep_direct_bytes(const helm_op *op, int l, int batch, int *np_out = nullptr, int *m_out = nullptr) {
     const int dims[3] = {op->nz, op->ny, op->nx};
     int out[3];
     for (int a = 0; a < 3; ++a) {
@@ -850,8 +853,85 @@ double keep_direct_bytes(const helm_op *op, int l, double *setup_s = nullptr) {
     int s = 0;
     for (int a = 1; a < 3; ++a) if (out[a] > out[s]) s = a;
     const double m = (double)out[(s + 1) % 3] * out[(s + 2) % 3];
-    if (setup_s) *setup_s = (double)out[s] * m * m * m * 8.0 / 21e12;
-    return (double)out[s] * m * m * sizeof(float2);
+    if (np_out) *np_out = out[s];
+    if (m_out) *m_out = (int)m;
+    const bool own = envi("HELM_MG3_BT_GEMM", 0) == 0 && batch <= 16;
+    const bool f32 = own && envi("HELM_MG3_BT_F32", 1) != 0;
+    if (f32) return (double)out[s] * m * m * sizeof(float2) + 4.0 * m * m * sizeof(cplx);        // + the set-up's double-precision ping-pong planes
+    double mpad = m;
+    if (!own) { const int ks = std::max(1, std::min(16, 255 / (((int)m + 63) / 64))); mpad = (double)(((int)m + ks - 1) / ks) * ks; }
+    return (double)out[s] * mpad * m * sizeof(cplx);
+}
+
+// ---- what the depth decision is made from: timed on this device at set-up, once per process and size class ---------------------------------
+__global__ void k3_cal_fill(cplx *A, int n) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < (long long)n * n; e += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(e / n), j = (int)(e % n);
+        const unsigned h = (unsigned)(i * 2654435761u) ^ (unsigned)(j * 40503u);
+        A[e] = i == j ? cmake(4.0, 1.0) : cmake(((h & 1023) / 1024.0 - 0.5) / n, (((h >> 10) & 1023) / 1024.0 - 0.5) / n);
+    }
+}
+std::mutex g_cal_mu;
+std::map<std::pair<int, int>, double> g_cal_inverse;       // (device, size) -> seconds of one dense inversion
+// seconds the dense blocked Gauss-Jordan takes for one m x m plane: timed on a synthetic matrix of min(m, 4096) rows, scaled with the cube of
+// the size above that (the rate still rises a little there, so large planes are over- rather than under-estimated)
+double inverse_seconds(helm_op *op, int m) {
+    const int mc = std::max(32, std::min(m, 4096));
+    double t = -1.0;
+    {
+        std::lock_guard<std::mutex> lk(g_cal_mu);
+        auto it = g_cal_inverse.find(std::make_pair(op->device, mc));
+        if (it != g_cal_inverse.end()) t = it->second;
+    }
+    if (t < 0) {
+        const size_t mb = (size_t)mc * mc * sizeof(cplx);
+        cplx *A = (cplx *)helm_pool_alloc(op->device, mb), *W = (cplx *)helm_pool_alloc(op->device, mb);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (A && W && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+            for (int rep = 0; rep < 2; ++rep) {                       // the second run is the timed one
+                hipLaunchKernelGGL(k3_cal_fill, dim3(1024), dim3(256), 0, op->stream, A, mc);
+                hipEventRecord(e0, op->stream);
+                nd_dense_inverse(op, A, mc, W);
+                hipEventRecord(e1, op->stream);
+            }
+            float ms = 0.f;
+            if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0) t = ms * 1e-3;
+        }
+        if (e0) hipEventDestroy(e0);
+        if (e1) hipEventDestroy(e1);
+        hipStreamSynchronize(op->stream);
+        helm_pool_free(op->device, A, mb); helm_pool_free(op->device, W, mb);
+        if (t < 0) t = 8.0 * mc * (double)mc * mc / 20e12;             // (could not time it: a nominal rate)
+        std::lock_guard<std::mutex> lk(g_cal_mu);
+        g_cal_inverse[std::make_pair(op->device, mc)] = t;
+    }
+    const double r = (double)m / mc;
+    return t * r * r * r;
+}
+// seconds one fine-grid 27-point apply takes per right-hand side at the batch width of this call (the unit an iteration is priced in)
+double apply_seconds_per_rhs(helm_op *op, int batch) {
+    const int nb = std::max(1, std::min(batch, 16));
+    const size_t vb = (size_t)nb * op->N * sizeof(cplx);
+    cplx *X = (cplx *)helm_pool_alloc(op->device, vb), *Y = (cplx *)helm_pool_alloc(op->device, vb);
+    double t = -1.0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (X && Y && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+        hipMemsetAsync(X, 0, vb, op->stream);
+        ApplyArgs a = ApplyArgs();
+        a.planes = op->d_C; a.X = X; a.Y = Y; a.ld = op->N; a.nrhs = nb; a.epi = EPI_NONE; a.profile = 0;
+        int rc = helm_launch_apply(op, a);
+        hipEventRecord(e0, op->stream);
+        if (!rc) rc = helm_launch_apply(op, a);
+        hipEventRecord(e1, op->stream);
+        float ms = 0.f;
+        if (!rc && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0) t = ms * 1e-3 / nb;
+    }
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    hipStreamSynchronize(op->stream);
+    helm_pool_free(op->device, X, vb); helm_pool_free(op->device, Y, vb);
+    if (t < 0) t = (double)op->N * (32.0 + 432.0 / nb) / 3.5e12;       // (could not time it: a nominal streaming rate)
+    return t;
 }
 
 // levels 0 .. ncoarsen of the layer-preserving hierarchy + the direct solver of the last one; on failure the caller falls back
@@ -977,21 +1057,36 @@ int mg3_setup(helm_op *op, int batch) {
         if (ncoarsen > 0) {
             size_t freeb = 0, totb = 0;
             hipMemGetInfo(&freeb, &totb);
-            const double cap = envd("HELM_MG3_BT_MAXGB", totb / 3.0e9) * 1e9;
+            // budget of the plane inverses: a third of the device, and never more than what is free now less the Krylov vectors of this call
+            const double krylov = 11.0 * batch * (double)op->N * sizeof(cplx);
+            const double cap = std::min(envd("HELM_MG3_BT_MAXGB", totb / 3.0e9) * 1e9, std::max(0.0, (double)freeb - (op->d_ws ? 0.0 : krylov)));
             const double ppwf = envd("HELM_MG3_PPWF", 6.0);
-            while (ncoarsen < 5 && keep_direct_bytes(op, ncoarsen) > cap && ppw / (double)(2 << ncoarsen) >= ppwf && (interior >> (ncoarsen + 1)) >= 3) ++ncoarsen;
+            while (ncoarsen < 5 && keep_direct_bytes(op, ncoarsen, batch) > cap && ppw / (double)(2 << ncoarsen) >= ppwf && (interior >> (ncoarsen + 1)) >= 3) ++ncoarsen;
             // ... and one level deeper (down to 5 points) when that SAVES time for the right-hand sides of the call that builds the preconditioner:
-            // the set-up of the deeper level is cheaper (8 np m^3 flop of plane inversions) but every right-hand side pays more iterations --
-            // measured on config 5 with the Galerkin direct level: +11 / +22 / +38 iterations at >= 8 / 6 / 5 points per wavelength, 2.6 ms per
-            // right-hand side and iteration at 8.4 M unknowns.  16 sources: 3 and 4 Hz go deeper (1.88 -> 0.95 / 1.38 s), 5 Hz does not.
+            // the set-up of the deeper level is cheaper (np plane inversions of m^3 work each) but every right-hand side pays more iterations.
+            //   set-up saved   = np_d t_inv(m_d) - np_{d+1} t_inv(m_{d+1}),  t_inv timed on this device (inverse_seconds)
+            //   iterations paid = nrhs * extra * t_iter,  t_iter = 18 fine-grid applies per right-hand side, the apply timed on this grid at this
+            //                    batch width (apply_seconds_per_rhs).  18: an iteration of the right-preconditioned BiCGSTAB is 2 applies, 2 cycles of
+            //                    ~3.7 fine-grid-apply equivalents each (two smoothing sweeps + the residual on the finest level, ~20 % more for the
+            //                    levels below it), 224 B per point of vector updates (~4 applies at 16 right-hand sides) and two coarse solves;
+            //                    on config 5 this reproduces the 2.6 ms per right-hand side and iteration measured there.
+            //   extra          = +11 / +22 / +38 iterations with the Galerkin direct level at >= 8 / 6 / 5 points per wavelength -- a property of the
+            //                    cycle, not of the machine: measured on config 5 (homogeneous) and on the heterogeneous probes of DESIGN.md 5.3.
             if (op->mg3_rhs_hint > 0 && envi("HELM_MG3_DEPTH_MODEL", 1) && ncoarsen < 5 && (interior >> (ncoarsen + 1)) >= 3) {
                 const double ppwd = ppw / (double)(2 << ncoarsen);
                 if (ppwd >= 5.0) {
-                    double t0 = 0, t1 = 0;
-                    keep_direct_bytes(op, ncoarsen, &t0); keep_direct_bytes(op, ncoarsen + 1, &t1);
+                    int np0 = 0, m0 = 0, np1 = 0, m1 = 0;
+                    keep_direct_bytes(op, ncoarsen, batch, &np0, &m0); keep_direct_bytes(op, ncoarsen + 1, batch, &np1, &m1);
+                    const double saved = envd("HELM_MG3_DEPTH_SETUP_SCALE", 1.0) * (np0 * inverse_seconds(op, m0) - np1 * inverse_seconds(op, m1));
                     const double extra_its = ppwd >= 8.0 ? 11.0 : (ppwd >= 6.0 ? 22.0 : 38.0);
-                    const double per_rhs_it = 2.6e-3 * (double)op->N / 8.4e6;
-                    if (t0 - t1 > op->mg3_rhs_hint * extra_its * per_rhs_it) ++ncoarsen;
+                    const double t_iter = 18.0 * apply_seconds_per_rhs(op, batch);
+                    const double paid = op->mg3_rhs_hint * extra_its * t_iter;
+                    const bool deeper = saved > paid || envi("HELM_MG3_DEPTH_FORCE_DEEPER", 0) != 0;
+                    if (envi("HELM_MG3_TRACE", 0))
+                        fprintf(stderr, "[mg3 depth] %d coarsenings (%.1f points per wavelength on the direct level): set-up %d x %d^2 planes; one deeper: %d x %d^2; saves %.3f s, "
+                                        "costs %d rhs x %.0f iterations x %.2f ms = %.3f s -> %s\n", ncoarsen, ppwd, np0, m0, np1, m1, saved, op->mg3_rhs_hint, extra_its,
+                                t_iter * 1e3, paid, deeper ? "deeper" : "stay");
+                    if (deeper) ++ncoarsen;
                 }
             }
         }

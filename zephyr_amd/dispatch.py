@@ -115,11 +115,14 @@ class DevicePipeline(object):
             self._run_solve(ready.get())
 
 
-def dispatch(items_by_device, lookahead=1):
-    """Start one DevicePipeline per device.  items_by_device: {device: [WorkItem, ...]} (each list in the order it
-    should run).  Returns the pipelines (join() them, or just wait on the items' futures)."""
+def dispatch(workers, lookahead=1):
+    """Start one DevicePipeline per worker.  workers: [(device, [WorkItem, ...]), ...] (each list in the order it should run;
+    the same device may appear twice: two pipelines then share that GPU).  Returns the pipelines (join() them, or just wait on
+    the items' futures)."""
+    if isinstance(workers, dict):
+        workers = list(workers.items())
     pipes = []
-    for dev, items in items_by_device.items():
+    for dev, items in workers:
         p = DevicePipeline(dev, lookahead)
         p.start(items)
         pipes.append(p)

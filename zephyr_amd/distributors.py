@@ -84,9 +84,10 @@ class BaseMPDist(BaseDist):
         if getattr(self, '_subProblems', None) is None:
             devs = self.devices
             subs = []
+            split = max(1, len(devs) // max(1, len(self.spUpdates)))      # spare GPUs: see __mul__
             for i, cfg in enumerate(self._spConfigs):
                 if self.parallel and 'device' not in cfg:
-                    cfg['device'] = devs[i % len(devs)]
+                    cfg['device'] = devs[(i * split) % len(devs)]
                 subs.append(self.Disc(cfg))
             self._subProblems = subs
             self._replicas = {}
@@ -135,7 +136,7 @@ class BaseMPDist(BaseDist):
         # every right-hand side is taken now, in order, like the reference's apply_async loop (distributors.py:161-166)
         devs = self.devices
         split = max(1, len(devs) // max(1, len(subs)))           # GPUs per frequency when there are spare ones
-        queues = dict((d, []) for d in devs)
+        queues = [[] for _ in devs]                              # one worker (solve + prepare thread) per entry of `devices`
         parts = []
         for i, sub in enumerate(subs):
             r = get(i)
@@ -143,20 +144,20 @@ class BaseMPDist(BaseDist):
             k = min(split, ncol) if hasattr(sub, 'prefactor') else 1
             if k <= 1:
                 it = self._item(sub, r)
-                queues[devs[i % len(devs)]].append(it)
+                queues[i % len(devs)].append(it)
                 parts.append([it])
                 continue
             rc = r.tocsc() if sp.issparse(r) else r
             bounds = [ncol * j // k for j in range(k + 1)]
             row = []
             for j in range(k):
-                dev = devs[(i * k + j) % len(devs)]
-                owner = sub if dev == getattr(sub, 'device', None) else self._replica(i, j + 1, dev)
+                w = (i * k + j) % len(devs)
+                owner = sub if j == 0 else self._replica(i, j, devs[w])
                 it = self._item(owner, rc[:, bounds[j]:bounds[j + 1]])
-                queues[dev].append(it)
+                queues[w].append(it)
                 row.append(it)
             parts.append(row)
-        self._pipes = dispatch.dispatch(queues, lookahead=1)
+        self._pipes = dispatch.dispatch(list(zip(devs, queues)), lookahead=1)
 
         def results():
             for row in parts:
