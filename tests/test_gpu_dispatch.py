@@ -78,3 +78,32 @@ def test_prefactor_then_solve_equals_lazy_factorisation(helm_lib):
     c = za.Eurus(cfg)
     c.prefactor()
     del c.factors                                   # destroying a handle with a factorisation in flight is safe
+
+
+@pytest.mark.parametrize('devices', ['0,0', '0,0,0,0,0,0,0,0'])
+def test_dpred_and_gradient_over_several_workers_match_golden(helm_lib, monkeypatch, devices):
+    """Survey.dpred and Problem.Jtvec (problem.py:124-179) with the work items (frequency, source batch) dealt over several workers:
+    3 frequencies on 2 workers (frequency-major), and on 8 workers (fewer frequencies than GPUs: the sources of a frequency are split
+    over 2 of them, each with its own copy of the operator) -- the reference's golden data and gradient either way."""
+    import zephyr_amd as za
+    from zephyr_amd.problem import Helm2DProblem
+    from zephyr_amd.survey import Helm2DSurvey
+    g = np.load(os.path.join(GOLD, 'g6_survey.npz'))
+    nz, nx = g['c'].shape
+    sc = dict(nx=nx, nz=nz, dx=10., dz=10., c=g['c'], rho=g['rho'], nPML=6, freqs=list(g['freqs']), Disc=za.MiniZephyrHD,
+              sterms=g['sterms'], geom=dict(src=g['src'], rec=g['rec'], mode='fixed'))
+    monkeypatch.setenv('HELM_DEVICES', devices)
+    prob, surv = Helm2DProblem(sc), Helm2DSurvey(sc)
+    prob.pair(surv)
+    nw = len(devices.split(','))
+    assert prob.system.nWorkers == nw
+    d = surv.dpred()
+    assert np.linalg.norm(d - g['dpred']) / np.linalg.norm(g['dpred']) <= 1e-7
+    gm = prob.Jtvec(None, g['resid'])
+    assert np.linalg.norm(gm - g['g_mux']) / np.linalg.norm(g['g_mux']) <= 1e-6
+    if nw > len(sc['freqs']):
+        assert len(prob.system.__dict__.get('_replicas', {})) == len(sc['freqs']) * (nw // len(sc['freqs']) - 1)
+    uF = prob.fields()                                   # host path through MultiFreq's own dispatch
+    gu = prob.Jtvec(None, g['resid'], u=uF)
+    assert np.linalg.norm(gu - g['g_u']) / np.linalg.norm(g['g_u']) <= 1e-6
+    del prob.factors

@@ -5,8 +5,12 @@ Interface of zephyr/middleware/problem.py:17-212 (HelmBaseProblem / Helm2DProble
 condition; both the "mux" branch that solves forward and back-propagated sources together and the
 branch that re-uses given forward fields) and `updateModel`.
 
-Multi-GPU: frequencies are sharded over ranks (`shardFreqs`, default on when torch.distributed is
-initialised); the only collective is one all-reduce of the gradient (problem.py:152,162 sum over
+Multi-GPU, two ways.  In one process (no process group): the system wrapper's parallel mode deals work items
+(frequency, source batch) frequency-major over the visible GPUs -- one solve thread and one prepare-ahead
+thread per GPU (`zephyr_amd.dispatch`), sources of a frequency split over spare GPUs when there are fewer
+frequencies than GPUs -- and the per-GPU partial gradients / data panels are summed on the host.  One
+process per GPU (`shardFreqs`, default on when torch.distributed is initialised): frequencies are sharded
+over ranks and the only collective is one all-reduce of the gradient (problem.py:152,162 sum over
 frequencies) or of the receiver data.
 """
 import numpy as np
@@ -17,6 +21,7 @@ from .config import BaseSCCache
 from .distributors import MultiFreq, ViscoMultiFreq
 from .survey import HelmBaseSurvey, Helm2DSurvey
 from . import parallel
+from . import dispatch
 
 EPS = 1e-15
 
@@ -95,11 +100,62 @@ class HelmBaseProblem(BaseModelDependent, BaseSCCache):
 
     def _solveOwned(self, rhs_list):
         'generator of (ifreq, scaleTerm * sub * rhs) over the owned frequencies'
-        subs = self.system.subProblems
-        scale = self.system.scaleTerm
-        for ifreq in self.ownedFreqs:
+        owned = self.ownedFreqs
+        sysw = self.system
+        if len(owned) == self.survey.nfreq and getattr(sysw, 'parallel', False) and hasattr(sysw, 'devices'):
+            # every frequency is this process's: the wrapper's own dispatch (all visible GPUs, prepare-ahead) does the loop
+            rl = list(rhs_list) if isinstance(rhs_list, (list, tuple)) else rhs_list
+            for ifreq, u in enumerate(sysw * rl):
+                yield ifreq, u
+            return
+        subs = sysw.subProblems
+        scale = sysw.scaleTerm
+        for ifreq in owned:
             r = rhs_list[ifreq] if isinstance(rhs_list, (list, tuple)) else rhs_list
             yield ifreq, scale * (subs[ifreq] * r)
+
+    # ---- device-resident work items ---------------------------------------------------------------------------
+    def _deviceItems(self, owned, ncols):
+        """Work items (worker, operator, ifreq, c0, c1) for the owned frequencies: frequency-major over the system wrapper's
+        devices (a GPU keeps the operators of its frequencies), and when there are fewer frequencies than GPUs the `ncols`
+        source columns of a frequency are split over the spare ones ((frequency, source-batch) items)."""
+        sysw = self.system
+        subs = sysw.subProblems
+        devs = list(sysw.devices) if hasattr(sysw, 'devices') else [subs[0].device]
+        nw = len(devs)
+        split = max(1, nw // max(1, len(owned))) if hasattr(sysw, '_replica') else 1
+        split = min(split, max(1, ncols))
+        items = []
+        for pos, ifreq in enumerate(owned):
+            bounds = [ncols * j // split for j in range(split + 1)]
+            for j in range(split):
+                if j == 0:          # the frequency's own operator, on the worker of the GPU it lives on
+                    op = subs[ifreq]
+                    w = devs.index(op.device) if op.device in devs else (pos * split) % nw
+                    if split > 1 and devs[(pos * split) % nw] == op.device:
+                        w = (pos * split) % nw
+                else:               # a copy of it on a spare GPU for another batch of its sources
+                    w = (pos * split + j) % nw
+                    op = sysw._replica(ifreq, j, devs[w])
+                items.append((w, op, ifreq, bounds[j], bounds[j + 1]))
+        return devs, items
+
+    def _runOnDevices(self, devs, items, fn):
+        """Run fn(state, op, ifreq, c0, c1) for every item on the worker thread of its GPU (`state`: a dict private to that
+        worker, for its device buffers), the factorisation of the worker's next item started ahead of time."""
+        states = [dict(device=d) for d in devs]
+        queues = [[] for _ in devs]
+        for w, op, ifreq, c0, c1 in items:
+            def solve(_p, w=w, op=op, ifreq=ifreq, c0=c0, c1=c1):
+                return fn(states[w], op, ifreq, c0, c1)
+            queues[w].append(dispatch.WorkItem(solve, op.prefactor if hasattr(op, 'prefactor') else None))
+        pipes = dispatch.dispatch(list(zip(devs, queues)), lookahead=1)
+        try:
+            out = [it.future.result() for q in queues for it in q]
+        finally:
+            for p in pipes:
+                p.join()
+        return states, out
 
     # ---- gradient scalers (problem.py:74-85) --------------------------------------------------------------
     def scaledTerms(self, ifreq):
@@ -218,60 +274,89 @@ class HelmBaseProblem(BaseModelDependent, BaseSCCache):
             return False
 
     def _JtvecDevice(self, qb, owned):
-        '''mux branch with wavefields kept in HBM: per owned frequency upload [qf | qb], solve 2*nsrc right-hand
-        sides on the device, accumulate scaler * sum_s uF (.) uB with the imaging kernel; ONE all-reduce of G.'''
+        '''mux branch with wavefields kept in HBM: per work item (frequency, source batch) upload [qf | qb] of its sources, solve them on
+        the item's GPU, accumulate scaler * sum_s uF (.) uB with the imaging kernel into that GPU's partial gradient; partial gradients are
+        summed on the host, then ONE all-reduce over ranks when the frequencies are sharded.'''
         import torch
         sv = self.survey
         nsrc, N = sv.nsrc, self.nrow
-        subs = self.system.subProblems
         scale = complex(self.system.scaleTerm)
-        from .discretization import default_device
-        dev = torch.device('cuda', subs[owned[0]].device if owned else default_device())
-        G = torch.zeros(N, dtype=torch.complex128, device=dev)
         qf = sv.getSources()
-        U = torch.empty((2 * nsrc, N), dtype=torch.complex128, device=dev)
-        R = torch.empty((2 * nsrc, N), dtype=torch.complex128, device=dev)
-        for ifreq in owned:
-            sub = subs[ifreq]
-            sub.rhsFromSparseDevice(sp.hstack((qf[ifreq], qb[ifreq])), R.data_ptr())      # sparse triplets up, dense on the device
+        if not owned:
+            g = np.zeros(N, dtype=np.complex128)
+            return parallel.allreduce_sum(g) if self._sharded else g
+        devs, items = self._deviceItems(owned, nsrc)
+
+        def one(wstate, op, ifreq, c0, c1):
+            dev = torch.device('cuda', op.device)
+            state = wstate.setdefault(('buffers', op.device), {})         # (a worker's buffers live on the GPU of the operator it is running)
+            k = c1 - c0
+            if 'G' not in state:
+                state['G'] = torch.zeros(N, dtype=torch.complex128, device=dev)
+            if state.get('cap', 0) < 2 * k:
+                state['U'] = torch.empty((2 * k, N), dtype=torch.complex128, device=dev)
+                state['R'] = torch.empty((2 * k, N), dtype=torch.complex128, device=dev)
+                state['cap'] = 2 * k
+            U, R = state['U'], state['R']
+            qfi, qbi = sp.csc_matrix(qf[ifreq]), sp.csc_matrix(qb[ifreq])
+            op.rhsFromSparseDevice(sp.hstack((qfi[:, c0:c1], qbi[:, c0:c1])), R.data_ptr())      # sparse triplets up, dense on the device
             scaler = torch.from_numpy(np.ascontiguousarray(self.gradientScaler(ifreq) * scale * scale)).to(dev)
             torch.cuda.synchronize(dev)
-            sub.solveDevice(R.data_ptr(), U.data_ptr(), 2 * nsrc, N)
-            sub.imagingAccumulateDevice(U.data_ptr(), U.data_ptr() + nsrc * N * 16, nsrc, scaler.data_ptr(), G.data_ptr())
-        if self._sharded:
-            parallel.allreduce_sum_device(G)
-        torch.cuda.synchronize(dev)
-        return G.cpu().numpy()
+            op.solveDevice(R.data_ptr(), U.data_ptr(), 2 * k, N)
+            op.imagingAccumulateDevice(U.data_ptr(), U.data_ptr() + k * N * 16, k, scaler.data_ptr(), state['G'].data_ptr())
+            return None
+        states, _ = self._runOnDevices(devs, items, one)
+        parts = [b['G'] for st in states for key, b in st.items() if isinstance(key, tuple) and 'G' in b]
+        if len(parts) == 1:
+            G = parts[0]
+            if self._sharded:
+                parallel.allreduce_sum_device(G)
+            torch.cuda.synchronize(G.device)
+            return G.cpu().numpy()
+        g = np.zeros(N, dtype=np.complex128)
+        for G in parts:                                   # per-GPU partial gradients: 16 B per grid point each
+            torch.cuda.synchronize(G.device)
+            g += G.cpu().numpy()
+        return parallel.allreduce_sum(g) if self._sharded else g
 
     def _dpredDevice(self, owned):
-        '''predicted data with the wavefields kept in HBM (fixed receiver array): per owned frequency the sparse sources are
-        expanded on the device, solved there, and only the receiver samples R u (nrec x nsrc) come back'''
+        '''predicted data with the wavefields kept in HBM (fixed receiver array): per work item (frequency, source batch) the sparse sources are
+        expanded on the item's GPU, solved there, and only the receiver samples R u (nrec x sources) come back'''
         import torch
         sv = self.survey
         nsrc, nrec, N = sv.nsrc, sv.nrec, self.nrow
-        subs = self.system.subProblems
         scale = complex(self.system.scaleTerm)
         data = np.zeros((nrec, nsrc, sv.nfreq), dtype=np.complex128)
         if not owned:
             return data
-        dev = torch.device('cuda', subs[owned[0]].device)
         Rm = sp.csr_matrix(sv.rVec(0))
         Rm.sum_duplicates()
-        csr = (torch.from_numpy(np.ascontiguousarray(Rm.indptr, dtype=np.int64)).to(dev),
-               torch.from_numpy(np.ascontiguousarray(Rm.indices, dtype=np.int64)).to(dev),
-               torch.from_numpy(np.ascontiguousarray(Rm.data, dtype=np.complex128)).to(dev), nrec)
         qf = sv.getSources()
-        R = torch.empty((nsrc, N), dtype=torch.complex128, device=dev)
-        U = torch.empty((nsrc, N), dtype=torch.complex128, device=dev)
-        out = torch.empty((nrec, nsrc), dtype=torch.complex128, device=dev)
-        for ifreq in owned:
-            sub = subs[ifreq]
+        devs, items = self._deviceItems(owned, nsrc)
+
+        def one(wstate, op, ifreq, c0, c1):
+            dev = torch.device('cuda', op.device)
+            state = wstate.setdefault(('buffers', op.device), {})
+            k = c1 - c0
+            if 'csr' not in state:
+                state['csr'] = (torch.from_numpy(np.ascontiguousarray(Rm.indptr, dtype=np.int64)).to(dev),
+                                torch.from_numpy(np.ascontiguousarray(Rm.indices, dtype=np.int64)).to(dev),
+                                torch.from_numpy(np.ascontiguousarray(Rm.data, dtype=np.complex128)).to(dev), nrec)
+            if state.get('cap', 0) < k:
+                state['R'] = torch.empty((k, N), dtype=torch.complex128, device=dev)
+                state['U'] = torch.empty((k, N), dtype=torch.complex128, device=dev)
+                state['out'] = torch.empty((nrec, k), dtype=torch.complex128, device=dev)
+                state['cap'] = k
+            R, U = state['R'], state['U']
+            out = state['out'] if state['cap'] == k else torch.empty((nrec, k), dtype=torch.complex128, device=dev)
             q = qf[ifreq] if isinstance(qf, (list, tuple)) else qf
-            sub.rhsFromSparseDevice(q, R.data_ptr())
-            sub.solveDevice(R.data_ptr(), U.data_ptr(), nsrc, N)
-            sub.sampleDevice(U.data_ptr(), nsrc, csr, out.data_ptr())
+            op.rhsFromSparseDevice(sp.csc_matrix(q)[:, c0:c1], R.data_ptr())
+            op.solveDevice(R.data_ptr(), U.data_ptr(), k, N)
+            op.sampleDevice(U.data_ptr(), k, state['csr'], out.data_ptr())
             torch.cuda.synchronize(dev)
-            data[:, :, ifreq] = scale * out.cpu().numpy()
+            data[:, c0:c1, ifreq] = scale * out.cpu().numpy()          # (disjoint slices per item: no two workers write the same entries)
+            return None
+        self._runOnDevices(devs, items, one)
         return data
 
     @property
