@@ -279,6 +279,9 @@ def main():
     ap.add_argument('--method', default='auto')
     ap.add_argument('--no-plain-pass', action='store_true', help='skip the extra un-profiled pass over the same work items')
     ap.add_argument('--no-cpu-2n', action='store_true', help='skip the faithful 2N x 2N Eurus LU baseline at 512^2 (~1 min, ~11 GB)')
+    ap.add_argument('--layout', choices=('node', 'rhs'), default='node',
+                    help="device buffers of the timed region: 'node' = the reference's (N, nsrc) C-order arrays (default), 'rhs' = one right-hand side per row")
+    ap.add_argument('--no-host-api', action='store_true', help='skip the host-array leg (MultiFreq * q with numpy / scipy-sparse in, numpy out; ~5 s)')
     ap.add_argument('--no-pipeline', dest='pipeline', action='store_false',
                     help='work items strictly one after the other (no prepare-ahead thread, no helm_prefactor)')
     ap.add_argument('--no-config5', action='store_true', help='skip the 3-D leg (BASELINE configs[4]: 256x256x128, 4 freqs x 16 sources; ~15 s)')
@@ -323,9 +326,15 @@ def main():
     N = n * n
 
     # all right-hand sides of the job are staged in HBM before the timed region
-    q_all = src(locs).toarray()                              # (N, 256) complex
-    d_rhs = torch.from_numpy(np.ascontiguousarray(q_all.T)).to(dev)      # [256][N]
-    d_u = torch.empty((B, N), dtype=torch.complex128, device=dev)
+    q_sparse = src(locs)                                     # (N, 256) scipy-sparse: what the surveys hand to `system * q`
+    q_all = q_sparse.toarray()                               # (N, 256) complex
+    node = args.layout == 'node' and B == NSRC
+    if node:            # the reference's own array layout: (N, nsrc) C-order in, (N, nsrc) C-order out (discretization.py:101-103)
+        d_rhs = torch.from_numpy(np.ascontiguousarray(q_all)).to(dev)        # [N][256]
+        d_u = torch.empty((N, B), dtype=torch.complex128, device=dev)
+    else:               # one right-hand side per row (the C ABI's default layout)
+        d_rhs = torch.from_numpy(np.ascontiguousarray(q_all.T)).to(dev)      # [256][N]
+        d_u = torch.empty((B, N), dtype=torch.complex128, device=dev)
 
     ops = {}
 
@@ -343,8 +352,8 @@ def main():
     def solve_item(w, op, ubuf=None):
         ubuf = d_u if ubuf is None else ubuf
         fi, bi = work_item(w, nb)
-        rhs_ptr = d_rhs.data_ptr() + bi * B * N * 16
-        info = op.solveDevice(rhs_ptr, ubuf.data_ptr(), B, N)
+        rhs_ptr = d_rhs.data_ptr() + (0 if node else bi * B * N * 16)
+        info = op.solveDevice(rhs_ptr, ubuf.data_ptr(), B, N, layout='node' if node else 'rhs')
         t = op.lastTiming()
         del op.factors                   # nothing is carried over between steps
         return fi, info, t
@@ -481,6 +490,8 @@ def main():
             'unprofiled': None if elapsed_plain is None else {'value': wavefields / elapsed_plain, 'ms_per_step': 1e3 * elapsed_plain / args.steps},
             'config': {'workload': 'Eurus 2D isotropic %dx%d synthetic-Marmousi (seed 20240512, dx=%g m), 16 freqs 2-9.5 Hz x 256 Kaiser sources; '
                                    'step = create + assemble 1 frequency + solve %d sources to true relres<=%g (method=%s: %s)' % (n, n, dx, B, args.rtol, args.method, how),
+                       'buffers': ("node-major: right-hand sides and wavefields in the reference's own (N, nsrc) C-order arrays, resident in HBM" if node else
+                                   'rhs-major: one right-hand side / wavefield per row, resident in HBM'),
                        'grid': [n, n], 'sources_per_step': B, 'work_items_in_flight': args.streams, 'freqs_hz_this_run': agg['freqs'], 'sharding': 'work items (freq, source batch) round-robin over ranks',
                        'solves_or_iterations_per_rhs_mean': float(np.mean(iters)) if iters else None,
                        'solves_or_iterations_per_rhs_max': int(np.max(iters)) if iters else None,
@@ -544,6 +555,39 @@ def main():
                 out['stencil_roofline']['traffic_source'] = 'profiles/r02_pmc_traffic_resid_nm.json (HBM bytes per k_resid_nm launch)'
         except Exception:
             pass
+        if world == 1 and not args.no_host_api and direct:
+            # The reference's actual call shape (discretization.py:101-103, distributors.py:127-173): `MultiFreq(systemConfig) * q` with a
+            # scipy-sparse source matrix in and one (N, nsrc) numpy array per frequency out -- all 16 frequencies of the job, every
+            # wavefield copied back to the host (4.3 GB per frequency over PCIe into pinned memory).  PCIe-inclusive: never `value`.
+            try:
+                from zephyr_amd import MultiFreq
+                del d_u
+                torch.cuda.empty_cache()
+                best = None
+                for wpd in (1, 2):
+                    os.environ['HELM_WORKERS_PER_DEVICE'] = str(wpd)
+                    sch = dict(cfg); sch.update(freqs=[float(f) for f in freqs], Disc=Eurus, rtol=args.rtol, maxit=400000, method=args.method, batch=NSRC)
+                    mf = MultiFreq(sch)
+                    torch.cuda.synchronize()
+                    th0 = time.perf_counter()
+                    chk = 0.0
+                    for u in mf * q_sparse:
+                        chk += float(abs(u[N // 2 + 7, 0]))       # touch the result; the array goes back to the pinned pool when dropped
+                        del u
+                    th = time.perf_counter() - th0
+                    del mf.factors
+                    rec = {'value': NFREQ * NSRC / th, 'unit': 'wavefields/s', 'seconds': th, 'workers_per_device': wpd}
+                    if best is None or rec['value'] > best['value']:
+                        best = rec
+                    out.setdefault('value_host_api_runs', []).append(rec)
+                os.environ.pop('HELM_WORKERS_PER_DEVICE', None)
+                best = dict(best)
+                best['what'] = ('MultiFreq(Disc=Eurus, 16 freqs) * q, q = scipy-sparse (N, 256) Kaiser sources, results = 16 numpy arrays (N, 256) complex128 in pinned host '
+                                'memory; includes operator construction, assembly, factorisation, the solves and the device-to-host copy of every wavefield')
+                out['value_host_api'] = best
+            except Exception as exc:
+                out['value_host_api'] = 'failed: %s' % exc
+            d_u = torch.empty((N, B) if node else (B, N), dtype=torch.complex128, device=dev)
         if world == 1 and not args.no_config5 and n == 1024:
             try:
                 del d_u
@@ -551,7 +595,7 @@ def main():
                 out['config5'] = config5_leg(local, rtol=args.config5_rtol)
             except Exception as exc:
                 out['config5'] = 'failed: %s' % exc
-            d_u = torch.empty((B, N), dtype=torch.complex128, device=dev)
+            d_u = torch.empty((N, B) if node else (B, N), dtype=torch.complex128, device=dev)
         if world == 1 and not args.no_cpu:
             cb, u_lu = cpu_baseline(cfg, freqs, q_all)
             out['cpu_baseline'] = cb
@@ -561,8 +605,10 @@ def main():
                 u_lu = u_lu[:, :ns]
                 sc = dict(cfg); sc.update(freq=cb['freq_hz'], rtol=args.rtol, maxit=400000, method=args.method, batch=B, device=local)
                 opp = Eurus(sc)
-                opp.solveDevice(d_rhs.data_ptr(), d_u.data_ptr(), ns, N)
-                u_gpu = d_u[:ns].cpu().numpy().T
+                d_rp = torch.from_numpy(np.ascontiguousarray(q_all[:, :ns].T)).to(dev)
+                d_up = torch.empty((ns, N), dtype=torch.complex128, device=dev)
+                opp.solveDevice(d_rp.data_ptr(), d_up.data_ptr(), ns, N)
+                u_gpu = d_up.cpu().numpy().T
                 rel = np.linalg.norm(u_gpu - u_lu, axis=0) / np.linalg.norm(u_lu, axis=0)
                 out['parity_vs_lu_max_rel'] = float(rel.max())
                 out['parity_vs_lu'] = {'freq_hz': cb['freq_hz'], 'sources': int(ns), 'grid': [n, n], 'tolerance': 1e-7, 'ok': bool(rel.max() <= 1e-7),

@@ -42,6 +42,8 @@
 #ifndef HELM_H
 #define HELM_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -76,13 +78,19 @@ enum {
     HELM_ERR_PML = -5          /* Eurus PML profile length hazard (reference raises ValueError, eurus.py:84-91) */
 };
 
+/* buffer layouts of the solve entry points (helm_solve_opts.flags).  Default (0): one right-hand side / wavefield per row,
+ * X[r*rows + i] (what np.ascontiguousarray(rhs.T) gives).  NODE_MAJOR: the reference's own (rows, nrhs) C-order arrays,
+ * X[i*nrhs + r] -- what `Disc * rhs` receives and what lu.solve returns (discretization.py:101-103).  With both set the direct
+ * path uses the right-hand sides where they lie and writes the wavefield from the kernel that checks its residual: no transposes. */
+enum { HELM_RHS_NODE_MAJOR = 1, HELM_OUT_NODE_MAJOR = 2, HELM_NODE_MAJOR = 3 };
+
 typedef struct helm_solve_opts {
     int method;        /* HELM_BICGSTAB | HELM_CGNR | HELM_AUTO | HELM_MG | HELM_DIRECT */
     double rtol;       /* stop when ||q' - A u||_2 / ||q'||_2 <= rtol (q' = premul*rhs), per RHS */
     int maxit;         /* iteration cap per right-hand side */
     int check_every;   /* iterations between host-side convergence checks (0 = default) */
     int batch;         /* right-hand sides iterated together on the device (0 = default) */
-    int flags;         /* reserved, 0 */
+    int flags;         /* buffer layouts: 0, or HELM_RHS_NODE_MAJOR | HELM_OUT_NODE_MAJOR */
 } helm_solve_opts;
 
 typedef struct helm_solve_info {
@@ -149,6 +157,15 @@ int helm_solve_device(helm_op *op, const void *dRHS, void *dU, int nrhs, long lo
                       double premul_re, double premul_im,
                       const helm_solve_opts *opts, helm_solve_info *info);
 
+/* Sparse right-hand sides given as host COO triplets (row: int64, col: int32 = right-hand side, val: complex128; no duplicates) --
+ * the reference's scipy-sparse source matrices (survey.py:162-169), which problemo densifies on the host before the LU solve.
+ * Here only the triplets cross PCIe; U (host, nrhs*rows complex128, layout per opts->flags) receives the wavefields. */
+int helm_solve_coo(helm_op *op, const long long *row, const int *col, const double *val, long long nnz, double *U, int nrhs,
+                   long long rows, double premul_re, double premul_im, const helm_solve_opts *opts, helm_solve_info *info);
+/* Pinned host memory for result arrays (device-to-host copies into it run at the PCIe rate); recycled by size. */
+void *helm_host_alloc(size_t bytes);
+void helm_host_free(void *p, size_t bytes);
+
 /* Start the factorisation the next helm_solve[_device] on this handle will need, without waiting for it: the launches go to
  * a high-priority stream of the handle and run beside whatever other handles are doing on the GPU (a dispatcher solving
  * frequency k calls this for frequency k+1: the latency-bound top of the elimination tree then hides under the
@@ -189,6 +206,9 @@ int helm_imaging_accumulate_device(helm_op *op, const void *dUF, const void *dUB
  * row: int64, col: int32, val: complex128, all device pointers. */
 int helm_rhs_from_coo_device(helm_op *op, const void *d_row, const void *d_col, const void *d_val, long long nnz,
                              void *dR, int nrhs, long long rows);
+/* the same with the layout of R chosen by `flags` (HELM_RHS_NODE_MAJOR: R[row[k]*nrhs + col[k]]) */
+int helm_rhs_from_coo_device_layout(helm_op *op, const void *d_row, const void *d_col, const void *d_val, long long nnz,
+                                    void *dR, int nrhs, long long rows, int flags);
 /* Receiver sampling data = R u (survey.py:152-160): out[r][s] = sum_k val[k] * U[s][col[k]] over the entries k of CSR
  * row r (rowptr, col: int64; val: complex128; U: nsrc x ld; out: nrec x nsrc complex128; device pointers). */
 int helm_sample_device(helm_op *op, const void *dU, int nsrc, long long ld, const void *d_rowptr, const void *d_col,

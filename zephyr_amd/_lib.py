@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, 'libhelm.so')
 
 HELM_MINIZEPHYR, HELM_EURUS, HELM_3D = 0, 1, 2
 HELM_BICGSTAB, HELM_CGNR, HELM_AUTO, HELM_MG, HELM_DIRECT = 0, 1, 2, 3, 4
+HELM_RHS_NODE_MAJOR, HELM_OUT_NODE_MAJOR, HELM_NODE_MAJOR = 1, 2, 3
 METHODS = {'bicgstab': HELM_BICGSTAB, 'cgnr': HELM_CGNR, 'auto': HELM_AUTO, 'mg': HELM_MG, 'direct': HELM_DIRECT}
 
 ERRORS = {-1: 'HELM_ERR_ARG', -2: 'HELM_ERR_DEVICE', -3: 'HELM_ERR_STATE', -4: 'HELM_ERR_UNSUPPORTED', -5: 'HELM_ERR_PML'}
@@ -67,6 +68,12 @@ _SIGNATURES = {
                                   ctypes.c_double, ctypes.c_double, ctypes.POINTER(SolveOpts), ctypes.POINTER(SolveInfo)]),
     'helm_solve_device': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong,
                                          ctypes.c_double, ctypes.c_double, ctypes.POINTER(SolveOpts), ctypes.POINTER(SolveInfo)]),
+    'helm_solve_coo': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int,
+                                      ctypes.c_longlong, ctypes.c_double, ctypes.c_double, ctypes.POINTER(SolveOpts), ctypes.POINTER(SolveInfo)]),
+    'helm_host_alloc': (ctypes.c_void_p, [ctypes.c_size_t]),
+    'helm_host_free': (None, [ctypes.c_void_p, ctypes.c_size_t]),
+    'helm_rhs_from_coo_device_layout': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong,
+                                                       ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_int]),
     'helm_prefactor': (ctypes.c_int, [ctypes.c_void_p]),
     'helm_last_timing': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Timing)]),
     'helm_set_profiling': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
@@ -136,6 +143,38 @@ def require_gpu():
     if n <= 0:
         raise HelmError(-2, 'no HIP device visible (%s); libhelm has no CPU path' % last_error(None))
     return n
+
+
+class _PinnedBlock(object):
+    'owner of one helm_host_alloc buffer; numpy arrays made from it keep it alive (it is their .base)'
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        self.ptr = load().helm_host_alloc(self.nbytes)
+        if not self.ptr:
+            raise MemoryError('helm_host_alloc(%d) failed' % self.nbytes)
+        self.__array_interface__ = {'shape': (self.nbytes,), 'typestr': '|u1', 'data': (self.ptr, False), 'version': 3}
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                load().helm_host_free(self.ptr, self.nbytes)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.complex128):
+    """np.empty in pinned host memory (device-to-host copies into it run at the PCIe rate, into pageable memory at a fraction of
+    it); falls back to ordinary memory when pinning fails."""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    if n == 0:
+        return np.empty(shape, dtype=dtype)
+    try:
+        block = _PinnedBlock(n)
+    except Exception:
+        return np.empty(shape, dtype=dtype)
+    return np.asarray(block).view(dtype).reshape(shape)
 
 
 def ptr(arr):

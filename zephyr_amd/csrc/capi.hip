@@ -794,11 +794,17 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
     // Node-major pipeline (single-block systems): the right-hand sides are transposed once on the way in (fused with premul /
     // the norm), stay [cell][rhs] through solve, true residual and refinement, and are transposed once on the way out.
     const bool nm = use_nm && !sys2 && (!factor_pending || nm_overlap);
+    // HELM_NODE_MAJOR (both buffers in the reference's (N, nrhs) layout; helm_solve_device only passes it for one batch of a single-block system):
+    // the right-hand sides are used where they lie -- premul moves to the output, u = conj(premul A^-1 q), the relative residual does not see
+    // it -- ||q||^2 comes out of the first residual launch, and the wavefield is written by the launch that checks it
+    const bool native_nm = nm && (o.flags & HELM_NODE_MAJOR) == HELM_NODE_MAJOR && nrhs <= Bmax && !sub && row_off == 0 && dUconj;
+    if ((o.flags & HELM_NODE_MAJOR) && !native_nm) HELM_FAIL(op, HELM_ERR_STATE, "direct solver: node-major buffers reached a path that cannot take them");
     for (int first = 0; nm && first < nrhs; first += Bmax) {
         const int n = std::min(Bmax, nrhs - first);
         const NdPlan &P = f->pd->plan;
         cplx *Qt = (cplx *)lease.ptr, *Xt = Qt + (long long)Bmax * N, *Rt = Xt + (long long)Bmax * N, *Dt = Rt + (long long)Bmax * N, *arenaV = Dt + (long long)Bmax * N;
         (void)P;
+        if (native_nm) Qt = const_cast<cplx *>(dRHS);             // read only from here on (the residual is stored to Rt, never over q)
         cplx *xout = cj ? dUconj + (long long)first * N : dXout + (long long)first * N;
         const cplx *rhs_b = dRHS + (long long)first * rhs_ld;
         const cplx *sub_b = sub ? sub + (long long)first * N : nullptr;
@@ -806,9 +812,14 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
         int *d_cols = (int *)(ptail + (size_t)Bmax * 2 * sizeof(double));
         int *h_cols = (int *)(htail + (size_t)op->scal_cap * 2 * sizeof(double));
         int nb_part = 0;
-        rc = nd_prep_transpose_norm(op, rhs_b, rhs_ld, row_off, premul, sub_b, Qt, N, n, (double *)op->d_part, nblk, &nb_part);
-        if (rc) return rc;
-        helm_launch_fin_ex(op, FIN_NORM, n, nb_part, nullptr, d_aux + n);           // ||q'||^2
+        if (!native_nm) {
+            rc = nd_prep_transpose_norm(op, rhs_b, rhs_ld, row_off, premul, sub_b, Qt, N, n, (double *)op->d_part, nblk, &nb_part);
+            if (rc) return rc;
+            helm_launch_fin_ex(op, FIN_NORM, n, nb_part, nullptr, d_aux + n);           // ||q'||^2
+        }
+        bool have_qnorm = !native_nm;
+        NdResidExtra rex;
+        if (native_nm) { rex.Uout = dUconj; rex.ldu = n; rex.oscale = premul; }
         if (factor_pending) {
             float fms = 0.f;
             rc = nd_factor_solve_nm(op, block, f, ws_factor, nullptr, Qt, Xt, n, arenaV, op->side_stream, &fms);
@@ -825,9 +836,11 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
         double prev_worst = 0.0;
         // every pass ends with the TRUE residual q' - A x of the vector that is returned (norms only); q' is kept for that
         auto true_residual_norms = [&]() -> int {
-            int r1 = nd_resid_nm(op, planes, Xt, n, Qt, n, nullptr, n, 0, nullptr, (double *)op->d_part, nblk, &nb_part);
+            rex.qnorm = have_qnorm ? 0 : 1;
+            int r1 = nd_resid_nm(op, planes, Xt, n, Qt, n, nullptr, n, 0, nullptr, (double *)op->d_part, nblk, &nb_part, native_nm ? &rex : nullptr);
             if (r1) return r1;
-            helm_launch_fin_ex(op, FIN_NORM, n, nb_part, nullptr, d_aux);
+            helm_launch_fin_ex(op, have_qnorm ? FIN_NORM : FIN_NORM2, n, nb_part, nullptr, d_aux);
+            have_qnorm = true;
             HIP_TRY(op, hipMemcpyAsync(h_aux, d_aux, 2 * n * sizeof(double), hipMemcpyDeviceToHost, op->stream));
             HIP_TRY(op, hipStreamSynchronize(op->stream));
             for (int b = 0; b < n; ++b) { qq[b] = h_aux[n + b]; relres[b] = qq[b] > 0 ? sqrt(h_aux[b] / qq[b]) : 0.0; }
@@ -873,8 +886,10 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
             rc = true_residual_norms();
             if (rc) return rc;
         }
-        rc = nd_transpose_out(op, Xt, N, n, xout, cj);
-        if (rc) return rc;
+        if (!native_nm) {           // (node-major callers: the last residual launch has written conj(premul x) already)
+            rc = nd_transpose_out(op, Xt, N, n, xout, cj);
+            if (rc) return rc;
+        }
         // Right-hand sides refinement left above rtol: is the residual at the floor fp64 allows (relres ~ eps || |A||x| + |q| || / ||q||,
         // see the coupled-system branch below)?  Evaluated node-major with |planes| and |x|; ||.|| of the sum bounded by the sum of norms.
         std::vector<int> at_floor(n, 0);
@@ -1419,18 +1434,52 @@ extern "C" int helm_solve_device(helm_op *op, const void *dRHS, void *dU, int nr
     const size_t xbytes = (size_t)nrhs * N * sizeof(cplx);
     cplx *dX = (cplx *)helm_pool_alloc(op->device, xbytes);
     if (!dX) { hipEventDestroy(e0); hipEventDestroy(e1); HELM_FAIL(op, HELM_ERR_DEVICE, "hipMalloc failed"); }
-    auto cleanup = [&]() { hipStreamSynchronize(op->stream); helm_pool_free(op->device, dX, xbytes); hipEventDestroy(e0); hipEventDestroy(e1); };
+    // Buffer layouts (opts.flags): HELM_RHS_NODE_MAJOR / HELM_OUT_NODE_MAJOR = the reference's (rows, nrhs) C-order arrays.  The direct path
+    // takes both natively for one batch of a single-block system (no transposes at all); every other combination goes through rhs-major
+    // temporaries here, so all paths below see one right-hand side per row.
+    const int lay = o.flags & HELM_NODE_MAJOR;
+    o.flags &= ~HELM_NODE_MAJOR;
+    const void *dRHS_use = dRHS; void *dU_use = dU;
+    cplx *tR = nullptr, *tU = nullptr;
+    const size_t lbytes = (size_t)nrhs * rows * sizeof(cplx);
+    auto cleanup = [&]() { hipStreamSynchronize(op->stream); helm_pool_free(op->device, dX, xbytes); helm_pool_free(op->device, tR, lbytes); helm_pool_free(op->device, tU, lbytes);
+                           hipEventDestroy(e0); hipEventDestroy(e1); };
+    bool native_done = false;
+    if (lay == HELM_NODE_MAJOR && op->ny == 0 && rows == N && !op->direct_failed && (o.method == HELM_AUTO || o.method == HELM_DIRECT) &&
+        (op->variant == HELM_MINIZEPHYR || op->block_zero[2]) && !testing_hook("HELM_ND_INJECT_FAILURE") && !testing_hook("HELM_ND_INJECT_STALL") &&
+        !(getenv("HELM_AUTO_DIRECT") && atoi(getenv("HELM_AUTO_DIRECT")) == 0 && o.method == HELM_AUTO)) {
+        helm_solve_opts on = o; on.flags |= HELM_NODE_MAJOR;
+        const int rcn = solve_block_direct(op, 0, (const cplx *)dRHS, nrhs, 0, premul, nullptr, nullptr, nrhs, on, info, 0, 0, (cplx *)dU);
+        if (rcn == 0) native_done = true;
+        else if (info) for (int r = 0; r < nrhs; ++r) { info[r].iterations = 0; info[r].status = 0; info[r].restarts = 0; info[r].method = o.method; info[r].relres = 0.0; }
+        // (anything else -- too many right-hand sides for one batch, a right-hand side above rtol, a failed factorisation: the general path)
+    }
+    if (lay && !native_done) {
+        if (lay & HELM_RHS_NODE_MAJOR) {
+            tR = (cplx *)helm_pool_alloc(op->device, lbytes);
+            if (!tR) { cleanup(); HELM_FAIL(op, HELM_ERR_DEVICE, "hipMalloc failed"); }
+            const int rct = nd_transpose(op, (const cplx *)dRHS, rows, nrhs, tR);
+            if (rct) { cleanup(); return rct; }
+            dRHS_use = tR;
+        }
+        if (lay & HELM_OUT_NODE_MAJOR) {
+            tU = (cplx *)helm_pool_alloc(op->device, lbytes);
+            if (!tU) { cleanup(); HELM_FAIL(op, HELM_ERR_DEVICE, "hipMalloc failed"); }
+            dU_use = tU;
+        }
+    }
 
-    if (op->variant == HELM_EURUS && !op->block_zero[2]) {
+    if (native_done) {
+    } else if (op->variant == HELM_EURUS && !op->block_zero[2]) {
         // eps != delta: M3 != 0, the two fields are coupled -> Jacobi-BiCGSTAB on the full 2N x 2N system
         // (eurus.py:430-464,512-533); N-row right-hand sides are zero-padded and the result clipped
         cplx *dW = nullptr;
         if (hipMalloc(&dW, (size_t)nrhs * 2 * N * sizeof(cplx)) != hipSuccess) { cleanup(); HELM_FAIL(op, HELM_ERR_DEVICE, "hipMalloc failed"); }
-        int rc = solve_block(op, 0, (const cplx *)dRHS, rows, 0, premul, nullptr, dW, nrhs, o, info, 1, rows);
+        int rc = solve_block(op, 0, (const cplx *)dRHS_use, rows, 0, premul, nullptr, dW, nrhs, o, info, 1, rows);
         if (rc >= 0) {
             result = rc;
-            rc = helm_launch_finish_ex(op, dW, 2 * N, 0, (cplx *)dU, rows, 0, nrhs);
-            if (!rc && stacked) rc = helm_launch_finish_ex(op, dW, 2 * N, N, (cplx *)dU, rows, N, nrhs);
+            rc = helm_launch_finish_ex(op, dW, 2 * N, 0, (cplx *)dU_use, rows, 0, nrhs);
+            if (!rc && stacked) rc = helm_launch_finish_ex(op, dW, 2 * N, N, (cplx *)dU_use, rows, N, nrhs);
             if (!rc && hipStreamSynchronize(op->stream) != hipSuccess) rc = HELM_ERR_DEVICE;
         }
         hipFree(dW);
@@ -1439,11 +1488,11 @@ extern "C" int helm_solve_device(helm_op *op, const void *dRHS, void *dU, int nr
         // Eurus with an N-row right-hand side: zero-padded second field => v = 0 and M1 u = q
         // when M3 == 0 (eurus.py:512-533)
         bool wrote_u = false;        // rows == N here: the direct path writes conj(x) into dU itself
-        int rc = solve_block(op, 0, (const cplx *)dRHS, rows, 0, premul, nullptr, dX, nrhs, o, info, 0, 0, (cplx *)dU, &wrote_u);
+        int rc = solve_block(op, 0, (const cplx *)dRHS_use, rows, 0, premul, nullptr, dX, nrhs, o, info, 0, 0, (cplx *)dU_use, &wrote_u);
         if (rc < 0) { cleanup(); return rc; }
         result = rc;
         if (!wrote_u) {
-            rc = helm_launch_finish(op, dX, (cplx *)dU, rows, nrhs, 0);
+            rc = helm_launch_finish(op, dX, (cplx *)dU_use, rows, nrhs, 0);
             if (rc) { cleanup(); return rc; }
         }
     } else {
@@ -1452,22 +1501,26 @@ extern "C" int helm_solve_device(helm_op *op, const void *dRHS, void *dU, int nr
         if (hipMalloc(&dV, (size_t)nrhs * N * sizeof(cplx)) != hipSuccess || hipMalloc(&dT, (size_t)nrhs * N * sizeof(cplx)) != hipSuccess) {
             hipFree(dV); cleanup(); HELM_FAIL(op, HELM_ERR_DEVICE, "hipMalloc failed");
         }
-        int rc = solve_block(op, 3, (const cplx *)dRHS, rows, N, premul, nullptr, dV, nrhs, o, info);
+        int rc = solve_block(op, 3, (const cplx *)dRHS_use, rows, N, premul, nullptr, dV, nrhs, o, info);
         if (rc >= 0) {
             result = rc;
             ApplyArgs a = ApplyArgs();
             a.planes = op->d_C + 1LL * 9 * N; a.X = dV; a.Y = dT; a.W = nullptr; a.ld = N; a.nrhs = nrhs; a.scaled = 0; a.adjoint = 0;
             a.epi = EPI_NONE; a.scal = nullptr; a.part = nullptr;
             rc = helm_launch_apply(op, a);
-            if (!rc) rc = solve_block(op, 0, (const cplx *)dRHS, rows, 0, premul, dT, dX, nrhs, o, info);
+            if (!rc) rc = solve_block(op, 0, (const cplx *)dRHS_use, rows, 0, premul, dT, dX, nrhs, o, info);
             if (rc >= 0) {
                 result = std::max(result, rc);
-                rc = helm_launch_finish(op, dX, (cplx *)dU, rows, nrhs, 0);
-                if (!rc) rc = helm_launch_finish(op, dV, (cplx *)dU, rows, nrhs, N);
+                rc = helm_launch_finish(op, dX, (cplx *)dU_use, rows, nrhs, 0);
+                if (!rc) rc = helm_launch_finish(op, dV, (cplx *)dU_use, rows, nrhs, N);
             }
         }
         hipFree(dV); hipFree(dT);
         if (rc < 0) { cleanup(); return rc; }
+    }
+    if (tU) {
+        const int rct = nd_transpose(op, tU, nrhs, rows, (cplx *)dU);
+        if (rct) { cleanup(); return rct; }
     }
     HIP_TRY(op, hipEventRecord(e1, op->stream));
     HIP_TRY(op, hipStreamSynchronize(op->stream));
@@ -1503,6 +1556,46 @@ extern "C" int helm_rhs_from_coo_device(helm_op *op, const void *d_row, const vo
     if (rc) return rc;
     HIP_TRY(op, hipStreamSynchronize(op->stream));
     return HELM_OK;
+}
+
+extern "C" int helm_rhs_from_coo_device_layout(helm_op *op, const void *d_row, const void *d_col, const void *d_val, long long nnz, void *dR, int nrhs, long long rows, int flags) {
+    if (!op || !dR || nrhs < 1 || rows < 1 || nnz < 0 || (nnz > 0 && (!d_row || !d_col || !d_val))) return HELM_ERR_ARG;
+    HIP_TRY(op, hipSetDevice(op->device));
+    int rc = helm_launch_rhs_from_coo(op, (const long long *)d_row, (const int *)d_col, (const cplx *)d_val, nnz, (cplx *)dR, nrhs, rows, (flags & HELM_RHS_NODE_MAJOR) ? 1 : 0);
+    if (rc) return rc;
+    HIP_TRY(op, hipStreamSynchronize(op->stream));
+    return HELM_OK;
+}
+
+// Pinned host memory for the caller's result arrays (recycled by size): device-to-host copies into it run at the PCIe rate, into
+// pageable memory at a fraction of it.
+extern "C" void *helm_host_alloc(size_t bytes) { return bytes ? helm_hostpool_alloc(bytes) : nullptr; }
+extern "C" void helm_host_free(void *p, size_t bytes) { helm_hostpool_free(p, bytes); }
+
+// Host-side sparse right-hand sides (the reference's scipy-sparse source matrices, survey.py:162-169): only the triplets cross PCIe,
+// the dense right-hand sides exist on the device alone; the wavefields come back into U (host; pinned memory from helm_host_alloc
+// makes that copy run at the PCIe rate).  Layout of U and of the implied dense right-hand sides per opts->flags.
+extern "C" int helm_solve_coo(helm_op *op, const long long *row, const int *col, const double *val, long long nnz, double *U, int nrhs, long long rows,
+                              double premul_re, double premul_im, const helm_solve_opts *opts, helm_solve_info *info) {
+    if (!op || !U || nrhs < 1 || rows < 1 || nnz < 0 || (nnz > 0 && (!row || !col || !val))) return HELM_ERR_ARG;
+    HIP_TRY(op, hipSetDevice(op->device));
+    const size_t bytes = (size_t)nrhs * rows * sizeof(cplx);
+    const size_t tb = (size_t)std::max<long long>(nnz, 1) * (sizeof(long long) + sizeof(int) + sizeof(cplx));
+    void *dR = helm_pool_alloc(op->device, bytes), *dU = helm_pool_alloc(op->device, bytes), *dT = helm_pool_alloc(op->device, tb);
+    auto release = [&]() { hipStreamSynchronize(op->stream); helm_pool_free(op->device, dR, bytes); helm_pool_free(op->device, dU, bytes); helm_pool_free(op->device, dT, tb); };
+    if (!dR || !dU || !dT) { release(); HELM_FAIL(op, HELM_ERR_DEVICE, "hipMalloc failed"); }
+    long long *d_row = (long long *)dT; cplx *d_val = (cplx *)(d_row + std::max<long long>(nnz, 1)); int *d_col = (int *)(d_val + std::max<long long>(nnz, 1));
+    int rc = HELM_OK;
+    if (nnz > 0 && (hipMemcpyAsync(d_row, row, nnz * sizeof(long long), hipMemcpyHostToDevice, op->stream) != hipSuccess ||
+                    hipMemcpyAsync(d_val, val, nnz * sizeof(cplx), hipMemcpyHostToDevice, op->stream) != hipSuccess ||
+                    hipMemcpyAsync(d_col, col, nnz * sizeof(int), hipMemcpyHostToDevice, op->stream) != hipSuccess)) rc = HELM_ERR_DEVICE;
+    const int flags = opts ? opts->flags : 0;
+    if (!rc) rc = helm_launch_rhs_from_coo(op, d_row, d_col, d_val, nnz, (cplx *)dR, nrhs, rows, (flags & HELM_RHS_NODE_MAJOR) ? 1 : 0);
+    if (!rc && hipStreamSynchronize(op->stream) != hipSuccess) rc = HELM_ERR_DEVICE;
+    if (!rc) rc = helm_solve_device(op, dR, dU, nrhs, rows, premul_re, premul_im, opts, info);
+    if (rc >= 0 && hipMemcpy(U, dU, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = HELM_ERR_DEVICE;
+    release();
+    return rc;
 }
 
 extern "C" int helm_sample_device(helm_op *op, const void *dU, int nsrc, long long ld, const void *d_rowptr, const void *d_col, const void *d_val, int nrec, void *d_out) {

@@ -1101,10 +1101,14 @@ __global__ __launch_bounds__(256) void k_prep_transpose_norm(const cplx *__restr
 //   q   : Q[cell * ldq + map(j)]   (map = qmap[j] or j)           r = q - A xin
 //   store != 0: r written to Rout (same indexing as q; Rout == null: over q)
 //   part[(j * 4) * nblk + block] = partial ||r_j||^2
+//   qnorm != 0: part[(j * 4 + 1) * nblk + block] = partial ||q_j||^2 (node-major callers: q is read here anyway, no separate norm pass)
+//   Uout != null: Uout[cell * ldu + j] = conj(oscale * xin[cell][j]) -- the wavefield in the reference's (N, nrhs) layout and sign
+//                 convention (discretization.py:101-103), written by the launch that checks it (one write instead of a read + write pass)
 template <int RPT>
 __global__ __launch_bounds__(256) void k_resid_nm(const cplx *__restrict__ planes, int nz, int nx, const cplx *__restrict__ Xin, int ldin,
                                                   cplx *__restrict__ Q, int ldq, const int *__restrict__ qmap, int ncol, int store,
-                                                  cplx *__restrict__ Rout, double *__restrict__ part, int nblk, int seg, int ntiles) {
+                                                  cplx *__restrict__ Rout, double *__restrict__ part, int nblk, int seg, int ntiles,
+                                                  int qnorm, cplx *__restrict__ Uout, int ldu, cplx oscale) {
     // RPT grid rows per thread: the window is (RPT + 2) x 3, so a step along x loads RPT + 2 values for RPT outputs and the rows a tile
     // shares with the tiles above and below (the only HBM re-reads of this kernel: 1.7 x the input at RPT = 1 by the PMC counters) shrink
     // from 2 per output row to 2 / RPT
@@ -1114,7 +1118,7 @@ __global__ __launch_bounds__(256) void k_resid_nm(const cplx *__restrict__ plane
     const int col = act ? (qmap ? qmap[j] : j) : 0;
     const long long N = (long long)nz * nx;
     const int nzt = (nz + RPT - 1) / RPT;
-    double acc = 0.0;
+    double acc = 0.0, accq = 0.0;
     // tile order: workgroup b serves band (b % 8) of the tile list, so that the workgroups of one XCD (b, b + 8, ...) walk
     // z-adjacent row segments together and the halo rows are served by that XCD's L2
     const int per = (ntiles + 7) / 8;
@@ -1145,6 +1149,7 @@ __global__ __launch_bounds__(256) void k_resid_nm(const cplx *__restrict__ plane
                 if (z >= nz) break;
                 const long long cell = (long long)z * nx + x;
                 cplx r = Q[cell * ldq + col];
+                if (qnorm) accq += cabs2(r);
                 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
                     const cplx c = planes[(long long)k * N + cell];
@@ -1153,6 +1158,7 @@ __global__ __launch_bounds__(256) void k_resid_nm(const cplx *__restrict__ plane
                     r.y = fma(-c.x, xv.y, r.y); r.y = fma(-c.y, xv.x, r.y);
                 }
                 if (store) (Rout ? Rout : Q)[cell * ldq + col] = r;
+                if (Uout) Uout[cell * ldu + j] = cconj(cmul(oscale, win[o + 1][1]));
                 acc += cabs2(r);
             }
         }
@@ -1161,8 +1167,17 @@ __global__ __launch_bounds__(256) void k_resid_nm(const cplx *__restrict__ plane
         red[ly * blockDim.x + j] = acc;
         __syncthreads();
         if (ly == 0) for (int q = 1; q < (int)blockDim.y; ++q) acc += red[q * blockDim.x + j];
+        if (qnorm) {
+            __syncthreads();
+            red[ly * blockDim.x + j] = accq;
+            __syncthreads();
+            if (ly == 0) for (int q = 1; q < (int)blockDim.y; ++q) accq += red[q * blockDim.x + j];
+        }
     }
-    if (ly == 0 && act) part[((long long)j * 4) * nblk + blockIdx.x] = acc;
+    if (ly == 0 && act) {
+        part[((long long)j * 4) * nblk + blockIdx.x] = acc;
+        if (qnorm) part[((long long)j * 4 + 1) * nblk + blockIdx.x] = accq;
+    }
 }
 
 // Xt[cell][cols[j]] += Dp[cell][j]  (corrections of the packed minority batch back into the full batch)
@@ -1905,7 +1920,11 @@ int nd_prep_transpose_norm(helm_op *op, const cplx *rhs, long long rhs_ld, long 
 
 // r = q - A xin node-major (see k_resid_nm); ncol columns of Xin (leading dimension ldin); returns the partial count per column
 int nd_resid_nm(helm_op *op, const cplx *planes, const cplx *Xin, int ldin, cplx *Q, int ldq, const int *qmap, int ncol, int store, cplx *Rout,
-                double *part, int nblk_cap, int *nblk_out) {
+                double *part, int nblk_cap, int *nblk_out, const NdResidExtra *ex) {
+    const int qnorm = ex ? ex->qnorm : 0;
+    cplx *Uout = ex ? ex->Uout : nullptr;
+    const int ldu = ex ? ex->ldu : 0;
+    const cplx oscale = ex ? ex->oscale : cmake(1.0, 0.0);
     int lx = 64;
     while (lx < ncol && lx < 256) lx <<= 1;
     const int ly = 256 / lx;
@@ -1924,7 +1943,8 @@ int nd_resid_nm(helm_op *op, const cplx *planes, const cplx *Xin, int ldin, cplx
     for (int c0 = 0; c0 < ncol; c0 += 256) {          // more than 256 columns: one launch per 256 (partials of later chunks follow the first)
         const int nc = std::min(256, ncol - c0);
 #define RESID_LAUNCH(RPT_) hipLaunchKernelGGL(k_resid_nm<RPT_>, dim3(nblk), dim3(lx, ly), 0, op->stream, planes, op->nz, op->nx, Xin + c0, ldin, Q + (qmap ? 0 : c0), ldq, \
-                           qmap ? qmap + c0 : nullptr, nc, store, Rout ? Rout + (qmap ? 0 : c0) : nullptr, part + (long long)c0 * 4 * nblk, nblk, seg, ntiles)
+                           qmap ? qmap + c0 : nullptr, nc, store, Rout ? Rout + (qmap ? 0 : c0) : nullptr, part + (long long)c0 * 4 * nblk, nblk, seg, ntiles, \
+                           qnorm, Uout ? Uout + c0 : nullptr, ldu, oscale)
         if (rpt == 1) RESID_LAUNCH(1); else if (rpt == 2) RESID_LAUNCH(2); else if (rpt == 8) RESID_LAUNCH(8); else RESID_LAUNCH(4);
 #undef RESID_LAUNCH
     }
@@ -1933,7 +1953,7 @@ int nd_resid_nm(helm_op *op, const cplx *planes, const cplx *Xin, int ldin, cplx
         // algorithmic bytes of what this launch has to move (SURVEY.md 8(d) convention: operands once, halo re-reads not counted):
         // the input columns and q (16 B each per point and column), the nine coefficients (144 B per point); r written only when it
         // is stored (+16)
-        op->ev_pending.push_back(std::make_pair((int)op->ev_used, (double)op->N * ((32.0 + (store ? 16.0 : 0.0)) * ncol + 144.0)));
+        op->ev_pending.push_back(std::make_pair((int)op->ev_used, (double)op->N * ((32.0 + (store ? 16.0 : 0.0) + (Uout ? 16.0 : 0.0)) * ncol + 144.0)));
         op->ev_used += 2;
     }
     *nblk_out = nblk;
@@ -1948,6 +1968,14 @@ int nd_scatter_add_cols(helm_op *op, cplx *Xt, int ldq, const int *d_cols, int k
 int nd_pack_cols(helm_op *op, const cplx *Qt, int ldq, const int *d_cols, int k, cplx *Rp, long long N) {
     hipLaunchKernelGGL(k_pack_cols, dim3((unsigned)std::min<long long>((N * k + 255) / 256, 1 << 20)), dim3(256), 0, op->stream, Qt, ldq, d_cols, k, Rp, N);
     return check_kernels(op, "column packing");
+}
+
+// out[c][r] = in[r][c] for an (rows x cols) array (layout conversions at the C ABI: the reference's (N, nrhs) arrays <-> one right-hand side per row)
+int nd_transpose(helm_op *op, const cplx *in, long long rows, long long cols, cplx *out) {
+    const bool swap = rows > cols;            // the long dimension rides on gridDim.x
+    dim3 grid = swap ? dim3((unsigned)((rows + 31) / 32), (unsigned)((cols + 31) / 32)) : dim3((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
+    hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, op->stream, in, rows, cols, out, swap ? 1 : 0, 0);
+    return check_kernels(op, "transpose");
 }
 
 // Xt (cells x nrhs) -> U (nrhs x N), conjugated on request

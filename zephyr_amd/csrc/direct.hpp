@@ -111,8 +111,14 @@ int nd_factor_solve_nm(helm_op *op, int block, NdFactor *f, cplx *ws_factor, con
                        hipStream_t side, float *factor_ms);
 int nd_prep_transpose_norm(helm_op *op, const cplx *rhs, long long rhs_ld, long long row_off, cplx premul, const cplx *sub, cplx *Qt, long long N, int nrhs,
                            double *part, int nblk_cap, int *nblk_out);     // nblk_cap: partials per right-hand side the buffer has room for
+struct NdResidExtra {      // optional by-products of the residual launch (node-major callers)
+    int qnorm = 0;                       // also the partials of ||q||^2 (slot 1 of the partial sums)
+    cplx *Uout = nullptr; int ldu = 0;   // Uout[cell][j] = conj(oscale * xin[cell][j])
+    cplx oscale = {1.0, 0.0};
+};
 int nd_resid_nm(helm_op *op, const cplx *planes, const cplx *Xin, int ldin, cplx *Q, int ldq, const int *qmap, int ncol, int store, cplx *Rout,
-                double *part, int nblk_cap, int *nblk_out);      // r = q - A xin; store: r -> Rout (null: over q)
+                double *part, int nblk_cap, int *nblk_out, const NdResidExtra *ex = nullptr);      // r = q - A xin; store: r -> Rout (null: over q)
+int nd_transpose(helm_op *op, const cplx *in, long long rows, long long cols, cplx *out);
 int nd_scatter_add_cols(helm_op *op, cplx *Xt, int ldq, const int *d_cols, int k, const cplx *Dp, long long N);
 int nd_pack_cols(helm_op *op, const cplx *Qt, int ldq, const int *d_cols, int k, cplx *Rp, long long N);
 int nd_transpose_out(helm_op *op, const cplx *Xt, long long N, int nrhs, cplx *U, int conj);

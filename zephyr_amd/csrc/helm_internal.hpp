@@ -249,7 +249,8 @@ int helm_launch_bicg_s(helm_op *op, VecPtrs w, int nrhs);
 int helm_launch_bicg_xr(helm_op *op, VecPtrs w, const cplx *xp, const cplx *xs, int nrhs);   // x += alpha xp + omega xs ; r = s - omega t
 int helm_launch_fin(helm_op *op, int which, int nrhs, int nblk_part);
 enum { FIN_BICG_INIT = 0, FIN_ALPHA = 1, FIN_OMEGA = 2, FIN_RHO = 3, FIN_RESTART = 4,
-       FIN_CG_INIT = 5, FIN_CG_ALPHA = 6, FIN_CG_RR = 7, FIN_CG_BETA = 8, FIN_NORM = 9 };
+       FIN_CG_INIT = 5, FIN_CG_ALPHA = 6, FIN_CG_RR = 7, FIN_CG_BETA = 8, FIN_NORM = 9,
+       FIN_NORM2 = 10 /* aux[b] = slot 0, aux[nrhs + b] = slot 1 */ };
 int helm_vec_num_blocks(const helm_op *op);
 // CGNR
 int helm_launch_cg_xr(helm_op *op, VecPtrs w, int nrhs);      // x += alpha p ; r -= alpha w(v) ; (r,r)
@@ -266,7 +267,7 @@ int helm_launch_prep_rhs(helm_op *op, const cplx *dRHS, long long rhs_ld, long l
 int helm_launch_prep_rhs_norm(helm_op *op, const cplx *dRHS, long long rhs_ld, long long row_off, cplx premul, const cplx *sub, cplx *out, int nrhs);
 int helm_launch_imaging(helm_op *op, const cplx *uf, const cplx *ub, int nsrc, const cplx *scaler, cplx *g);
 int helm_launch_zero(helm_op *op, cplx *p, long long n);
-int helm_launch_rhs_from_coo(helm_op *op, const long long *row, const int *col, const cplx *val, long long nnz, cplx *R, int nrhs, long long rows);
+int helm_launch_rhs_from_coo(helm_op *op, const long long *row, const int *col, const cplx *val, long long nnz, cplx *R, int nrhs, long long rows, int node_major = 0);
 int helm_launch_sample(helm_op *op, const cplx *U, int nsrc, long long ld, const long long *rowptr, const long long *col, const cplx *val, int nrec, cplx *out);
 int helm_launch_rowscale_inplace(helm_op *op, cplx *v, const double *rs, long long NV, int nrhs);
 int helm_launch_abs(helm_op *op, const cplx *in, cplx *out, long long n, double sign);      // out = sign |in|

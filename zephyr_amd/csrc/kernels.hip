@@ -571,10 +571,10 @@ __global__ __launch_bounds__(256) void k_fin(FinParams f) {
     __shared__ double smem[16];
     const int b = blockIdx.x;
     RhsScal *S = f.scal ? f.scal + b : nullptr;
-    if (f.which == FIN_NORM) {
+    if (f.which == FIN_NORM || f.which == FIN_NORM2) {
         double v[4];
         fin_sum(f.part, b, f.nblk, v, smem);
-        if (threadIdx.x == 0) f.aux[b] = v[0];
+        if (threadIdx.x == 0) { f.aux[b] = v[0]; if (f.which == FIN_NORM2) f.aux[gridDim.x + b] = v[1]; }
         return;
     }
     if (f.which == FIN_RESTART) {
@@ -961,13 +961,15 @@ int helm_launch_rowscale_inplace(helm_op *op, cplx *v, const double *rs, long lo
 
 // dense right-hand sides from the triplets of a sparse matrix (no duplicate entries): R[col][row] = val
 __global__ __launch_bounds__(256) void k_rhs_from_coo(const long long *__restrict__ row, const int *__restrict__ col, const cplx *__restrict__ val,
-                                                      long long nnz, cplx *__restrict__ R, long long rows) {
-    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (long long)gridDim.x * blockDim.x)
-        R[(long long)col[k] * rows + row[k]] = val[k];
+                                                      long long nnz, cplx *__restrict__ R, long long rows, int nrhs, int node_major) {
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (long long)gridDim.x * blockDim.x) {
+        if (node_major) R[row[k] * nrhs + col[k]] = val[k];          // the reference's (rows, nrhs) C-order array
+        else R[(long long)col[k] * rows + row[k]] = val[k];
+    }
 }
-int helm_launch_rhs_from_coo(helm_op *op, const long long *row, const int *col, const cplx *val, long long nnz, cplx *R, int nrhs, long long rows) {
+int helm_launch_rhs_from_coo(helm_op *op, const long long *row, const int *col, const cplx *val, long long nnz, cplx *R, int nrhs, long long rows, int node_major) {
     HIP_TRY(op, hipMemsetAsync(R, 0, (size_t)nrhs * rows * sizeof(cplx), op->stream));
-    if (nnz > 0) hipLaunchKernelGGL(k_rhs_from_coo, dim3((unsigned)std::min<long long>((nnz + 255) / 256, 65535)), dim3(256), 0, op->stream, row, col, val, nnz, R, rows);
+    if (nnz > 0) hipLaunchKernelGGL(k_rhs_from_coo, dim3((unsigned)std::min<long long>((nnz + 255) / 256, 65535)), dim3(256), 0, op->stream, row, col, val, nnz, R, rows, nrhs, node_major);
     HIP_TRY(op, hipGetLastError());
     return HELM_OK;
 }

@@ -207,16 +207,31 @@ class BaseDiscretization(BaseModelDependent):
         return o
 
     def _solve(self, rhs, rows):
-        'rhs: (rows, nrhs) dense complex -> (rows, nrhs)'
+        """rhs: (rows, nrhs) dense complex or scipy-sparse -> (rows, nrhs) complex128, C-order like the reference's `lu.solve` result.
+
+        Arrays cross the C ABI in the reference's own layout (HELM_NODE_MAJOR): no transposes on the host or on the device.  A sparse
+        right-hand side (the surveys' source matrices) is not densified on the host -- only its triplets go to the GPU (helm_solve_coo),
+        where problemo's `b.toarray()` happens.  The result array lives in pinned host memory so the copy back runs at the PCIe rate."""
         lib = _lib.load()
         h = self.handle
-        nrhs = rhs.shape[1]
-        R = np.ascontiguousarray(rhs.T, dtype=np.complex128)       # each RHS contiguous
-        U = np.empty_like(R)
+        nrhs = int(rhs.shape[1])
         info = (_lib.SolveInfo * nrhs)()
         opts = self._solve_opts()
+        opts.flags = _lib.HELM_NODE_MAJOR
         pm = complex(self.premul)
-        rc = lib.helm_solve(h, _lib.ptr(R), _lib.ptr(U), nrhs, int(rows), pm.real, pm.imag, ctypes.byref(opts), info)
+        nbytes = int(rows) * nrhs * 16
+        U = _lib.pinned_empty((int(rows), nrhs), np.complex128) if nbytes >= (1 << 20) else np.empty((int(rows), nrhs), dtype=np.complex128)
+        if sp.issparse(rhs):
+            coo = sp.coo_matrix(rhs)
+            coo.sum_duplicates()
+            row = np.ascontiguousarray(coo.row, dtype=np.int64)
+            col = np.ascontiguousarray(coo.col, dtype=np.int32)
+            val = np.ascontiguousarray(coo.data, dtype=np.complex128)
+            rc = lib.helm_solve_coo(h, _lib.ptr(row), _lib.ptr(col), _lib.ptr(val), int(coo.nnz), _lib.ptr(U), nrhs, int(rows),
+                                    pm.real, pm.imag, ctypes.byref(opts), info)
+        else:
+            R = np.ascontiguousarray(rhs, dtype=np.complex128)
+            rc = lib.helm_solve(h, _lib.ptr(R), _lib.ptr(U), nrhs, int(rows), pm.real, pm.imag, ctypes.byref(opts), info)
         _lib.check(rc, h)
         self.lastInfo = [dict(iterations=i.iterations, status=i.status, restarts=i.restarts, method=i.method,
                               relres=i.relres) for i in info]
@@ -224,18 +239,20 @@ class BaseDiscretization(BaseModelDependent):
             worst = max(i.relres for i in info)
             raise ArithmeticError('%d of %d right-hand sides did not reach rtol=%g (worst relative residual %.3e, maxit=%d)'
                                   % (rc, nrhs, self.rtol, worst, self.maxit))
-        return U.T
+        return U
 
-    def solveDevice(self, d_rhs, d_u, nrhs, rows=None):
+    def solveDevice(self, d_rhs, d_u, nrhs, rows=None, layout='rhs'):
         '''Solve with right-hand sides and wavefields already resident in HBM.
 
-        d_rhs / d_u: device pointers (ints) to [nrhs][rows] complex128, each RHS contiguous.
+        d_rhs / d_u: device pointers (ints) to complex128 buffers: layout 'rhs' = [nrhs][rows], each right-hand side contiguous;
+        layout 'node' = [rows][nrhs], the reference's (N, nrhs) C-order arrays (no transposes inside the direct path).
         Returns the per-RHS info list; raises if a right-hand side misses the tolerance.'''
         lib = _lib.load()
         h = self.handle
         rows = int(self.nrow if rows is None else rows)
         info = (_lib.SolveInfo * nrhs)()
         opts = self._solve_opts()
+        opts.flags = _lib.HELM_NODE_MAJOR if layout == 'node' else 0
         pm = complex(self.premul)
         rc = lib.helm_solve_device(h, ctypes.c_void_p(d_rhs), ctypes.c_void_p(d_u), int(nrhs), rows, pm.real, pm.imag,
                                    ctypes.byref(opts), info)
@@ -252,9 +269,9 @@ class BaseDiscretization(BaseModelDependent):
         _lib.check(lib.helm_imaging_accumulate_device(self.handle, ctypes.c_void_p(d_uf), ctypes.c_void_p(d_ub), int(nsrc),
                                                       ctypes.c_void_p(d_scaler), ctypes.c_void_p(d_g)), self.handle)
 
-    def rhsFromSparseDevice(self, q, d_rhs):
-        '''Fill the device buffer d_rhs ([ncols][nrow] complex128) from the scipy-sparse right-hand-side matrix q (nrow x ncols)
-        without densifying it on the host: only the COO triplets cross PCIe.'''
+    def rhsFromSparseDevice(self, q, d_rhs, layout='rhs'):
+        '''Fill the device buffer d_rhs ([ncols][nrow] complex128; layout 'node': [nrow][ncols]) from the scipy-sparse right-hand-side
+        matrix q (nrow x ncols) without densifying it on the host: only the COO triplets cross PCIe.'''
         import torch
         lib = _lib.load()
         coo = sp.coo_matrix(q)
@@ -264,9 +281,9 @@ class BaseDiscretization(BaseModelDependent):
         col = torch.from_numpy(np.ascontiguousarray(coo.col, dtype=np.int32)).to(dev)
         val = torch.from_numpy(np.ascontiguousarray(coo.data, dtype=np.complex128)).to(dev)
         torch.cuda.synchronize(dev)
-        _lib.check(lib.helm_rhs_from_coo_device(self.handle, ctypes.c_void_p(row.data_ptr()), ctypes.c_void_p(col.data_ptr()),
-                                                ctypes.c_void_p(val.data_ptr()), int(coo.nnz), ctypes.c_void_p(d_rhs), int(coo.shape[1]),
-                                                int(coo.shape[0])), self.handle)
+        _lib.check(lib.helm_rhs_from_coo_device_layout(self.handle, ctypes.c_void_p(row.data_ptr()), ctypes.c_void_p(col.data_ptr()),
+                                                       ctypes.c_void_p(val.data_ptr()), int(coo.nnz), ctypes.c_void_p(d_rhs), int(coo.shape[1]),
+                                                       int(coo.shape[0]), _lib.HELM_RHS_NODE_MAJOR if layout == 'node' else 0), self.handle)
 
     def sampleDevice(self, d_u, nsrc, csr_dev, d_out):
         'd_out[nrec][nsrc] = R u for the CSR receiver matrix uploaded by the caller: csr_dev = (rowptr, col, val, nrec) device tensors'
@@ -296,9 +313,16 @@ class BaseDiscretization(BaseModelDependent):
             rhs = rhs.reshape((-1, 1))
         return rhs, onedim
 
+    @staticmethod
+    def _as_rhs(rhs):
+        'like _dense_rhs, but a scipy-sparse right-hand side stays sparse (it is expanded on the GPU)'
+        if sp.issparse(rhs):
+            return rhs, False
+        return BaseDiscretization._dense_rhs(rhs)
+
     def __mul__(self, rhs):
         'conj(A^-1 (premul * rhs))  (discretization.py:101-103)'
-        rhs, onedim = self._dense_rhs(rhs)
+        rhs, onedim = self._as_rhs(rhs)
         if rhs.shape[0] != self.nrow:
             raise ValueError('dimension mismatch')
         u = self._solve(rhs, self.nrow)

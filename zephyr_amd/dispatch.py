@@ -35,6 +35,16 @@ def visible_devices():
     return list(range(max(1, n)))
 
 
+def workers_per_device():
+    """Pipelines per GPU (HELM_WORKERS_PER_DEVICE, default 1).  Two let the device-to-host copy of one frequency's wavefields run while
+    the other worker's frequency is being solved: worth it for callers that take host arrays back (`MultiFreq * q`), pointless for
+    device-resident ones."""
+    try:
+        return max(1, int(os.environ.get('HELM_WORKERS_PER_DEVICE', '1')))
+    except ValueError:
+        return 1
+
+
 class WorkItem(object):
     """prepare() runs on the device's prepare thread (may be None), solve(prepared) on its solve thread;
     `future` receives solve's return value or the first exception of either step."""

@@ -69,10 +69,10 @@ class BaseMPDist(BaseDist):
         if not self.parallel:
             return [self.systemConfig['device']] if 'device' in self.systemConfig else dispatch.visible_devices()[:1]
         if 'device' in self.systemConfig:                      # the caller pinned the operators to one GPU
-            return [int(self.systemConfig['device'])]
+            return [int(self.systemConfig['device'])] * dispatch.workers_per_device()
         devs = dispatch.visible_devices()
         cap = int(getattr(self, '_nWorkers', len(devs)))
-        return devs[:max(1, cap)]
+        return devs[:max(1, cap)] * dispatch.workers_per_device()
 
     @property
     def nWorkers(self):

@@ -65,7 +65,7 @@ class Eurus(BaseDiscretization, BaseAnisotropic):
 
     def __mul__(self, rhs):
         'N-row rhs: zero-pad the second field and clip the result; 2N-row rhs: full result (eurus.py:512-533)'
-        rhs, onedim = self._dense_rhs(rhs)
+        rhs, onedim = self._as_rhs(rhs)
         n2 = self.shape[1]
         if 2 * rhs.shape[0] == n2:
             rows = self.nrow
