@@ -567,6 +567,11 @@ def main():
                 for wpd in (1, 2):
                     os.environ['HELM_WORKERS_PER_DEVICE'] = str(wpd)
                     sch = dict(cfg); sch.update(freqs=[float(f) for f in freqs], Disc=Eurus, rtol=args.rtol, maxit=400000, method=args.method, batch=NSRC)
+                    # untimed warm-up (like the W warm-up steps): the pinned result buffers and device pools come into being here
+                    mfw = MultiFreq(dict(sch, freqs=[float(f) for f in freqs[:3 * wpd]]))
+                    for u in mfw * q_sparse:
+                        del u
+                    del mfw.factors
                     mf = MultiFreq(sch)
                     torch.cuda.synchronize()
                     th0 = time.perf_counter()

@@ -129,4 +129,4 @@ def test_operator_times_sparse_and_dense_rhs(helm_lib):
     big = za.MiniZephyr(cfg) * np.ones((N, 8), complex)
     assert big.nbytes >= (1 << 20) and big.base is not None
     with pytest.raises(ValueError):
-        za.MiniZephyr(cfg) * qs[:-1]
+        za.MiniZephyr(cfg) * sp.csr_matrix(qs)[:-1]

@@ -35,14 +35,35 @@ def visible_devices():
     return list(range(max(1, n)))
 
 
-def workers_per_device():
-    """Pipelines per GPU (HELM_WORKERS_PER_DEVICE, default 1).  Two let the device-to-host copy of one frequency's wavefields run while
-    the other worker's frequency is being solved: worth it for callers that take host arrays back (`MultiFreq * q`), pointless for
-    device-resident ones."""
+def workers_per_device(default=1):
+    """Pipelines per GPU (HELM_WORKERS_PER_DEVICE, else `default`).  Two let the device-to-host copy of one frequency's wavefields run
+    while the other worker's frequency is being solved: worth it for callers that take host arrays back (`MultiFreq * q`), pointless
+    for device-resident ones."""
     try:
-        return max(1, int(os.environ.get('HELM_WORKERS_PER_DEVICE', '1')))
+        return max(1, int(os.environ.get('HELM_WORKERS_PER_DEVICE', default)))
     except ValueError:
-        return 1
+        return default
+
+
+class Throttle(object):
+    """Back-pressure between a worker and the consumer of its results: at most `depth` results of a worker exist that the caller has
+    not taken yet (a frequency's wavefields are GBs of pinned host memory; the reference's pool keeps every pending result alive).
+    `close()` lifts the limit -- an abandoned generator must not leave worker threads waiting."""
+
+    def __init__(self, depth=2):
+        self._sem = threading.Semaphore(max(1, int(depth)))
+        self._closed = False
+
+    def acquire(self):
+        while not self._closed:
+            if self._sem.acquire(timeout=0.05):
+                return
+
+    def release(self):
+        self._sem.release()
+
+    def close(self):
+        self._closed = True
 
 
 class WorkItem(object):
@@ -100,15 +121,17 @@ class DevicePipeline(object):
 
     @staticmethod
     def _run_solve(item):
-        if not item.future.set_running_or_notify_cancel():
+        fut = item.future                  # (the consumer drops item.future once it has the result)
+        if fut is None or not fut.set_running_or_notify_cancel():
             return
         if item._error is not None:
-            item.future.set_exception(item._error)
+            fut.set_exception(item._error)
             return
         try:
-            item.future.set_result(item.solve(item._prepared))
+            fut.set_result(item.solve(item._prepared))
         except BaseException as exc:
-            item.future.set_exception(exc)
+            fut.set_exception(exc)
+        item._prepared = None
 
     def _serial(self, items):
         for item in items:
@@ -147,6 +170,9 @@ def pipelined(items, device=0, lookahead=1):
     pipe.start(items)
     try:
         for item in items:
-            yield item.future.result()
+            res = item.future.result()
+            item.future = None
+            yield res
+            del res
     finally:
         pipe.join()

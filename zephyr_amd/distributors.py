@@ -69,10 +69,10 @@ class BaseMPDist(BaseDist):
         if not self.parallel:
             return [self.systemConfig['device']] if 'device' in self.systemConfig else dispatch.visible_devices()[:1]
         if 'device' in self.systemConfig:                      # the caller pinned the operators to one GPU
-            return [int(self.systemConfig['device'])] * dispatch.workers_per_device()
+            return [int(self.systemConfig['device'])]
         devs = dispatch.visible_devices()
         cap = int(getattr(self, '_nWorkers', len(devs)))
-        return devs[:max(1, cap)] * dispatch.workers_per_device()
+        return devs[:max(1, cap)]
 
     @property
     def nWorkers(self):
@@ -120,49 +120,88 @@ class BaseMPDist(BaseDist):
                 return shared
         return get
 
+    def _scaled(self, u):
+        'scaleTerm * u without a second copy of a multi-GB wavefield array: in place where the result is this call\'s own complex array'
+        st = self.scaleTerm
+        if st == 1.:
+            return u
+        if isinstance(u, np.ndarray) and u.dtype == np.complex128 and u.flags.writeable:
+            u *= st
+            return u
+        return st * u
+
     @staticmethod
-    def _item(sub, r):
+    def _item(sub, r, throttle=None):
         prep = None
         if hasattr(sub, 'prefactor'):
             def prep():
                 sub.prefactor()           # builds the handle (assembly on the GPU) and enqueues the factorisation
-        return dispatch.WorkItem(lambda _prepared: sub * r, prep)
+
+        def solve(_prepared):
+            if throttle is not None:
+                throttle.acquire()        # not more than two results of this worker ahead of the consumer
+            return sub * r
+        return dispatch.WorkItem(solve, prep)
 
     def __mul__(self, rhs):
         get = self._rhs_getter(rhs)
         subs = self.subProblems
         if not self.parallel:
-            return (self.scaleTerm * (sub * get(i)) for i, sub in enumerate(subs))
+            return (self._scaled(sub * get(i)) for i, sub in enumerate(subs))
         # every right-hand side is taken now, in order, like the reference's apply_async loop (distributors.py:161-166)
         devs = self.devices
-        split = max(1, len(devs) // max(1, len(subs)))           # GPUs per frequency when there are spare ones
-        queues = [[] for _ in devs]                              # one worker (solve + prepare thread) per entry of `devices`
+        nd = len(devs)
+        split = max(1, nd // max(1, len(subs)))                  # GPUs per frequency when there are spare ones
+        # results go back to the host here (GBs per frequency over PCIe): two workers per GPU, so that the copy of one frequency's wavefields
+        # runs while the other worker's frequency is being solved (HELM_WORKERS_PER_DEVICE overrides)
+        wpd = dispatch.workers_per_device(2)
+        workers = devs * wpd                                     # worker k drives GPU workers[k]; one solve + one prepare thread each
+        queues = [[] for _ in workers]
+        throttles = [dispatch.Throttle(2) for _ in workers]
+        turn = [0] * nd
+
+        def worker_of(slot):                                     # the workers of a GPU take its items in turn
+            w = slot + nd * (turn[slot] % wpd)
+            turn[slot] += 1
+            return w
         parts = []
         for i, sub in enumerate(subs):
             r = get(i)
             ncol = r.shape[1] if getattr(r, 'ndim', 1) > 1 else 1
             k = min(split, ncol) if hasattr(sub, 'prefactor') else 1
             if k <= 1:
-                it = self._item(sub, r)
-                queues[i % len(devs)].append(it)
-                parts.append([it])
+                w = worker_of((i * split) % nd)
+                it = self._item(sub, r, throttles[w])
+                queues[w].append(it)
+                parts.append([(it, w)])
                 continue
             rc = r.tocsc() if sp.issparse(r) else r
             bounds = [ncol * j // k for j in range(k + 1)]
             row = []
             for j in range(k):
-                w = (i * k + j) % len(devs)
-                owner = sub if j == 0 else self._replica(i, j, devs[w])
-                it = self._item(owner, rc[:, bounds[j]:bounds[j + 1]])
+                w = worker_of((i * split + j) % nd)
+                owner = sub if j == 0 else self._replica(i, j, workers[w])
+                it = self._item(owner, rc[:, bounds[j]:bounds[j + 1]], throttles[w])
                 queues[w].append(it)
-                row.append(it)
+                row.append((it, w))
             parts.append(row)
-        self._pipes = dispatch.dispatch(list(zip(devs, queues)), lookahead=1)
+        self._pipes = dispatch.dispatch(list(zip(workers, queues)), lookahead=1)
 
         def results():
-            for row in parts:
-                cols = [it.future.result() for it in row]
-                yield self.scaleTerm * (cols[0] if len(cols) == 1 else np.hstack(cols))
+            try:
+                for row in parts:
+                    cols = []
+                    for it, w in row:
+                        cols.append(it.future.result())
+                        it.future = None             # the item must not keep a multi-GB result alive after it has been handed over
+                        throttles[w].release()
+                    u = cols[0] if len(cols) == 1 else np.hstack(cols)
+                    del cols
+                    yield self._scaled(u)
+                    del u
+            finally:
+                for t in throttles:                  # an abandoned generator must not leave the workers waiting
+                    t.close()
         return results()
 
     @property
