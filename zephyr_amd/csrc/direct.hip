@@ -1113,7 +1113,10 @@ __global__ __launch_bounds__(256) void k_resid_nm(const cplx *__restrict__ plane
     // shares with the tiles above and below (the only HBM re-reads of this kernel: 1.7 x the input at RPT = 1 by the PMC counters) shrink
     // from 2 per output row to 2 / RPT
     __shared__ double red[256];
-    const int j = threadIdx.x, ly = threadIdx.y;
+    // blockDim.x is a multiple of the wave size, so threadIdx.y -- and with it the tile, the row and the cell a thread works on -- is uniform
+    // across a wave: saying so (readfirstlane) turns the nine coefficient loads per cell into scalar loads through the constant cache
+    // instead of 64 lanes fetching the same 16 bytes through the vector memory pipeline (36 of the 46 loads of a step at RPT = 4)
+    const int j = threadIdx.x, ly = __builtin_amdgcn_readfirstlane(threadIdx.y);
     const bool act = j < ncol;
     const int col = act ? (qmap ? qmap[j] : j) : 0;
     const long long N = (long long)nz * nx;
@@ -1124,10 +1127,14 @@ __global__ __launch_bounds__(256) void k_resid_nm(const cplx *__restrict__ plane
     const int per = (ntiles + 7) / 8;
     for (int w = blockIdx.x * blockDim.y + ly; w < per * 8; w += gridDim.x * blockDim.y) {
         const int t = (w & 7) * per + (w >> 3);
-        if (t >= ntiles || !act) continue;
+        if (t >= ntiles) continue;
+        if (!act) continue;
         const int sgi = t / nzt, z0 = (t - sgi * nzt) * RPT;      // z fastest: consecutive tiles are vertically adjacent
         const int x0 = sgi * seg, x1 = min(nx, x0 + seg);
         cplx win[RPT + 2][3];                                     // win[d][.] = columns x-1, x, x+1 of row z0-1+d
+        // software pipeline: the column that enters the window in the NEXT step (`pre`) and the next column of q (`qn`) are loaded
+        // while the current column is being multiplied, so a wave never waits on the loads it has just issued
+        cplx pre[RPT + 2], qn[RPT];
         #pragma unroll
         for (int d = 0; d < RPT + 2; ++d) {
             const int zz = z0 - 1 + d;
@@ -1135,20 +1142,33 @@ __global__ __launch_bounds__(256) void k_resid_nm(const cplx *__restrict__ plane
             win[d][0] = cmake(0.0, 0.0);
             win[d][1] = (zin && x0 - 1 >= 0) ? Xin[((long long)zz * nx + x0 - 1) * ldin + j] : cmake(0.0, 0.0);
             win[d][2] = zin ? Xin[((long long)zz * nx + x0) * ldin + j] : cmake(0.0, 0.0);
+            pre[d] = (zin && x0 + 1 < nx) ? Xin[((long long)zz * nx + x0 + 1) * ldin + j] : cmake(0.0, 0.0);
         }
+        #pragma unroll
+        for (int o = 0; o < RPT; ++o) qn[o] = (z0 + o < nz) ? Q[((long long)(z0 + o) * nx + x0) * ldq + col] : cmake(0.0, 0.0);
         for (int x = x0; x < x1; ++x) {
+            cplx qc[RPT];
             #pragma unroll
             for (int d = 0; d < RPT + 2; ++d) {
                 const int zz = z0 - 1 + d;
-                win[d][0] = win[d][1]; win[d][1] = win[d][2];
-                win[d][2] = (zz >= 0 && zz < nz && x + 1 < nx) ? Xin[((long long)zz * nx + x + 1) * ldin + j] : cmake(0.0, 0.0);
+                win[d][0] = win[d][1]; win[d][1] = win[d][2]; win[d][2] = pre[d];
+                cplx v = cmake(0.0, 0.0);
+                if (zz >= 0 && zz < nz && x + 1 < x1 && x + 2 < nx) v = Xin[((long long)zz * nx + x + 2) * ldin + j];
+                pre[d] = v;
+            }
+            #pragma unroll
+            for (int o = 0; o < RPT; ++o) {
+                qc[o] = qn[o];
+                cplx v = cmake(0.0, 0.0);
+                if (z0 + o < nz && x + 1 < x1) v = Q[((long long)(z0 + o) * nx + x + 1) * ldq + col];
+                qn[o] = v;
             }
             #pragma unroll
             for (int o = 0; o < RPT; ++o) {
                 const int z = z0 + o;
                 if (z >= nz) break;
                 const long long cell = (long long)z * nx + x;
-                cplx r = Q[cell * ldq + col];
+                cplx r = qc[o];
                 if (qnorm) accq += cabs2(r);
                 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
@@ -1175,6 +1195,93 @@ __global__ __launch_bounds__(256) void k_resid_nm(const cplx *__restrict__ plane
         }
     }
     if (ly == 0 && act) {
+        part[((long long)j * 4) * nblk + blockIdx.x] = acc;
+        if (qnorm) part[((long long)j * 4 + 1) * nblk + blockIdx.x] = accq;
+    }
+}
+
+// The same kernel for full-width batches (blockDim = (256, 1): the four waves of a workgroup share their tile).  The nine coefficients of
+// the tile's RPT x 32 cells are staged in LDS once per tile by coalesced loads along x (18 KB at RPT = 4) and read back as broadcasts:
+// the per-cell coefficient fetches of k_resid_nm -- 36 of its 46 memory instructions per step at RPT = 4, each a 16-byte request -- leave
+// the vector memory pipeline, which then only carries the streams that have to move (x, q, and what is stored).
+#define RESID_SEG 32
+template <int RPT>
+__global__ __launch_bounds__(256) void k_resid_nm_lds(const cplx *__restrict__ planes, int nz, int nx, const cplx *__restrict__ Xin, int ldin,
+                                                      cplx *__restrict__ Q, int ldq, const int *__restrict__ qmap, int ncol, int store,
+                                                      cplx *__restrict__ Rout, double *__restrict__ part, int nblk, int ntiles,
+                                                      int qnorm, cplx *__restrict__ Uout, int ldu, cplx oscale) {
+    __shared__ cplx cs[9][RPT][RESID_SEG];
+    const int j = threadIdx.x;
+    const bool act = j < ncol;
+    const int col = act ? (qmap ? qmap[j] : j) : 0;
+    const long long N = (long long)nz * nx;
+    const int nzt = (nz + RPT - 1) / RPT;
+    double acc = 0.0, accq = 0.0;
+    const int per = (ntiles + 7) / 8;
+    for (int w = blockIdx.x; w < per * 8; w += gridDim.x) {
+        const int t = (w & 7) * per + (w >> 3);                   // banded tile order, see k_resid_nm
+        if (t >= ntiles) continue;                                // (uniform across the workgroup)
+        const int sgi = t / nzt, z0 = (t - sgi * nzt) * RPT;
+        const int x0 = sgi * RESID_SEG, x1 = min(nx, x0 + RESID_SEG);
+        __syncthreads();                                          // the previous tile's coefficients are no longer being read
+        for (int e = j; e < 9 * RPT * RESID_SEG; e += 256) {
+            const int xx = e % RESID_SEG, o = (e / RESID_SEG) % RPT, k = e / (RESID_SEG * RPT);
+            cplx v = cmake(0.0, 0.0);
+            if (z0 + o < nz && x0 + xx < nx) v = planes[(long long)k * N + (long long)(z0 + o) * nx + x0 + xx];
+            cs[k][o][xx] = v;
+        }
+        __syncthreads();
+        if (!act) continue;
+        cplx win[RPT + 2][3], pre[RPT + 2], qn[RPT];
+        #pragma unroll
+        for (int d = 0; d < RPT + 2; ++d) {
+            const int zz = z0 - 1 + d;
+            const bool zin = zz >= 0 && zz < nz;
+            win[d][0] = cmake(0.0, 0.0);
+            win[d][1] = (zin && x0 - 1 >= 0) ? Xin[((long long)zz * nx + x0 - 1) * ldin + j] : cmake(0.0, 0.0);
+            win[d][2] = zin ? Xin[((long long)zz * nx + x0) * ldin + j] : cmake(0.0, 0.0);
+            pre[d] = (zin && x0 + 1 < nx) ? Xin[((long long)zz * nx + x0 + 1) * ldin + j] : cmake(0.0, 0.0);
+        }
+        #pragma unroll
+        for (int o = 0; o < RPT; ++o) qn[o] = (z0 + o < nz) ? Q[((long long)(z0 + o) * nx + x0) * ldq + col] : cmake(0.0, 0.0);
+        for (int x = x0; x < x1; ++x) {
+            cplx qc[RPT];
+            #pragma unroll
+            for (int d = 0; d < RPT + 2; ++d) {
+                const int zz = z0 - 1 + d;
+                win[d][0] = win[d][1]; win[d][1] = win[d][2]; win[d][2] = pre[d];
+                cplx v = cmake(0.0, 0.0);
+                if (zz >= 0 && zz < nz && x + 1 < x1 && x + 2 < nx) v = Xin[((long long)zz * nx + x + 2) * ldin + j];
+                pre[d] = v;
+            }
+            #pragma unroll
+            for (int o = 0; o < RPT; ++o) {
+                qc[o] = qn[o];
+                cplx v = cmake(0.0, 0.0);
+                if (z0 + o < nz && x + 1 < x1) v = Q[((long long)(z0 + o) * nx + x + 1) * ldq + col];
+                qn[o] = v;
+            }
+            #pragma unroll
+            for (int o = 0; o < RPT; ++o) {
+                const int z = z0 + o;
+                if (z >= nz) break;
+                const long long cell = (long long)z * nx + x;
+                cplx r = qc[o];
+                if (qnorm) accq += cabs2(r);
+                #pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const cplx c = cs[k][o][x - x0];
+                    const cplx xv = win[o + k / 3][k % 3];
+                    r.x = fma(-c.x, xv.x, r.x); r.x = fma(c.y, xv.y, r.x);
+                    r.y = fma(-c.x, xv.y, r.y); r.y = fma(-c.y, xv.x, r.y);
+                }
+                if (store) (Rout ? Rout : Q)[cell * ldq + col] = r;
+                if (Uout) Uout[cell * ldu + j] = cconj(cmul(oscale, win[o + 1][1]));
+                acc += cabs2(r);
+            }
+        }
+    }
+    if (act) {
         part[((long long)j * 4) * nblk + blockIdx.x] = acc;
         if (qnorm) part[((long long)j * 4 + 1) * nblk + blockIdx.x] = accq;
     }
@@ -1928,8 +2035,11 @@ int nd_resid_nm(helm_op *op, const cplx *planes, const cplx *Xin, int ldin, cplx
     int lx = 64;
     while (lx < ncol && lx < 256) lx <<= 1;
     const int ly = 256 / lx;
-    const int seg = 32;
-    // rows per thread: measured on 1024^2 x 256 (norm-only launch): 1 -> 2.52 ms, 2 -> 3.71 ms, 4 -> 2.23 ms
+    static const int seg_env = getenv("HELM_ND_RESID_SEG") ? atoi(getenv("HELM_ND_RESID_SEG")) : 32;
+    const int seg = std::max(8, seg_env);
+    // rows per thread: measured on 1024^2 x 256 (norm-only launch, round 2): 1 -> 2.52 ms, 2 -> 3.71 ms, 4 -> 2.23 ms.  Round 3, launch with the
+    // wavefield store (13 GB moved): 3.45 ms -> 2.59 ms (5.0 TB/s, the rate of a plain copy on this part) with the coefficients staged in
+    // LDS (k_resid_nm_lds, full-width batches); wave-uniform scalar loads of the coefficients instead: 3.3 ms at RPT = 2, SGPR spills at 4
     static const int rpt_env = getenv("HELM_ND_RESID_RPT") ? atoi(getenv("HELM_ND_RESID_RPT")) : 4;
     const int rpt = (rpt_env == 1 || rpt_env == 2 || rpt_env == 8) ? rpt_env : 4;
     const int ntiles = ((op->nz + rpt - 1) / rpt) * ((op->nx + seg - 1) / seg);
@@ -1945,6 +2055,15 @@ int nd_resid_nm(helm_op *op, const cplx *planes, const cplx *Xin, int ldin, cplx
 #define RESID_LAUNCH(RPT_) hipLaunchKernelGGL(k_resid_nm<RPT_>, dim3(nblk), dim3(lx, ly), 0, op->stream, planes, op->nz, op->nx, Xin + c0, ldin, Q + (qmap ? 0 : c0), ldq, \
                            qmap ? qmap + c0 : nullptr, nc, store, Rout ? Rout + (qmap ? 0 : c0) : nullptr, part + (long long)c0 * 4 * nblk, nblk, seg, ntiles, \
                            qnorm, Uout ? Uout + c0 : nullptr, ldu, oscale)
+        static const int lds_env = getenv("HELM_ND_RESID_LDS") ? atoi(getenv("HELM_ND_RESID_LDS")) : 1;
+        if (lds_env && ly == 1 && seg == RESID_SEG && (rpt == 2 || rpt == 4)) {
+#define RESID_LDS(RPT_) hipLaunchKernelGGL(k_resid_nm_lds<RPT_>, dim3(nblk), dim3(256, 1), 0, op->stream, planes, op->nz, op->nx, Xin + c0, ldin, Q + (qmap ? 0 : c0), ldq, \
+                           qmap ? qmap + c0 : nullptr, nc, store, Rout ? Rout + (qmap ? 0 : c0) : nullptr, part + (long long)c0 * 4 * nblk, nblk, ntiles, \
+                           qnorm, Uout ? Uout + c0 : nullptr, ldu, oscale)
+            if (rpt == 2) RESID_LDS(2); else RESID_LDS(4);
+#undef RESID_LDS
+            continue;
+        }
         if (rpt == 1) RESID_LAUNCH(1); else if (rpt == 2) RESID_LAUNCH(2); else if (rpt == 8) RESID_LAUNCH(8); else RESID_LAUNCH(4);
 #undef RESID_LAUNCH
     }
