@@ -351,3 +351,36 @@ def test_unreachable_rtol_reports_fp64_floor(helm_lib):
     assert all(1e-17 < i['relres'] < 1e-12 for i in op.lastInfo), op.lastInfo
     ref = ho.DirectOperator(ho.eurus_coefficients(nz, nx, c, ho.gardner_rho(c.astype(complex)), 9., dx=10., dz=10., nPML=8), eurus=True) * q
     assert nrm(u, ref) <= 1e-9
+
+
+def test_ill_conditioned_fronts_reeliminated_with_lu(helm_lib, monkeypatch):
+    """HELM_ND_STABLE=1 (direct.hip, NdStable): fronts whose pivot block is near-singular -- subdomains close to a resonance at this
+    frequency -- are eliminated again with one pivoted LU used for the Schur complement, the forward and the backward pass.  On the
+    512^2 bench model at 16 Hz four of 8191 fronts are taken (condition numbers 1e4 ... 9e5) and the first pass then meets rtol 1e-10
+    where the explicit inverses alone need a refinement pass (first-pass residual 1.2e-9); same wavefield either way, and the same as
+    the sparse LU of the oracle's matrix."""
+    import zephyr_amd as za
+    from zephyr_amd.models import marmousi_like
+    from oracle import helm_oracle as ho
+    n, dx, f = 512, 9.0, 16.0
+    c = marmousi_like(n, n, dx)
+    cfg = dict(nx=n, nz=n, dx=dx, dz=dx, c=c, nPML=10, cPML=1e3, freq=f, rtol=1e-10, method='direct')
+    q = np.zeros((n * n, 3), complex)
+    q[2 * n + n // 5, 0] = 1.; q[(n // 2) * n + n // 3, 1] = 1j; q[40 * n + 400, 2] = 1. - 1j
+    op0 = za.Eurus(cfg)
+    u0 = op0 * q
+    passes0 = max(i['iterations'] for i in op0.lastInfo)
+    monkeypatch.setenv('HELM_ND_STABLE', '1')
+    op1 = za.Eurus(cfg)
+    u1 = op1 * q
+    assert all(i['status'] == 0 and i['relres'] <= 1e-10 for i in op1.lastInfo), op1.lastInfo
+    passes1 = max(i['iterations'] for i in op1.lastInfo)
+    assert passes1 == 1 and passes0 == 2, (passes0, passes1)
+    assert np.linalg.norm(u1 - u0) / np.linalg.norm(u0) <= 1e-8
+    u1b = op1 * q                                   # factors (and the treated fronts) are re-used
+    assert np.array_equal(u1, u1b)
+    rho = ho.gardner_rho(c)
+    C4 = ho.eurus_coefficients(n, n, c, rho, f, dx=dx, dz=dx, nPML=10, cPML=1e3)
+    ref = ho.DirectOperator(C4[0]) * q
+    assert np.linalg.norm(u1 - ref) / np.linalg.norm(ref) <= 1e-7
+    del op0.factors, op1.factors

@@ -228,9 +228,10 @@ __global__ __launch_bounds__(256) void k_nd_extend_add(const NdDev *nodes, int f
 // every other padded slot.  The inverse maps are the same closed-form nd_cell / nd_local; a workgroup tabulates them for the
 // front's rows once in LDS and then streams `rb` rows.  Traffic per level: children's F22 read once, the fronts written once
 // (the scatter form read-modify-wrote the parents twice on top of the memsets).
-__global__ __launch_bounds__(256) void k_nd_build_front(const NdDev *nodes, int first, cplx *arenaF, cplx *fac, const cplx *planes, int nz, int nx, int rb) {
+__global__ __launch_bounds__(256) void k_nd_build_front(const NdDev *nodes, int first, cplx *arenaF, cplx *fac, const cplx *planes, int nz, int nx, int rb,
+                                                        const NdDev *ovr = nullptr) {
     extern __shared__ int2 finfo[];        // per padded row: x = z | x << 16 (-1: padding), y = (k0 + 1) | (k1 + 1) << 14 | comp << 28
-    const NdDev n = nodes[first + blockIdx.y];
+    const NdDev n = ovr ? *ovr : nodes[first + blockIdx.y];      // (ovr: one front rebuilt with its [F11 | F12] rows redirected, see NdStable)
     const int nmax = n.smax + n.mmax;
     const int r0 = blockIdx.x * rb;
     if (r0 >= nmax) return;
@@ -1037,6 +1038,127 @@ __global__ __launch_bounds__(256) void k_gj_slices(const cplx *T0, int ld, long 
     }
 }
 
+// ---- ill-conditioned fronts (NdStable) -------------------------------------------------------------------------------------------------
+// infinity norm (largest absolute row sum, |z| taken as |re| + |im|) of the s x s pivot block of every front of a group -- before the
+// inversion: F11, after it: F11^-1; their product is the condition estimate.  (The max-entry norm was tried first: for a near-singular
+// front F11^-1 ~ u v^T / sigma with u, v spread over all unknowns, and max |entry| then underestimates the norm by the front's size --
+// the worst front of the 8-Hz bench operator, cond 1.1e6, came out as 2.5e4 and stayed below the threshold.)
+// (over the front's own s x s unknowns: the identity that pads a smaller front to the group's size is not part of its conditioning)
+__global__ __launch_bounds__(256) void k_front_absmax(const cplx *M0, int ld, long long stride, const NdDev *nodes, double *out) {
+    __shared__ double red[4];
+    const cplx *M = M0 + (long long)blockIdx.x * stride;
+    const int n = nodes[blockIdx.x].s;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double best = 0.0;
+    for (int i = wv; i < n; i += 4) {                      // a wave per row: coalesced along the row
+        double v = 0.0;
+        for (int j = lane; j < n; j += 64) { const cplx a = M[(long long)i * ld + j]; v += fabs(a.x) + fabs(a.y); }
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        v = __shfl(v, 0);
+        best = fmax(best, v);
+    }
+    if (lane == 0) red[wv] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+// list[0] = number of fronts with  scale * a[j] * b[j] > thr  (capped), list[1..] = their positions in the group, worst first is not needed
+__global__ void k_front_flag(const double *a, const double *b, int cnt, double scale, double thr, int *list, int cap) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += gridDim.x * blockDim.x)
+        if (!(scale * a[j] * b[j] <= thr)) {                                                               // (NaN counts as flagged)
+            const int slot = atomicAdd(list, 1);
+            if (slot < cap) list[1 + slot] = j;
+        }
+}
+// the same for n <= 64 with the matrix held in LDS (every elimination step is then a few hundred nanoseconds instead of several global round trips)
+__global__ __launch_bounds__(256) void k_lu_factor64(cplx *A0, int ld, int n, int *piv) {
+    __shared__ cplx A[64][65];
+    __shared__ double rv[256];
+    __shared__ int ri[256];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < n * n; e += 256) A[e / n][e % n] = A0[(long long)(e / n) * ld + e % n];
+    __syncthreads();
+    for (int k = 0; k < n; ++k) {
+        double best = -1.0; int bi = k;
+        for (int i = k + tid; i < n; i += 256) { const double v = cabs2(A[i][k]); if (v > best) { best = v; bi = i; } }
+        rv[tid] = best; ri[tid] = bi;
+        __syncthreads();
+        for (int off = 32; off > 0; off >>= 1) {          // (at most 64 candidates: the first wave's entries)
+            if (tid < off && (rv[tid + off] > rv[tid] || (rv[tid + off] == rv[tid] && ri[tid + off] < ri[tid]))) { rv[tid] = rv[tid + off]; ri[tid] = ri[tid + off]; }
+            __syncthreads();
+        }
+        const int p = ri[0];
+        if (tid == 0) piv[k] = p;
+        if (p != k && tid < n) { const cplx t = A[k][tid]; A[k][tid] = A[p][tid]; A[p][tid] = t; }
+        __syncthreads();
+        const cplx d = crecip(A[k][k]);
+        if (tid > k && tid < n) A[tid][k] = cmul(A[tid][k], d);
+        __syncthreads();
+        const int w = n - k - 1;
+        for (int e = tid; e < w * w; e += 256) {
+            const int i = k + 1 + e / w, j = k + 1 + e % w;
+            const cplx l = A[i][k], u = A[k][j];
+            cplx a = A[i][j];
+            a.x = fma(-l.x, u.x, a.x); a.x = fma(l.y, u.y, a.x);
+            a.y = fma(-l.x, u.y, a.y); a.y = fma(-l.y, u.x, a.y);
+            A[i][j] = a;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < n * n; e += 256) A0[(long long)(e / n) * ld + e % n] = A[e / n][e % n];
+}
+// LU with partial pivoting of one n x n matrix in global memory (one workgroup; the matrix is small and lives in L2)
+__global__ __launch_bounds__(256) void k_lu_factor(cplx *A, int ld, int n, int *piv) {
+    __shared__ double rv[256];
+    __shared__ int ri[256];
+    __shared__ int psh;
+    const int tid = threadIdx.x;
+    for (int k = 0; k < n; ++k) {
+        double best = -1.0; int bi = k;
+        for (int i = k + tid; i < n; i += 256) { const double v = cabs2(A[(long long)i * ld + k]); if (v > best) { best = v; bi = i; } }
+        rv[tid] = best; ri[tid] = bi;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off && (rv[tid + off] > rv[tid] || (rv[tid + off] == rv[tid] && ri[tid + off] < ri[tid]))) { rv[tid] = rv[tid + off]; ri[tid] = ri[tid + off]; }
+            __syncthreads();
+        }
+        if (tid == 0) { psh = ri[0]; piv[k] = ri[0]; }
+        __syncthreads();
+        const int p = psh;
+        if (p != k) for (int j = tid; j < n; j += 256) { const cplx t = A[(long long)k * ld + j]; A[(long long)k * ld + j] = A[(long long)p * ld + j]; A[(long long)p * ld + j] = t; }
+        __syncthreads();
+        const cplx d = crecip(A[(long long)k * ld + k]);
+        for (int i = k + 1 + tid; i < n; i += 256) A[(long long)i * ld + k] = cmul(A[(long long)i * ld + k], d);
+        __syncthreads();
+        const int w = n - k - 1;
+        for (int e = tid; e < w * w; e += 256) {
+            const int i = k + 1 + e / w, j = k + 1 + e % w;
+            const cplx l = A[(long long)i * ld + k], u = A[(long long)k * ld + j];
+            cplx a = A[(long long)i * ld + j];
+            a.x = fma(-l.x, u.x, a.x); a.x = fma(l.y, u.y, a.x);
+            a.y = fma(-l.x, u.y, a.y); a.y = fma(-l.y, u.x, a.y);
+            A[(long long)i * ld + j] = a;
+        }
+        __syncthreads();
+    }
+}
+// B <- (L U)^-1 P B in place, one thread per column of B (row-major, leading dimension ldb): the factor entries are uniform across the
+// threads (scalar loads), the column entries coalesced
+__global__ __launch_bounds__(64) void k_lu_solve(const cplx *__restrict__ LU, int ld, int n, const int *__restrict__ piv, cplx *B, int ldb, int ncols) {
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    if (j >= ncols) return;
+    for (int k = 0; k < n; ++k) { const int p = piv[k]; if (p != k) { const cplx t = B[(long long)k * ldb + j]; B[(long long)k * ldb + j] = B[(long long)p * ldb + j]; B[(long long)p * ldb + j] = t; } }
+    for (int i = 1; i < n; ++i) {                  // L y = P b (unit lower triangle)
+        cplx acc = B[(long long)i * ldb + j];
+        for (int k = 0; k < i; ++k) { const cplx l = LU[(long long)i * ld + k], y = B[(long long)k * ldb + j]; acc.x = fma(-l.x, y.x, acc.x); acc.x = fma(l.y, y.y, acc.x); acc.y = fma(-l.x, y.y, acc.y); acc.y = fma(-l.y, y.x, acc.y); }
+        B[(long long)i * ldb + j] = acc;
+    }
+    for (int i = n - 1; i >= 0; --i) {             // U x = y
+        cplx acc = B[(long long)i * ldb + j];
+        for (int k = i + 1; k < n; ++k) { const cplx u = LU[(long long)i * ld + k], x = B[(long long)k * ldb + j]; acc.x = fma(-u.x, x.x, acc.x); acc.x = fma(u.y, x.y, acc.x); acc.y = fma(-u.x, x.y, acc.y); acc.y = fma(-u.y, x.x, acc.y); }
+        B[(long long)i * ldb + j] = cmul(acc, crecip(LU[(long long)i * ld + i]));
+    }
+}
+
 // ---- solve-phase data movement -----------------------------------------------------------------------------------
 // out[i][r] = in[r][i]   (in: rows x cols)
 // (the long dimension always rides on gridDim.x: `swap` exchanges the roles of blockIdx.x / blockIdx.y)
@@ -1662,8 +1784,23 @@ int nd_get_plan(helm_op *op, int leaf, int dof, std::shared_ptr<NdPlanDev> *out)
 }
 
 // ---- factorisation ---------------------------------------------------------------------------------------------
+static void stable_free(NdFactor *f) {
+    const int dev = f->pd ? f->pd->device : 0;
+    for (NdStable &st : f->stable) {
+        const size_t nmax = (size_t)st.smax + st.mmax;
+        helm_pool_free(dev, st.lu, (size_t)st.smax * nmax * sizeof(cplx));
+        helm_pool_free(dev, st.f21, (size_t)std::max(1, st.mmax) * st.smax * sizeof(cplx));
+        helm_pool_free(dev, st.piv, (size_t)st.smax * sizeof(int));
+        helm_pool_free(dev, st.d_node, sizeof(NdDev));
+        helm_pool_free(dev, st.vs, st.vs_elems * sizeof(cplx));
+    }
+    f->stable.clear();
+}
+
 void nd_free(NdFactor *f) {
     if (!f) return;
+    stable_free(f);
+    if (f->d_est) helm_pool_free(f->pd ? f->pd->device : 0, f->d_est, f->est_elems * sizeof(double));
     if (f->d_fac) helm_pool_free(f->pd ? f->pd->device : 0, f->d_fac, (size_t)f->pd->plan.fac_elems * sizeof(cplx));
     delete f;
 }
@@ -1674,6 +1811,94 @@ namespace {
 bool merged_leaf_backward() {
     static const int v = getenv("HELM_ND_MERGED_LEAF") ? atoi(getenv("HELM_ND_MERGED_LEAF")) : 1;
     return v != 0 && gemm_variant() != 0;
+}
+
+// ---- ill-conditioned fronts: detection and re-elimination with a pivoted LU (see NdStable in direct.hpp) -------------------------------------
+// OFF by default (HELM_ND_STABLE=1 switches it on).  Measured on the 16-frequency bench job (MI355X, round 3): every wavefield then meets
+// rtol 1e-10 in ONE pass (passes per wavefield 1.15 -> 1.00, worst first-pass residual 7e-9 -> 6e-11), but the job is slower, 7775 against
+// 8090 wavefields/s: detection costs 0.9 ms per factorisation (two norm kernels and one read-back per tree level), every treated front
+// 0.4 ms at factor time and 0.6 ms per pass with the one-front-at-a-time kernels below, and ten to forty fronts per frequency exceed the
+// threshold while only three of sixteen frequencies save a whole refinement pass (20 ms).  What would make it pay: the treated fronts of a
+// level handled by batched launches, and a wave-synchronous LDS triangular solve.
+// HELM_ND_STABLE_THR: a front is taken when its condition estimate ||F11||_inf ||F11^-1||_inf
+// exceeds it (default 2e4: at 1024^2 / 9 Hz about ten of 32 767 fronts, which between them are the difference between a first-pass residual
+// of 4e-9 and 2e-12; a typical leaf sits at 20-40, the tree top at 50-1000).
+// Fronts of more than HELM_ND_STABLE_SMAX (128) separator unknowns are left alone: the one-workgroup LU would cost more than the
+// refinement pass it saves, and none that large has been seen ill-conditioned (the tree top sits at cond 50-1000)
+bool stable_enabled(const NdPlan &P) {
+    const char *e = getenv("HELM_ND_STABLE");          // (read per call: the tests switch it)
+    return e && atoi(e) != 0 && P.dof == 1 && gemm_variant() != 0;
+}
+#define ND_STABLE_CAP 32
+int ensure_est(helm_op *op, NdFactor *f, int cnt) {
+    const size_t need = 2 * (size_t)cnt + (ND_STABLE_CAP + 2) / 2 + 8;         // two doubles per front + the flag list (ints) behind them
+    if (f->est_elems >= need) return HELM_OK;
+    if (f->d_est) { hipStreamSynchronize(op->stream); helm_pool_free(op->device, f->d_est, f->est_elems * sizeof(double)); f->d_est = nullptr; f->est_elems = 0; }
+    int maxcnt = cnt;
+    for (const NdGroup &g : f->pd->plan.groups) maxcnt = std::max(maxcnt, g.cnt);
+    const size_t elems = 2 * (size_t)maxcnt + (ND_STABLE_CAP + 2) / 2 + 8;
+    f->d_est = (double *)helm_pool_alloc(op->device, elems * sizeof(double));
+    if (!f->d_est) return HELM_ERR_DEVICE;
+    f->est_elems = elems;
+    return HELM_OK;
+}
+
+int check_kernels(helm_op *op, const char *what);
+
+// after the batched elimination of group gi: find its ill-conditioned fronts (one small read-back per group) and eliminate each of them again
+int stabilise_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, const cplx *planes) {
+    const NdPlan &P = f->pd->plan;
+    const NdGroup &g = P.groups[gi];
+    hipStream_t st = op->stream;
+    const double thr = getenv("HELM_ND_STABLE_THR") ? atof(getenv("HELM_ND_STABLE_THR")) : 2e4;
+    const int nmax = g.smax + g.mmax;
+    int *d_list = (int *)(f->d_est + 2 * (size_t)g.cnt);
+    HIP_TRY(op, hipMemsetAsync(d_list, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_front_flag, dim3((g.cnt + 255) / 256), dim3(256), 0, st, (const double *)f->d_est, (const double *)(f->d_est + g.cnt), g.cnt, 1.0, thr, d_list, ND_STABLE_CAP);
+    int h_list[ND_STABLE_CAP + 1];
+    HIP_TRY(op, hipMemcpyAsync(h_list, d_list, sizeof(h_list), hipMemcpyDeviceToHost, st));
+    HIP_TRY(op, hipStreamSynchronize(st));
+    const int nflag = std::max(0, std::min(h_list[0], ND_STABLE_CAP));
+    std::sort(h_list + 1, h_list + 1 + nflag);                                   // (the atomics hand the slots out in no particular order)
+    if (getenv("HELM_ND_DEBUG") && atoi(getenv("HELM_ND_DEBUG")) >= 2) {
+        std::vector<double> h(2 * (size_t)g.cnt);
+        hipMemcpy(h.data(), f->d_est, h.size() * sizeof(double), hipMemcpyDeviceToHost);
+        double worst = 0; int wj = 0;
+        for (int j = 0; j < g.cnt; ++j) { const double e = h[j] * h[g.cnt + j]; if (!(e <= worst)) { worst = e; wj = j; } }
+        fprintf(stderr, "[helm direct] level %d s %d cnt %d: estimate of front 0 = %.3e * %.3e; worst %.3e at %d; flagged %d\n", g.level, g.smax, g.cnt, h[0], h[g.cnt], worst, wj, h_list[0]);
+    }
+    if ((long long)g.smax * g.mmax > P.work_elems) return HELM_OK;               // (no room for the s x m solve: leave the group as it is)
+    const cplx one = cmake(1, 0), mone = cmake(-1, 0);
+    for (int q = 0; q < nflag; ++q) {
+        const int j = h_list[1 + q];
+        NdStable S;
+        S.node = g.first + j; S.group = gi; S.smax = g.smax; S.mmax = g.mmax;
+        S.lu = (cplx *)helm_pool_alloc(op->device, (size_t)g.smax * nmax * sizeof(cplx));
+        S.f21 = (cplx *)helm_pool_alloc(op->device, (size_t)std::max(1, g.mmax) * g.smax * sizeof(cplx));
+        S.piv = (int *)helm_pool_alloc(op->device, (size_t)g.smax * sizeof(int));
+        S.d_node = (NdDev *)helm_pool_alloc(op->device, sizeof(NdDev));
+        f->stable.push_back(S);                                                   // (owned by the factor from here on: freed by nd_free on every path)
+        if (!S.lu || !S.f21 || !S.piv || !S.d_node) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: allocation for an ill-conditioned front failed");
+        NdDev n = P.nodes[S.node];
+        const long long foff = n.foff;
+        n.finv_off = 0; n.f12_off = g.smax;                                       // [F11 | F12] rows go to S.lu, [F21 | F22] back to the arena
+        HIP_TRY(op, hipMemcpyAsync(S.d_node, &n, sizeof(NdDev), hipMemcpyHostToDevice, st));
+        HIP_TRY(op, hipStreamSynchronize(st));                                    // (n is a stack copy)
+        const int rb = std::max(std::min(nmax, 4), (nmax + 2047) / 2048);
+        hipLaunchKernelGGL(k_nd_build_front, dim3((nmax + rb - 1) / rb, 1), dim3(256), (size_t)nmax * sizeof(int2), st, f->pd->d_nodes, 0, arenaF, S.lu, planes, op->nz, op->nx, rb,
+                           (const NdDev *)S.d_node);
+        cplx *F21 = arenaF + foff, *F22 = arenaF + foff + g.smax;
+        HIP_TRY(op, hipMemcpy2DAsync(S.f21, (size_t)g.smax * sizeof(cplx), F21, (size_t)nmax * sizeof(cplx), (size_t)g.smax * sizeof(cplx), (size_t)g.mmax, hipMemcpyDeviceToDevice, st));
+        if (g.smax <= 64) hipLaunchKernelGGL(k_lu_factor64, dim3(1), dim3(256), 0, st, S.lu, nmax, g.smax, S.piv);
+        else hipLaunchKernelGGL(k_lu_factor, dim3(1), dim3(256), 0, st, S.lu, nmax, g.smax, S.piv);
+        // Schur complement through the same factors: F22 -= F21 (F11^-1 F12)
+        HIP_TRY(op, hipMemcpy2DAsync(work, (size_t)g.mmax * sizeof(cplx), S.lu + g.smax, (size_t)nmax * sizeof(cplx), (size_t)g.mmax * sizeof(cplx), (size_t)g.smax, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_lu_solve, dim3((g.mmax + 63) / 64), dim3(64), 0, st, (const cplx *)S.lu, nmax, g.smax, (const int *)S.piv, work, g.mmax, g.mmax);
+        gemm(op, g.mmax, g.mmax, g.smax, mone, S.f21, g.smax, 0, work, g.mmax, 0, one, F22, nmax, 0, 1, nullptr);
+    }
+    static const int dbg = getenv("HELM_ND_DEBUG") ? atoi(getenv("HELM_ND_DEBUG")) : 0;
+    if (dbg && nflag) fprintf(stderr, "[helm direct] level %d (%s, s = %d, m = %d): %d ill-conditioned front(s) re-eliminated with a pivoted LU\n", g.level, g.leaf ? "leaves" : "separators", g.smax, g.mmax, nflag);
+    return check_kernels(op, "re-elimination of ill-conditioned fronts");
 }
 
 // factorisation of one group (tree level x kind) on op->stream
@@ -1724,7 +1949,13 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
     // the few huge fronts at the top of the tree are one long chain of single-matrix launches: the wider base block halves it
     static const int gj_top = getenv("HELM_ND_GJ_TOP") ? atoi(getenv("HELM_ND_GJ_TOP")) : 0;
     const int base = g.leaf ? gj_leaf : (g.cnt <= gj_top ? 64 : gj_upper);
+    const int stable_smax = getenv("HELM_ND_STABLE_SMAX") ? atoi(getenv("HELM_ND_STABLE_SMAX")) : 128;
+    const bool watch = stable_enabled(P) && g.mmax > 0 && g.smax <= stable_smax && ensure_est(op, f, g.cnt) == HELM_OK;
+    if (watch) for (int j0 = 0; j0 < g.cnt; j0 += 65535)
+        hipLaunchKernelGGL(k_front_absmax, dim3(std::min(65535, g.cnt - j0)), dim3(256), 0, st, Finv + (long long)j0 * s1, nmax, s1, d_nodes + g.first + j0, f->d_est + j0);
     invert(op, Finv, nmax, s1, g.smax, g.cnt, work, s11, P.dof, base);      // F11 -> F11^-1 where it stays
+    if (watch) for (int j0 = 0; j0 < g.cnt; j0 += 65535)
+        hipLaunchKernelGGL(k_front_absmax, dim3(std::min(65535, g.cnt - j0)), dim3(256), 0, st, Finv + (long long)j0 * s1, nmax, s1, d_nodes + g.first + j0, f->d_est + g.cnt + j0);
     if (g.mmax > 0) {
         // G21 = F21 F11^-1 ; F22 -= G21 F12
         gemm(op, g.mmax, g.smax, g.smax, one, F, nmax, fs, Finv, nmax, s1, zero, G21, g.smax, (long long)g.mmax * g.smax, g.cnt);
@@ -1742,6 +1973,7 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
         }
     }
     f->flops += (double)g.cnt * 8.0 * (2.0 * g.smax * g.smax * g.smax + (double)g.smax * g.smax * g.mmax + (double)g.smax * g.mmax * g.mmax);
+    if (watch) return stabilise_group(op, f, gi, arenaF, work, planes);
     return HELM_OK;
 }
 
@@ -1763,8 +1995,32 @@ SolveCtx solve_ctx(const NdFactor *f, cplx *ws, int nrhs) {
     return c;
 }
 
+// ill-conditioned fronts of group gi (NdStable): their outgoing rows once more, through the front's own LU
+void forward_stable(helm_op *op, NdFactor *f, size_t gi, const SolveCtx &c) {
+    const NdPlan &P = f->pd->plan;
+    const NdGroup &g = P.groups[gi];
+    const cplx one = cmake(1, 0), mone = cmake(-1, 0);
+    for (NdStable &S : f->stable) {
+        if (S.group != gi) continue;
+        const NdDev &n = P.nodes[S.node];
+        const int nmax = S.smax + S.mmax, nrhs = c.nrhs;
+        cplx *V = c.arenaV + n.voff * nrhs;
+        // the front vector gathered again: separator rows q_S + the children's rows (written to Xt as y_S for the back substitution), ring rows
+        // the children's rows; then z = F11^-1 y_S through the LU and V_B -= F21 z
+        hipLaunchKernelGGL(k_nd_fwd_rows, c.rgrid(nmax), c.rb, 0, op->stream, c.tab + n.roff, V, c.arenaV, c.Qt, c.Xt, (long long)nmax, nrhs, g.leaf ? 0 : 1);
+        hipLaunchKernelGGL(k_lu_solve, dim3((nrhs + 63) / 64), dim3(64), 0, op->stream, (const cplx *)S.lu, nmax, S.smax, (const int *)S.piv, V, nrhs, nrhs);
+        gemm(op, S.mmax, nrhs, S.smax, mone, S.f21, S.smax, 0, V, nrhs, 0, one, V + (long long)S.smax * nrhs, nrhs, 0, 1);
+    }
+}
+
+void forward_group_batched(helm_op *op, NdFactor *f, size_t gi, const SolveCtx &c);
 // forward elimination of one group on op->stream
 void forward_group(helm_op *op, NdFactor *f, size_t gi, const SolveCtx &c) {
+    forward_group_batched(op, f, gi, c);
+    if (!f->stable.empty()) forward_stable(op, f, gi, c);
+}
+
+void forward_group_batched(helm_op *op, NdFactor *f, size_t gi, const SolveCtx &c) {
     const NdPlan &P = f->pd->plan;
     const cplx one = cmake(1, 0), mone = cmake(-1, 0), zero = cmake(0, 0);
     const NdGroup &g = P.groups[gi];
@@ -1796,8 +2052,43 @@ void forward_group(helm_op *op, NdFactor *f, size_t gi, const SolveCtx &c) {
              V + (long long)g.smax * nrhs, nrhs, (long long)nmax * nrhs, g.cnt);
 }
 
+// ill-conditioned fronts of group gk: [y_S; x_B] is set aside before the batched launches overwrite y_S in Xt (pre), and x_S = F11^-1 (y_S - F12 x_B)
+// through the front's LU replaces what they wrote (post)
+int backward_stable(helm_op *op, NdFactor *f, size_t gk, const SolveCtx &c, bool post) {
+    const NdPlan &P = f->pd->plan;
+    const NdGroup &g = P.groups[gk];
+    const cplx one = cmake(1, 0), mone = cmake(-1, 0);
+    for (NdStable &S : f->stable) {
+        if (S.group != gk) continue;
+        const NdDev &n = P.nodes[S.node];
+        const int nmax = S.smax + S.mmax, nrhs = c.nrhs;
+        if (!post) {
+            const size_t need = (size_t)nmax * nrhs;
+            if (S.vs_elems < need) {
+                if (S.vs) { hipStreamSynchronize(op->stream); helm_pool_free(op->device, S.vs, S.vs_elems * sizeof(cplx)); S.vs = nullptr; S.vs_elems = 0; }
+                S.vs = (cplx *)helm_pool_alloc(op->device, need * sizeof(cplx));
+                if (!S.vs) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: scratch for an ill-conditioned front failed");
+                S.vs_elems = need;
+            }
+            hipLaunchKernelGGL(k_nd_bwd_gather, c.rgrid(nmax), c.rb, 0, op->stream, c.tab + n.roff, S.vs, g.leaf ? c.Qt : (const cplx *)c.Xt, (const cplx *)c.Xt, (long long)nmax, nrhs);
+        } else {
+            if (S.mmax > 0) gemm(op, S.smax, nrhs, S.mmax, mone, S.lu + S.smax, nmax, 0, S.vs + (long long)S.smax * nrhs, nrhs, 0, one, S.vs, nrhs, 0, 1);
+            hipLaunchKernelGGL(k_lu_solve, dim3((nrhs + 63) / 64), dim3(64), 0, op->stream, (const cplx *)S.lu, nmax, S.smax, (const int *)S.piv, S.vs, nrhs, nrhs);
+            hipLaunchKernelGGL(k_nd_bwd_store, c.rgrid(S.smax), c.rb, 0, op->stream, c.tab + n.roff, (const cplx *)S.vs, c.Xt, (long long)S.smax, S.smax, nmax, nrhs);
+        }
+    }
+    return HELM_OK;
+}
+
+void backward_group_batched(helm_op *op, NdFactor *f, size_t gk, const SolveCtx &c);
 // back substitution of one group on op->stream
 void backward_group(helm_op *op, NdFactor *f, size_t gk, const SolveCtx &c) {
+    if (!f->stable.empty()) (void)backward_stable(op, f, gk, c, false);
+    backward_group_batched(op, f, gk, c);
+    if (!f->stable.empty()) (void)backward_stable(op, f, gk, c, true);
+}
+
+void backward_group_batched(helm_op *op, NdFactor *f, size_t gk, const SolveCtx &c) {
     const NdPlan &P = f->pd->plan;
     const cplx one = cmake(1, 0), mone = cmake(-1, 0), zero = cmake(0, 0);
     const NdGroup &g = P.groups[gk];

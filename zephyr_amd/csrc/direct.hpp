@@ -46,11 +46,29 @@ struct NdPlanDev {            // plan + its device-resident tables, shared by ev
     ~NdPlanDev();
 };
 
+// A front whose pivot block F11 is too ill-conditioned for its explicit inverse (a near-resonant subdomain: the subtree's region with its
+// ring clamped has an eigenvalue close to zero at this frequency; a handful per frequency at most).  The batched path multiplies with
+// F11^-1 in three places -- Schur complement, forward and backward pass -- and the rounding of those three is not consistent, which costs
+// cond(F11) eps in the residual.  Such a front is eliminated again with ONE pivoted LU used in all three places (what a CPU multifrontal
+// code does for every front): the factorisation error then cancels between them.
+struct NdStable {
+    int node = -1;               // front (plan order)
+    size_t group = 0;
+    int smax = 0, mmax = 0;
+    cplx *lu = nullptr;          // [smax][smax + mmax]: L\U of F11 in the first smax columns, the original F12 beside it
+    cplx *f21 = nullptr;         // [mmax][smax]: the original F21
+    int *piv = nullptr;          // [smax] row exchanges
+    NdDev *d_node = nullptr;     // the front's node record with its [F11 | F12] rows redirected to `lu` (rebuild pass)
+    cplx *vs = nullptr; size_t vs_elems = 0;     // back-substitution scratch [smax + mmax][nrhs], grown on demand
+};
+
 struct NdFactor {
     std::shared_ptr<NdPlanDev> pd;
     cplx *d_fac = nullptr;
     int block = 0;
     double flops = 0;
+    std::vector<NdStable> stable;
+    double *d_est = nullptr; size_t est_elems = 0;      // per front of a group: max |F11| before, max |F11^-1| after the inversion; flag list
 };
 
 // local index of unknown (cell (z, x), component comp) in the front: [0, s) separator, [s, s+m) ring; -1 when the cell
