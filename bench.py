@@ -284,6 +284,9 @@ def main():
     ap.add_argument('--no-host-api', action='store_true', help='skip the host-array leg (MultiFreq * q with numpy / scipy-sparse in, numpy out; ~5 s)')
     ap.add_argument('--no-pipeline', dest='pipeline', action='store_false',
                     help='work items strictly one after the other (no prepare-ahead thread, no helm_prefactor)')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
+                    help="weak (default, the driver's contract): every rank does --steps work items; strong: the 16-frequency job itself (16 items of 256 sources) "
+                         "split over the ranks, frequency-major, one number for the whole job")
     ap.add_argument('--no-config5', action='store_true', help='skip the 3-D leg (BASELINE configs[4]: 256x256x128, 4 freqs x 16 sources; ~15 s)')
     ap.add_argument('--config5-rtol', type=float, default=1e-8)
     ap.add_argument('--streams', type=int, default=1, help='work items in flight per GPU (host threads, one operator handle / HIP stream each)')
@@ -376,13 +379,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run_items([rank + world * k for k in range(args.warmup)], False)
+    if args.scaling == 'strong':
+        # the job: work items 0 .. 15 (all 16 frequencies, 256 sources each), dealt round-robin over the ranks; a rank with nothing to do just waits
+        timed_items = [w for w in range(NFREQ * nb) if w % world == rank]
+        warm_items = timed_items[:args.warmup]
+    else:
+        timed_items = [rank + world * (args.warmup + k) for k in range(args.steps)]
+        warm_items = [rank + world * k for k in range(args.warmup)]
+    nsteps = max(1, len(timed_items)) if args.scaling == 'strong' else args.steps
+    run_items(warm_items, False)
 
     barrier()
     t0 = time.perf_counter()
-    results = [None] * args.steps
+    results = [None] * len(timed_items)
     if args.streams <= 1:
-        results = run_items([rank + world * (args.warmup + k) for k in range(args.steps)], True)
+        results = run_items(timed_items, True)
     else:
         # several work items in flight: each host thread drives its own operator handle (own HIP stream); ctypes
         # releases the GIL, so the latency-bound coarse multigrid levels of one item overlap the fine levels of another
@@ -391,8 +402,8 @@ def main():
         torch.cuda.synchronize()
 
         def worker(tid):
-            for k in range(tid, args.steps, args.streams):
-                results[k] = run_item(rank + world * (args.warmup + k), True, bufs[tid])
+            for k in range(tid, len(timed_items), args.streams):
+                results[k] = run_item(timed_items[k], True, bufs[tid])
         threads = [threading.Thread(target=worker, args=(t,)) for t in range(args.streams)]
         for th in threads:
             th.start()
@@ -428,7 +439,7 @@ def main():
     agg_k = agg
     if args.pipeline and args.streams <= 1:
         barrier()
-        agg_k = aggregate([run_item(rank + world * (args.warmup + k), True) for k in range(args.steps)])
+        agg_k = aggregate([run_item(w, True) for w in timed_items])
         barrier()
 
     # the same K work items once more with the per-launch HIP events off: what the event traffic of the roofline measurement costs
@@ -436,11 +447,11 @@ def main():
     if args.streams <= 1 and not args.no_plain_pass:
         barrier()
         t1 = time.perf_counter()
-        run_items([rank + world * (args.warmup + k) for k in range(args.steps)], False)
+        run_items(timed_items, False)
         barrier()
         elapsed_plain = max_over_ranks(time.perf_counter() - t1)
 
-    wavefields = world * args.steps * B
+    wavefields = (NFREQ * nb * B) if args.scaling == 'strong' else world * args.steps * B
     value = wavefields / elapsed
 
     out = None
@@ -481,21 +492,21 @@ def main():
         iters = agg['iters']
         out = {
             'metric': 'wavefields/sec (freq x source solves/s) on 1024^2 grid',
-            'value': value, 'unit': 'wavefields/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'value': value, 'unit': 'wavefields/s', 'n_gpus': world, 'steps': nsteps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / nsteps, 'higher_is_better': True, 'scaling': args.scaling,
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'timed_region': 'K work items through the device pipeline with per-launch HIP events on; `unprofiled` repeats the same K items with the events off',
             'pipeline': ('device pipeline of zephyr_amd.dispatch (MultiFreq parallel mode): item k+1 is created, assembled and its factorisation enqueued '
                          '(helm_prefactor, high-priority stream) while item k is being solved' if args.pipeline else 'off: items strictly one after the other'),
-            'unprofiled': None if elapsed_plain is None else {'value': wavefields / elapsed_plain, 'ms_per_step': 1e3 * elapsed_plain / args.steps},
+            'unprofiled': None if elapsed_plain is None else {'value': wavefields / elapsed_plain, 'ms_per_step': 1e3 * elapsed_plain / nsteps},
             'config': {'workload': 'Eurus 2D isotropic %dx%d synthetic-Marmousi (seed 20240512, dx=%g m), 16 freqs 2-9.5 Hz x 256 Kaiser sources; '
                                    'step = create + assemble 1 frequency + solve %d sources to true relres<=%g (method=%s: %s)' % (n, n, dx, B, args.rtol, args.method, how),
                        'buffers': ("node-major: right-hand sides and wavefields in the reference's own (N, nsrc) C-order arrays, resident in HBM" if node else
                                    'rhs-major: one right-hand side / wavefield per row, resident in HBM'),
-                       'grid': [n, n], 'sources_per_step': B, 'work_items_in_flight': args.streams, 'freqs_hz_this_run': agg['freqs'], 'sharding': 'work items (freq, source batch) round-robin over ranks',
+                       'grid': [n, n], 'sources_per_step': B, 'work_items_in_flight': args.streams, 'freqs_hz_this_run': agg['freqs'], 'sharding': ('strong: the 16 work items of the job (one frequency x 256 sources each) round-robin over ranks; value = 4096 wavefields / slowest rank' if args.scaling == 'strong' else 'work items (freq, source batch) round-robin over ranks'),
                        'solves_or_iterations_per_rhs_mean': float(np.mean(iters)) if iters else None,
                        'solves_or_iterations_per_rhs_max': int(np.max(iters)) if iters else None,
-                       'device_ms_per_step': {'solve_call': agg['solve_ms'] / args.steps, 'of_which_factorisation': agg['factor_ms'] / args.steps,
+                       'device_ms_per_step': {'solve_call': agg['solve_ms'] / nsteps, 'of_which_factorisation': agg['factor_ms'] / nsteps,
                                               'note': 'pipelined: solve_call covers the triangular solves + residual checks of an item, the factorisation (of_which_factorisation: its span on its own '
                                                       'stream, beside the previous item) is no longer inside it' if args.pipeline else 'serial: the factorisation is inside solve_call'}},
         }
