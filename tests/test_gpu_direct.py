@@ -354,7 +354,7 @@ def test_unreachable_rtol_reports_fp64_floor(helm_lib):
 
 
 def test_ill_conditioned_fronts_reeliminated_with_lu(helm_lib, monkeypatch):
-    """HELM_ND_STABLE=1 (direct.hip, NdStable): fronts whose pivot block is near-singular -- subdomains close to a resonance at this
+    """direct.hip, NdStable (default; HELM_ND_STABLE=0 switches it off): fronts whose pivot block is near-singular -- subdomains close to a resonance at this
     frequency -- are eliminated again with one pivoted LU used for the Schur complement, the forward and the backward pass.  On the
     512^2 bench model at 16 Hz four of 8191 fronts are taken (condition numbers 1e4 ... 9e5) and the first pass then meets rtol 1e-10
     where the explicit inverses alone need a refinement pass (first-pass residual 1.2e-9); same wavefield either way, and the same as
@@ -367,10 +367,11 @@ def test_ill_conditioned_fronts_reeliminated_with_lu(helm_lib, monkeypatch):
     cfg = dict(nx=n, nz=n, dx=dx, dz=dx, c=c, nPML=10, cPML=1e3, freq=f, rtol=1e-10, method='direct')
     q = np.zeros((n * n, 3), complex)
     q[2 * n + n // 5, 0] = 1.; q[(n // 2) * n + n // 3, 1] = 1j; q[40 * n + 400, 2] = 1. - 1j
+    monkeypatch.setenv('HELM_ND_STABLE', '0')
     op0 = za.Eurus(cfg)
     u0 = op0 * q
     passes0 = max(i['iterations'] for i in op0.lastInfo)
-    monkeypatch.setenv('HELM_ND_STABLE', '1')
+    monkeypatch.delenv('HELM_ND_STABLE')
     op1 = za.Eurus(cfg)
     u1 = op1 * q
     assert all(i['status'] == 0 and i['relres'] <= 1e-10 for i in op1.lastInfo), op1.lastInfo

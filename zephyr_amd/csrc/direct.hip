@@ -1141,22 +1141,59 @@ __global__ __launch_bounds__(256) void k_lu_factor(cplx *A, int ld, int n, int *
         __syncthreads();
     }
 }
-// B <- (L U)^-1 P B in place, one thread per column of B (row-major, leading dimension ldb): the factor entries are uniform across the
-// threads (scalar loads), the column entries coalesced
-__global__ __launch_bounds__(64) void k_lu_solve(const cplx *__restrict__ LU, int ld, int n, const int *__restrict__ piv, cplx *B, int ldb, int ncols) {
-    const int j = blockIdx.x * 64 + threadIdx.x;
-    if (j >= ncols) return;
-    for (int k = 0; k < n; ++k) { const int p = piv[k]; if (p != k) { const cplx t = B[(long long)k * ldb + j]; B[(long long)k * ldb + j] = B[(long long)p * ldb + j]; B[(long long)p * ldb + j] = t; } }
-    for (int i = 1; i < n; ++i) {                  // L y = P b (unit lower triangle)
-        cplx acc = B[(long long)i * ldb + j];
-        for (int k = 0; k < i; ++k) { const cplx l = LU[(long long)i * ld + k], y = B[(long long)k * ldb + j]; acc.x = fma(-l.x, y.x, acc.x); acc.x = fma(l.y, y.y, acc.x); acc.y = fma(-l.x, y.y, acc.y); acc.y = fma(-l.y, y.x, acc.y); }
-        B[(long long)i * ldb + j] = acc;
+// B <- (L U)^-1 P B in place (B row-major, leading dimension ldb; n <= 128).  A workgroup takes 16 columns into LDS; a wave owns four of
+// them, 16 lanes per column: a row's dot product against the rows already solved is split over the 16 lanes (k = p, p + 16, ...) and summed
+// with four shuffles.  Everything a wave touches in LDS is its own four columns, so there is no barrier inside the substitutions (LDS
+// operations of a wave execute in order); the factor's row i + 1 is in flight from L2 while row i is being reduced.
+#define LUS_NMAX 128
+__global__ __launch_bounds__(256) void k_lu_solve(const cplx *__restrict__ LU, int ld, int n, const int *__restrict__ piv, cplx *B, int ldb, int ncols) {
+    __shared__ cplx Bt[LUS_NMAX][16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int cl = wv * 4 + (lane >> 4), p = lane & 15;          // local column 0..15, part 0..15
+    const int j0 = blockIdx.x * 16;
+    for (int e = tid; e < n * 16; e += 256) { const int i = e >> 4, c = e & 15; Bt[i][c] = j0 + c < ncols ? B[(long long)i * ldb + j0 + c] : cmake(0.0, 0.0); }
+    __syncthreads();
+    if (p == 0) for (int k = 0; k < n; ++k) { const int q = piv[k]; if (q != k) { const cplx t = Bt[k][cl]; Bt[k][cl] = Bt[q][cl]; Bt[q][cl] = t; } }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int NK = LUS_NMAX / 16;
+    cplx cur[NK], nxt[NK];
+    auto load_row = [&](cplx (&dst)[NK], int i, int klo, int khi) {        // entries k in [klo, khi), k = p + 16 q
+        #pragma unroll
+        for (int q = 0; q < NK; ++q) { const int k = p + 16 * q; dst[q] = (i >= 0 && i < n && k >= klo && k < khi) ? LU[(long long)i * ld + k] : cmake(0.0, 0.0); }
+    };
+    // L y = P b (unit lower triangle): rows top-down
+    load_row(cur, 1, 0, 1);
+    for (int i = 1; i < n; ++i) {
+        load_row(nxt, i + 1, 0, i + 1);
+        cplx acc = cmake(0.0, 0.0);
+        #pragma unroll
+        for (int q = 0; q < NK; ++q) { const int k = p + 16 * q; if (k < i) cfma(acc, cur[q], Bt[k][cl]); }
+        #pragma unroll
+        for (int off = 8; off > 0; off >>= 1) { acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off); }
+        if (p == 0) Bt[i][cl] = csub(Bt[i][cl], acc);
+        __builtin_amdgcn_wave_barrier();
+        #pragma unroll
+        for (int q = 0; q < NK; ++q) cur[q] = nxt[q];
     }
-    for (int i = n - 1; i >= 0; --i) {             // U x = y
-        cplx acc = B[(long long)i * ldb + j];
-        for (int k = i + 1; k < n; ++k) { const cplx u = LU[(long long)i * ld + k], x = B[(long long)k * ldb + j]; acc.x = fma(-u.x, x.x, acc.x); acc.x = fma(u.y, x.y, acc.x); acc.y = fma(-u.x, x.y, acc.y); acc.y = fma(-u.y, x.x, acc.y); }
-        B[(long long)i * ldb + j] = cmul(acc, crecip(LU[(long long)i * ld + i]));
+    // U x = y: rows bottom-up
+    load_row(cur, n - 1, n - 1, n);
+    for (int i = n - 1; i >= 0; --i) {
+        load_row(nxt, i - 1, i - 1, n);
+        cplx acc = cmake(0.0, 0.0), d = cmake(1.0, 0.0);
+        #pragma unroll
+        for (int q = 0; q < NK; ++q) { const int k = p + 16 * q; if (k > i && k < n) cfma(acc, cur[q], Bt[k][cl]); if (k == i) d = cur[q]; }
+        #pragma unroll
+        for (int off = 8; off > 0; off >>= 1) { acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off); }
+        // the diagonal entry sits with the lane whose k == i: hand it to lane 0 of the group
+        const int src = (lane & 48) | (i & 15);
+        const double dx = __shfl(d.x, src), dy = __shfl(d.y, src);
+        if (p == 0) Bt[i][cl] = cmul(csub(Bt[i][cl], acc), crecip(cmake(dx, dy)));
+        __builtin_amdgcn_wave_barrier();
+        #pragma unroll
+        for (int q = 0; q < NK; ++q) cur[q] = nxt[q];
     }
+    __syncthreads();
+    for (int e = tid; e < n * 16; e += 256) { const int i = e >> 4, c = e & 15; if (j0 + c < ncols) B[(long long)i * ldb + j0 + c] = Bt[i][c]; }
 }
 
 // ---- solve-phase data movement -----------------------------------------------------------------------------------
@@ -1814,20 +1851,20 @@ bool merged_leaf_backward() {
 }
 
 // ---- ill-conditioned fronts: detection and re-elimination with a pivoted LU (see NdStable in direct.hpp) -------------------------------------
-// OFF by default (HELM_ND_STABLE=1 switches it on).  Measured on the 16-frequency bench job (MI355X, round 3): every wavefield then meets
-// rtol 1e-10 in ONE pass (passes per wavefield 1.15 -> 1.00, worst first-pass residual 7e-9 -> 6e-11), but the job is slower, 7775 against
-// 8090 wavefields/s: detection costs 0.9 ms per factorisation (two norm kernels and one read-back per tree level), every treated front
-// 0.4 ms at factor time and 0.6 ms per pass with the one-front-at-a-time kernels below, and ten to forty fronts per frequency exceed the
-// threshold while only three of sixteen frequencies save a whole refinement pass (20 ms).  What would make it pay: the treated fronts of a
-// level handled by batched launches, and a wave-synchronous LDS triangular solve.
+// ON by default (HELM_ND_STABLE=0 switches it off).  Measured on the 16-frequency bench job (MI355X, round 3): every wavefield meets rtol
+// 1e-10 in ONE pass (passes per wavefield 1.15 -> 1.00, worst first-pass residual 7e-9 -> 3e-11) and the job runs at 9180 against 8170
+// wavefields/s: detection costs 0.5-0.9 ms per factorisation (two norm kernels and one 4-byte read-back per watched tree level), a treated
+// front ~0.15 ms at factor time and per pass, 0-15 fronts per frequency are taken, and 5 of 16 frequencies save a refinement pass of 8-20 ms.
+// (A first version with one thread per column in the triangular solves and a threshold of 2e4 that also watched the leaves was correct but
+// slower than doing nothing: 7775 wavefields/s.)
 // HELM_ND_STABLE_THR: a front is taken when its condition estimate ||F11||_inf ||F11^-1||_inf
-// exceeds it (default 2e4: at 1024^2 / 9 Hz about ten of 32 767 fronts, which between them are the difference between a first-pass residual
+// exceeds it (default 5e4: at 1024^2 / 9 Hz about ten of 32 767 fronts, which between them are the difference between a first-pass residual
 // of 4e-9 and 2e-12; a typical leaf sits at 20-40, the tree top at 50-1000).
 // Fronts of more than HELM_ND_STABLE_SMAX (128) separator unknowns are left alone: the one-workgroup LU would cost more than the
 // refinement pass it saves, and none that large has been seen ill-conditioned (the tree top sits at cond 50-1000)
 bool stable_enabled(const NdPlan &P) {
     const char *e = getenv("HELM_ND_STABLE");          // (read per call: the tests switch it)
-    return e && atoi(e) != 0 && P.dof == 1 && gemm_variant() != 0;
+    return (!e || atoi(e) != 0) && P.dof == 1 && gemm_variant() != 0;
 }
 #define ND_STABLE_CAP 32
 int ensure_est(helm_op *op, NdFactor *f, int cnt) {
@@ -1850,7 +1887,7 @@ int stabilise_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *wor
     const NdPlan &P = f->pd->plan;
     const NdGroup &g = P.groups[gi];
     hipStream_t st = op->stream;
-    const double thr = getenv("HELM_ND_STABLE_THR") ? atof(getenv("HELM_ND_STABLE_THR")) : 2e4;
+    const double thr = getenv("HELM_ND_STABLE_THR") ? atof(getenv("HELM_ND_STABLE_THR")) : 5e4;
     const int nmax = g.smax + g.mmax;
     int *d_list = (int *)(f->d_est + 2 * (size_t)g.cnt);
     HIP_TRY(op, hipMemsetAsync(d_list, 0, sizeof(int), st));
@@ -1893,7 +1930,7 @@ int stabilise_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *wor
         else hipLaunchKernelGGL(k_lu_factor, dim3(1), dim3(256), 0, st, S.lu, nmax, g.smax, S.piv);
         // Schur complement through the same factors: F22 -= F21 (F11^-1 F12)
         HIP_TRY(op, hipMemcpy2DAsync(work, (size_t)g.mmax * sizeof(cplx), S.lu + g.smax, (size_t)nmax * sizeof(cplx), (size_t)g.mmax * sizeof(cplx), (size_t)g.smax, hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(k_lu_solve, dim3((g.mmax + 63) / 64), dim3(64), 0, st, (const cplx *)S.lu, nmax, g.smax, (const int *)S.piv, work, g.mmax, g.mmax);
+        hipLaunchKernelGGL(k_lu_solve, dim3((g.mmax + 15) / 16), dim3(256), 0, st, (const cplx *)S.lu, nmax, g.smax, (const int *)S.piv, work, g.mmax, g.mmax);
         gemm(op, g.mmax, g.mmax, g.smax, mone, S.f21, g.smax, 0, work, g.mmax, 0, one, F22, nmax, 0, 1, nullptr);
     }
     static const int dbg = getenv("HELM_ND_DEBUG") ? atoi(getenv("HELM_ND_DEBUG")) : 0;
@@ -1950,7 +1987,9 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
     static const int gj_top = getenv("HELM_ND_GJ_TOP") ? atoi(getenv("HELM_ND_GJ_TOP")) : 0;
     const int base = g.leaf ? gj_leaf : (g.cnt <= gj_top ? 64 : gj_upper);
     const int stable_smax = getenv("HELM_ND_STABLE_SMAX") ? atoi(getenv("HELM_ND_STABLE_SMAX")) : 128;
-    const bool watch = stable_enabled(P) && g.mmax > 0 && g.smax <= stable_smax && ensure_est(op, f, g.cnt) == HELM_OK;
+    // (leaves are not watched: 20-40 typically, below 6e3 in every operator examined, and their level is the one where two more passes over
+    // every front cost something)
+    const bool watch = stable_enabled(P) && !g.leaf && g.mmax > 0 && g.smax <= std::min(stable_smax, LUS_NMAX) && ensure_est(op, f, g.cnt) == HELM_OK;
     if (watch) for (int j0 = 0; j0 < g.cnt; j0 += 65535)
         hipLaunchKernelGGL(k_front_absmax, dim3(std::min(65535, g.cnt - j0)), dim3(256), 0, st, Finv + (long long)j0 * s1, nmax, s1, d_nodes + g.first + j0, f->d_est + j0);
     invert(op, Finv, nmax, s1, g.smax, g.cnt, work, s11, P.dof, base);      // F11 -> F11^-1 where it stays
@@ -2008,7 +2047,7 @@ void forward_stable(helm_op *op, NdFactor *f, size_t gi, const SolveCtx &c) {
         // the front vector gathered again: separator rows q_S + the children's rows (written to Xt as y_S for the back substitution), ring rows
         // the children's rows; then z = F11^-1 y_S through the LU and V_B -= F21 z
         hipLaunchKernelGGL(k_nd_fwd_rows, c.rgrid(nmax), c.rb, 0, op->stream, c.tab + n.roff, V, c.arenaV, c.Qt, c.Xt, (long long)nmax, nrhs, g.leaf ? 0 : 1);
-        hipLaunchKernelGGL(k_lu_solve, dim3((nrhs + 63) / 64), dim3(64), 0, op->stream, (const cplx *)S.lu, nmax, S.smax, (const int *)S.piv, V, nrhs, nrhs);
+        hipLaunchKernelGGL(k_lu_solve, dim3((nrhs + 15) / 16), dim3(256), 0, op->stream, (const cplx *)S.lu, nmax, S.smax, (const int *)S.piv, V, nrhs, nrhs);
         gemm(op, S.mmax, nrhs, S.smax, mone, S.f21, S.smax, 0, V, nrhs, 0, one, V + (long long)S.smax * nrhs, nrhs, 0, 1);
     }
 }
@@ -2073,7 +2112,7 @@ int backward_stable(helm_op *op, NdFactor *f, size_t gk, const SolveCtx &c, bool
             hipLaunchKernelGGL(k_nd_bwd_gather, c.rgrid(nmax), c.rb, 0, op->stream, c.tab + n.roff, S.vs, g.leaf ? c.Qt : (const cplx *)c.Xt, (const cplx *)c.Xt, (long long)nmax, nrhs);
         } else {
             if (S.mmax > 0) gemm(op, S.smax, nrhs, S.mmax, mone, S.lu + S.smax, nmax, 0, S.vs + (long long)S.smax * nrhs, nrhs, 0, one, S.vs, nrhs, 0, 1);
-            hipLaunchKernelGGL(k_lu_solve, dim3((nrhs + 63) / 64), dim3(64), 0, op->stream, (const cplx *)S.lu, nmax, S.smax, (const int *)S.piv, S.vs, nrhs, nrhs);
+            hipLaunchKernelGGL(k_lu_solve, dim3((nrhs + 15) / 16), dim3(256), 0, op->stream, (const cplx *)S.lu, nmax, S.smax, (const int *)S.piv, S.vs, nrhs, nrhs);
             hipLaunchKernelGGL(k_nd_bwd_store, c.rgrid(S.smax), c.rb, 0, op->stream, c.tab + n.roff, (const cplx *)S.vs, c.Xt, (long long)S.smax, S.smax, nmax, nrhs);
         }
     }
