@@ -549,21 +549,34 @@ def main():
                 del opm.factors
             except Exception as exc:          # never let the extra measurement break the bench line
                 micro_target['apply_microbench'] = 'failed: %s' % exc
-        # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same
-        # command; bench.py cannot run the profiler on itself) -- only when it was collected for this workload
+        # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command in two separate
+        # runs, tools/run_profiles_r3.sh; bench.py cannot run the profiler on itself) -- only when they were collected for this workload
+        def pmc(name):
+            for rnd in ('r03', 'r02'):
+                path = os.path.join(ROOT, 'profiles', '%s_%s.json' % (rnd, name))
+                if os.path.exists(path):
+                    try:
+                        d_ = json.load(open(path))
+                        if d_.get('batch') == B and d_.get('grid') == [n, n]:
+                            return d_, 'profiles/%s_%s.json' % (rnd, name)
+                    except Exception:
+                        pass
+            return None, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_krylov_pmc_traffic.json')))
-            if not direct and pmc.get('batch') == B and pmc.get('grid') == [n, n]:
-                out['roofline']['traffic'] = pmc['traffic_bytes_per_launch_outer_applies']
-                out['roofline']['traffic_source'] = 'profiles/r01_krylov_pmc_traffic.json'
-            pmd = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic_zgemm.json')))
-            if direct and pmd.get('batch') == B and pmd.get('grid') == [n, n]:
-                out['roofline']['traffic'] = pmd['traffic_bytes_per_launch']
-                out['roofline']['traffic_source'] = 'profiles/r02_pmc_traffic_zgemm.json (HBM bytes per k_zgemm2 launch, FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes)'
-            pmr = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic_resid_nm.json')))
-            if direct and pmr.get('batch') == B and pmr.get('grid') == [n, n]:
-                out['stencil_roofline']['traffic'] = pmr['traffic_bytes_per_launch']
-                out['stencil_roofline']['traffic_source'] = 'profiles/r02_pmc_traffic_resid_nm.json (HBM bytes per k_resid_nm launch)'
+            if direct:
+                pz, src_z = pmc('pmc_traffic_zgemm')
+                if pz:
+                    out['roofline']['traffic'] = pz['traffic_bytes_per_launch']
+                    out['roofline']['traffic_source'] = src_z + ' (HBM bytes per k_zgemm2 launch, FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes)'
+                pr, src_r = pmc('pmc_traffic_resid_nm')
+                if pr:
+                    out['stencil_roofline']['traffic'] = pr['traffic_bytes_per_launch']
+                    out['stencil_roofline']['traffic_source'] = src_r + ' (HBM bytes per residual-kernel launch)'
+            else:
+                pk = json.load(open(os.path.join(ROOT, 'profiles', 'r01_krylov_pmc_traffic.json')))
+                if pk.get('batch') == B and pk.get('grid') == [n, n]:
+                    out['roofline']['traffic'] = pk['traffic_bytes_per_launch_outer_applies']
+                    out['roofline']['traffic_source'] = 'profiles/r01_krylov_pmc_traffic.json'
         except Exception:
             pass
         if world == 1 and not args.no_host_api and direct:
