@@ -267,8 +267,8 @@ def spawn_ranks(ngpus, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=2)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--grid', '--n', dest='n', type=int, default=1024, help='grid side (1024 = BASELINE workload)')
     ap.add_argument('--dx', type=float, default=9.0)
     ap.add_argument('--batch', type=int, default=256, help='sources per work item (256 = all sources of a frequency)')
