@@ -139,7 +139,7 @@ class BaseMPDist(BaseDist):
 
         def solve(_prepared):
             if throttle is not None:
-                throttle.acquire()        # not more than two results of this worker ahead of the consumer
+                throttle.acquire()        # not more than one finished result of this worker waiting for the consumer
             return sub * r
         return dispatch.WorkItem(solve, prep)
 
@@ -157,7 +157,7 @@ class BaseMPDist(BaseDist):
         wpd = dispatch.workers_per_device(2)
         workers = devs * wpd                                     # worker k drives GPU workers[k]; one solve + one prepare thread each
         queues = [[] for _ in workers]
-        throttles = [dispatch.Throttle(2) for _ in workers]
+        throttles = [dispatch.Throttle(1) for _ in workers]      # (a result is GBs of pinned memory: one waiting per worker, one in the making)
         turn = [0] * nd
 
         def worker_of(slot):                                     # the workers of a GPU take its items in turn
