@@ -140,3 +140,36 @@ def test_single_device_under_a_launcher(monkeypatch):
     monkeypatch.delenv('HELM_DEVICES', raising=False)
     monkeypatch.setenv('LOCAL_RANK', '3')
     assert dispatch.visible_devices() == [3]
+
+
+def test_problem_work_items_cover_every_source_once(monkeypatch):
+    """HelmBaseProblem._deviceItems: (frequency, source-batch) items for the device-resident dpred / Jtvec loops -- frequency-major over the
+    GPUs, sources split when there are spare ones; every (frequency, source) pair exactly once, replicas only on GPUs other than the
+    frequency's own."""
+    from zephyr_amd.problem import Helm2DProblem
+    from zephyr_amd.survey import Helm2DSurvey
+    g = np.load(os.path.join(GOLD, 'g6_survey.npz'))
+    nz, nx = g['c'].shape
+    sc = dict(nx=nx, nz=nz, dx=10., dz=10., c=g['c'], rho=g['rho'], nPML=6, freqs=list(g['freqs']), Disc=RecordingDisc,
+              sterms=g['sterms'], geom=dict(src=g['src'], rec=g['rec'], mode='fixed'))
+    for devices, nfreq_expected_split in (('0', 1), ('0,1', 1), ('0,1,2,3,4,5,6,7', 2)):
+        monkeypatch.setenv('HELM_DEVICES', devices)
+        prob, surv = Helm2DProblem(sc), Helm2DSurvey(sc)
+        prob.pair(surv)
+        nsrc, nfreq = surv.nsrc, surv.nfreq
+        devs, items = prob._deviceItems(list(range(nfreq)), nsrc)
+        assert devs == [int(d) for d in devices.split(',')]
+        seen = np.zeros((nfreq, nsrc), int)
+        per_freq = {}
+        for w, op, ifreq, c0, c1 in items:
+            assert 0 <= w < len(devs) and op.device == devs[w]
+            seen[ifreq, c0:c1] += 1
+            per_freq.setdefault(ifreq, []).append(op)
+        assert np.all(seen == 1)
+        assert all(len(ops) == nfreq_expected_split for ops in per_freq.values())
+        for ifreq, ops in per_freq.items():
+            assert ops[0] is prob.system.subProblems[ifreq]
+            assert len(set(o.device for o in ops)) == len(ops)
+        # a rank that owns a subset of the frequencies (one process per GPU) keeps them on its own GPU
+        devs1, items1 = prob._deviceItems([1], nsrc)
+        assert sorted((c0, c1) for _, _, i, c0, c1 in items1 if i == 1)[0][0] == 0 and sum(c1 - c0 for _, _, _, c0, c1 in items1) == nsrc

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void k_nd_extend_add(const NdDev *nodes, int f
 // front's rows once in LDS and then streams `rb` rows.  Traffic per level: children's F22 read once, the fronts written once
 // (the scatter form read-modify-wrote the parents twice on top of the memsets).
 __global__ __launch_bounds__(256) void k_nd_build_front(const NdDev *nodes, int first, cplx *arenaF, cplx *fac, const cplx *planes, int nz, int nx, int rb,
-                                                        const NdDev *ovr = nullptr) {
+                                                        const NdDev *ovr = nullptr, int skip22 = 0) {
     extern __shared__ int2 finfo[];        // per padded row: x = z | x << 16 (-1: padding), y = (k0 + 1) | (k1 + 1) << 14 | comp << 28
     const NdDev n = ovr ? *ovr : nodes[first + blockIdx.y];      // (ovr: one front rebuilt with its [F11 | F12] rows redirected, see NdStable)
     const int nmax = n.smax + n.mmax;
@@ -265,7 +265,10 @@ __global__ __launch_bounds__(256) void k_nd_build_front(const NdDev *nodes, int 
     for (int r = r0 + ty; r < r1; r += 4) {
         const int2 ia = finfo[r];
         const int za = ia.x & 0xffff, xa = ia.x >> 16, ca = (ia.y >> 28) & 1, a0 = (ia.y & 0x3fff) - 1, a1 = ((ia.y >> 14) & 0x3fff) - 1;
-        for (int c = tx; c < nmax; c += 64) {
+        // skip22: the ring x ring block (the sum of the children's Schur complements, most of a front below the tree top) is not
+        // materialised -- the Schur-complement product gathers it itself (k_zgemm2<.., 4, ..>) and writes S where F22 would have been
+        const int cend = (skip22 && r >= n.smax) ? n.smax : nmax;
+        for (int c = tx; c < cend; c += 64) {
             const int2 ib = finfo[c];
             cplx v = cmake(0.0, 0.0);
             if (ia.x < 0 || ib.x < 0) { if (r == c && r < n.smax) v = cmake(1.0, 0.0); }
@@ -310,6 +313,11 @@ struct GemmRows {
     int tm64 = 0;                             // one 64-row tile per matrix (M <= 64): C may then overwrite B (every workgroup has read all of its B columns
                                               // before it stores, and no other workgroup reads them)
     const GjPivotArgs *la = nullptr;          // (host pointer) fuse this pivot sweep into the launch: 64 x 32 tiles, one extra z-slice
+    // Schur-complement mode (k_zgemm2<.., 4, ..>): C = (children's Schur complement entries that land on (r, c), gathered through the row
+    // table) + alpha A B -- the ring x ring block of a front is never written by the build pass and never read back here
+    int schur4 = 0;
+    const NdDev *nodes = nullptr; int first = 0;
+    const cplx *arenaS = nullptr;
 };
 #define GB_K 8
 #define GB_KIDX 512       // largest K with indexed B rows
@@ -461,6 +469,27 @@ __device__ __forceinline__ void zgemm2_body(int M, int Nn, int K, cplx alpha, co
         for (int k = tid; k < K; k += 256) kidx4[k] = R.tabB[trow + R.offB + k];
         __syncthreads();
     }
+    // IDX == 4: child-local ring indices (child 0, child 1; -1: not on that child's ring) of the tile's rows and columns
+    __shared__ int2 sgr[IDX == 4 ? TM : 1], sgc[IDX == 4 ? TN : 1];
+    const cplx *S0 = nullptr, *S1 = nullptr;
+    int ld0 = 0, ld1 = 0;
+    if (IDX == 4) {
+        const NdDev nd = R.nodes[R.first + R.z0 + blockIdx.z];
+        int base0 = 0, base1 = 0;
+        if (nd.kid[0] >= 0) { const NdDev c0 = R.nodes[nd.kid[0]]; S0 = R.arenaS + c0.foff + c0.smax; ld0 = c0.smax + c0.mmax; base0 = (int)(c0.voff + c0.smax); }
+        if (nd.kid[1] >= 0) { const NdDev c1 = R.nodes[nd.kid[1]]; S1 = R.arenaS + c1.foff + c1.smax; ld1 = c1.smax + c1.mmax; base1 = (int)(c1.voff + c1.smax); }
+        for (int t = tid; t < TM + TN; t += 256) {
+            const int q = t < TM ? m0 + t : n0 + (t - TM);           // row / column of the ring block
+            int2 e = make_int2(-1, -1);
+            if (q < (t < TM ? M : Nn)) {
+                const int4 t4 = R.tabCi[trow + nd.smax + q];
+                if (t4.y >= 0 && S0) e.x = t4.y - base0;
+                if (t4.z >= 0 && S1) e.y = t4.z - base1;
+            }
+            if (t < TM) sgr[t] = e; else sgc[t - TM] = e;
+        }
+        __syncthreads();
+    }
     cplx acc[4][RN];
     #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -552,7 +581,14 @@ __device__ __forceinline__ void zgemm2_body(int M, int Nn, int K, cplx alpha, co
             if (cc >= Nn) continue;
             if (srow && cc >= R.sk0 && cc < R.sk1) continue;
             cplx v = cmul(alpha, acc[i][j]);
-            if (IDX == 2) {
+            if (IDX == 4) {
+                const int2 er = sgr[r - m0], ec = sgc[cc - n0];
+                cplx c = cmake(0.0, 0.0);
+                if (er.x >= 0 && ec.x >= 0) c = S0[(long long)er.x * ld0 + ec.x];
+                if (er.y >= 0 && ec.y >= 0) c = cadd(c, S1[(long long)er.y * ld1 + ec.y]);
+                v = cadd(c, v);
+            }
+            else if (IDX == 2) {
                 cplx c = cin ? cin[cc] : cmake(0.0, 0.0);
                 if (cin2) c = cadd(c, cin2[cc]);
                 v = cadd(v, cmul(beta, c));
@@ -582,7 +618,8 @@ void launch_vec2(hipStream_t st, int idx, int nb, int M, int Nn, int K, cplx alp
                  cplx beta, cplx *C, int ldc, long long sc, const GemmRows &R) {
     constexpr int TN = (1024 / TM) * RN;
     dim3 grid((Nn + TN - 1) / TN, (M + TM - 1) / TM, nb);
-    if (idx == 2) ZG_LAUNCH((k_zgemm2<TM, 2, RN, KS, UNR, OCC>), grid, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
+    if (idx == 4) ZG_LAUNCH((k_zgemm2<TM, 4, RN, KS, UNR, OCC>), grid, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
+    else if (idx == 2) ZG_LAUNCH((k_zgemm2<TM, 2, RN, KS, UNR, OCC>), grid, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
     else if (idx) ZG_LAUNCH((k_zgemm2<TM, 1, RN, KS, UNR, OCC>), grid, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
     else ZG_LAUNCH((k_zgemm2<TM, 0, RN, KS, UNR, OCC>), grid, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
 }
@@ -1623,7 +1660,7 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
                 tl_ev0 = tl_ev1 = nullptr;
             }
         } arm(op, ext, 8.0 * M * (double)Nn * K * nb);
-#define ZG_ARGS st, (rows && !rows->dense ? (rows->fwd3 ? 2 : 1) : 0), nb, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R
+#define ZG_ARGS st, (rows && rows->schur4 ? 4 : (rows && !rows->dense ? (rows->fwd3 ? 2 : 1) : 0)), nb, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R
 #define ZG_VEC(TM_, RN_) do { switch (gv) { \
             case 0: launch_vec<TM_, RN_>(ZG_ARGS); break; \
             case 6: launch_vec2<TM_, RN_, (RN_ == 1 ? 32 : (RN_ == 2 ? 16 : 8)), 1, 1>(ZG_ARGS); break; \
@@ -1951,6 +1988,11 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
     cplx *F = arenaF + g.foff;
     cplx *Finv = f->d_fac + g.finv, *G21 = f->d_fac + g.g21, *F12 = f->d_fac + g.f12;
     static const int fused_build = getenv("HELM_ND_FUSEDBUILD") ? atoi(getenv("HELM_ND_FUSEDBUILD")) : 1;
+    // the ring x ring block of a non-leaf front stays unbuilt: its Schur-complement product gathers the children's contributions itself
+    static const int schur_gather_env = getenv("HELM_ND_SCHURGATHER") ? atoi(getenv("HELM_ND_SCHURGATHER")) : 1;
+    bool schur_gather = false;
+    if (fused_build && (size_t)nmax * sizeof(int2) <= 64 * 1024 && nmax < (1 << 14) && op->nz < 65536 && op->nx < 32768)
+        schur_gather = schur_gather_env && !g.leaf && g.mmax > 0 && gemm_variant() != 0 && P.dof == 1;
     if (fused_build && (size_t)nmax * sizeof(int2) <= 64 * 1024 && nmax < (1 << 14) && op->nz < 65536 && op->nx < 32768) {      // (its row table must fit the 64 KB of LDS a launch gets by default: larger fronts take the unfused path)
         // rows per workgroup: whole fronts while there are thousands of them, a few rows each for the handful of big ones at the top
         const int want = std::max(1, 2048 / g.cnt);
@@ -1958,7 +2000,7 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
         for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
             const int nb = std::min(65535, g.cnt - j0);
             hipLaunchKernelGGL(k_nd_build_front, dim3((nmax + rb - 1) / rb, nb), dim3(256), (size_t)nmax * sizeof(int2), st, d_nodes, g.first + j0, arenaF, f->d_fac, planes,
-                               op->nz, op->nx, rb);
+                               op->nz, op->nx, rb, (const NdDev *)nullptr, schur_gather ? 1 : 0);
         }
     } else {
         if (fs > 0) HIP_TRY(op, hipMemsetAsync(F, 0, (size_t)g.cnt * fs * sizeof(cplx), st));
@@ -1998,6 +2040,10 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
     if (g.mmax > 0) {
         // G21 = F21 F11^-1 ; F22 -= G21 F12
         gemm(op, g.mmax, g.smax, g.smax, one, F, nmax, fs, Finv, nmax, s1, zero, G21, g.smax, (long long)g.mmax * g.smax, g.cnt);
+        if (schur_gather) {
+            GemmRows R; R.schur4 = 1; R.nodes = d_nodes; R.first = g.first; R.arenaS = arenaF; R.tabCi = f->pd->d_tab + g.roff; R.tab_stride = nmax;
+            gemm(op, g.mmax, g.mmax, g.smax, mone, G21, g.smax, (long long)g.mmax * g.smax, F12, nmax, s1, zero, F + g.smax, nmax, fs, g.cnt, &R);
+        } else
         gemm(op, g.mmax, g.mmax, g.smax, mone, G21, g.smax, (long long)g.mmax * g.smax, F12, nmax, s1, one, F + g.smax, nmax, fs, g.cnt);
         if (g.leaf && merged_leaf_backward()) {
             // leaves: F12 <- -F11^-1 F12, in place where a front is one 64-row tile (GemmRows::tm64), else through the inversion workspace
