@@ -186,6 +186,7 @@ class BaseMPDist(BaseDist):
                 row.append((it, w))
             parts.append(row)
         self._pipes = dispatch.dispatch(list(zip(workers, queues)), lookahead=1)
+        self._throttles = throttles
 
         def results():
             try:
@@ -212,9 +213,12 @@ class BaseMPDist(BaseDist):
 
     @factors.deleter
     def factors(self):
+        for t in self.__dict__.get('_throttles', []):      # (a half-consumed result generator must not keep the workers waiting)
+            t.close()
         for p in self.__dict__.get('_pipes', []):
             p.join()
         self._pipes = []
+        self._throttles = []
         DiscretizationWrapper.factors.fdel(self)
         for rep in self.__dict__.get('_replicas', {}).values():
             del rep.factors
