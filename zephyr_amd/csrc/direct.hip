@@ -1895,7 +1895,7 @@ bool merged_leaf_backward() {
 // (A first version with one thread per column in the triangular solves and a threshold of 2e4 that also watched the leaves was correct but
 // slower than doing nothing: 7775 wavefields/s.)
 // HELM_ND_STABLE_THR: a front is taken when its condition estimate ||F11||_inf ||F11^-1||_inf
-// exceeds it (default 5e4: at 1024^2 / 9 Hz about ten of 32 767 fronts, which between them are the difference between a first-pass residual
+// exceeds it (default 1e5: at 1024^2 / 9 Hz a handful of 32 767 fronts, which between them are the difference between a first-pass residual
 // of 4e-9 and 2e-12; a typical leaf sits at 20-40, the tree top at 50-1000).
 // Fronts of more than HELM_ND_STABLE_SMAX (128) separator unknowns are left alone: the one-workgroup LU would cost more than the
 // refinement pass it saves, and none that large has been seen ill-conditioned (the tree top sits at cond 50-1000)
@@ -1924,7 +1924,7 @@ int stabilise_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *wor
     const NdPlan &P = f->pd->plan;
     const NdGroup &g = P.groups[gi];
     hipStream_t st = op->stream;
-    const double thr = getenv("HELM_ND_STABLE_THR") ? atof(getenv("HELM_ND_STABLE_THR")) : 5e4;
+    const double thr = getenv("HELM_ND_STABLE_THR") ? atof(getenv("HELM_ND_STABLE_THR")) : 1e5;
     const int nmax = g.smax + g.mmax;
     int *d_list = (int *)(f->d_est + 2 * (size_t)g.cnt);
     HIP_TRY(op, hipMemsetAsync(d_list, 0, sizeof(int), st));
