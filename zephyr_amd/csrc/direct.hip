@@ -1901,7 +1901,10 @@ bool merged_leaf_backward() {
 // refinement pass it saves, and none that large has been seen ill-conditioned (the tree top sits at cond 50-1000)
 bool stable_enabled(const NdPlan &P) {
     const char *e = getenv("HELM_ND_STABLE");          // (read per call: the tests switch it)
-    return (!e || atoi(e) != 0) && P.dof == 1 && gemm_variant() != 0;
+    // one unknown per cell and the out-of-place node-major passes only: the fix-ups of the passes gather a front's right-hand-side rows again,
+    // which an in-place pass (HELM_ND_NM=0, the coupled system's rhs-major path) has overwritten by then
+    static const int use_nm = getenv("HELM_ND_NM") ? atoi(getenv("HELM_ND_NM")) : 1;
+    return (!e || atoi(e) != 0) && P.dof == 1 && use_nm != 0 && gemm_variant() != 0;
 }
 #define ND_STABLE_CAP 32
 int ensure_est(helm_op *op, NdFactor *f, int cnt) {
