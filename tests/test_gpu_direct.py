@@ -385,3 +385,34 @@ def test_ill_conditioned_fronts_reeliminated_with_lu(helm_lib, monkeypatch):
     ref = ho.DirectOperator(C4[0]) * q
     assert np.linalg.norm(u1 - ref) / np.linalg.norm(ref) <= 1e-7
     del op0.factors, op1.factors
+
+
+@pytest.mark.parametrize('seed', range(3))
+def test_lu_treatment_forced_on_many_fronts(helm_lib, monkeypatch, seed):
+    """The same machinery with the threshold lowered until dozens of fronts on every watched level are taken (HELM_ND_STABLE_THR=30): rebuild of
+    the front from its children, pivoted LU, Schur complement through triangular solves, forward / backward fix-ups -- against the sparse LU
+    of the oracle's matrix, MiniZephyr with free surfaces and Eurus, odd grid shapes, several right-hand sides."""
+    import zephyr_amd as za
+    rng = np.random.default_rng(77 + seed)
+    nz, nx = int(rng.integers(150, 260)), int(rng.integers(150, 300))
+    c = 1600. + 2200. * rng.random((nz, nx))
+    rho = 1000. + 600. * rng.random((nz, nx))
+    f = float(rng.uniform(8., 20.))
+    nrhs = int(rng.integers(3, 40))
+    q = np.zeros((nz * nx, nrhs), complex)
+    q[rng.integers(0, nz * nx, nrhs), np.arange(nrhs)] = rng.standard_normal(nrhs) + 1j * rng.standard_normal(nrhs)
+    monkeypatch.setenv('HELM_ND_STABLE_THR', '30')
+    cfg = dict(nx=nx, nz=nz, dx=10., dz=10., c=c, rho=rho, freq=f, nPML=8, method='direct', rtol=1e-10)
+    if seed % 2 == 0:
+        fs = (True, False, False, False)
+        op = za.MiniZephyr(dict(cfg, freeSurf=fs))
+        C = ho.minizephyr_coefficients(nz, nx, c, rho, f, dx=10., dz=10., nPML=8, freeSurf=fs)
+        ref = ho.DirectOperator(C) * q
+    else:
+        op = za.Eurus(cfg)
+        C4 = ho.eurus_coefficients(nz, nx, c, rho, f, dx=10., dz=10., nPML=8)
+        ref = ho.DirectOperator(C4[0]) * q
+    u = op * q
+    assert all(i['status'] == 0 and i['relres'] <= 1e-10 for i in op.lastInfo), op.lastInfo
+    assert nrm(u, ref) <= 1e-7, (seed, nrm(u, ref))
+    del op.factors
