@@ -350,6 +350,8 @@ def main():
 
     ops = {}
 
+    stamps = []                          # completion time of every work item (diagnostics: `item_done_ms` of the timed region)
+
     def prepare_item(w, profile):
         'create the operator of work item w, assemble it on the GPU (inside the timed region) and start its factorisation'
         fi, bi = work_item(w, nb)
@@ -368,6 +370,7 @@ def main():
         info = op.solveDevice(rhs_ptr, ubuf.data_ptr(), B, N, layout='node' if node else 'rhs')
         t = op.lastTiming()
         del op.factors                   # nothing is carried over between steps
+        stamps.append(time.perf_counter())
         return fi, info, t
 
     def run_item(w, profile, ubuf=None):
@@ -399,6 +402,7 @@ def main():
     run_items(warm_items, True)          # (events on, like the timed region: the per-process event pool comes into being here, not inside it)
 
     barrier()
+    del stamps[:]
     t0 = time.perf_counter()
     results = [None] * len(timed_items)
     if args.streams <= 1:
@@ -433,6 +437,7 @@ def main():
     agg = aggregate(results)
     barrier()
     elapsed = time.perf_counter() - t0
+    item_done_ms = [round(1e3 * (x - t0), 2) for x in stamps]
 
     def max_over_ranks(x):
         if world == 1:
@@ -507,6 +512,7 @@ def main():
             'timed_region': 'K work items through the device pipeline with per-launch HIP events on; `unprofiled` repeats the same K items with the events off',
             'pipeline': ('device pipeline of zephyr_amd.dispatch (MultiFreq parallel mode): item k+1 is created, assembled and its factorisation enqueued '
                          '(helm_prefactor, high-priority stream) while item k is being solved' if args.pipeline else 'off: items strictly one after the other'),
+            'item_done_ms': item_done_ms,
             'unprofiled': None if elapsed_plain is None else {'value': wavefields / elapsed_plain, 'ms_per_step': 1e3 * elapsed_plain / nsteps},
             'config': {'workload': 'Eurus 2D isotropic %dx%d synthetic-Marmousi (seed 20240512, dx=%g m), 16 freqs 2-9.5 Hz x 256 Kaiser sources; '
                                    'step = create + assemble 1 frequency + solve %d sources to true relres<=%g (method=%s: %s)' % (n, n, dx, B, args.rtol, args.method, how),
@@ -597,11 +603,14 @@ def main():
                 del d_u
                 torch.cuda.empty_cache()
                 best = None
-                for wpd in (1, 2):
+                for wpd in (1, 3):
                     os.environ['HELM_WORKERS_PER_DEVICE'] = str(wpd)
                     sch = dict(cfg); sch.update(freqs=[float(f) for f in freqs], Disc=Eurus, rtol=args.rtol, maxit=400000, method=args.method, batch=NSRC)
                     # untimed warm-up (like the W warm-up steps): the pinned result buffers and device pools come into being here
-                    mfw = MultiFreq(dict(sch, freqs=[float(f) for f in freqs[:3 * wpd]]))
+                    from zephyr_amd import _lib as _zl
+                    from zephyr_amd import dispatch as _zd
+                    _zl.pinned_reserve((N, NSRC), wpd * (_zd.results_ahead() + 1) + 1)
+                    mfw = MultiFreq(dict(sch))            # (the whole job once: every operator's device buffers then come from the library's pool)
                     for u in mfw * q_sparse:
                         del u
                     del mfw.factors
@@ -609,12 +618,14 @@ def main():
                     torch.cuda.synchronize()
                     th0 = time.perf_counter()
                     chk = 0.0
+                    arrivals = []
                     for u in mf * q_sparse:
                         chk += float(abs(u[N // 2 + 7, 0]))       # touch the result; the array goes back to the pinned pool when dropped
+                        arrivals.append(int(1e3 * (time.perf_counter() - th0)))
                         del u
                     th = time.perf_counter() - th0
                     del mf.factors
-                    rec = {'value': NFREQ * NSRC / th, 'unit': 'wavefields/s', 'seconds': th, 'workers_per_device': wpd}
+                    rec = {'value': NFREQ * NSRC / th, 'unit': 'wavefields/s', 'seconds': th, 'workers_per_device': wpd, 'arrivals_ms': arrivals}
                     if best is None or rec['value'] > best['value']:
                         best = rec
                     out.setdefault('value_host_api_runs', []).append(rec)

@@ -20,6 +20,7 @@
  *                                     Eurus.__mul__ pad/clip              eurus.py:512-533
  *   helm_prefactor                 <- the worker pool of BaseMPDist.__mul__ (distributors.py:80-96,161-168): the LU of the
  *                                     NEXT frequency is built while the current one is being solved
+ *   helm_reserve                   <- (same pool: its workers' scratch, allocated before they start)
  *   helm_imaging_accumulate_device <- zero-lag imaging condition in HelmBaseProblem.Jtvec
  *                                     zephyr/middleware/problem.py:152,162
  *   helm_destroy                   <- `del obj.factors` / __del__         discretization.py:86-99
@@ -174,6 +175,13 @@ void helm_host_free(void *p, size_t bytes);
  * LU lazily inside the first `Disc * rhs` (discretization.py:78-85) and overlaps frequencies with a process pool
  * (distributors.py:161-168). */
 int helm_prefactor(helm_op *op);
+
+/* Scratch for `concurrent` host-array solves (helm_solve / helm_solve_coo) of `nrhs` right-hand sides with `rows` rows running at the
+ * same time on this handle's GPU, allocated now instead of inside the first solves: the shared scratch slots of the direct path and the
+ * device images of right-hand sides and wavefields.  For dispatchers that start several workers per GPU -- the worker pool of
+ * BaseMPDist.__mul__ (distributors.py:80-96): a hipMalloc issued beside running kernels and copies can take a second.  A hint:
+ * HELM_OK unless the arguments are invalid. */
+int helm_reserve(helm_op *op, int nrhs, long long rows, int concurrent);
 
 /* Timing of the last solve/apply on this handle, measured with HIP events on the handle's
  * stream: total ms, and ms / launches / algorithmic bytes of the stencil-apply kernel. */

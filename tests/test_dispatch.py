@@ -20,6 +20,10 @@ LOCK = threading.Lock()
 
 class RecordingDisc(za.MiniZephyr):
 
+    def reserve(self, nrhs, rows=None, concurrent=1):
+        with LOCK:
+            LOG.append(('reserve', int(nrhs), self.device, int(concurrent)))
+
     def prefactor(self):
         with LOCK:
             LOG.append(('prefactor', complex(self.freq).real, self.device, threading.current_thread().name))
@@ -68,8 +72,10 @@ def test_parallel_mode_matches_serial_bit_for_bit_and_keeps_order(monkeypatch):
     # on the prepare thread of its device
     freqs = list(g['freqs'])
     assert [s.device for s in mf.subProblems] == [0, 1, 0]
+    # before the workers start, each GPU's scratch is booked once for the workers that will run on it (two on GPU 0, one on GPU 1)
+    assert sorted(e for e in LOG if e[0] == 'reserve') == [('reserve', g['q'].shape[1], 0, 2), ('reserve', g['q'].shape[1], 1, 1)]
     for f, d in zip(freqs, (0, 1, 0)):
-        ev = [e for e in LOG if e[1] == f]
+        ev = [e for e in LOG if e[1] == f and e[0] != 'reserve']
         assert [e[0] for e in ev] == ['prefactor', 'solve'] and all(e[2] == d for e in ev)
         assert ev[0][3] == 'helm-prep%d' % d and ev[1][3] == 'helm-solve%d' % d
     # list and generator right-hand sides are consumed in order at submission, like the reference's apply_async loop

@@ -4,6 +4,7 @@
 // the host looks at the per-RHS status records every `check_every` iterations.
 #include "helm_internal.hpp"
 #include "direct.hpp"
+#include <chrono>
 #include <mutex>
 #include <map>
 #include <cstring>
@@ -45,7 +46,7 @@ extern "C" int helm_device_count(void) {
 struct WsSlot { void *ptr = nullptr; size_t bytes = 0; int device = -1; bool busy = false; };
 struct SharedWs { std::mutex mu; WsSlot slot[4]; };
 static SharedWs g_shared_ws;
-static int shared_ws_slots() { const char *e = getenv("HELM_WS_SLOTS"); const int n = e ? atoi(e) : 2; return n < 1 ? 1 : (n > 4 ? 4 : n); }
+static int shared_ws_slots() { const char *e = getenv("HELM_WS_SLOTS"); const int n = e ? atoi(e) : 3; return n < 1 ? 1 : (n > 4 ? 4 : n); }
 static int g_live_handles = 0;     // guarded by g_shared_ws.mu
 
 struct DevPool { std::mutex mu; std::multimap<std::pair<int, size_t>, void *> idle; size_t held = 0; };
@@ -65,11 +66,34 @@ int helm_events_grow(helm_op *op, int n) {
 }
 // (small buffers too: hipFree waits for every stream of the device, which would stall a host thread that prepares the next operator
 // while another one is solving -- the per-operator scratch of a few KB goes through the pool like the GB-sized buffers)
-static const size_t kPoolMinBytes = (size_t)64, kPoolCapBytes = (size_t)64 << 30;
+static const size_t kPoolMinBytes = (size_t)64;
+// What the pool may hold idle: half of the device's memory (HELM_POOL_GB overrides).  A 16-frequency job at 1024^2 hands back ~70 GB of
+// factors when its operators go; with a 64-GB cap the overflow went to hipFree and the next job's hipMalloc calls -- issued while other
+// threads had kernels and copies in flight -- took 1.2-1.5 s EACH (HELM_ALLOC_TRACE=1 shows them).
+static size_t pool_cap_bytes() {
+    static const size_t cap = [] {
+        if (const char *e = getenv("HELM_POOL_GB")) return (size_t)(atof(e) * 1e9);
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return (size_t)64 << 30; }
+        return tot / 2;
+    }();
+    return cap;
+}
 
 // pinned host buffers (per-handle scalar records) and HIP streams are recycled the same way: a job creates one operator per frequency
 struct HostPool { std::mutex mu; std::multimap<size_t, void *> idle; };
 static HostPool g_hostpool;
+// HELM_ALLOC_TRACE=1: every allocator call that reaches the driver and takes more than a millisecond is reported on stderr
+struct AllocTrace {
+    const char *what; size_t bytes; std::chrono::steady_clock::time_point t0; bool on;
+    AllocTrace(const char *w, size_t b) : what(w), bytes(b), t0(std::chrono::steady_clock::now()) { static const bool e = getenv("HELM_ALLOC_TRACE") && atoi(getenv("HELM_ALLOC_TRACE")); on = e; }
+    ~AllocTrace() {
+        if (!on) return;
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ms > 1.0) fprintf(stderr, "[helm alloc] %-14s %8.3f GB %9.1f ms\n", what, bytes * 1e-9, ms);
+    }
+};
+
 void *helm_hostpool_alloc(size_t bytes) {
     {
         std::lock_guard<std::mutex> lk(g_hostpool.mu);
@@ -77,6 +101,7 @@ void *helm_hostpool_alloc(size_t bytes) {
         if (it != g_hostpool.idle.end()) { void *p = it->second; g_hostpool.idle.erase(it); return p; }
     }
     void *p = nullptr;
+    AllocTrace tr("hipHostMalloc", bytes);
     if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return p;
 }
@@ -117,6 +142,7 @@ void *helm_pool_alloc(int device, size_t bytes) {
         if (it != g_pool.idle.end()) { void *p = it->second; g_pool.idle.erase(it); g_pool.held -= bytes; return p; }
     }
     void *p = nullptr;
+    AllocTrace tr("pool hipMalloc", bytes);
     if (hipMalloc(&p, bytes) != hipSuccess) {
         (void)hipGetLastError();
         // under memory pressure give the cached buffers back and try once more
@@ -130,12 +156,14 @@ void *helm_pool_alloc(int device, size_t bytes) {
 void helm_pool_free(int device, void *p, size_t bytes) {
     if (!p) return;
     {
+        const size_t cap = pool_cap_bytes();
         std::lock_guard<std::mutex> lk(g_pool.mu);
-        if (bytes >= kPoolMinBytes && g_pool.held + bytes <= kPoolCapBytes) {
+        if (bytes >= kPoolMinBytes && g_pool.held + bytes <= cap) {
             g_pool.idle.insert(std::make_pair(std::make_pair(device, bytes), p)); g_pool.held += bytes;
             return;
         }
     }
+    AllocTrace tr("pool hipFree", bytes);
     hipFree(p);
 }
 
@@ -666,6 +694,7 @@ void *ws_checkout(helm_op *op, size_t bytes, int *slot_out) {
         if (pick >= 0) {
             WsSlot &w = g_shared_ws.slot[pick];
             if (w.bytes < bytes) {
+                AllocTrace tr("ws slot grow", bytes);
                 if (w.ptr) hipFree(w.ptr);
                 w.ptr = nullptr; w.bytes = 0;
                 if (hipMalloc(&w.ptr, bytes) != hipSuccess) { w.ptr = nullptr; (void)hipGetLastError(); }
@@ -1405,6 +1434,54 @@ extern "C" int helm_prefactor(helm_op *op) {
     if (rc) { hipStreamSynchronize(op->fstream); helm_pool_free(op->device, ws, wsb); nd_free(f); return rc; }
     op->direct[0] = f;
     op->pf_ws = ws; op->pf_ws_bytes = wsb; op->pf_pending = true;
+    return HELM_OK;
+}
+
+// Scratch for `concurrent` host-array solves (helm_solve / helm_solve_coo) of nrhs right-hand sides running on this handle's GPU at the
+// same time, brought into being NOW: the shared scratch slots of the direct path and the device images of the right-hand sides and
+// wavefields (three buffers per call).  Everything here is taken lazily anyway; but a hipMalloc issued while other host threads have
+// kernels and copies in flight was measured at 0.7-1.5 s (HELM_ALLOC_TRACE=1), so a dispatcher that knows how many workers it is
+// about to start on a GPU asks once, before they run.  A hint: errors other than bad arguments are swallowed.
+extern "C" int helm_reserve(helm_op *op, int nrhs, long long rows, int concurrent) {
+    if (!op || nrhs < 1 || rows < 1 || concurrent < 1) return HELM_ERR_ARG;
+    if (hipSetDevice(op->device) != hipSuccess) { (void)hipGetLastError(); return HELM_OK; }
+    if (concurrent > 4) concurrent = 4;
+    const size_t bytes = (size_t)nrhs * rows * sizeof(cplx);
+    {   // device images: idle buffers of that size the pool holds already count
+        size_t have = 0;
+        { std::lock_guard<std::mutex> lk(g_pool.mu); have = g_pool.idle.count(std::make_pair(op->device, bytes)); }
+        std::vector<void *> got;
+        for (size_t k = have; k < (size_t)3 * concurrent; ++k) {
+            void *p = nullptr;
+            if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+            got.push_back(p);
+        }
+        for (void *p : got) helm_pool_free(op->device, p, bytes);
+    }
+    const bool direct2d = op->assembled && op->ny == 0 && !op->direct_failed && !(op->variant == HELM_EURUS && !op->block_zero[2]);
+    { const char *e = getenv("HELM_AUTO_DIRECT"); if (e && atoi(e) == 0) return HELM_OK; }
+    if (!direct2d) return HELM_OK;
+    std::shared_ptr<NdPlanDev> pd;
+    const char *e = getenv("HELM_ND_LEAF");
+    if (nd_get_plan(op, e ? std::max(2, atoi(e)) : 8, 1, &pd) != HELM_OK || !pd) return HELM_OK;
+    const long long per_rhs = 4 * op->N + 2 * pd->plan.vregion;
+    int Bmax = std::min(nrhs, 256);
+    const char *capenv = getenv("HELM_ND_WS_GB");
+    const double cap = (capenv ? atof(capenv) : 32.0) * 1e9;
+    while (Bmax > 1 && (double)per_rhs * Bmax * sizeof(cplx) > cap) Bmax = (Bmax + 1) / 2;
+    const size_t wsb = (size_t)per_rhs * Bmax * sizeof(cplx);
+    std::lock_guard<std::mutex> lk(g_shared_ws.mu);
+    const int ns = shared_ws_slots();
+    int ready = 0;
+    for (int i = 0; i < ns; ++i) { const WsSlot &w = g_shared_ws.slot[i]; if (w.ptr && w.device == op->device && w.bytes >= wsb) ready += 1; }
+    for (int i = 0; i < ns && ready < concurrent; ++i) {
+        WsSlot &w = g_shared_ws.slot[i];
+        if (w.busy || (w.ptr && w.device == op->device && w.bytes >= wsb)) continue;
+        if (w.ptr && w.device != op->device) continue;                 // another GPU's slot: leave it
+        if (w.ptr) { hipFree(w.ptr); w.ptr = nullptr; w.bytes = 0; }
+        if (hipMalloc(&w.ptr, wsb) != hipSuccess) { (void)hipGetLastError(); w.ptr = nullptr; break; }
+        w.bytes = wsb; w.device = op->device; ready += 1;
+    }
     return HELM_OK;
 }
 

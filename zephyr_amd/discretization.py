@@ -144,6 +144,12 @@ class BaseDiscretization(BaseModelDependent):
         if str(self.method).lower() in ('auto', 'direct'):
             _lib.check(_lib.load().helm_prefactor(self.handle), self.handle)
 
+    def reserve(self, nrhs, rows=None, concurrent=1):
+        """Bring into being what `concurrent` host-array solves of `nrhs` right-hand sides on this operator's GPU take from the
+        library's pools (helm_reserve) -- called by the dispatcher before it starts its workers."""
+        if str(self.method).lower() in ('auto', 'direct'):
+            _lib.load().helm_reserve(self.handle, int(nrhs), int(rows if rows else self.nz * self.nx), int(concurrent))
+
     @Ainv.deleter
     def Ainv(self):
         h = getattr(self, '_handle', None)

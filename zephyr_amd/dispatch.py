@@ -36,11 +36,20 @@ def visible_devices():
 
 
 def workers_per_device(default=1):
-    """Pipelines per GPU (HELM_WORKERS_PER_DEVICE, else `default`).  Two let the device-to-host copy of one frequency's wavefields run
-    while the other worker's frequency is being solved: worth it for callers that take host arrays back (`MultiFreq * q`), pointless
-    for device-resident ones."""
+    """Pipelines per GPU (HELM_WORKERS_PER_DEVICE, else `default`).  More than one lets the device-to-host copy of one frequency's
+    wavefields run while another worker's frequency is being solved: worth it for callers that take host arrays back (`MultiFreq * q`:
+    with three there is always a finished frequency to copy, and the results arrive at the PCIe rate), pointless for device-resident
+    ones."""
     try:
         return max(1, int(os.environ.get('HELM_WORKERS_PER_DEVICE', default)))
+    except ValueError:
+        return default
+
+
+def results_ahead(default=2):
+    'finished results a worker may hold before its consumer has taken any (HELM_RESULTS_AHEAD): the depth of its Throttle'
+    try:
+        return max(1, int(os.environ.get('HELM_RESULTS_AHEAD', default)))
     except ValueError:
         return default
 
@@ -70,7 +79,7 @@ class WorkItem(object):
     """prepare() runs on the device's prepare thread (may be None), solve(prepared) on its solve thread;
     `future` receives solve's return value or the first exception of either step."""
 
-    __slots__ = ('prepare', 'solve', 'future', '_prepared', '_error')
+    __slots__ = ('prepare', 'solve', 'future', '_prepared', '_error', 'owner', 'nrow', 'ncol')
 
     def __init__(self, solve, prepare=None):
         self.prepare = prepare

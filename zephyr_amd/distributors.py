@@ -10,6 +10,7 @@ sources of a frequency are split over the spare ones.  Under a one-process-per-G
 result contract is unchanged: an iterable, in `freqs` order, of `scaleTerm * (sub * rhs_i)` arrays
 of shape (N, nrhs).
 """
+import os
 import types
 import numpy as np
 import scipy.sparse as sp
@@ -141,7 +142,11 @@ class BaseMPDist(BaseDist):
             if throttle is not None:
                 throttle.acquire()        # not more than one finished result of this worker waiting for the consumer
             return sub * r
-        return dispatch.WorkItem(solve, prep)
+        it = dispatch.WorkItem(solve, prep)
+        it.owner = sub
+        it.nrow = int(r.shape[0])
+        it.ncol = int(r.shape[1]) if getattr(r, 'ndim', 1) > 1 else 1
+        return it
 
     def __mul__(self, rhs):
         get = self._rhs_getter(rhs)
@@ -154,10 +159,11 @@ class BaseMPDist(BaseDist):
         split = max(1, nd // max(1, len(subs)))                  # GPUs per frequency when there are spare ones
         # results go back to the host here (GBs per frequency over PCIe): two workers per GPU, so that the copy of one frequency's wavefields
         # runs while the other worker's frequency is being solved (HELM_WORKERS_PER_DEVICE overrides)
-        wpd = dispatch.workers_per_device(2)
+        wpd = dispatch.workers_per_device(3)
         workers = devs * wpd                                     # worker k drives GPU workers[k]; one solve + one prepare thread each
         queues = [[] for _ in workers]
-        throttles = [dispatch.Throttle(1) for _ in workers]      # (a result is GBs of pinned memory: one waiting per worker, one in the making)
+        # (a result is GBs of pinned memory: HELM_RESULTS_AHEAD waiting per worker, one in the making)
+        throttles = [dispatch.Throttle(dispatch.results_ahead(2)) for _ in workers]
         turn = [0] * nd
 
         def worker_of(slot):                                     # the workers of a GPU take its items in turn
@@ -185,6 +191,16 @@ class BaseMPDist(BaseDist):
                 queues[w].append(it)
                 row.append((it, w))
             parts.append(row)
+        # what `wpd` concurrent solves on a GPU take from the library's pools is brought into being before the workers start: a
+        # hipMalloc issued beside running kernels and copies can take a second (helm_reserve)
+        booked = {}
+        for w, q in enumerate(queues):
+            if q:
+                booked.setdefault(workers[w], []).append(q[0])
+        for dev, firsts in booked.items():
+            owner = firsts[0].owner
+            if hasattr(owner, 'reserve'):
+                owner.reserve(max(it.ncol for w, q in enumerate(queues) if workers[w] == dev for it in q), rows=firsts[0].nrow, concurrent=len(firsts))
         self._pipes = dispatch.dispatch(list(zip(workers, queues)), lookahead=1)
         self._throttles = throttles
 
