@@ -424,14 +424,15 @@ def main():
             th.join()
     def aggregate(res):
         a = dict(iters=[], freqs=[], apply_ms=0.0, apply_launches=0, apply_bytes=0.0, solve_ms=0.0, gemm_ms=0.0, gemm_launches=0, gemm_flops=0.0,
-                 factor_ms=0.0, methods=set(), big_ms=0.0, big_launches=0, big_flops=0.0)
+                 factor_ms=0.0, methods=set(), big_ms=0.0, big_launches=0, big_flops=0.0, gemm_bytes=0.0, gemm_sol_ms=0.0)
         for fi, info, t in res:
             a['iters'] += [i['iterations'] for i in info]
             a['freqs'].append(float(freqs[fi]))
             a['methods'].update(i['method'] for i in info)
             for k_, t_ in (('apply_ms', 'apply_ms'), ('apply_launches', 'apply_launches'), ('apply_bytes', 'apply_bytes'), ('solve_ms', 'solve_ms'),
                            ('gemm_ms', 'gemm_ms'), ('gemm_launches', 'gemm_launches'), ('gemm_flops', 'gemm_flops'), ('factor_ms', 'factor_ms'),
-                           ('big_ms', 'gemm_big_ms'), ('big_launches', 'gemm_big_launches'), ('big_flops', 'gemm_big_flops')):
+                           ('big_ms', 'gemm_big_ms'), ('big_launches', 'gemm_big_launches'), ('big_flops', 'gemm_big_flops'),
+                           ('gemm_bytes', 'gemm_bytes'), ('gemm_sol_ms', 'gemm_sol_ms')):
                 a[k_] += t[t_]
         return a
     agg = aggregate(results)
@@ -490,6 +491,13 @@ def main():
                     'launches_timed': int(a['gemm_launches']), 'avg_launch_us': 1e3 * a['gemm_ms'] / a['gemm_launches'] if a['gemm_launches'] else None,
                     'flops_per_launch_algorithmic': a['gemm_flops'] / a['gemm_launches'] if a['gemm_launches'] else None,
                     'gemm_share_of_solve_time': a['gemm_ms'] / a['solve_ms'] if a['solve_ms'] > 0 else None,
+                    # the launches are not all bound by the same roof: the thin fronts low in the tree are HBM-bound products.  Per launch
+                    # max(flops / fp64 peak, operand bytes / 8 TB/s) with every operand counted once; their sum against the measured time
+                    'two_roofs': {'frac': a['gemm_sol_ms'] / a['gemm_ms'] if a['gemm_ms'] > 0 else None,
+                                  'roofline_ms_per_item': a['gemm_sol_ms'] / max(1, len(a['freqs'])), 'measured_ms_per_item': a['gemm_ms'] / max(1, len(a['freqs'])),
+                                  'operand_GB_per_item': a['gemm_bytes'] / max(1, len(a['freqs'])) / 1e9,
+                                  'flop_per_byte': a['gemm_flops'] / a['gemm_bytes'] if a['gemm_bytes'] > 0 else None,
+                                  'what': 'sum over launches of max(8MNK / 78.6 TFLOP/s, 16 (MK + KN + MN (1 or 2)) / 8 TB/s) divided by their measured time'},
                     'launches_of_at_least_1_GFLOP': {'launches': int(a['big_launches']), 'share_of_gemm_time': a['big_ms'] / a['gemm_ms'] if a['gemm_ms'] > 0 else None,
                                                      'achieved': a['big_flops'] / (a['big_ms'] * 1e-3) / 1e12 if a['big_ms'] > 0 else None, 'unit': 'TFLOP/s',
                                                      'frac': a['big_flops'] / (a['big_ms'] * 1e-3) / 1e12 / F64_PEAK_TFLOPS if a['big_ms'] > 0 else None}}
@@ -605,7 +613,8 @@ def main():
                 best = None
                 for wpd in (1, 3):
                     os.environ['HELM_WORKERS_PER_DEVICE'] = str(wpd)
-                    sch = dict(cfg); sch.update(freqs=[float(f) for f in freqs], Disc=Eurus, rtol=args.rtol, maxit=400000, method=args.method, batch=NSRC)
+                    sch = dict(cfg); sch.update(freqs=[float(f) for f in freqs], Disc=Eurus, rtol=args.rtol, maxit=400000, method=args.method, batch=NSRC,
+                                               device=local)        # this leg is a one-GPU figure like `value`, also on a node with eight
                     # untimed warm-up (like the W warm-up steps): the pinned result buffers and device pools come into being here
                     from zephyr_amd import _lib as _zl
                     from zephyr_amd import dispatch as _zd

@@ -197,6 +197,8 @@ typedef struct helm_timing {
     double gemm_big_ms;      /* the same over the launches of at least 1 GFLOP (throughput-bound ones) */
     long long gemm_big_launches;
     double gemm_big_flops;
+    double gemm_bytes;       /* operand bytes of the same launches, every operand once: 16 (M K + K N + M N (1 or 2)) per batch item */
+    double gemm_sol_ms;      /* sum over the launches of max(flops / 78.6 TFLOP/s, bytes / 8 TB/s): what the two roofs allow */
 } helm_timing;
 int helm_last_timing(const helm_op *op, helm_timing *out);
 /* enable per-launch HIP-event timing of the stencil kernel inside solves (costs a little) */

@@ -29,7 +29,7 @@ def test_struct_layouts_match_header():
     from zephyr_amd import _lib
     assert ctypes.sizeof(_lib.SolveOpts) == 32
     assert ctypes.sizeof(_lib.SolveInfo) == 24
-    assert ctypes.sizeof(_lib.Timing) == 88
+    assert ctypes.sizeof(_lib.Timing) == 104      # 11 + 2 (gemm_bytes, gemm_sol_ms) eight-byte fields
 
 
 def test_code_object_is_gfx950():

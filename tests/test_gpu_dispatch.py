@@ -107,3 +107,24 @@ def test_dpred_and_gradient_over_several_workers_match_golden(helm_lib, monkeypa
     gu = prob.Jtvec(None, g['resid'], u=uF)
     assert np.linalg.norm(gu - g['g_u']) / np.linalg.norm(g['g_u']) <= 1e-6
     del prob.factors
+
+
+def test_reserve_books_scratch_and_changes_no_result(helm_lib, monkeypatch):
+    """helm_reserve: a hint -- the shared scratch slots and device images of `concurrent` solves exist afterwards (with HELM_ALLOC_TRACE a
+    second call allocates nothing), bad arguments are rejected, and the wavefields are the same bits with or without it."""
+    import ctypes
+    import zephyr_amd as za
+    sc, q = config(freqs=[5.5])
+    op = za.Eurus(dict(sc, freq=5.5))
+    ref = op * q
+    del op.factors
+    op2 = za.Eurus(dict(sc, freq=5.5))
+    lib = helm_lib
+    N = sc['nx'] * sc['nz']
+    assert lib.helm_reserve(op2.handle, q.shape[1], N, 3) == 0
+    assert lib.helm_reserve(op2.handle, q.shape[1], N, 3) == 0          # everything is there already
+    assert lib.helm_reserve(op2.handle, 0, N, 1) < 0 and lib.helm_reserve(op2.handle, 4, 0, 1) < 0 and lib.helm_reserve(op2.handle, 4, N, 0) < 0
+    assert lib.helm_reserve(None, 4, N, 1) < 0
+    op2.reserve(q.shape[1], concurrent=2)
+    assert np.array_equal(op2 * q, ref)
+    del op2.factors

@@ -40,7 +40,8 @@ class Timing(ctypes.Structure):
                 ('apply_launches', ctypes.c_longlong), ('apply_bytes', ctypes.c_double),
                 ('factor_ms', ctypes.c_double), ('gemm_ms', ctypes.c_double),
                 ('gemm_launches', ctypes.c_longlong), ('gemm_flops', ctypes.c_double),
-                ('gemm_big_ms', ctypes.c_double), ('gemm_big_launches', ctypes.c_longlong), ('gemm_big_flops', ctypes.c_double)]
+                ('gemm_big_ms', ctypes.c_double), ('gemm_big_launches', ctypes.c_longlong), ('gemm_big_flops', ctypes.c_double),
+                ('gemm_bytes', ctypes.c_double), ('gemm_sol_ms', ctypes.c_double)]
 
 
 # every symbol include/helm.h declares, with its ctypes signature

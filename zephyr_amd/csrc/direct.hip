@@ -1575,6 +1575,15 @@ __global__ void k_axpy_one(cplx *y, const cplx *x, long long n, int conj) {
 
 int g_gemm_variant = -1;        // >= 0: overrides HELM_ND_GEMMV (helm_debug_zgemm_bench)
 int g_gemm_tile = -1;           // >= 0: forces the tile configuration (helm_debug_zgemm_bench)
+// What one GEMM launch has to move at the very least -- every operand once: A (M x K), B (K x N), C written (and read when beta != 0) -- and the
+// time the part's two roofs allow it: max(flops / 78.6 TFLOP/s, bytes / 8 TB/s).  The thin fronts low in the tree are HBM-bound products
+// (a level-13 front multiplies a 48 x 8 block into 256 right-hand sides: 1.6 flop per byte), the big ones fp64-bound; the bench adds both up.
+inline double gemm_operand_bytes(int M, int Nn, int K, cplx beta) {
+    const bool rd = !(beta.x == 0.0 && beta.y == 0.0);
+    return 16.0 * ((double)M * K + (double)K * Nn + (double)M * Nn * (rd ? 2.0 : 1.0));
+}
+inline double gemm_sol_ms(double flops, double bytes) { return 1e3 * std::max(flops / 78.6e12, bytes / 8.0e12); }
+
 int gemm_variant() {
     // 0: first-generation kernel (kept for before / after comparisons); 1: second-generation kernel, K slab 8; 6: K slab 32 on the 1-column
     // tiles.  Measured and dropped (profiles/r02_zgemm_lab_variants.txt): K slab 16 (occupancy 2), k loop unrolled twice (+1-2 %, 166 VGPRs),
@@ -1646,8 +1655,8 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
         // (a 4 x 8 register block per thread -- RN = 8, 64 x 128 tile -- was measured too: 230 VGPRs, occupancy 2, 38 % slower)
         const int gv = gemm_variant();
         struct ExtArm {            // arms the per-launch event pair for the launchers below, books it when the launch is out
-            helm_op *op; bool on; double fl;
-            ExtArm(helm_op *o, bool e, double f) : op(o), on(false), fl(f) {
+            helm_op *op; bool on; double fl, by;
+            ExtArm(helm_op *o, bool e, double f, double b) : op(o), on(false), fl(f), by(b) {
                 if (!e) return;
                 if (op->ev_used + 2 > op->ev_pool.size() && op->ev_pool.size() < 16384) (void)helm_events_grow(op, 64);
                 if (op->ev_used + 2 <= op->ev_pool.size()) { tl_ev0 = op->ev_pool[op->ev_used]; tl_ev1 = op->ev_pool[op->ev_used + 1]; on = true; }
@@ -1656,10 +1665,12 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
                 if (!on) return;
                 op->ev_pending_gemm.push_back(std::make_pair((int)op->ev_used, fl));
                 op->ev_pending_gemm_n.push_back(1);
+                op->ev_pending_gemm_bytes.push_back(by);
+                op->ev_pending_gemm_sol.push_back(gemm_sol_ms(fl, by));
                 op->ev_used += 2;
                 tl_ev0 = tl_ev1 = nullptr;
             }
-        } arm(op, ext, 8.0 * M * (double)Nn * K * nb);
+        } arm(op, ext, 8.0 * M * (double)Nn * K * nb, gemm_operand_bytes(M, Nn, K, beta) * nb);
 #define ZG_ARGS st, (rows && rows->schur4 ? 4 : (rows && !rows->dense ? (rows->fwd3 ? 2 : 1) : 0)), nb, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R
 #define ZG_VEC(TM_, RN_) do { switch (gv) { \
             case 0: launch_vec<TM_, RN_>(ZG_ARGS); break; \
@@ -1692,13 +1703,16 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
 #undef ZG_VEC
     }
     const double flops = 8.0 * M * (double)Nn * K * batch;
+    const double obytes = gemm_operand_bytes(M, Nn, K, beta) * batch;
     if (ext) return 0;
     if (in_run) {                       // the run's end event is recorded by GemmRun's destructor
-        if (op->gemm_run_pair >= 0) { op->gemm_run_flops += flops; op->gemm_run_launches += 1; }
+        if (op->gemm_run_pair >= 0) { op->gemm_run_flops += flops; op->gemm_run_bytes += obytes; op->gemm_run_sol += gemm_sol_ms(flops, obytes); op->gemm_run_launches += 1; }
     } else if (e0) {
         hipEventRecord(e1, st);
         op->ev_pending_gemm.push_back(std::make_pair((int)op->ev_used, flops));
         op->ev_pending_gemm_n.push_back(1);
+        op->ev_pending_gemm_bytes.push_back(obytes);
+        op->ev_pending_gemm_sol.push_back(gemm_sol_ms(flops, obytes));
         op->ev_used += 2;
     }
     return 0;
@@ -1708,13 +1722,15 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
 // two and four) share one pair of timing events: the per-launch average stays exact, two thirds of the event traffic go away.
 struct GemmRun {
     helm_op *op;
-    explicit GemmRun(helm_op *o) : op(o) { if (op && op->gemm_run_depth++ == 0) { op->gemm_run_pair = -1; op->gemm_run_flops = 0; op->gemm_run_launches = 0; } }
+    explicit GemmRun(helm_op *o) : op(o) { if (op && op->gemm_run_depth++ == 0) { op->gemm_run_pair = -1; op->gemm_run_flops = 0; op->gemm_run_bytes = 0; op->gemm_run_sol = 0; op->gemm_run_launches = 0; } }
     ~GemmRun() {
         if (!op || --op->gemm_run_depth != 0) return;
         if (op->gemm_run_pair >= 0 && op->gemm_run_launches > 0) {
             hipEventRecord(op->ev_pool[op->gemm_run_pair + 1], op->stream);
             op->ev_pending_gemm.push_back(std::make_pair(op->gemm_run_pair, op->gemm_run_flops));
             op->ev_pending_gemm_n.push_back(op->gemm_run_launches);
+            op->ev_pending_gemm_bytes.push_back(op->gemm_run_bytes);
+            op->ev_pending_gemm_sol.push_back(op->gemm_run_sol);
         }
         op->gemm_run_pair = -1;
     }

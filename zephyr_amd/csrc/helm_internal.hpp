@@ -149,8 +149,9 @@ struct helm_op {
     std::vector<std::pair<int, double>> ev_pending;   // (event-pair index, bytes)
     std::vector<std::pair<int, double>> ev_pending_gemm;   // (event-pair index, flops) of the direct solver's GEMM launches / runs of launches
     std::vector<int> ev_pending_gemm_n;                    // launches covered by each pair
+    std::vector<double> ev_pending_gemm_bytes, ev_pending_gemm_sol;   // operand bytes and roofline time (ms) of the same launches
     int gemm_run_depth = 0, gemm_run_launches = 0;         // back-to-back GEMM launches timed with ONE event pair (direct.hip)
-    double gemm_run_flops = 0;
+    double gemm_run_flops = 0, gemm_run_bytes = 0, gemm_run_sol = 0;
     int gemm_run_pair = -1;
     size_t ev_used = 0;
     int active_hint = -1;        // right-hand sides currently iterating (for the byte count of profiled launches)

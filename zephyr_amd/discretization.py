@@ -307,7 +307,8 @@ class BaseDiscretization(BaseModelDependent):
         _lib.check(_lib.load().helm_last_timing(self.handle, ctypes.byref(t)), self.handle)
         return dict(solve_ms=t.solve_ms, apply_ms=t.apply_ms, apply_launches=t.apply_launches, apply_bytes=t.apply_bytes,
                     factor_ms=t.factor_ms, gemm_ms=t.gemm_ms, gemm_launches=t.gemm_launches, gemm_flops=t.gemm_flops,
-                    gemm_big_ms=t.gemm_big_ms, gemm_big_launches=t.gemm_big_launches, gemm_big_flops=t.gemm_big_flops)
+                    gemm_big_ms=t.gemm_big_ms, gemm_big_launches=t.gemm_big_launches, gemm_big_flops=t.gemm_big_flops,
+                    gemm_bytes=t.gemm_bytes, gemm_sol_ms=t.gemm_sol_ms)
 
     @staticmethod
     def _dense_rhs(rhs):
