@@ -242,6 +242,7 @@ int helm_debug_inverse(int device, int n, double *A, int batch);
 /* average milliseconds per launch of one strided-batched GEMM shape (random operands, `reps` timed launches) with tile-kernel
  * variant `variant` (-1: default; 0: first-generation tile kernel; 1 / 2: conflict-free double-buffered kernel, K slab 8 / 16) */
 int helm_debug_zgemm_bench(int device, int M, int N, int K, int batch, int variant, int reps, double *ms_out);
+int helm_debug_inverse_bench(int device, int n, const double *A, int reps, int recurse_n, double *ms_out);
 
 /* --- diagnostics of the 3-D multigrid hierarchy (host only, no GPU needed; zephyr_amd/csrc/mg3d.hip) ------------------ */
 /* One axis of n nodes (spacing h, npml absorbing-layer nodes at each end, damping amplitude cpml) coarsened `level` times by the

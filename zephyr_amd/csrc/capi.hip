@@ -168,6 +168,9 @@ void helm_pool_free(int device, void *p, size_t bytes) {
 }
 
 
+// priority class of the factor stream of helm_prefactor (HELM_PF_PRIO: 1 highest, 0 normal, -1 lowest)
+static int pf_prio() { static const int p = getenv("HELM_PF_PRIO") ? atoi(getenv("HELM_PF_PRIO")) : 1; return p > 0 ? 1 : (p < 0 ? -1 : 0); }
+
 static helm_op *create_common(helm_op *op);
 
 extern "C" helm_op *helm_create3d(int device, int nz, int ny, int nx, double dx, double dy, double dz, int nPML) {
@@ -232,7 +235,7 @@ extern "C" void helm_destroy(helm_op *op) {
     if (op->pf_done) hipEventDestroy(op->pf_done);
     if (op->pf_t0) hipEventDestroy(op->pf_t0);
     if (op->pf_t1) hipEventDestroy(op->pf_t1);
-    if (op->fstream) helm_stream_release(op->device, 1, op->fstream);
+    if (op->fstream) helm_stream_release(op->device, pf_prio(), op->fstream);
     {   // timing events go back to the process-wide free list
         std::lock_guard<std::mutex> lk(g_pool.mu);
         std::vector<hipEvent_t> &idle = g_idle_events[op->device];
@@ -1411,7 +1414,7 @@ extern "C" int helm_prefactor(helm_op *op) {
     if (testing_hook("HELM_ND_INJECT_FAILURE")) return HELM_OK;
     HIP_TRY(op, hipSetDevice(op->device));
     if (!op->fstream) {
-        op->fstream = helm_stream_acquire(op->device, 1);
+        op->fstream = helm_stream_acquire(op->device, pf_prio());
         if (!op->fstream) HELM_FAIL(op, HELM_ERR_DEVICE, "hipStreamCreate failed");
     }
     if (!op->pf_done) HIP_TRY(op, hipEventCreateWithFlags(&op->pf_done, hipEventDisableTiming));

@@ -1738,6 +1738,7 @@ struct GemmRun {
 
 // in-place inverse of `batch` n x n blocks (row-major, leading dimension ld, batch stride `stride`); W: workspace with
 // batch stride ws, at least n*n elements per matrix
+int g_recurse_min = -1;     // (helm_debug_inverse_bench overrides HELM_ND_RECURSE_N)
 void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cplx *W, long long ws, int align = 1, int base = 0) {
     hipStream_t st = op ? op->stream : nullptr;
     // the coupled two-field system (align == 2) is far worse conditioned: it gets the wider pivoting window by default
@@ -1747,7 +1748,15 @@ void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cp
     // block inversion below is kept for the coupled two-field system (64-wide pivot windows) and as HELM_ND_BLOCKED=0
     static const int blocked = getenv("HELM_ND_BLOCKED") ? atoi(getenv("HELM_ND_BLOCKED")) : 1;
     static const int blocked_max_batch = getenv("HELM_ND_BLOCKED_BATCH") ? atoi(getenv("HELM_ND_BLOCKED_BATCH")) : 1024;
-    if (blocked && batch <= blocked_max_batch && gemm_variant() != 0 && n > gj_base && gj_base == 32 && (long long)2 * PNB * n <= ws) {
+    // Large single matrices (the dense plane inverses of the 3-D coarse solve, n = 3713) take ONE level of the 2 x 2 block recursion first:
+    // the same n^3 multiply-adds, but three quarters of them in products with an inner dimension of n / 2 (compute-bound, 44 TFLOP/s)
+    // instead of rank-32 updates that read and write the whole matrix every 32 columns (HBM-bound, 30 TFLOP/s); the halves go back to the
+    // blocked form.  Measured (helm_debug_inverse_bench, n = 3713): 15.9 -> 14.5 ms; a second level of recursion loses (17.3 ms: the
+    // blocked form of a 928^2 quarter is latency-bound, 58 us per block step), and so does recursion at n = 1857 (3.4 -> 4.5 ms).
+    static const int recurse_env = getenv("HELM_ND_RECURSE_N") ? atoi(getenv("HELM_ND_RECURSE_N")) : 3000;
+    const int recurse_min = g_recurse_min > 0 ? g_recurse_min : recurse_env;
+    const bool recurse = align == 1 && n >= recurse_min && (long long)n * n <= ws;
+    if (!recurse && blocked && batch <= blocked_max_batch && gemm_variant() != 0 && n > gj_base && gj_base == 32 && (long long)2 * PNB * n <= ws) {
         cplx *Wc = W, *Wr = W + (long long)PNB * n;
         // look-ahead: the pivot block of step k+1 is inverted beside the update of step k, in the same launch (k_zgemm2_la)
         // (the dense plane inverses of the 3-D coarse solve, n = 3713: -7 %; the 2-D fronts of 512 and 1024 unknowns at the top of the tree, with the
@@ -2617,6 +2626,29 @@ extern "C" int helm_debug_inverse(int device, int n, double *A, int batch) {
     invert((helm_op *)nullptr, dA, n, (long long)n * n, n, batch, dW, (long long)n * n);
     hipError_t e = hipDeviceSynchronize();
     hipMemcpy(A, dA, na * 16, hipMemcpyDeviceToHost);
+    hipFree(dA); hipFree(dW);
+    return e == hipSuccess ? HELM_OK : HELM_ERR_DEVICE;
+}
+
+// times `reps` in-place inversions of one n x n matrix (the caller's A, uploaded once; an inverse of an inverse is as good a test
+// matrix as the original) with the 2 x 2 block recursion applied from `recurse_n` unknowns up (0: the default policy)
+extern "C" int helm_debug_inverse_bench(int device, int n, const double *A, int reps, int recurse_n, double *ms_out) {
+    if (hipSetDevice(device) != hipSuccess) return HELM_ERR_DEVICE;
+    cplx *dA, *dW;
+    const size_t na = (size_t)n * n;
+    if (hipMalloc((void **)&dA, na * 16) != hipSuccess || hipMalloc((void **)&dW, na * 16) != hipSuccess) return HELM_ERR_DEVICE;
+    hipMemcpy(dA, A, na * 16, hipMemcpyHostToDevice);
+    g_recurse_min = recurse_n > 0 ? recurse_n : -1;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    invert((helm_op *)nullptr, dA, n, (long long)n * n, n, 1, dW, (long long)n * n);
+    hipEventRecord(e0, nullptr);
+    for (int r = 0; r < reps; ++r) invert((helm_op *)nullptr, dA, n, (long long)n * n, n, 1, dW, (long long)n * n);
+    hipEventRecord(e1, nullptr);
+    const hipError_t e = hipEventSynchronize(e1);
+    float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+    *ms_out = ms / std::max(1, reps);
+    g_recurse_min = -1;
+    hipEventDestroy(e0); hipEventDestroy(e1);
     hipFree(dA); hipFree(dW);
     return e == hipSuccess ? HELM_OK : HELM_ERR_DEVICE;
 }
