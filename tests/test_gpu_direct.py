@@ -50,6 +50,21 @@ def test_batched_inverse(helm_lib, n, batch):
         assert np.abs(out[b] @ A[b] - np.eye(n)).max() <= 1e-10
 
 
+@pytest.mark.parametrize('n,batch', [(512, 1), (600, 2), (1000, 1), (1101, 3), (3100, 1)])
+def test_large_inverse_with_look_ahead_and_block_recursion(helm_lib, n, batch):
+    """From 512 unknowns up the blocked Gauss-Jordan sweeps the next pivot block inside the launch of the current rank-32 update; from 3000
+    up one level of the 2 x 2 block recursion comes first.  Sizes that are not multiples of 32 / 64, several matrices per launch, row
+    exchanges inside pivot blocks."""
+    rng = np.random.default_rng(n)
+    A = crand(rng, batch, n, n) + 2.0 * np.sqrt(n) * np.eye(n)
+    A[0, 0, 0] = 0.0
+    A[-1, 32:36, 32:36] = np.fliplr(np.eye(4)) * 3.0                   # a permutation-like piece in the second pivot block
+    out = np.ascontiguousarray(A.copy())
+    assert helm_lib.helm_debug_inverse(0, n, out.ctypes.data_as(ctypes.c_void_p), batch) == 0
+    for b in range(batch):
+        assert np.abs(out[b] @ A[b] - np.eye(n)).max() <= 1e-9
+
+
 @pytest.mark.parametrize('cls', ['MiniZephyr', 'Eurus'])
 @pytest.mark.parametrize('nz,nx', [(64, 64), (70, 90), (41, 150), (9, 9)])
 def test_direct_matches_sparse_lu(helm_lib, cls, nz, nx):
