@@ -66,14 +66,20 @@ def small_lu():
 
 
 @pytest.mark.parametrize('env', [
-    {},                                                                         # the rule: one coarsening, rediscretised levels + Galerkin direct level
+    {},                                                                         # the rule: one coarsening, rediscretised levels + Galerkin direct level (column dissection)
     {'HELM_MG3_KEEP_LEVELS': '2'},                                              # one deeper: 5.6 points per wavelength, Galerkin operator
     {'HELM_MG3_KEEP_LEVELS': '2', 'HELM_MG3_GALERKIN': '0'},                    # the same depth with the rediscretised operator
-    {'HELM_MG3_KEEP_LEVELS': '2', 'HELM_MG3_BT_F32': '0'},                      # double-precision plane inverses
-    {'HELM_MG3_KEEP_LEVELS': '1', 'HELM_MG3_BT_F32': '0', 'HELM_MG3_GALERKIN': '0'},
+    {'HELM_MG3_KEEP_LEVELS': '1', 'HELM_MG3_GALERKIN': '0', 'HELM_MG3_ND_LEAF': '4'},
     {'HELM_MG3_DEPTH_MODEL': '0'},                                              # no cost model: the 10-points rule alone
     {'HELM_MG3_DEPTH_MODEL': '1', 'HELM_MG3_DEPTH_FORCE_DEEPER': '1'},          # the cost model's "deeper" verdict, whatever it measures
-    {'HELM_MG3_BT_TWIST': '0'},                                                 # one elimination chain instead of two
+    # the plane-by-plane elimination (what levels with 128 layers or more get)
+    {'HELM_MG3_COARSE': 'bt'},
+    {'HELM_MG3_COARSE': 'bt', 'HELM_MG3_KEEP_LEVELS': '2'},
+    {'HELM_MG3_COARSE': 'bt', 'HELM_MG3_KEEP_LEVELS': '2', 'HELM_MG3_GALERKIN': '0'},
+    {'HELM_MG3_COARSE': 'bt', 'HELM_MG3_KEEP_LEVELS': '2', 'HELM_MG3_BT_F32': '0'},          # double-precision plane inverses
+    {'HELM_MG3_COARSE': 'bt', 'HELM_MG3_KEEP_LEVELS': '1', 'HELM_MG3_BT_F32': '0', 'HELM_MG3_GALERKIN': '0'},
+    {'HELM_MG3_COARSE': 'bt', 'HELM_MG3_DEPTH_MODEL': '1', 'HELM_MG3_DEPTH_FORCE_DEEPER': '1'},
+    {'HELM_MG3_COARSE': 'bt', 'HELM_MG3_BT_TWIST': '0'},                                     # one elimination chain instead of two
 ], ids=lambda e: ','.join('%s=%s' % (k.replace('HELM_MG3_', ''), v) for k, v in sorted(e.items())) or 'default')
 def test_every_depth_branch_matches_sparse_lu(helm_lib, monkeypatch, small_lu, env):
     import zephyr_amd as za

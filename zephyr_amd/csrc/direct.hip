@@ -140,7 +140,8 @@ int nd_build_plan(NdPlan &P, int nz, int nx, int leaf, int dof) {
         NdGroup &g = P.groups[gi];
         g.foff += (long long)(g.level & 1) * P.fregion;
         g.voff += (long long)(g.level & 1) * P.vregion;
-        P.work_elems = std::max(P.work_elems, (long long)g.cnt * g.smax * g.smax);
+        // (the inversion's scratch; a leaf level with more than 64 unknowns per front also forms -F11^-1 F12 there: smax x mmax per front)
+        P.work_elems = std::max(P.work_elems, (long long)g.cnt * g.smax * (g.leaf ? std::max(g.smax, g.mmax) : g.smax));
         for (int j = 0; j < g.cnt; ++j) {
             NdDev &n = P.nodes[g.first + j];
             const long long nmax = g.smax + g.mmax;
@@ -179,16 +180,21 @@ __global__ __launch_bounds__(256) void k_nd_assemble(const NdDev *nodes, int fir
         int z, x, ca;
         nd_cell(n, a, z, x, ca);
         const int ra = nd_pos(n, a);
-        for (int cb = 0; cb < n.dof; ++cb) {
+        // dof > 2 (column mode, the 3-D coarse solve): a cell is a column of dof unknowns along the slowest axis of a (dof, nz, nx) grid with a
+        // 27-point operator -- component ca couples to ca - 1, ca, ca + 1 of the nine neighbour columns; plane 9 (dc + 1) + 3 (dz + 1) + dx + 1
+        const int cb0 = n.dof > 2 ? max(ca - 1, 0) : 0, cb1 = n.dof > 2 ? min(ca + 1, n.dof - 1) : n.dof - 1;
+        for (int cb = cb0; cb <= cb1; ++cb) {
             // dof 2: row component ca, column component cb -> Eurus block 2 ca + cb (M1 M2 / M3 M4), nine planes each
-            const cplx *pl = planes + (long long)(n.dof == 2 ? 2 * ca + cb : 0) * 9 * N;
+            const cplx *pl = n.dof > 2 ? planes + (long long)(cb - ca + 1) * 9 * N * n.dof + (long long)ca * N
+                                       : planes + (long long)(n.dof == 2 ? 2 * ca + cb : 0) * 9 * N;
+            const long long pstride = n.dof > 2 ? N * n.dof : N;
             #pragma unroll
             for (int k = 0; k < 9; ++k) {
                 const int z2 = z + k / 3 - 1, x2 = x + k % 3 - 1;
                 if (z2 < 0 || z2 >= nz || x2 < 0 || x2 >= nx) continue;
                 const int b = nd_local(n, nz, nx, z2, x2, cb);
                 if (b < 0 || (a >= n.s && b >= n.s)) continue;            // ring x ring entries belong to an ancestor
-                *front_entry(n, arenaF, fac, ra, nd_pos(n, b)) = pl[(long long)k * N + (long long)z * nx + x];
+                *front_entry(n, arenaF, fac, ra, nd_pos(n, b)) = pl[(long long)k * pstride + (long long)z * nx + x];
             }
         }
     }
@@ -251,8 +257,8 @@ __global__ __launch_bounds__(256) void k_nd_build_front(const NdDev *nodes, int 
             int k0 = 0, k1 = 0;
             if (h0) { const int la = nd_local(c0, nz, nx, z, x, comp); if (la >= c0.s) k0 = la - c0.s + 1; }
             if (h1) { const int la = nd_local(c1, nz, nx, z, x, comp); if (la >= c1.s) k1 = la - c1.s + 1; }
-            e.x = z | (x << 16);
-            e.y = k0 | (k1 << 14) | (comp << 28);
+            if (n.dof > 2) { e.x = z | (x << 12) | (comp << 24); e.y = k0 | (k1 << 16); }      // (column mode: up to 127 components, rings up to 65534)
+            else { e.x = z | (x << 16); e.y = k0 | (k1 << 14) | (comp << 28); }
         }
         finfo[r] = e;
     }
@@ -264,7 +270,10 @@ __global__ __launch_bounds__(256) void k_nd_build_front(const NdDev *nodes, int 
     const int tx = tid & 63, ty = tid >> 6;
     for (int r = r0 + ty; r < r1; r += 4) {
         const int2 ia = finfo[r];
-        const int za = ia.x & 0xffff, xa = ia.x >> 16, ca = (ia.y >> 28) & 1, a0 = (ia.y & 0x3fff) - 1, a1 = ((ia.y >> 14) & 0x3fff) - 1;
+        const bool colmode = n.dof > 2;
+        const int za = colmode ? (ia.x & 0xfff) : (ia.x & 0xffff), xa = colmode ? ((ia.x >> 12) & 0xfff) : (ia.x >> 16);
+        const int ca = colmode ? ((ia.x >> 24) & 0x7f) : ((ia.y >> 28) & 1);
+        const int a0 = (colmode ? (ia.y & 0xffff) : (ia.y & 0x3fff)) - 1, a1 = (colmode ? ((ia.y >> 16) & 0xffff) : ((ia.y >> 14) & 0x3fff)) - 1;
         // skip22: the ring x ring block (the sum of the children's Schur complements, most of a front below the tree top) is not
         // materialised -- the Schur-complement product gathers it itself (k_zgemm2<.., 4, ..>) and writes S where F22 would have been
         const int cend = (skip22 && r >= n.smax) ? n.smax : nmax;
@@ -274,13 +283,19 @@ __global__ __launch_bounds__(256) void k_nd_build_front(const NdDev *nodes, int 
             if (ia.x < 0 || ib.x < 0) { if (r == c && r < n.smax) v = cmake(1.0, 0.0); }
             else {
                 if (r < n.smax || c < n.smax) {              // ring x ring entries belong to an ancestor
-                    const int dz = (ib.x & 0xffff) - za, dx = (ib.x >> 16) - xa;
+                    const int zb = colmode ? (ib.x & 0xfff) : (ib.x & 0xffff), xb = colmode ? ((ib.x >> 12) & 0xfff) : (ib.x >> 16);
+                    const int dz = zb - za, dx = xb - xa;
                     if (dz >= -1 && dz <= 1 && dx >= -1 && dx <= 1) {
-                        const int blk = n.dof == 2 ? 2 * ca + ((ib.y >> 28) & 1) : 0;
-                        v = planes[((long long)blk * 9 + (dz + 1) * 3 + dx + 1) * N + (long long)za * nx + xa];
+                        if (colmode) {
+                            const int dc = ((ib.x >> 24) & 0x7f) - ca;
+                            if (dc >= -1 && dc <= 1) v = planes[((long long)(dc + 1) * 9 + (dz + 1) * 3 + dx + 1) * N * n.dof + (long long)ca * N + (long long)za * nx + xa];
+                        } else {
+                            const int blk = n.dof == 2 ? 2 * ca + ((ib.y >> 28) & 1) : 0;
+                            v = planes[((long long)blk * 9 + (dz + 1) * 3 + dx + 1) * N + (long long)za * nx + xa];
+                        }
                     }
                 }
-                const int b0 = (ib.y & 0x3fff) - 1, b1 = ((ib.y >> 14) & 0x3fff) - 1;
+                const int b0 = (colmode ? (ib.y & 0xffff) : (ib.y & 0x3fff)) - 1, b1 = (colmode ? ((ib.y >> 16) & 0xffff) : ((ib.y >> 14) & 0x3fff)) - 1;
                 if (a0 >= 0 && b0 >= 0) v = cadd(v, S0[(long long)a0 * ld0 + b0]);
                 if (a1 >= 0 && b1 >= 0) v = cadd(v, S1[(long long)a1 * ld1 + b1]);
             }
@@ -1848,11 +1863,14 @@ std::mutex g_plan_mu;
 std::vector<std::shared_ptr<NdPlanDev>> g_plans;     // most recently used last, at most 4 kept alive by the cache
 }
 
-int nd_get_plan(helm_op *op, int leaf, int dof, std::shared_ptr<NdPlanDev> *out) {
+int nd_get_plan(helm_op *op, int leaf, int dof, std::shared_ptr<NdPlanDev> *out) { return nd_get_plan_dims(op, op->nz, op->nx, leaf, dof, out); }
+
+// the same for a grid that is not the handle's own: the 3-D coarse solve runs the 2-D dissection over (ny, nx) columns of nz unknowns (dof = nz)
+int nd_get_plan_dims(helm_op *op, int pnz, int pnx, int leaf, int dof, std::shared_ptr<NdPlanDev> *out) {
     std::lock_guard<std::mutex> lk(g_plan_mu);
     for (size_t i = 0; i < g_plans.size(); ++i) {
         const NdPlanDev &c = *g_plans[i];
-        if (c.device == op->device && c.plan.nz == op->nz && c.plan.nx == op->nx && c.plan.leaf == std::max(2, leaf) && c.plan.dof == dof) {
+        if (c.device == op->device && c.plan.nz == pnz && c.plan.nx == pnx && c.plan.leaf == std::max(2, leaf) && c.plan.dof == dof) {
             std::shared_ptr<NdPlanDev> hit = g_plans[i];
             g_plans.erase(g_plans.begin() + i); g_plans.push_back(hit);
             *out = hit;
@@ -1861,7 +1879,7 @@ int nd_get_plan(helm_op *op, int leaf, int dof, std::shared_ptr<NdPlanDev> *out)
     }
     std::shared_ptr<NdPlanDev> pd(new NdPlanDev());
     pd->device = op->device;
-    nd_build_plan(pd->plan, op->nz, op->nx, leaf, dof);
+    nd_build_plan(pd->plan, pnz, pnx, leaf, dof);
     const NdPlan &P = pd->plan;
     if (2 * P.vregion >= (1LL << 31) || P.total_rows >= (1LL << 31)) HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "direct solver: grid too large for 32-bit row indices");
     HIP_TRY(op, hipMalloc((void **)&pd->d_nodes, P.nodes.size() * sizeof(NdDev)));
@@ -1987,7 +2005,7 @@ int stabilise_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *wor
         HIP_TRY(op, hipMemcpyAsync(S.d_node, &n, sizeof(NdDev), hipMemcpyHostToDevice, st));
         HIP_TRY(op, hipStreamSynchronize(st));                                    // (n is a stack copy)
         const int rb = std::max(std::min(nmax, 4), (nmax + 2047) / 2048);
-        hipLaunchKernelGGL(k_nd_build_front, dim3((nmax + rb - 1) / rb, 1), dim3(256), (size_t)nmax * sizeof(int2), st, f->pd->d_nodes, 0, arenaF, S.lu, planes, op->nz, op->nx, rb,
+        hipLaunchKernelGGL(k_nd_build_front, dim3((nmax + rb - 1) / rb, 1), dim3(256), (size_t)nmax * sizeof(int2), st, f->pd->d_nodes, 0, arenaF, S.lu, planes, P.nz, P.nx, rb,
                            (const NdDev *)S.d_node);
         cplx *F21 = arenaF + foff, *F22 = arenaF + foff + g.smax;
         HIP_TRY(op, hipMemcpy2DAsync(S.f21, (size_t)g.smax * sizeof(cplx), F21, (size_t)nmax * sizeof(cplx), (size_t)g.smax * sizeof(cplx), (size_t)g.mmax, hipMemcpyDeviceToDevice, st));
@@ -2019,23 +2037,24 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
     // the ring x ring block of a non-leaf front stays unbuilt: its Schur-complement product gathers the children's contributions itself
     static const int schur_gather_env = getenv("HELM_ND_SCHURGATHER") ? atoi(getenv("HELM_ND_SCHURGATHER")) : 1;
     bool schur_gather = false;
-    if (fused_build && (size_t)nmax * sizeof(int2) <= 64 * 1024 && nmax < (1 << 14) && op->nz < 65536 && op->nx < 32768)
+    const bool packs = P.dof <= 2 ? (nmax < (1 << 14) && P.nz < 65536 && P.nx < 32768) : (nmax < 65535 && P.nz < 4096 && P.nx < 4096 && P.dof < 128);
+    if (fused_build && (size_t)nmax * sizeof(int2) <= 64 * 1024 && packs)
         schur_gather = schur_gather_env && !g.leaf && g.mmax > 0 && gemm_variant() != 0 && P.dof == 1;
-    if (fused_build && (size_t)nmax * sizeof(int2) <= 64 * 1024 && nmax < (1 << 14) && op->nz < 65536 && op->nx < 32768) {      // (its row table must fit the 64 KB of LDS a launch gets by default: larger fronts take the unfused path)
+    if (fused_build && (size_t)nmax * sizeof(int2) <= 64 * 1024 && packs) {      // (its row table must fit the 64 KB of LDS a launch gets by default: larger fronts take the unfused path)
         // rows per workgroup: whole fronts while there are thousands of them, a few rows each for the handful of big ones at the top
         const int want = std::max(1, 2048 / g.cnt);
         const int rb = std::max(std::min(nmax, 4), (nmax + want - 1) / want);
         for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
             const int nb = std::min(65535, g.cnt - j0);
             hipLaunchKernelGGL(k_nd_build_front, dim3((nmax + rb - 1) / rb, nb), dim3(256), (size_t)nmax * sizeof(int2), st, d_nodes, g.first + j0, arenaF, f->d_fac, planes,
-                               op->nz, op->nx, rb, (const NdDev *)nullptr, schur_gather ? 1 : 0);
+                               P.nz, P.nx, rb, (const NdDev *)nullptr, schur_gather ? 1 : 0);
         }
     } else {
         if (fs > 0) HIP_TRY(op, hipMemsetAsync(F, 0, (size_t)g.cnt * fs * sizeof(cplx), st));
         HIP_TRY(op, hipMemsetAsync(Finv, 0, (size_t)g.cnt * s1 * sizeof(cplx), st));
         for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
             const int nb = std::min(65535, g.cnt - j0);
-            hipLaunchKernelGGL(k_nd_assemble, dim3((nmax + 255) / 256, nb), dim3(256), 0, st, d_nodes, g.first + j0, arenaF, f->d_fac, planes, op->nz, op->nx);
+            hipLaunchKernelGGL(k_nd_assemble, dim3((nmax + 255) / 256, nb), dim3(256), 0, st, d_nodes, g.first + j0, arenaF, f->d_fac, planes, P.nz, P.nx);
         }
         if (!g.leaf) {
             // children's ring sizes are bounded by this group's front size
@@ -2047,7 +2066,7 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
                     const long long total = (long long)nmax * nmax;
                     const int chunk = (int)std::max<long long>(4096, std::min<long long>(total, std::max<long long>(16LL * nmax, total / std::max(1, 2048 / nb))));
                     const int gx = (int)std::max<long long>(1, std::min<long long>((total + chunk - 1) / chunk, 65535));
-                    hipLaunchKernelGGL(k_nd_extend_add, dim3(gx, nb), dim3(256), shm, st, d_nodes, g.first + j0, slot, arenaF, f->d_fac, op->nz, op->nx, chunk);
+                    hipLaunchKernelGGL(k_nd_extend_add, dim3(gx, nb), dim3(256), shm, st, d_nodes, g.first + j0, slot, arenaF, f->d_fac, P.nz, P.nx, chunk);
                 }
         }
     }

@@ -115,6 +115,7 @@ __host__ __device__ inline int nd_pos(const NdDev &n, int a) { return a < n.s ? 
 int nd_build_plan(NdPlan &P, int nz, int nx, int leaf, int dof = 1);
 long long nd_factor_ws_elems(const NdPlan &P);
 int nd_get_plan(helm_op *op, int leaf, int dof, std::shared_ptr<NdPlanDev> *out);    // cached per (device, grid, leaf, dof)
+int nd_get_plan_dims(helm_op *op, int nz, int nx, int leaf, int dof, std::shared_ptr<NdPlanDev> *out);
 int nd_factor(helm_op *op, int block, NdFactor *f, cplx *ws, const cplx *planes = nullptr);    // f->pd must be set; dof 2: block ignored, all four Eurus blocks
 int nd_factor_enqueue(helm_op *op, int block, NdFactor *f, cplx *ws, const cplx *planes = nullptr);    // the same without the final synchronisation: launches only
 void nd_free(NdFactor *f);

@@ -9,10 +9,13 @@
 //    ~10 points per wavelength.  DESIGN.md section 5.3 has the measurements behind each of these choices.
 #include "helm_internal.hpp"
 #include <map>
+#include <tuple>
 #include <mutex>
 #include "direct.hpp"
 #include <algorithm>
 #include <complex>
+#include <cstring>
+#include <memory>
 
 struct Mg3Level {
     helm_op *op = nullptr;
@@ -199,10 +202,22 @@ struct Bt3 {                        // direct solver of the coarsest level
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
 };
 
+// Nested-dissection alternative to Bt3 (HELM_MG3_COARSE=nd): the multifrontal solver of the 2-D path (direct.hip) run over the (ny, nx) grid of
+// z-columns of the level -- a "cell" is a column of nz unknowns (NdPlan::dof = nz), its 27-point coupling to the nine neighbour columns a
+// block-tridiagonal nz x nz block.  The top separator is one plane of the level (the size Bt3 inverts np times); below it the fronts shrink.
+struct Nd3 {
+    std::shared_ptr<NdPlanDev> pd;
+    NdFactor *f = nullptr;
+    cplx *ws = nullptr; size_t ws_bytes = 0;        // solve scratch (nd_solve_ws_elems), from the pool
+    int device = 0, batch = 0;
+    bool on() const { return f != nullptr; }
+};
+
 struct Mg3Keep {
     std::vector<cplx *> dl1;                         // per level: l1-Jacobi inverse diagonal
     std::vector<PTab *> pt[3]; std::vector<RTab *> rt[3];   // per transfer (level l -> l+1) and axis (z, y, x): device tables
     Bt3 bt;
+    Nd3 nd;
     double omega_l1 = 1.6;
 };
 
@@ -723,6 +738,83 @@ int bt_setup(helm_op *op, Bt3 &B, const Mg3Level &L, int batch) {
     return HELM_OK;
 }
 
+void nd3_free(Nd3 &D) {
+    if (D.ws) helm_pool_free(D.device, D.ws, D.ws_bytes);
+    if (D.f) nd_free(D.f);
+    D = Nd3();
+}
+
+bool nd3_applicable(int nz, int ny, int nx) { return nz >= 3 && nz < 128 && ny >= 3 && nx >= 3 && ny < 4096 && nx < 4096; }
+
+// what the column dissection of an (nz, ny, nx) level costs: flops of its factorisation, bytes of its factors and of the factorisation scratch
+// (host side: the plan only; cached, the plan of a 79 x 79 grid has 2000 fronts)
+struct Nd3Cost { double flops = 0, fac_bytes = 0, ws_bytes = 0; int top = 0; };
+Nd3Cost nd3_cost(int nz, int ny, int nx) {
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int, int>, Nd3Cost> cache;
+    const int leaf = envi("HELM_MG3_ND_LEAF", 2);
+    std::lock_guard<std::mutex> lk(mu);
+    auto key = std::make_tuple(nz, ny, nx, leaf);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    NdPlan P;
+    nd_build_plan(P, ny, nx, leaf, nz);
+    Nd3Cost c;
+    for (const NdGroup &g : P.groups) {
+        c.flops += (double)g.cnt * 8.0 * (2.0 * g.smax * g.smax * g.smax + (double)g.smax * g.smax * g.mmax + (double)g.smax * g.mmax * g.mmax);
+        c.top = std::max(c.top, g.smax);
+    }
+    c.fac_bytes = (double)P.fac_elems * sizeof(cplx);
+    c.ws_bytes = (double)nd_factor_ws_elems(P) * sizeof(cplx);
+    cache[key] = c;
+    return c;
+}
+
+// Which direct solver the level gets.  HELM_MG3_COARSE = nd | bt forces one; otherwise the column dissection wherever it applies and needs fewer
+// flops than the plane-by-plane elimination (np inversions of m^3): on config 5's 47 x 79 x 79 level 10.5 against 32.6 TFLOP.
+bool coarse_is_nd(int nz, int ny, int nx) {
+    const char *cs = getenv("HELM_MG3_COARSE");
+    if (cs && !strcmp(cs, "bt")) return false;
+    if (!nd3_applicable(nz, ny, nx)) return false;
+    if (cs && !strcmp(cs, "nd")) return true;
+    const int d[3] = {nz, ny, nx};
+    int sI = 0;
+    for (int a = 1; a < 3; ++a) if (d[a] > d[sI]) sI = a;
+    const double m = (double)d[(sI + 1) % 3] * d[(sI + 2) % 3];
+    return nd3_cost(nz, ny, nx).flops < (double)d[sI] * 8.0 * m * m * m;
+}
+
+int nd3_setup(helm_op *op, Nd3 &D, const Mg3Level &L, int batch) {
+    if (!nd3_applicable(L.nz, L.ny, L.nx)) HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "3-D multigrid: the column dissection takes levels with fewer than 128 layers");
+    D.device = op->device; D.batch = batch;
+    int rc = nd_get_plan_dims(op, L.ny, L.nx, envi("HELM_MG3_ND_LEAF", 2), L.nz, &D.pd);
+    if (rc) return rc;
+    const NdPlan &P = D.pd->plan;
+    const size_t fwb = (size_t)nd_factor_ws_elems(P) * sizeof(cplx);
+    D.ws_bytes = (size_t)nd_solve_ws_elems(P, batch) * sizeof(cplx);
+    {
+        size_t freeb = 0, totb = 0;
+        hipMemGetInfo(&freeb, &totb);
+        const double need = (double)P.fac_elems * sizeof(cplx) + (double)fwb + (double)D.ws_bytes;
+        if (need > 0.9 * (double)freeb) HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "3-D multigrid: the factors of the directly solved level (%.1f GB) do not fit", need / 1e9);
+    }
+    hipStreamSynchronize(op->stream);
+    D.f = new NdFactor();
+    D.f->pd = D.pd;
+    cplx *fw = (cplx *)helm_pool_alloc(op->device, fwb);
+    D.ws = (cplx *)helm_pool_alloc(op->device, D.ws_bytes);
+    if (!fw || !D.ws) { if (fw) helm_pool_free(op->device, fw, fwb); nd3_free(D); HELM_FAIL(op, HELM_ERR_DEVICE, "3-D multigrid: scratch of the column dissection does not fit"); }
+    rc = nd_factor(op, 0, D.f, fw, L.op->d_C);
+    helm_pool_free(op->device, fw, fwb);
+    if (rc) { nd3_free(D); return rc; }
+    if (envi("HELM_MG3_TRACE", 0))
+        fprintf(stderr, "[helm mg3] column dissection of the %d x %d x %d level: %zu fronts, factors %.2f GB, %.2f TFLOP\n", L.nz, L.ny, L.nx, P.nodes.size(),
+                P.fac_elems * 16e-9, D.f->flops * 1e-12);
+    return HELM_OK;
+}
+
+int nd3_solve(helm_op *op, Nd3 &D, const cplx *f, cplx *u, int nrhs) { return nd_solve(op, D.f, f, u, nrhs, D.ws); }
+
 // u = A^-1 f on the coarsest level (f, u: [nrhs][N])
 int bt_solve(helm_op *op, Bt3 &B, const Mg3Level &L, const cplx *f, cplx *u, int nrhs) {
     hipStream_t sts[2] = {op->stream, B.aux->stream};
@@ -790,7 +882,7 @@ int cycle_keep(helm_op *op, Mg3Precond *P, size_t l, int nrhs, cplx *final_out =
     Mg3Keep *K = P->keep;
     Mg3Level &L = P->lv[l];
     hipStream_t st = op->stream;
-    if (l + 1 == P->lv.size()) return bt_solve(op, K->bt, L, L.f, L.u, nrhs);
+    if (l + 1 == P->lv.size()) return K->nd.on() ? nd3_solve(op, K->nd, L.f, L.u, nrhs) : bt_solve(op, K->bt, L, L.f, L.u, nrhs);
     Mg3Level &C = P->lv[l + 1];
     const cplx *dl1 = K->dl1[l];
     const double w = K->omega_l1;
@@ -824,6 +916,7 @@ void keep_free(Mg3Precond *P) {
     for (cplx *d : K->dl1) hipFree(d);
     for (int a = 0; a < 3; ++a) { for (PTab *t : K->pt[a]) hipFree(t); for (RTab *t : K->rt[a]) hipFree(t); }
     bt_free(K->bt);
+    nd3_free(K->nd);
     delete K;
     P->keep = nullptr;
 }
@@ -838,6 +931,20 @@ template <typename T> T *upload(const std::vector<T> &v) {
 // geometry of the directly solved level if it is the one reached after `l` layer-preserving coarsenings: np planes of m x m;
 // returns the bytes of its plane inverses as bt_setup will store them for `batch` right-hand sides (single precision for up to 16
 // with the library's own plane product, double precision -- padded for the generic batched GEMM -- beyond that or on request)
+// nodes per axis (z, y, x) of level l of the layer-preserving hierarchy
+void keep_level_dims(const helm_op *op, int l, int out[3]) {
+    const int dims[3] = {op->nz, op->ny, op->nx};
+    for (int a = 0; a < 3; ++a) {
+        Ax3 ax; const int n = dims[a], np = op->nPML;
+        ax.x.resize(n); ax.gam.assign(n, 0.0); ax.lay.assign(n, 0);
+        for (int i = 0; i < n; ++i) ax.x[i] = i;
+        for (int k = 0; k < np && k < n; ++k) { ax.lay[k] = 1; ax.lay[n - np + k] = 1; }
+        Ax3 c; std::vector<int> kept; std::vector<PTab> pt; std::vector<RTab> rt;
+        for (int i = 0; i < l; ++i) { coarsen_axis(ax, true, c, kept, pt, rt); ax = c; }
+        out[a] = ax.n();
+    }
+}
+
 double keep_direct_bytes(const helm_op *op, int l, int batch, int *np_out = nullptr, int *m_out = nullptr) {
     const int dims[3] = {op->nz, op->ny, op->nx};
     int out[3];
@@ -934,6 +1041,25 @@ double apply_seconds_per_rhs(helm_op *op, int batch) {
     return t;
 }
 
+// memory and set-up time of the direct solver of level l, whichever kind it gets (coarse_is_nd): the plane-by-plane elimination is np timed
+// inversions; the column dissection is priced at its flop count over the rate of a timed inversion of its top separator's size (its big
+// fronts run the same blocked Gauss-Jordan and the same tile kernel: 10.5 TFLOP in 0.42 s on config 5 = the 25 TFLOP/s of the 3713^2 inversion)
+struct CoarseEst { bool nd = false; double bytes = 0, seconds = 0; int np = 0, m = 0; };
+CoarseEst coarse_estimate(helm_op *op, int l, int batch, bool timed) {
+    CoarseEst e;
+    int d[3];
+    keep_level_dims(op, l, d);
+    e.bytes = keep_direct_bytes(op, l, batch, &e.np, &e.m);
+    e.nd = coarse_is_nd(d[0], d[1], d[2]);
+    if (e.nd) {
+        const Nd3Cost c = nd3_cost(d[0], d[1], d[2]);
+        e.bytes = c.fac_bytes + c.ws_bytes;
+        if (timed) { const int mt = std::max(64, c.top); e.seconds = c.flops / (8.0 * mt * (double)mt * mt / inverse_seconds(op, mt)); }
+        e.np = 1; e.m = c.top;
+    } else if (timed) e.seconds = e.np * inverse_seconds(op, e.m);
+    return e;
+}
+
 // levels 0 .. ncoarsen of the layer-preserving hierarchy + the direct solver of the last one; on failure the caller falls back
 int setup_keep(helm_op *op, Mg3Precond *P, int batch, int ncoarsen, double tauM) {
     Mg3Keep *K = new Mg3Keep();
@@ -1005,7 +1131,9 @@ int setup_keep(helm_op *op, Mg3Precond *P, int batch, int ncoarsen, double tauM)
                            (const PTab *)K->pt[0][t], (const PTab *)K->pt[1][t], (const PTab *)K->pt[2][t]);
         HIP_TRY(op, hipGetLastError());
     }
-    return bt_setup(op, K->bt, P->lv.back(), batch);
+    const Mg3Level &Ld = P->lv.back();
+    if (coarse_is_nd(Ld.nz, Ld.ny, Ld.nx)) return nd3_setup(op, K->nd, Ld, batch);
+    return bt_setup(op, K->bt, Ld, batch);
 }
 
 }  // namespace
@@ -1061,7 +1189,7 @@ int mg3_setup(helm_op *op, int batch) {
             const double krylov = 11.0 * batch * (double)op->N * sizeof(cplx);
             const double cap = std::min(envd("HELM_MG3_BT_MAXGB", totb / 3.0e9) * 1e9, std::max(0.0, (double)freeb - (op->d_ws ? 0.0 : krylov)));
             const double ppwf = envd("HELM_MG3_PPWF", 6.0);
-            while (ncoarsen < 5 && keep_direct_bytes(op, ncoarsen, batch) > cap && ppw / (double)(2 << ncoarsen) >= ppwf && (interior >> (ncoarsen + 1)) >= 3) ++ncoarsen;
+            while (ncoarsen < 5 && coarse_estimate(op, ncoarsen, batch, false).bytes > cap && ppw / (double)(2 << ncoarsen) >= ppwf && (interior >> (ncoarsen + 1)) >= 3) ++ncoarsen;
             // ... and one level deeper (down to 5 points) when that SAVES time for the right-hand sides of the call that builds the preconditioner:
             // the set-up of the deeper level is cheaper (np plane inversions of m^3 work each) but every right-hand side pays more iterations.
             //   set-up saved   = np_d t_inv(m_d) - np_{d+1} t_inv(m_{d+1}),  t_inv timed on this device (inverse_seconds)
@@ -1075,16 +1203,17 @@ int mg3_setup(helm_op *op, int batch) {
             if (op->mg3_rhs_hint > 0 && envi("HELM_MG3_DEPTH_MODEL", 1) && ncoarsen < 5 && (interior >> (ncoarsen + 1)) >= 3) {
                 const double ppwd = ppw / (double)(2 << ncoarsen);
                 if (ppwd >= 5.0) {
-                    int np0 = 0, m0 = 0, np1 = 0, m1 = 0;
-                    keep_direct_bytes(op, ncoarsen, batch, &np0, &m0); keep_direct_bytes(op, ncoarsen + 1, batch, &np1, &m1);
-                    const double saved = envd("HELM_MG3_DEPTH_SETUP_SCALE", 1.0) * (np0 * inverse_seconds(op, m0) - np1 * inverse_seconds(op, m1));
+                    const CoarseEst e0 = coarse_estimate(op, ncoarsen, batch, true), e1 = coarse_estimate(op, ncoarsen + 1, batch, true);
+                    const int np0 = e0.np, m0 = e0.m, np1 = e1.np, m1 = e1.m;
+                    const double saved = envd("HELM_MG3_DEPTH_SETUP_SCALE", 1.0) * (e0.seconds - e1.seconds);
                     const double extra_its = ppwd >= 8.0 ? 11.0 : (ppwd >= 6.0 ? 22.0 : 38.0);
                     const double t_iter = 18.0 * apply_seconds_per_rhs(op, batch);
                     const double paid = op->mg3_rhs_hint * extra_its * t_iter;
                     const bool deeper = saved > paid || envi("HELM_MG3_DEPTH_FORCE_DEEPER", 0) != 0;
                     if (envi("HELM_MG3_TRACE", 0))
-                        fprintf(stderr, "[mg3 depth] %d coarsenings (%.1f points per wavelength on the direct level): set-up %d x %d^2 planes; one deeper: %d x %d^2; saves %.3f s, "
-                                        "costs %d rhs x %.0f iterations x %.2f ms = %.3f s -> %s\n", ncoarsen, ppwd, np0, m0, np1, m1, saved, op->mg3_rhs_hint, extra_its,
+                        fprintf(stderr, "[mg3 depth] %d coarsenings (%.1f points per wavelength on the direct level): set-up %d x %d^2 (%s); one deeper: %d x %d^2 (%s); saves %.3f s, "
+                                        "costs %d rhs x %.0f iterations x %.2f ms = %.3f s -> %s\n", ncoarsen, ppwd, np0, m0, e0.nd ? "column dissection, top separator" : "planes",
+                                np1, m1, e1.nd ? "column dissection, top separator" : "planes", saved, op->mg3_rhs_hint, extra_its,
                                 t_iter * 1e3, paid, deeper ? "deeper" : "stay");
                     if (deeper) ++ncoarsen;
                 }
