@@ -181,7 +181,7 @@ def config5_leg(local, rtol=1e-8, nsrc=16, freqs=(2., 3., 4., 5.), grid=(128, 25
     dev = torch.device('cuda', local)
     cfg = dict(nx=nx, ny=ny, nz=nz, dx=10., c=2000., rho=1., freq=freqs[0], nPML=10, rtol=rtol, maxit=60000, batch=nsrc, method='auto', device=local)
     out = {'workload': '3D 27-pt Helmholtz %dx%dx%d (nx, ny, nz) homogeneous c=2000 m/s, rho=1, h=10 m, nPML=10; %d freqs x %d sources, rtol %g, fp64; '
-                       'BiCGSTAB right-preconditioned by the layer-preserving 3-D multigrid with a block-tridiagonal direct coarse solve'
+                       'BiCGSTAB right-preconditioned by the layer-preserving 3-D multigrid with a direct coarse solve (column dissection: the 2-D multifrontal solver over z-columns; plane-by-plane elimination where that is cheaper)'
                        % (nx, ny, nz, len(freqs), nsrc, rtol),
            'grid_nz_ny_nx': [nz, ny, nx], 'rtol': rtol, 'per_frequency': [], 'apply': []}
     q = np.zeros((nsrc, N), complex)

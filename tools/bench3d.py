@@ -24,7 +24,7 @@ cfg = dict(nx=nx, ny=ny, nz=nz, dx=10., c=2000., rho=1., freq=a.freqs[0], nPML=1
 op = Helm3D(cfg)
 lib = _lib.load()
 dev = torch.device('cuda', 0)
-out = {'grid': [nz, ny, nx], 'preconditioner': 'standard shifted cycle' if a.standard_cycle else 'layer-preserving hierarchy + block-tridiagonal coarse solve', 'apply': []}
+out = {'grid': [nz, ny, nx], 'preconditioner': 'standard shifted cycle' if a.standard_cycle else 'layer-preserving hierarchy + direct coarse solve (column dissection / plane-by-plane elimination)', 'apply': []}
 for B in (() if a.no_apply else (1, 4, 8, 16)):
     X = torch.randn((B, N), dtype=torch.complex128, device=dev)
     Y = torch.empty_like(X)
