@@ -320,6 +320,25 @@ extern "C" int helm_set_model(helm_op *op, const double *c, const double *rho, c
     return HELM_OK;
 }
 
+// The model of an operator that lives on the device already (a multigrid level: the caller's arrays, or values a kernel has put into
+// dst->d_c / dst->d_rho -- then both pointers are null): device-to-device, nothing visits the host.  Isotropic operators only.
+int helm_adopt_model_device(helm_op *dst, const cplx *d_c, const double *d_rho) {
+    if (!dst || (d_c == nullptr) != (d_rho == nullptr)) return HELM_ERR_ARG;
+    HIP_TRY(dst, hipSetDevice(dst->device));
+    const size_t N = (size_t)dst->N;
+    if (d_c) {
+        HIP_TRY(dst, hipMemcpyAsync(dst->d_c, d_c, N * sizeof(cplx), hipMemcpyDeviceToDevice, dst->stream));
+        HIP_TRY(dst, hipMemcpyAsync(dst->d_rho, d_rho, N * sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
+    }
+    dst->aniso = false;
+    dst->h_c.clear(); dst->h_rho.clear(); dst->h_theta.clear(); dst->h_eps.clear(); dst->h_delta.clear();
+    dst->block_zero[0] = dst->block_zero[1] = dst->block_zero[3] = false;
+    dst->block_zero[2] = true;
+    dst->has_model = true;
+    dst->assembled = false;
+    return HELM_OK;
+}
+
 int helm_ensure_host_model(helm_op *op) {
     if (!op->has_model) HELM_FAIL(op, HELM_ERR_STATE, "model not set");
     if (!op->h_c.empty()) return HELM_OK;

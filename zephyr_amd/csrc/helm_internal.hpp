@@ -274,3 +274,4 @@ int helm_launch_rowscale_inplace(helm_op *op, cplx *v, const double *rs, long lo
 int helm_launch_abs(helm_op *op, const cplx *in, cplx *out, long long n, double sign);      // out = sign |in|
 int helm_launch_gardner_rho(helm_op *op);     // d_rho = 310 Re(d_c)^0.25
 int helm_ensure_host_model(helm_op *op);      // h_c, h_rho, ... (downloaded from the device on first use)
+int helm_adopt_model_device(helm_op *dst, const cplx *d_c, const double *d_rho);     // model of a multigrid level from device arrays (capi.hip)

@@ -8,6 +8,7 @@
 //    absorbing layers, l1-Jacobi, true layer with a small shift, block-tridiagonal direct solve of the level that still has
 //    ~10 points per wavelength.  DESIGN.md section 5.3 has the measurements behind each of these choices.
 #include "helm_internal.hpp"
+#include <chrono>
 #include <map>
 #include <tuple>
 #include <mutex>
@@ -1060,8 +1061,36 @@ CoarseEst coarse_estimate(helm_op *op, int l, int batch, bool timed) {
     return e;
 }
 
+// smallest Re(c) of the model, on the device (positive doubles order like their bit patterns)
+__global__ void k3_min_re(const cplx *__restrict__ c, long long n, unsigned long long *out) {
+    double m = 1e300;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) m = fmin(m, c[e].x);
+    for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_down(m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMin(out, (unsigned long long)__double_as_longlong(m));
+}
+// model of a coarser level: the values at the nodes it keeps (kz / ky / kx: kept node indices per axis)
+__global__ void k3_inject_model(const cplx *__restrict__ c, const double *__restrict__ rho, int fny, int fnx, const int *__restrict__ kz, const int *__restrict__ ky,
+                                const int *__restrict__ kx, int nzc, int nyc, int nxc, cplx *__restrict__ cc, double *__restrict__ rc) {
+    const long long n = (long long)nzc * nyc * nxc;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        const int X = (int)(e % nxc), Y = (int)((e / nxc) % nyc), Z = (int)(e / ((long long)nxc * nyc));
+        const long long src = ((long long)kz[Z] * fny + ky[Y]) * fnx + kx[X];
+        cc[e] = c[src]; rc[e] = rho[src];
+    }
+}
+
 // levels 0 .. ncoarsen of the layer-preserving hierarchy + the direct solver of the last one; on failure the caller falls back
 int setup_keep(helm_op *op, Mg3Precond *P, int batch, int ncoarsen, double tauM) {
+    const bool trace = envi("HELM_MG3_TRACE", 0) != 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto tprev = now();
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        hipStreamSynchronize(op->stream);
+        const auto t = now();
+        fprintf(stderr, "[helm mg3 set-up] %-34s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(t - tprev).count());
+        tprev = t;
+    };
     Mg3Keep *K = new Mg3Keep();
     P->keep = K;
     K->omega_l1 = envd("HELM_MG3_OMEGA_L1", 1.6);
@@ -1081,9 +1110,11 @@ int setup_keep(helm_op *op, Mg3Precond *P, int batch, int ncoarsen, double tauM)
             ax[a].gam[n - np + k] = cpml * cos((M_PI / 2) * ((np - 1 - k) * hs[a] / Lh)); ax[a].lay[n - np + k] = 1;
         }
     }
-    std::vector<cplx> c = op->h_c;
-    std::vector<double> rho = op->h_rho;
+    // the levels' models never visit the host: level 0 copies the caller's device arrays, a coarser level takes the values at the nodes it keeps
+    std::vector<int> kept[3];
+    lap("axes");
     for (int l = 0; l <= ncoarsen; ++l) {
+        if (l) lap("level (operator, vectors, tables)");
         Mg3Level L;
         L.nz = ax[0].n(); L.ny = ax[1].n(); L.nx = ax[2].n(); L.N = (long long)L.nz * L.ny * L.nx;
         L.op = helm_create3d(op->device, L.nz, L.ny, L.nx, 1.0, 1.0, 1.0, 2);
@@ -1096,7 +1127,25 @@ int setup_keep(helm_op *op, Mg3Precond *P, int batch, int ncoarsen, double tauM)
         Lr.op->lap_override = Lx;
         Lr.op->lap_override.insert(Lr.op->lap_override.end(), Ly.begin(), Ly.end());
         Lr.op->lap_override.insert(Lr.op->lap_override.end(), Lz.begin(), Lz.end());
-        int rc = helm_set_model(Lr.op, (const double *)c.data(), rho.data(), nullptr, nullptr, nullptr);
+        int rc = HELM_OK;
+        if (l == 0) rc = helm_adopt_model_device(Lr.op, op->d_c, op->d_rho);
+        else {
+            const Mg3Level &Lf = P->lv[l - 1];
+            const size_t kb = (kept[0].size() + kept[1].size() + kept[2].size()) * sizeof(int);
+            int *dk = (int *)helm_pool_alloc(op->device, kb);
+            if (!dk) HELM_FAIL(op, HELM_ERR_DEVICE, "3-D multigrid: transfer tables do not fit");
+            size_t off = 0;
+            const int *dka[3];
+            for (int a = 0; a < 3; ++a) {
+                hipMemcpyAsync(dk + off, kept[a].data(), kept[a].size() * sizeof(int), hipMemcpyHostToDevice, op->stream);
+                dka[a] = dk + off; off += kept[a].size();
+            }
+            hipLaunchKernelGGL(k3_inject_model, dim3((unsigned)std::min<long long>((Lr.N + 255) / 256, 65535)), dim3(256), 0, op->stream, (const cplx *)Lf.op->d_c,
+                               (const double *)Lf.op->d_rho, Lf.ny, Lf.nx, dka[0], dka[1], dka[2], Lr.nz, Lr.ny, Lr.nx, Lr.op->d_c, Lr.op->d_rho);
+            hipStreamSynchronize(op->stream);                    // (kept[] is overwritten below; the table buffer goes back to the pool)
+            helm_pool_free(op->device, dk, kb);
+            rc = helm_adopt_model_device(Lr.op, nullptr, nullptr);
+        }
         if (!rc) rc = helm_assemble(Lr.op, op->a_freq_re, op->a_freq_im, tauM, 0.0, cpml);
         if (rc) HELM_FAIL(op, rc, "%s", helm_last_error(Lr.op));
         if (!level_vectors(op, Lr, batch)) HELM_FAIL(op, HELM_ERR_DEVICE, "3-D multigrid: level vectors do not fit");
@@ -1106,7 +1155,7 @@ int setup_keep(helm_op *op, Mg3Precond *P, int batch, int ncoarsen, double tauM)
         K->dl1.push_back(dl1);
         hipLaunchKernelGGL(k3_l1_dinv, dim3((unsigned)std::min<long long>((Lr.N + 255) / 256, 65535)), dim3(256), 0, op->stream, (const cplx *)Lr.op->d_C, dl1, Lr.N, K->omega_l1);
         // next level
-        Ax3 cx[3]; std::vector<int> kept[3];
+        Ax3 cx[3];
         for (int a = 0; a < 3; ++a) {
             std::vector<PTab> pt; std::vector<RTab> rt;
             coarsen_axis(ax[a], true, cx[a], kept[a], pt, rt);
@@ -1114,15 +1163,9 @@ int setup_keep(helm_op *op, Mg3Precond *P, int batch, int ncoarsen, double tauM)
             K->pt[a].push_back(dp); K->rt[a].push_back(dr);
             if (!dp || !dr) HELM_FAIL(op, HELM_ERR_DEVICE, "3-D multigrid: transfer tables do not fit");
         }
-        const int nzc = cx[0].n(), nyc = cx[1].n(), nxc = cx[2].n();
-        std::vector<cplx> cc((size_t)nzc * nyc * nxc); std::vector<double> rc2(cc.size());
-        for (int Z = 0; Z < nzc; ++Z) for (int Y = 0; Y < nyc; ++Y) for (int X = 0; X < nxc; ++X) {
-            const size_t src = ((size_t)kept[0][Z] * L.ny + kept[1][Y]) * L.nx + kept[2][X], dst = ((size_t)Z * nyc + Y) * nxc + X;
-            cc[dst] = c[src]; rc2[dst] = rho[src];
-        }
-        c.swap(cc); rho.swap(rc2);
         for (int a = 0; a < 3; ++a) ax[a] = cx[a];
     }
+    lap("last level");
     if (ncoarsen > 0 && envi("HELM_MG3_GALERKIN", 1)) {        // the directly solved level carries the Galerkin product of the level above it
         const Mg3Level &Lf = P->lv[ncoarsen - 1]; Mg3Level &Lc = P->lv[ncoarsen];
         const int t = ncoarsen - 1;
@@ -1131,9 +1174,11 @@ int setup_keep(helm_op *op, Mg3Precond *P, int batch, int ncoarsen, double tauM)
                            (const PTab *)K->pt[0][t], (const PTab *)K->pt[1][t], (const PTab *)K->pt[2][t]);
         HIP_TRY(op, hipGetLastError());
     }
+    lap("Galerkin product");
     const Mg3Level &Ld = P->lv.back();
-    if (coarse_is_nd(Ld.nz, Ld.ny, Ld.nx)) return nd3_setup(op, K->nd, Ld, batch);
-    return bt_setup(op, K->bt, Ld, batch);
+    const int rcd = coarse_is_nd(Ld.nz, Ld.ny, Ld.nx) ? nd3_setup(op, K->nd, Ld, batch) : bt_setup(op, K->bt, Ld, batch);
+    lap("direct solver of the last level");
+    return rcd;
 }
 
 }  // namespace
@@ -1154,8 +1199,7 @@ void mg3_destroy(helm_op *op) {
 int mg3_setup(helm_op *op, int batch) {
     if (op->mg3 && op->mg3->batch >= batch) return HELM_OK;
     if (op->mg3) mg3_destroy(op);
-    int rc = helm_ensure_host_model(op);
-    if (rc) return rc;
+    int rc = HELM_OK;
     Mg3Precond *P = new Mg3Precond();
     op->mg3 = P;
     P->batch = batch;
@@ -1167,7 +1211,17 @@ int mg3_setup(helm_op *op, int batch) {
     // shift: 0.6 at 10 grid points per wavelength, growing with the square of the oversampling up to 8 -- measured at
     // 256 x 256 x 128, 40-100 points per wavelength: beta 0.6 / 3 / 6 / 12 -> 26 / 16 / 14 / 14 s per 4 sources at 3 Hz
     double cmin = 1e300;
-    for (const cplx &cv : op->h_c) cmin = std::min(cmin, cv.x);
+    {
+        unsigned long long *dmin = (unsigned long long *)helm_pool_alloc(op->device, sizeof(unsigned long long));
+        unsigned long long hmin = ~0ULL;
+        if (!dmin) HELM_FAIL(op, HELM_ERR_DEVICE, "3-D multigrid: scratch allocation failed");
+        hipMemcpyAsync(dmin, &hmin, sizeof(hmin), hipMemcpyHostToDevice, op->stream);
+        hipLaunchKernelGGL(k3_min_re, dim3(2048), dim3(256), 0, op->stream, (const cplx *)op->d_c, op->N, dmin);
+        hipMemcpyAsync(&hmin, dmin, sizeof(hmin), hipMemcpyDeviceToHost, op->stream);
+        HIP_TRY(op, hipStreamSynchronize(op->stream));
+        helm_pool_free(op->device, dmin, sizeof(unsigned long long));
+        if (hmin != ~0ULL) { long long b = (long long)hmin; cmin = __builtin_bit_cast(double, b); }
+    }
     const double hmax = std::max(op->dx, std::max(op->dy, op->dz));
     const double ppw = omega > 0 ? cmin / (omega / (2.0 * M_PI) * hmax) : 10.0;
     const double over = std::max(1.0, ppw / 10.0);
@@ -1244,6 +1298,8 @@ int mg3_setup(helm_op *op, int batch) {
     // with the small shift beta = 0.6 only gamma / omega <= 0.4 was stable)
     P->cpml_m = envd("HELM_MG3_CPML", 2.0 * omega);
     const double cpml = std::min(P->cpml_m, op->a_cpml > 0 ? op->a_cpml : P->cpml_m);
+    rc = helm_ensure_host_model(op);               // (the standard hierarchy injects its models on the host)
+    if (rc) return rc;
     std::vector<cplx> c = op->h_c;
     std::vector<double> rho = op->h_rho;
     int nz = op->nz, ny = op->ny, nx = op->nx, npml = op->nPML;
