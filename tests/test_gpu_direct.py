@@ -20,7 +20,9 @@ def crand(rng, *shape):
     return rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
 
 
-@pytest.mark.parametrize('M,N,K,batch', [(64, 64, 8, 1), (36, 256, 64, 7), (1, 1, 1, 3), (65, 67, 9, 2), (130, 33, 71, 3), (9, 256, 9, 40)])
+@pytest.mark.parametrize('M,N,K,batch', [(64, 64, 8, 1), (36, 256, 64, 7), (1, 1, 1, 3), (65, 67, 9, 2), (130, 33, 71, 3), (9, 256, 9, 40),
+                                         # tall-and-skinny products (<= 16 columns, long inner dimension): the streaming kernel of the 3-D coarse solve
+                                         (100, 16, 500, 3), (8, 16, 384, 1), (893, 16, 2900, 2), (37, 5, 1000, 2), (64, 1, 2000, 1), (13, 9, 447, 4)])
 def test_batched_zgemm(helm_lib, M, N, K, batch):
     rng = np.random.default_rng(M * 7 + N)
     A, B, C = crand(rng, batch, M, K), crand(rng, batch, K, N), crand(rng, batch, M, N)

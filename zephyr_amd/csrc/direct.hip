@@ -1630,12 +1630,16 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
     // tile of the vector kernel: 4 x RN outputs per thread, TM x TN = TM x (1024 / TM * RN).  The padded area is weighed by how
     // well a register block re-uses its LDS reads (4 x 4: 1, 4 x 2: 0.7, 4 x 1: 0.45): narrow tiles only win on small outputs
     // (the 32 x 32 blocks at the bottom of the inversion recursion, 17- and 35-wide separators of the middle tree levels)
-    static const int vc_tm[8] = {64, 32, 16, 64, 32, 16, 32, 16}, vc_rn[8] = {4, 4, 4, 2, 2, 2, 1, 1};
+    // (the 128 x 16 tile: products with at most 16 columns -- the solve passes of the 3-D coarse level push 16 right-hand sides through fronts of
+    // thousands of unknowns -- where the 64 x 32 tile leaves half of its columns idle)
+    static const int vc_tm[9] = {64, 32, 16, 64, 32, 16, 32, 16, 128}, vc_rn[9] = {4, 4, 4, 2, 2, 2, 1, 1, 2};
     static const double w2 = getenv("HELM_ND_EFF2") ? atof(getenv("HELM_ND_EFF2")) : 0.7, w1 = getenv("HELM_ND_EFF1") ? atof(getenv("HELM_ND_EFF1")) : 0.45;
-    static const double vc_eff[8] = {1.0, 1.0, 1.0, w2, w2, w2, w1, w1};
+    static const double vc_eff[9] = {1.0, 1.0, 1.0, w2, w2, w2, w1, w1, w2};
     static const int narrow = getenv("HELM_ND_NARROW") ? atoi(getenv("HELM_ND_NARROW")) : 1;
     int vsel = 0; double vcost = -1;
-    for (int c = 0; c < (narrow ? 8 : 3); ++c) {
+    static const int tall = getenv("HELM_ND_TALL") ? atoi(getenv("HELM_ND_TALL")) : 1;
+    for (int c = 0; c < (narrow ? (tall ? 9 : 8) : 3); ++c) {
+        if (c == 8 && (Nn > 16 || gemm_variant() == 0)) continue;
         const int tm = vc_tm[c], tn = 1024 / tm * vc_rn[c];
         const double cost = (double)((M + tm - 1) / tm) * tm * ((Nn + tn - 1) / tn) * tn / vc_eff[c];
         if (vcost < 0 || cost < vcost * 0.999) { vsel = c; vcost = cost; }
@@ -1713,6 +1717,7 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
             case 4: ZG_VEC(32, 2); break;
             case 5: ZG_VEC(16, 2); break;
             case 6: ZG_VEC(32, 1); break;
+            case 8: launch_vec2<128, 2, 8, 1, 1>(ZG_ARGS); break;      // (second-generation kernel only: see the candidate loop)
             default: ZG_VEC(16, 1); break;
         }
 #undef ZG_VEC
