@@ -125,7 +125,7 @@ coefficients, `||q||^2` and the wavefield store fused; `k_front_absmax` / `k_lu_
 {table_of(rows3, 10)}
 
 (`k_zgemm2<64, 0, 4, ..>` / `k_zgemm2_la` / `k_gj_*` / `k_nd_build_front`: the column dissection of the directly solved level -- the 2-D multifrontal solver over z-columns;
-`k_zgemm2<64, 0, 2, ..>` / `<32, 0, 1, ..>` / `k_nd_fwd_rows` / `k_nd_bwd_*`: its forward / backward passes for 16 right-hand sides inside the cycles; `k_stencil3<false, EPI>`: 4 = residual,
+`k_zgemm2<128, 0, 2, ..>` (128 x 16 tile) / `<32, 0, 1, ..>` (the few big fronts at the top) / `k_nd_fwd_rows` / `k_nd_bwd_*`: its forward / backward passes for 16 right-hand sides inside the cycles; `k_stencil3<false, EPI>`: 4 = residual,
 5 = l1-Jacobi sweep, 1 / 6 = the outer BiCGSTAB applies with fused dots.)
 
 The whole 4-frequency job is the `config5` block of `r03_bench_n1.json` (above).  Round-2 files `r02_config5_*` (tool runs, standard-cycle comparison) are kept.
