@@ -153,3 +153,28 @@ def test_helm3d_against_the_2p5d_summation_on_a_layered_model(helm_lib):
     print('2.5-D vs 3-D: alpha = %s, homogeneous %.3f, layered %.3f' % (alpha, nrm(alpha * a25, a3), err))
     assert err < 1e-1, err
     assert nrm(alpha * a25, b3) > 3 * err                            # the layering matters at this accuracy: the check is not vacuous
+
+
+def test_prefactor_builds_the_3d_preconditioner_ahead_of_the_solve(helm_lib, monkeypatch, small_lu):
+    """helm_prefactor_n on a 3-D operator: the multigrid hierarchy and the factorisation of its directly solved level exist when it returns
+    (built on a low-priority stream, what a dispatcher's prepare thread calls for frequency k+1 while frequency k iterates); the solve that
+    follows re-uses them and returns the same wavefield as a solve that builds them itself -- and the LU's."""
+    import time
+    import zephyr_amd as za
+    cfg, q, ref = small_lu
+    monkeypatch.setenv('HELM_MG3_KEEP', '2')
+    a = za.Helm3D(cfg)
+    ua = a * q
+    ia = [i['iterations'] for i in a.lastInfo]
+    del a.factors
+    b = za.Helm3D(cfg)
+    b.prefactor(q.shape[1])
+    t0 = time.perf_counter()
+    b.prefactor(q.shape[1])                                          # a second call finds the preconditioner in place
+    assert time.perf_counter() - t0 < 0.05
+    ub = b * q
+    assert [i['iterations'] for i in b.lastInfo] == ia
+    assert np.array_equal(ua, ub)
+    assert nrm(ub, ref) <= 1e-7
+    assert helm_lib.helm_prefactor_n(None, 3) < 0
+    del b.factors

@@ -76,6 +76,7 @@ _SIGNATURES = {
     'helm_rhs_from_coo_device_layout': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong,
                                                        ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_int]),
     'helm_prefactor': (ctypes.c_int, [ctypes.c_void_p]),
+    'helm_prefactor_n': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'helm_reserve': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_int]),
     'helm_last_timing': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Timing)]),
     'helm_set_profiling': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),

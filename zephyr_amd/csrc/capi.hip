@@ -67,7 +67,8 @@ int helm_events_grow(helm_op *op, int n) {
 // (small buffers too: hipFree waits for every stream of the device, which would stall a host thread that prepares the next operator
 // while another one is solving -- the per-operator scratch of a few KB goes through the pool like the GB-sized buffers)
 static const size_t kPoolMinBytes = (size_t)64;
-// What the pool may hold idle: half of the device's memory (HELM_POOL_GB overrides).  A 16-frequency job at 1024^2 hands back ~70 GB of
+// What the pool may hold idle: three quarters of the device's memory (HELM_POOL_GB overrides; buffers below 1 MB are always kept: their hipFree
+// would be a device synchronisation for nothing).  A 16-frequency job at 1024^2 hands back ~70 GB of
 // factors when its operators go; with a 64-GB cap the overflow went to hipFree and the next job's hipMalloc calls -- issued while other
 // threads had kernels and copies in flight -- took 1.2-1.5 s EACH (HELM_ALLOC_TRACE=1 shows them).
 static size_t pool_cap_bytes() {
@@ -75,7 +76,7 @@ static size_t pool_cap_bytes() {
         if (const char *e = getenv("HELM_POOL_GB")) return (size_t)(atof(e) * 1e9);
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return (size_t)64 << 30; }
-        return tot / 2;
+        return tot / 4 * 3;           // (what is in use plus what idles here cannot exceed the device: a failed hipMalloc empties the pool and retries)
     }();
     return cap;
 }
@@ -146,6 +147,7 @@ void *helm_pool_alloc(int device, size_t bytes) {
     if (hipMalloc(&p, bytes) != hipSuccess) {
         (void)hipGetLastError();
         // under memory pressure give the cached buffers back and try once more
+        AllocTrace trf("pool flush", g_pool.held);
         std::lock_guard<std::mutex> lk(g_pool.mu);
         for (auto &kv : g_pool.idle) hipFree(kv.second);
         g_pool.idle.clear(); g_pool.held = 0;
@@ -158,7 +160,7 @@ void helm_pool_free(int device, void *p, size_t bytes) {
     {
         const size_t cap = pool_cap_bytes();
         std::lock_guard<std::mutex> lk(g_pool.mu);
-        if (bytes >= kPoolMinBytes && g_pool.held + bytes <= cap) {
+        if (bytes >= kPoolMinBytes && (g_pool.held + bytes <= cap || bytes < ((size_t)1 << 20))) {
             g_pool.idle.insert(std::make_pair(std::make_pair(device, bytes), p)); g_pool.held += bytes;
             return;
         }
@@ -1421,6 +1423,41 @@ void helm_pf_retire(helm_op *op) {
     helm_pool_free(op->device, op->pf_ws, op->pf_ws_bytes);
     op->pf_ws = nullptr; op->pf_ws_bytes = 0;
     op->pf_pending = false;
+}
+
+// 3-D: what the next solve would build first -- the multigrid hierarchy with its directly solved level (hundreds of ms of GPU work and host logic,
+// with waits in between) -- built NOW, in the calling thread.  Meant for a dispatcher's prepare thread: the set-up of frequency k+1 then runs
+// beside the Krylov iterations of frequency k on another handle.  nrhs: right-hand sides the solve will bring (batch width, depth decision).
+static int prefactor3d(helm_op *op, int nrhs) {
+    if (op->mg3 || op->mg3_no_keep) return HELM_OK;
+    static const int auto_mg3 = getenv("HELM_AUTO_MG3") ? atoi(getenv("HELM_AUTO_MG3")) : 1;
+    if (!auto_mg3 || std::min(op->nz, std::min(op->ny, op->nx)) < 24) return HELM_OK;
+    HIP_TRY(op, hipSetDevice(op->device));
+    const int Bmax = std::max(1, std::min(nrhs > 0 ? nrhs : 16, 16));
+    NvGuard guard(op, op->N);
+    if (helm_ensure_scaled(op) != HELM_OK) return HELM_OK;
+    if (ensure_ws(op, (size_t)11 * Bmax * op->N * sizeof(cplx)) != HELM_OK || ensure_part(op, Bmax) != HELM_OK) return HELM_OK;
+    op->mg3_rhs_hint = nrhs > 0 ? nrhs : 16;
+    // on a low-priority stream: the set-up is compute-bound products that would otherwise take the CUs from the (bandwidth-bound, critical-path)
+    // iterations of the frequency being solved on another handle
+    static const int prio = getenv("HELM_PF3_PRIO") ? atoi(getenv("HELM_PF3_PRIO")) : -1;
+    hipStream_t main = op->stream, low = prio < 0 ? helm_stream_acquire(op->device, -1) : nullptr;
+    if (low) op->stream = low;
+    (void)mg_setup(op, Bmax);            // a hint: a failure here is the solve's to report
+    if (low) {
+        hipStreamSynchronize(low);
+        op->stream = main;
+        mg3_retarget_stream(op, main);
+        helm_stream_release(op->device, -1, low);
+    }
+    return HELM_OK;
+}
+
+extern "C" int helm_prefactor_n(helm_op *op, int nrhs) {
+    if (!op) return HELM_ERR_ARG;
+    if (!op->assembled) HELM_FAIL(op, HELM_ERR_STATE, "operator not assembled");
+    if (op->ny > 0) return prefactor3d(op, nrhs);
+    return helm_prefactor(op);
 }
 
 extern "C" int helm_prefactor(helm_op *op) {

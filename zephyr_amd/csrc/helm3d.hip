@@ -242,8 +242,8 @@ int helm3d_launch_assemble(helm_op *op, double freq_re, double freq_im, double t
     // levels of the layer-preserving multigrid hierarchy (mg3d.hip) bring their own factors: non-uniform node spacing, 1/h^2 included
     const bool over = op->lap_override.size() == all.size();
     if (over) all = op->lap_override;
-    cplx *d_L = nullptr;
-    HIP_TRY(op, hipMalloc(&d_L, all.size() * sizeof(cplx)));
+    cplx *d_L = (cplx *)helm_pool_alloc(op->device, all.size() * sizeof(cplx));
+    if (!d_L) HELM_FAIL(op, HELM_ERR_DEVICE, "hipMalloc of the stretch profiles failed");
     HIP_TRY(op, hipMemcpyAsync(d_L, all.data(), all.size() * sizeof(cplx), hipMemcpyHostToDevice, op->stream));
     Asm3Params P;
     P.nz = op->nz; P.ny = op->ny; P.nx = op->nx; P.dx = op->dx; P.dy = op->dy; P.dz = op->dz;
@@ -254,7 +254,7 @@ int helm3d_launch_assemble(helm_op *op, double freq_re, double freq_im, double t
                        (const cplx *)d_L, (const cplx *)(d_L + 3 * (size_t)op->nx), (const cplx *)(d_L + 3 * (size_t)op->nx + 3 * (size_t)op->ny), op->d_C);
     HIP_TRY(op, hipGetLastError());
     HIP_TRY(op, hipStreamSynchronize(op->stream));
-    HIP_TRY(op, hipFree(d_L));
+    helm_pool_free(op->device, d_L, all.size() * sizeof(cplx));
     return HELM_OK;
 }
 

@@ -187,6 +187,7 @@ int mg_apply(helm_op *op, const cplx *in, cplx *out, int nrhs, const RhsScal *sc
 // 3-D counterpart (mg3d.hip): layer-preserving hierarchy with a direct coarse solve on oversampled grids, otherwise a
 // shifted-Laplacian V-cycle with damped-Jacobi smoothing and a weak absorbing layer
 int mg3_setup(helm_op *op, int batch);
+void mg3_retarget_stream(helm_op *op, hipStream_t st);
 void mg3_destroy(helm_op *op);
 int mg3_apply(helm_op *op, const cplx *in, cplx *out, int nrhs);
 bool mg3_is_layer_preserving(const helm_op *op);           // the hierarchy in use is the layer-preserving one

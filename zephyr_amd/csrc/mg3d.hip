@@ -216,6 +216,8 @@ struct Nd3 {
 
 struct Mg3Keep {
     std::vector<cplx *> dl1;                         // per level: l1-Jacobi inverse diagonal
+    std::vector<size_t> dl1_bytes; int device = 0;   // (everything here comes from the size-keyed pool: hipMalloc / hipFree beside another handle's solve stall)
+    std::vector<std::pair<void *, size_t>> tabs;     // the transfer tables' buffers
     std::vector<PTab *> pt[3]; std::vector<RTab *> rt[3];   // per transfer (level l -> l+1) and axis (z, y, x): device tables
     Bt3 bt;
     Nd3 nd;
@@ -914,18 +916,20 @@ int cycle_keep(helm_op *op, Mg3Precond *P, size_t l, int nrhs, cplx *final_out =
 void keep_free(Mg3Precond *P) {
     Mg3Keep *K = P->keep;
     if (!K) return;
-    for (cplx *d : K->dl1) hipFree(d);
-    for (int a = 0; a < 3; ++a) { for (PTab *t : K->pt[a]) hipFree(t); for (RTab *t : K->rt[a]) hipFree(t); }
+    for (size_t i = 0; i < K->dl1.size(); ++i) helm_pool_free(K->device, K->dl1[i], K->dl1_bytes[i]);
+    for (auto &t : K->tabs) helm_pool_free(K->device, t.first, t.second);
     bt_free(K->bt);
     nd3_free(K->nd);
     delete K;
     P->keep = nullptr;
 }
 
-template <typename T> T *upload(const std::vector<T> &v) {
-    T *d = nullptr;
-    if (hipMalloc((void **)&d, v.size() * sizeof(T)) != hipSuccess) return nullptr;
-    if (hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { hipFree(d); return nullptr; }
+template <typename T> T *upload(Mg3Keep *K, const std::vector<T> &v) {
+    const size_t b = v.size() * sizeof(T);
+    T *d = (T *)helm_pool_alloc(K->device, b);
+    if (!d) return nullptr;
+    K->tabs.push_back(std::make_pair((void *)d, b));
+    if (hipMemcpy(d, v.data(), b, hipMemcpyHostToDevice) != hipSuccess) return nullptr;      // (the buffer goes back with the others in keep_free)
     return d;
 }
 
@@ -983,7 +987,24 @@ std::mutex g_cal_mu;
 std::map<std::pair<int, int>, double> g_cal_inverse;       // (device, size) -> seconds of one dense inversion
 // seconds the dense blocked Gauss-Jordan takes for one m x m plane: timed on a synthetic matrix of min(m, 4096) rows, scaled with the cube of
 // the size above that (the rate still rises a little there, so large planes are over- rather than under-estimated)
+double inverse_seconds_class(helm_op *op, int mc);
+// All size classes are timed the first time any of them is asked for -- the first set-up of the process, before anything else runs on the GPU:
+// a dispatcher later builds the next frequency's preconditioner BESIDE the current frequency's iterations, and a timing taken there would
+// measure the sharing (set-ups that look slow send the depth decision one level deeper than it should go).
 double inverse_seconds(helm_op *op, int m) {
+    static const int classes[5] = {256, 512, 1024, 2048, 4096};
+    {
+        bool have = false;
+        { std::lock_guard<std::mutex> lk(g_cal_mu); have = g_cal_inverse.count(std::make_pair(op->device, 4096)) != 0; }
+        if (!have) for (int c : classes) (void)inverse_seconds_class(op, c);
+    }
+    int mc = 4096;
+    for (int c : classes) if (m <= c) { mc = c; break; }
+    const double t = inverse_seconds_class(op, mc);
+    const double r = (double)m / mc;
+    return t * r * r * r;
+}
+double inverse_seconds_class(helm_op *op, int m) {
     const int mc = std::max(32, std::min(m, 4096));
     double t = -1.0;
     {
@@ -1094,6 +1115,7 @@ int setup_keep(helm_op *op, Mg3Precond *P, int batch, int ncoarsen, double tauM)
     Mg3Keep *K = new Mg3Keep();
     P->keep = K;
     K->omega_l1 = envd("HELM_MG3_OMEGA_L1", 1.6);
+    K->device = op->device;
     std::complex<double> om(2.0 * M_PI * op->a_freq_re, 2.0 * M_PI * op->a_freq_im);
     om -= std::complex<double>(0.0, 1.0 / tauM);
     const double cpml = op->a_cpml;
@@ -1150,16 +1172,16 @@ int setup_keep(helm_op *op, Mg3Precond *P, int batch, int ncoarsen, double tauM)
         if (rc) HELM_FAIL(op, rc, "%s", helm_last_error(Lr.op));
         if (!level_vectors(op, Lr, batch)) HELM_FAIL(op, HELM_ERR_DEVICE, "3-D multigrid: level vectors do not fit");
         if (l == ncoarsen) break;
-        cplx *dl1 = nullptr;
-        if (hipMalloc((void **)&dl1, (size_t)Lr.N * sizeof(cplx)) != hipSuccess) HELM_FAIL(op, HELM_ERR_DEVICE, "3-D multigrid: level vectors do not fit");
-        K->dl1.push_back(dl1);
+        cplx *dl1 = (cplx *)helm_pool_alloc(op->device, (size_t)Lr.N * sizeof(cplx));
+        if (!dl1) HELM_FAIL(op, HELM_ERR_DEVICE, "3-D multigrid: level vectors do not fit");
+        K->dl1.push_back(dl1); K->dl1_bytes.push_back((size_t)Lr.N * sizeof(cplx));
         hipLaunchKernelGGL(k3_l1_dinv, dim3((unsigned)std::min<long long>((Lr.N + 255) / 256, 65535)), dim3(256), 0, op->stream, (const cplx *)Lr.op->d_C, dl1, Lr.N, K->omega_l1);
         // next level
         Ax3 cx[3];
         for (int a = 0; a < 3; ++a) {
             std::vector<PTab> pt; std::vector<RTab> rt;
             coarsen_axis(ax[a], true, cx[a], kept[a], pt, rt);
-            PTab *dp = upload(pt); RTab *dr = upload(rt);
+            PTab *dp = upload(K, pt); RTab *dr = upload(K, rt);
             K->pt[a].push_back(dp); K->rt[a].push_back(dr);
             if (!dp || !dr) HELM_FAIL(op, HELM_ERR_DEVICE, "3-D multigrid: transfer tables do not fit");
         }
@@ -1182,6 +1204,13 @@ int setup_keep(helm_op *op, Mg3Precond *P, int batch, int ncoarsen, double tauM)
 }
 
 }  // namespace
+
+// the hierarchy's level operators launch on the stream they were built on: point them at another one (helm_prefactor_n builds on a
+// low-priority stream, the solves run on the handle's own)
+void mg3_retarget_stream(helm_op *op, hipStream_t st) {
+    if (!op->mg3) return;
+    for (Mg3Level &L : op->mg3->lv) if (L.op) L.op->stream = st;
+}
 
 void mg3_destroy(helm_op *op) {
     Mg3Precond *P = op->mg3;
@@ -1212,14 +1241,14 @@ int mg3_setup(helm_op *op, int batch) {
     // 256 x 256 x 128, 40-100 points per wavelength: beta 0.6 / 3 / 6 / 12 -> 26 / 16 / 14 / 14 s per 4 sources at 3 Hz
     double cmin = 1e300;
     {
-        unsigned long long *dmin = (unsigned long long *)helm_pool_alloc(op->device, sizeof(unsigned long long));
+        unsigned long long *dmin = (unsigned long long *)helm_pool_alloc(op->device, 64);     // (64 bytes: the pool's smallest size class)
         unsigned long long hmin = ~0ULL;
         if (!dmin) HELM_FAIL(op, HELM_ERR_DEVICE, "3-D multigrid: scratch allocation failed");
         hipMemcpyAsync(dmin, &hmin, sizeof(hmin), hipMemcpyHostToDevice, op->stream);
         hipLaunchKernelGGL(k3_min_re, dim3(2048), dim3(256), 0, op->stream, (const cplx *)op->d_c, op->N, dmin);
         hipMemcpyAsync(&hmin, dmin, sizeof(hmin), hipMemcpyDeviceToHost, op->stream);
         HIP_TRY(op, hipStreamSynchronize(op->stream));
-        helm_pool_free(op->device, dmin, sizeof(unsigned long long));
+        helm_pool_free(op->device, dmin, 64);
         if (hmin != ~0ULL) { long long b = (long long)hmin; cmin = __builtin_bit_cast(double, b); }
     }
     const double hmax = std::max(op->dx, std::max(op->dy, op->dz));

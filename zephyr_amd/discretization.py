@@ -136,13 +136,15 @@ class BaseDiscretization(BaseModelDependent):
     def Ainv(self):
         return self.handle
 
-    def prefactor(self):
+    def prefactor(self, nrhs=None):
         """Start the factorisation the next solve on this operator needs and return at once (helm_prefactor): the launches go
         to a high-priority stream of the handle and run beside the solves of other operators.  The reference builds its LU
         lazily inside the first `Disc * rhs` (discretization.py:78-85); its dispatcher overlaps frequencies with a process
-        pool (distributors.py:161-168) -- `zephyr_amd.dispatch` does it with this call."""
-        if str(self.method).lower() in ('auto', 'direct'):
-            _lib.check(_lib.load().helm_prefactor(self.handle), self.handle)
+        pool (distributors.py:161-168) -- `zephyr_amd.dispatch` does it with this call.  3-D operators build their multigrid
+        hierarchy here, in the calling thread (helm_prefactor_n: `nrhs` = right-hand sides the solve will bring)."""
+        m = str(self.method).lower()
+        if m in ('auto', 'direct') or (m == 'mg' and getattr(self, 'ny', 0)):
+            _lib.check(_lib.load().helm_prefactor_n(self.handle, int(nrhs or 0)), self.handle)
 
     def reserve(self, nrhs, rows=None, concurrent=1):
         """Bring into being what `concurrent` host-array solves of `nrhs` right-hand sides on this operator's GPU take from the

@@ -135,8 +135,13 @@ class BaseMPDist(BaseDist):
     def _item(sub, r, throttle=None):
         prep = None
         if hasattr(sub, 'prefactor'):
+            ncol = int(r.shape[1]) if getattr(r, 'ndim', 1) > 1 else 1
+
             def prep():
-                sub.prefactor()           # builds the handle (assembly on the GPU) and enqueues the factorisation
+                try:
+                    sub.prefactor(ncol)   # builds the handle (assembly on the GPU) and enqueues the factorisation / builds the 3-D hierarchy
+                except TypeError:
+                    sub.prefactor()
 
         def solve(_prepared):
             if throttle is not None:
