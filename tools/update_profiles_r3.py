@@ -88,7 +88,7 @@ kept for the before / after comparison; their description is in the git history 
 
 | file | what |
 |---|---|
-| `r03_bench_n1.json` | `python bench.py` (default: {d['steps']} timed items after {d['warmup']} warm-up items, frequencies {', '.join('%g' % f for f in d['config']['freqs_hz_this_run'])} Hz): **{d['value']:.0f} wavefields/s**, {d['ms_per_step']:.1f} ms per item through the device pipeline with the per-launch HIP events on ({d['unprofiled']['value']:.0f} with them off); passes per wavefield {d['config']['solves_or_iterations_per_rhs_mean']:.2f}; `parity_vs_lu_max_rel` = {d['parity_vs_lu_max_rel']:.2e} (8 sources at 6 Hz against the SuperLU wavefields of the CPU leg).  `roofline` (kernel pass over the same items with nothing else on the GPU): all `k_zgemm2` launches, {R['achieved']:.1f} TFLOP/s = **{100 * R['frac']:.0f} %** of the 78.6 TFLOP/s nominal fp64 peak ({R['launches_timed']} launches, avg {R['avg_launch_us']:.0f} us; inside the pipelined region, where two streams share the CUs: {100 * R['in_pipeline']['frac']:.0f} %).  `stencil_roofline` / `roofline_northstar`: the node-major residual launches (`k_resid_nm_lds`), {St['achieved']:.0f} GB/s = **{100 * St['frac']:.0f} %** of 8 TB/s on N((32 + 16)B + 144) = {alg_resid / 1e9:.2f} GB (x and q in, the wavefield out), avg {St['avg_launch_us']:.0f} us; rhs-major apply microbenchmark {', '.join('%.0f' % (100 * m['frac_of_peak']) for m in St['apply_microbench'])} % at B = 1 / 8 / 32 / 64.  `value_host_api`: the whole job through `MultiFreq * q` with scipy-sparse sources in and numpy wavefields out, **{ha['value']:.0f} wavefields/s** ({ha['seconds']:.2f} s for 4096 wavefields, 4.3 GB per frequency over PCIe, {ha['workers_per_device']} workers per GPU; runs: {', '.join('%d worker(s): %.0f' % (r['workers_per_device'], r['value']) for r in d['value_host_api_runs'])}).  `config5`: {c5['job_seconds']:.2f} s for the 3-D job ({', '.join('%g Hz %.2f s / %d its' % (p['freq_hz'], p['seconds'], max(p['iterations'])) for p in c5['per_frequency'])}; 27-point apply {', '.join('%.0f' % (100 * a['frac_of_peak']) for a in c5['apply'])} % of 8 TB/s at B = 1 / 4 / 8 / 16).  CPU legs on the GPU box's own host (256 logical CPUs): 1 core, M1-only LU {cb['value']:.2f} wavefields/s (assemble {cb['assemble_s']:.1f} s, factor {cb['factor_s']:.1f} s, {cb['per_rhs_s']:.3f} s per source); the faithful 2N x 2N system at 512^2: {c2.get('value', float('nan')):.2f}; 16 processes, one per frequency: {cpool.get('value', float('nan')):.1f} |
+| `r03_bench_n1.json` | `python bench.py` (default: {d['steps']} timed items after {d['warmup']} warm-up items, frequencies {', '.join('%g' % f for f in d['config']['freqs_hz_this_run'])} Hz): **{d['value']:.0f} wavefields/s**, {d['ms_per_step']:.1f} ms per item through the device pipeline with the per-launch HIP events on ({d['unprofiled']['value']:.0f} with them off); passes per wavefield {d['config']['solves_or_iterations_per_rhs_mean']:.2f}; `parity_vs_lu_max_rel` = {d['parity_vs_lu_max_rel']:.2e} (8 sources at 6 Hz against the SuperLU wavefields of the CPU leg).  `roofline` (kernel pass over the same items with nothing else on the GPU): all `k_zgemm2` launches, {R['achieved']:.1f} TFLOP/s = **{100 * R['frac']:.0f} %** of the 78.6 TFLOP/s nominal fp64 peak ({R['launches_timed']} launches, avg {R['avg_launch_us']:.0f} us; inside the pipelined region, where two streams share the CUs: {100 * R['in_pipeline']['frac']:.0f} %).  `stencil_roofline` / `roofline_northstar`: the node-major residual launches (`k_resid_nm_lds`), {St['achieved']:.0f} GB/s = **{100 * St['frac']:.0f} %** of 8 TB/s on N((32 + 16)B + 144) = {alg_resid / 1e9:.2f} GB (x and q in, the wavefield out), avg {St['avg_launch_us']:.0f} us; rhs-major apply microbenchmark {', '.join('%.0f' % (100 * m['frac_of_peak']) for m in St['apply_microbench'])} % at B = 1 / 8 / 32 / 64.  `value_host_api`: the whole job through `MultiFreq * q` with scipy-sparse sources in and numpy wavefields out, **{ha['value']:.0f} wavefields/s** ({ha['seconds']:.2f} s for 4096 wavefields, 4.3 GB per frequency over PCIe, {ha['workers_per_device']} workers per GPU; runs: {', '.join('%d worker(s): %.0f' % (r['workers_per_device'], r['value']) for r in d['value_host_api_runs'])}).  `config5`: {c5['job_seconds']:.2f} s for the 3-D job through the device pipeline (set-up of frequency k+1 beside the iterations of frequency k; {c5.get('job_seconds_one_after_the_other', c5['job_seconds']):.2f} s one frequency after the other: {', '.join('%g Hz %.2f s / %d its' % (p['freq_hz'], p['seconds'], max(p['iterations'])) for p in c5['per_frequency'])}; 27-point apply {', '.join('%.0f' % (100 * a['frac_of_peak']) for a in c5['apply'])} % of 8 TB/s at B = 1 / 4 / 8 / 16).  CPU legs on the GPU box's own host (256 logical CPUs): 1 core, M1-only LU {cb['value']:.2f} wavefields/s (assemble {cb['assemble_s']:.1f} s, factor {cb['factor_s']:.1f} s, {cb['per_rhs_s']:.3f} s per source); the faithful 2N x 2N system at 512^2: {c2.get('value', float('nan')):.2f}; 16 processes, one per frequency: {cpool.get('value', float('nan')):.1f} |
 | `r03_bench_driver_cmd.json` | the driver's command line, `python bench.py --steps 20 --warmup 5 --no-cpu` (all 16 frequencies): **{dd['value']:.0f} wavefields/s**, {dd['ms_per_step']:.1f} ms per item ({dd['unprofiled']['value']:.0f} with the events off), passes per wavefield {dd['config']['solves_or_iterations_per_rhs_mean']:.2f}, `roofline.frac` {Rd['frac']:.3f}, `stencil_roofline.frac` {dd['stencil_roofline']['frac']:.3f} |
 | `r03_bench_serial_rocprofv3_kernel_stats.csv`, `r03_bench_serial_under_rocprofv3.json` | `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu --no-config5 --no-host-api --no-pipeline --steps 8 --warmup 2 --no-plain-pass`: the kernels with nothing else on the GPU -- the run `roofline` must agree with |
 | `r03_bench_pipelined_rocprofv3_kernel_stats.csv`, `r03_bench_pipelined_under_rocprofv3.json` | the same command without `--no-pipeline` ({dp['value']:.0f} wavefields/s under the profiler): durations stretched by the sharing |

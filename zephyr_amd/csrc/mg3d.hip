@@ -1198,7 +1198,9 @@ int setup_keep(helm_op *op, Mg3Precond *P, int batch, int ncoarsen, double tauM)
     }
     lap("Galerkin product");
     const Mg3Level &Ld = P->lv.back();
-    const int rcd = coarse_is_nd(Ld.nz, Ld.ny, Ld.nx) ? nd3_setup(op, K->nd, Ld, batch) : bt_setup(op, K->bt, Ld, batch);
+    int rcd = HELM_ERR_UNSUPPORTED;
+    if (coarse_is_nd(Ld.nz, Ld.ny, Ld.nx)) rcd = nd3_setup(op, K->nd, Ld, batch);
+    if (rcd == HELM_ERR_UNSUPPORTED) rcd = bt_setup(op, K->bt, Ld, batch);          // (also when the dissection's factors do not fit: the plane inverses are single precision)
     lap("direct solver of the last level");
     return rcd;
 }
