@@ -201,7 +201,7 @@ def config5_leg(local, rtol=1e-8, nsrc=16, freqs=(2., 3., 4., 5.), grid=(128, 25
         return o
 
     def solve(o):
-        marks.append(('solve starts', float(o.freq), time.perf_counter()))
+        marks.append(('solve starts', float(complex(o.freq).real), time.perf_counter()))
         try:
             o.solveDevice(Q.data_ptr(), U.data_ptr(), nsrc)
             st = 'ok'
@@ -209,11 +209,11 @@ def config5_leg(local, rtol=1e-8, nsrc=16, freqs=(2., 3., 4., 5.), grid=(128, 25
             st = str(e)
         its_ = [i['iterations'] for i in o.lastInfo]
         del o.factors
-        marks.append(('solve done', float(o.freq), time.perf_counter()))
+        marks.append(('solve done', float(complex(o.freq).real), time.perf_counter()))
         return st, its_
 
     def pipelined_job():
-        return list(dispatch.pipelined([dispatch.WorkItem(solve, (lambda f=f: prep(f))) for f in freqs], device=local, lookahead=1))
+        return list(dispatch.pipelined([dispatch.WorkItem(solve, (lambda f=f: prep(f))) for f in freqs], device=local, lookahead=1, strict=True))
     # untimed warm-up (the W of this leg): the job once through the pipeline brings the Krylov workspaces (23 GB per operator in flight), the factor
     # storage of the directly solved levels and the once-per-process calibrations of the depth model into being; everything goes back to the
     # library's pools before the clock starts

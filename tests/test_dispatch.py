@@ -179,3 +179,26 @@ def test_problem_work_items_cover_every_source_once(monkeypatch):
         # a rank that owns a subset of the frequencies (one process per GPU) keeps them on its own GPU
         devs1, items1 = prob._deviceItems([1], nsrc)
         assert sorted((c0, c1) for _, _, i, c0, c1 in items1 if i == 1)[0][0] == 0 and sum(c1 - c0 for _, _, _, c0, c1 in items1) == nsrc
+
+
+def test_strict_pipeline_prepares_exactly_one_item_ahead():
+    'strict=True: the preparation of item k+1 starts when the solve of item k starts, never earlier (3-D operators: heavy on the GPU and in memory)'
+    log = []
+
+    def make(k):
+        def prep():
+            log.append(('p0', k, time.perf_counter()))
+            time.sleep(0.02)
+            return k
+
+        def solve(p):
+            log.append(('s0', k, time.perf_counter()))
+            time.sleep(0.08)
+            log.append(('s1', k, time.perf_counter()))
+            return k
+        return dispatch.WorkItem(solve, prep)
+    assert list(dispatch.pipelined([make(k) for k in range(4)], device=0, lookahead=1, strict=True)) == [0, 1, 2, 3]
+    t = dict(((a, k), v) for a, k, v in log)
+    for k in range(1, 4):
+        assert t[('p0', k)] >= t[('s0', k - 1)] - 1e-3            # not before the previous item's solve has started
+        assert t[('p0', k)] < t[('s1', k - 1)]                    # but during it

@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/c5p
-for p in -1 0 -1 0; do
+for p in -1 -1 -1; do
 HELM_PF3_PRIO=$p timeout 900 python bench.py --no-cpu --no-host-api --steps 2 --warmup 1 > gpurun_out/c5p/p.json 2> gpurun_out/c5p/p.err
 python - <<PY
 import json

@@ -92,9 +92,10 @@ class WorkItem(object):
 class DevicePipeline(object):
     """Two threads for one GPU: items are prepared up to `lookahead` ahead of the one being solved."""
 
-    def __init__(self, device, lookahead=1):
+    def __init__(self, device, lookahead=1, strict=False):
         self.device = device
         self.lookahead = max(0, int(lookahead))
+        self.strict = bool(strict)
         self._threads = []
 
     def start(self, items):
@@ -108,8 +109,11 @@ class DevicePipeline(object):
             self._threads = [t]
             return
         ready = queue.Queue(maxsize=self.lookahead)
-        tp = threading.Thread(target=self._prepare_loop, args=(items, ready), name='helm-prep%d' % self.device)
-        ts = threading.Thread(target=self._solve_loop, args=(len(items), ready), name='helm-solve%d' % self.device)
+        # strict: item k+1 is prepared while item k is being solved and not before (a queue of one lets the prepare thread start on item k+2
+        # as soon as item k+1 waits in it) -- for operators whose preparation is heavy on the GPU and in memory (3-D preconditioners)
+        gate = threading.Semaphore(1) if self.strict else None
+        tp = threading.Thread(target=self._prepare_loop, args=(items, ready, gate), name='helm-prep%d' % self.device)
+        ts = threading.Thread(target=self._solve_loop, args=(len(items), ready, gate), name='helm-solve%d' % self.device)
         for t in (tp, ts):
             t.daemon = True
             t.start()
@@ -147,17 +151,22 @@ class DevicePipeline(object):
             self._run_prepare(item)
             self._run_solve(item)
 
-    def _prepare_loop(self, items, ready):
+    def _prepare_loop(self, items, ready, gate=None):
         for item in items:
+            if gate is not None:
+                gate.acquire()          # released when the solve of the previous item starts
             self._run_prepare(item)
             ready.put(item)             # blocks while `lookahead` prepared items are waiting
 
-    def _solve_loop(self, n, ready):
+    def _solve_loop(self, n, ready, gate=None):
         for _ in range(n):
-            self._run_solve(ready.get())
+            item = ready.get()
+            if gate is not None:
+                gate.release()
+            self._run_solve(item)
 
 
-def dispatch(workers, lookahead=1):
+def dispatch(workers, lookahead=1, strict=False):
     """Start one DevicePipeline per worker.  workers: [(device, [WorkItem, ...]), ...] (each list in the order it should run;
     the same device may appear twice: two pipelines then share that GPU).  Returns the pipelines (join() them, or just wait on
     the items' futures)."""
@@ -165,17 +174,17 @@ def dispatch(workers, lookahead=1):
         workers = list(workers.items())
     pipes = []
     for dev, items in workers:
-        p = DevicePipeline(dev, lookahead)
+        p = DevicePipeline(dev, lookahead, strict)
         p.start(items)
         pipes.append(p)
     return pipes
 
 
-def pipelined(items, device=0, lookahead=1):
+def pipelined(items, device=0, lookahead=1, strict=False):
     """Run `items` on one device with prepare-ahead and yield their results in order (exceptions surface where the
     failing item's result is consumed)."""
     items = list(items)
-    pipe = DevicePipeline(device, lookahead)
+    pipe = DevicePipeline(device, lookahead, strict)
     pipe.start(items)
     try:
         for item in items:

@@ -206,7 +206,8 @@ class BaseMPDist(BaseDist):
             owner = firsts[0].owner
             if hasattr(owner, 'reserve'):
                 owner.reserve(max(it.ncol for w, q in enumerate(queues) if workers[w] == dev for it in q), rows=firsts[0].nrow, concurrent=len(firsts))
-        self._pipes = dispatch.dispatch(list(zip(workers, queues)), lookahead=1)
+        # (3-D operators build their preconditioner in the prepare step: strictly one item ahead of the solve)
+        self._pipes = dispatch.dispatch(list(zip(workers, queues)), lookahead=1, strict=any(getattr(s_, 'ny', 0) for s_ in subs[:1]))
         self._throttles = throttles
 
         def results():
