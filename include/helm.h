@@ -175,7 +175,8 @@ void helm_host_free(void *p, size_t bytes);
  * LU lazily inside the first `Disc * rhs` (discretization.py:78-85) and overlaps frequencies with a process pool
  * (distributors.py:161-168). */
 int helm_prefactor(helm_op *op);
-/* The same with the number of right-hand sides the next solve will bring.  2-D: helm_prefactor.  3-D: the multigrid hierarchy and the
+/* The same with the number of right-hand sides the next solve will bring (the reference's pool hands a sub-problem its right-hand sides together
+ * with the job: distributors.py:161-166).  2-D: helm_prefactor.  3-D: the multigrid hierarchy and the
  * factorisation of its directly solved level are built NOW, in the calling thread (hundreds of ms): a dispatcher's prepare thread calls this
  * for frequency k+1 while another handle iterates on frequency k.  A hint like helm_prefactor. */
 int helm_prefactor_n(helm_op *op, int nrhs);
