@@ -22,7 +22,9 @@ def crand(rng, *shape):
 
 @pytest.mark.parametrize('M,N,K,batch', [(64, 64, 8, 1), (36, 256, 64, 7), (1, 1, 1, 3), (65, 67, 9, 2), (130, 33, 71, 3), (9, 256, 9, 40),
                                          # tall-and-skinny products (<= 16 columns, long inner dimension): the streaming kernel of the 3-D coarse solve
-                                         (100, 16, 500, 3), (8, 16, 384, 1), (893, 16, 2900, 2), (37, 5, 1000, 2), (64, 1, 2000, 1), (13, 9, 447, 4)])
+                                         (100, 16, 500, 3), (8, 16, 384, 1), (893, 16, 2900, 2), (37, 5, 1000, 2), (64, 1, 2000, 1), (13, 9, 447, 4),
+                                         # ... and few enough of them that the inner dimension is split over workgroups (chunks that do not divide it, an empty last chunk)
+                                         (300, 16, 1027, 1), (1900, 16, 3001, 2), (129, 7, 1024, 5), (40, 16, 1032, 9)])
 def test_batched_zgemm(helm_lib, M, N, K, batch):
     rng = np.random.default_rng(M * 7 + N)
     A, B, C = crand(rng, batch, M, K), crand(rng, batch, K, N), crand(rng, batch, M, N)

@@ -323,6 +323,8 @@ struct GemmRows {
     int fwd3 = 0;         // forward-gather mode (k_zgemm2<.., 2, ..>): Bx = right-hand sides, Cix = front-vector arena, Cox = where y_S goes
     int zr0 = 0, zr1 = 0, zc0 = 0, zc1 = 0;   // rows [zr0, zr1) and columns [zc0, zc1) of C are taken as zero on input (beta masked): blocked Gauss-Jordan
     int sk0 = 0, sk1 = 0;                     // the diagonal block [sk0, sk1)^2 of C is neither read nor written (the next pivot block, owned by k_gj_pivot)
+    int ksplit = 0, kc = 0; long long pstride = 0;   // split over the inner dimension (dense operands only): z = matrix * ksplit + chunk; chunk c multiplies columns
+                                              // [c kc, (c + 1) kc) of A into its own partial product at C0 + c pstride + matrix sc (k_splitk_reduce adds them up)
     int dense = 0;                            // only the masks above are in use: launch the plain (un-indexed) kernel
     const cplx *Bx2 = nullptr; int k2 = 0;    // rows k < k2 of an indexed B come from Bx2 instead of Bx (a leaf's y_S is still in the right-hand sides)
     int tm64 = 0;                             // one 64-row tile per matrix (M <= 64): C may then overwrite B (every workgroup has read all of its B columns
@@ -469,9 +471,17 @@ __device__ __forceinline__ void zgemm2_body(int M, int Nn, int K, cplx alpha, co
     cplx (&Bs)[2][KS][TN] = *reinterpret_cast<cplx (*)[2][KS][TN]>(lds_b);
     __shared__ int kidx[IDX == 1 ? GB_KIDX : 1];
     __shared__ int4 kidx4[IDX == 2 ? GB_KIDX : 1];
-    const cplx *A = A0 + (long long)blockIdx.z * sa;
-    const cplx *B = B0 + (long long)blockIdx.z * sb;
-    cplx *C = C0 + (long long)blockIdx.z * sc;
+    int zb = blockIdx.z;
+    if (IDX == 0 && R.ksplit > 1) {                      // this workgroup's share of the inner dimension
+        const int kch = zb % R.ksplit;
+        zb /= R.ksplit;
+        const int kbeg = kch * R.kc;
+        A0 += kbeg; B0 += (long long)kbeg * ldb; C0 += (long long)kch * R.pstride;
+        K = K - kbeg < R.kc ? (K - kbeg > 0 ? K - kbeg : 0) : R.kc;
+    }
+    const cplx *A = A0 + (long long)zb * sa;
+    const cplx *B = B0 + (long long)zb * sb;
+    cplx *C = C0 + (long long)zb * sc;
     const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
     const int tid = threadIdx.x, ty = tid / TXN, tx = tid % TXN;
     const long long trow = IDX ? (long long)(R.z0 + blockIdx.z) * R.tab_stride : 0;
@@ -1590,6 +1600,22 @@ __global__ void k_axpy_one(cplx *y, const cplx *x, long long n, int conj) {
 
 int g_gemm_variant = -1;        // >= 0: overrides HELM_ND_GEMMV (helm_debug_zgemm_bench)
 int g_gemm_tile = -1;           // >= 0: forces the tile configuration (helm_debug_zgemm_bench)
+// C = beta C + alpha (sum of the ksplit partial products of a split launch); parts: [chunk][matrix][M x Nn]
+__global__ __launch_bounds__(256) void k_splitk_reduce(const cplx *__restrict__ parts, int ksplit, long long pstride, int M, int Nn, cplx alpha, cplx beta,
+                                                       cplx *__restrict__ C, int ldc, long long sc, long long total) {
+    const bool rd = !(beta.x == 0.0 && beta.y == 0.0);
+    const long long per = (long long)M * Nn;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        cplx sum = parts[e];
+        for (int k = 1; k < ksplit; ++k) sum = cadd(sum, parts[(long long)k * pstride + e]);
+        const long long b = e / per, rem = e - b * per;
+        cplx *dst = C + b * sc + (rem / Nn) * ldc + rem % Nn;
+        cplx o = cmul(alpha, sum);
+        if (rd) o = cadd(o, cmul(beta, *dst));
+        *dst = o;
+    }
+}
+
 // What one GEMM launch has to move at the very least -- every operand once: A (M x K), B (K x N), C written (and read when beta != 0) -- and the
 // time the part's two roofs allow it: max(flops / 78.6 TFLOP/s, bytes / 8 TB/s).  The thin fronts low in the tree are HBM-bound products
 // (a level-13 front multiplies a 48 x 8 block into 256 right-hand sides: 1.6 flop per byte), the big ones fp64-bound; the bench adds both up.
@@ -1626,6 +1652,34 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
     }
     if (e0) hipEventRecord(e0, st);
     if (in_run && e0) { op->gemm_run_pair = (int)op->ev_used; op->ev_used += 2; }
+    // Products with at most 16 columns over a few big matrices (the top of the 3-D coarse level's passes: 16 right-hand sides through fronts of
+    // thousands of unknowns) fill a few dozen 128 x 16 tiles: the inner dimension is split over up to 16 workgroups per tile, each writes its
+    // partial product to the handle's scratch and a small launch adds them up (with alpha / beta applied there).
+    static const int splitk = getenv("HELM_ND_SPLITK") ? atoi(getenv("HELM_ND_SPLITK")) : 1;
+    bool split_done = false;
+    if (splitk && op && !rows && !ext && Nn <= 16 && K >= 1024 && gemm_variant() != 0 && batch <= 64) {
+        const long long tiles = (long long)batch * ((M + 127) / 128);
+        static const int sk_tiles = getenv("HELM_ND_SPLITK_TILES") ? atoi(getenv("HELM_ND_SPLITK_TILES")) : 300;
+        static const int sk_wgs = getenv("HELM_ND_SPLITK_WGS") ? atoi(getenv("HELM_ND_SPLITK_WGS")) : 768;      // (measured on the 47 x 79 x 79 level: 96 / 192 -> 5.8 ms per coarse solve, 300 / 768 -> 5.0, more changes nothing)
+        if (tiles < sk_tiles) {
+            const int ks = (int)std::min<long long>(16, std::max<long long>(2, sk_wgs / tiles));
+            const int kc = (((K + ks - 1) / ks) + 7) & ~7;
+            const long long per = (long long)batch * M * Nn;
+            const size_t need = (size_t)ks * per * sizeof(cplx);
+            if (op->sk_bytes < need) {
+                if (op->sk_buf) { hipStreamSynchronize(st); helm_pool_free(op->device, op->sk_buf, op->sk_bytes); op->sk_buf = nullptr; op->sk_bytes = 0; }
+                op->sk_buf = (cplx *)helm_pool_alloc(op->device, need);
+                op->sk_bytes = op->sk_buf ? need : 0;
+            }
+            if (op->sk_buf) {
+                GemmRows R; R.dense = 1; R.ksplit = ks; R.kc = kc; R.pstride = per;
+                launch_vec2<128, 2, 8, 1, 1>(st, 0, batch * ks, M, Nn, K, cmake(1, 0), A, lda, sa, B, ldb, sb, cmake(0, 0), op->sk_buf, Nn, (long long)M * Nn, R);
+                hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)std::min<long long>((per + 255) / 256, 4096)), dim3(256), 0, st, (const cplx *)op->sk_buf, ks, per, M, Nn, alpha, beta,
+                                   C, ldc, sc, per);
+                split_done = true;
+            }
+        }
+    }
     static const int fixed_tm = getenv("HELM_ND_TM") ? atoi(getenv("HELM_ND_TM")) : 0;
     // tile of the vector kernel: 4 x RN outputs per thread, TM x TN = TM x (1024 / TM * RN).  The padded area is weighed by how
     // well a register block re-uses its LDS reads (4 x 4: 1, 4 x 2: 0.7, 4 x 1: 0.45): narrow tiles only win on small outputs
@@ -1665,7 +1719,7 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
     // the fused update + sweep launch exists for two tiles: 64 x 32 (large matrices) and the 32 x 32 latency tile (under-filled launches)
     if (rows && rows->la) { vsel = latency_mode ? 6 : 3; }
     if (rows && rows->tm64 && M <= 64) { vsel = Nn <= 32 ? 3 : 0; latency_mode = false; }
-    for (int b0 = 0; b0 < batch; b0 += 65535) {
+    for (int b0 = 0; b0 < batch && !split_done; b0 += 65535) {
         const int nb = std::min(65535, batch - b0);
         GemmRows R; if (rows) R = *rows;
         R.z0 = b0;
@@ -2634,10 +2688,14 @@ extern "C" int helm_debug_zgemm(int device, int M, int Nn, int K, const double *
     const size_t na = (size_t)batch * M * K, nb = (size_t)batch * K * Nn, nc = (size_t)batch * M * Nn;
     if (hipMalloc((void **)&dA, na * 16) != hipSuccess || hipMalloc((void **)&dB, nb * 16) != hipSuccess || hipMalloc((void **)&dC, nc * 16) != hipSuccess) return HELM_ERR_DEVICE;
     hipMemcpy(dA, A, na * 16, hipMemcpyHostToDevice); hipMemcpy(dB, B, nb * 16, hipMemcpyHostToDevice); hipMemcpy(dC, C, nc * 16, hipMemcpyHostToDevice);
-    gemm((helm_op *)nullptr, M, Nn, K, cmake(alpha[0], alpha[1]), dA, K, (long long)M * K, dB, Nn, (long long)K * Nn, cmake(beta[0], beta[1]), dC, Nn, (long long)M * Nn, batch);
+    // (with a handle, like the solver's own calls: the paths that keep scratch on it -- the split over the inner dimension -- are taken too)
+    const int fs[4] = {0, 0, 0, 0};
+    helm_op *tmp = helm_create(device, 0, 8, 8, 1.0, 1.0, 2, fs);
+    gemm(tmp, M, Nn, K, cmake(alpha[0], alpha[1]), dA, K, (long long)M * K, dB, Nn, (long long)K * Nn, cmake(beta[0], beta[1]), dC, Nn, (long long)M * Nn, batch);
     hipError_t e = hipDeviceSynchronize();
     hipMemcpy(C, dC, nc * 16, hipMemcpyDeviceToHost);
     hipFree(dA); hipFree(dB); hipFree(dC);
+    if (tmp) helm_destroy(tmp);
     return e == hipSuccess ? HELM_OK : HELM_ERR_DEVICE;
 }
 
