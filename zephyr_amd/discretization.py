@@ -143,7 +143,7 @@ class BaseDiscretization(BaseModelDependent):
         pool (distributors.py:161-168) -- `zephyr_amd.dispatch` does it with this call.  3-D operators build their multigrid
         hierarchy here, in the calling thread (helm_prefactor_n: `nrhs` = right-hand sides the solve will bring)."""
         m = str(self.method).lower()
-        if m in ('auto', 'direct') or (m == 'mg' and getattr(self, 'ny', 0)):
+        if m in ('auto', 'direct') or (m == 'mg' and getattr(self, 'heavyPrepare', False)):
             _lib.check(_lib.load().helm_prefactor_n(self.handle, int(nrhs or 0)), self.handle)
 
     def reserve(self, nrhs, rows=None, concurrent=1):

@@ -207,7 +207,7 @@ class BaseMPDist(BaseDist):
             if hasattr(owner, 'reserve'):
                 owner.reserve(max(it.ncol for w, q in enumerate(queues) if workers[w] == dev for it in q), rows=firsts[0].nrow, concurrent=len(firsts))
         # (3-D operators build their preconditioner in the prepare step: strictly one item ahead of the solve)
-        self._pipes = dispatch.dispatch(list(zip(workers, queues)), lookahead=1, strict=any(getattr(s_, 'ny', 0) for s_ in subs[:1]))
+        self._pipes = dispatch.dispatch(list(zip(workers, queues)), lookahead=1, strict=any(getattr(s_, 'heavyPrepare', False) for s_ in subs[:1]))
         self._throttles = throttles
 
         def results():

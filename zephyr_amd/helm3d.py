@@ -5,7 +5,8 @@ zephyr/backend/source.py:43-44 raises NotImplementedError), so there is no class
 follows the same `systemConfig` contract as the 2-D discretisations (keys nx, ny, nz, dx, dy, dz, c, rho,
 freq, tau, premul, nPML, cPML) and the same result convention conj(A^-1 (premul rhs)).  The operator is
 defined in oracle/helm3d_oracle.py (trilinear-element-weighted 27-point star, C-PML on all six faces).
-Solves use the Jacobi-preconditioned BiCGSTAB / CGNR of libhelm.
+Solves: BiCGSTAB right-preconditioned by the layer-preserving 3-D multigrid of libhelm (mg3d.hip) whose coarsest level is solved directly;
+Jacobi-preconditioned BiCGSTAB / CGNR on request.
 """
 import ctypes
 import numpy as np
@@ -16,6 +17,8 @@ from .discretization import BaseDiscretization
 
 
 class Helm3D(BaseDiscretization):
+
+    heavyPrepare = True          # the prepare step builds the multigrid preconditioner (helm_prefactor_n): dispatchers keep strictly one item ahead
 
     VARIANT = _lib.HELM_3D
 
