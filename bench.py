@@ -385,21 +385,25 @@ def main():
     ops = {}
 
     stamps = []                          # completion time of every work item (diagnostics: `item_done_ms` of the timed region)
+    tl = []                              # (what, item, time) marks of the prepare / solve steps (`first_items_timeline_ms`)
 
     def prepare_item(w, profile):
         'create the operator of work item w, assemble it on the GPU (inside the timed region) and start its factorisation'
         fi, bi = work_item(w, nb)
+        tl.append(('prepare starts', w, time.perf_counter()))
         sc = dict(cfg)
         sc.update(freq=float(freqs[fi]), rtol=args.rtol, maxit=400000, method=args.method, batch=B, device=local)
         op = Eurus(sc)
         op.setProfiling(profile and os.environ.get('HELM_BENCH_NOPROFILE', '0') != '1')
         if args.pipeline:
             op.prefactor()               # launches only: the factorisation runs beside the solves of the previous item
+        tl.append(('prepare done', w, time.perf_counter()))
         return op
 
     def solve_item(w, op, ubuf=None):
         ubuf = d_u if ubuf is None else ubuf
         fi, bi = work_item(w, nb)
+        tl.append(('solve starts', w, time.perf_counter()))
         rhs_ptr = d_rhs.data_ptr() + (0 if node else bi * B * N * 16)
         info = op.solveDevice(rhs_ptr, ubuf.data_ptr(), B, N, layout='node' if node else 'rhs')
         t = op.lastTiming()
@@ -417,7 +421,7 @@ def main():
             return [run_item(w, profile) for w in ws]
         from zephyr_amd import dispatch
         items = [dispatch.WorkItem((lambda op, w=w: solve_item(w, op)), (lambda w=w: prepare_item(w, profile))) for w in ws]
-        return list(dispatch.pipelined(items, device=local, lookahead=1))
+        return list(dispatch.pipelined(items, device=local, lookahead=int(os.environ.get('HELM_BENCH_LOOKAHEAD', '1')), strict=os.environ.get('HELM_BENCH_STRICT', '0') == '1'))
 
     def barrier():
         torch.cuda.synchronize()
@@ -437,6 +441,7 @@ def main():
 
     barrier()
     del stamps[:]
+    del tl[:]
     t0 = time.perf_counter()
     results = [None] * len(timed_items)
     if args.streams <= 1:
@@ -473,6 +478,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     item_done_ms = [round(1e3 * (x - t0), 2) for x in stamps]
+    first_items = [(a, int(w_), round(1e3 * (t_ - t0), 2)) for a, w_, t_ in sorted(tl, key=lambda m: m[2])][:12]
 
     def max_over_ranks(x):
         if world == 1:
@@ -554,7 +560,7 @@ def main():
             'timed_region': 'K work items through the device pipeline with per-launch HIP events on; `unprofiled` repeats the same K items with the events off',
             'pipeline': ('device pipeline of zephyr_amd.dispatch (MultiFreq parallel mode): item k+1 is created, assembled and its factorisation enqueued '
                          '(helm_prefactor, high-priority stream) while item k is being solved' if args.pipeline else 'off: items strictly one after the other'),
-            'item_done_ms': item_done_ms,
+            'item_done_ms': item_done_ms, 'first_items_timeline_ms': first_items,
             'unprofiled': None if elapsed_plain is None else {'value': wavefields / elapsed_plain, 'ms_per_step': 1e3 * elapsed_plain / nsteps},
             'config': {'workload': 'Eurus 2D isotropic %dx%d synthetic-Marmousi (seed 20240512, dx=%g m), 16 freqs 2-9.5 Hz x 256 Kaiser sources; '
                                    'step = create + assemble 1 frequency + solve %d sources to true relres<=%g (method=%s: %s)' % (n, n, dx, B, args.rtol, args.method, how),
