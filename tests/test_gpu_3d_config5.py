@@ -21,11 +21,14 @@ def nrm(a, b):
     return np.linalg.norm(a - b) / np.linalg.norm(b)
 
 
-def test_config5_grid_one_frequency_properties(helm_lib):
-    """256 x 256 x 128, c = 2000 m/s, h = 10 m, 4 Hz, two sources (the depth model then puts the directly solved level one coarsening
-    deeper, at 6 points per wavelength, with the Galerkin operator -- the branch behind the config-5 job time): the returned fields
-    satisfy the operator through the independent apply entry point, and the solve is conj-linear."""
+@pytest.mark.parametrize('coarse', ['nd', 'bt'])
+def test_config5_grid_one_frequency_properties(helm_lib, monkeypatch, coarse):
+    """256 x 256 x 128, c = 2000 m/s, h = 10 m, 4 Hz, two sources, with either direct solver of the coarsest kept level (the column
+    dissection keeps the 8-points level: 47 x 79 x 79, 14 GB of factors; the plane-by-plane elimination goes one coarsening deeper for two
+    sources, to 6 points per wavelength with the Galerkin operator): the returned fields satisfy the operator through the independent apply
+    entry point, and the solve is conj-linear."""
     import zephyr_amd as za
+    monkeypatch.setenv('HELM_MG3_COARSE', coarse)
     nz, ny, nx, f = 128, 256, 256, 4.
     cfg = dict(nx=nx, ny=ny, nz=nz, dx=10., c=2000., rho=1., freq=f, nPML=10, rtol=1e-8, maxit=60000, method='auto', batch=2)
     N = nz * ny * nx
