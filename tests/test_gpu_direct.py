@@ -24,7 +24,9 @@ def crand(rng, *shape):
                                          # tall-and-skinny products (<= 16 columns, long inner dimension): the streaming kernel of the 3-D coarse solve
                                          (100, 16, 500, 3), (8, 16, 384, 1), (893, 16, 2900, 2), (37, 5, 1000, 2), (64, 1, 2000, 1), (13, 9, 447, 4),
                                          # ... and few enough of them that the inner dimension is split over workgroups (chunks that do not divide it, an empty last chunk)
-                                         (300, 16, 1027, 1), (1900, 16, 3001, 2), (129, 7, 1024, 5), (40, 16, 1032, 9)])
+                                         (300, 16, 1027, 1), (1900, 16, 3001, 2), (129, 7, 1024, 5), (40, 16, 1032, 9),
+                                         # 49-row fronts (the leaves): three blocks of 16 rows on the matrix cores + one row on the vector ALUs
+                                         (49, 256, 81, 5), (49, 64, 49, 3), (49, 100, 7, 2), (49, 300, 83, 2), (49, 32, 49, 4)])
 def test_batched_zgemm(helm_lib, M, N, K, batch):
     rng = np.random.default_rng(M * 7 + N)
     A, B, C = crand(rng, batch, M, K), crand(rng, batch, K, N), crand(rng, batch, M, N)

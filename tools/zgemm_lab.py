@@ -8,6 +8,7 @@ from zephyr_amd import _lib
 lib = _lib.load()
 
 SHAPES = [  # (label, M, N, K, batch)
+    ('real leaf bwd', 49, 256, 81, 16129), ('real leaf fwd', 32, 256, 49, 16129), ('real leaf G21', 32, 49, 49, 16129), ('real leaf G', 49, 32, 49, 16129),
     ('leaf fwd   G21 x', 32, 256, 64, 16384), ('leaf bwd   F12 x', 64, 256, 32, 16384), ('leaf bwd   F11i t', 64, 256, 64, 16384),
     ('s8  fwd', 48, 256, 8, 8192), ('s8  bwd', 8, 256, 48, 8192),
     ('s16 fwd', 64, 256, 16, 4096), ('s16 bwd', 16, 256, 64, 4096),
@@ -19,12 +20,16 @@ SHAPES = [  # (label, M, N, K, batch)
     ('top inv 512^3 x1', 512, 512, 512, 1), ('top inv 256^3 x2', 256, 256, 256, 2), ('inv 128^3 x8', 128, 128, 128, 8),
     ('inv 64^3 x16', 64, 64, 64, 16), ('inv 32^3 x4', 32, 32, 32, 4),
 ]
-variants = [int(v) for v in (sys.argv[1].split(',') if len(sys.argv) > 1 else '0,1,6'.split(','))]
+variants = [int(v) for v in (sys.argv[1].split(',') if len(sys.argv) > 1 else '1,7'.split(','))]
+only = sys.argv[2] if len(sys.argv) > 2 else ''      # substring filter on the shape label
+maxreps = int(sys.argv[3]) if len(sys.argv) > 3 else 50
 rows = []
 print('%-22s %6s %5s %5s %6s | ' % ('shape', 'M', 'N', 'K', 'batch') + ' '.join('v%d TF/s (us)   ' % v for v in variants))
 for label, M, N, K, b in SHAPES:
+    if only and only not in label:
+        continue
     fl = 8.0 * M * N * K * b
-    reps = max(3, min(50, int(2e11 / fl)))
+    reps = max(1, min(maxreps, int(2e11 / fl)))
     cells = []
     for v in variants:
         ms = ctypes.c_double(0)

@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void k_zgemm(int M, int Nn, int K, cplx alpha,
 }
 
 template <int TM, int RN = 4>
-void launch_vec(hipStream_t st, bool idx, int nb, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, long long sa, const cplx *B, int ldb, long long sb,
+void launch_vec(hipStream_t st, int idx, int nb, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, long long sa, const cplx *B, int ldb, long long sb,
                 cplx beta, cplx *C, int ldc, long long sc, const GemmRows &R) {
     constexpr int TN = (1024 / TM) * RN;
     dim3 grid((Nn + TN - 1) / TN, (M + TM - 1) / TM, nb);
@@ -647,6 +647,286 @@ void launch_vec2(hipStream_t st, int idx, int nb, int M, int Nn, int K, cplx alp
     else if (idx == 2) ZG_LAUNCH((k_zgemm2<TM, 2, RN, KS, UNR, OCC>), grid, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
     else if (idx) ZG_LAUNCH((k_zgemm2<TM, 1, RN, KS, UNR, OCC>), grid, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
     else ZG_LAUNCH((k_zgemm2<TM, 0, RN, KS, UNR, OCC>), grid, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
+}
+
+// ---- third-generation tile kernel: the same products on the matrix cores (v_mfma_f64_16x16x4_f64) -----------------------
+// Round 4.  tools/fp64_clock.hip with the occupancy pinned (profiles/r04_fp64_clock_probe.txt) settled what the fp64 units give: the
+// vector FMAs of the 4 x 4 complex register block saturate at 55-56 TFLOP/s at 2, 4 and 8 waves per SIMD (the chip holds 2.04-2.09 GHz
+// under that load), whereas v_mfma_f64_16x16x4_f64 runs at 77.8 TFLOP/s = 99 % of nominal from two waves per SIMD up at 2.38 GHz, 73.4
+// in the complex product's own mix of 16 MFMAs on 8 rotating operand registers.  (Rounds 2 and 3 measured 35-47 for the MFMA and
+// concluded it could not win: that was one wave per SIMD under __launch_bounds__(256), where hipcc parks the accumulators in AGPRs
+// and copies them around every instruction.)  One MFMA replaces 16 vector FMAs per lane-pair of operands, so the inner loop issues
+// (MT + NT) 16-byte LDS reads for 4 MT NT matrix instructions of 64 cycles each: LDS and VALU issue are out of the picture.
+//   tile      256 threads = WM x WN waves; a wave owns MT x NT blocks of 16 x 16 outputs, real and imaginary accumulators apart
+//             (C = (Ar Br - Ai Bi) + i (Ar Bi + Ai Br): four real MFMAs per block and k step of 4, -Ai formed once per fragment)
+//   LDS       fragment-ordered: every (k group of 4, 16-row block of A | 16-column block of B) is one 1-KB run that a wave reads with
+//             lane l at offset 16 l -- conflict-free by construction -- A[row l & 15][k l >> 4], B[k l >> 4][col l & 15].  The B
+//             fragment IS a row-major 4 x 16 piece of B.  A arrives k-contiguous (8 lanes = 8 k of one row): its slot inside the
+//             fragment is XOR-swizzled with (k & 3) ^ 4 (k / 4 & 1) so that those 8 lanes hit 8 different 16-byte bank groups on the
+//             store and the 16-lane groups of ds_read_b128 still cover all 64 banks on the load.
+//   C / D     lane l holds rows (l >> 4) + 4 q, q = 0..3, of column l & 15: a store is four 256-byte row segments.
+// Addressing modes (IDX), masks, split-K and the fused gathers are those of zgemm2_body, operand for operand.
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+// XR = 1 (WM == 1 only): the tile has ONE more row than its 16 MT rows of matrix-core blocks -- row 16 MT goes through the vector ALUs, which the
+// MFMA loop leaves idle (thread = column x share of the k range, partial sums added up through LDS at the end).  98 % of the leaves of a 2^k grid
+// have 49 = 3 x 16 + 1 unknowns: a fourth block of 16 rows for the 49th would spend a quarter of the leaf level's matrix instructions on padding.
+template <int WM, int WN, int MT, int NT, int IDX, int KS, int XR = 0>
+__device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, const cplx *A0, int lda, long long sa,
+                                            const cplx *B0, int ldb, long long sb, cplx beta, cplx *C0, int ldc, long long sc, const GemmRows &R,
+                                            cplx *lds) {
+    static_assert(WM * WN == 4 && KS % 4 == 0, "four waves per workgroup, k groups of 4");
+    static_assert(!XR || (WM == 1 && (IDX == 0 || IDX == 1)), "the extra row needs all four waves side by side and plain / row-table addressing");
+    constexpr int TMM = 16 * MT * WM;                                   // rows on the matrix cores
+    constexpr int TM = TMM + (XR ? 1 : 0), TN = 16 * NT * WN;           // rows / columns of C per workgroup
+    constexpr int FA = TMM / 16 + (XR ? 1 : 0), FB = TN / 16, KG = KS / 4;
+    constexpr int NA = (FA * 16 * KS + 255) / 256, NB = (TN * KS + 255) / 256;
+    constexpr int XP = 256 / TN;                                        // (XR) shares of the k range
+    constexpr int ABUF = KG * FA * 64, BBUF = KG * FB * 64;           // elements per buffer
+    cplx *As = lds, *Bs = lds + 2 * ABUF;
+    __shared__ int kidx[IDX == 1 ? GB_KIDX : 1];
+    __shared__ int4 kidx4[IDX == 2 ? GB_KIDX : 1];
+    int zb = blockIdx.z;
+    if (IDX == 0 && R.ksplit > 1) {                      // this workgroup's share of the inner dimension
+        const int kch = zb % R.ksplit;
+        zb /= R.ksplit;
+        const int kbeg = kch * R.kc;
+        A0 += kbeg; B0 += (long long)kbeg * ldb; C0 += (long long)kch * R.pstride;
+        K = K - kbeg < R.kc ? (K - kbeg > 0 ? K - kbeg : 0) : R.kc;
+    }
+    const cplx *A = A0 + (long long)zb * sa;
+    const cplx *B = B0 + (long long)zb * sb;
+    cplx *C = C0 + (long long)zb * sc;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave / WN, wn = wave % WN, lr = lane & 15, lq = lane >> 4;
+    const long long trow = IDX ? (long long)(R.z0 + blockIdx.z) * R.tab_stride : 0;
+    const bool idxB = IDX == 1 && R.tabB != nullptr;
+    if (idxB) {
+        for (int k = tid; k < K; k += 256) kidx[k] = R.tabB[trow + R.offB + k].x;
+        __syncthreads();
+    }
+    if (IDX == 2) {
+        for (int k = tid; k < K; k += 256) kidx4[k] = R.tabB[trow + R.offB + k];
+        __syncthreads();
+    }
+    __shared__ int2 sgr[IDX == 4 ? TM : 1], sgc[IDX == 4 ? TN : 1];
+    const cplx *S0 = nullptr, *S1 = nullptr;
+    int ld0 = 0, ld1 = 0;
+    if (IDX == 4) {
+        const NdDev nd = R.nodes[R.first + R.z0 + blockIdx.z];
+        int base0 = 0, base1 = 0;
+        if (nd.kid[0] >= 0) { const NdDev c0 = R.nodes[nd.kid[0]]; S0 = R.arenaS + c0.foff + c0.smax; ld0 = c0.smax + c0.mmax; base0 = (int)(c0.voff + c0.smax); }
+        if (nd.kid[1] >= 0) { const NdDev c1 = R.nodes[nd.kid[1]]; S1 = R.arenaS + c1.foff + c1.smax; ld1 = c1.smax + c1.mmax; base1 = (int)(c1.voff + c1.smax); }
+        for (int t = tid; t < TM + TN; t += 256) {
+            const int q = t < TM ? m0 + t : n0 + (t - TM);
+            int2 e = make_int2(-1, -1);
+            if (q < (t < TM ? M : Nn)) {
+                const int4 t4 = R.tabCi[trow + nd.smax + q];
+                if (t4.y >= 0 && S0) e.x = t4.y - base0;
+                if (t4.z >= 0 && S1) e.y = t4.z - base1;
+            }
+            if (t < TM) sgr[t] = e; else sgc[t - TM] = e;
+        }
+        __syncthreads();
+    }
+    v4f64 cr[MT][NT], ci[MT][NT];
+    #pragma unroll
+    for (int i = 0; i < MT; ++i)
+        #pragma unroll
+        for (int j = 0; j < NT; ++j) { cr[i][j] = (v4f64){0, 0, 0, 0}; ci[i][j] = (v4f64){0, 0, 0, 0}; }
+    cplx xacc = cmake(0.0, 0.0);                                       // (XR) this thread's share of row TMM, column tid % TN
+    const int xc = tid % TN, xh = tid / TN;
+    cplx ra[NA], rb[NB];
+    auto fetch = [&](int k0) {
+        #pragma unroll
+        for (int e = 0; e < NA; ++e) {
+            const int idx = tid + e * 256;
+            const int ar = idx / KS, ak = idx % KS;
+            cplx v = cmake(0.0, 0.0);
+            if (idx < FA * 16 * KS && ar < TM && m0 + ar < M && k0 + ak < K) v = A[(long long)(m0 + ar) * lda + k0 + ak];
+            ra[e] = v;
+        }
+        #pragma unroll
+        for (int e = 0; e < NB; ++e) {
+            const int idx = tid + e * 256;
+            const int bk = idx / TN, bc = idx % TN;
+            cplx v = cmake(0.0, 0.0);
+            if (idx < TN * KS && k0 + bk < K && n0 + bc < Nn) {
+                if (IDX == 2) {
+                    const int4 t4 = kidx4[k0 + bk];
+                    if (t4.w) v = R.Bx[(long long)t4.x * R.ldx + n0 + bc];
+                    if (t4.y >= 0) v = cadd(v, R.Cix[(long long)t4.y * R.ldx + n0 + bc]);
+                    if (t4.z >= 0) v = cadd(v, R.Cix[(long long)t4.z * R.ldx + n0 + bc]);
+                    if (blockIdx.y == 0 && t4.w && R.Cox) R.Cox[(long long)t4.x * R.ldx + n0 + bc] = v;      // y_S
+                }
+                else if (idxB) { const int r = kidx[k0 + bk]; if (r >= 0) v = (k0 + bk < R.k2 ? R.Bx2 : R.Bx)[(long long)r * R.ldx + n0 + bc]; }
+                else v = B[(long long)(k0 + bk) * ldb + n0 + bc];
+            }
+            rb[e] = v;
+        }
+    };
+    auto stash = [&](int buf) {
+        #pragma unroll
+        for (int e = 0; e < NA; ++e) {
+            const int idx = tid + e * 256;
+            const int ar = idx / KS, ak = idx % KS;
+            if (idx < FA * 16 * KS) As[buf * ABUF + ((ak >> 2) * FA + (ar >> 4)) * 64 + (ak & 3) * 16 + ((ar & 15) ^ (ak & 3) ^ (((ak >> 2) & 1) << 2))] = ra[e];
+        }
+        #pragma unroll
+        for (int e = 0; e < NB; ++e) {
+            const int idx = tid + e * 256;
+            const int bk = idx / TN, bc = idx % TN;
+            if (idx < TN * KS) Bs[buf * BBUF + ((bk >> 2) * FB + (bc >> 4)) * 64 + (bk & 3) * 16 + (bc & 15)] = rb[e];
+        }
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = 0; k0 < K; k0 += KS) {
+        const bool more = k0 + KS < K;
+        if (more) fetch(k0 + KS);
+        #pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+            if (KG > 1 && k0 + 4 * kg >= K) break;                  // (a k group that is all padding)
+            cplx a[MT], b[NT];
+            #pragma unroll
+            for (int i = 0; i < MT; ++i) a[i] = As[cur * ABUF + (kg * FA + wm * MT + i) * 64 + lq * 16 + (lr ^ lq ^ ((kg & 1) << 2))];
+            #pragma unroll
+            for (int j = 0; j < NT; ++j) b[j] = Bs[cur * BBUF + (kg * FB + wn * NT + j) * 64 + lane];
+            #pragma unroll
+            for (int i = 0; i < MT; ++i)
+                #pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    cr[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, cr[i][j], 0, 0, 0);
+                    ci[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].y, ci[i][j], 0, 0, 0);
+                }
+            #pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const double nai = -a[i].y;
+                #pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    cr[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, b[j].y, cr[i][j], 0, 0, 0);
+                    ci[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].x, ci[i][j], 0, 0, 0);
+                }
+            }
+        }
+        if (XR) {
+            #pragma unroll
+            for (int kk = 0; kk < KS / XP; ++kk) {
+                const int k = kk * XP + xh;                            // k of the slab
+                const int kg = k >> 2, kq = k & 3;
+                const cplx av = As[cur * ABUF + (kg * FA + FA - 1) * 64 + kq * 16 + (kq ^ ((kg & 1) << 2))];
+                const cplx bv = Bs[cur * BBUF + (kg * FB + (xc >> 4)) * 64 + kq * 16 + (xc & 15)];
+                cfma(xacc, av, bv);
+            }
+        }
+        if (more) { stash(cur ^ 1); __syncthreads(); cur ^= 1; }
+    }
+    const bool b0 = (beta.x == 0.0 && beta.y == 0.0);
+    #pragma unroll
+    for (int i = 0; i < MT; ++i)
+        #pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = m0 + (wm * MT + i) * 16 + lq + 4 * q;
+            if (r >= M) continue;
+            cplx *dst = C + (long long)r * ldc;
+            const cplx *cin = dst;
+            const cplx *cin2 = nullptr;
+            if (IDX == 2) {
+                const int4 t4 = R.tabCi[trow + R.offCi + r];
+                cin = t4.y >= 0 ? R.Cix + (long long)t4.y * R.ldx : nullptr;
+                cin2 = t4.z >= 0 ? R.Cix + (long long)t4.z * R.ldx : nullptr;
+            }
+            if (IDX == 1 && R.tabCo) {
+                const int ix = R.tabCo[trow + R.offCo + r].x;
+                if (ix < 0) continue;
+                dst = R.Cox + (long long)ix * R.ldx;
+            }
+            if (IDX == 1 && R.tabCi && !b0) {
+                const int ix = R.tabCi[trow + R.offCi + r].x;
+                cin = ix >= 0 ? R.Cix + (long long)ix * R.ldx : nullptr;
+            }
+            const bool zrow = r >= R.zr0 && r < R.zr1;
+            const bool srow = r >= R.sk0 && r < R.sk1;
+            #pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int cc = n0 + (wn * NT + j) * 16 + lr;
+                if (cc >= Nn) continue;
+                if (srow && cc >= R.sk0 && cc < R.sk1) continue;
+                cplx v = cmul(alpha, cmake(cr[i][j][q], ci[i][j][q]));
+                if (IDX == 4) {
+                    const int2 er = sgr[r - m0], ec = sgc[cc - n0];
+                    cplx c = cmake(0.0, 0.0);
+                    if (er.x >= 0 && ec.x >= 0) c = S0[(long long)er.x * ld0 + ec.x];
+                    if (er.y >= 0 && ec.y >= 0) c = cadd(c, S1[(long long)er.y * ld1 + ec.y]);
+                    v = cadd(c, v);
+                }
+                else if (IDX == 2) {
+                    cplx c = cin ? cin[cc] : cmake(0.0, 0.0);
+                    if (cin2) c = cadd(c, cin2[cc]);
+                    v = cadd(v, cmul(beta, c));
+                }
+                else if (!b0 && cin && !zrow && !(cc >= R.zc0 && cc < R.zc1)) v = cadd(v, cmul(beta, cin[cc]));
+                dst[cc] = v;
+            }
+        }
+    if (XR) {
+        __syncthreads();                                               // every wave is done with the operand tiles: their LDS holds the partial sums now
+        cplx *part = lds;
+        if (xh > 0) part[(xh - 1) * TN + xc] = xacc;
+        __syncthreads();
+        const int r = m0 + TMM, cc = n0 + xc;
+        if (xh == 0 && r < M && cc < Nn) {
+            #pragma unroll
+            for (int h = 1; h < XP; ++h) xacc = cadd(xacc, part[(h - 1) * TN + xc]);
+            cplx *dst = C + (long long)r * ldc;
+            const cplx *cin = dst;
+            bool keep = true;
+            if (IDX == 1 && R.tabCo) {
+                const int ix = R.tabCo[trow + R.offCo + r].x;
+                keep = ix >= 0;
+                dst = R.Cox + (long long)(ix >= 0 ? ix : 0) * R.ldx;
+            }
+            if (IDX == 1 && R.tabCi && !b0) {
+                const int ix = R.tabCi[trow + R.offCi + r].x;
+                cin = ix >= 0 ? R.Cix + (long long)ix * R.ldx : nullptr;
+            }
+            if (keep) {
+                cplx v = cmul(alpha, xacc);
+                if (!b0 && cin) v = cadd(v, cmul(beta, cin[cc]));
+                dst[cc] = v;
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int MT, int NT, int IDX, int KS, int OCC, int XR = 0>
+__global__ __launch_bounds__(256, OCC) void k_zgemm3(int M, int Nn, int K, cplx alpha, const cplx *A0, int lda, long long sa,
+                                                     const cplx *B0, int ldb, long long sb, cplx beta, cplx *C0, int ldc, long long sc, GemmRows R) {
+    __shared__ cplx tiles[2 * (KS / 4) * (MT * WM + XR + NT * WN) * 64];
+    zgemm3_body<WM, WN, MT, NT, IDX, KS, XR>(M, Nn, K, alpha, A0, lda, sa, B0, ldb, sb, beta, C0, ldc, sc, R, tiles);
+}
+
+// the 16 MT + 1-row tile (XR) for dense and row-table operands
+template <int MT, int NT, int KS, int OCC = 2>
+void launch_mfma_xr(hipStream_t st, int idx, int nb, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, long long sa, const cplx *B, int ldb, long long sb,
+                    cplx beta, cplx *C, int ldc, long long sc, const GemmRows &R) {
+    constexpr int TM = 16 * MT + 1, TN = 16 * NT * 4;
+    dim3 grid((Nn + TN - 1) / TN, (M + TM - 1) / TM, nb);
+    if (idx) ZG_LAUNCH((k_zgemm3<1, 4, MT, NT, 1, KS, OCC, 1>), grid, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
+    else ZG_LAUNCH((k_zgemm3<1, 4, MT, NT, 0, KS, OCC, 1>), grid, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
+}
+
+template <int WM, int WN, int MT, int NT, int KS, int OCC = 2>
+void launch_mfma(hipStream_t st, int idx, int nb, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, long long sa, const cplx *B, int ldb, long long sb,
+                 cplx beta, cplx *C, int ldc, long long sc, const GemmRows &R) {
+    constexpr int TM = 16 * MT * WM, TN = 16 * NT * WN;
+    dim3 grid((Nn + TN - 1) / TN, (M + TM - 1) / TM, nb);
+    if (idx == 4) ZG_LAUNCH((k_zgemm3<WM, WN, MT, NT, 4, KS, OCC>), grid, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
+    else if (idx == 2) ZG_LAUNCH((k_zgemm3<WM, WN, MT, NT, 2, KS, OCC>), grid, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
+    else if (idx) ZG_LAUNCH((k_zgemm3<WM, WN, MT, NT, 1, KS, OCC>), grid, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
+    else ZG_LAUNCH((k_zgemm3<WM, WN, MT, NT, 0, KS, OCC>), grid, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
 }
 
 #define GJ_MAX 64
@@ -1053,6 +1333,21 @@ __global__ __launch_bounds__(256) void k_zgemm2_la(int M, int Nn, int K, cplx al
     }
     zgemm2_body<TM, 0, RN, KS, UNR>(M, Nn, K, alpha, A0 - sa, lda, sa, B0 - sb, ldb, sb, beta, C0 - sc, ldc, sc, R,
                                   reinterpret_cast<cplx *>(lds), reinterpret_cast<cplx *>(lds + ABYTES));     // (its batch index is blockIdx.z - 1)
+}
+
+// the same fused launch with the matrix-core tile body (generation 7)
+template <int WM, int WN, int MT, int NT, int KS>
+__global__ __launch_bounds__(256, 2) void k_zgemm3_la(int M, int Nn, int K, cplx alpha, const cplx *A0, int lda, long long sa,
+                                                      const cplx *B0, int ldb, long long sb, cplx beta, cplx *C0, int ldc, long long sc, GemmRows R, GjPivotArgs pv) {
+    constexpr int TBYTES = 2 * (KS / 4) * (MT * WM + NT * WN) * 64 * (int)sizeof(cplx);
+    constexpr int LDS = TBYTES > GJ_PIVOT_LDS ? TBYTES : GJ_PIVOT_LDS;
+    __shared__ __attribute__((aligned(16))) char lds[LDS];
+    if (blockIdx.z == 0) {
+        const int mat = blockIdx.y * gridDim.x + blockIdx.x;
+        if (mat < pv.batch) gj_pivot_body(pv.T0, pv.ld, pv.stride, pv.n, pv.k0, pv.nb, pv.Wc0, pv.Wr0, pv.wstride, pv.Pb0, pv.pstride, mat, lds);
+        return;
+    }
+    zgemm3_body<WM, WN, MT, NT, 0, KS>(M, Nn, K, alpha, A0 - sa, lda, sa, B0 - sb, ldb, sb, beta, C0 - sc, ldc, sc, R, reinterpret_cast<cplx *>(lds));
 }
 
 __global__ __launch_bounds__(256) void k_gj_slices(const cplx *T0, int ld, long long stride, int n, int k0, int nb, cplx *Wc0, cplx *Wr0, long long wstride,
@@ -1630,7 +1925,8 @@ int gemm_variant() {
     // tiles.  Measured and dropped (profiles/r02_zgemm_lab_variants.txt): K slab 16 (occupancy 2), k loop unrolled twice (+1-2 %, 166 VGPRs),
     // a 4-waves-per-SIMD register budget (spills), and a 3M complex product (48 FMAs for 64 per k step but 192 VGPRs and twelve more LDS
     // reads: 3 % SLOWER on the large shapes, and its rounding pushed two more of the 16 bench frequencies over rtol into a second pass)
-    static const int gemm_v = getenv("HELM_ND_GEMMV") ? atoi(getenv("HELM_ND_GEMMV")) : 1;
+    // 7 (round 4, the default): the matrix-core kernel k_zgemm3 (v_mfma_f64_16x16x4_f64) -- 1.2-1.4 x the vector kernel on every compute-bound shape
+    static const int gemm_v = getenv("HELM_ND_GEMMV") ? atoi(getenv("HELM_ND_GEMMV")) : 7;
     return g_gemm_variant >= 0 ? g_gemm_variant : gemm_v;
 }
 
@@ -1673,7 +1969,8 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
             }
             if (op->sk_buf) {
                 GemmRows R; R.dense = 1; R.ksplit = ks; R.kc = kc; R.pstride = per;
-                launch_vec2<128, 2, 8, 1, 1>(st, 0, batch * ks, M, Nn, K, cmake(1, 0), A, lda, sa, B, ldb, sb, cmake(0, 0), op->sk_buf, Nn, (long long)M * Nn, R);
+                if (gemm_variant() == 7) launch_mfma<4, 1, 2, 1, 8>(st, 0, batch * ks, M, Nn, K, cmake(1, 0), A, lda, sa, B, ldb, sb, cmake(0, 0), op->sk_buf, Nn, (long long)M * Nn, R);
+                else launch_vec2<128, 2, 8, 1, 1>(st, 0, batch * ks, M, Nn, K, cmake(1, 0), A, lda, sa, B, ldb, sb, cmake(0, 0), op->sk_buf, Nn, (long long)M * Nn, R);
                 hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)std::min<long long>((per + 255) / 256, 4096)), dim3(256), 0, st, (const cplx *)op->sk_buf, ks, per, M, Nn, alpha, beta,
                                    C, ldc, sc, per);
                 split_done = true;
@@ -1749,13 +2046,42 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
             case 0: launch_vec<TM_, RN_>(ZG_ARGS); break; \
             case 6: launch_vec2<TM_, RN_, (RN_ == 1 ? 32 : (RN_ == 2 ? 16 : 8)), 1, 1>(ZG_ARGS); break; \
             default: launch_vec2<TM_, RN_, 8, 1, 1>(ZG_ARGS); break; } } while (0)
+        // matrix-core kernel (generation 7): the same nine tile shapes as WM x WN waves of MT x NT blocks of 16 x 16
+#define ZG_MFMA(WM_, WN_, MT_, NT_, KS_) launch_mfma<WM_, WN_, MT_, NT_, KS_>(ZG_ARGS)
+        if (gv == 7 && !(rows && rows->la)) {
+            // fronts of 16 a + 1 rows (the 49-unknown leaves): a rows of blocks on the matrix cores, the last row on the vector ALUs
+            static const int xr_on = getenv("HELM_ND_XR") ? atoi(getenv("HELM_ND_XR")) : 1;
+            const int idxmode = rows && rows->schur4 ? 4 : (rows && !rows->dense ? (rows->fwd3 ? 2 : 1) : 0);
+            const bool plain = !rows || (!rows->schur4 && !rows->fwd3 && !rows->ksplit && rows->zr1 == 0 && rows->zc1 == 0 && rows->sk1 == 0);
+            if (xr_on && M == 49 && Nn >= 64 && plain && idxmode <= 1 && g_gemm_tile < 0) {
+                static const int xr_nt = getenv("HELM_ND_XR_NT") ? atoi(getenv("HELM_ND_XR_NT")) : 2;
+                if (xr_nt == 2 && (Nn % 128 == 0 || Nn > 192)) launch_mfma_xr<3, 2, 8>(ZG_ARGS); else launch_mfma_xr<3, 1, 8>(ZG_ARGS);
+                continue;
+            }
+            if (latency_mode) { if (vsel == 6) ZG_MFMA(2, 2, 1, 1, 16); else ZG_MFMA(1, 4, 1, 1, 16); continue; }
+            switch (vsel) {
+                case 0: ZG_MFMA(2, 2, 2, 2, 8); break;
+                case 1: ZG_MFMA(1, 4, 2, 2, 8); break;
+                case 2: ZG_MFMA(1, 4, 1, 4, 8); break;
+                case 3: ZG_MFMA(2, 2, 2, 1, 8); break;
+                case 4: ZG_MFMA(2, 2, 1, 2, 8); break;
+                case 5: ZG_MFMA(1, 4, 1, 2, 8); break;
+                case 6: ZG_MFMA(2, 2, 1, 1, 8); break;
+                case 8: ZG_MFMA(4, 1, 2, 1, 8); break;
+                default: ZG_MFMA(1, 4, 1, 1, 8); break;
+            }
+            continue;
+        }
+#undef ZG_MFMA
         if (rows && rows->la && gv != 0) {           // update + pivot sweep of the next block in one launch
             if (latency_mode) {
                 dim3 grid((Nn + 31) / 32, (M + 31) / 32, nb + 1);
-                ZG_LAUNCH((k_zgemm2_la<32, 1, 32, 4>), grid, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R, *rows->la);
+                if (gv == 7) ZG_LAUNCH((k_zgemm3_la<2, 2, 1, 1, 16>), grid, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R, *rows->la);
+                else ZG_LAUNCH((k_zgemm2_la<32, 1, 32, 4>), grid, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R, *rows->la);
             } else {
                 dim3 grid((Nn + 31) / 32, (M + 63) / 64, nb + 1);
-                ZG_LAUNCH((k_zgemm2_la<64, 2, 8, 1>), grid, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R, *rows->la);
+                if (gv == 7) ZG_LAUNCH((k_zgemm3_la<2, 2, 2, 1, 8>), grid, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R, *rows->la);
+                else ZG_LAUNCH((k_zgemm2_la<64, 2, 8, 1>), grid, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R, *rows->la);
             }
             continue;
         }
