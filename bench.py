@@ -753,7 +753,7 @@ def main():
                    'config5_apply_frac_B16': next((a.get('frac_of_peak') for a in (c5.get('apply') or []) if a.get('B') == 16), None) if c5 else None,
                    'parity_vs_lu_max_rel': out.get('parity_vs_lu_max_rel'),
                    'cpu_baseline_value': out['cpu_baseline'].get('value') if isinstance(out.get('cpu_baseline'), dict) else None}
-            out['config']['driver_visible'] = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in vis.items()}
+            out['config']['driver_visible'] = {k: (float('%.5g' % v) if isinstance(v, float) else v) for k, v in vis.items()}
         except Exception as exc:
             out['config']['driver_visible'] = 'failed: %s' % exc
         print(json.dumps(out), flush=True)

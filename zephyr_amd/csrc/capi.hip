@@ -437,7 +437,7 @@ static void timing_begin(helm_op *op) {
     if (!op->pf_pending) {       // (the launches of a factorisation started by helm_prefactor are booked with the solve that uses it)
         op->ev_used = 0;
         op->ev_pending.clear();
-        op->ev_pending_gemm.clear(); op->ev_pending_gemm_n.clear(); op->ev_pending_gemm_bytes.clear(); op->ev_pending_gemm_sol.clear();
+        op->ev_pending_gemm.clear(); op->ev_pending_gemm_n.clear(); op->ev_pending_gemm_bytes.clear(); op->ev_pending_gemm_sol.clear(); op->ev_pending_gemm_shape.clear();
     }
     op->timing.apply_ms = 0; op->timing.apply_launches = 0; op->timing.apply_bytes = 0;
     op->timing.factor_ms = 0; op->timing.gemm_ms = 0; op->timing.gemm_launches = 0; op->timing.gemm_flops = 0; op->timing.gemm_bytes = 0; op->timing.gemm_sol_ms = 0;
@@ -451,17 +451,23 @@ static void timing_collect(helm_op *op) {
         }
     }
     op->ev_pending.clear();
+    static const int gemm_log = getenv("HELM_GEMM_LOG") ? atoi(getenv("HELM_GEMM_LOG")) : 0;
     for (size_t i = 0; i < op->ev_pending_gemm.size(); ++i) {
         const std::pair<int, double> &pr = op->ev_pending_gemm[i];
         const int nl = i < op->ev_pending_gemm_n.size() ? op->ev_pending_gemm_n[i] : 1;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, op->ev_pool[pr.first], op->ev_pool[pr.first + 1]) == hipSuccess) {
+            if (gemm_log && 5 * i + 4 < op->ev_pending_gemm_shape.size()) {
+                const long long *sh = &op->ev_pending_gemm_shape[5 * i];
+                fprintf(stderr, "[gemm log] M %lld N %lld K %lld batch %lld mode %lld : %.1f us, %.2f TFLOP/s, %.0f GB/s of operands\n", sh[0], sh[1], sh[2], sh[3], sh[4],
+                        1e3 * ms, pr.second / (ms * 1e-3) / 1e12, (i < op->ev_pending_gemm_bytes.size() ? op->ev_pending_gemm_bytes[i] : 0.0) / (ms * 1e-3) / 1e9);
+            }
             op->timing.gemm_ms += ms; op->timing.gemm_launches += nl; op->timing.gemm_flops += pr.second;
             if (i < op->ev_pending_gemm_bytes.size()) { op->timing.gemm_bytes += op->ev_pending_gemm_bytes[i]; op->timing.gemm_sol_ms += op->ev_pending_gemm_sol[i]; }
             if (pr.second >= 1e9 * nl) { op->timing.gemm_big_ms += ms; op->timing.gemm_big_launches += nl; op->timing.gemm_big_flops += pr.second; }
         }
     }
-    op->ev_pending_gemm.clear(); op->ev_pending_gemm_n.clear(); op->ev_pending_gemm_bytes.clear(); op->ev_pending_gemm_sol.clear();
+    op->ev_pending_gemm.clear(); op->ev_pending_gemm_n.clear(); op->ev_pending_gemm_bytes.clear(); op->ev_pending_gemm_sol.clear(); op->ev_pending_gemm_shape.clear();
     op->ev_used = 0;
 }
 
@@ -1484,7 +1490,7 @@ extern "C" int helm_prefactor(helm_op *op) {
     const size_t wsb = (size_t)nd_factor_ws_elems(f->pd->plan) * sizeof(cplx);
     void *ws = helm_pool_alloc(op->device, wsb);
     if (!ws) { nd_free(f); HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: cannot allocate %.1f GB of factorisation scratch", wsb / 1e9); }
-    { op->ev_used = 0; op->ev_pending.clear(); op->ev_pending_gemm.clear(); op->ev_pending_gemm_n.clear(); op->ev_pending_gemm_bytes.clear(); op->ev_pending_gemm_sol.clear(); }
+    { op->ev_used = 0; op->ev_pending.clear(); op->ev_pending_gemm.clear(); op->ev_pending_gemm_n.clear(); op->ev_pending_gemm_bytes.clear(); op->ev_pending_gemm_sol.clear(); op->ev_pending_gemm_shape.clear(); }
     hipStream_t main = op->stream;
     op->stream = op->fstream;                    // (the assembled planes are complete: helm_assemble synchronises)
     hipEventRecord(op->pf_t0, op->fstream);

@@ -667,6 +667,7 @@ void launch_vec2(hipStream_t st, int idx, int nb, int M, int Nn, int K, cplx alp
 //   C / D     lane l holds rows (l >> 4) + 4 q, q = 0..3, of column l & 15: a store is four 256-byte row segments.
 // Addressing modes (IDX), masks, split-K and the fused gathers are those of zgemm2_body, operand for operand.
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+__device__ cplx g_zero_page[4];       // 64 bytes of zeros: what masked lanes load instead of branching around a load
 // XR = 1 (WM == 1 only): the tile has ONE more row than its 16 MT rows of matrix-core blocks -- row 16 MT goes through the vector ALUs, which the
 // MFMA loop leaves idle (thread = column x share of the k range, partial sums added up through LDS at the end).  98 % of the leaves of a 2^k grid
 // have 49 = 3 x 16 + 1 unknowns: a fourth block of 16 rows for the 49th would spend a quarter of the leaf level's matrix instructions on padding.
@@ -824,53 +825,78 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
         if (more) { stash(cur ^ 1); __syncthreads(); cur ^= 1; }
     }
     const bool b0 = (beta.x == 0.0 && beta.y == 0.0);
+    // Epilogue, one block row of 16 at a time: first the addresses of its four rows (row-table look-ups), then EVERY value of C that has to be
+    // read (beta != 0, the forward gather's child rows, the Schur gather's child entries) with the loads issued back to back -- masked elements
+    // read a zero page instead of being branched around (a per-element `if (...) load` made hipcc wait vmcnt(0) after each one: up to 16
+    // dependent round trips per thread) -- then the arithmetic and the stores.
     #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MT; ++i) {
+        cplx *dstq[4];
+        const cplx *cinq[4], *cin2q[4];
+        int2 erq[4];
+        bool rowok[4];
         #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = m0 + (wm * MT + i) * 16 + lq + 4 * q;
-            if (r >= M) continue;
-            cplx *dst = C + (long long)r * ldc;
-            const cplx *cin = dst;
-            const cplx *cin2 = nullptr;
+            rowok[q] = r < M;
+            const int rr = rowok[q] ? r : m0;                              // (a valid row for the look-ups of a masked one)
+            cplx *dst = C + (long long)rr * ldc;
+            const cplx *cin = dst, *cin2 = nullptr;
             if (IDX == 2) {
-                const int4 t4 = R.tabCi[trow + R.offCi + r];
+                const int4 t4 = R.tabCi[trow + R.offCi + rr];
                 cin = t4.y >= 0 ? R.Cix + (long long)t4.y * R.ldx : nullptr;
                 cin2 = t4.z >= 0 ? R.Cix + (long long)t4.z * R.ldx : nullptr;
             }
             if (IDX == 1 && R.tabCo) {
-                const int ix = R.tabCo[trow + R.offCo + r].x;
-                if (ix < 0) continue;
-                dst = R.Cox + (long long)ix * R.ldx;
+                const int ix = R.tabCo[trow + R.offCo + rr].x;
+                if (ix < 0) rowok[q] = false;
+                dst = R.Cox + (long long)(ix >= 0 ? ix : 0) * R.ldx;
             }
             if (IDX == 1 && R.tabCi && !b0) {
-                const int ix = R.tabCi[trow + R.offCi + r].x;
+                const int ix = R.tabCi[trow + R.offCi + rr].x;
                 cin = ix >= 0 ? R.Cix + (long long)ix * R.ldx : nullptr;
             }
-            const bool zrow = r >= R.zr0 && r < R.zr1;
+            if (IDX == 4) erq[q] = sgr[rr - m0];
+            if ((IDX == 0 || IDX == 1) && (b0 || (rr >= R.zr0 && rr < R.zr1))) cin = nullptr;
+            dstq[q] = dst; cinq[q] = cin; cin2q[q] = cin2;
+        }
+        cplx cv[4][NT];
+        #pragma unroll
+        for (int q = 0; q < 4; ++q)
+            #pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int cc = n0 + (wn * NT + j) * 16 + lr;
+                const bool ok = rowok[q] && cc < Nn;
+                if (IDX == 4) {
+                    const int2 ec = sgc[cc < Nn ? cc - n0 : 0];
+                    const cplx *p0 = (ok && erq[q].x >= 0 && ec.x >= 0) ? S0 + (long long)erq[q].x * ld0 + ec.x : g_zero_page;
+                    const cplx *p1 = (ok && erq[q].y >= 0 && ec.y >= 0) ? S1 + (long long)erq[q].y * ld1 + ec.y : g_zero_page;
+                    cv[q][j] = cadd(*p0, *p1);
+                } else if (IDX == 2) {
+                    const cplx *p0 = (ok && cinq[q]) ? cinq[q] + cc : g_zero_page;
+                    const cplx *p1 = (ok && cin2q[q]) ? cin2q[q] + cc : g_zero_page;
+                    cv[q][j] = cadd(*p0, *p1);
+                } else {
+                    const cplx *p0 = (ok && cinq[q] && !(cc >= R.zc0 && cc < R.zc1)) ? cinq[q] + cc : g_zero_page;
+                    cv[q][j] = *p0;
+                }
+            }
+        #pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = m0 + (wm * MT + i) * 16 + lq + 4 * q;
             const bool srow = r >= R.sk0 && r < R.sk1;
             #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int cc = n0 + (wn * NT + j) * 16 + lr;
-                if (cc >= Nn) continue;
+                if (!rowok[q] || cc >= Nn) continue;
                 if (srow && cc >= R.sk0 && cc < R.sk1) continue;
                 cplx v = cmul(alpha, cmake(cr[i][j][q], ci[i][j][q]));
-                if (IDX == 4) {
-                    const int2 er = sgr[r - m0], ec = sgc[cc - n0];
-                    cplx c = cmake(0.0, 0.0);
-                    if (er.x >= 0 && ec.x >= 0) c = S0[(long long)er.x * ld0 + ec.x];
-                    if (er.y >= 0 && ec.y >= 0) c = cadd(c, S1[(long long)er.y * ld1 + ec.y]);
-                    v = cadd(c, v);
-                }
-                else if (IDX == 2) {
-                    cplx c = cin ? cin[cc] : cmake(0.0, 0.0);
-                    if (cin2) c = cadd(c, cin2[cc]);
-                    v = cadd(v, cmul(beta, c));
-                }
-                else if (!b0 && cin && !zrow && !(cc >= R.zc0 && cc < R.zc1)) v = cadd(v, cmul(beta, cin[cc]));
-                dst[cc] = v;
+                if (IDX == 4) v = cadd(cv[q][j], v);
+                else v = cadd(v, cmul(beta, cv[q][j]));
+                dstq[q][cc] = v;
             }
         }
+    }
     if (XR) {
         __syncthreads();                                               // every wave is done with the operand tiles: their LDS holds the partial sums now
         cplx *part = lds;
@@ -908,6 +934,12 @@ __global__ __launch_bounds__(256, OCC) void k_zgemm3(int M, int Nn, int K, cplx 
     zgemm3_body<WM, WN, MT, NT, IDX, KS, XR>(M, Nn, K, alpha, A0, lda, sa, B0, ldb, sb, beta, C0, ldc, sc, R, tiles);
 }
 
+// (Round 4, measured and removed: the same kernel with LDS-DMA staging -- global_load_lds_dwordx4 writing each 1-KB fragment straight into a
+// three- or four-stage LDS ring, counted vmcnt, one raw barrier per slab, every LDS read of the loop in inline asm because hipcc makes any
+// ds_read it can see wait vmcnt(0) while a DMA is in flight.  Correct on the product shapes, and 3-8 % SLOWER than the register-staged
+// kernel above on every shape of tools/zgemm_lab.py (leaf back substitution 2989 against 2839 us, 1024 x 1024 x 256 x 16: 619 against 597 us,
+// under-filled 1025 x 256 x 512 x 4: 164 against 163 us): at 3-4 workgroups per CU the other workgroups already cover a slab's load latency, and
+// the DMA's per-fragment address arithmetic costs what the staging registers did.  profiles/r04_zgemm_lab_mfma.txt keeps the table.)
 // the 16 MT + 1-row tile (XR) for dense and row-table operands
 template <int MT, int NT, int KS, int OCC = 2>
 void launch_mfma_xr(hipStream_t st, int idx, int nb, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, long long sa, const cplx *B, int ldb, long long sb,
@@ -2025,8 +2057,8 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
         // (a 4 x 8 register block per thread -- RN = 8, 64 x 128 tile -- was measured too: 230 VGPRs, occupancy 2, 38 % slower)
         const int gv = gemm_variant();
         struct ExtArm {            // arms the per-launch event pair for the launchers below, books it when the launch is out
-            helm_op *op; bool on; double fl, by;
-            ExtArm(helm_op *o, bool e, double f, double b) : op(o), on(false), fl(f), by(b) {
+            helm_op *op; bool on; double fl, by; long long shape[5];
+            ExtArm(helm_op *o, bool e, double f, double b, int m_, int n_, int k_, int nb_, int mode_) : op(o), on(false), fl(f), by(b), shape{m_, n_, k_, nb_, mode_} {
                 if (!e) return;
                 if (op->ev_used + 2 > op->ev_pool.size() && op->ev_pool.size() < 16384) (void)helm_events_grow(op, 64);
                 if (op->ev_used + 2 <= op->ev_pool.size()) { tl_ev0 = op->ev_pool[op->ev_used]; tl_ev1 = op->ev_pool[op->ev_used + 1]; on = true; }
@@ -2037,10 +2069,12 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
                 op->ev_pending_gemm_n.push_back(1);
                 op->ev_pending_gemm_bytes.push_back(by);
                 op->ev_pending_gemm_sol.push_back(gemm_sol_ms(fl, by));
+                for (int q = 0; q < 5; ++q) op->ev_pending_gemm_shape.push_back(shape[q]);
                 op->ev_used += 2;
                 tl_ev0 = tl_ev1 = nullptr;
             }
-        } arm(op, ext, 8.0 * M * (double)Nn * K * nb, gemm_operand_bytes(M, Nn, K, beta) * nb);
+        } arm(op, ext, 8.0 * M * (double)Nn * K * nb, gemm_operand_bytes(M, Nn, K, beta) * nb, M, Nn, K, nb,
+              rows && rows->schur4 ? 4 : (rows && !rows->dense ? (rows->fwd3 ? 2 : 1) : (rows && rows->la ? 5 : 0)));
 #define ZG_ARGS st, (rows && rows->schur4 ? 4 : (rows && !rows->dense ? (rows->fwd3 ? 2 : 1) : 0)), nb, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R
 #define ZG_VEC(TM_, RN_) do { switch (gv) { \
             case 0: launch_vec<TM_, RN_>(ZG_ARGS); break; \
