@@ -232,6 +232,23 @@ int helm_sample_device(helm_op *op, const void *dU, int nsrc, long long ld, cons
 /* Free the scratch memory the library keeps between calls (the direct path's shared workspace, tens of GB at
  * 1024^2 x 256 right-hand sides).  HELM_ERR_STATE while a solve is using it. */
 int helm_trim(void);
+/* Only the pinned host buffers the library holds idle (results of helm_solve / helm_solve_coo and helm_host_alloc memory that was
+ * handed back): the idle pool is capped by bytes (HELM_HOSTPOOL_GB, default a quarter of the host's memory, at most 96 GB); helm_trim
+ * calls this too.  Counterpart of dropping the reference's result arrays (discretization.py:101-103 returns fresh numpy arrays). */
+int helm_host_trim(void);
+/* (diagnostic) number of scratch slots of `device` that hold a buffer of at least `bytes` bytes -- the direct path's shared workspace is
+ * kept PER DEVICE, HELM_WS_SLOTS (default 3) slots each, so that every GPU of an in-process multi-GPU job (distributors.py:80-96: one
+ * address space per worker in the reference) finds its own; device < 0: the number of slots per device. */
+int helm_debug_ws_slots(int device, long long bytes);
+/* (diagnostic) number of elimination-tree plans the per-device cache holds for `device` (HELM_ND_PLANS, default 6 per device) */
+int helm_debug_plan_cache(int device);
+/* (diagnostic, no GPU needed) the scratch-slot table exercised with `ndev` logical devices and host memory: every device books `concurrent`
+ * slots of `bytes`, then that many leases are taken on every device at once.  0: every lease was a booked slot of its own device and none
+ * allocated; < 0: which check failed. */
+int helm_debug_ws_selftest(int ndev, int concurrent, long long bytes);
+/* (diagnostic) allocator calls of the library that reached the driver and took more than a millisecond since the last reset (what
+ * HELM_ALLOC_TRACE=1 prints): a job that booked its memory with helm_reserve must issue none. */
+int helm_debug_alloc_stats(int reset, long long *slow_calls, double *worst_ms);
 
 /* --- diagnostics of the direct solver ---------------------------------------------------- */
 /* Elimination-tree plan of an (nz, nx) grid (host only, no GPU needed).  out == NULL: returns the number of fronts;
@@ -245,7 +262,7 @@ int helm_debug_zgemm(int device, int M, int N, int K, const double *alpha, const
                      const double *beta, double *C, int batch);
 int helm_debug_inverse(int device, int n, double *A, int batch);
 /* average milliseconds per launch of one strided-batched GEMM shape (random operands, `reps` timed launches) with tile-kernel
- * variant `variant` (-1: default; 0: first-generation tile kernel; 1 / 2: conflict-free double-buffered kernel, K slab 8 / 16) */
+ * variant `variant` (-1: default; 0: first-generation tile kernel; 1: conflict-free double-buffered vector-FMA kernel; 7: matrix-core kernel) */
 int helm_debug_zgemm_bench(int device, int M, int N, int K, int batch, int variant, int reps, double *ms_out);
 int helm_debug_inverse_bench(int device, int n, const double *A, int reps, int recurse_n, double *ms_out);
 

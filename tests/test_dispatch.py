@@ -202,3 +202,40 @@ def test_strict_pipeline_prepares_exactly_one_item_ahead():
     for k in range(1, 4):
         assert t[('p0', k)] >= t[('s0', k - 1)] - 1e-3            # not before the previous item's solve has started
         assert t[('p0', k)] < t[('s1', k - 1)]                    # but during it
+
+
+def test_a_result_object_that_is_never_iterated_starts_no_worker(monkeypatch):
+    """the pipelines start with the first result that is asked for, so dropping `sys * q` un-iterated leaves no thread spinning
+    in a throttle with multi-GB results in its hands."""
+    monkeypatch.setenv('HELM_DEVICES', '0,1')
+    g, sc = config()
+    del LOG[:]
+    mf = za.MultiFreq(sc)
+    before = threading.active_count()
+    res = mf * g['q']
+    time.sleep(0.2)
+    assert threading.active_count() == before and not [e for e in LOG if e[0] in ('solve', 'prefactor', 'reserve')]
+    del res
+    assert not mf.__dict__.get('_pipes')
+    out = list(mf * g['q'])                           # and the next call is a normal one
+    assert len(out) == len(sc['freqs'])
+
+
+def test_a_second_call_stops_the_workers_of_an_undrained_first_one(monkeypatch):
+    """two sets of threads must never drive the same operator handles.  The first call's generator is advanced by one result and
+    kept; the second call joins the first's pipelines before it creates its own."""
+    monkeypatch.setenv('HELM_DEVICES', '0,1')
+    g, sc = config()
+    serial = list(za.MultiFreq(dict(sc, parallel=False)) * g['q'])
+    mf = za.MultiFreq(sc)
+    first = mf * g['q']
+    u0 = next(first)
+    assert np.array_equal(u0, serial[0])
+    old_threads = [t for p in mf.__dict__['_pipes'] for t in p._threads]
+    assert old_threads
+    second = mf * g['q']
+    assert not any(t.is_alive() for t in old_threads)          # joined by the second call, before it has started anything of its own
+    second = list(second)
+    for a, b in zip(second, serial):
+        assert np.array_equal(a, b)
+    del first

@@ -128,3 +128,29 @@ def test_reserve_books_scratch_and_changes_no_result(helm_lib, monkeypatch):
     op2.reserve(q.shape[1], concurrent=2)
     assert np.array_equal(op2 * q, ref)
     del op2.factors
+
+
+def test_eight_logical_devices_book_their_memory_before_the_workers_start(helm_lib, monkeypatch):
+    """once the pools of a process are warm (the W warm-up items of a bench run, the first job of a long-lived process), a job
+    must not issue a single allocator call that reaches the driver and takes more than a millisecond after the bookings of helm_reserve
+    (per-device scratch slots, pooled fall-back workspaces, right-hand-side images).  Eight logical devices on the one physical GPU: more
+    concurrent solves than the device has slots, so the pooled fall-backs are exercised too."""
+    import ctypes
+    import zephyr_amd as za
+    sc, q = config(freqs=[3., 3.5, 4., 4.5, 5., 5.5, 6., 6.5, 7., 7.5, 8., 8.5])
+    serial = list(za.MultiFreq(dict(sc, parallel=False)) * q)
+    monkeypatch.setenv('HELM_DEVICES', '0,0,0,0,0,0,0,0')
+    monkeypatch.setenv('HELM_WORKERS_PER_DEVICE', '1')
+    slow, worst = ctypes.c_longlong(0), ctypes.c_double(0.0)
+    for job in range(3):
+        mf = za.MultiFreq(sc)
+        assert mf.nWorkers == 8
+        mf.__dict__['_after_reserve'] = lambda: helm_lib.helm_debug_alloc_stats(1, None, None)
+        par = list(mf * q)
+        helm_lib.helm_debug_alloc_stats(0, ctypes.byref(slow), ctypes.byref(worst))
+        for a, b in zip(par, serial):
+            assert np.array_equal(a, b)
+        if job > 0:            # (job 0 is the warm-up: operators, planes and factors of twelve frequencies come into being inside it)
+            assert slow.value == 0, 'job %d: %d allocator call(s) of more than 1 ms after the bookings (worst %.1f ms)' % (job, slow.value, worst.value)
+        del mf.factors
+    assert helm_lib.helm_debug_ws_slots(0, 1) >= 1          # device 0's own table holds the booked scratch

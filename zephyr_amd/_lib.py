@@ -83,6 +83,11 @@ _SIGNATURES = {
     'helm_imaging_accumulate_device': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                                       ctypes.c_void_p, ctypes.c_void_p]),
     'helm_trim': (ctypes.c_int, []),
+    'helm_host_trim': (ctypes.c_int, []),
+    'helm_debug_ws_slots': (ctypes.c_int, [ctypes.c_int, ctypes.c_longlong]),
+    'helm_debug_plan_cache': (ctypes.c_int, [ctypes.c_int]),
+    'helm_debug_ws_selftest': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_longlong]),
+    'helm_debug_alloc_stats': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_double)]),
     'helm_rhs_from_coo_device': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong,
                                                 ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong]),
     'helm_sample_device': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p,

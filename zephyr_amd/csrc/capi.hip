@@ -5,6 +5,8 @@
 #include "helm_internal.hpp"
 #include "direct.hpp"
 #include <chrono>
+#include <atomic>
+#include <unistd.h>
 #include <mutex>
 #include <map>
 #include <cstring>
@@ -43,13 +45,20 @@ extern "C" int helm_device_count(void) {
 // Scratch of the direct path (fronts while factoring, front vectors while solving) is tens of GB at the bench size and
 // is only needed during a call, so all handles of a process share one buffer; a handle that finds it taken (another
 // host thread is inside a solve) falls back to its own.
-struct WsSlot { void *ptr = nullptr; size_t bytes = 0; int device = -1; bool busy = false; };
-struct SharedWs { std::mutex mu; WsSlot slot[4]; };
+// r4: the table is PER DEVICE (HELM_WS_SLOTS slots each, default 3, at most 4).  Round 3 kept one table of 3-4 slots for the whole process,
+// tagged with a device: under the in-process dispatcher on an 8-GPU node the first three or four GPUs to ask got them and every other GPU
+// allocated its ~30 GB beside running kernels on every solve (the 0.7-1.5 s stalls helm_reserve exists to remove).  A lease is
+// (device, slot) packed as device * WS_SLOTS_MAX + slot.
+#define WS_SLOTS_MAX 4
+struct WsSlot { void *ptr = nullptr; size_t bytes = 0; bool busy = false; };
+struct WsDevice { WsSlot slot[WS_SLOTS_MAX]; };
+struct SharedWs { std::mutex mu; std::map<int, WsDevice> dev; };
 static SharedWs g_shared_ws;
-static int shared_ws_slots() { const char *e = getenv("HELM_WS_SLOTS"); const int n = e ? atoi(e) : 3; return n < 1 ? 1 : (n > 4 ? 4 : n); }
+static int shared_ws_slots() { const char *e = getenv("HELM_WS_SLOTS"); const int n = e ? atoi(e) : 3; return n < 1 ? 1 : (n > WS_SLOTS_MAX ? WS_SLOTS_MAX : n); }
 static int g_live_handles = 0;     // guarded by g_shared_ws.mu
 
-struct DevPool { std::mutex mu; std::multimap<std::pair<int, size_t>, void *> idle; size_t held = 0; };
+// idle device buffers by (device, size); `held` and the cap are per device (r4: one sum over all GPUs hit a single device's cap with the second GPU's buffers)
+struct DevPool { std::mutex mu; std::multimap<std::pair<int, size_t>, void *> idle; std::map<int, size_t> held; };
 static DevPool g_pool;
 static std::map<int, std::vector<hipEvent_t>> g_idle_events;      // per device, guarded by g_pool.mu
 
@@ -71,35 +80,66 @@ static const size_t kPoolMinBytes = (size_t)64;
 // would be a device synchronisation for nothing).  A 16-frequency job at 1024^2 hands back ~70 GB of
 // factors when its operators go; with a 64-GB cap the overflow went to hipFree and the next job's hipMalloc calls -- issued while other
 // threads had kernels and copies in flight -- took 1.2-1.5 s EACH (HELM_ALLOC_TRACE=1 shows them).
-static size_t pool_cap_bytes() {
-    static const size_t cap = [] {
-        if (const char *e = getenv("HELM_POOL_GB")) return (size_t)(atof(e) * 1e9);
-        size_t fr = 0, tot = 0;
-        if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return (size_t)64 << 30; }
-        return tot / 4 * 3;           // (what is in use plus what idles here cannot exceed the device: a failed hipMalloc empties the pool and retries)
-    }();
+static size_t pool_cap_bytes(int device) {          // (call with g_pool.mu held)
+    static std::map<int, size_t> caps;
+    auto it = caps.find(device);
+    if (it != caps.end()) return it->second;
+    size_t cap = (size_t)64 << 30;
+    if (const char *e = getenv("HELM_POOL_GB")) cap = (size_t)(atof(e) * 1e9);
+    else {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) cap = prop.totalGlobalMem / 4 * 3;     // (in use + idle here cannot exceed the device: a failed hipMalloc empties the pool and retries)
+        else (void)hipGetLastError();
+    }
+    caps[device] = cap;
     return cap;
 }
 
 // pinned host buffers (per-handle scalar records) and HIP streams are recycled the same way: a job creates one operator per frequency
-struct HostPool { std::mutex mu; std::multimap<size_t, void *> idle; };
+// r4: the idle pool is capped by BYTES (HELM_HOSTPOOL_GB, default a quarter of the host's memory, at most 96 GB) and helm_trim / helm_host_trim
+// give it back: results of 1 MB or more go through it (4.3 GB per frequency of the 2-D job), and with only an entry-count cap a long-lived
+// process that changed nsrc or the split sizes could accumulate hundreds of GB of locked memory in size classes it never used again
+struct HostPool { std::mutex mu; std::multimap<size_t, void *> idle; size_t held = 0; };
 static HostPool g_hostpool;
+static size_t hostpool_cap_bytes() {
+    static const size_t cap = [] {
+        if (const char *e = getenv("HELM_HOSTPOOL_GB")) return (size_t)(atof(e) * 1e9);
+        const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
+        const size_t ram = pages > 0 && psz > 0 ? (size_t)pages * (size_t)psz : (size_t)64 << 30;
+        return std::min(ram / 4, (size_t)96 << 30);
+    }();
+    return cap;
+}
 // HELM_ALLOC_TRACE=1: every allocator call that reaches the driver and takes more than a millisecond is reported on stderr
+// (always counted -- helm_debug_alloc_stats -- so that a test can assert that a job issued none after its bookings)
+static std::atomic<long long> g_alloc_slow{0};
+static std::atomic<long long> g_alloc_worst_us{0};
 struct AllocTrace {
     const char *what; size_t bytes; std::chrono::steady_clock::time_point t0; bool on;
     AllocTrace(const char *w, size_t b) : what(w), bytes(b), t0(std::chrono::steady_clock::now()) { static const bool e = getenv("HELM_ALLOC_TRACE") && atoi(getenv("HELM_ALLOC_TRACE")); on = e; }
     ~AllocTrace() {
-        if (!on) return;
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        if (ms > 1.0) fprintf(stderr, "[helm alloc] %-14s %8.3f GB %9.1f ms\n", what, bytes * 1e-9, ms);
+        if (ms > 1.0) {
+            g_alloc_slow += 1;
+            long long us = (long long)(ms * 1e3), prev = g_alloc_worst_us.load();
+            while (us > prev && !g_alloc_worst_us.compare_exchange_weak(prev, us)) {}
+            if (on) fprintf(stderr, "[helm alloc] %-14s %8.3f GB %9.1f ms\n", what, bytes * 1e-9, ms);
+        }
     }
 };
+// allocator calls (hipMalloc / hipFree / hipHostMalloc / pool flushes) that reached the driver and took more than 1 ms since the last reset
+extern "C" int helm_debug_alloc_stats(int reset, long long *slow_calls, double *worst_ms) {
+    if (slow_calls) *slow_calls = g_alloc_slow.load();
+    if (worst_ms) *worst_ms = g_alloc_worst_us.load() * 1e-3;
+    if (reset) { g_alloc_slow = 0; g_alloc_worst_us = 0; }
+    return HELM_OK;
+}
 
 void *helm_hostpool_alloc(size_t bytes) {
     {
         std::lock_guard<std::mutex> lk(g_hostpool.mu);
         auto it = g_hostpool.idle.find(bytes);
-        if (it != g_hostpool.idle.end()) { void *p = it->second; g_hostpool.idle.erase(it); return p; }
+        if (it != g_hostpool.idle.end()) { void *p = it->second; g_hostpool.idle.erase(it); g_hostpool.held -= bytes; return p; }
     }
     void *p = nullptr;
     AllocTrace tr("hipHostMalloc", bytes);
@@ -108,9 +148,22 @@ void *helm_hostpool_alloc(size_t bytes) {
 }
 void helm_hostpool_free(void *p, size_t bytes) {
     if (!p) return;
-    std::lock_guard<std::mutex> lk(g_hostpool.mu);
-    if (g_hostpool.idle.size() < 256) { g_hostpool.idle.insert(std::make_pair(bytes, p)); return; }
+    {
+        std::lock_guard<std::mutex> lk(g_hostpool.mu);
+        if (g_hostpool.idle.size() < 1024 && (g_hostpool.held + bytes <= hostpool_cap_bytes() || bytes < ((size_t)1 << 20))) {
+            g_hostpool.idle.insert(std::make_pair(bytes, p)); g_hostpool.held += bytes;
+            return;
+        }
+    }
+    AllocTrace tr("hipHostFree", bytes);
     hipHostFree(p);
+}
+// pinned host memory the library holds idle goes back to the system
+extern "C" int helm_host_trim(void) {
+    std::lock_guard<std::mutex> lk(g_hostpool.mu);
+    for (auto &kv : g_hostpool.idle) hipHostFree(kv.second);
+    g_hostpool.idle.clear(); g_hostpool.held = 0;
+    return HELM_OK;
 }
 struct StreamPool { std::mutex mu; std::multimap<std::pair<int, int>, hipStream_t> idle; };     // (device, priority class) -> idle streams
 static StreamPool g_streams;
@@ -136,32 +189,52 @@ void helm_stream_release(int device, int prio, hipStream_t s) {
     hipStreamDestroy(s);
 }
 
+// idle bytes of one device (what hipMemGetInfo's "free" figure does not count although an allocation can have them: the budgets of mg3d.hip add it)
+size_t helm_pool_idle_bytes(int device) {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    auto it = g_pool.held.find(device);
+    return it == g_pool.held.end() ? 0 : it->second;
+}
+// give this device's idle buffers back to the driver (the current device must be `device`)
+static void pool_flush_device(int device) {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    AllocTrace trf("pool flush", g_pool.held[device]);
+    for (auto it = g_pool.idle.lower_bound(std::make_pair(device, (size_t)0)); it != g_pool.idle.end() && it->first.first == device; ) {
+        hipFree(it->second);
+        it = g_pool.idle.erase(it);
+    }
+    g_pool.held[device] = 0;
+}
+// hipMalloc that, under memory pressure, empties the device's idle pool and tries once more -- for every allocation of the library that does
+// not go through the size-keyed pool itself (scratch slots, temporaries of the host-buffer entry points, plans)
+hipError_t helm_malloc_retry(int device, void **p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess) return e;
+    (void)hipGetLastError();
+    pool_flush_device(device);
+    e = hipMalloc(p, bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); *p = nullptr; }
+    return e;
+}
 void *helm_pool_alloc(int device, size_t bytes) {
     {
         std::lock_guard<std::mutex> lk(g_pool.mu);
         auto it = g_pool.idle.find(std::make_pair(device, bytes));
-        if (it != g_pool.idle.end()) { void *p = it->second; g_pool.idle.erase(it); g_pool.held -= bytes; return p; }
+        if (it != g_pool.idle.end()) { void *p = it->second; g_pool.idle.erase(it); g_pool.held[device] -= bytes; return p; }
     }
     void *p = nullptr;
     AllocTrace tr("pool hipMalloc", bytes);
-    if (hipMalloc(&p, bytes) != hipSuccess) {
-        (void)hipGetLastError();
-        // under memory pressure give the cached buffers back and try once more
-        AllocTrace trf("pool flush", g_pool.held);
-        std::lock_guard<std::mutex> lk(g_pool.mu);
-        for (auto &kv : g_pool.idle) hipFree(kv.second);
-        g_pool.idle.clear(); g_pool.held = 0;
-        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    }
+    if (helm_malloc_retry(device, &p, bytes) != hipSuccess) return nullptr;
     return p;
 }
 void helm_pool_free(int device, void *p, size_t bytes) {
     if (!p) return;
     {
-        const size_t cap = pool_cap_bytes();
         std::lock_guard<std::mutex> lk(g_pool.mu);
-        if (bytes >= kPoolMinBytes && (g_pool.held + bytes <= cap || bytes < ((size_t)1 << 20))) {
-            g_pool.idle.insert(std::make_pair(std::make_pair(device, bytes), p)); g_pool.held += bytes;
+        const size_t cap = pool_cap_bytes(device);
+        size_t &held = g_pool.held[device];
+        if (bytes >= kPoolMinBytes && (held + bytes <= cap || bytes < ((size_t)1 << 20))) {
+            g_pool.idle.insert(std::make_pair(std::make_pair(device, bytes), p)); held += bytes;
             return;
         }
     }
@@ -254,17 +327,34 @@ extern "C" void helm_destroy(helm_op *op) {
 // Release what the library caches between calls (the shared scratch of the direct path).  The scratch is kept across
 // handles on purpose -- allocating tens of GB costs far more than a solve -- so a host that wants the memory back says so.
 extern "C" int helm_trim(void) {
-    std::lock_guard<std::mutex> lk(g_shared_ws.mu);
-    for (int i = 0; i < 4; ++i) if (g_shared_ws.slot[i].busy) return HELM_ERR_STATE;
-    for (int i = 0; i < 4; ++i) {
-        WsSlot &w = g_shared_ws.slot[i];
-        if (w.ptr) { hipSetDevice(w.device); hipFree(w.ptr); }
-        w.ptr = nullptr; w.bytes = 0; w.device = -1;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    {
+        std::lock_guard<std::mutex> lk(g_shared_ws.mu);
+        for (auto &kv : g_shared_ws.dev) for (int i = 0; i < WS_SLOTS_MAX; ++i) if (kv.second.slot[i].busy) return HELM_ERR_STATE;
+        for (auto &kv : g_shared_ws.dev)
+            for (int i = 0; i < WS_SLOTS_MAX; ++i) {
+                WsSlot &w = kv.second.slot[i];
+                if (w.ptr) { hipSetDevice(kv.first); hipFree(w.ptr); }
+                w.ptr = nullptr; w.bytes = 0;
+            }
+        std::lock_guard<std::mutex> lp(g_pool.mu);
+        for (auto &kv : g_pool.idle) { hipSetDevice(kv.first.first); hipFree(kv.second); }
+        g_pool.idle.clear(); g_pool.held.clear();
     }
-    std::lock_guard<std::mutex> lp(g_pool.mu);
-    for (auto &kv : g_pool.idle) { hipSetDevice(kv.first.first); hipFree(kv.second); }
-    g_pool.idle.clear(); g_pool.held = 0;
-    return HELM_OK;
+    (void)hipSetDevice(cur);
+    return helm_host_trim();
+}
+
+// (tests) how many scratch slots of `device` hold a buffer of at least `bytes`; -1: the number of slots per device
+extern "C" int helm_debug_ws_slots(int device, long long bytes) {
+    if (device < 0) return shared_ws_slots();
+    std::lock_guard<std::mutex> lk(g_shared_ws.mu);
+    auto it = g_shared_ws.dev.find(device);
+    if (it == g_shared_ws.dev.end()) return 0;
+    int n = 0;
+    for (int i = 0; i < WS_SLOTS_MAX; ++i) if (it->second.slot[i].ptr && (long long)it->second.slot[i].bytes >= bytes) n += 1;
+    return n;
 }
 
 extern "C" int helm_set_stream(helm_op *op, void *hip_stream) {
@@ -715,34 +805,97 @@ struct NvGuard {     // Krylov vector length of the handle for the duration of a
 };
 
 
-void *ws_checkout(helm_op *op, size_t bytes, int *slot_out) {
-    {
-        std::lock_guard<std::mutex> lk(g_shared_ws.mu);
-        const int ns = shared_ws_slots();
-        // prefer an idle slot that is already big enough, then any idle slot
-        int pick = -1;
-        for (int i = 0; i < ns; ++i) { WsSlot &w = g_shared_ws.slot[i]; if (!w.busy && w.ptr && w.device == op->device && w.bytes >= bytes) { pick = i; break; } }
-        if (pick < 0) for (int i = 0; i < ns; ++i) { WsSlot &w = g_shared_ws.slot[i]; if (!w.busy && (w.ptr == nullptr || w.device == op->device)) { pick = i; break; } }
-        if (pick >= 0) {
-            WsSlot &w = g_shared_ws.slot[pick];
-            if (w.bytes < bytes) {
-                AllocTrace tr("ws slot grow", bytes);
-                if (w.ptr) hipFree(w.ptr);
-                w.ptr = nullptr; w.bytes = 0;
-                if (hipMalloc(&w.ptr, bytes) != hipSuccess) { w.ptr = nullptr; (void)hipGetLastError(); }
-                else { w.bytes = bytes; w.device = op->device; }
-            }
-            if (w.ptr) { w.busy = true; *slot_out = pick; return w.ptr; }
-        }
+// the slot table's two operations, over any table and allocator (the library's own: g_shared_ws with hipMalloc; helm_debug_ws_selftest: a
+// scratch table with malloc, so that the booking logic is testable without a GPU)
+typedef void *(*ws_alloc_fn)(int device, size_t bytes);
+typedef void (*ws_free_fn)(int device, void *p);
+static void *ws_dev_alloc(int device, size_t bytes) { void *p = nullptr; AllocTrace tr("ws slot alloc", bytes); (void)helm_malloc_retry(device, &p, bytes); return p; }
+static void ws_dev_free(int, void *p) { hipFree(p); }
+// an idle slot of `device` that is already big enough, else any idle one (grown to `bytes`); nullptr when every slot of the device is taken or
+// the allocation fails.  *lease = device * WS_SLOTS_MAX + slot.
+static void *ws_table_checkout(SharedWs &T, int device, size_t bytes, int *lease, ws_alloc_fn al, ws_free_fn fr) {
+    std::lock_guard<std::mutex> lk(T.mu);
+    const int ns = shared_ws_slots();
+    WsDevice &D = T.dev[device];
+    int pick = -1;
+    for (int i = 0; i < ns; ++i) { WsSlot &w = D.slot[i]; if (!w.busy && w.ptr && w.bytes >= bytes) { pick = i; break; } }
+    if (pick < 0) for (int i = 0; i < ns; ++i) { WsSlot &w = D.slot[i]; if (!w.busy) { pick = i; break; } }
+    if (pick < 0) return nullptr;
+    WsSlot &w = D.slot[pick];
+    if (w.bytes < bytes) {
+        if (w.ptr) fr(device, w.ptr);
+        w.ptr = al(device, bytes);
+        w.bytes = w.ptr ? bytes : 0;
     }
-    *slot_out = -1;
+    if (!w.ptr) return nullptr;
+    w.busy = true; *lease = device * WS_SLOTS_MAX + pick;
+    return w.ptr;
+}
+static void ws_table_checkin(SharedWs &T, int lease) {
+    if (lease < 0) return;
+    std::lock_guard<std::mutex> lk(T.mu);
+    T.dev[lease / WS_SLOTS_MAX].slot[lease % WS_SLOTS_MAX].busy = false;
+}
+// make sure `concurrent` slots of `device` hold at least `bytes` each (idle slots that are too small are re-allocated; another device's table is
+// never touched); returns the number of slots that are ready
+static int ws_table_reserve(SharedWs &T, int device, size_t bytes, int concurrent, ws_alloc_fn al, ws_free_fn fr) {
+    std::lock_guard<std::mutex> lk(T.mu);
+    const int ns = shared_ws_slots();
+    WsDevice &D = T.dev[device];
+    int ready = 0;
+    for (int i = 0; i < ns; ++i) { const WsSlot &w = D.slot[i]; if (w.ptr && w.bytes >= bytes) ready += 1; }
+    for (int i = 0; i < ns && ready < concurrent; ++i) {
+        WsSlot &w = D.slot[i];
+        if (w.busy || (w.ptr && w.bytes >= bytes)) continue;
+        if (w.ptr) { fr(device, w.ptr); w.ptr = nullptr; w.bytes = 0; }
+        w.ptr = al(device, bytes);
+        if (!w.ptr) break;
+        w.bytes = bytes; ready += 1;
+    }
+    return ready;
+}
+
+void *ws_checkout(helm_op *op, size_t bytes, int *slot_out) {
+    void *p = ws_table_checkout(g_shared_ws, op->device, bytes, slot_out, ws_dev_alloc, ws_dev_free);
+    if (p) return p;
+    *slot_out = -1;                        // every slot of this device is inside a solve (or the allocation failed): the handle's own buffer
     if (ensure_ws(op, bytes) != HELM_OK) return nullptr;
     return op->d_ws;
 }
-void ws_checkin(int slot) {
-    if (slot < 0) return;
-    std::lock_guard<std::mutex> lk(g_shared_ws.mu);
-    g_shared_ws.slot[slot].busy = false;
+void ws_checkin(int slot) { ws_table_checkin(g_shared_ws, slot); }
+
+// (tests, no GPU needed) the slot table with `ndev` logical devices and host memory: every device books `concurrent` slots of `bytes`, then
+// `concurrent` leases are taken on every device at once.  Returns 0 when every lease is a booked slot of its own device, no lease needed a
+// new allocation, one lease more than the table has slots is refused, and a device's bookings survive the other devices' bookings; a negative
+// code says which of these failed.
+static int g_selftest_allocs = 0;
+static void *ws_host_alloc(int, size_t bytes) { g_selftest_allocs += 1; return malloc(bytes); }
+static void ws_host_free(int, void *p) { free(p); }
+extern "C" int helm_debug_ws_selftest(int ndev, int concurrent, long long bytes) {
+    if (ndev < 1 || concurrent < 1 || bytes < 1) return HELM_ERR_ARG;
+    SharedWs T;
+    int rc = 0;
+    const int ns = shared_ws_slots();
+    const int want = std::min(concurrent, ns);
+    g_selftest_allocs = 0;
+    for (int d = 0; d < ndev; ++d) if (ws_table_reserve(T, d, (size_t)bytes, concurrent, ws_host_alloc, ws_host_free) != want) rc = -1;
+    if (g_selftest_allocs != ndev * want) rc = rc ? rc : -2;
+    std::vector<int> leases;
+    std::vector<void *> ptrs;
+    for (int d = 0; d < ndev && !rc; ++d)
+        for (int k = 0; k < want; ++k) {
+            int lease = -1;
+            void *p = ws_table_checkout(T, d, (size_t)bytes, &lease, ws_host_alloc, ws_host_free);
+            if (!p || lease / WS_SLOTS_MAX != d) { rc = -3; break; }
+            for (void *q : ptrs) if (q == p) rc = -4;                   // two leases on one buffer
+            leases.push_back(lease); ptrs.push_back(p);
+        }
+    if (!rc && g_selftest_allocs != ndev * want) rc = -5;              // a lease after the booking allocated
+    if (!rc && want == ns) { int lease = -1; if (ws_table_checkout(T, 0, (size_t)bytes, &lease, ws_host_alloc, ws_host_free)) rc = -6; }   // all of device 0's slots are out
+    for (int l : leases) ws_table_checkin(T, l);
+    if (!rc) { int lease = -1; if (!ws_table_checkout(T, ndev - 1, (size_t)bytes / 2 + 1, &lease, ws_host_alloc, ws_host_free) || g_selftest_allocs != ndev * want) rc = -7; else ws_table_checkin(T, lease); }
+    for (auto &kv : T.dev) for (int i = 0; i < WS_SLOTS_MAX; ++i) if (kv.second.slot[i].ptr) free(kv.second.slot[i].ptr);
+    return rc;
 }
 struct WsLease {
     int slot = -1; void *ptr = nullptr;
@@ -1512,7 +1665,7 @@ extern "C" int helm_prefactor(helm_op *op) {
 extern "C" int helm_reserve(helm_op *op, int nrhs, long long rows, int concurrent) {
     if (!op || nrhs < 1 || rows < 1 || concurrent < 1) return HELM_ERR_ARG;
     if (hipSetDevice(op->device) != hipSuccess) { (void)hipGetLastError(); return HELM_OK; }
-    if (concurrent > 4) concurrent = 4;
+    if (concurrent > 64) concurrent = 64;
     const size_t bytes = (size_t)nrhs * rows * sizeof(cplx);
     {   // device images: idle buffers of that size the pool holds already count
         size_t have = 0;
@@ -1520,7 +1673,7 @@ extern "C" int helm_reserve(helm_op *op, int nrhs, long long rows, int concurren
         std::vector<void *> got;
         for (size_t k = have; k < (size_t)3 * concurrent; ++k) {
             void *p = nullptr;
-            if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+            if (helm_malloc_retry(op->device, &p, bytes) != hipSuccess) break;
             got.push_back(p);
         }
         for (void *p : got) helm_pool_free(op->device, p, bytes);
@@ -1537,17 +1690,21 @@ extern "C" int helm_reserve(helm_op *op, int nrhs, long long rows, int concurren
     const double cap = (capenv ? atof(capenv) : 32.0) * 1e9;
     while (Bmax > 1 && (double)per_rhs * Bmax * sizeof(cplx) > cap) Bmax = (Bmax + 1) / 2;
     const size_t wsb = (size_t)per_rhs * Bmax * sizeof(cplx);
-    std::lock_guard<std::mutex> lk(g_shared_ws.mu);
-    const int ns = shared_ws_slots();
-    int ready = 0;
-    for (int i = 0; i < ns; ++i) { const WsSlot &w = g_shared_ws.slot[i]; if (w.ptr && w.device == op->device && w.bytes >= wsb) ready += 1; }
-    for (int i = 0; i < ns && ready < concurrent; ++i) {
-        WsSlot &w = g_shared_ws.slot[i];
-        if (w.busy || (w.ptr && w.device == op->device && w.bytes >= wsb)) continue;
-        if (w.ptr && w.device != op->device) continue;                 // another GPU's slot: leave it
-        if (w.ptr) { hipFree(w.ptr); w.ptr = nullptr; w.bytes = 0; }
-        if (hipMalloc(&w.ptr, wsb) != hipSuccess) { (void)hipGetLastError(); w.ptr = nullptr; break; }
-        w.bytes = wsb; w.device = op->device; ready += 1;
+    const int ready = ws_table_reserve(g_shared_ws, op->device, wsb, concurrent, ws_dev_alloc, ws_dev_free);      // this device's own table: booking for one GPU never touches another's
+    // more concurrent solves than slots (several workers per GPU): the others fall back to their handle's own workspace, which comes from the
+    // size-keyed pool -- put that many buffers there now, as long as they fit beside everything else (half of what is free)
+    if (concurrent > ready) {
+        size_t have = 0, freeb = 0, totb = 0;
+        { std::lock_guard<std::mutex> lk(g_pool.mu); have = g_pool.idle.count(std::make_pair(op->device, wsb)); }
+        if (hipMemGetInfo(&freeb, &totb) != hipSuccess) { (void)hipGetLastError(); freeb = 0; }
+        std::vector<void *> got;
+        for (size_t k = have; k < (size_t)(concurrent - ready) && (got.size() + 1) * wsb <= freeb / 2; ++k) {
+            void *p = nullptr;
+            AllocTrace tr("ws fallback", wsb);
+            if (hipMalloc(&p, wsb) != hipSuccess) { (void)hipGetLastError(); break; }
+            got.push_back(p);
+        }
+        for (void *p : got) helm_pool_free(op->device, p, wsb);
     }
     return HELM_OK;
 }
@@ -1618,7 +1775,7 @@ extern "C" int helm_solve_device(helm_op *op, const void *dRHS, void *dU, int nr
         // eps != delta: M3 != 0, the two fields are coupled -> Jacobi-BiCGSTAB on the full 2N x 2N system
         // (eurus.py:430-464,512-533); N-row right-hand sides are zero-padded and the result clipped
         cplx *dW = nullptr;
-        if (hipMalloc(&dW, (size_t)nrhs * 2 * N * sizeof(cplx)) != hipSuccess) { cleanup(); HELM_FAIL(op, HELM_ERR_DEVICE, "hipMalloc failed"); }
+        if (helm_malloc_retry(op->device, (void **)&dW, (size_t)nrhs * 2 * N * sizeof(cplx)) != hipSuccess) { cleanup(); HELM_FAIL(op, HELM_ERR_DEVICE, "hipMalloc failed"); }
         int rc = solve_block(op, 0, (const cplx *)dRHS_use, rows, 0, premul, nullptr, dW, nrhs, o, info, 1, rows);
         if (rc >= 0) {
             result = rc;
@@ -1642,7 +1799,7 @@ extern "C" int helm_solve_device(helm_op *op, const void *dRHS, void *dU, int nr
     } else {
         // block-triangular: v = M4^-1 q2 ; u = M1^-1 (q1 - M2 v)
         cplx *dV = nullptr, *dT = nullptr;
-        if (hipMalloc(&dV, (size_t)nrhs * N * sizeof(cplx)) != hipSuccess || hipMalloc(&dT, (size_t)nrhs * N * sizeof(cplx)) != hipSuccess) {
+        if (helm_malloc_retry(op->device, (void **)&dV, (size_t)nrhs * N * sizeof(cplx)) != hipSuccess || helm_malloc_retry(op->device, (void **)&dT, (size_t)nrhs * N * sizeof(cplx)) != hipSuccess) {
             hipFree(dV); cleanup(); HELM_FAIL(op, HELM_ERR_DEVICE, "hipMalloc failed");
         }
         int rc = solve_block(op, 3, (const cplx *)dRHS_use, rows, N, premul, nullptr, dV, nrhs, o, info);
@@ -1728,8 +1885,15 @@ extern "C" int helm_solve_coo(helm_op *op, const long long *row, const int *col,
     void *dR = helm_pool_alloc(op->device, bytes), *dU = helm_pool_alloc(op->device, bytes), *dT = helm_pool_alloc(op->device, tb);
     auto release = [&]() { hipStreamSynchronize(op->stream); helm_pool_free(op->device, dR, bytes); helm_pool_free(op->device, dU, bytes); helm_pool_free(op->device, dT, tb); };
     if (!dR || !dU || !dT) { release(); HELM_FAIL(op, HELM_ERR_DEVICE, "hipMalloc failed"); }
-    long long *d_row = (long long *)dT; cplx *d_val = (cplx *)(d_row + std::max<long long>(nnz, 1)); int *d_col = (int *)(d_val + std::max<long long>(nnz, 1));
+    // packed as [val (16-byte entries) | row (8) | col (4)]: every array starts on a multiple of its own element size whatever the parity of nnz
+    // (r3 packed row | val | col, which left val on an 8-byte boundary for odd nnz although the expansion kernel reads it as 16-byte vectors)
+    cplx *d_val = (cplx *)dT; long long *d_row = (long long *)(d_val + std::max<long long>(nnz, 1)); int *d_col = (int *)(d_row + std::max<long long>(nnz, 1));
     int rc = HELM_OK;
+    for (long long k = 0; k < nnz; ++k)              // the scatter trusts its indices: check them where they arrive
+        if (row[k] < 0 || row[k] >= rows || col[k] < 0 || col[k] >= nrhs) {
+            release();
+            HELM_FAIL(op, HELM_ERR_ARG, "sparse right-hand side: entry %lld addresses (row %lld, column %d) outside the %lld x %d right-hand-side matrix", k, row[k], col[k], rows, nrhs);
+        }
     if (nnz > 0 && (hipMemcpyAsync(d_row, row, nnz * sizeof(long long), hipMemcpyHostToDevice, op->stream) != hipSuccess ||
                     hipMemcpyAsync(d_val, val, nnz * sizeof(cplx), hipMemcpyHostToDevice, op->stream) != hipSuccess ||
                     hipMemcpyAsync(d_col, col, nnz * sizeof(int), hipMemcpyHostToDevice, op->stream) != hipSuccess)) rc = HELM_ERR_DEVICE;

@@ -28,6 +28,7 @@
 #include <hip/hip_ext.h>
 #include <algorithm>
 #include <mutex>
+#include <map>
 
 namespace {
 
@@ -2272,37 +2273,52 @@ void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cp
 }  // namespace
 
 // ---- plan cache ---------------------------------------------------------------------------------------------------
+// Per device, most recently used last, HELM_ND_PLANS (default 6) kept alive per device by the cache (a factor keeps its own plan alive whatever the
+// cache does).  r4: round 3 had ONE list of four for the whole process, searched and FILLED under one mutex: with the in-process dispatcher dealing
+// operators over eight GPUs (or a 2-D plan beside the 3-D column-dissection plans) every new operator missed, and each miss rebuilt the host
+// plan -- tens of milliseconds of recursion -- and ran hipMalloc / hipFree with the lock held, i.e. with every other GPU's prepare thread waiting.
+// Now: look-up under the lock, build outside it (two threads that miss on the same key both build; the second finds the first's entry and
+// drops its own), tables from the size-keyed device pool.
 NdPlanDev::~NdPlanDev() {
-    if (d_nodes) hipFree(d_nodes);
-    if (d_tab) hipFree(d_tab);
+    if (d_nodes) helm_pool_free(device, d_nodes, plan.nodes.size() * sizeof(NdDev));
+    if (d_tab) helm_pool_free(device, d_tab, (size_t)plan.total_rows * sizeof(int4));
 }
 
 namespace {
 std::mutex g_plan_mu;
-std::vector<std::shared_ptr<NdPlanDev>> g_plans;     // most recently used last, at most 4 kept alive by the cache
+// (never destroyed: a plan's destructor hands its tables to the device pool of capi.hip, which may be gone first when the process exits)
+std::map<int, std::vector<std::shared_ptr<NdPlanDev>>> &g_plans = *new std::map<int, std::vector<std::shared_ptr<NdPlanDev>>>();
+
+std::shared_ptr<NdPlanDev> plan_lookup(int device, int pnz, int pnx, int leaf, int dof) {      // (g_plan_mu held)
+    std::vector<std::shared_ptr<NdPlanDev>> &L = g_plans[device];
+    for (size_t i = 0; i < L.size(); ++i) {
+        const NdPlanDev &c = *L[i];
+        if (c.plan.nz == pnz && c.plan.nx == pnx && c.plan.leaf == std::max(2, leaf) && c.plan.dof == dof) {
+            std::shared_ptr<NdPlanDev> hit = L[i];
+            L.erase(L.begin() + i); L.push_back(hit);
+            return hit;
+        }
+    }
+    return nullptr;
+}
 }
 
 int nd_get_plan(helm_op *op, int leaf, int dof, std::shared_ptr<NdPlanDev> *out) { return nd_get_plan_dims(op, op->nz, op->nx, leaf, dof, out); }
 
 // the same for a grid that is not the handle's own: the 3-D coarse solve runs the 2-D dissection over (ny, nx) columns of nz unknowns (dof = nz)
 int nd_get_plan_dims(helm_op *op, int pnz, int pnx, int leaf, int dof, std::shared_ptr<NdPlanDev> *out) {
-    std::lock_guard<std::mutex> lk(g_plan_mu);
-    for (size_t i = 0; i < g_plans.size(); ++i) {
-        const NdPlanDev &c = *g_plans[i];
-        if (c.device == op->device && c.plan.nz == pnz && c.plan.nx == pnx && c.plan.leaf == std::max(2, leaf) && c.plan.dof == dof) {
-            std::shared_ptr<NdPlanDev> hit = g_plans[i];
-            g_plans.erase(g_plans.begin() + i); g_plans.push_back(hit);
-            *out = hit;
-            return HELM_OK;
-        }
+    {
+        std::lock_guard<std::mutex> lk(g_plan_mu);
+        if (std::shared_ptr<NdPlanDev> hit = plan_lookup(op->device, pnz, pnx, leaf, dof)) { *out = hit; return HELM_OK; }
     }
     std::shared_ptr<NdPlanDev> pd(new NdPlanDev());
     pd->device = op->device;
     nd_build_plan(pd->plan, pnz, pnx, leaf, dof);
     const NdPlan &P = pd->plan;
     if (2 * P.vregion >= (1LL << 31) || P.total_rows >= (1LL << 31)) HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "direct solver: grid too large for 32-bit row indices");
-    HIP_TRY(op, hipMalloc((void **)&pd->d_nodes, P.nodes.size() * sizeof(NdDev)));
-    HIP_TRY(op, hipMalloc((void **)&pd->d_tab, (size_t)P.total_rows * sizeof(int4)));
+    pd->d_nodes = (NdDev *)helm_pool_alloc(op->device, P.nodes.size() * sizeof(NdDev));
+    pd->d_tab = (int4 *)helm_pool_alloc(op->device, (size_t)P.total_rows * sizeof(int4));
+    if (!pd->d_nodes || !pd->d_tab) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: allocation of the plan tables failed");
     HIP_TRY(op, hipMemcpyAsync(pd->d_nodes, P.nodes.data(), P.nodes.size() * sizeof(NdDev), hipMemcpyHostToDevice, op->stream));
     for (size_t gi = 0; gi < P.groups.size(); ++gi) {
         const NdGroup &g = P.groups[gi];
@@ -2312,11 +2328,25 @@ int nd_get_plan_dims(helm_op *op, int pnz, int pnx, int leaf, int dof, std::shar
             hipLaunchKernelGGL(k_nd_build_tab, dim3((nmax + 255) / 256, nb), dim3(256), 0, op->stream, pd->d_nodes, g.first + j0, pd->d_tab, P.nz, P.nx);
         }
     }
-    HIP_TRY(op, hipStreamSynchronize(op->stream));      // the host-side node array may go away after this
-    g_plans.push_back(pd);
-    if (g_plans.size() > 4) g_plans.erase(g_plans.begin());
+    HIP_TRY(op, hipStreamSynchronize(op->stream));      // the tables are complete before another handle (another stream) can find them
+    static const int keep = getenv("HELM_ND_PLANS") ? std::max(1, atoi(getenv("HELM_ND_PLANS"))) : 6;
+    std::shared_ptr<NdPlanDev> evicted;                  // (destroyed after the lock is released)
+    {
+        std::lock_guard<std::mutex> lk(g_plan_mu);
+        if (std::shared_ptr<NdPlanDev> hit = plan_lookup(op->device, pnz, pnx, leaf, dof)) { *out = hit; return HELM_OK; }      // another thread was faster: ours goes back to the pool
+        std::vector<std::shared_ptr<NdPlanDev>> &L = g_plans[op->device];
+        L.push_back(pd);
+        if ((int)L.size() > keep) { evicted = L.front(); L.erase(L.begin()); }
+    }
     *out = pd;
     return HELM_OK;
+}
+
+// (tests) number of plans the cache holds for `device`
+extern "C" int helm_debug_plan_cache(int device) {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    auto it = g_plans.find(device);
+    return it == g_plans.end() ? 0 : (int)it->second.size();
 }
 
 // ---- factorisation ---------------------------------------------------------------------------------------------

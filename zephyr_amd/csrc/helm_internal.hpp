@@ -171,6 +171,8 @@ void helm_set_error(helm_op *op, const char *msg);
 // operators of identical shape, and hipMalloc/hipFree of GB-sized buffers cost milliseconds each.  helm_trim() empties it.
 void *helm_pool_alloc(int device, size_t bytes);          // nullptr on failure
 void helm_pool_free(int device, void *p, size_t bytes);   // the buffer must no longer be in use by any stream
+size_t helm_pool_idle_bytes(int device);                  // what the pool holds idle on that device (not in hipMemGetInfo's free figure)
+hipError_t helm_malloc_retry(int device, void **p, size_t bytes);   // hipMalloc; on failure the device's idle pool is emptied and the call repeated
 void *helm_hostpool_alloc(size_t bytes);                  // pinned host memory, recycled by size
 void helm_hostpool_free(void *p, size_t bytes);
 hipStream_t helm_stream_acquire(int device, int prio);    // prio 0 normal, 1 highest, -1 lowest; recycled across handles

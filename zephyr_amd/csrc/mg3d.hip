@@ -669,6 +669,7 @@ int bt_setup(helm_op *op, Bt3 &B, const Mg3Level &L, int batch) {
     {   // leave room for the Krylov workspace: the plane inverses may take a third of the device memory (HELM_MG3_BT_MAXGB overrides)
         size_t freeb = 0, totb = 0;
         hipMemGetInfo(&freeb, &totb);
+        freeb += helm_pool_idle_bytes(op->device);       // (r4: idle buffers of the library's own pool are available to it)
         const double cap = std::min(envd("HELM_MG3_BT_MAXGB", totb / 3.0e9) * 1e9, 0.95 * (double)freeb);     // (free memory: several 3-D handles may be alive)
         if ((double)(tb + B.tbytes32) > cap)
             HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "3-D multigrid: the plane inverses of the directly solved level (%.1f GB) exceed the budget of %.1f GB", (tb + B.tbytes32) / 1e9, cap / 1e9);
@@ -798,6 +799,7 @@ int nd3_setup(helm_op *op, Nd3 &D, const Mg3Level &L, int batch) {
     {
         size_t freeb = 0, totb = 0;
         hipMemGetInfo(&freeb, &totb);
+        freeb += helm_pool_idle_bytes(op->device);       // (r4: idle buffers of the library's own pool are available to it)
         const double need = (double)P.fac_elems * sizeof(cplx) + (double)fwb + (double)D.ws_bytes;
         if (need > 0.9 * (double)freeb) HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "3-D multigrid: the factors of the directly solved level (%.1f GB) do not fit", need / 1e9);
     }
@@ -1270,6 +1272,7 @@ int mg3_setup(helm_op *op, int batch) {
         if (ncoarsen > 0) {
             size_t freeb = 0, totb = 0;
             hipMemGetInfo(&freeb, &totb);
+            freeb += helm_pool_idle_bytes(op->device);       // (r4: idle buffers of the library's own pool are available to it)
             // budget of the plane inverses: a third of the device, and never more than what is free now less the Krylov vectors of this call
             const double krylov = 11.0 * batch * (double)op->N * sizeof(cplx);
             const double cap = std::min(envd("HELM_MG3_BT_MAXGB", totb / 3.0e9) * 1e9, std::max(0.0, (double)freeb - (op->d_ws ? 0.0 : krylov)));

@@ -158,6 +158,8 @@ class BaseMPDist(BaseDist):
         subs = self.subProblems
         if not self.parallel:
             return (self._scaled(sub * get(i)) for i, sub in enumerate(subs))
+        # a previous call whose results were not drained must not keep driving the same operator handles (they are not thread-safe)
+        self._stop_workers()
         # every right-hand side is taken now, in order, like the reference's apply_async loop (distributors.py:161-166)
         devs = self.devices
         nd = len(devs)
@@ -196,22 +198,31 @@ class BaseMPDist(BaseDist):
                 queues[w].append(it)
                 row.append((it, w))
             parts.append(row)
-        # what `wpd` concurrent solves on a GPU take from the library's pools is brought into being before the workers start: a
-        # hipMalloc issued beside running kernels and copies can take a second (helm_reserve)
-        booked = {}
-        for w, q in enumerate(queues):
-            if q:
-                booked.setdefault(workers[w], []).append(q[0])
-        for dev, firsts in booked.items():
-            owner = firsts[0].owner
-            if hasattr(owner, 'reserve'):
-                owner.reserve(max(it.ncol for w, q in enumerate(queues) if workers[w] == dev for it in q), rows=firsts[0].nrow, concurrent=len(firsts))
-        # (3-D operators build their preconditioner in the prepare step: strictly one item ahead of the solve)
-        self._pipes = dispatch.dispatch(list(zip(workers, queues)), lookahead=1, strict=any(getattr(s_, 'heavyPrepare', False) for s_ in subs[:1]))
         self._throttles = throttles
+        strict = any(getattr(s_, 'heavyPrepare', False) for s_ in subs[:1])      # (3-D operators build their preconditioner in the prepare step: strictly one item ahead of the solve)
+
+        def start():
+            # what `wpd` concurrent solves on a GPU take from the library's pools is brought into being before the workers start: a
+            # hipMalloc issued beside running kernels and copies can take a second (helm_reserve)
+            booked = {}
+            for w, q in enumerate(queues):
+                if q:
+                    booked.setdefault(workers[w], []).append(q[0])
+            for dev, firsts in booked.items():
+                owner = firsts[0].owner
+                if hasattr(owner, 'reserve'):
+                    owner.reserve(max(it.ncol for w, q in enumerate(queues) if workers[w] == dev for it in q), rows=firsts[0].nrow, concurrent=len(firsts))
+            hook = self.__dict__.get('_after_reserve')            # (tests: called once the bookings are made and before any worker starts)
+            if hook:
+                hook()
+            self._pipes = dispatch.dispatch(list(zip(workers, queues)), lookahead=1, strict=strict)
 
         def results():
+            # the workers start with the first result that is asked for (the body of a generator runs from the first next() on): a result object
+            # that is dropped without being iterated never starts a thread, one that is dropped half-way closes its throttles in `finally`
+            # (which the interpreter runs when the generator is collected)
             try:
+                start()
                 for row in parts:
                     cols = []
                     for it, w in row:
@@ -233,14 +244,17 @@ class BaseMPDist(BaseDist):
             return True
         return any(rep.factors for rep in self.__dict__.get('_replicas', {}).values())
 
-    @factors.deleter
-    def factors(self):
+    def _stop_workers(self):
         for t in self.__dict__.get('_throttles', []):      # (a half-consumed result generator must not keep the workers waiting)
             t.close()
         for p in self.__dict__.get('_pipes', []):
             p.join()
         self._pipes = []
         self._throttles = []
+
+    @factors.deleter
+    def factors(self):
+        self._stop_workers()
         DiscretizationWrapper.factors.fdel(self)
         for rep in self.__dict__.get('_replicas', {}).values():
             del rep.factors
