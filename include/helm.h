@@ -180,6 +180,11 @@ int helm_prefactor(helm_op *op);
  * factorisation of its directly solved level are built NOW, in the calling thread (hundreds of ms): a dispatcher's prepare thread calls this
  * for frequency k+1 while another handle iterates on frequency k.  A hint like helm_prefactor. */
 int helm_prefactor_n(helm_op *op, int nrhs);
+/* The relative tolerance the solves on this operator will ask for, told before its factors are built (helm_prefactor takes no options):
+ * fronts whose condition estimate exceeds rtol / (8 eps) are re-eliminated with a pivoted LU so that one pass meets rtol.  Default 1e-10;
+ * a solve that builds the factors itself uses its own opts->rtol.  Counterpart of the `Solver` the reference receives through its
+ * systemConfig (discretization.py:23-31,83-84: SuperLU's pivoting is not negotiable there). */
+int helm_set_tolerance_hint(helm_op *op, double rtol);
 
 /* Scratch for `concurrent` host-array solves (helm_solve / helm_solve_coo) of `nrhs` right-hand sides with `rows` rows running at the
  * same time on this handle's GPU, allocated now instead of inside the first solves: the shared scratch slots of the direct path and the

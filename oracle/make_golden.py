@@ -266,6 +266,39 @@ def g8_25d():
     np.savez_compressed(os.path.join(OUT, 'g8_25d.npz'), **out)
 
 
+def g11_25d_survey():
+    """The 2.5-D pairing classes (zephyr/middleware/problem.py:225-238, survey.py:343-346).  In the reference itself
+    `Helm25DProblem({'Disc': MiniZephyr25D, ...})` cannot run: MultiFreq hands its own 'Disc' key down (distributors.py:254 masks only
+    'freqs'), MiniZephyr25D takes it as the discretisation of its ky sub-problems (minizephyr.py:353-370) and the nested MiniZephyr25D then
+    misses the masked 'nky' -- asserted below.  What the pairing is meant to compute is pinned from the reference's own parts instead:
+    the fields of `MiniZephyr25D(dict(sc, freq=f)) * q_f` with the sources of `Helm25DSurvey.getSources()`, projected by
+    `Helm25DSurvey._lazyProjectFields` (survey.py:152-160)."""
+    from zephyr.middleware import Helm25DProblem, Helm25DSurvey
+    nz, nx = 48, 64
+    rng = np.random.default_rng(77)
+    c = 2200. + 900. * rng.random((nz, nx))
+    rho = 1000. + 150. * rng.random((nz, nx))
+    src = np.stack([np.linspace(120, 500, 5), np.full(5, 90.)], 1)
+    rec = np.stack([np.linspace(80, 560, 7), np.full(7, 380.)], 1)
+    sterms = np.array([1.0 + 0.25j, 0.8 - 0.1j])
+    freqs = [7., 11.]
+    sc = dict(nx=nx, nz=nz, dx=10., dz=10., c=c, rho=rho, nPML=6, freqs=freqs, Disc=zb.MiniZephyr25D, nky=6, parallel=False,
+              sterms=sterms, geom=dict(src=src, rec=rec, mode='fixed'))
+    prob, surv = Helm25DProblem(sc), Helm25DSurvey(sc)
+    prob.pair(surv)
+    try:
+        surv.dpred()
+        raise AssertionError('the reference pairing ran: regenerate g11 from it directly')
+    except ValueError as exc:
+        assert 'nky' in str(exc), exc
+    qs = surv.getSources()
+    base = {k: v for k, v in sc.items() if k not in ('freqs', 'Disc')}
+    u = [zb.MiniZephyr25D(dict(base, freq=f)) * qs[i] for i, f in enumerate(freqs)]
+    d = surv._lazyProjectFields(u).ravel()
+    out = dict(c=c, rho=rho, src=src, rec=rec, sterms=sterms, freqs=np.array(freqs), nky=6, dpred=d, u_f0_src2=np.asarray(u[0])[:, 2])
+    np.savez_compressed(os.path.join(OUT, 'g11_25d_survey.npz'), **out)
+
+
 def ibm_to_float(words):
     '''IBM System/360 single precision (big-endian uint32 words) -> float64'''
     w = np.asarray(words, dtype=np.uint64)
@@ -384,8 +417,8 @@ def g7_analytic():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10']
-    table = dict(g1=g1_minizephyr_planes, g2=g2_eurus_planes, g3=g3_wavefields, g4=g4_multifreq, g5=g5_sources, g6=g6_survey, g7=g7_analytic, g8=g8_25d, g9=g9_xhlayr, g10=g10_omega)
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11']
+    table = dict(g1=g1_minizephyr_planes, g2=g2_eurus_planes, g3=g3_wavefields, g4=g4_multifreq, g5=g5_sources, g6=g6_survey, g7=g7_analytic, g8=g8_25d, g9=g9_xhlayr, g10=g10_omega, g11=g11_25d_survey)
     for name in which:
         table[name]()
         print('wrote', name, flush=True)

@@ -17,3 +17,11 @@ class OracleMiniZephyr(za.MiniZephyr):
 
 class OracleMiniZephyrHD(za.MiniZephyrHD, OracleMiniZephyr):
     __mul__ = OracleMiniZephyr.__mul__
+
+
+class OracleMiniZephyr25D(za.MiniZephyr25D):
+    'the ky sum with CPU-oracle sub-problems'
+
+    @property
+    def Disc(self):
+        return OracleMiniZephyr

@@ -78,6 +78,7 @@ _SIGNATURES = {
     'helm_prefactor': (ctypes.c_int, [ctypes.c_void_p]),
     'helm_prefactor_n': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'helm_reserve': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_int]),
+    'helm_set_tolerance_hint': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double]),
     'helm_last_timing': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Timing)]),
     'helm_set_profiling': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'helm_imaging_accumulate_device': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,

@@ -1613,6 +1613,15 @@ static int prefactor3d(helm_op *op, int nrhs) {
     return HELM_OK;
 }
 
+// The tolerance the solves on this operator will ask for, told BEFORE its factors are built (helm_prefactor has no options argument): which
+// ill-conditioned fronts get the pivoted-LU treatment follows from it (direct.hip, stabilise_group).  Every solve records its own rtol as well,
+// so a factorisation that happens inside a solve needs no hint.
+extern "C" int helm_set_tolerance_hint(helm_op *op, double rtol) {
+    if (!op || !(rtol > 0)) return HELM_ERR_ARG;
+    op->rtol_hint = rtol;
+    return HELM_OK;
+}
+
 extern "C" int helm_prefactor_n(helm_op *op, int nrhs) {
     if (!op) return HELM_ERR_ARG;
     if (!op->assembled) HELM_FAIL(op, HELM_ERR_STATE, "operator not assembled");
@@ -1722,6 +1731,7 @@ extern "C" int helm_solve_device(helm_op *op, const void *dRHS, void *dU, int nr
     if (opts) o = *opts; else { o.method = HELM_AUTO; o.rtol = 1e-10; o.maxit = 200000; o.check_every = 0; o.batch = 0; o.flags = 0; }
     if (!(o.rtol > 0)) o.rtol = 1e-10;
     if (o.maxit < 1) o.maxit = 200000;
+    if (!op->direct[0] && !op->pf_pending) op->rtol_hint = o.rtol;      // (factors that exist, or are on their way, were conditioned for the hint they were given)
     if (info) for (int r = 0; r < nrhs; ++r) { info[r].iterations = 0; info[r].status = 0; info[r].restarts = 0; info[r].method = o.method; info[r].relres = 0.0; }
     const cplx premul = cmake(premul_re, premul_im);
 

@@ -2386,9 +2386,9 @@ bool merged_leaf_backward() {
 // front ~0.15 ms at factor time and per pass, 0-15 fronts per frequency are taken, and 5 of 16 frequencies save a refinement pass of 8-20 ms.
 // (A first version with one thread per column in the triangular solves and a threshold of 2e4 that also watched the leaves was correct but
 // slower than doing nothing: 7775 wavefields/s.)
-// HELM_ND_STABLE_THR: a front is taken when its condition estimate ||F11||_inf ||F11^-1||_inf
-// exceeds it (default 1e5: at 1024^2 / 9 Hz a handful of 32 767 fronts, which between them are the difference between a first-pass residual
-// of 4e-9 and 2e-12; a typical leaf sits at 20-40, the tree top at 50-1000).
+// A front is taken when its condition estimate ||F11||_inf ||F11^-1||_inf exceeds rtol / (8 eps) (see stabilise_group; 1.1e5 at rtol 1e-10: at
+// 1024^2 / 9 Hz a handful of 32 767 fronts, which between them are the difference between a first-pass residual of 4e-9 and 2e-12; a typical
+// leaf sits at 20-40, the tree top at 50-1000).
 // Fronts of more than HELM_ND_STABLE_SMAX (128) separator unknowns are left alone: the one-workgroup LU would cost more than the
 // refinement pass it saves, and none that large has been seen ill-conditioned (the tree top sits at cond 50-1000)
 bool stable_enabled(const NdPlan &P) {
@@ -2419,7 +2419,15 @@ int stabilise_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *wor
     const NdPlan &P = f->pd->plan;
     const NdGroup &g = P.groups[gi];
     hipStream_t st = op->stream;
-    const double thr = getenv("HELM_ND_STABLE_THR") ? atof(getenv("HELM_ND_STABLE_THR")) : 1e5;
+    // Which fronts are taken follows from the tolerance the factors are built for, not from a constant fitted to one model: an explicit inverse of a
+    // front with condition number kappa leaves a first-pass residual of about kappa * eps (measured front by front, DESIGN.md 5.1: 8.8e5 -> 4e-9),
+    // and it has to stay below rtol with a margin for the handful of such fronts that add up and for what the estimate ||F11||_inf ||F11^-1||_inf
+    // misses:   kappa_max = rtol / (HELM_ND_STABLE_SAFETY * eps),  safety 8 by default  ->  1.1e5 at the 1e-10 of the reference parity tests, 1.1e7
+    // at 1e-8, 1.1e3 at 1e-12 (where most fronts of the middle levels would be taken: the floor of 2e3 keeps the treatment a handful-of-fronts
+    // affair and leaves the rest to the refinement pass, which always exists).  HELM_ND_STABLE_THR overrides with a fixed number.
+    const double safety = getenv("HELM_ND_STABLE_SAFETY") ? std::max(1.0, atof(getenv("HELM_ND_STABLE_SAFETY"))) : 8.0;
+    const double rt = op->rtol_hint > 0 ? op->rtol_hint : 1e-10;
+    const double thr = getenv("HELM_ND_STABLE_THR") ? atof(getenv("HELM_ND_STABLE_THR")) : std::min(1e9, std::max(2e3, rt / (safety * 1.1102230246251565e-16)));
     const int nmax = g.smax + g.mmax;
     int *d_list = (int *)(f->d_est + 2 * (size_t)g.cnt);
     HIP_TRY(op, hipMemsetAsync(d_list, 0, sizeof(int), st));

@@ -150,6 +150,7 @@ struct helm_op {
     std::vector<std::pair<int, double>> ev_pending;   // (event-pair index, bytes)
     std::vector<std::pair<int, double>> ev_pending_gemm;   // (event-pair index, flops) of the direct solver's GEMM launches / runs of launches
     std::vector<int> ev_pending_gemm_n;                    // launches covered by each pair
+    double rtol_hint = 1e-10;                              // tolerance the next factorisation is conditioned for (helm_set_tolerance_hint; every solve records its own)
     std::vector<long long> ev_pending_gemm_shape;          // (HELM_GEMM_LOG=1) M, N, K, batch, addressing mode of each record, five entries apiece
     std::vector<double> ev_pending_gemm_bytes, ev_pending_gemm_sol;   // operand bytes and roofline time (ms) of the same launches
     int gemm_run_depth = 0, gemm_run_launches = 0;         // back-to-back GEMM launches timed with ONE event pair (direct.hip)

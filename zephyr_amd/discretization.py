@@ -144,7 +144,9 @@ class BaseDiscretization(BaseModelDependent):
         hierarchy here, in the calling thread (helm_prefactor_n: `nrhs` = right-hand sides the solve will bring)."""
         m = str(self.method).lower()
         if m in ('auto', 'direct') or (m == 'mg' and getattr(self, 'heavyPrepare', False)):
-            _lib.check(_lib.load().helm_prefactor_n(self.handle, int(nrhs or 0)), self.handle)
+            lib = _lib.load()
+            lib.helm_set_tolerance_hint(self.handle, float(self.rtol))      # the factors are conditioned for the tolerance the solves will ask for
+            _lib.check(lib.helm_prefactor_n(self.handle, int(nrhs or 0)), self.handle)
 
     def reserve(self, nrhs, rows=None, concurrent=1):
         """Bring into being what `concurrent` host-array solves of `nrhs` right-hand sides on this operator's GPU take from the

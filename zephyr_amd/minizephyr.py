@@ -70,7 +70,11 @@ class MiniZephyr25D(BaseDiscretization, DiscretizationWrapper):
 
     @property
     def Disc(self):
-        if getattr(self, '_Disc', None) is None:
+        """discretisation of the ky sub-problems.  A frequency dispatcher hands its own 'Disc' key down (distributors.py:254 masks only 'freqs'),
+        so under `Helm25DProblem` / `MultiFreq(Disc=MiniZephyr25D)` this class finds ITSELF there: in the reference that recursion ends in
+        "requires parameter 'nky'" (minizephyr.py:353-370; oracle/make_golden.py g11 asserts it), here it means the default."""
+        d = getattr(self, '_Disc', None)
+        if d is None or (isinstance(d, type) and issubclass(d, MiniZephyr25D)):
             self._Disc = MiniZephyr
         return self._Disc
 

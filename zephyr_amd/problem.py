@@ -19,7 +19,7 @@ import scipy.sparse as sp
 from .base import BaseModelDependent
 from .config import BaseSCCache
 from .distributors import MultiFreq, ViscoMultiFreq
-from .survey import HelmBaseSurvey, Helm2DSurvey
+from .survey import HelmBaseSurvey, Helm2DSurvey, Helm25DSurvey
 from . import parallel
 from . import dispatch
 
@@ -381,3 +381,22 @@ class Helm2DProblem(HelmBaseProblem):
 class Helm2DViscoProblem(Helm2DProblem):
 
     SystemWrapper = ViscoMultiFreq
+
+
+class Helm25DProblem(HelmBaseProblem):
+    """2.5-D counterpart of Helm2DProblem (zephyr/middleware/problem.py:225-235): same machinery, paired with Helm25DSurvey; the caller's
+    systemConfig names `Disc = MiniZephyr25D` (and `nky`), every frequency is a sum over cross-line wavenumbers."""
+
+    initMap = {
+        'SystemWrapper':    (False,    None,        None),
+    }
+
+    surveyPair = Helm25DSurvey
+    SystemWrapper = MultiFreq
+
+
+class Helm25DViscoProblem(Helm25DProblem):
+    'zephyr/middleware/problem.py:236-238'
+
+    SystemWrapper = ViscoMultiFreq
+

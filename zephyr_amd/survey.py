@@ -163,3 +163,9 @@ class HelmBaseSurvey(BaseSCCache):
 
 class Helm2DSurvey(HelmBaseSurvey):
     pass
+
+
+class Helm25DSurvey(HelmBaseSurvey):
+    'zephyr/middleware/survey.py:343-346'
+    pass
+
