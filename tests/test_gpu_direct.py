@@ -437,3 +437,52 @@ def test_lu_treatment_forced_on_many_fronts(helm_lib, monkeypatch, seed):
     assert all(i['status'] == 0 and i['relres'] <= 1e-10 for i in op.lastInfo), op.lastInfo
     assert nrm(u, ref) <= 1e-7, (seed, nrm(u, ref))
     del op.factors
+
+
+@pytest.mark.parametrize('force_pivoted', [0, 1])
+@pytest.mark.parametrize('cls,nz,nx,fs', [('MiniZephyr', 64, 64, (0, 0, 0, 0)), ('Eurus', 70, 90, (0, 0, 0, 0)), ('MiniZephyr', 41, 150, (1, 0, 0, 1)),
+                                          ('Eurus', 128, 128, (0, 0, 0, 0)), ('MiniZephyr', 57, 33, (0, 1, 1, 0))])
+def test_fused_leaf_level_matches_sparse_lu(helm_lib, monkeypatch, cls, nz, nx, fs, force_pivoted):
+    """The leaf level in one kernel (k_leaf_factor: banded LU + per-column substitution straight from the coefficient planes) on grids whose
+    leaves have every shape between 3 and 8 cells a side, with free surfaces, and -- force_pivoted -- every leaf re-done by the row-pivoted
+    fall-back kernel.  (By default only leaf groups of 2048 fronts or more take that kernel: the small grids of this suite would never see it.)"""
+    import zephyr_amd as za
+    monkeypatch.setenv('HELM_ND_FUSEDLEAF_MIN', '1')
+    if force_pivoted:
+        monkeypatch.setenv('HELM_LEAF_DBG', '8')
+    rng = np.random.default_rng(nz * 3 + nx)
+    c = 1700. + 2500. * rng.random((nz, nx))
+    rho = 1000. + 500. * rng.random((nz, nx))
+    cfg = dict(nx=nx, nz=nz, dx=10., dz=12., c=c, rho=rho, freq=11., nPML=6, rtol=1e-11, method='direct', freeSurf=fs)
+    op = getattr(za, cls)(cfg)
+    q = za.SimpleSource(cfg)(np.array([[nx * 3.3, nz * 4.1], [nx * 6.0, nz * 7.7], [25., 30.]]))
+    u = op * q
+    if cls == 'MiniZephyr':
+        C = ho.minizephyr_coefficients(nz, nx, c, rho, 11., dx=10., dz=12., nPML=6, freeSurf=fs)
+        ref = ho.DirectOperator(C) * q
+    else:
+        ref = ho.DirectOperator(ho.eurus_coefficients(nz, nx, c, rho, 11., dx=10., dz=12., nPML=6), eurus=True) * q
+    assert nrm(u, ref) <= 1e-8
+    assert all(i['status'] == 0 and i['relres'] <= 1e-11 for i in op.lastInfo), op.lastInfo
+    # ... and bit-for-bit what the batched leaf path returns is NOT required (other elimination order), only the same wavefield
+    monkeypatch.setenv('HELM_ND_FUSEDLEAF', '0')
+    op2 = getattr(za, cls)(cfg)
+    assert nrm(op2 * q, u) <= 1e-9
+
+
+def test_fused_leaf_level_at_coarse_sampling_falls_back_where_it_must(helm_lib, monkeypatch):
+    """Few points per wavelength make the leaf blocks indefinite: elimination without pivoting then meets small pivots in some of them, the
+    kernel flags those leaves and the pivoted kernel re-does them -- the wavefield must come out right either way."""
+    import zephyr_amd as za
+    monkeypatch.setenv('HELM_ND_FUSEDLEAF_MIN', '1')
+    nz = nx = 96
+    rng = np.random.default_rng(5)
+    c = 1500. + 300. * rng.random((nz, nx))
+    cfg = dict(nx=nx, nz=nz, dx=10., dz=10., c=c, freq=30., nPML=8, rtol=1e-10, method='direct')          # ~5 points per wavelength
+    op = za.MiniZephyr(cfg)
+    q = za.SimpleSource(cfg)(np.array([[300., 320.], [610., 450.]]))
+    u = op * q
+    C = ho.minizephyr_coefficients(nz, nx, c, op.rho, 30., dx=10., dz=10., nPML=8)
+    ref = ho.DirectOperator(C) * q
+    assert nrm(u, ref) <= 1e-7
+    assert all(i['status'] in (0, 3) for i in op.lastInfo), op.lastInfo

@@ -1,0 +1,14 @@
+cd $GRAFT_REPO_ROOT
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r4_h; mkdir -p $OUT
+timeout 1500 python -m pytest tests/test_gpu_direct.py tests/test_gpu_stable_fronts.py -x -q -m gpu 2>&1 | tail -8
+HELM_ND_TRACE=1 python3 tools/bench_direct.py --freqs 5.5 > $OUT/trace.txt 2>&1
+grep "nd trace" $OUT/trace.txt | head -52 | grep -E "total|leaf"
+tail -1 $OUT/trace.txt | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); print([ (r['solves'], r['relres']) for r in d['runs']])"
+python3 bench.py --no-cpu --no-config5 --no-host-api --steps 16 --warmup 4 > $OUT/bench.json 2> $OUT/bench.err
+python3 - <<PY
+import json
+d=json.loads(open('$OUT/bench.json').read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'], d['config']['driver_visible'])
+PY
