@@ -486,3 +486,33 @@ def test_fused_leaf_level_at_coarse_sampling_falls_back_where_it_must(helm_lib, 
     ref = ho.DirectOperator(C) * q
     assert nrm(u, ref) <= 1e-7
     assert all(i['status'] in (0, 3) for i in op.lastInfo), op.lastInfo
+
+
+@pytest.mark.parametrize('nsrc', [3, 70, 200])
+def test_sparse_right_hand_sides_skip_nothing_that_matters(helm_lib, monkeypatch, nsrc):
+    """The forward pass leaves out the fronts whose right-hand-side rows and whose children's rows are all zero in a block of 64 columns
+    (GemmRows::act).  Point sources, sources in some column blocks only, a dense random right-hand side and an all-zero column: bit for bit the
+    wavefields of the pass that computes every front (HELM_ND_SPARSE_RHS=0)."""
+    import zephyr_amd as za
+    nz, nx = 150, 170
+    rng = np.random.default_rng(nsrc)
+    c = 1800. + 2000. * rng.random((nz, nx))
+    cfg = dict(nx=nx, nz=nz, dx=10., dz=10., c=c, freq=8., nPML=8, rtol=1e-10, method='direct', batch=256)
+    locs = np.stack([rng.uniform(100., 10. * nx - 100., nsrc), rng.uniform(20., 60., nsrc)], axis=1)       # near the surface, like a survey's sources
+    q = za.SparseKaiserSource(cfg)(locs).toarray()
+    q[:, 1] = 0.0                                                    # a column without a source
+    if nsrc > 64:
+        q[:, 64:128] = 0.0                                           # a whole block of 64 columns without any
+        q[:, -1] = rng.standard_normal(nz * nx) + 1j * rng.standard_normal(nz * nx)      # and a dense one
+    out = {}
+    monkeypatch.setenv('HELM_ND_POISON', '1')              # unwritten front-vector rows are NaN: a read that a flag should have masked cannot hide
+    for mode in ('1', '0'):
+        monkeypatch.setenv('HELM_ND_SPARSE_RHS', mode)
+        op = za.Eurus(cfg)
+        out[mode] = op * q
+        assert all(i['status'] == 0 for j, i in enumerate(op.lastInfo) if np.any(q[:, j])), op.lastInfo
+        del op.factors
+    assert np.array_equal(out['1'], out['0'])
+    assert not np.any(out['1'][:, 1])
+    ref = ho.DirectOperator(ho.eurus_coefficients(nz, nx, c, za.Eurus(cfg).rho, 8., dx=10., dz=10., nPML=8), eurus=True) * q[:, [0, 2, nsrc - 1]]
+    assert nrm(out['1'][:, [0, 2, nsrc - 1]], ref) <= 1e-7

@@ -336,6 +336,10 @@ struct GemmRows {
     int schur4 = 0;
     const NdDev *nodes = nullptr; int first = 0;
     const cplx *arenaS = nullptr;
+    // forward pass on sparse right-hand sides (sources of a survey touch a handful of cells): act[front * nct + column / 64] != 0 when that front's
+    // outgoing rows were computed for that block of 64 columns -- a front whose own right-hand-side rows and whose children's rows are all zero
+    // there has nothing to add, writes zeros for its y_S rows and leaves its ring rows unwritten (its parent reads the flag, not the rows)
+    int *act = nullptr; int nct = 0;
 };
 #define GB_K 8
 #define GB_KIDX 512       // largest K with indexed B rows
@@ -711,6 +715,39 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
         for (int k = tid; k < K; k += 256) kidx4[k] = R.tabB[trow + R.offB + k];
         __syncthreads();
     }
+    // (IDX 2, sparse right-hand sides) bit j of am0 / am1: child 0 / 1 has outgoing rows for the j-th block of 64 columns of this tile
+    unsigned am0 = ~0u, am1 = ~0u;
+    if (IDX == 2 && R.act) {
+        const int node = R.first + R.z0 + blockIdx.z;
+        const NdDev nd = R.nodes[node];
+        const int ct0 = n0 >> 6, ncl = ((Nn - n0 < TN ? Nn - n0 : TN) + 63) >> 6;
+        am0 = 0; am1 = 0;
+        for (int j = 0; j < ncl; ++j) {
+            if (nd.kid[0] >= 0 && R.act[nd.kid[0] * R.nct + ct0 + j]) am0 |= 1u << j;
+            if (nd.kid[1] >= 0 && R.act[nd.kid[1] * R.nct + ct0 + j]) am1 |= 1u << j;
+        }
+        int nzq = 0;                                                     // any nonzero among the front's own right-hand-side rows in these columns?
+        // (over whole blocks of 64 columns: the workgroups of a tile narrower than that share a flag and must all come to the same verdict)
+        constexpr int TS = TN < 64 ? 64 : TN;
+        const int ns0 = TN < 64 ? (n0 & ~63) : n0;
+        if (!(am0 | am1))
+            for (int e = tid; e < K * TS; e += 256) {
+                const int k = e / TS, bc = e % TS;
+                const int4 t4 = kidx4[k];
+                if (t4.w && ns0 + bc < Nn) { const cplx v = R.Bx[(long long)t4.x * R.ldx + ns0 + bc]; nzq |= (v.x != 0.0 || v.y != 0.0); }
+            }
+        if (!(am0 | am1) && !__syncthreads_or(nzq)) {
+            if (blockIdx.y == 0 && R.Cox)                                // y_S = 0 where the back substitution will look for it
+                for (int e = tid; e < K * TN; e += 256) {
+                    const int k = e / TN, bc = e % TN;
+                    const int4 t4 = kidx4[k];
+                    if (t4.w && n0 + bc < Nn) R.Cox[(long long)t4.x * R.ldx + n0 + bc] = cmake(0.0, 0.0);
+                }
+            return;
+        }
+        if (blockIdx.y == 0 && tid < ncl) R.act[node * R.nct + ct0 + tid] = 1;
+    }
+    int nzb = 0;                                                         // (IDX 1 with act: leaf level) bit j: a nonzero right-hand-side entry in the j-th block of 64 columns
     __shared__ int2 sgr[IDX == 4 ? TM : 1], sgc[IDX == 4 ? TN : 1];
     const cplx *S0 = nullptr, *S1 = nullptr;
     int ld0 = 0, ld1 = 0;
@@ -757,11 +794,14 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
                 if (IDX == 2) {
                     const int4 t4 = kidx4[k0 + bk];
                     if (t4.w) v = R.Bx[(long long)t4.x * R.ldx + n0 + bc];
-                    if (t4.y >= 0) v = cadd(v, R.Cix[(long long)t4.y * R.ldx + n0 + bc]);
-                    if (t4.z >= 0) v = cadd(v, R.Cix[(long long)t4.z * R.ldx + n0 + bc]);
+                    if (t4.y >= 0 && ((am0 >> (bc >> 6)) & 1)) v = cadd(v, R.Cix[(long long)t4.y * R.ldx + n0 + bc]);
+                    if (t4.z >= 0 && ((am1 >> (bc >> 6)) & 1)) v = cadd(v, R.Cix[(long long)t4.z * R.ldx + n0 + bc]);
                     if (blockIdx.y == 0 && t4.w && R.Cox) R.Cox[(long long)t4.x * R.ldx + n0 + bc] = v;      // y_S
                 }
-                else if (idxB) { const int r = kidx[k0 + bk]; if (r >= 0) v = (k0 + bk < R.k2 ? R.Bx2 : R.Bx)[(long long)r * R.ldx + n0 + bc]; }
+                else if (idxB) {
+                    const int r = kidx[k0 + bk];
+                    if (r >= 0) v = (k0 + bk < R.k2 ? R.Bx2 : R.Bx)[(long long)r * R.ldx + n0 + bc];
+                }
                 else v = B[(long long)(k0 + bk) * ldb + n0 + bc];
             }
             rb[e] = v;
@@ -779,6 +819,9 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
             const int idx = tid + e * 256;
             const int bk = idx / TN, bc = idx % TN;
             if (idx < TN * KS) Bs[buf * BBUF + ((bk >> 2) * FB + (bc >> 4)) * 64 + (bk & 3) * 16 + (bc & 15)] = rb[e];
+            // (leaf level of the sparse-right-hand-side pass: looked at HERE, where the slab is in registers anyway -- testing the value in fetch()
+            // made every load wait for its data and cost the kernel half of its bandwidth)
+            if (IDX == 1 && R.act) { const long long bx = __double_as_longlong(rb[e].x) | __double_as_longlong(rb[e].y); nzb |= (bx << 1) ? 1 << (bc >> 6) : 0; }
         }
     };
     fetch(0);
@@ -825,6 +868,21 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
         }
         if (more) { stash(cur ^ 1); __syncthreads(); cur ^= 1; }
     }
+    unsigned colmask = ~0u;                                              // blocks of 64 columns of this tile whose results are stored
+    if (IDX == 1 && R.act) {                                             // leaf level: which blocks of 64 columns carry a right-hand side at all
+        const int node = R.first + R.z0 + blockIdx.z;
+        colmask = 0;
+        #pragma unroll
+        for (int j = 0; j < (TN + 63) / 64; ++j)
+            if (__syncthreads_or((nzb >> j) & 1)) {
+                colmask |= 1u << j;
+                if (blockIdx.y == 0 && tid == 0 && (n0 >> 6) + j < R.nct) R.act[node * R.nct + (n0 >> 6) + j] = 1;
+            }
+        // tiles narrower than a block of 64 columns share its flag with their neighbours: another workgroup may raise it, so this one writes its
+        // zeros; from 64 columns up nothing but zeros coming in means the rows stay unwritten and the flag stays 0
+        if (TN < 64) colmask = ~0u;
+        if (!colmask) return;
+    }
     const bool b0 = (beta.x == 0.0 && beta.y == 0.0);
     // Epilogue, one block row of 16 at a time: first the addresses of its four rows (row-table look-ups), then EVERY value of C that has to be
     // read (beta != 0, the forward gather's child rows, the Schur gather's child entries) with the loads issued back to back -- masked elements
@@ -867,15 +925,16 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
             #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int cc = n0 + (wn * NT + j) * 16 + lr;
-                const bool ok = rowok[q] && cc < Nn;
+                const bool ok = rowok[q] && cc < Nn && ((colmask >> (((wn * NT + j) * 16 + lr) >> 6)) & 1);
                 if (IDX == 4) {
                     const int2 ec = sgc[cc < Nn ? cc - n0 : 0];
                     const cplx *p0 = (ok && erq[q].x >= 0 && ec.x >= 0) ? S0 + (long long)erq[q].x * ld0 + ec.x : g_zero_page;
                     const cplx *p1 = (ok && erq[q].y >= 0 && ec.y >= 0) ? S1 + (long long)erq[q].y * ld1 + ec.y : g_zero_page;
                     cv[q][j] = cadd(*p0, *p1);
                 } else if (IDX == 2) {
-                    const cplx *p0 = (ok && cinq[q]) ? cinq[q] + cc : g_zero_page;
-                    const cplx *p1 = (ok && cin2q[q]) ? cin2q[q] + cc : g_zero_page;
+                    const int cl = ((wn * NT + j) * 16 + lr) >> 6;          // block of 64 columns inside the tile
+                    const cplx *p0 = (ok && cinq[q] && ((am0 >> cl) & 1)) ? cinq[q] + cc : g_zero_page;
+                    const cplx *p1 = (ok && cin2q[q] && ((am1 >> cl) & 1)) ? cin2q[q] + cc : g_zero_page;
                     cv[q][j] = cadd(*p0, *p1);
                 } else {
                     const cplx *p0 = (ok && cinq[q] && !(cc >= R.zc0 && cc < R.zc1)) ? cinq[q] + cc : g_zero_page;
@@ -889,7 +948,7 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
             #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int cc = n0 + (wn * NT + j) * 16 + lr;
-                if (!rowok[q] || cc >= Nn) continue;
+                if (!rowok[q] || cc >= Nn || !((colmask >> (((wn * NT + j) * 16 + lr) >> 6)) & 1)) continue;
                 if (srow && cc >= R.sk0 && cc < R.sk1) continue;
                 cplx v = cmul(alpha, cmake(cr[i][j][q], ci[i][j][q]));
                 if (IDX == 4) v = cadd(cv[q][j], v);
@@ -2160,17 +2219,22 @@ __global__ __launch_bounds__(256) void k_nd_build_tab(const NdDev *nodes, int fi
 
 // forward pass, one group: V[row] = [separator row: Xt[cell]] + outgoing rows of the children; separator rows of
 // non-leaf fronts are final (y_S) and written back to Xt.  blockDim = (LX, 256 / LX), LX lanes over the right-hand sides.
-__global__ __launch_bounds__(256) void k_nd_fwd_rows(const int4 *tab, cplx *V, const cplx *arenaV, const cplx *Qt, cplx *Xt, long long rows, int nrhs, int write_back) {
+// act (may be null): flags of the sparse-right-hand-side forward pass (GemmRows::act) -- a child's rows count only where its flag is set;
+// nodes / first / nmax: the fronts these rows belong to (row / nmax-th front from `first`)
+__global__ __launch_bounds__(256) void k_nd_fwd_rows(const int4 *tab, cplx *V, const cplx *arenaV, const cplx *Qt, cplx *Xt, long long rows, int nrhs, int write_back,
+                                                     const int *act = nullptr, int nct = 0, const NdDev *nodes = nullptr, int first = 0, int nmax = 1) {
     for (long long row = (long long)blockIdx.x * blockDim.y + threadIdx.y; row < rows; row += (long long)gridDim.x * blockDim.y) {
         const int4 e = tab[row];
         cplx *dst = V + row * nrhs;
         const cplx *s0 = e.w ? Qt + (long long)e.x * nrhs : nullptr;
         const cplx *s1 = e.y >= 0 ? arenaV + (long long)e.y * nrhs : nullptr;
         const cplx *s2 = e.z >= 0 ? arenaV + (long long)e.z * nrhs : nullptr;
+        const int *a1 = nullptr, *a2 = nullptr;
+        if (act) { const NdDev nd = nodes[first + (int)(row / nmax)]; a1 = nd.kid[0] >= 0 ? act + (long long)nd.kid[0] * nct : nullptr; a2 = nd.kid[1] >= 0 ? act + (long long)nd.kid[1] * nct : nullptr; }
         for (int r = threadIdx.x; r < nrhs; r += blockDim.x) {
             cplx acc = s0 ? s0[r] : cmake(0.0, 0.0);
-            if (s1) acc = cadd(acc, s1[r]);
-            if (s2) acc = cadd(acc, s2[r]);
+            if (s1 && (!act || (a1 && a1[r >> 6]))) acc = cadd(acc, s1[r]);
+            if (s2 && (!act || (a2 && a2[r >> 6]))) acc = cadd(acc, s2[r]);
             dst[r] = acc;
             if (write_back && e.w) Xt[(long long)e.x * nrhs + r] = acc;
         }
@@ -2649,6 +2713,7 @@ void nd_free(NdFactor *f) {
     stable_free(f);
     if (f->d_est) helm_pool_free(f->pd ? f->pd->device : 0, f->d_est, f->est_elems * sizeof(double));
     if (f->d_leafflag) helm_pool_free(f->pd ? f->pd->device : 0, f->d_leafflag, f->leafflag_elems * sizeof(int));
+    if (f->d_act) helm_pool_free(f->pd ? f->pd->device : 0, f->d_act, f->act_elems * sizeof(int));
     if (f->d_fac) helm_pool_free(f->pd ? f->pd->device : 0, f->d_fac, (size_t)f->pd->plan.fac_elems * sizeof(cplx));
     delete f;
 }
@@ -2876,6 +2941,7 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
 struct SolveCtx {
     const int4 *tab; cplx *Xt, *arenaV; int nrhs; dim3 rb; int use_idx;
     const cplx *Qt;       // node-major right-hand sides (read only); == Xt for an in-place solve
+    int *act = nullptr; int nct = 0;     // sparse-right-hand-side flags of the forward pass (null: every front is computed)
     dim3 rgrid(long long rows) const { return dim3((unsigned)std::min<long long>((rows + rb.y - 1) / rb.y, 1 << 20)); }
 };
 
@@ -2903,7 +2969,9 @@ void forward_stable(helm_op *op, NdFactor *f, size_t gi, const SolveCtx &c) {
         cplx *V = c.arenaV + n.voff * nrhs;
         // the front vector gathered again: separator rows q_S + the children's rows (written to Xt as y_S for the back substitution), ring rows
         // the children's rows; then z = F11^-1 y_S through the LU and V_B -= F21 z
-        hipLaunchKernelGGL(k_nd_fwd_rows, c.rgrid(nmax), c.rb, 0, op->stream, c.tab + n.roff, V, c.arenaV, c.Qt, c.Xt, (long long)nmax, nrhs, g.leaf ? 0 : 1);
+        hipLaunchKernelGGL(k_nd_fwd_rows, c.rgrid(nmax), c.rb, 0, op->stream, c.tab + n.roff, V, c.arenaV, c.Qt, c.Xt, (long long)nmax, nrhs, g.leaf ? 0 : 1,
+                           (const int *)c.act, c.nct, (const NdDev *)f->pd->d_nodes, S.node, nmax);
+        if (c.act) hipMemsetAsync(c.act + (long long)S.node * c.nct, 1, (size_t)c.nct * sizeof(int), op->stream);      // (every row of this front has been written)
         hipLaunchKernelGGL(k_lu_solve, dim3((nrhs + 15) / 16), dim3(256), 0, op->stream, (const cplx *)S.lu, nmax, S.smax, (const int *)S.piv, V, nrhs, nrhs);
         gemm(op, S.mmax, nrhs, S.smax, mone, S.f21, S.smax, 0, V, nrhs, 0, one, V + (long long)S.smax * nrhs, nrhs, 0, 1);
     }
@@ -2926,8 +2994,11 @@ void forward_group_batched(helm_op *op, NdFactor *f, size_t gi, const SolveCtx &
     if (c.use_idx && g.leaf && g.mmax > 0 && g.smax <= GB_KIDX) {
         // leaves have no children: the outgoing ring part is -G21 x_S with x_S read straight from Xt
         GemmRows R; R.tabB = c.tab + g.roff; R.offB = 0; R.tab_stride = nmax; R.Bx = c.Qt; R.ldx = nrhs;
+        static const int leaf_detect = getenv("HELM_ND_SPARSE_LEAF") ? atoi(getenv("HELM_ND_SPARSE_LEAF")) : 1;
+        R.act = (gemm_variant() == 7 && leaf_detect) ? c.act : nullptr; R.nct = c.nct; R.first = g.first;
         gemm(op, g.mmax, nrhs, g.smax, mone, f->d_fac + g.g21, g.smax, (long long)g.mmax * g.smax, nullptr, 0, 0, zero,
              V + (long long)g.smax * nrhs, nrhs, (long long)nmax * nrhs, g.cnt, &R);
+        if (c.act && !R.act) hipMemsetAsync(c.act + (long long)g.first * c.nct, 1, (size_t)g.cnt * c.nct * sizeof(int), op->stream);
         return;
     }
     static const int fuse_fwd = getenv("HELM_ND_FUSEFWD") ? atoi(getenv("HELM_ND_FUSEFWD")) : 1;
@@ -2938,11 +3009,15 @@ void forward_group_batched(helm_op *op, NdFactor *f, size_t gi, const SolveCtx &
         // y_S stored to Xt on the way
         GemmRows R; R.fwd3 = 1; R.tabB = c.tab + g.roff; R.offB = 0; R.tabCi = c.tab + g.roff; R.offCi = g.smax; R.tab_stride = nmax;
         R.Bx = c.Qt; R.Cix = c.arenaV; R.Cox = c.Xt; R.ldx = nrhs;
+        R.act = gemm_variant() == 7 ? c.act : nullptr; R.nct = c.nct; R.first = g.first; R.nodes = f->pd->d_nodes;
         gemm(op, g.mmax, nrhs, g.smax, mone, f->d_fac + g.g21, g.smax, (long long)g.mmax * g.smax, nullptr, 0, 0, one,
              V + (long long)g.smax * nrhs, nrhs, (long long)nmax * nrhs, g.cnt, &R);
+        if (c.act && !R.act) hipMemsetAsync(c.act + (long long)g.first * c.nct, 1, (size_t)g.cnt * c.nct * sizeof(int), op->stream);
         return;
     }
-    hipLaunchKernelGGL(k_nd_fwd_rows, c.rgrid(rows), c.rb, 0, op->stream, c.tab + g.roff, V, c.arenaV, c.Qt, c.Xt, rows, nrhs, g.leaf ? 0 : 1);
+    hipLaunchKernelGGL(k_nd_fwd_rows, c.rgrid(rows), c.rb, 0, op->stream, c.tab + g.roff, V, c.arenaV, c.Qt, c.Xt, rows, nrhs, g.leaf ? 0 : 1,
+                       (const int *)c.act, c.nct, (const NdDev *)f->pd->d_nodes, g.first, nmax);
+    if (c.act) hipMemsetAsync(c.act + (long long)g.first * c.nct, 1, (size_t)g.cnt * c.nct * sizeof(int), op->stream);      // (these fronts write every row)
     if (g.mmax > 0)     // outgoing ring part: V_B -= G21 V_S
         gemm(op, g.mmax, nrhs, g.smax, mone, f->d_fac + g.g21, g.smax, (long long)g.mmax * g.smax, V, nrhs, (long long)nmax * nrhs, one,
              V + (long long)g.smax * nrhs, nrhs, (long long)nmax * nrhs, g.cnt);
@@ -3138,10 +3213,34 @@ int nd_solve(helm_op *op, NdFactor *f, const cplx *Xin, cplx *Xout, int nrhs, cp
 }
 
 // node-major solve: Qt (cells x nrhs, read only) -> Xt (may alias Qt); arenaV: 2 * vregion * nrhs elements
+// Flags of the forward pass on sparse right-hand sides, zeroed on `st` (HELM_ND_SPARSE_RHS=0: every front is computed, as before round 4).
+// A survey's sources touch a handful of grid cells (81 per Kaiser-windowed source at the surface): below the few fronts that contain them the
+// forward elimination multiplies zeros -- the reference hands such right-hand sides over as scipy-sparse matrices for the same reason
+// (survey.py:86-89, discretization.py:101-103).  Dense right-hand sides set every flag and cost one flag read per workgroup.
+static void arm_sparse_rhs(helm_op *op, NdFactor *f, SolveCtx &c, hipStream_t st) {
+    const int on = getenv("HELM_ND_SPARSE_RHS") ? atoi(getenv("HELM_ND_SPARSE_RHS")) : 1;        // (read per call: a test compares both)
+    c.act = nullptr; c.nct = 0;
+    if (!on || c.Qt == c.Xt || gemm_variant() != 7 || f->pd->plan.dof != 1) return;
+    const int nct = (c.nrhs + 63) / 64;
+    const size_t need = f->pd->plan.nodes.size() * (size_t)nct;
+    if (f->act_elems < need) {
+        if (f->d_act) { hipStreamSynchronize(st); helm_pool_free(op->device, f->d_act, f->act_elems * sizeof(int)); f->d_act = nullptr; f->act_elems = 0; }
+        const size_t want = f->pd->plan.nodes.size() * (size_t)std::max(4, nct);
+        f->d_act = (int *)helm_pool_alloc(op->device, want * sizeof(int));
+        if (!f->d_act) return;
+        f->act_elems = want;
+    }
+    if (hipMemsetAsync(f->d_act, 0, need * sizeof(int), st) != hipSuccess) { (void)hipGetLastError(); return; }
+    c.act = f->d_act; c.nct = nct;
+    // (tests) HELM_ND_POISON=1: the front-vector arena is filled with NaNs first, so that a read of rows no front has written shows up in the wavefield
+    if (getenv("HELM_ND_POISON") && atoi(getenv("HELM_ND_POISON"))) (void)hipMemsetAsync(c.arenaV, 0xFF, (size_t)2 * f->pd->plan.vregion * c.nrhs * sizeof(cplx), st);
+}
+
 int nd_solve_nm(helm_op *op, NdFactor *f, const cplx *Qt, cplx *Xt, int nrhs, cplx *arenaV) {
     const NdPlan &P = f->pd->plan;
     SolveCtx c = solve_ctx(f, Xt, nrhs);
     c.Qt = Qt; c.Xt = Xt; c.arenaV = arenaV;
+    arm_sparse_rhs(op, f, c, op->stream);
     GroupTrace tf(op->stream, "forward");
     for (size_t gi = 0; gi < P.groups.size(); ++gi) { forward_group(op, f, gi, c); tf.mark(); }
     tf.report(P, false);
@@ -3184,6 +3283,7 @@ int nd_factor_solve_nm(helm_op *op, int block, NdFactor *f, cplx *ws_factor, con
     hipEvent_t t0 = evs.timed[0], t1 = evs.timed[1];
     hipEventRecord(ev[ng], main);                 // the right-hand sides were prepared on the main stream
     hipStreamWaitEvent(side, ev[ng], 0);
+    arm_sparse_rhs(op, f, c, side);
     hipEventRecord(t0, main);
     for (size_t gi = 0; gi < ng && !rc; ++gi) {
         rc = factor_group(op, f, gi, ws_factor, ws_factor + 2 * P.fregion, planes);

@@ -69,6 +69,7 @@ struct NdFactor {
     double flops = 0;
     std::vector<NdStable> stable;
     double *d_est = nullptr; size_t est_elems = 0;      // per front of a group: max |F11| before, max |F11^-1| after the inversion; flag list
+    int *d_act = nullptr; size_t act_elems = 0;              // forward pass on sparse right-hand sides: per front and block of 64 columns, were its outgoing rows computed?
     int *d_leafflag = nullptr; size_t leafflag_elems = 0;     // per leaf of a group: 1 when the fused leaf kernel met a small pivot (the leaf is then re-done with pivoting)
 };
 
