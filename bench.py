@@ -501,10 +501,16 @@ def main():
     # Kernel-level roofline: in the pipelined region the factorisation of item k+1 shares the CUs with the solves of item k, so the
     # per-launch durations there measure the sharing (both kernels stretch).  The same K items therefore run once more strictly one after
     # the other with the events on; `roofline` quotes that pass, `roofline.in_pipeline` the stretched figures of the timed region itself.
+    # r4: this pass runs with HELM_ND_SPARSE_RHS=0, i.e. every front of the forward pass and every row of the leaf back substitution is
+    # multiplied whatever the right-hand sides hold -- gemm() books 8 M N K per launch, and a launch that skips the zero rows of a survey's point
+    # sources would be credited with flops it did not do.  (The pipelined figures `in_pipeline` come from the timed region, where the skipping
+    # is on: their TFLOP/s are marked `counts_skipped_flops`.)
     agg_k = agg
     if args.pipeline and args.streams <= 1:
         barrier()
+        os.environ['HELM_ND_SPARSE_RHS'] = '0'
         agg_k = aggregate([run_item(w, True) for w in timed_items])
+        os.environ.pop('HELM_ND_SPARSE_RHS', None)
         barrier()
 
     # the same K work items once more with the per-launch HIP events off: what the event traffic of the roofline measurement costs
@@ -515,6 +521,17 @@ def main():
         run_items(timed_items, False)
         barrier()
         elapsed_plain = max_over_ranks(time.perf_counter() - t1)
+    # ... and once more with the forward pass computing every front whatever the right-hand sides hold (HELM_ND_SPARSE_RHS=0): what the job costs
+    # when the sources are NOT the point sources of a survey (a dense right-hand side sets every flag itself and lands here too)
+    elapsed_dense = None
+    if args.streams <= 1 and not args.no_plain_pass and args.method in ('auto', 'direct'):
+        os.environ['HELM_ND_SPARSE_RHS'] = '0'
+        barrier()
+        t1 = time.perf_counter()
+        run_items(timed_items, False)
+        barrier()
+        elapsed_dense = max_over_ranks(time.perf_counter() - t1)
+        os.environ.pop('HELM_ND_SPARSE_RHS', None)
 
     wavefields = (NFREQ * nb * B) if args.scaling == 'strong' else world * args.steps * B
     value = wavefields / elapsed
@@ -572,6 +589,10 @@ def main():
                          '(helm_prefactor, high-priority stream) while item k is being solved' if args.pipeline else 'off: items strictly one after the other'),
             'item_done_ms': item_done_ms, 'first_items_timeline_ms': first_items,
             'unprofiled': None if elapsed_plain is None else {'value': wavefields / elapsed_plain, 'ms_per_step': 1e3 * elapsed_plain / nsteps},
+            'every_front_computed': None if elapsed_dense is None else {
+                'value': wavefields / elapsed_dense, 'ms_per_step': 1e3 * elapsed_dense / nsteps,
+                'what': 'the same K items (events off) with HELM_ND_SPARSE_RHS=0: the forward pass visits every front; `value` lets it skip the fronts '
+                        'whose right-hand-side rows (81 nonzeros per Kaiser source at the surface) and whose children are all zero in a block of 64 columns'},
             'config': {'workload': 'Eurus 2D isotropic %dx%d synthetic-Marmousi (seed 20240512, dx=%g m), 16 freqs 2-9.5 Hz x 256 Kaiser sources; '
                                    'step = create + assemble 1 frequency + solve %d sources to true relres<=%g (method=%s: %s)' % (n, n, dx, B, args.rtol, args.method, how),
                        'buffers': ("node-major: right-hand sides and wavefields in the reference's own (N, nsrc) C-order arrays, resident in HBM" if node else
@@ -594,6 +615,8 @@ def main():
             out['roofline'].update(gemm_block(agg_k))
             if agg_k is not agg:
                 out['roofline']['in_pipeline'] = gemm_block(agg)
+                out['roofline']['in_pipeline']['counts_skipped_flops'] = True
+                out['roofline']['serial_pass_env'] = 'HELM_ND_SPARSE_RHS=0: every booked flop is executed'
             out['stencil_roofline'] = stencil
         else:
             out['roofline'] = stencil
@@ -747,6 +770,7 @@ def main():
                    'roofline_two_roofs_frac': (out['roofline'].get('two_roofs') or {}).get('frac'),
                    'stencil_frac': (out.get('stencil_roofline') or out['roofline']).get('frac'),
                    'unprofiled_value': (out.get('unprofiled') or {}).get('value'),
+                   'every_front_computed_value': (out.get('every_front_computed') or {}).get('value'),
                    'value_host_api': out['value_host_api'].get('value') if isinstance(out.get('value_host_api'), dict) else None,
                    'config5_job_seconds': c5.get('job_seconds') if c5 else None, 'config5_rtol': c5.get('rtol') if c5 else None,
                    'config5_job_seconds_rtol1e10': c5.get('job_seconds_rtol1e10') if c5 else None,

@@ -340,6 +340,9 @@ struct GemmRows {
     // outgoing rows were computed for that block of 64 columns -- a front whose own right-hand-side rows and whose children's rows are all zero
     // there has nothing to add, writes zeros for its y_S rows and leaves its ring rows unwritten (its parent reads the flag, not the rows)
     int *act = nullptr; int nct = 0;
+    // back substitution of the leaves, same flags read-only: where a leaf's flag is 0 its first k2 rows of B (its right-hand-side rows y_S) are all
+    // zero in that block of columns, and the product starts at row k2 -- x_S = G x_B, 32 of the 81 columns of [F11^-1 | G]
+    const int *act_ro = nullptr;
 };
 #define GB_K 8
 #define GB_KIDX 512       // largest K with indexed B rows
@@ -824,11 +827,19 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
             if (IDX == 1 && R.act) { const long long bx = __double_as_longlong(rb[e].x) | __double_as_longlong(rb[e].y); nzb |= (bx << 1) ? 1 << (bc >> 6) : 0; }
         }
     };
-    fetch(0);
+    int kbeg = 0;
+    if (IDX == 1 && R.act_ro && R.k2 > 0) {                             // (leaf back substitution on sparse right-hand sides, see GemmRows::act_ro)
+        const int *fl = R.act_ro + (long long)(R.first + R.z0 + blockIdx.z) * R.nct + (n0 >> 6);
+        const int ncl = ((Nn - n0 < TN ? Nn - n0 : TN) + 63) >> 6;
+        int any = 0;
+        for (int j = 0; j < ncl; ++j) any |= fl[j];
+        if (!any) kbeg = (R.k2 / KS) * KS;
+    }
+    fetch(kbeg);
     stash(0);
     __syncthreads();
     int cur = 0;
-    for (int k0 = 0; k0 < K; k0 += KS) {
+    for (int k0 = kbeg; k0 < K; k0 += KS) {
         const bool more = k0 + KS < K;
         if (more) fetch(k0 + KS);
         #pragma unroll
@@ -3080,6 +3091,7 @@ void backward_group_batched(helm_op *op, NdFactor *f, size_t gk, const SolveCtx 
             // straight to the Xt rows (no intermediate: 2 x 3.2 GB less per pass at 1024^2 x 256)
             GemmRows R; R.tabB = c.tab + g.roff; R.offB = 0; R.tabCo = c.tab + g.roff; R.offCo = 0; R.tab_stride = nmax;
             R.Bx = c.Xt; R.Bx2 = c.Qt; R.k2 = g.smax; R.Cox = c.Xt; R.ldx = nrhs;
+            R.act_ro = gemm_variant() == 7 ? c.act : nullptr; R.nct = c.nct; R.first = g.first;
             gemm(op, g.smax, nrhs, nmax, one, Finv, nmax, s1, nullptr, 0, 0, zero, nullptr, 0, 0, g.cnt, &R);
             return;
         }
