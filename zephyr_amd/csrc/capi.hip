@@ -1045,13 +1045,16 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
             rc = nd_solve_nm(op, f, Qt, Xt, n, arenaV);
             if (rc) return rc;
         }
+        // where the right-hand sides of this batch can be nonzero at all (the flags of the sparse forward pass just run on Qt): the residual
+        // launches read q only there -- every later evaluation too, Qt does not change
+        rex.qmask = nd_rhs_mask(op, f);
         std::vector<double> relres(n, 0.0), qq(n, 0.0);
         std::vector<int> extra_solves(n, 0);
         double prev_worst = 0.0;
         // every pass ends with the TRUE residual q' - A x of the vector that is returned (norms only); q' is kept for that
         auto true_residual_norms = [&]() -> int {
             rex.qnorm = have_qnorm ? 0 : 1;
-            int r1 = nd_resid_nm(op, planes, Xt, n, Qt, n, nullptr, n, 0, nullptr, (double *)op->d_part, nblk, &nb_part, native_nm ? &rex : nullptr);
+            int r1 = nd_resid_nm(op, planes, Xt, n, Qt, n, nullptr, n, 0, nullptr, (double *)op->d_part, nblk, &nb_part, (native_nm || rex.qmask) ? &rex : nullptr);
             if (r1) return r1;
             helm_launch_fin_ex(op, have_qnorm ? FIN_NORM : FIN_NORM2, n, nb_part, nullptr, d_aux);
             have_qnorm = true;

@@ -2109,7 +2109,7 @@ template <int RPT>
 __global__ __launch_bounds__(256) void k_resid_nm_lds(const cplx *__restrict__ planes, int nz, int nx, const cplx *__restrict__ Xin, int ldin,
                                                       cplx *__restrict__ Q, int ldq, const int *__restrict__ qmap, int ncol, int store,
                                                       cplx *__restrict__ Rout, double *__restrict__ part, int nblk, int ntiles,
-                                                      int qnorm, cplx *__restrict__ Uout, int ldu, cplx oscale) {
+                                                      int qnorm, cplx *__restrict__ Uout, int ldu, cplx oscale, const unsigned char *__restrict__ qm) {
     __shared__ cplx cs[9][RPT][RESID_SEG];
     const int j = threadIdx.x;
     const bool act = j < ncol;
@@ -2142,8 +2142,17 @@ __global__ __launch_bounds__(256) void k_resid_nm_lds(const cplx *__restrict__ p
             win[d][2] = zin ? Xin[((long long)zz * nx + x0) * ldin + j] : cmake(0.0, 0.0);
             pre[d] = (zin && x0 + 1 < nx) ? Xin[((long long)zz * nx + x0 + 1) * ldin + j] : cmake(0.0, 0.0);
         }
+        // qm (sparse right-hand sides): a byte per cell, bit = this wave's block of 64 columns may hold a nonzero there; a 0 bit means q is not read.
+        // The bytes run one column ahead of the q loads they gate (mk: column x + 1, fetched while column x is worked on).
+        const int qbit = j >> 6;
+        unsigned mk[RPT];
         #pragma unroll
-        for (int o = 0; o < RPT; ++o) qn[o] = (z0 + o < nz) ? Q[((long long)(z0 + o) * nx + x0) * ldq + col] : cmake(0.0, 0.0);
+        for (int o = 0; o < RPT; ++o) {
+            const bool in = z0 + o < nz;
+            const unsigned m0 = (qm && in) ? qm[(long long)(z0 + o) * nx + x0] : 0xFFu;
+            qn[o] = (in && ((m0 >> qbit) & 1)) ? Q[((long long)(z0 + o) * nx + x0) * ldq + col] : cmake(0.0, 0.0);
+            mk[o] = (qm && in && x0 + 1 < x1) ? qm[(long long)(z0 + o) * nx + x0 + 1] : 0xFFu;
+        }
         for (int x = x0; x < x1; ++x) {
             cplx qc[RPT];
             #pragma unroll
@@ -2158,8 +2167,9 @@ __global__ __launch_bounds__(256) void k_resid_nm_lds(const cplx *__restrict__ p
             for (int o = 0; o < RPT; ++o) {
                 qc[o] = qn[o];
                 cplx v = cmake(0.0, 0.0);
-                if (z0 + o < nz && x + 1 < x1) v = Q[((long long)(z0 + o) * nx + x + 1) * ldq + col];
+                if (z0 + o < nz && x + 1 < x1 && ((mk[o] >> qbit) & 1)) v = Q[((long long)(z0 + o) * nx + x + 1) * ldq + col];
                 qn[o] = v;
+                mk[o] = (qm && z0 + o < nz && x + 2 < x1) ? qm[(long long)(z0 + o) * nx + x + 2] : 0xFFu;
             }
             #pragma unroll
             for (int o = 0; o < RPT; ++o) {
@@ -2184,6 +2194,23 @@ __global__ __launch_bounds__(256) void k_resid_nm_lds(const cplx *__restrict__ p
     if (act) {
         part[((long long)j * 4) * nblk + blockIdx.x] = acc;
         if (qnorm) part[((long long)j * 4 + 1) * nblk + blockIdx.x] = accq;
+    }
+}
+
+// cellnode[cell] = front of the leaf that eliminates the cell (rows of a leaf group's table with the separator flag)
+__global__ __launch_bounds__(256) void k_nd_cellnode(const int4 *tab, long long rows, int nmax, int first, int *cellnode) {
+    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long long)gridDim.x * blockDim.x) {
+        const int4 e = tab[r];
+        if (e.w && e.x >= 0) cellnode[e.x] = first + (int)(r / nmax);
+    }
+}
+// mask[cell]: bit b = the right-hand sides may be nonzero at this cell in block b of 64 columns (leaf cells: the leaf's flag; separator cells: always)
+__global__ __launch_bounds__(256) void k_nd_qmask(const int *cellnode, const int *act, int nct, long long N, unsigned char *mask) {
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < N; c += (long long)gridDim.x * blockDim.x) {
+        const int nd = cellnode[c];
+        unsigned m = 0xFF;
+        if (nd >= 0) { m = 0; for (int b = 0; b < nct && b < 8; ++b) if (act[(long long)nd * nct + b]) m |= 1u << b; }
+        mask[c] = (unsigned char)m;
     }
 }
 
@@ -2638,6 +2665,7 @@ void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cp
 NdPlanDev::~NdPlanDev() {
     if (d_nodes) helm_pool_free(device, d_nodes, plan.nodes.size() * sizeof(NdDev));
     if (d_tab) helm_pool_free(device, d_tab, (size_t)plan.total_rows * sizeof(int4));
+    if (d_cellnode) helm_pool_free(device, d_cellnode, (size_t)plan.nz * plan.nx * sizeof(int));
 }
 
 namespace {
@@ -2684,6 +2712,19 @@ int nd_get_plan_dims(helm_op *op, int pnz, int pnx, int leaf, int dof, std::shar
             hipLaunchKernelGGL(k_nd_build_tab, dim3((nmax + 255) / 256, nb), dim3(256), 0, op->stream, pd->d_nodes, g.first + j0, pd->d_tab, P.nz, P.nx);
         }
     }
+    if (dof == 1) {                                      // which leaf eliminates a cell (the residual's q mask on sparse right-hand sides)
+        pd->d_cellnode = (int *)helm_pool_alloc(op->device, (size_t)pnz * pnx * sizeof(int));
+        if (pd->d_cellnode) {
+            HIP_TRY(op, hipMemsetAsync(pd->d_cellnode, 0xFF, (size_t)pnz * pnx * sizeof(int), op->stream));
+            for (size_t gi = 0; gi < P.groups.size(); ++gi) {
+                const NdGroup &g = P.groups[gi];
+                if (!g.leaf) continue;
+                const long long rows = (long long)g.cnt * (g.smax + g.mmax);
+                hipLaunchKernelGGL(k_nd_cellnode, dim3((unsigned)std::min<long long>((rows + 255) / 256, 65535)), dim3(256), 0, op->stream,
+                                   (const int4 *)(pd->d_tab + g.roff), rows, g.smax + g.mmax, g.first, pd->d_cellnode);
+            }
+        }
+    }
     HIP_TRY(op, hipStreamSynchronize(op->stream));      // the tables are complete before another handle (another stream) can find them
     static const int keep = getenv("HELM_ND_PLANS") ? std::max(1, atoi(getenv("HELM_ND_PLANS"))) : 6;
     std::shared_ptr<NdPlanDev> evicted;                  // (destroyed after the lock is released)
@@ -2725,6 +2766,7 @@ void nd_free(NdFactor *f) {
     if (f->d_est) helm_pool_free(f->pd ? f->pd->device : 0, f->d_est, f->est_elems * sizeof(double));
     if (f->d_leafflag) helm_pool_free(f->pd ? f->pd->device : 0, f->d_leafflag, f->leafflag_elems * sizeof(int));
     if (f->d_act) helm_pool_free(f->pd ? f->pd->device : 0, f->d_act, f->act_elems * sizeof(int));
+    if (f->d_qmask) helm_pool_free(f->pd ? f->pd->device : 0, f->d_qmask, f->qmask_elems);
     if (f->d_fac) helm_pool_free(f->pd ? f->pd->device : 0, f->d_fac, (size_t)f->pd->plan.fac_elems * sizeof(cplx));
     delete f;
 }
@@ -3232,6 +3274,7 @@ int nd_solve(helm_op *op, NdFactor *f, const cplx *Xin, cplx *Xout, int nrhs, cp
 static void arm_sparse_rhs(helm_op *op, NdFactor *f, SolveCtx &c, hipStream_t st) {
     const int on = getenv("HELM_ND_SPARSE_RHS") ? atoi(getenv("HELM_ND_SPARSE_RHS")) : 1;        // (read per call: a test compares both)
     c.act = nullptr; c.nct = 0;
+    f->act_nct = 0;
     if (!on || c.Qt == c.Xt || gemm_variant() != 7 || f->pd->plan.dof != 1) return;
     const int nct = (c.nrhs + 63) / 64;
     const size_t need = f->pd->plan.nodes.size() * (size_t)nct;
@@ -3244,8 +3287,22 @@ static void arm_sparse_rhs(helm_op *op, NdFactor *f, SolveCtx &c, hipStream_t st
     }
     if (hipMemsetAsync(f->d_act, 0, need * sizeof(int), st) != hipSuccess) { (void)hipGetLastError(); return; }
     c.act = f->d_act; c.nct = nct;
+    f->act_nct = nct;
     // (tests) HELM_ND_POISON=1: the front-vector arena is filled with NaNs first, so that a read of rows no front has written shows up in the wavefield
     if (getenv("HELM_ND_POISON") && atoi(getenv("HELM_ND_POISON"))) (void)hipMemsetAsync(c.arenaV, 0xFF, (size_t)2 * f->pd->plan.vregion * c.nrhs * sizeof(cplx), st);
+}
+
+const unsigned char *nd_rhs_mask(helm_op *op, NdFactor *f) {
+    if (!f || !f->act_nct || f->act_nct > 8 || !f->d_act || !f->pd->d_cellnode) return nullptr;
+    const long long N = (long long)f->pd->plan.nz * f->pd->plan.nx;
+    if (f->qmask_elems < (size_t)N) {
+        if (f->d_qmask) { hipStreamSynchronize(op->stream); helm_pool_free(op->device, f->d_qmask, f->qmask_elems); f->d_qmask = nullptr; f->qmask_elems = 0; }
+        f->d_qmask = (unsigned char *)helm_pool_alloc(op->device, (size_t)N);
+        if (!f->d_qmask) return nullptr;
+        f->qmask_elems = (size_t)N;
+    }
+    hipLaunchKernelGGL(k_nd_qmask, dim3((unsigned)std::min<long long>((N + 255) / 256, 4096)), dim3(256), 0, op->stream, (const int *)f->pd->d_cellnode, (const int *)f->d_act, f->act_nct, N, f->d_qmask);
+    return f->d_qmask;
 }
 
 int nd_solve_nm(helm_op *op, NdFactor *f, const cplx *Qt, cplx *Xt, int nrhs, cplx *arenaV) {
@@ -3331,6 +3388,7 @@ int nd_resid_nm(helm_op *op, const cplx *planes, const cplx *Xin, int ldin, cplx
     cplx *Uout = ex ? ex->Uout : nullptr;
     const int ldu = ex ? ex->ldu : 0;
     const cplx oscale = ex ? ex->oscale : cmake(1.0, 0.0);
+    const unsigned char *qmask = (ex && !qmap) ? ex->qmask : nullptr;
     int lx = 64;
     while (lx < ncol && lx < 256) lx <<= 1;
     const int ly = 256 / lx;
@@ -3358,7 +3416,7 @@ int nd_resid_nm(helm_op *op, const cplx *planes, const cplx *Xin, int ldin, cplx
         if (lds_env && ly == 1 && seg == RESID_SEG && (rpt == 2 || rpt == 4)) {
 #define RESID_LDS(RPT_) hipLaunchKernelGGL(k_resid_nm_lds<RPT_>, dim3(nblk), dim3(256, 1), 0, op->stream, planes, op->nz, op->nx, Xin + c0, ldin, Q + (qmap ? 0 : c0), ldq, \
                            qmap ? qmap + c0 : nullptr, nc, store, Rout ? Rout + (qmap ? 0 : c0) : nullptr, part + (long long)c0 * 4 * nblk, nblk, ntiles, \
-                           qnorm, Uout ? Uout + c0 : nullptr, ldu, oscale)
+                           qnorm, Uout ? Uout + c0 : nullptr, ldu, oscale, c0 == 0 ? qmask : nullptr)
             if (rpt == 2) RESID_LDS(2); else RESID_LDS(4);
 #undef RESID_LDS
             continue;

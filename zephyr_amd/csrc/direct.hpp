@@ -43,6 +43,7 @@ struct NdPlanDev {            // plan + its device-resident tables, shared by ev
     int device = 0;
     NdDev *d_nodes = nullptr;
     int4 *d_tab = nullptr;
+    int *d_cellnode = nullptr;       // (dof 1) per grid cell: the leaf front that eliminates it, -1 for separator cells
     ~NdPlanDev();
 };
 
@@ -69,6 +70,8 @@ struct NdFactor {
     double flops = 0;
     std::vector<NdStable> stable;
     double *d_est = nullptr; size_t est_elems = 0;      // per front of a group: max |F11| before, max |F11^-1| after the inversion; flag list
+    int act_nct = 0;                                          // blocks of 64 columns the flags of the LAST forward pass cover (0: that pass computed every front)
+    unsigned char *d_qmask = nullptr; size_t qmask_elems = 0;  // per grid cell: bit b set when the right-hand sides may be nonzero there in block b of 64 columns
     int *d_act = nullptr; size_t act_elems = 0;              // forward pass on sparse right-hand sides: per front and block of 64 columns, were its outgoing rows computed?
     int *d_leafflag = nullptr; size_t leafflag_elems = 0;     // per leaf of a group: 1 when the fused leaf kernel met a small pivot (the leaf is then re-done with pivoting)
 };
@@ -132,10 +135,14 @@ int nd_factor_solve_nm(helm_op *op, int block, NdFactor *f, cplx *ws_factor, con
                        hipStream_t side, float *factor_ms);
 int nd_prep_transpose_norm(helm_op *op, const cplx *rhs, long long rhs_ld, long long row_off, cplx premul, const cplx *sub, cplx *Qt, long long N, int nrhs,
                            double *part, int nblk_cap, int *nblk_out);     // nblk_cap: partials per right-hand side the buffer has room for
+// per-cell mask of where the right-hand sides of the last nd_solve_nm / nd_factor_solve_nm on f can be nonzero (leaf cells: the leaf's flag of the
+// sparse forward pass; separator cells: always), for nd_resid_nm; null when that pass computed every front
+const unsigned char *nd_rhs_mask(helm_op *op, NdFactor *f);
 struct NdResidExtra {      // optional by-products of the residual launch (node-major callers)
     int qnorm = 0;                       // also the partials of ||q||^2 (slot 1 of the partial sums)
     cplx *Uout = nullptr; int ldu = 0;   // Uout[cell][j] = conj(oscale * xin[cell][j])
     cplx oscale = {1.0, 0.0};
+    const unsigned char *qmask = nullptr;   // nd_rhs_mask of the q passed in: cells and blocks of 64 columns whose bit is 0 are not read (they hold zeros)
 };
 int nd_resid_nm(helm_op *op, const cplx *planes, const cplx *Xin, int ldin, cplx *Q, int ldq, const int *qmap, int ncol, int store, cplx *Rout,
                 double *part, int nblk_cap, int *nblk_out, const NdResidExtra *ex = nullptr);      // r = q - A xin; store: r -> Rout (null: over q)
