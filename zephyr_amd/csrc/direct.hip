@@ -2779,6 +2779,17 @@ bool merged_leaf_backward() {
     return v != 0 && gemm_variant() != 0;
 }
 
+// Fronts that keep G = -F11^-1 F12 where F12 was, so that their back substitution is ONE product [F11^-1 | G] [y_S; x_B]: the leaves (round 2).
+// Round 4 tried the same for every separator front of at most 64 unknowns (levels 13-7 at 1024^2; one 64-row tile per front, because the product
+// overwrites the y_S rows it has just read): HELM_ND_MERGED_SEP=1.  Measured and left off: the 64-row tile pads the 8-, 16- and 32-row fronts of
+// levels 13-10 eight-, four- and two-fold on the matrix cores (back substitution of level 13: 0.59 -> 1.11 ms, 12: 0.44 -> 0.79, 11: 0.30 -> 0.54,
+// 10: 0.29 -> 0.40) and the 64-row levels gain 0.02 ms apiece: 5.5 -> 6.7 ms per pass.
+bool merged_group(const NdPlan &P, const NdGroup &g) {
+    static const int sep = getenv("HELM_ND_MERGED_SEP") ? atoi(getenv("HELM_ND_MERGED_SEP")) : 0;
+    if (g.mmax <= 0 || !merged_leaf_backward()) return false;
+    return g.leaf || (sep && P.dof == 1 && g.smax <= 64 && g.smax + g.mmax <= GB_KIDX);
+}
+
 // ---- ill-conditioned fronts: detection and re-elimination with a pivoted LU (see NdStable in direct.hpp) -------------------------------------
 // ON by default (HELM_ND_STABLE=0 switches it off).  Measured on the 16-frequency bench job (MI355X, round 3): every wavefield meets rtol
 // 1e-10 in ONE pass (passes per wavefield 1.15 -> 1.00, worst first-pass residual 7e-9 -> 3e-11) and the job runs at 9180 against 8170
@@ -2974,8 +2985,8 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
             gemm(op, g.mmax, g.mmax, g.smax, mone, G21, g.smax, (long long)g.mmax * g.smax, F12, nmax, s1, zero, F + g.smax, nmax, fs, g.cnt, &R);
         } else
         gemm(op, g.mmax, g.mmax, g.smax, mone, G21, g.smax, (long long)g.mmax * g.smax, F12, nmax, s1, one, F + g.smax, nmax, fs, g.cnt);
-        if (g.leaf && merged_leaf_backward()) {
-            // leaves: F12 <- -F11^-1 F12, in place where a front is one 64-row tile (GemmRows::tm64), else through the inversion workspace
+        if (merged_group(P, g)) {
+            // leaves (and small separator fronts): F12 <- -F11^-1 F12, in place where a front is one 64-row tile (GemmRows::tm64), else through the inversion workspace
             if (g.smax <= 64) {
                 GemmRows R; R.dense = 1; R.tm64 = 1;
                 gemm(op, g.smax, g.mmax, g.smax, mone, Finv, nmax, s1, F12, nmax, s1, zero, F12, nmax, s1, g.cnt, &R);
@@ -3121,7 +3132,7 @@ void backward_group_batched(helm_op *op, NdFactor *f, size_t gk, const SolveCtx 
     const long long s1 = (long long)g.smax * nmax;                 // stride of a front's [F11^-1 | F12] rows
     const cplx *Finv = f->d_fac + g.finv, *F12 = f->d_fac + g.f12;
     // leaves under HELM_ND_MERGED_LEAF hold G = -F11^-1 F12 in place of F12: x_S = F11^-1 y_S + G x_B
-    const bool gform = g.leaf && g.mmax > 0 && merged_leaf_backward();
+    const bool gform = merged_group(P, g);
     cplx *V = c.arenaV + g.voff * nrhs;
     // the other region is free in this pass: separator results go there
     const long long xs_off = g.voff + ((g.level & 1) ? -P.vregion : P.vregion);
@@ -3132,8 +3143,9 @@ void backward_group_batched(helm_op *op, NdFactor *f, size_t gk, const SolveCtx 
             // leaves: x_S = [F11^-1 | G] [y_S; x_B] in ONE product -- y_S rows from the right-hand sides, x_B rows from Xt; the result goes
             // straight to the Xt rows (no intermediate: 2 x 3.2 GB less per pass at 1024^2 x 256)
             GemmRows R; R.tabB = c.tab + g.roff; R.offB = 0; R.tabCo = c.tab + g.roff; R.offCo = 0; R.tab_stride = nmax;
-            R.Bx = c.Xt; R.Bx2 = c.Qt; R.k2 = g.smax; R.Cox = c.Xt; R.ldx = nrhs;
-            R.act_ro = gemm_variant() == 7 ? c.act : nullptr; R.nct = c.nct; R.first = g.first;
+            R.Bx = c.Xt; R.Bx2 = g.leaf ? c.Qt : (const cplx *)c.Xt; R.k2 = g.smax; R.Cox = c.Xt; R.ldx = nrhs;      // (a separator front's y_S was left in Xt by the forward pass)
+            if (!g.leaf) R.tm64 = 1;                                                 // one row tile per front: the product overwrites rows it reads
+            R.act_ro = (gemm_variant() == 7 && g.leaf) ? c.act : nullptr; R.nct = c.nct; R.first = g.first;
             gemm(op, g.smax, nrhs, nmax, one, Finv, nmax, s1, nullptr, 0, 0, zero, nullptr, 0, 0, g.cnt, &R);
             return;
         }
