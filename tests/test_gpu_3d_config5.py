@@ -99,7 +99,7 @@ def test_every_depth_branch_matches_sparse_lu(helm_lib, monkeypatch, small_lu, e
     del op.factors
 
 
-def test_depth_model_uses_what_it_measures(helm_lib, monkeypatch, small_lu):
+def test_depth_model_uses_what_it_measures(helm_lib, monkeypatch, small_lu, capfd):
     """The depth decision is taken from quantities timed at set-up on THIS grid (plane-inversion rate, one fine-grid apply), not from
     constants of one benchmark: with a single right-hand side and a (pretended) slow inversion it goes deeper, with many right-hand
     sides it does not -- and both hierarchies return the LU's wavefield."""
@@ -118,6 +118,22 @@ def test_depth_model_uses_what_it_measures(helm_lib, monkeypatch, small_lu):
         its[label] = max(i['iterations'] for i in op.lastInfo)
         del op.factors
     assert its['deeper'] > its['rule'], its                         # the deeper hierarchy pays more iterations: the two runs did differ
+    # r4: both classes of hierarchy have now run in this process -- the next decision prices the deeper one with the iteration counts it has
+    # booked for the two (mg3_record_iterations), not with the constants of the prior
+    import re
+    capfd.readouterr()
+    monkeypatch.setenv('HELM_MG3_DEPTH_SETUP_SCALE', '1')
+    op = za.Helm3D(dict(cfg, batch=1))
+    u = op * q[:, :1]
+    assert nrm(u, ref[:, :1]) <= 1e-7
+    err = capfd.readouterr().err
+    m = re.search(r'iterations booked in this process: this depth ([-\d.]+), one deeper ([-\d.]+)', err)
+    assert m, err[-2000:]
+    booked_rule, booked_deeper = float(m.group(1)), float(m.group(2))
+    assert booked_rule > 0 and booked_deeper > booked_rule, (booked_rule, booked_deeper)
+    m2 = re.search(r'costs 1 rhs x (\d+) iterations', err)
+    assert m2 and abs(int(m2.group(1)) - round(booked_deeper - booked_rule)) <= 1, (m2 and m2.group(0), booked_rule, booked_deeper)
+    del op.factors
 
 
 def test_helm3d_against_the_2p5d_summation_on_a_layered_model(helm_lib):

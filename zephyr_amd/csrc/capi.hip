@@ -1570,6 +1570,11 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
         }
         HIP_TRY(op, hipMemcpyAsync(dXout + (long long)first * NV, B.w.x, (size_t)n * NV * sizeof(cplx), hipMemcpyDeviceToDevice, op->stream));
         HIP_TRY(op, hipStreamSynchronize(op->stream));
+        if (use_mg && op->ny > 0 && mg3_is_layer_preserving(op)) {      // what this class of hierarchy needed: the depth model's book
+            double sum = 0.0;
+            for (int b = 0; b < n; ++b) sum += total_iters[b] + op->h_scal[b].iters;
+            mg3_record_iterations(op, sum / n, o.rtol);
+        }
     }
     return unconverged;
 }

@@ -195,6 +195,7 @@ int mg3_setup(helm_op *op, int batch);
 void mg3_retarget_stream(helm_op *op, hipStream_t st);
 void mg3_destroy(helm_op *op);
 int mg3_apply(helm_op *op, const cplx *in, cplx *out, int nrhs);
+void mg3_record_iterations(helm_op *op, double mean_iterations, double rtol);   // books what a solve through the layer-preserving hierarchy needed (depth model)
 bool mg3_is_layer_preserving(const helm_op *op);           // the hierarchy in use is the layer-preserving one
 int mg3_retreat(helm_op *op, int batch);                   // rebuild as the standard cycle for the rest of this frequency
 

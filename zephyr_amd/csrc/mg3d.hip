@@ -30,11 +30,39 @@ struct Mg3Keep;
 struct Mg3Precond {
     std::vector<Mg3Level> lv;
     Mg3Keep *keep = nullptr;      // layer-preserving hierarchy (below) instead of the standard one
+    int kept_levels = 0; double ppw_direct = 0.0;     // (layer-preserving) coarsenings above the directly solved level and its points per wavelength: the class its iteration counts are booked under
     cplx *cinvT = nullptr;        // transposed dense inverse of the coarsest operator
     int nc = 0, batch = 0;
     double omega_j = 0.8, beta = 0.6, cpml_m = 30.0;
     int nu1 = 1, nu2 = 1, min_n = 8;
 };
+
+// ---- what the layer-preserving cycle has actually needed: iterations per right-hand side, by class -----------------------------------------
+// The depth decision of mg3_setup trades set-up seconds against extra iterations of the deeper hierarchy.  Round 3 priced those with three
+// constants measured on config 5 (+11 / +22 / +38 at >= 8 / 6 / 5 points per wavelength on the direct level).  Now every solve through a
+// layer-preserving hierarchy books its mean iteration count under (grid, coarsenings, points per wavelength of the direct level to the nearest
+// 0.5, log10 rtol), and the decision uses the booked counts of both candidates where it has them; the constants remain only as the prior for a
+// class that has never run in this process (the first frequency of the first job).
+namespace {
+struct ItKey { int nz, ny, nx, depth, ppw2, ltol; bool operator<(const ItKey &o) const { return std::tie(nz, ny, nx, depth, ppw2, ltol) < std::tie(o.nz, o.ny, o.nx, o.depth, o.ppw2, o.ltol); } };
+std::mutex g_its_mu;
+std::map<ItKey, std::pair<double, int>> &g_its = *new std::map<ItKey, std::pair<double, int>>();     // key -> (sum of mean iterations, solves)
+ItKey it_key(const helm_op *op, int depth, double ppwd, double rtol) {
+    return ItKey{op->nz, op->ny, op->nx, depth, (int)std::lround(2.0 * ppwd), (int)std::lround(-std::log10(std::max(rtol, 1e-16)))};
+}
+// mean iterations booked for the class, < 0 when it has never run
+double its_lookup(const helm_op *op, int depth, double ppwd, double rtol) {
+    std::lock_guard<std::mutex> lk(g_its_mu);
+    auto it = g_its.find(it_key(op, depth, ppwd, rtol));
+    return it == g_its.end() || it->second.second == 0 ? -1.0 : it->second.first / it->second.second;
+}
+}
+void mg3_record_iterations(helm_op *op, double mean_iterations, double rtol) {
+    if (!op || !op->mg3 || !op->mg3->keep || !(mean_iterations > 0)) return;
+    std::lock_guard<std::mutex> lk(g_its_mu);
+    std::pair<double, int> &e = g_its[it_key(op, op->mg3->kept_levels, op->mg3->ppw_direct, rtol)];
+    e.first += mean_iterations; e.second += 1;
+}
 
 namespace {
 
@@ -1294,7 +1322,11 @@ int mg3_setup(helm_op *op, int batch) {
                     const CoarseEst e0 = coarse_estimate(op, ncoarsen, batch, true), e1 = coarse_estimate(op, ncoarsen + 1, batch, true);
                     const int np0 = e0.np, m0 = e0.m, np1 = e1.np, m1 = e1.m;
                     const double saved = envd("HELM_MG3_DEPTH_SETUP_SCALE", 1.0) * (e0.seconds - e1.seconds);
-                    const double extra_its = ppwd >= 8.0 ? 11.0 : (ppwd >= 6.0 ? 22.0 : 38.0);
+                    // iterations the deeper hierarchy costs per right-hand side: booked counts of both classes where this process has run them,
+                    // the prior (+11 / +22 / +38) on top of the booked count of the other, or alone, where it has not
+                    const double prior = ppwd >= 8.0 ? 11.0 : (ppwd >= 6.0 ? 22.0 : 38.0);
+                    const double its0 = its_lookup(op, ncoarsen, 2.0 * ppwd, op->rtol_hint), its1 = its_lookup(op, ncoarsen + 1, ppwd, op->rtol_hint);      // (ppwd: the DEEPER candidate's direct level)
+                    const double extra_its = (its0 > 0 && its1 > 0) ? std::max(0.0, its1 - its0) : prior;
                     const double t_iter = 18.0 * apply_seconds_per_rhs(op, batch);
                     const double paid = op->mg3_rhs_hint * extra_its * t_iter;
                     const bool deeper = saved > paid || envi("HELM_MG3_DEPTH_FORCE_DEEPER", 0) != 0;
@@ -1303,6 +1335,8 @@ int mg3_setup(helm_op *op, int batch) {
                                         "costs %d rhs x %.0f iterations x %.2f ms = %.3f s -> %s\n", ncoarsen, ppwd, np0, m0, e0.nd ? "column dissection, top separator" : "planes",
                                 np1, m1, e1.nd ? "column dissection, top separator" : "planes", saved, op->mg3_rhs_hint, extra_its,
                                 t_iter * 1e3, paid, deeper ? "deeper" : "stay");
+                    if (envi("HELM_MG3_TRACE", 0))
+                        fprintf(stderr, "[mg3 depth]   iterations booked in this process: this depth %.1f, one deeper %.1f (< 0: never run; prior +%.0f)\n", its0, its1, prior);
                     if (deeper) ++ncoarsen;
                 }
             }
@@ -1313,7 +1347,7 @@ int mg3_setup(helm_op *op, int batch) {
             double inv_tau_k = omega * betak / 2.0;
             if (std::isfinite(op->a_tau) && op->a_tau != 0.0) inv_tau_k += 1.0 / op->a_tau;
             const int rck = setup_keep(op, P, batch, ncoarsen, 1.0 / inv_tau_k);
-            if (rck == HELM_OK) { P->beta = betak; hipStreamSynchronize(op->stream); return HELM_OK; }
+            if (rck == HELM_OK) { P->beta = betak; P->kept_levels = ncoarsen; P->ppw_direct = ppw / (double)(1 << ncoarsen); hipStreamSynchronize(op->stream); return HELM_OK; }
             if (envi("HELM_MG3_KEEP", 1) == 2) { const std::string msg = op->err; mg3_destroy(op); helm_set_error(op, msg.c_str()); return rck; }
             // not this time: release what was built and go on with the standard hierarchy
             keep_free(P);
