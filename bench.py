@@ -533,6 +533,19 @@ def main():
         elapsed_dense = max_over_ranks(time.perf_counter() - t1)
         os.environ.pop('HELM_ND_SPARSE_RHS', None)
 
+    # ... and, under the default weak-scaling run, the job north_star names once through: all 16 frequencies x 256 sources = 4096 wavefields, the
+    # 16 work items dealt round-robin over the ranks (events off) -- the strong-scaling figure of the same launch, so that a driver that only ever
+    # calls `bench.py --gpus N` gets both curves
+    strong_job = None
+    if args.scaling == 'weak' and args.streams <= 1 and not args.no_plain_pass:
+        job_items = [w for w in range(NFREQ * nb) if w % world == rank]
+        barrier()
+        t1 = time.perf_counter()
+        run_items(job_items, False)
+        barrier()
+        tj = max_over_ranks(time.perf_counter() - t1)
+        strong_job = {'wavefields': NFREQ * nb * B, 'seconds': tj, 'value': NFREQ * nb * B / tj, 'unit': 'wavefields/s',
+                      'what': 'the whole 16-frequency job (every frequency x %d sources), its work items round-robin over the %d rank(s); max over ranks' % (B * nb, world)}
     wavefields = (NFREQ * nb * B) if args.scaling == 'strong' else world * args.steps * B
     value = wavefields / elapsed
 
@@ -589,6 +602,7 @@ def main():
                          '(helm_prefactor, high-priority stream) while item k is being solved' if args.pipeline else 'off: items strictly one after the other'),
             'item_done_ms': item_done_ms, 'first_items_timeline_ms': first_items,
             'unprofiled': None if elapsed_plain is None else {'value': wavefields / elapsed_plain, 'ms_per_step': 1e3 * elapsed_plain / nsteps},
+            'strong_scaling_job': strong_job,
             'every_front_computed': None if elapsed_dense is None else {
                 'value': wavefields / elapsed_dense, 'ms_per_step': 1e3 * elapsed_dense / nsteps,
                 'what': 'the same K items (events off) with HELM_ND_SPARSE_RHS=0: the forward pass visits every front; `value` lets it skip the fronts '
@@ -771,6 +785,7 @@ def main():
                    'stencil_frac': (out.get('stencil_roofline') or out['roofline']).get('frac'),
                    'unprofiled_value': (out.get('unprofiled') or {}).get('value'),
                    'every_front_computed_value': (out.get('every_front_computed') or {}).get('value'),
+                   'strong_job_value': (out.get('strong_scaling_job') or {}).get('value'), 'strong_job_seconds': (out.get('strong_scaling_job') or {}).get('seconds'),
                    'value_host_api': out['value_host_api'].get('value') if isinstance(out.get('value_host_api'), dict) else None,
                    'config5_job_seconds': c5.get('job_seconds') if c5 else None, 'config5_rtol': c5.get('rtol') if c5 else None,
                    'config5_job_seconds_rtol1e10': c5.get('job_seconds_rtol1e10') if c5 else None,
