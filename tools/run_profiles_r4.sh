@@ -14,7 +14,8 @@ python3 bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 python3 bench.py --steps 20 --warmup 5 --no-cpu > $OUT/bench_driver.json 2> $OUT/bench_driver.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_pipe -o s -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-config5 --no-host-api --steps 8 --warmup 2 --no-plain-pass > $OUT/bench_pipelined_under_rocprof.json 2> $OUT/stats_pipe.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_serial -o s -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-config5 --no-host-api --no-pipeline --steps 8 --warmup 2 --no-plain-pass > $OUT/bench_serial_under_rocprof.json 2> $OUT/stats_serial.err
+HELM_ND_SPARSE_RHS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_serial -o s -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-config5 --no-host-api --no-pipeline --steps 8 --warmup 2 --no-plain-pass > $OUT/bench_serial_under_rocprof.json 2> $OUT/stats_serial.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_serial_sparse -o s -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-config5 --no-host-api --no-pipeline --steps 8 --warmup 2 --no-plain-pass --no-roofline-pass > $OUT/bench_serial_sparse_under_rocprof.json 2> $OUT/stats_serial_sparse.err
 export HELM_ND_SPARSE_RHS=0
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-config5 --no-host-api --no-pipeline --no-plain-pass > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err
@@ -36,7 +37,7 @@ timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_gemm_sq -- python3 $GRAFT_REPO_ROOT/tools/zgemm_lab.py 7 "s256 Schur" 3 > $OUT/pmc_gemm_sq.txt 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d $OUT/pmc_gemm_sq2 -- python3 $GRAFT_REPO_ROOT/tools/zgemm_lab.py 7 "s256 Schur" 3 > $OUT/pmc_gemm_sq2.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats3d -o s -- python3 $GRAFT_REPO_ROOT/tools/bench3d.py --freqs 5 --nsrc 16 > $OUT/bench3d_under_rocprof.txt 2> $OUT/stats3d.err
-find $OUT/stats_pipe $OUT/stats_serial $OUT/stats3d $OUT/pmc_probe $OUT/pmc_gemm_sq $OUT/pmc_gemm_sq2 -name "*kernel_trace.csv" -size +4M -delete
+find $OUT/stats_pipe $OUT/stats_serial $OUT/stats_serial_sparse $OUT/stats3d $OUT/pmc_probe $OUT/pmc_gemm_sq $OUT/pmc_gemm_sq2 -name "*kernel_trace.csv" -size +4M -delete
 find $OUT -name "*agent_info.csv" -delete
 cd $GRAFT_REPO_ROOT
 python3 tools/zgemm_lab.py 1,7 > $OUT/zgemm_lab.txt 2>&1

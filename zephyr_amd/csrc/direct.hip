@@ -343,6 +343,8 @@ struct GemmRows {
     // back substitution of the leaves, same flags read-only: where a leaf's flag is 0 its first k2 rows of B (its right-hand-side rows y_S) are all
     // zero in that block of columns, and the product starts at row k2 -- x_S = G x_B, 32 of the 81 columns of [F11^-1 | G]
     const int *act_ro = nullptr;
+    int xcd_map = 0;            // regroup the workgroup ids so that the column tiles of a front share an XCD (zgemm3_body)
+    int child_rows = 0;         // (fwd3, host-side bookkeeping) ring rows of a front's two children: what the gather has to read besides q_S
 };
 #define GB_K 8
 #define GB_KIDX 512       // largest K with indexed B rows
@@ -694,7 +696,19 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
     cplx *As = lds, *Bs = lds + 2 * ABUF;
     __shared__ int kidx[IDX == 1 ? GB_KIDX : 1];
     __shared__ int4 kidx4[IDX == 2 ? GB_KIDX : 1];
-    int zb = blockIdx.z;
+    // Which (front, column tile) this workgroup takes.  Workgroups are dealt round-robin over the eight XCDs in launch order (x fastest), so the
+    // column tiles of one front -- which all read the same A operand, the front's factors -- would land on different XCDs with different L2s and the
+    // factors would cross the fabric once per tile.  With one row tile per front the ids are regrouped in blocks of eight fronts: ids L and L + 8 are
+    // the same front's neighbouring column tiles, i.e. the same XCD (speed only: nothing depends on where a workgroup runs).
+    int bxi = blockIdx.x, bzi = blockIdx.z;
+    if (gridDim.y == 1 && gridDim.x > 1 && gridDim.z >= 16 && R.la == nullptr && !(IDX == 0 && R.ksplit > 1) && R.xcd_map) {
+        const int nxt = gridDim.x, nbz = gridDim.z;
+        const int L = blockIdx.x + nxt * blockIdx.z;
+        const int full = (nbz / 8) * 8 * nxt;                         // ids covered by whole blocks of eight fronts
+        if (L < full) { const int grp = L / (8 * nxt), w = L % (8 * nxt); bzi = grp * 8 + (w & 7); bxi = w >> 3; }
+        else { bzi = (nbz / 8) * 8 + (L - full) / nxt; bxi = (L - full) % nxt; }
+    }
+    int zb = bzi;
     if (IDX == 0 && R.ksplit > 1) {                      // this workgroup's share of the inner dimension
         const int kch = zb % R.ksplit;
         zb /= R.ksplit;
@@ -705,10 +719,10 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
     const cplx *A = A0 + (long long)zb * sa;
     const cplx *B = B0 + (long long)zb * sb;
     cplx *C = C0 + (long long)zb * sc;
-    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    const int m0 = blockIdx.y * TM, n0 = bxi * TN;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave / WN, wn = wave % WN, lr = lane & 15, lq = lane >> 4;
-    const long long trow = IDX ? (long long)(R.z0 + blockIdx.z) * R.tab_stride : 0;
+    const long long trow = IDX ? (long long)(R.z0 + bzi) * R.tab_stride : 0;
     const bool idxB = IDX == 1 && R.tabB != nullptr;
     if (idxB) {
         for (int k = tid; k < K; k += 256) kidx[k] = R.tabB[trow + R.offB + k].x;
@@ -721,7 +735,7 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
     // (IDX 2, sparse right-hand sides) bit j of am0 / am1: child 0 / 1 has outgoing rows for the j-th block of 64 columns of this tile
     unsigned am0 = ~0u, am1 = ~0u;
     if (IDX == 2 && R.act) {
-        const int node = R.first + R.z0 + blockIdx.z;
+        const int node = R.first + R.z0 + bzi;
         const NdDev nd = R.nodes[node];
         const int ct0 = n0 >> 6, ncl = ((Nn - n0 < TN ? Nn - n0 : TN) + 63) >> 6;
         am0 = 0; am1 = 0;
@@ -755,7 +769,7 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
     const cplx *S0 = nullptr, *S1 = nullptr;
     int ld0 = 0, ld1 = 0;
     if (IDX == 4) {
-        const NdDev nd = R.nodes[R.first + R.z0 + blockIdx.z];
+        const NdDev nd = R.nodes[R.first + R.z0 + bzi];
         int base0 = 0, base1 = 0;
         if (nd.kid[0] >= 0) { const NdDev c0 = R.nodes[nd.kid[0]]; S0 = R.arenaS + c0.foff + c0.smax; ld0 = c0.smax + c0.mmax; base0 = (int)(c0.voff + c0.smax); }
         if (nd.kid[1] >= 0) { const NdDev c1 = R.nodes[nd.kid[1]]; S1 = R.arenaS + c1.foff + c1.smax; ld1 = c1.smax + c1.mmax; base1 = (int)(c1.voff + c1.smax); }
@@ -829,7 +843,7 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
     };
     int kbeg = 0;
     if (IDX == 1 && R.act_ro && R.k2 > 0) {                             // (leaf back substitution on sparse right-hand sides, see GemmRows::act_ro)
-        const int *fl = R.act_ro + (long long)(R.first + R.z0 + blockIdx.z) * R.nct + (n0 >> 6);
+        const int *fl = R.act_ro + (long long)(R.first + R.z0 + bzi) * R.nct + (n0 >> 6);
         const int ncl = ((Nn - n0 < TN ? Nn - n0 : TN) + 63) >> 6;
         int any = 0;
         for (int j = 0; j < ncl; ++j) any |= fl[j];
@@ -881,7 +895,7 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
     }
     unsigned colmask = ~0u;                                              // blocks of 64 columns of this tile whose results are stored
     if (IDX == 1 && R.act) {                                             // leaf level: which blocks of 64 columns carry a right-hand side at all
-        const int node = R.first + R.z0 + blockIdx.z;
+        const int node = R.first + R.z0 + bzi;
         colmask = 0;
         #pragma unroll
         for (int j = 0; j < (TN + 63) / 64; ++j)
@@ -2330,8 +2344,15 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const cplx *__restrict__ 
 // What one GEMM launch has to move at the very least -- every operand once: A (M x K), B (K x N), C written (and read when beta != 0) -- and the
 // time the part's two roofs allow it: max(flops / 78.6 TFLOP/s, bytes / 8 TB/s).  The thin fronts low in the tree are HBM-bound products
 // (a level-13 front multiplies a 48 x 8 block into 256 right-hand sides: 1.6 flop per byte), the big ones fp64-bound; the bench adds both up.
-inline double gemm_operand_bytes(int M, int Nn, int K, cplx beta) {
+// r4: the two gather modes read more than "every operand once" of a plain product, and that is necessary traffic, not waste --
+//   forward gather (fwd3): a B row is q_S plus the children's rows that land on it, the C that is read is the children's rows of a ring row, and the
+//     gathered separator rows are written back as y_S: every child ring row (child_rows of them per front) is read once, K more rows are written;
+//   Schur gather (schur4): nothing of C is read (beta = 0) but the children's Schur-complement entries that land on the ring x ring block are:
+//     about half of its M N entries receive one (both cells on the same child's ring), a few receive two.
+inline double gemm_operand_bytes(int M, int Nn, int K, cplx beta, const GemmRows *rows = nullptr) {
     const bool rd = !(beta.x == 0.0 && beta.y == 0.0);
+    if (rows && rows->fwd3) return 16.0 * ((double)M * K + (double)K * Nn + (double)rows->child_rows * Nn + (double)M * Nn + (double)K * Nn);
+    if (rows && rows->schur4) return 16.0 * ((double)M * K + (double)K * Nn + 1.5 * (double)M * Nn);
     return 16.0 * ((double)M * K + (double)K * Nn + (double)M * Nn * (rd ? 2.0 : 1.0));
 }
 inline double gemm_sol_ms(double flops, double bytes) { return 1e3 * std::max(flops / 78.6e12, bytes / 8.0e12); }
@@ -2436,6 +2457,8 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
         const int nb = std::min(65535, batch - b0);
         GemmRows R; if (rows) R = *rows;
         R.z0 = b0;
+        static const int xcd_env = getenv("HELM_ND_XCDMAP") ? atoi(getenv("HELM_ND_XCDMAP")) : 1;
+        R.xcd_map = xcd_env;
         const cplx *Ab = A + b0 * sa, *Bb = B ? B + b0 * sb : B;
         cplx *Cb = C ? C + b0 * sc : C;
         // (a 4 x 8 register block per thread -- RN = 8, 64 x 128 tile -- was measured too: 230 VGPRs, occupancy 2, 38 % slower)
@@ -2457,7 +2480,7 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
                 op->ev_used += 2;
                 tl_ev0 = tl_ev1 = nullptr;
             }
-        } arm(op, ext, 8.0 * M * (double)Nn * K * nb, gemm_operand_bytes(M, Nn, K, beta) * nb, M, Nn, K, nb,
+        } arm(op, ext, 8.0 * M * (double)Nn * K * nb, gemm_operand_bytes(M, Nn, K, beta, rows) * nb, M, Nn, K, nb,
               rows && rows->schur4 ? 4 : (rows && !rows->dense ? (rows->fwd3 ? 2 : 1) : (rows && rows->la ? 5 : 0)));
 #define ZG_ARGS st, (rows && rows->schur4 ? 4 : (rows && !rows->dense ? (rows->fwd3 ? 2 : 1) : 0)), nb, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R
 #define ZG_VEC(TM_, RN_) do { switch (gv) { \
@@ -2521,7 +2544,7 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
 #undef ZG_VEC
     }
     const double flops = 8.0 * M * (double)Nn * K * batch;
-    const double obytes = gemm_operand_bytes(M, Nn, K, beta) * batch;
+    const double obytes = gemm_operand_bytes(M, Nn, K, beta, rows) * batch;
     if (ext) return 0;
     if (in_run) {                       // the run's end event is recorded by GemmRun's destructor
         if (op->gemm_run_pair >= 0) { op->gemm_run_flops += flops; op->gemm_run_bytes += obytes; op->gemm_run_sol += gemm_sol_ms(flops, obytes); op->gemm_run_launches += 1; }
@@ -3074,6 +3097,7 @@ void forward_group_batched(helm_op *op, NdFactor *f, size_t gi, const SolveCtx &
         GemmRows R; R.fwd3 = 1; R.tabB = c.tab + g.roff; R.offB = 0; R.tabCi = c.tab + g.roff; R.offCi = g.smax; R.tab_stride = nmax;
         R.Bx = c.Qt; R.Cix = c.arenaV; R.Cox = c.Xt; R.ldx = nrhs;
         R.act = gemm_variant() == 7 ? c.act : nullptr; R.nct = c.nct; R.first = g.first; R.nodes = f->pd->d_nodes;
+        { const NdDev &n0 = P.nodes[g.first]; R.child_rows = (n0.kid[0] >= 0 ? P.nodes[n0.kid[0]].mmax : 0) + (n0.kid[1] >= 0 ? P.nodes[n0.kid[1]].mmax : 0); }
         gemm(op, g.mmax, nrhs, g.smax, mone, f->d_fac + g.g21, g.smax, (long long)g.mmax * g.smax, nullptr, 0, 0, one,
              V + (long long)g.smax * nrhs, nrhs, (long long)nmax * nrhs, g.cnt, &R);
         if (c.act && !R.act) hipMemsetAsync(c.act + (long long)g.first * c.nct, 1, (size_t)g.cnt * c.nct * sizeof(int), op->stream);
