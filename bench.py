@@ -213,7 +213,8 @@ def config5_leg(local, rtol=1e-8, nsrc=16, freqs=(2., 3., 4., 5.), grid=(128, 25
         return st, its_
 
     def pipelined_job():
-        return list(dispatch.pipelined([dispatch.WorkItem(solve, (lambda f=f: prep(f))) for f in freqs], device=local, lookahead=1, strict=True))
+        return list(dispatch.pipelined([dispatch.WorkItem(solve, (lambda f=f: prep(f))) for f in freqs], device=local,
+                                       lookahead=int(os.environ.get('HELM_C5_LOOKAHEAD', '1')), strict=os.environ.get('HELM_C5_STRICT', '1') != '0'))
     # untimed warm-up (the W of this leg): the job once through the pipeline brings the Krylov workspaces (23 GB per operator in flight), the factor
     # storage of the directly solved levels and the once-per-process calibrations of the depth model into being; everything goes back to the
     # library's pools before the clock starts

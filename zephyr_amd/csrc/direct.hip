@@ -1104,8 +1104,10 @@ __device__ __forceinline__ void gj_lds(cplx (*a)[NMAX + 1], cplx *fcol, int *piv
 // (Measured and reverted: exchanging the pivot row and the multiplier column through small LDS buffers instead of the full matrix --
 // fewer LDS bytes, but write -> barrier -> read makes three dependent LDS round trips per step instead of two: 65 -> 88 us per block step.)
 struct Gj32 {
-    cplx a[32][33];
-    unsigned cand[32];
+    cplx a[32][33];       // the matrix on entry, the result on return
+    cplx b[32][33];       // second buffer: step k reads one and writes the other, so a step needs ONE barrier
+    unsigned cand[2][32];
+    cplx dinv[2][32];     // reciprocal of every row's entry in the column that is eliminated next
     int piv[32];          // sigma: pivot row of step k
     int sinv[32];         // step at which row r was the pivot
 };
@@ -1118,51 +1120,69 @@ __device__ __forceinline__ unsigned gj_key(cplx v, int i) {
     const float m = (float)fmax(fabs(v.x), fabs(v.y));
     return (__float_as_uint(m) & ~31u) | (unsigned)i;
 }
+__device__ __forceinline__ cplx gj_recip(cplx d) {
+    const double rr = gj_rcp(d.x * d.x + d.y * d.y);
+    return cmake(d.x * rr, -d.y * rr);
+}
 // S.a must hold the matrix padded with the identity to 32 x 32; all 256 threads call.
 // Implicit pivoting (rows stay where they are, S.piv[k] = sigma(k) = pivot row of step k, S.sinv its inverse) and deferred scaling of the
-// pivot rows (see k_gj32w_inverse): a step is   read keys -> p;  read row p, column k (old values);  barrier;  write own entries + next
-// keys;  barrier.  On return S.a holds the storage rows R with   inverse[i][sigma(k)] = R[sigma(i)][k].
+// pivot rows (see k_gj32w_inverse).  A step is a chain of latencies, so it is kept short:
+//   * a thread keeps its four entries in registers for the whole elimination and publishes them to the buffer the NEXT step reads:
+//     one barrier per step;
+//   * the thread that produces row i's entry of column k + 1 also publishes the pivot key and the reciprocal of that entry, so step k + 1
+//     starts with   read keys -> p;  read row p, 1 / d, own multiplier   and goes straight to the multiply-adds (the division is off the
+//     critical path: it runs beside the other three entries' updates of the previous step).
+// On return S.a holds the storage rows R with   inverse[i][sigma(k)] = R[sigma(i)][k].
 __device__ __forceinline__ void gj32(Gj32 &S, int n, int tid) {
     const int i = tid >> 3, jc = tid & 7, j0 = jc * 4;
     bool used = i >= n;
     cplx srow = cmake(1.0, 0.0);
-    if (jc == 0) { S.cand[i] = used ? (unsigned)i : gj_key(S.a[i][0], i); S.piv[i] = i; S.sinv[i] = i; }
-    __syncthreads();
-    for (int k = 0; k < n; ++k) {
-        const uint4 *c4 = reinterpret_cast<const uint4 *>(S.cand);
-        unsigned m = 0;
-        #pragma unroll
-        for (int q = 0; q < 8; ++q) { const uint4 v = c4[q]; m = max(m, max(max(v.x, v.y), max(v.z, v.w))); }
-        const int p = (int)(m & 31u);
-        const cplx d = S.a[p][k], f = S.a[i][k];
-        cplx pr[4], out[4];
-        #pragma unroll
-        for (int q = 0; q < 4; ++q) { pr[q] = S.a[p][j0 + q]; out[q] = S.a[i][j0 + q]; }
-        if (tid == 0) { S.piv[k] = p; S.sinv[p] = k; }
-        const double rr = gj_rcp(d.x * d.x + d.y * d.y);
-        const cplx dinv = cmake(d.x * rr, -d.y * rr);
-        const cplx fp = (i == p) ? cmake(0.0, 0.0) : cmul(f, dinv);
-        const cplx vk = (i == p) ? cmake(1.0, 0.0) : cneg(fp);          // column k of the running inverse
-        #pragma unroll
-        for (int q = 0; q < 4; ++q) {                 // (static register indices only: an `a[k & 3] = ...` sends the array to scratch memory)
-            out[q].x = fma(-fp.x, pr[q].x, out[q].x); out[q].x = fma(fp.y, pr[q].y, out[q].x);
-            out[q].y = fma(-fp.x, pr[q].y, out[q].y); out[q].y = fma(-fp.y, pr[q].x, out[q].y);
-            if (j0 + q == k) out[q] = vk;
-        }
-        if (i == p) { srow = dinv; used = true; }
-        __syncthreads();
-        #pragma unroll
-        for (int q = 0; q < 4; ++q) S.a[i][j0 + q] = out[q];
-        if (k + 1 < n && jc == ((k + 1) >> 2)) {    // pivot keys of the next column (unused rows only: their scale is still 1)
-            cplx v = out[0];
-            #pragma unroll
-            for (int q = 1; q < 4; ++q) if (((k + 1) & 3) == q) v = out[q];
-            S.cand[i] = used ? (unsigned)i : gj_key(v, i);
-        }
-        __syncthreads();
-    }
+    cplx out[4];
     #pragma unroll
-    for (int q = 0; q < 4; ++q) S.a[i][j0 + q] = cmul(S.a[i][j0 + q], srow);
+    for (int q = 0; q < 4; ++q) out[q] = S.a[i][j0 + q];
+    if (jc == 0) { S.cand[0][i] = used ? (unsigned)i : gj_key(out[0], i); S.dinv[0][i] = gj_recip(out[0]); S.piv[i] = i; S.sinv[i] = i; }
+    __syncthreads();
+    cplx (*cur)[33] = S.a, (*nxt)[33] = S.b;
+    // four steps per trip, so that the register that holds column k (out[k & 3]) is known at compile time: one select per step instead of four
+    // compare-and-select groups, and no select chain for the next column's key
+#define GJ32_STEP(Q_) do {                                                                                                         \
+        const int k = k4 + (Q_);                                                                                                   \
+        if (k >= n) break;                                                                                                         \
+        const int pb = k & 1;                                                                                                      \
+        const uint4 *c4 = reinterpret_cast<const uint4 *>(S.cand[pb]);                                                             \
+        unsigned m = 0;                                                                                                            \
+        _Pragma("unroll")                                                                                                          \
+        for (int q = 0; q < 8; ++q) { const uint4 v = c4[q]; m = max(m, max(max(v.x, v.y), max(v.z, v.w))); }                       \
+        const int p = (int)(m & 31u);                                                                                              \
+        const cplx dinv = S.dinv[pb][p], f = cur[i][k];                                                                            \
+        cplx pr[4];                                                                                                                \
+        _Pragma("unroll")                                                                                                          \
+        for (int q = 0; q < 4; ++q) pr[q] = cur[p][j0 + q];                                                                        \
+        if (tid == 0) { S.piv[k] = p; S.sinv[p] = k; }                                                                             \
+        const cplx fp = (i == p) ? cmake(0.0, 0.0) : cmul(f, dinv);                                                                \
+        _Pragma("unroll")                                                                                                          \
+        for (int q = 0; q < 4; ++q) {                                                                                              \
+            out[q].x = fma(-fp.x, pr[q].x, out[q].x); out[q].x = fma(fp.y, pr[q].y, out[q].x);                                     \
+            out[q].y = fma(-fp.x, pr[q].y, out[q].y); out[q].y = fma(-fp.y, pr[q].x, out[q].y);                                    \
+        }                                                                                                                          \
+        if (jc == (k4 >> 2)) out[Q_] = (i == p) ? cmake(1.0, 0.0) : cneg(fp);        /* column k of the running inverse */            \
+        if (i == p) { srow = dinv; used = true; }                                                                                  \
+        if (k + 1 < n) {                                                                                                           \
+            if (jc == ((k + 1) >> 2)) {        /* key and reciprocal of the next column (unused rows only: their scale is still 1) */ \
+                const cplx v = out[((Q_) + 1) & 3];                                                                                \
+                S.cand[pb ^ 1][i] = used ? (unsigned)i : gj_key(v, i);                                                             \
+                S.dinv[pb ^ 1][i] = gj_recip(v);                                                                                   \
+            }                                                                                                                      \
+            _Pragma("unroll")                                                                                                      \
+            for (int q = 0; q < 4; ++q) nxt[i][j0 + q] = out[q];                                                                   \
+        }                                                                                                                          \
+        __syncthreads();                                                                                                           \
+        cplx (*t_)[33] = cur; cur = nxt; nxt = t_;                                                                                 \
+    } while (0)
+    for (int k4 = 0; k4 < n; k4 += 4) { GJ32_STEP(0); GJ32_STEP(1); GJ32_STEP(2); GJ32_STEP(3); }
+#undef GJ32_STEP
+    #pragma unroll
+    for (int q = 0; q < 4; ++q) S.a[i][j0 + q] = cmul(out[q], srow);
     __syncthreads();
 }
 
@@ -1369,15 +1389,15 @@ __global__ __launch_bounds__(256) void k_gj_panel(cplx *T0, int ld, long long st
 // block privately (the GEMM skips it, GemmRows::sk0/sk1), inverts it and leaves P in Pb; k_gj_slices then forms the
 // panels R_k = P T[k-rows, :], C_k = T[:, k-cols] from the updated front.
 // LDS of the sweep: wc | wr (2 x 32 x 33 complex) while the pending update is applied to the block, then the Gj32 state in the same place
-constexpr int GJ_PIVOT_LDS = 2 * PNB * (PNB + 1) * (int)sizeof(cplx) + PNB * (int)sizeof(int);
-static_assert(sizeof(Gj32) <= 2 * PNB * (PNB + 1) * sizeof(cplx), "Gj32 must fit over the two panels");
+constexpr int GJ_PIVOT_LDS = (int)sizeof(Gj32) + PNB * (int)sizeof(int);
+static_assert(sizeof(Gj32) >= 2 * PNB * (PNB + 1) * sizeof(cplx), "the two panels lie over Gj32's buffers");
 
 __device__ __forceinline__ void gj_pivot_body(const cplx *T0, int ld, long long stride, int n, int k0, int nb, const cplx *Wc0, const cplx *Wr0, long long wstride,
                                               cplx *Pb0, long long pstride, int mat, char *lds) {
     cplx (&wc)[PNB][PNB + 1] = *reinterpret_cast<cplx (*)[PNB][PNB + 1]>(lds);
     cplx (&wr)[PNB][PNB + 1] = *reinterpret_cast<cplx (*)[PNB][PNB + 1]>(lds + PNB * (PNB + 1) * sizeof(cplx));
     Gj32 &S = *reinterpret_cast<Gj32 *>(lds);
-    int *cperm = reinterpret_cast<int *>(lds + 2 * PNB * (PNB + 1) * sizeof(cplx));
+    int *cperm = reinterpret_cast<int *>(lds + sizeof(Gj32));
     const cplx *T = T0 + (long long)mat * stride;
     const cplx *Wc = Wc0 + (long long)mat * wstride, *Wr = Wr0 + (long long)mat * wstride;
     cplx *Pb = Pb0 + (long long)mat * pstride;
@@ -2429,7 +2449,10 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
     for (int c = 0; c < (narrow ? (tall ? 9 : 8) : 3); ++c) {
         if (c == 8 && (Nn > 16 || gemm_variant() == 0)) continue;
         const int tm = vc_tm[c], tn = 1024 / tm * vc_rn[c];
-        const double cost = (double)((M + tm - 1) / tm) * tm * ((Nn + tn - 1) / tn) * tn / vc_eff[c];
+        double cost = (double)((M + tm - 1) / tm) * tm * ((Nn + tn - 1) / tn) * tn / vc_eff[c];
+        // matrix-core kernel: a 16-row tile is one block row per wave column -- right for fronts of 8 and 16 rows, 40-50 % slower than the
+        // 64- and 32-row tiles on tall operands, where only the padding of an odd row count (1025, 1281) made it look cheap (tools/tile_lab.py)
+        if (gemm_variant() == 7 && tm == 16 && M > 32) cost *= 1.6;
         if (vcost < 0 || cost < vcost * 0.999) { vsel = c; vcost = cost; }
     }
     if (fixed_tm == 64) vsel = 0; else if (fixed_tm == 32) vsel = 1; else if (fixed_tm == 16) vsel = 2;
@@ -2438,11 +2461,16 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
     // SIMD nothing else hides the LDS and HBM latencies (measured on 1024 x 256 x 1024: 240 -> 118 us)
     static const int latency_tiles = getenv("HELM_ND_LATTILES") ? atoi(getenv("HELM_ND_LATTILES")) : 1;
     bool latency_mode = false;
-    if (latency_tiles && (long long)batch * ((M + 63) / 64) * ((Nn + 63) / 64) < 256) {
+    static const int latency_max = getenv("HELM_ND_LATTILES_MAX") ? atoi(getenv("HELM_ND_LATTILES_MAX")) : 256;
+    if (latency_tiles && (long long)batch * ((M + 63) / 64) * ((Nn + 63) / 64) < latency_max) {
         const long long a6 = (long long)((M + 31) / 32) * 32 * ((Nn + 31) / 32) * 32, a7 = (long long)((M + 15) / 16) * 16 * ((Nn + 63) / 64) * 64;
         vsel = a7 < a6 ? 7 : 6;
         latency_mode = true;
     }
+    // a few hundred 64 x 64 tiles (one or two per compute unit, gone in a single round): 32 x 32 tiles give every unit four to eight
+    // workgroups to overlap (1025 x 256 x 512 x 4: 152 -> 106 us, 1025 x 512 x 512 x 4: 219 -> 183, tools/tile_lab.py)
+    static const int midfill_max = getenv("HELM_ND_MIDFILL_MAX") ? atoi(getenv("HELM_ND_MIDFILL_MAX")) : 600;
+    if (!latency_mode && gemm_variant() == 7 && M > 64 && (long long)batch * ((M + 63) / 64) * ((Nn + 63) / 64) < midfill_max) vsel = 6;
     // forward-gather launches are HBM-bound and every row-tile repeats the three-source gather of the B rows: one row-tile per front
     // wherever the front has at most 64 rows, whatever the padding costs in flops
     if (rows && rows->fwd3 && M <= 64 && !latency_mode) vsel = 0;
@@ -2645,8 +2673,9 @@ void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cp
             // the fast kernel is built for latency (every thread repeats the pivot search): with thousands of matrices in flight the
             // chip is issue-bound and the plain kernel is as fast or faster (8192 blocks of 8 x 8: 54 vs 139 us)
             static const int gj_wave = getenv("HELM_ND_GJWAVE") ? atoi(getenv("HELM_ND_GJWAVE")) : 1;
-            if (n <= 32 && gj_wave && batch >= 2048) hipLaunchKernelGGL(k_gj32w_inverse, dim3((nb + 3) / 4), dim3(256), 0, st, M + b0 * stride, ld, stride, n, nb);
-            else if (n <= 32 && gj_fast && batch < 2048) hipLaunchKernelGGL(k_gj32_inverse, dim3(nb), dim3(256), 0, st, M + b0 * stride, ld, stride, n);
+            static const int gj_wave_min = getenv("HELM_ND_GJWAVE_MIN") ? atoi(getenv("HELM_ND_GJWAVE_MIN")) : 2048;
+            if (n <= 32 && gj_wave && batch >= gj_wave_min) hipLaunchKernelGGL(k_gj32w_inverse, dim3((nb + 3) / 4), dim3(256), 0, st, M + b0 * stride, ld, stride, n, nb);
+            else if (n <= 32 && gj_fast && batch < gj_wave_min) hipLaunchKernelGGL(k_gj32_inverse, dim3(nb), dim3(256), 0, st, M + b0 * stride, ld, stride, n);
             else if (n <= 32 && gj_threads == 1024) hipLaunchKernelGGL((k_gj_inverse<32, 1024>), dim3(nb), dim3(1024), 0, st, M + b0 * stride, ld, stride, n);
             else if (n <= 32) hipLaunchKernelGGL(k_gj_inverse<32>, dim3(nb), dim3(gj_threads), 0, st, M + b0 * stride, ld, stride, n);
             else hipLaunchKernelGGL(k_gj_inverse<64>, dim3(nb), dim3(256), 0, st, M + b0 * stride, ld, stride, n);
