@@ -4,8 +4,11 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from zephyr_amd import _lib
 lib = _lib.load()
-SHAPES = [(1025, 256, 512, 4), (1281, 256, 256, 8), (1025, 512, 512, 4), (512, 256, 1025, 4), (256, 256, 1281, 8), (512, 256, 1024, 2), (1024, 256, 1024, 1),
+SHAPES_TOP = [(1025, 256, 512, 4), (1281, 256, 256, 8), (1025, 512, 512, 4), (512, 256, 1025, 4), (256, 256, 1281, 8), (512, 256, 1024, 2), (1024, 256, 1024, 1),
           (1024, 256, 512, 2), (768, 256, 128, 32), (384, 256, 64, 128), (128, 256, 768, 32), (1024, 512, 512, 2), (1025, 1025, 512, 4), (1281, 1281, 256, 8)]
+SHAPES_LOW = [(8, 256, 48, 8192), (16, 256, 64, 4096), (16, 256, 96, 2048), (32, 256, 128, 1024), (32, 256, 192, 512), (8, 256, 8, 8192), (16, 256, 16, 4096),
+              (32, 256, 32, 1024), (32, 256, 49, 16129), (64, 256, 256, 256), (64, 256, 384, 128), (48, 256, 8, 8192), (64, 256, 16, 4096), (96, 256, 16, 2048), (128, 256, 32, 1024)]
+SHAPES = SHAPES_LOW if (len(sys.argv) > 1 and sys.argv[1] == 'low') else SHAPES_TOP
 vs = [7] + [7 + 16 * (t + 1) for t in range(8)]
 print('%-22s | default  ' % 'M N K batch' + ' '.join('tile%d   ' % t for t in range(8)))
 for M, N, K, b in SHAPES:

@@ -700,13 +700,16 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
     // column tiles of one front -- which all read the same A operand, the front's factors -- would land on different XCDs with different L2s and the
     // factors would cross the fabric once per tile.  With one row tile per front the ids are regrouped in blocks of eight fronts: ids L and L + 8 are
     // the same front's neighbouring column tiles, i.e. the same XCD (speed only: nothing depends on where a workgroup runs).
-    int bxi = blockIdx.x, bzi = blockIdx.z;
-    if (gridDim.y == 1 && gridDim.x > 1 && gridDim.z >= 16 && R.la == nullptr && !(IDX == 0 && R.ksplit > 1) && R.xcd_map) {
-        const int nxt = gridDim.x, nbz = gridDim.z;
-        const int L = blockIdx.x + nxt * blockIdx.z;
-        const int full = (nbz / 8) * 8 * nxt;                         // ids covered by whole blocks of eight fronts
-        if (L < full) { const int grp = L / (8 * nxt), w = L % (8 * nxt); bzi = grp * 8 + (w & 7); bxi = w >> 3; }
-        else { bzi = (nbz / 8) * 8 + (L - full) / nxt; bxi = (L - full) % nxt; }
+    int bxi = blockIdx.x, byi = blockIdx.y, bzi = blockIdx.z;
+    if (gridDim.x * gridDim.y > 1 && gridDim.z >= 16 && R.la == nullptr && !(IDX == 0 && R.ksplit > 1) && R.xcd_map && (gridDim.y == 1 || R.xcd_map > 1)) {
+        // (xcd_map > 1: fronts with several row tiles too -- every row tile repeats the gather of the B rows, which then comes out of that XCD's L2)
+        const int nxt = gridDim.x, nt = gridDim.x * gridDim.y, nbz = gridDim.z;
+        const int L = blockIdx.x + nxt * blockIdx.y + nt * blockIdx.z;
+        const int full = (nbz / 8) * 8 * nt;                          // ids covered by whole blocks of eight fronts
+        int tile;
+        if (L < full) { const int grp = L / (8 * nt), w = L % (8 * nt); bzi = grp * 8 + (w & 7); tile = w >> 3; }
+        else { bzi = (nbz / 8) * 8 + (L - full) / nt; tile = (L - full) % nt; }
+        bxi = tile % nxt; byi = tile / nxt;
     }
     int zb = bzi;
     if (IDX == 0 && R.ksplit > 1) {                      // this workgroup's share of the inner dimension
@@ -719,7 +722,7 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
     const cplx *A = A0 + (long long)zb * sa;
     const cplx *B = B0 + (long long)zb * sb;
     cplx *C = C0 + (long long)zb * sc;
-    const int m0 = blockIdx.y * TM, n0 = bxi * TN;
+    const int m0 = byi * TM, n0 = bxi * TN;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave / WN, wn = wave % WN, lr = lane & 15, lq = lane >> 4;
     const long long trow = IDX ? (long long)(R.z0 + bzi) * R.tab_stride : 0;
@@ -754,7 +757,7 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
                 if (t4.w && ns0 + bc < Nn) { const cplx v = R.Bx[(long long)t4.x * R.ldx + ns0 + bc]; nzq |= (v.x != 0.0 || v.y != 0.0); }
             }
         if (!(am0 | am1) && !__syncthreads_or(nzq)) {
-            if (blockIdx.y == 0 && R.Cox)                                // y_S = 0 where the back substitution will look for it
+            if (byi == 0 && R.Cox)                                // y_S = 0 where the back substitution will look for it
                 for (int e = tid; e < K * TN; e += 256) {
                     const int k = e / TN, bc = e % TN;
                     const int4 t4 = kidx4[k];
@@ -762,7 +765,7 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
                 }
             return;
         }
-        if (blockIdx.y == 0 && tid < ncl) R.act[node * R.nct + ct0 + tid] = 1;
+        if (byi == 0 && tid < ncl) R.act[node * R.nct + ct0 + tid] = 1;
     }
     int nzb = 0;                                                         // (IDX 1 with act: leaf level) bit j: a nonzero right-hand-side entry in the j-th block of 64 columns
     __shared__ int2 sgr[IDX == 4 ? TM : 1], sgc[IDX == 4 ? TN : 1];
@@ -813,7 +816,7 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
                     if (t4.w) v = R.Bx[(long long)t4.x * R.ldx + n0 + bc];
                     if (t4.y >= 0 && ((am0 >> (bc >> 6)) & 1)) v = cadd(v, R.Cix[(long long)t4.y * R.ldx + n0 + bc]);
                     if (t4.z >= 0 && ((am1 >> (bc >> 6)) & 1)) v = cadd(v, R.Cix[(long long)t4.z * R.ldx + n0 + bc]);
-                    if (blockIdx.y == 0 && t4.w && R.Cox) R.Cox[(long long)t4.x * R.ldx + n0 + bc] = v;      // y_S
+                    if (byi == 0 && t4.w && R.Cox) R.Cox[(long long)t4.x * R.ldx + n0 + bc] = v;      // y_S
                 }
                 else if (idxB) {
                     const int r = kidx[k0 + bk];
@@ -901,7 +904,7 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
         for (int j = 0; j < (TN + 63) / 64; ++j)
             if (__syncthreads_or((nzb >> j) & 1)) {
                 colmask |= 1u << j;
-                if (blockIdx.y == 0 && tid == 0 && (n0 >> 6) + j < R.nct) R.act[node * R.nct + (n0 >> 6) + j] = 1;
+                if (byi == 0 && tid == 0 && (n0 >> 6) + j < R.nct) R.act[node * R.nct + (n0 >> 6) + j] = 1;
             }
         // tiles narrower than a block of 64 columns share its flag with their neighbours: another workgroup may raise it, so this one writes its
         // zeros; from 64 columns up nothing but zeros coming in means the rows stay unwritten and the flag stays 0
@@ -2467,6 +2470,8 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
         vsel = a7 < a6 ? 7 : 6;
         latency_mode = true;
     }
+    // fronts of 8 and 16 rows: the 16 x 64 tile (four workgroups per front) is 4-15 % ahead of 16 x 256 (tools/tile_lab.py low)
+    if (!latency_mode && gemm_variant() == 7 && M <= 16 && vsel == 2) vsel = 7;
     // a few hundred 64 x 64 tiles (one or two per compute unit, gone in a single round): 32 x 32 tiles give every unit four to eight
     // workgroups to overlap (1025 x 256 x 512 x 4: 152 -> 106 us, 1025 x 512 x 512 x 4: 219 -> 183, tools/tile_lab.py)
     static const int midfill_max = getenv("HELM_ND_MIDFILL_MAX") ? atoi(getenv("HELM_ND_MIDFILL_MAX")) : 600;
@@ -2485,7 +2490,7 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
         const int nb = std::min(65535, batch - b0);
         GemmRows R; if (rows) R = *rows;
         R.z0 = b0;
-        static const int xcd_env = getenv("HELM_ND_XCDMAP") ? atoi(getenv("HELM_ND_XCDMAP")) : 1;
+        static const int xcd_env = getenv("HELM_ND_XCDMAP") ? atoi(getenv("HELM_ND_XCDMAP")) : 2;
         R.xcd_map = xcd_env;
         const cplx *Ab = A + b0 * sa, *Bb = B ? B + b0 * sb : B;
         cplx *Cb = C ? C + b0 * sc : C;
