@@ -1136,6 +1136,11 @@ __device__ __forceinline__ cplx gj_recip(cplx d) {
 //     starts with   read keys -> p;  read row p, 1 / d, own multiplier   and goes straight to the multiply-adds (the division is off the
 //     critical path: it runs beside the other three entries' updates of the previous step).
 // On return S.a holds the storage rows R with   inverse[i][sigma(k)] = R[sigma(i)][k].
+// Measured with clock64 around the call (2.39 GHz, one workgroup): 48 000 cycles for 32 steps = 1500 per step for ~110 instructions per
+// wave -- the step is bound by the number of instructions one wave has to issue one after the other, not by a particular latency.  A form
+// in panels of four steps (the four columns of a panel in one half-wave: pivot search and pivot row by v_readlane, the other threads apply
+// four steps at once after one barrier; bit-for-bit the same result) was built and measured: 3550 cycles for the four narrow steps + 1700
+// for the rank-4 update per panel = the same 46-50 000 cycles; reverted.
 __device__ __forceinline__ void gj32(Gj32 &S, int n, int tid) {
     const int i = tid >> 3, jc = tid & 7, j0 = jc * 4;
     bool used = i >= n;
@@ -3466,7 +3471,9 @@ int nd_resid_nm(helm_op *op, const cplx *planes, const cplx *Xin, int ldin, cplx
     const int seg = std::max(8, seg_env);
     // rows per thread: measured on 1024^2 x 256 (norm-only launch, round 2): 1 -> 2.52 ms, 2 -> 3.71 ms, 4 -> 2.23 ms.  Round 3, launch with the
     // wavefield store (13 GB moved): 3.45 ms -> 2.59 ms (5.0 TB/s, the rate of a plain copy on this part) with the coefficients staged in
-    // LDS (k_resid_nm_lds, full-width batches); wave-uniform scalar loads of the coefficients instead: 3.3 ms at RPT = 2, SGPR spills at 4
+    // LDS (k_resid_nm_lds, full-width batches); wave-uniform scalar loads of the coefficients instead: 3.3 ms at RPT = 2, SGPR spills at 4.
+    // Round 4, LDS kernel without the wavefield store, q read everywhere / q masked: RPT 4 -> 1.57 / 1.20 ms, 6 -> 1.63 / 1.39, 8 -> 2.73 / 2.62
+    // (the window of 10 x 3 values halves the occupancy): 4 stays
     static const int rpt_env = getenv("HELM_ND_RESID_RPT") ? atoi(getenv("HELM_ND_RESID_RPT")) : 4;
     const int rpt = (rpt_env == 1 || rpt_env == 2 || rpt_env == 8) ? rpt_env : 4;
     const int ntiles = ((op->nz + rpt - 1) / rpt) * ((op->nx + seg - 1) / seg);
