@@ -56,6 +56,26 @@ def test_batched_inverse(helm_lib, n, batch):
         assert np.abs(out[b] @ A[b] - np.eye(n)).max() <= 1e-10
 
 
+@pytest.mark.parametrize('n,batch', [(512, 2), (545, 1), (1024, 1), (1101, 3)])
+def test_one_launch_block_step_agrees_with_the_two_launch_form(helm_lib, n, batch, monkeypatch):
+    """From 512 to 1536 unknowns a block step of the Gauss-Jordan inversion is ONE launch that reads one copy of the matrix and writes the other
+    (k_gj_step, direct.hip); HELM_ND_GJSTEP=0 is the panel copy + update pair.  Same pivots, the products in another order: the inverses agree
+    to rounding -- even and odd numbers of steps (the odd ones end in the workspace and are copied back), a last block of 1 and of 13 columns."""
+    rng = np.random.default_rng(7 * n)
+    A = crand(rng, batch, n, n) + 2.0 * np.sqrt(n) * np.eye(n)
+    A[0, 0, 0] = 0.0
+    A[-1, 32:36, 32:36] = np.fliplr(np.eye(4)) * 3.0
+    outs = []
+    for flag in ('0', '1'):
+        monkeypatch.setenv('HELM_ND_GJSTEP', flag)
+        out = np.ascontiguousarray(A.copy())
+        assert helm_lib.helm_debug_inverse(0, n, out.ctypes.data_as(ctypes.c_void_p), batch) == 0
+        outs.append(out)
+    for b in range(batch):
+        assert np.abs(outs[1][b] @ A[b] - np.eye(n)).max() <= 1e-9
+        assert np.abs(outs[1][b] - outs[0][b]).max() <= 1e-11 * np.abs(outs[0][b]).max() * n
+
+
 @pytest.mark.parametrize('n,batch', [(512, 1), (600, 2), (1000, 1), (1101, 3), (3100, 1)])
 def test_large_inverse_with_look_ahead_and_block_recursion(helm_lib, n, batch):
     """From 512 unknowns up the blocked Gauss-Jordan sweeps the next pivot block inside the launch of the current rank-32 update; from 3000

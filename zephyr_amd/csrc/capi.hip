@@ -306,6 +306,7 @@ extern "C" void helm_destroy(helm_op *op) {
     for (int b = 0; b < 4; ++b) { nd_free(op->direct[b]); op->direct[b] = nullptr; }
     helm_pool_free(op->device, op->d_ws, op->ws_bytes); helm_pool_free(op->device, op->d_part, op->part_bytes);
     helm_pool_free(op->device, op->sk_buf, op->sk_bytes);
+    helm_pool_free(op->device, op->gjp_buf, op->gjp_bytes);
     helm_pool_free(op->device, op->d_scal, (size_t)op->scal_cap * sizeof(RhsScal));
     helm_hostpool_free(op->h_scal, op->h_scal_bytes);
     if (op->pf_done) hipEventDestroy(op->pf_done);

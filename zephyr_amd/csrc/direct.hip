@@ -1495,6 +1495,184 @@ __global__ __launch_bounds__(256, 2) void k_zgemm3_la(int M, int Nn, int K, cplx
     zgemm3_body<WM, WN, MT, NT, 0, KS>(M, Nn, K, alpha, A0 - sa, lda, sa, B0 - sb, ldb, sb, beta, C0 - sc, ldc, sc, R, reinterpret_cast<cplx *>(lds));
 }
 
+// ---- one launch per block step of the blocked Gauss-Jordan inversion (round 4) ---------------------------------------------------------------
+// The step   T <- Z(T) - C R   with   R = P T[k rows, :] (R_k := P),  C = T[:, k cols] (C_k := -I)   needed two launches because the update overwrites
+// the pivot rows and columns that the other tiles still read: k_gj_slices copied the panels out first (18 us of the 54 us a step of a 1024-wide
+// front takes).  With TWO copies of the matrix -- a step reads one and writes the other -- nothing a tile reads is written in the same launch,
+// so every 64 x 32 tile forms its own slab of R (P times the raw pivot rows of its 32 columns: 32^3 multiply-adds, redundant across the row
+// tiles, hidden behind the sweep) and takes its slab of C straight from the source.  The sweep of the NEXT pivot block rides in the first
+// z-slice as before; it applies the step to its 32 x 32 block privately, now from the source matrix and P (two 32^3 products) instead of
+// the panels.  The workspace W holds the second copy (n^2 per matrix), the two alternating P buffers come from the handle.
+struct GjStepArgs {
+    const cplx *Ta; int lda; long long sa;     // source: read-only in this launch
+    cplx *Tb; int ldb; long long sb;           // destination
+    int n, k0, nb;                             // this step's pivot block: rows / columns [k0, k0 + nb)
+    const cplx *P; cplx *Pn; long long sp;     // its inverse (PNB x PNB per matrix) ; where the sweep leaves the next block's
+    int k1, nb1;                               // the next pivot block (nb1 == 0: none)
+    int batch;
+};
+constexpr int GJS_LDS = 4 * PNB * (PNB + 1) * (int)sizeof(cplx);
+static_assert(GJS_LDS >= (int)sizeof(Gj32) + PNB * (int)sizeof(int), "the sweep state lies over the four blocks");
+
+__global__ __launch_bounds__(256, 2) void k_gj_step(GjStepArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[GJS_LDS];
+    const int tid = threadIdx.x;
+    const int k0 = a.k0, nb = a.nb, n = a.n;
+    if (blockIdx.z == 0) {                                   // ---- sweep of the next pivot block (one workgroup per matrix)
+        const int mat = blockIdx.y * gridDim.x + blockIdx.x;
+        if (mat >= a.batch || a.nb1 == 0) return;
+        const cplx *Ta = a.Ta + (long long)mat * a.sa, *P = a.P + (long long)mat * a.sp;
+        cplx *Pn = a.Pn + (long long)mat * a.sp;
+        const int k1 = a.k1, nb1 = a.nb1, lda = a.lda;
+        cplx (&Ls)[PNB][PNB + 1] = *reinterpret_cast<cplx (*)[PNB][PNB + 1]>(lds);
+        cplx (&Us)[PNB][PNB + 1] = *reinterpret_cast<cplx (*)[PNB][PNB + 1]>(lds + PNB * (PNB + 1) * sizeof(cplx));
+        cplx (&Ps)[PNB][PNB + 1] = *reinterpret_cast<cplx (*)[PNB][PNB + 1]>(lds + 2 * PNB * (PNB + 1) * sizeof(cplx));
+        cplx (&Vs)[PNB][PNB + 1] = *reinterpret_cast<cplx (*)[PNB][PNB + 1]>(lds + 3 * PNB * (PNB + 1) * sizeof(cplx));
+        Gj32 &S = *reinterpret_cast<Gj32 *>(lds);
+        int *cperm = reinterpret_cast<int *>(lds + sizeof(Gj32));
+        const int i = tid >> 3, j0 = (tid & 7) * 4;
+        cplx v[4];
+        #pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = j0 + q;
+            Ls[i][j] = (i < nb1 && j < nb) ? Ta[(long long)(k1 + i) * lda + k0 + j] : cmake(0.0, 0.0);       // C_k, rows of the next block
+            Us[i][j] = (i < nb && j < nb1) ? Ta[(long long)(k0 + i) * lda + k1 + j] : cmake(0.0, 0.0);       // pivot rows, columns of the next block
+            Ps[i][j] = (i < nb && j < nb) ? P[i * PNB + j] : cmake(0.0, 0.0);
+            v[q] = (i < nb1 && j < nb1) ? Ta[(long long)(k1 + i) * lda + k1 + j] : cmake(i == j ? 1.0 : 0.0, 0.0);
+        }
+        __syncthreads();
+        {
+            cplx acc[4];
+            #pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = cmake(0.0, 0.0);
+            #pragma unroll 2
+            for (int p = 0; p < PNB; ++p) {
+                const cplx x = Ps[i][p];
+                #pragma unroll
+                for (int q = 0; q < 4; ++q) cfma(acc[q], x, Us[p][j0 + q]);
+            }
+            #pragma unroll
+            for (int q = 0; q < 4; ++q) Vs[i][j0 + q] = acc[q];                                               // R_k, columns of the next block
+        }
+        __syncthreads();
+        {
+            cplx acc[4];
+            #pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = cmake(0.0, 0.0);
+            #pragma unroll 2
+            for (int p = 0; p < PNB; ++p) {
+                const cplx x = Ls[i][p];
+                #pragma unroll
+                for (int q = 0; q < 4; ++q) cfma(acc[q], x, Vs[p][j0 + q]);
+            }
+            #pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = csub(v[q], acc[q]);
+        }
+        __syncthreads();                                     // the four blocks are read: S takes their place
+        #pragma unroll
+        for (int q = 0; q < 4; ++q) S.a[i][j0 + q] = v[q];
+        __syncthreads();
+        gj32(S, nb1, tid);
+        if (tid < PNB) cperm[tid] = S.piv[tid] & 31;         // P[r][sigma(j)] = S.a[sigma(r)][j]
+        __syncthreads();
+        #pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = j0 + q;
+            if (i < nb1 && j < nb1) Pn[i * PNB + cperm[j]] = S.a[cperm[i]][j];
+        }
+        return;
+    }
+    // ---- a 64 x 32 tile of the update
+    const int mat = blockIdx.z - 1;
+    const cplx *Ta = a.Ta + (long long)mat * a.sa, *P = a.P + (long long)mat * a.sp;
+    cplx *Tb = a.Tb + (long long)mat * a.sb;
+    const int lda = a.lda, ldb = a.ldb;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 32;
+    cplx (&As)[64][PNB + 1] = *reinterpret_cast<cplx (*)[64][PNB + 1]>(lds);
+    cplx (&Ps)[PNB][PNB + 1] = *reinterpret_cast<cplx (*)[PNB][PNB + 1]>(lds + 2 * PNB * (PNB + 1) * sizeof(cplx));
+    cplx (&Bs)[PNB][PNB + 1] = *reinterpret_cast<cplx (*)[PNB][PNB + 1]>(lds + 3 * PNB * (PNB + 1) * sizeof(cplx));
+    #pragma unroll
+    for (int l = 0; l < 8; ++l) {                            // C slab: T[tile rows, k cols], -I on the pivot rows
+        const int e = tid + 256 * l, r = e >> 5, j = e & 31, gr = r0 + r;
+        cplx x = cmake(0.0, 0.0);
+        if (gr < n && j < nb) {
+            if (gr >= k0 && gr < k0 + nb) x = cmake(gr - k0 == j ? -1.0 : 0.0, 0.0);
+            else x = Ta[(long long)gr * lda + k0 + j];
+        }
+        As[r][j] = x;
+    }
+    #pragma unroll
+    for (int l = 0; l < 4; ++l) {                            // P, and the raw pivot rows of the tile's columns (the identity where they are pivot columns: R_k = P)
+        const int e = tid + 256 * l, r = e >> 5, c = e & 31, gc = c0 + c;
+        Ps[r][c] = (r < nb && c < nb) ? P[r * PNB + c] : cmake(0.0, 0.0);
+        cplx x = cmake(0.0, 0.0);
+        if (r < nb && gc < n) {
+            if (gc >= k0 && gc < k0 + nb) x = cmake(gc - k0 == r ? 1.0 : 0.0, 0.0);
+            else x = Ta[(long long)(k0 + r) * lda + gc];
+        }
+        Bs[r][c] = x;
+    }
+    __syncthreads();
+    // both products on the matrix cores (v_mfma_f64_16x16x4_f64: A lane l = A[l % 16][l / 16], B lane l = B[l / 16][l % 16], D register q of lane l =
+    // D[l / 16 + 4 q][l % 16]; four real instructions per complex block and k step of 4, as in zgemm3_body)
+    const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+    {
+        const int br = wave >> 1, bc = wave & 1;             // wave -> one 16 x 16 block of the 32 x 32 slab R = P * (raw pivot rows)
+        v4f64 er = {0.0, 0.0, 0.0, 0.0}, ei = {0.0, 0.0, 0.0, 0.0};
+        #pragma unroll
+        for (int ks = 0; ks < PNB / 4; ++ks) {
+            const cplx x = Ps[16 * br + lr][4 * ks + lq], y = Bs[4 * ks + lq][16 * bc + lr];
+            er = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, y.x, er, 0, 0, 0);
+            ei = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, y.y, ei, 0, 0, 0);
+            er = __builtin_amdgcn_mfma_f64_16x16x4f64(-x.y, y.y, er, 0, 0, 0);
+            ei = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, y.x, ei, 0, 0, 0);
+        }
+        __syncthreads();                                     // the raw rows are read: the slab takes their place
+        #pragma unroll
+        for (int q = 0; q < 4; ++q) Bs[16 * br + lq + 4 * q][16 * bc + lr] = cmake(er[q], ei[q]);
+    }
+    __syncthreads();
+    v4f64 cr[2], ci[2];                                      // wave -> rows 16 wave .. + 15 of the tile, both 16-column blocks
+    #pragma unroll
+    for (int j = 0; j < 2; ++j) { cr[j] = v4f64{0.0, 0.0, 0.0, 0.0}; ci[j] = v4f64{0.0, 0.0, 0.0, 0.0}; }
+    #pragma unroll
+    for (int ks = 0; ks < PNB / 4; ++ks) {
+        const cplx x = As[16 * wave + lr][4 * ks + lq];
+        #pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const cplx y = Bs[4 * ks + lq][16 * j + lr];
+            cr[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, y.x, cr[j], 0, 0, 0);
+            ci[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, y.y, ci[j], 0, 0, 0);
+            cr[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x.y, y.y, cr[j], 0, 0, 0);
+            ci[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, y.x, ci[j], 0, 0, 0);
+        }
+    }
+    #pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int gr = r0 + 16 * wave + lq + 4 * q;
+        if (gr >= n) continue;
+        const bool prow = gr >= k0 && gr < k0 + nb;
+        #pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int gc = c0 + 16 * j + lr;
+            if (gc >= n) continue;
+            const bool zero = prow || (gc >= k0 && gc < k0 + nb);
+            const cplx cin = zero ? cmake(0.0, 0.0) : Ta[(long long)gr * lda + gc];
+            Tb[(long long)gr * ldb + gc] = csub(cin, cmake(cr[j][q], ci[j][q]));
+        }
+    }
+}
+
+// dst[mat][r][c] = src[mat][r][c] for n x n blocks with different leading dimensions (the odd step count of k_gj_step leaves the result in W)
+__global__ __launch_bounds__(256) void k_copy_blocks(const cplx *src, int lds_, long long ss, cplx *dst, int ldd, long long sd, int n) {
+    const cplx *s = src + (long long)blockIdx.y * ss;
+    cplx *d = dst + (long long)blockIdx.y * sd;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < (long long)n * n; e += (long long)gridDim.x * 256) {
+        const int r = (int)(e / n), c = (int)(e % n);
+        d[(long long)r * ldd + c] = s[(long long)r * lds_ + c];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_gj_slices(const cplx *T0, int ld, long long stride, int n, int k0, int nb, cplx *Wc0, cplx *Wr0, long long wstride,
                                                    const cplx *Pb0, long long pstride) {
     __shared__ cplx P[PNB][PNB + 1];
@@ -2395,6 +2573,25 @@ int gemm_variant() {
     return g_gemm_variant >= 0 ? g_gemm_variant : gemm_v;
 }
 
+struct ExtArm {            // arms the per-launch event pair for the launchers below, books it when the launch is out
+    helm_op *op; bool on; double fl, by; long long shape[5];
+    ExtArm(helm_op *o, bool e, double f, double b, int m_, int n_, int k_, int nb_, int mode_) : op(o), on(false), fl(f), by(b), shape{m_, n_, k_, nb_, mode_} {
+        if (!e) return;
+        if (op->ev_used + 2 > op->ev_pool.size() && op->ev_pool.size() < 16384) (void)helm_events_grow(op, 64);
+        if (op->ev_used + 2 <= op->ev_pool.size()) { tl_ev0 = op->ev_pool[op->ev_used]; tl_ev1 = op->ev_pool[op->ev_used + 1]; on = true; }
+    }
+    ~ExtArm() {
+        if (!on) return;
+        op->ev_pending_gemm.push_back(std::make_pair((int)op->ev_used, fl));
+        op->ev_pending_gemm_n.push_back(1);
+        op->ev_pending_gemm_bytes.push_back(by);
+        op->ev_pending_gemm_sol.push_back(gemm_sol_ms(fl, by));
+        for (int q = 0; q < 5; ++q) op->ev_pending_gemm_shape.push_back(shape[q]);
+        op->ev_used += 2;
+        tl_ev0 = tl_ev1 = nullptr;
+    }
+};
+
 // op may be null (diagnostic entry points): default stream, no profiling
 int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, long long sa, const cplx *B, int ldb, long long sb,
          cplx beta, cplx *C, int ldc, long long sc, int batch, const GemmRows *rows = nullptr) {
@@ -2501,24 +2698,7 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
         cplx *Cb = C ? C + b0 * sc : C;
         // (a 4 x 8 register block per thread -- RN = 8, 64 x 128 tile -- was measured too: 230 VGPRs, occupancy 2, 38 % slower)
         const int gv = gemm_variant();
-        struct ExtArm {            // arms the per-launch event pair for the launchers below, books it when the launch is out
-            helm_op *op; bool on; double fl, by; long long shape[5];
-            ExtArm(helm_op *o, bool e, double f, double b, int m_, int n_, int k_, int nb_, int mode_) : op(o), on(false), fl(f), by(b), shape{m_, n_, k_, nb_, mode_} {
-                if (!e) return;
-                if (op->ev_used + 2 > op->ev_pool.size() && op->ev_pool.size() < 16384) (void)helm_events_grow(op, 64);
-                if (op->ev_used + 2 <= op->ev_pool.size()) { tl_ev0 = op->ev_pool[op->ev_used]; tl_ev1 = op->ev_pool[op->ev_used + 1]; on = true; }
-            }
-            ~ExtArm() {
-                if (!on) return;
-                op->ev_pending_gemm.push_back(std::make_pair((int)op->ev_used, fl));
-                op->ev_pending_gemm_n.push_back(1);
-                op->ev_pending_gemm_bytes.push_back(by);
-                op->ev_pending_gemm_sol.push_back(gemm_sol_ms(fl, by));
-                for (int q = 0; q < 5; ++q) op->ev_pending_gemm_shape.push_back(shape[q]);
-                op->ev_used += 2;
-                tl_ev0 = tl_ev1 = nullptr;
-            }
-        } arm(op, ext, 8.0 * M * (double)Nn * K * nb, gemm_operand_bytes(M, Nn, K, beta, rows) * nb, M, Nn, K, nb,
+        ExtArm arm(op, ext, 8.0 * M * (double)Nn * K * nb, gemm_operand_bytes(M, Nn, K, beta, rows) * nb, M, Nn, K, nb,
               rows && rows->schur4 ? 4 : (rows && !rows->dense ? (rows->fwd3 ? 2 : 1) : (rows && rows->la ? 5 : 0)));
 #define ZG_ARGS st, (rows && rows->schur4 ? 4 : (rows && !rows->dense ? (rows->fwd3 ? 2 : 1) : 0)), nb, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R
 #define ZG_VEC(TM_, RN_) do { switch (gv) { \
@@ -2615,6 +2795,26 @@ struct GemmRun {
     }
 };
 
+// scratch for the alternating pivot-block inverses of k_gj_step (2 PNB^2 per matrix): the handle's own, or one process-wide buffer for the
+// diagnostic entry points (single-threaded)
+static cplx *gj_pbuf(helm_op *op, int batch) {
+    const size_t need = (size_t)batch * 2 * PNB * PNB * sizeof(cplx);
+    if (op) {
+        if (op->gjp_bytes < need) {
+            if (op->gjp_buf) { hipStreamSynchronize(op->stream); helm_pool_free(op->device, op->gjp_buf, op->gjp_bytes); op->gjp_buf = nullptr; op->gjp_bytes = 0; }
+            op->gjp_buf = (cplx *)helm_pool_alloc(op->device, need);
+            op->gjp_bytes = op->gjp_buf ? need : 0;
+        }
+        return op->gjp_buf;
+    }
+    static cplx *buf = nullptr; static size_t bytes = 0;
+    if (bytes < need) {
+        if (buf) { hipDeviceSynchronize(); hipFree(buf); buf = nullptr; bytes = 0; }
+        if (hipMalloc((void **)&buf, need) == hipSuccess) bytes = need; else buf = nullptr;
+    }
+    return buf;
+}
+
 // in-place inverse of `batch` n x n blocks (row-major, leading dimension ld, batch stride `stride`); W: workspace with
 // batch stride ws, at least n*n elements per matrix
 int g_recurse_min = -1;     // (helm_debug_inverse_bench overrides HELM_ND_RECURSE_N)
@@ -2641,6 +2841,37 @@ void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cp
         // (the dense plane inverses of the 3-D coarse solve, n = 3713: -7 %; the 2-D fronts of 512 and 1024 unknowns at the top of the tree, with the
         // 32 x 32 latency tile: +0.6 % on the bench; below that the split panel kernels cost more than the sweep hides.
         // A first version ran the sweep on a second stream: same gain at n = 3713, but two cross-stream event hops per step, -5 % in 2-D)
+        // one launch per block step (k_gj_step): the second copy of the matrix lives in W, the two P buffers in the handle's scratch
+        const int gjstep = getenv("HELM_ND_GJSTEP") ? atoi(getenv("HELM_ND_GJSTEP")) : 1;          // (read per call: the tests compare the two forms)
+        static const int gjstep_min = getenv("HELM_ND_GJSTEP_MIN") ? atoi(getenv("HELM_ND_GJSTEP_MIN")) : 512;
+        static const int gjstep_max = getenv("HELM_ND_GJSTEP_MAX") ? atoi(getenv("HELM_ND_GJSTEP_MAX")) : 1536;
+        if (gjstep && gemm_variant() == 7 && n >= gjstep_min && n <= gjstep_max && (long long)n * n <= ws && (long long)((n + 63) / 64) * ((n + 31) / 32) >= batch) {
+            cplx *Pb = gj_pbuf(op, batch);
+            if (Pb) {
+                const long long sp = 2LL * PNB * PNB;
+                hipLaunchKernelGGL(k_gj_pivot, dim3(batch), dim3(256), 0, st, M, ld, stride, n, 0, std::min(PNB, n), (const cplx *)nullptr, (const cplx *)nullptr, ws, Pb, sp);
+                static const int prof_ext = getenv("HELM_PROF_EXT") ? atoi(getenv("HELM_PROF_EXT")) : 1;
+                const bool ext = prof_ext && op && op->profiling;
+                int step = 0;
+                for (int k0 = 0; k0 < n; k0 += PNB, ++step) {
+                    const int nb = std::min(PNB, n - k0);
+                    GjStepArgs a;
+                    const bool fromM = (step & 1) == 0;
+                    a.Ta = fromM ? M : W; a.lda = fromM ? ld : n; a.sa = fromM ? stride : ws;
+                    a.Tb = fromM ? W : M; a.ldb = fromM ? n : ld; a.sb = fromM ? ws : stride;
+                    a.n = n; a.k0 = k0; a.nb = nb;
+                    a.P = Pb + (step & 1) * PNB * PNB; a.Pn = Pb + ((step + 1) & 1) * PNB * PNB; a.sp = sp;
+                    a.k1 = k0 + PNB; a.nb1 = k0 + PNB < n ? std::min(PNB, n - k0 - PNB) : 0;
+                    a.batch = batch;
+                    // booked with the products (mode 5: update + pivot sweep): 8 n^2 nb flop, the matrix read and written once
+                    ExtArm arm(op, ext, 8.0 * n * (double)n * nb * batch, 16.0 * (2.0 * n * (double)n + 2.0 * n * nb) * batch, n, n, nb, batch, 5);
+                    const dim3 grid((n + 31) / 32, (n + 63) / 64, batch + 1);
+                    ZG_LAUNCH(k_gj_step, grid, a);
+                }
+                if (step & 1) hipLaunchKernelGGL(k_copy_blocks, dim3((unsigned)std::min<long long>(((long long)n * n + 255) / 256, 1024), batch), dim3(256), 0, st, (const cplx *)W, n, ws, M, ld, stride, n);
+                return;
+            }
+        }
         static const int lookahead = getenv("HELM_ND_LOOKAHEAD") ? atoi(getenv("HELM_ND_LOOKAHEAD")) : 1;
         static const int lookahead_min_n = getenv("HELM_ND_LOOKAHEAD_N") ? atoi(getenv("HELM_ND_LOOKAHEAD_N")) : 512;
         // (one sweep per matrix rides in the first z-slice of the update's grid: that slice must have a workgroup for each)

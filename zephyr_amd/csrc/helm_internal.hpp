@@ -99,6 +99,7 @@ struct helm_op {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     cplx *sk_buf = nullptr; size_t sk_bytes = 0;   // partial products of split-K launches (direct.hip gemm), from the pool
+    cplx *gjp_buf = nullptr; size_t gjp_bytes = 0; // alternating pivot-block inverses of the one-launch Gauss-Jordan step (direct.hip k_gj_step), from the pool
     hipStream_t side_stream = nullptr;    // second stream of the direct path (forward elimination behind the factorisation), on demand
     // helm_prefactor: the factorisation of the assembled operator enqueued on a high-priority stream of its own, so that it runs beside
     // the solves of ANOTHER handle (the previous frequency of a job); the next solve on this handle waits for pf_done on the device
