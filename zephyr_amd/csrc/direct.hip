@@ -1511,64 +1511,59 @@ struct GjStepArgs {
     int k1, nb1;                               // the next pivot block (nb1 == 0: none)
     int batch;
 };
-constexpr int GJS_LDS = 4 * PNB * (PNB + 1) * (int)sizeof(cplx);
-static_assert(GJS_LDS >= (int)sizeof(Gj32) + PNB * (int)sizeof(int), "the sweep state lies over the four blocks");
+// LDS: the sweep state (35 KB) -- the two 32 x 32 blocks of the private update and the tiles' P and R slab lie over it.  (A first version kept four
+// blocks, 68 KB: alone on the GPU the same speed, but beside the solve kernels of the previous work item a workgroup of that size waits for a
+// compute unit with that much LDS free -- the products' launches took 171 instead of 156 us on average inside the pipeline; with 35 KB 156.)
+constexpr int GJS_LDS = (int)sizeof(Gj32) + PNB * (int)sizeof(int);
+static_assert(GJS_LDS >= 2 * PNB * (PNB + 1) * (int)sizeof(cplx), "two 32 x 32 blocks lie over the sweep state");
 
 __global__ __launch_bounds__(256, 2) void k_gj_step(GjStepArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[GJS_LDS];
     const int tid = threadIdx.x;
     const int k0 = a.k0, nb = a.nb, n = a.n;
+    cplx (&X0)[PNB][PNB + 1] = *reinterpret_cast<cplx (*)[PNB][PNB + 1]>(lds);
+    cplx (&X1)[PNB][PNB + 1] = *reinterpret_cast<cplx (*)[PNB][PNB + 1]>(lds + PNB * (PNB + 1) * sizeof(cplx));
     if (blockIdx.z == 0) {                                   // ---- sweep of the next pivot block (one workgroup per matrix)
         const int mat = blockIdx.y * gridDim.x + blockIdx.x;
         if (mat >= a.batch || a.nb1 == 0) return;
         const cplx *Ta = a.Ta + (long long)mat * a.sa, *P = a.P + (long long)mat * a.sp;
         cplx *Pn = a.Pn + (long long)mat * a.sp;
         const int k1 = a.k1, nb1 = a.nb1, lda = a.lda;
-        cplx (&Ls)[PNB][PNB + 1] = *reinterpret_cast<cplx (*)[PNB][PNB + 1]>(lds);
-        cplx (&Us)[PNB][PNB + 1] = *reinterpret_cast<cplx (*)[PNB][PNB + 1]>(lds + PNB * (PNB + 1) * sizeof(cplx));
-        cplx (&Ps)[PNB][PNB + 1] = *reinterpret_cast<cplx (*)[PNB][PNB + 1]>(lds + 2 * PNB * (PNB + 1) * sizeof(cplx));
-        cplx (&Vs)[PNB][PNB + 1] = *reinterpret_cast<cplx (*)[PNB][PNB + 1]>(lds + 3 * PNB * (PNB + 1) * sizeof(cplx));
         Gj32 &S = *reinterpret_cast<Gj32 *>(lds);
         int *cperm = reinterpret_cast<int *>(lds + sizeof(Gj32));
         const int i = tid >> 3, j0 = (tid & 7) * 4;
-        cplx v[4];
+        cplx v[4], lreg[4];
         #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int j = j0 + q;
-            Ls[i][j] = (i < nb1 && j < nb) ? Ta[(long long)(k1 + i) * lda + k0 + j] : cmake(0.0, 0.0);       // C_k, rows of the next block
-            Us[i][j] = (i < nb && j < nb1) ? Ta[(long long)(k0 + i) * lda + k1 + j] : cmake(0.0, 0.0);       // pivot rows, columns of the next block
-            Ps[i][j] = (i < nb && j < nb) ? P[i * PNB + j] : cmake(0.0, 0.0);
+            X0[i][j] = (i < nb && j < nb1) ? Ta[(long long)(k0 + i) * lda + k1 + j] : cmake(0.0, 0.0);       // pivot rows, columns of the next block
+            X1[i][j] = (i < nb && j < nb) ? P[i * PNB + j] : cmake(0.0, 0.0);
+            lreg[q] = (i < nb1 && j < nb) ? Ta[(long long)(k1 + i) * lda + k0 + j] : cmake(0.0, 0.0);        // C_k, rows of the next block
             v[q] = (i < nb1 && j < nb1) ? Ta[(long long)(k1 + i) * lda + k1 + j] : cmake(i == j ? 1.0 : 0.0, 0.0);
         }
         __syncthreads();
-        {
-            cplx acc[4];
+        cplx acc[4];
+        #pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = cmake(0.0, 0.0);
+        #pragma unroll 2
+        for (int p = 0; p < PNB; ++p) {
+            const cplx x = X1[i][p];
             #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = cmake(0.0, 0.0);
-            #pragma unroll 2
-            for (int p = 0; p < PNB; ++p) {
-                const cplx x = Ps[i][p];
-                #pragma unroll
-                for (int q = 0; q < 4; ++q) cfma(acc[q], x, Us[p][j0 + q]);
-            }
-            #pragma unroll
-            for (int q = 0; q < 4; ++q) Vs[i][j0 + q] = acc[q];                                               // R_k, columns of the next block
+            for (int q = 0; q < 4; ++q) cfma(acc[q], x, X0[p][j0 + q]);
         }
         __syncthreads();
-        {
-            cplx acc[4];
+        #pragma unroll
+        for (int q = 0; q < 4; ++q) { X0[i][j0 + q] = acc[q]; X1[i][j0 + q] = lreg[q]; acc[q] = cmake(0.0, 0.0); }      // R_k (columns of the next block), C_k
+        __syncthreads();
+        #pragma unroll 2
+        for (int p = 0; p < PNB; ++p) {
+            const cplx x = X1[i][p];
             #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = cmake(0.0, 0.0);
-            #pragma unroll 2
-            for (int p = 0; p < PNB; ++p) {
-                const cplx x = Ls[i][p];
-                #pragma unroll
-                for (int q = 0; q < 4; ++q) cfma(acc[q], x, Vs[p][j0 + q]);
-            }
-            #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = csub(v[q], acc[q]);
+            for (int q = 0; q < 4; ++q) cfma(acc[q], x, X0[p][j0 + q]);
         }
-        __syncthreads();                                     // the four blocks are read: S takes their place
+        #pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = csub(v[q], acc[q]);
+        __syncthreads();                                     // the two blocks are read: S takes their place
         #pragma unroll
         for (int q = 0; q < 4; ++q) S.a[i][j0 + q] = v[q];
         __syncthreads();
@@ -1582,24 +1577,28 @@ __global__ __launch_bounds__(256, 2) void k_gj_step(GjStepArgs a) {
         }
         return;
     }
-    // ---- a 64 x 32 tile of the update
+    // ---- a 64 x 32 tile of the update, both products on the matrix cores (v_mfma_f64_16x16x4_f64: A lane l = A[l % 16][l / 16], B lane l = B[l / 16][l % 16],
+    // D register q of lane l = D[l / 16 + 4 q][l % 16]; four real instructions per complex block and k step of 4, as in zgemm3_body)
     const int mat = blockIdx.z - 1;
     const cplx *Ta = a.Ta + (long long)mat * a.sa, *P = a.P + (long long)mat * a.sp;
     cplx *Tb = a.Tb + (long long)mat * a.sb;
     const int lda = a.lda, ldb = a.ldb;
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 32;
-    cplx (&As)[64][PNB + 1] = *reinterpret_cast<cplx (*)[64][PNB + 1]>(lds);
-    cplx (&Ps)[PNB][PNB + 1] = *reinterpret_cast<cplx (*)[PNB][PNB + 1]>(lds + 2 * PNB * (PNB + 1) * sizeof(cplx));
-    cplx (&Bs)[PNB][PNB + 1] = *reinterpret_cast<cplx (*)[PNB][PNB + 1]>(lds + 3 * PNB * (PNB + 1) * sizeof(cplx));
-    #pragma unroll
-    for (int l = 0; l < 8; ++l) {                            // C slab: T[tile rows, k cols], -I on the pivot rows
-        const int e = tid + 256 * l, r = e >> 5, j = e & 31, gr = r0 + r;
-        cplx x = cmake(0.0, 0.0);
-        if (gr < n && j < nb) {
-            if (gr >= k0 && gr < k0 + nb) x = cmake(gr - k0 == j ? -1.0 : 0.0, 0.0);
-            else x = Ta[(long long)gr * lda + k0 + j];
+    const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+    cplx (&Ps)[PNB][PNB + 1] = X0;
+    cplx (&Bs)[PNB][PNB + 1] = X1;
+    // this lane's fragments of the C slab T[tile rows, k cols] (-I on the pivot rows): row 16 wave + lr, columns 4 ks + lq -- straight from the source
+    cplx afr[PNB / 4];
+    {
+        const int gr = r0 + 16 * wave + lr;
+        const bool prow = gr >= k0 && gr < k0 + nb;
+        #pragma unroll
+        for (int ks = 0; ks < PNB / 4; ++ks) {
+            const int j = 4 * ks + lq;
+            cplx x = cmake(0.0, 0.0);
+            if (gr < n && j < nb) x = prow ? cmake(gr - k0 == j ? -1.0 : 0.0, 0.0) : Ta[(long long)gr * lda + k0 + j];
+            afr[ks] = x;
         }
-        As[r][j] = x;
     }
     #pragma unroll
     for (int l = 0; l < 4; ++l) {                            // P, and the raw pivot rows of the tile's columns (the identity where they are pivot columns: R_k = P)
@@ -1613,9 +1612,6 @@ __global__ __launch_bounds__(256, 2) void k_gj_step(GjStepArgs a) {
         Bs[r][c] = x;
     }
     __syncthreads();
-    // both products on the matrix cores (v_mfma_f64_16x16x4_f64: A lane l = A[l % 16][l / 16], B lane l = B[l / 16][l % 16], D register q of lane l =
-    // D[l / 16 + 4 q][l % 16]; four real instructions per complex block and k step of 4, as in zgemm3_body)
-    const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
     {
         const int br = wave >> 1, bc = wave & 1;             // wave -> one 16 x 16 block of the 32 x 32 slab R = P * (raw pivot rows)
         v4f64 er = {0.0, 0.0, 0.0, 0.0}, ei = {0.0, 0.0, 0.0, 0.0};
@@ -1637,7 +1633,7 @@ __global__ __launch_bounds__(256, 2) void k_gj_step(GjStepArgs a) {
     for (int j = 0; j < 2; ++j) { cr[j] = v4f64{0.0, 0.0, 0.0, 0.0}; ci[j] = v4f64{0.0, 0.0, 0.0, 0.0}; }
     #pragma unroll
     for (int ks = 0; ks < PNB / 4; ++ks) {
-        const cplx x = As[16 * wave + lr][4 * ks + lq];
+        const cplx x = afr[ks];
         #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const cplx y = Bs[4 * ks + lq][16 * j + lr];
