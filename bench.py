@@ -688,6 +688,13 @@ def main():
                 if pz:
                     out['roofline']['traffic'] = pz['traffic_bytes_per_launch']
                     out['roofline']['traffic_source'] = src_z + ' (HBM bytes per GEMM launch, FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes)'
+                    try:      # the same figure per work item against the operand bytes the library books for the launches of this run's serial pass
+                        tr = out['roofline']
+                        per_item = pz['traffic_bytes_per_launch'] * tr['launches_timed'] / float(args.steps) / 1e9
+                        tr['traffic_GB_per_item'] = per_item
+                        tr['traffic_over_operand_bytes'] = per_item / tr['two_roofs']['operand_GB_per_item']
+                    except Exception:
+                        pass
                 pr, src_r = pmc('pmc_traffic_resid_nm')
                 if pr:
                     out['stencil_roofline']['traffic'] = pr['traffic_bytes_per_launch']

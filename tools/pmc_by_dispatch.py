@@ -12,7 +12,7 @@ def load(path, counter, pattern):
     for f in glob.glob(os.path.join(path, '**', '*counter_collection.csv'), recursive=True):
         per = {}
         for r in csv.DictReader(open(f)):
-            if r.get('Counter_Name') != counter or pattern not in r.get('Kernel_Name', ''):
+            if r.get('Counter_Name') != counter or not any(pt in r.get('Kernel_Name', '') for pt in pattern.split(',')):
                 continue
             mm = re.search(r'(k_\w+(?:<[^>]*>)?)', r['Kernel_Name'])
             name = mm.group(1) if mm else r['Kernel_Name'][:40]

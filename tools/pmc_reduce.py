@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Reduce two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, as MI355X_MICROARCH.md prescribes) of the
-same command to HBM bytes per launch of the kernels whose name contains a pattern.
+same command to HBM bytes per launch of the kernels whose name contains a pattern (or one of several, comma-separated).
 
     python tools/pmc_reduce.py --fetch <dir-or-csv> --write <dir-or-csv> --kernel k_zgemm --out profiles/x.json
 
@@ -15,7 +15,7 @@ def load(path, counter, pattern):
     per = {}
     for f in files:
         for r in csv.DictReader(open(f)):
-            if r.get('Counter_Name') != counter or pattern not in r.get('Kernel_Name', ''):
+            if r.get('Counter_Name') != counter or not any(pt in r.get('Kernel_Name', '') for pt in pattern.split(',')):
                 continue
             key = r.get('Dispatch_Id')
             per[key] = per.get(key, 0.0) + float(r['Counter_Value'])

@@ -22,7 +22,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 unset HELM_ND_SPARSE_RHS
 cd $GRAFT_REPO_ROOT
-python3 tools/pmc_reduce.py --fetch $OUT/pmc_FETCH_SIZE --write $OUT/pmc_WRITE_SIZE --kernel k_zgemm3 --out $OUT/pmc_traffic_zgemm.json --note "all k_zgemm3 dispatches of one work item (factorisation + solve passes), serial, every front computed (HELM_ND_SPARSE_RHS=0)" > /dev/null
+python3 tools/pmc_reduce.py --fetch $OUT/pmc_FETCH_SIZE --write $OUT/pmc_WRITE_SIZE --kernel k_zgemm3,k_gj_step --out $OUT/pmc_traffic_zgemm.json --note "all k_zgemm3 and k_gj_step (one-launch Gauss-Jordan block step, booked with the products) dispatches of one work item (factorisation + solve passes), serial, every front computed (HELM_ND_SPARSE_RHS=0)" > /dev/null
 python3 tools/pmc_reduce.py --fetch $OUT/pmc_FETCH_SIZE --write $OUT/pmc_WRITE_SIZE --kernel k_resid_nm --out $OUT/pmc_traffic_resid.json --note "node-major residual launches (9-point stencil apply + q operand + wavefield store) of one work item, q read everywhere (HELM_ND_SPARSE_RHS=0)" > /dev/null
 python3 tools/pmc_reduce.py --fetch $OUT/pmc_FETCH_SIZE --write $OUT/pmc_WRITE_SIZE --kernel k_stencil_t --out $OUT/pmc_traffic_stencil_micro.json --note "rhs-major stencil apply launches of the in-bench microbenchmark (B = 1, 8, 32, 64; 6 launches each)" > /dev/null
 find $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE -name "*.csv" -size +2M -delete

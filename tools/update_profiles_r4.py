@@ -141,7 +141,9 @@ c5 = d['config5']; ha = d['value_host_api']
 gc_s, gn_s, gavg_s, gpct_s = gemm_avg(rows_s)
 rc_s, ravg_s = resid_avg(rows_s)
 alg_resid = St['bytes_per_launch_algorithmic']
-traffic_item = pz['traffic_bytes_per_launch'] * pz['launches_fetch_pass'] / 1e9
+# the PMC command runs the timed item and the separate roofline pass: two work items (launches per item from the driver-command record)
+pmc_items = max(1, round(pz['launches_fetch_pass'] / (Rd['launches_timed'] / float(dd['steps']))))
+traffic_item = pz['traffic_bytes_per_launch'] * pz['launches_fetch_pass'] / 1e9 / pmc_items
 oper_item = Rd['two_roofs']['operand_GB_per_item']
 text = f'''# profiles/ -- round 4 (MI355X, 1 GPU; collected at git `{HASH}`)
 
@@ -157,7 +159,8 @@ for the before / after comparison; their descriptions are in the git history of 
 | `r04_bench_n1.json` | `python bench.py` (default: {d['steps']} timed items after {d['warmup']} warm-up items): {d['value']:.0f} wavefields/s, {d['ms_per_step']:.1f} ms per item ({d['unprofiled']['value']:.0f} with the events off); passes per wavefield {d['config']['solves_or_iterations_per_rhs_mean']:.2f}; `parity_vs_lu_max_rel` = {d['parity_vs_lu_max_rel']:.2e} (8 sources at 6 Hz against the SuperLU wavefields of the CPU leg).  `value_host_api` (MultiFreq * q, scipy-sparse sources in, numpy wavefields out over PCIe): **{ha['value']:.0f} wavefields/s**.  `config5`: **{c5['job_seconds']:.2f} s** at rtol 1e-8 through the device pipeline ({c5.get('job_seconds_one_after_the_other', 0):.2f} s one frequency after the other: {', '.join('%g Hz %.2f s / %d its' % (p['freq_hz'], p['seconds'], max(p['iterations'])) for p in c5['per_frequency'])}), **{c5.get('job_seconds_rtol1e10', float('nan')):.2f} s at rtol 1e-10**; 27-point apply {', '.join('%.0f' % (100 * a['frac_of_peak']) for a in c5['apply'])} % of 8 TB/s at B = 1 / 4 / 8 / 16.  CPU legs on the GPU box's own host: 1 core, M1-only LU {cb['value']:.2f} wavefields/s (assemble {cb['assemble_s']:.1f} s, factor {cb['factor_s']:.1f} s, {cb['per_rhs_s']:.3f} s per source); the faithful 2N x 2N system at 512^2: {c2.get('value', float('nan')):.2f}; 16 processes, one per frequency: {cpool.get('value', float('nan')):.1f} |
 | `r04_bench_serial_rocprofv3_kernel_stats.csv`, `r04_bench_serial_under_rocprofv3.json` | `HELM_ND_SPARSE_RHS=0 rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu --no-config5 --no-host-api --no-pipeline --steps 8 --warmup 2 --no-plain-pass`: the kernels with nothing else on the GPU and nothing skipped -- the run `roofline` must agree with.  `r04_bench_serial_sparse_rhs_rocprofv3_kernel_stats.csv`: the same with the skipping on (what a production item costs) |
 | `r04_bench_pipelined_rocprofv3_kernel_stats.csv`, `r04_bench_pipelined_under_rocprofv3.json` | the pipelined timed region under the profiler ({dp['value']:.0f} wavefields/s): durations stretched by the sharing |
-| `r04_pmc_traffic_zgemm.json`, `r04_pmc_traffic_resid_nm.json`, `r04_pmc_traffic_stencil_apply.json` | `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (two separate passes) of one serial work item with every front computed, reduced per kernel by `tools/pmc_reduce.py` (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): `k_zgemm3` {pz['traffic_bytes_per_launch'] / 1e6:.0f} MB per launch over {pz['launches_fetch_pass']} launches = {traffic_item:.1f} GB per item against {oper_item:.1f} GB of necessary operand bytes = **{traffic_item / oper_item:.2f} x** (round 3: 1.41 x against operand bytes that left the gathers' necessary reads out); the residual kernel {pr['traffic_bytes_per_launch'] / 1e9:.2f} GB per launch against {alg_resid / 1e9:.2f} GB algorithmic; the rhs-major apply of the microbenchmark {ps['traffic_bytes_per_launch'] / 1e9:.2f} GB per launch averaged over B = 1, 8, 32, 64 |
+| `r04_pmc_traffic_zgemm.json`, `r04_pmc_traffic_resid_nm.json`, `r04_pmc_traffic_stencil_apply.json` | `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (two separate passes) of one serial work item with every front computed, reduced per kernel by `tools/pmc_reduce.py` (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): `k_zgemm3` + `k_gj_step` {pz['traffic_bytes_per_launch'] / 1e6:.0f} MB per launch over {pz['launches_fetch_pass']} launches of {pmc_items} work items = {traffic_item:.1f} GB per item against {oper_item:.1f} GB of necessary operand bytes = **{traffic_item / oper_item:.2f} x** (round 3: 1.41 x against operand bytes that left the gathers' necessary reads out); the residual kernel {pr['traffic_bytes_per_launch'] / 1e9:.2f} GB per launch against {alg_resid / 1e9:.2f} GB algorithmic; the rhs-major apply of the microbenchmark {ps['traffic_bytes_per_launch'] / 1e9:.2f} GB per launch averaged over B = 1, 8, 32, 64 |
+| `r04_pmc_traffic_by_shape.txt` | the same two PMC passes on `tools/bench_direct.py` (one factorisation + three passes), every `k_zgemm3` / `k_gj_step` dispatch paired with the `[gemm log]` line of the same launch (`tools/run_pmc_by_shape.sh`, `tools/pmc_by_dispatch.py`, `tools/pmc_pair.py`): measured bytes against booked operand bytes per shape, largest excess first; 141.4 GB against 132.6 GB = 1.07 x over the run (1.21 x before all tiles of a front were kept on one XCD) |
 | `r04_pmc_sq_zgemm_large_launch.json` | SQ counters of one large `k_zgemm3` launch (1024 x 1024 x 256, batch 16): matrix-pipe utilisation, shader clock during the launch, LDS bank conflicts (0) |
 | `r04_direct_per_level_trace.txt` | `HELM_ND_TRACE=1 python tools/bench_direct.py --freqs 5.5`: device milliseconds per tree level of the factorisation and of the forward / backward sweeps, with and without the sparse-right-hand-side skipping |
 | `r04_gemm_log_by_shape.txt` | every product of one factorisation + three passes aggregated by shape and addressing mode: microseconds, TFLOP/s, operand GB/s, roofline microseconds |
