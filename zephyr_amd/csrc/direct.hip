@@ -1141,7 +1141,8 @@ __device__ __forceinline__ cplx gj_recip(cplx d) {
 // wave -- the step is bound by the number of instructions one wave has to issue one after the other, not by a particular latency.  A form
 // in panels of four steps (the four columns of a panel in one half-wave: pivot search and pivot row by v_readlane, the other threads apply
 // four steps at once after one barrier; bit-for-bit the same result) was built and measured: 3550 cycles for the four narrow steps + 1700
-// for the rank-4 update per panel = the same 46-50 000 cycles; reverted.
+// for the rank-4 update per panel = the same 46-50 000 cycles; reverted.  The pivot search as an LDS atomic (ds_max_u32 by the 32 threads that hold the
+// column, one word read by everybody instead of 32 keys and their maximum): 22.5 -> 29.2 us per block; reverted.
 __device__ __forceinline__ void gj32(Gj32 &S, int n, int tid) {
     const int i = tid >> 3, jc = tid & 7, j0 = jc * 4;
     bool used = i >= n;
