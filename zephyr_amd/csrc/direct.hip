@@ -1113,7 +1113,6 @@ struct Gj32 {
     cplx dinv[2][32];     // reciprocal of every row's entry in the column that is eliminated next
     int piv[32];          // sigma: pivot row of step k
     int sinv[32];         // step at which row r was the pivot
-    unsigned best[4];     // the largest key of a column (three in rotation: read by step k, filled for step k + 1, cleared for step k + 2)
 };
 __device__ __forceinline__ double gj_rcp(double x) {
     double y = __builtin_amdgcn_rcp(x);
@@ -1150,13 +1149,8 @@ __device__ __forceinline__ void gj32(Gj32 &S, int n, int tid) {
     cplx out[4];
     #pragma unroll
     for (int q = 0; q < 4; ++q) out[q] = S.a[i][j0 + q];
-    if (tid < 4) S.best[tid] = 0u;
+    if (jc == 0) { S.cand[0][i] = used ? (unsigned)i : gj_key(out[0], i); S.dinv[0][i] = gj_recip(out[0]); S.piv[i] = i; S.sinv[i] = i; }
     __syncthreads();
-    // the pivot search is an LDS atomic: the 32 threads that hold a column's entries each put their key in (ds_max_u32, a few cycles beside the other
-    // threads' stores), every thread then reads ONE word where it read all 32 keys and took their maximum (8 wide loads + 11 v_max per wave and step)
-    if (jc == 0) { atomicMax(&S.best[0], used ? (unsigned)i : gj_key(out[0], i)); S.dinv[0][i] = gj_recip(out[0]); S.piv[i] = i; S.sinv[i] = i; }
-    __syncthreads();
-    int br = 0, bw = 1, bz = 2;                        // best[] in rotation: read, filled, cleared
     cplx (*cur)[33] = S.a, (*nxt)[33] = S.b;
     // four steps per trip, so that the register that holds column k (out[k & 3]) is known at compile time: one select per step instead of four
     // compare-and-select groups, and no select chain for the next column's key
@@ -1164,8 +1158,11 @@ __device__ __forceinline__ void gj32(Gj32 &S, int n, int tid) {
         const int k = k4 + (Q_);                                                                                                   \
         if (k >= n) break;                                                                                                         \
         const int pb = k & 1;                                                                                                      \
-        const int p = (int)(S.best[br] & 31u);                                                                                     \
-        if (tid == 0) S.best[bz] = 0u;                                                                                             \
+        const uint4 *c4 = reinterpret_cast<const uint4 *>(S.cand[pb]);                                                             \
+        unsigned m = 0;                                                                                                            \
+        _Pragma("unroll")                                                                                                          \
+        for (int q = 0; q < 8; ++q) { const uint4 v = c4[q]; m = max(m, max(max(v.x, v.y), max(v.z, v.w))); }                       \
+        const int p = (int)(m & 31u);                                                                                              \
         const cplx dinv = S.dinv[pb][p], f = cur[i][k];                                                                            \
         cplx pr[4];                                                                                                                \
         _Pragma("unroll")                                                                                                          \
@@ -1182,7 +1179,7 @@ __device__ __forceinline__ void gj32(Gj32 &S, int n, int tid) {
         if (k + 1 < n) {                                                                                                           \
             if (jc == ((k + 1) >> 2)) {        /* key and reciprocal of the next column (unused rows only: their scale is still 1) */ \
                 const cplx v = out[((Q_) + 1) & 3];                                                                                \
-                atomicMax(&S.best[bw], used ? (unsigned)i : gj_key(v, i));                                                         \
+                S.cand[pb ^ 1][i] = used ? (unsigned)i : gj_key(v, i);                                                             \
                 S.dinv[pb ^ 1][i] = gj_recip(v);                                                                                   \
             }                                                                                                                      \
             _Pragma("unroll")                                                                                                      \
@@ -1190,7 +1187,6 @@ __device__ __forceinline__ void gj32(Gj32 &S, int n, int tid) {
         }                                                                                                                          \
         __syncthreads();                                                                                                           \
         cplx (*t_)[33] = cur; cur = nxt; nxt = t_;                                                                                 \
-        { const int b_ = br; br = bw; bw = bz; bz = b_; }                                                                          \
     } while (0)
     for (int k4 = 0; k4 < n; k4 += 4) { GJ32_STEP(0); GJ32_STEP(1); GJ32_STEP(2); GJ32_STEP(3); }
 #undef GJ32_STEP
