@@ -56,7 +56,7 @@ def test_batched_inverse(helm_lib, n, batch):
         assert np.abs(out[b] @ A[b] - np.eye(n)).max() <= 1e-10
 
 
-@pytest.mark.parametrize('n,batch', [(512, 2), (545, 1), (1024, 1), (1101, 3)])
+@pytest.mark.parametrize('n,batch', [(512, 2), (545, 1), (1024, 1), (1101, 3), (40, 7), (64, 40), (100, 3), (129, 300), (257, 2)])
 def test_one_launch_block_step_agrees_with_the_two_launch_form(helm_lib, n, batch, monkeypatch):
     """From 512 to 1536 unknowns a block step of the Gauss-Jordan inversion is ONE launch that reads one copy of the matrix and writes the other
     (k_gj_step, direct.hip); HELM_ND_GJSTEP=0 is the panel copy + update pair.  Same pivots, the products in another order: the inverses agree
@@ -65,7 +65,8 @@ def test_one_launch_block_step_agrees_with_the_two_launch_form(helm_lib, n, batc
     A = crand(rng, batch, n, n) + 2.0 * np.sqrt(n) * np.eye(n)
     A[0, 0, 0] = 0.0
     A[-1, 32:36, 32:36] = np.fliplr(np.eye(4)) * 3.0
-    outs = []
+    monkeypatch.setenv('HELM_ND_GJSTEP_MIN', '33')                     # (default 512: below that the two-launch form is kept; more matrices than tiles
+    outs = []                                                          #  per matrix put the sweeps in several z-slices of the grid)
     for flag in ('0', '1'):
         monkeypatch.setenv('HELM_ND_GJSTEP', flag)
         out = np.ascontiguousarray(A.copy())

@@ -1510,7 +1510,7 @@ struct GjStepArgs {
     int n, k0, nb;                             // this step's pivot block: rows / columns [k0, k0 + nb)
     const cplx *P; cplx *Pn; long long sp;     // its inverse (PNB x PNB per matrix) ; where the sweep leaves the next block's
     int k1, nb1;                               // the next pivot block (nb1 == 0: none)
-    int batch;
+    int batch, nsw;                            // matrices; z-slices of the grid that hold the sweeps (one workgroup per matrix)
 };
 // LDS: the sweep state (35 KB) -- the two 32 x 32 blocks of the private update and the tiles' P and R slab lie over it.  (A first version kept four
 // blocks, 68 KB: alone on the GPU the same speed, but beside the solve kernels of the previous work item a workgroup of that size waits for a
@@ -1524,8 +1524,8 @@ __global__ __launch_bounds__(256, 2) void k_gj_step(GjStepArgs a) {
     const int k0 = a.k0, nb = a.nb, n = a.n;
     cplx (&X0)[PNB][PNB + 1] = *reinterpret_cast<cplx (*)[PNB][PNB + 1]>(lds);
     cplx (&X1)[PNB][PNB + 1] = *reinterpret_cast<cplx (*)[PNB][PNB + 1]>(lds + PNB * (PNB + 1) * sizeof(cplx));
-    if (blockIdx.z == 0) {                                   // ---- sweep of the next pivot block (one workgroup per matrix)
-        const int mat = blockIdx.y * gridDim.x + blockIdx.x;
+    if ((int)blockIdx.z < a.nsw) {                           // ---- sweep of the next pivot block (one workgroup per matrix, the first nsw z-slices)
+        const int mat = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         if (mat >= a.batch || a.nb1 == 0) return;
         const cplx *Ta = a.Ta + (long long)mat * a.sa, *P = a.P + (long long)mat * a.sp;
         cplx *Pn = a.Pn + (long long)mat * a.sp;
@@ -1580,7 +1580,7 @@ __global__ __launch_bounds__(256, 2) void k_gj_step(GjStepArgs a) {
     }
     // ---- a 64 x 32 tile of the update, both products on the matrix cores (v_mfma_f64_16x16x4_f64: A lane l = A[l % 16][l / 16], B lane l = B[l / 16][l % 16],
     // D register q of lane l = D[l / 16 + 4 q][l % 16]; four real instructions per complex block and k step of 4, as in zgemm3_body)
-    const int mat = blockIdx.z - 1;
+    const int mat = blockIdx.z - a.nsw;
     const cplx *Ta = a.Ta + (long long)mat * a.sa, *P = a.P + (long long)mat * a.sp;
     cplx *Tb = a.Tb + (long long)mat * a.sb;
     const int lda = a.lda, ldb = a.ldb;
@@ -2840,9 +2840,9 @@ void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cp
         // A first version ran the sweep on a second stream: same gain at n = 3713, but two cross-stream event hops per step, -5 % in 2-D)
         // one launch per block step (k_gj_step): the second copy of the matrix lives in W, the two P buffers in the handle's scratch
         const int gjstep = getenv("HELM_ND_GJSTEP") ? atoi(getenv("HELM_ND_GJSTEP")) : 1;          // (read per call: the tests compare the two forms)
-        static const int gjstep_min = getenv("HELM_ND_GJSTEP_MIN") ? atoi(getenv("HELM_ND_GJSTEP_MIN")) : 512;
+        const int gjstep_min = getenv("HELM_ND_GJSTEP_MIN") ? atoi(getenv("HELM_ND_GJSTEP_MIN")) : 512;      // (per call, like the switch)
         static const int gjstep_max = getenv("HELM_ND_GJSTEP_MAX") ? atoi(getenv("HELM_ND_GJSTEP_MAX")) : 1536;
-        if (gjstep && gemm_variant() == 7 && n >= gjstep_min && n <= gjstep_max && (long long)n * n <= ws && (long long)((n + 63) / 64) * ((n + 31) / 32) >= batch) {
+        if (gjstep && gemm_variant() == 7 && n >= gjstep_min && n <= gjstep_max && (long long)n * n <= ws && batch <= 32768) {
             cplx *Pb = gj_pbuf(op, batch);
             if (Pb) {
                 const long long sp = 2LL * PNB * PNB;
@@ -2860,9 +2860,11 @@ void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cp
                     a.P = Pb + (step & 1) * PNB * PNB; a.Pn = Pb + ((step + 1) & 1) * PNB * PNB; a.sp = sp;
                     a.k1 = k0 + PNB; a.nb1 = k0 + PNB < n ? std::min(PNB, n - k0 - PNB) : 0;
                     a.batch = batch;
+                    const int per_slice = ((n + 31) / 32) * ((n + 63) / 64);
+                    a.nsw = (batch + per_slice - 1) / per_slice;
                     // booked with the products (mode 5: update + pivot sweep): 8 n^2 nb flop, the matrix read and written once
                     ExtArm arm(op, ext, 8.0 * n * (double)n * nb * batch, 16.0 * (2.0 * n * (double)n + 2.0 * n * nb) * batch, n, n, nb, batch, 5);
-                    const dim3 grid((n + 31) / 32, (n + 63) / 64, batch + 1);
+                    const dim3 grid((n + 31) / 32, (n + 63) / 64, batch + a.nsw);
                     ZG_LAUNCH(k_gj_step, grid, a);
                 }
                 if (step & 1) hipLaunchKernelGGL(k_copy_blocks, dim3((unsigned)std::min<long long>(((long long)n * n + 255) / 256, 1024), batch), dim3(256), 0, st, (const cplx *)W, n, ws, M, ld, stride, n);
