@@ -2710,7 +2710,9 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
             const int idxmode = rows && rows->schur4 ? 4 : (rows && !rows->dense ? (rows->fwd3 ? 2 : 1) : 0);
             const bool plain = !rows || (!rows->schur4 && !rows->fwd3 && !rows->ksplit && rows->zr1 == 0 && rows->zc1 == 0 && rows->sk1 == 0);
             if (xr_on && M == 49 && Nn >= 64 && plain && idxmode <= 1 && g_gemm_tile < 0) {
-                static const int xr_nt = getenv("HELM_ND_XR_NT") ? atoi(getenv("HELM_ND_XR_NT")) : 2;
+                static const int xr_nt = getenv("HELM_ND_XR_NT") ? atoi(getenv("HELM_ND_XR_NT")) : 1;
+                // (49 x 64 tile, four workgroups per compute unit, against 49 x 128 with two: leaf back substitution 3.23 -> 2.90 ms with every front
+                // computed, 1.89 -> 1.70 on point sources; a K slab of 16 halves the occupancy again: 3.7 / 4.7 ms)
                 if (xr_nt == 2 && (Nn % 128 == 0 || Nn > 192)) launch_mfma_xr<3, 2, 8>(ZG_ARGS); else launch_mfma_xr<3, 1, 8>(ZG_ARGS);
                 continue;
             }
