@@ -1661,12 +1661,12 @@ __global__ __launch_bounds__(256, 2) void k_gj_step(GjStepArgs a) {
 }
 
 // dst[mat][r][c] = src[mat][r][c] for n x n blocks with different leading dimensions (the odd step count of k_gj_step leaves the result in W)
-__global__ __launch_bounds__(256) void k_copy_blocks(const cplx *src, int lds_, long long ss, cplx *dst, int ldd, long long sd, int n) {
+__global__ __launch_bounds__(256) void k_copy_blocks(const cplx *src, int ld_src, long long ss, cplx *dst, int ldd, long long sd, int n) {
     const cplx *s = src + (long long)blockIdx.y * ss;
     cplx *d = dst + (long long)blockIdx.y * sd;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < (long long)n * n; e += (long long)gridDim.x * 256) {
         const int r = (int)(e / n), c = (int)(e % n);
-        d[(long long)r * ldd + c] = s[(long long)r * lds_ + c];
+        d[(long long)r * ldd + c] = s[(long long)r * ld_src + c];
     }
 }
 
@@ -2681,6 +2681,11 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
     // rank-32 updates of one large matrix (blocked Gauss-Jordan of the 3-D plane inverses): HBM-bound, the 64 x 32 tile is the fastest
     // (3713^2 x 32: 87 us against 93 for 64 x 64, tools/zgemm_tiles.py)
     if (rows && rows->dense && K <= 32 && !latency_mode && batch == 1) vsel = 3;
+    // 32-row fronts through the row tables (leaf forward elimination, levels 10 and 9 of the back substitution): HELM_ND_M32_TILE=4 gives them the
+    // 32 x 64 tile (five workgroups on a compute unit where 32 x 128 keeps three).  Alone on the GPU that is faster (leaf forward 1.31 -> 1.24 ms, level 10
+    // backward 0.295 -> 0.264, every_front_computed +1.5 %); beside the factorisation of the next item it is not (headline 13 580 -> 13 420 in two runs each): off
+    static const int m32_tile = getenv("HELM_ND_M32_TILE") ? atoi(getenv("HELM_ND_M32_TILE")) : -1;
+    if (m32_tile >= 0 && M == 32 && rows && !rows->dense && !rows->schur4 && !latency_mode && gemm_variant() == 7) vsel = m32_tile;
     if (g_gemm_tile >= 0) { vsel = g_gemm_tile & 7; latency_mode = false; }
     // the fused update + sweep launch exists for two tiles: 64 x 32 (large matrices) and the 32 x 32 latency tile (under-filled launches)
     if (rows && rows->la) { vsel = latency_mode ? 6 : 3; }
