@@ -2322,7 +2322,8 @@ __global__ __launch_bounds__(256) void k_resid_nm(const cplx *__restrict__ plane
 // the per-cell coefficient fetches of k_resid_nm -- 36 of its 46 memory instructions per step at RPT = 4, each a 16-byte request -- leave
 // the vector memory pipeline, which then only carries the streams that have to move (x, q, and what is stored).
 #define RESID_SEG 32
-template <int RPT>
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+template <int RPT, int NT_STORE>
 __global__ __launch_bounds__(256) void k_resid_nm_lds(const cplx *__restrict__ planes, int nz, int nx, const cplx *__restrict__ Xin, int ldin,
                                                       cplx *__restrict__ Q, int ldq, const int *__restrict__ qmap, int ncol, int store,
                                                       cplx *__restrict__ Rout, double *__restrict__ part, int nblk, int ntiles,
@@ -2403,7 +2404,11 @@ __global__ __launch_bounds__(256) void k_resid_nm_lds(const cplx *__restrict__ p
                     r.y = fma(-c.x, xv.y, r.y); r.y = fma(-c.y, xv.x, r.y);
                 }
                 if (store) (Rout ? Rout : Q)[cell * ldq + col] = r;
-                if (Uout) Uout[cell * ldu + j] = cconj(cmul(oscale, win[o + 1][1]));
+                if (Uout) {                                   // written once, read by nobody on the GPU: past the caches
+                    const cplx u = cconj(cmul(oscale, win[o + 1][1]));
+                    if (NT_STORE) __builtin_nontemporal_store((v2f64){u.x, u.y}, reinterpret_cast<v2f64 *>(Uout + cell * ldu + j));
+                    else Uout[cell * ldu + j] = u;
+                }
                 acc += cabs2(r);
             }
         }
@@ -3728,10 +3733,21 @@ int nd_resid_nm(helm_op *op, const cplx *planes, const cplx *Xin, int ldin, cplx
                            qnorm, Uout ? Uout + c0 : nullptr, ldu, oscale)
         static const int lds_env = getenv("HELM_ND_RESID_LDS") ? atoi(getenv("HELM_ND_RESID_LDS")) : 1;
         if (lds_env && ly == 1 && seg == RESID_SEG && (rpt == 2 || rpt == 4)) {
-#define RESID_LDS(RPT_) hipLaunchKernelGGL(k_resid_nm_lds<RPT_>, dim3(nblk), dim3(256, 1), 0, op->stream, planes, op->nz, op->nx, Xin + c0, ldin, Q + (qmap ? 0 : c0), ldq, \
+#define RESID_LDS(RPT_) hipLaunchKernelGGL((k_resid_nm_lds<RPT_, NTS_>), dim3(nblk), dim3(256, 1), 0, op->stream, planes, op->nz, op->nx, Xin + c0, ldin, Q + (qmap ? 0 : c0), ldq, \
                            qmap ? qmap + c0 : nullptr, nc, store, Rout ? Rout + (qmap ? 0 : c0) : nullptr, part + (long long)c0 * 4 * nblk, nblk, ntiles, \
                            qnorm, Uout ? Uout + c0 : nullptr, ldu, oscale, c0 == 0 ? qmask : nullptr)
-            if (rpt == 2) RESID_LDS(2); else RESID_LDS(4);
+            // the wavefield is written once and read by nobody on the GPU: nontemporal stores (2578 -> 2549 us with the store, within the run-to-run spread; q loaded
+            // nontemporally as well: no difference)
+            static const int nt_store = getenv("HELM_ND_RESID_NT") ? atoi(getenv("HELM_ND_RESID_NT")) : 1;
+            if (nt_store) {
+#define NTS_ 1
+                if (rpt == 2) RESID_LDS(2); else RESID_LDS(4);
+#undef NTS_
+            } else {
+#define NTS_ 0
+                if (rpt == 2) RESID_LDS(2); else RESID_LDS(4);
+#undef NTS_
+            }
 #undef RESID_LDS
             continue;
         }
