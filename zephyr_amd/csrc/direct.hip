@@ -343,6 +343,7 @@ struct GemmRows {
     // back substitution of the leaves, same flags read-only: where a leaf's flag is 0 its first k2 rows of B (its right-hand-side rows y_S) are all
     // zero in that block of columns, and the product starts at row k2 -- x_S = G x_B, 32 of the 81 columns of [F11^-1 | G]
     const int *act_ro = nullptr;
+    int ntc = 0;                // store C with nontemporal stores (large HBM-bound launches whose output is not read again soon)
     int xcd_map = 0;            // regroup the workgroup ids so that the column tiles of a front share an XCD (zgemm3_body)
     int child_rows = 0;         // (fwd3, host-side bookkeeping) ring rows of a front's two children: what the gather has to read besides q_S
 };
@@ -677,6 +678,7 @@ void launch_vec2(hipStream_t st, int idx, int nb, int M, int Nn, int K, cplx alp
 //   C / D     lane l holds rows (l >> 4) + 4 q, q = 0..3, of column l & 15: a store is four 256-byte row segments.
 // Addressing modes (IDX), masks, split-K and the fused gathers are those of zgemm2_body, operand for operand.
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef double v2f64 __attribute__((ext_vector_type(2)));
 __device__ cplx g_zero_page[4];       // 64 bytes of zeros: what masked lanes load instead of branching around a load
 // XR = 1 (WM == 1 only): the tile has ONE more row than its 16 MT rows of matrix-core blocks -- row 16 MT goes through the vector ALUs, which the
 // MFMA loop leaves idle (thread = column x share of the k range, partial sums added up through LDS at the end).  98 % of the leaves of a 2^k grid
@@ -981,7 +983,7 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
                 cplx v = cmul(alpha, cmake(cr[i][j][q], ci[i][j][q]));
                 if (IDX == 4) v = cadd(cv[q][j], v);
                 else v = cadd(v, cmul(beta, cv[q][j]));
-                dstq[q][cc] = v;
+                if (R.ntc) __builtin_nontemporal_store((v2f64){v.x, v.y}, reinterpret_cast<v2f64 *>(dstq[q] + cc)); else dstq[q][cc] = v;
             }
         }
     }
@@ -2322,7 +2324,6 @@ __global__ __launch_bounds__(256) void k_resid_nm(const cplx *__restrict__ plane
 // the per-cell coefficient fetches of k_resid_nm -- 36 of its 46 memory instructions per step at RPT = 4, each a 16-byte request -- leave
 // the vector memory pipeline, which then only carries the streams that have to move (x, q, and what is stored).
 #define RESID_SEG 32
-typedef double v2f64 __attribute__((ext_vector_type(2)));
 template <int RPT, int NT_STORE>
 __global__ __launch_bounds__(256) void k_resid_nm_lds(const cplx *__restrict__ planes, int nz, int nx, const cplx *__restrict__ Xin, int ldin,
                                                       cplx *__restrict__ Q, int ldq, const int *__restrict__ qmap, int ncol, int store,
@@ -2701,6 +2702,10 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
         R.z0 = b0;
         static const int xcd_env = getenv("HELM_ND_XCDMAP") ? atoi(getenv("HELM_ND_XCDMAP")) : 2;
         R.xcd_map = xcd_env;
+        // gathered products over many fronts (the row-table and forward-gather levels of both passes) store C with nontemporal stores: the rows are not read
+        // again before a whole level has gone by (headline +1.5 %, every_front_computed +1 %; HELM_ND_NTC = fronts per launch from which, 0 off)
+        static const int ntc_env = getenv("HELM_ND_NTC") ? atoi(getenv("HELM_ND_NTC")) : 64;
+        if (ntc_env && rows && !rows->dense && !rows->schur4 && nb >= ntc_env) R.ntc = 1;
         const cplx *Ab = A + b0 * sa, *Bb = B ? B + b0 * sb : B;
         cplx *Cb = C ? C + b0 * sc : C;
         // (a 4 x 8 register block per thread -- RN = 8, 64 x 128 tile -- was measured too: 230 VGPRs, occupancy 2, 38 % slower)
