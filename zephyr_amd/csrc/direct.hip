@@ -2705,7 +2705,7 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
         // gathered products over many fronts (the row-table and forward-gather levels of both passes) store C with nontemporal stores: the rows are not read
         // again before a whole level has gone by (headline +1.5 %, every_front_computed +1 %; HELM_ND_NTC = fronts per launch from which, 0 off)
         static const int ntc_env = getenv("HELM_ND_NTC") ? atoi(getenv("HELM_ND_NTC")) : 64;
-        if (ntc_env && rows && !rows->dense && !rows->schur4 && nb >= ntc_env) R.ntc = 1;
+        if (ntc_env && rows && !rows->dense && !rows->schur4 && nb >= ntc_env) R.ntc = 1;                            // (the Schur complements, read back one level later: no difference either way)
         const cplx *Ab = A + b0 * sa, *Bb = B ? B + b0 * sb : B;
         cplx *Cb = C ? C + b0 * sc : C;
         // (a 4 x 8 register block per thread -- RN = 8, 64 x 128 tile -- was measured too: 230 VGPRs, occupancy 2, 38 % slower)
