@@ -394,6 +394,16 @@ def main():
         d_rhs = torch.from_numpy(np.ascontiguousarray(q_all.T)).to(dev)      # [256][N]
         d_u = torch.empty((B, N), dtype=torch.complex128, device=dev)
 
+    # the support of the sparse source matrix, as Discretization.rhsSupportFromSparse makes it (one byte per cell, bit b = block b of 64 sources has an entry there):
+    # used by the extra `support_declared` pass only -- the headline lets the library find the nonzeros of the dense right-hand sides itself
+    use_support = [False]
+    d_support = None
+    if node:
+        coo_ = q_sparse.tocoo()
+        bits_ = np.zeros(((N + 3) // 4) * 4, np.uint8)
+        np.bitwise_or.at(bits_, coo_.row, (1 << (coo_.col >> 6)).astype(np.uint8))
+        d_support = torch.from_numpy(bits_).to(dev)
+
     ops = {}
 
     stamps = []                          # completion time of every work item (diagnostics: `item_done_ms` of the timed region)
@@ -417,7 +427,7 @@ def main():
         fi, bi = work_item(w, nb)
         tl.append(('solve starts', w, time.perf_counter()))
         rhs_ptr = d_rhs.data_ptr() + (0 if node else bi * B * N * 16)
-        info = op.solveDevice(rhs_ptr, ubuf.data_ptr(), B, N, layout='node' if node else 'rhs')
+        info = op.solveDevice(rhs_ptr, ubuf.data_ptr(), B, N, layout='node' if node else 'rhs', support=d_support if (use_support[0] and node) else None)
         t = op.lastTiming()
         del op.factors                   # nothing is carried over between steps
         stamps.append(time.perf_counter())
@@ -535,6 +545,18 @@ def main():
         elapsed_dense = max_over_ranks(time.perf_counter() - t1)
         os.environ.pop('HELM_ND_SPARSE_RHS', None)
 
+    # ... and with the support of the sparse source matrix declared to the solver (helm_set_rhs_support; the reference's sources ARE scipy-sparse matrices): the leaf
+    # level of the forward pass then does not read the dense right-hand sides to look for their nonzeros
+    elapsed_support = None
+    if args.streams <= 1 and not args.no_plain_pass and args.method in ('auto', 'direct') and d_support is not None:
+        use_support[0] = True
+        barrier()
+        t1 = time.perf_counter()
+        run_items(timed_items, False)
+        barrier()
+        elapsed_support = max_over_ranks(time.perf_counter() - t1)
+        use_support[0] = False
+
     # ... and, under the default weak-scaling run, the job north_star names once through: all 16 frequencies x 256 sources = 4096 wavefields, the
     # 16 work items dealt round-robin over the ranks (events off) -- the strong-scaling figure of the same launch, so that a driver that only ever
     # calls `bench.py --gpus N` gets both curves
@@ -605,6 +627,10 @@ def main():
             'item_done_ms': item_done_ms, 'first_items_timeline_ms': first_items,
             'unprofiled': None if elapsed_plain is None else {'value': wavefields / elapsed_plain, 'ms_per_step': 1e3 * elapsed_plain / nsteps},
             'strong_scaling_job': strong_job,
+            'support_declared': None if elapsed_support is None else {
+                'value': wavefields / elapsed_support, 'ms_per_step': 1e3 * elapsed_support / nsteps,
+                'what': 'the same K items (events off) with the support of the scipy-sparse source matrix handed to the solver (solveDevice(..., support=), '
+                        'helm_set_rhs_support): no scan of the dense right-hand sides at the leaf level of the forward pass. NOT the headline: `value` lets the library find the nonzeros itself'},
             'every_front_computed': None if elapsed_dense is None else {
                 'value': wavefields / elapsed_dense, 'ms_per_step': 1e3 * elapsed_dense / nsteps,
                 'what': 'the same K items (events off) with HELM_ND_SPARSE_RHS=0: the forward pass visits every front; `value` lets it skip the fronts '
@@ -798,6 +824,7 @@ def main():
                    'stencil_frac': (out.get('stencil_roofline') or out['roofline']).get('frac'),
                    'unprofiled_value': (out.get('unprofiled') or {}).get('value'),
                    'every_front_computed_value': (out.get('every_front_computed') or {}).get('value'),
+                   'support_declared_value': (out.get('support_declared') or {}).get('value'),
                    'strong_job_value': (out.get('strong_scaling_job') or {}).get('value'), 'strong_job_seconds': (out.get('strong_scaling_job') or {}).get('seconds'),
                    'value_host_api': out['value_host_api'].get('value') if isinstance(out.get('value_host_api'), dict) else None,
                    'config5_job_seconds': c5.get('job_seconds') if c5 else None, 'config5_rtol': c5.get('rtol') if c5 else None,

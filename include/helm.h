@@ -229,6 +229,15 @@ int helm_rhs_from_coo_device(helm_op *op, const void *d_row, const void *d_col, 
 /* the same with the layout of R chosen by `flags` (HELM_RHS_NODE_MAJOR: R[row[k]*nrhs + col[k]]) */
 int helm_rhs_from_coo_device_layout(helm_op *op, const void *d_row, const void *d_col, const void *d_val, long long nnz,
                                     void *dR, int nrhs, long long rows, int flags);
+
+/* Declared support of the next solve's right-hand sides (the reference's sources are scipy-sparse matrices, survey.py:86-89,162-188: where they
+ * are nonzero is part of the input).  d_bits: one byte per row on the device, bit b = block b of 64 right-hand sides may be nonzero in that row; the
+ * caller guarantees zeros elsewhere.  One shot: applies to the next helm_solve_device on this handle (same rows / nrhs, node-major layout), then
+ * forgotten; NULL clears it.  HELM_ND_SUPPORT_CHECK=1 verifies the guarantee and fails the solve if it does not hold. */
+int helm_set_rhs_support(helm_op *op, const void *d_bits, long long rows, int nrhs);
+/* d_bits ((rows + 3) / 4 * 4 bytes on the device) from the triplets of a sparse right-hand-side matrix (device arrays, as for
+ * helm_rhs_from_coo_device_layout) */
+int helm_rhs_support_from_coo(helm_op *op, const void *d_row, const void *d_col, long long nnz, void *d_bits, long long rows, int nrhs);
 /* Receiver sampling data = R u (survey.py:152-160): out[r][s] = sum_k val[k] * U[s][col[k]] over the entries k of CSR
  * row r (rowptr, col: int64; val: complex128; U: nsrc x ld; out: nrec x nsrc complex128; device pointers). */
 int helm_sample_device(helm_op *op, const void *dU, int nsrc, long long ld, const void *d_rowptr, const void *d_col,

@@ -509,6 +509,51 @@ def test_fused_leaf_level_at_coarse_sampling_falls_back_where_it_must(helm_lib, 
     assert all(i['status'] in (0, 3) for i in op.lastInfo), op.lastInfo
 
 
+
+@pytest.mark.parametrize('nsrc', [5, 130])
+def test_declared_support_gives_the_wavefields_of_the_scan(helm_lib, monkeypatch, nsrc):
+    """helm_set_rhs_support: the support of the sparse source matrix, made by the library from its triplets, stands in for the scan of the dense
+    right-hand sides at the leaf level of the forward pass.  Device-resident solve in the reference's (N, nsrc) layout: bit for bit the wavefields of
+    the solve that looks for the nonzeros itself, with the front-vector arena poisoned; HELM_ND_SUPPORT_CHECK=1 passes on the true support and fails the
+    solve when a source is missing from the declared one; the declaration is forgotten after one solve."""
+    import torch
+    import scipy.sparse as sp
+    import zephyr_amd as za
+    nz, nx = 150, 170
+    N = nz * nx
+    rng = np.random.default_rng(50 + nsrc)
+    c = 1800. + 2000. * rng.random((nz, nx))
+    cfg = dict(nx=nx, nz=nz, dx=10., dz=10., c=c, freq=8., nPML=8, rtol=1e-10, method='direct', batch=256)
+    locs = np.stack([rng.uniform(100., 10. * nx - 100., nsrc), rng.uniform(20., 60., nsrc)], axis=1)
+    qs = sp.csc_matrix(za.SparseKaiserSource(cfg)(locs))
+    dev = torch.device('cuda', 0)
+    monkeypatch.setenv('HELM_ND_POISON', '1')
+    op = za.Eurus(cfg)
+    R = torch.zeros((N, nsrc), dtype=torch.complex128, device=dev)
+    op.rhsFromSparseDevice(qs, R.data_ptr(), layout='node')
+    bits = op.rhsSupportFromSparse(qs)
+    assert int(bits.count_nonzero()) == len(np.unique(qs.tocoo().row))
+    U0 = torch.empty_like(R); U1 = torch.empty_like(R); U2 = torch.empty_like(R)
+    op.solveDevice(R.data_ptr(), U0.data_ptr(), nsrc, N, layout='node')                       # the library scans
+    monkeypatch.setenv('HELM_ND_SUPPORT_CHECK', '1')
+    op.solveDevice(R.data_ptr(), U1.data_ptr(), nsrc, N, layout='node', support=bits)         # declared (and verified)
+    monkeypatch.delenv('HELM_ND_SUPPORT_CHECK')
+    op.solveDevice(R.data_ptr(), U2.data_ptr(), nsrc, N, layout='node')                       # one shot: this one scans again
+    torch.cuda.synchronize()
+    assert torch.equal(torch.view_as_real(U0), torch.view_as_real(U1))
+    assert torch.equal(torch.view_as_real(U0), torch.view_as_real(U2))
+    assert bool(torch.isfinite(torch.view_as_real(U1)).all())
+    # a support that misses the first source: the check refuses the solve
+    wrong_full = torch.zeros_like(bits)
+    coo = qs[:, 1:].tocoo()
+    wrong_full[torch.from_numpy(np.unique(coo.row)).to(dev)] = 0xFF
+    lone = np.setdiff1d(np.unique(qs[:, [0]].tocoo().row), np.unique(coo.row))
+    if lone.size:                                                    # (the first source has rows no other source touches)
+        monkeypatch.setenv('HELM_ND_SUPPORT_CHECK', '1')
+        with pytest.raises(Exception):
+            op.solveDevice(R.data_ptr(), U1.data_ptr(), nsrc, N, layout='node', support=wrong_full)
+    del op.factors
+
 @pytest.mark.parametrize('nsrc', [3, 70, 200])
 def test_sparse_right_hand_sides_skip_nothing_that_matters(helm_lib, monkeypatch, nsrc):
     """The forward pass leaves out the fronts whose right-hand-side rows and whose children's rows are all zero in a block of 64 columns

@@ -1736,6 +1736,10 @@ extern "C" int helm_solve_device(helm_op *op, const void *dRHS, void *dU, int nr
     if (rows != N && !stacked) HELM_FAIL(op, HELM_ERR_ARG, "dimension mismatch: rhs has %lld rows, operator has %lld%s", rows, N,
                                          op->variant == HELM_EURUS ? " (or 2N stacked)" : "");
     HIP_TRY(op, hipSetDevice(op->device));
+    // a declared support (helm_set_rhs_support) belongs to THIS call's right-hand sides and to no later one
+    struct SupportOneShot { helm_op *o; ~SupportOneShot() { o->rhs_bits = nullptr; o->rhs_bits_q = nullptr; o->rhs_bits_violated = 0; } } support_one_shot{op};
+    if (op->rhs_bits && (op->rhs_bits_rows != rows || op->rhs_bits_nrhs != nrhs)) HELM_FAIL(op, HELM_ERR_ARG, "helm_set_rhs_support was given %lld rows x %d right-hand sides, this solve has %lld x %d", op->rhs_bits_rows, op->rhs_bits_nrhs, rows, nrhs);
+    op->rhs_bits_q = op->rhs_bits ? dRHS : nullptr;
     helm_solve_opts o;
     if (opts) o = *opts; else { o.method = HELM_AUTO; o.rtol = 1e-10; o.maxit = 200000; o.check_every = 0; o.batch = 0; o.flags = 0; }
     if (!(o.rtol > 0)) o.rtol = 1e-10;
@@ -1770,6 +1774,7 @@ extern "C" int helm_solve_device(helm_op *op, const void *dRHS, void *dU, int nr
         !(getenv("HELM_AUTO_DIRECT") && atoi(getenv("HELM_AUTO_DIRECT")) == 0 && o.method == HELM_AUTO)) {
         helm_solve_opts on = o; on.flags |= HELM_NODE_MAJOR;
         const int rcn = solve_block_direct(op, 0, (const cplx *)dRHS, nrhs, 0, premul, nullptr, nullptr, nrhs, on, info, 0, 0, (cplx *)dU);
+        if (op->rhs_bits_violated) { cleanup(); return HELM_ERR_ARG; }          // (HELM_ND_SUPPORT_CHECK: the message is set)
         if (rcn == 0) native_done = true;
         else if (info) for (int r = 0; r < nrhs; ++r) { info[r].iterations = 0; info[r].status = 0; info[r].restarts = 0; info[r].method = o.method; info[r].relres = 0.0; }
         // (anything else -- too many right-hand sides for one batch, a right-hand side above rtol, a failed factorisation: the general path)
@@ -1887,6 +1892,42 @@ extern "C" int helm_rhs_from_coo_device_layout(helm_op *op, const void *d_row, c
     return HELM_OK;
 }
 
+// Declared support of right-hand sides (round 4).  The reference hands its sources over as scipy-sparse matrices (survey.py:86-89,162-188): where they are
+// nonzero is part of the input, not something to be found.  bits: one byte per row (cell) on the device, bit b set = the right-hand sides of block b of
+// 64 columns MAY be nonzero in that row (at most 512 right-hand sides); the caller guarantees zeros everywhere else.  One shot: it applies to the next
+// helm_solve_device on this handle (same rows and right-hand-side count, node-major layout) and is forgotten when that call returns.  The direct path then
+// sets the leaf flags of its forward pass from the bits instead of reading every right-hand-side row to look for nonzeros (3.2 of 4.3 GB at 1024^2 x 256).
+// HELM_ND_SUPPORT_CHECK=1 verifies the guarantee (one pass over q) and fails the solve if it does not hold.
+extern "C" int helm_set_rhs_support(helm_op *op, const void *d_bits, long long rows, int nrhs) {
+    if (!op) return HELM_ERR_ARG;
+    if (!d_bits) { op->rhs_bits = nullptr; op->rhs_bits_q = nullptr; return HELM_OK; }
+    if (rows < 1 || nrhs < 1 || nrhs > 512) HELM_FAIL(op, HELM_ERR_ARG, "helm_set_rhs_support: rows >= 1 and 1 <= nrhs <= 512");
+    op->rhs_bits = (const unsigned char *)d_bits; op->rhs_bits_rows = rows; op->rhs_bits_nrhs = nrhs; op->rhs_bits_violated = 0;
+    return HELM_OK;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void k_support_from_coo(const long long *row, const int *col, long long nnz, long long rows, int nrhs, unsigned *words) {
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (long long)gridDim.x * blockDim.x) {
+        const long long r = row[k]; const int c = col[k];
+        if (r < 0 || r >= rows || c < 0 || c >= nrhs) continue;
+        atomicOr(&words[r >> 2], (1u << (c >> 6)) << (8 * (int)(r & 3)));
+    }
+}
+}  // namespace
+// bits (rows bytes, rounded up to a multiple of 4, on the device) from the triplets of a sparse right-hand-side matrix (device arrays as for
+// helm_rhs_from_coo_device_layout): what helm_set_rhs_support takes
+extern "C" int helm_rhs_support_from_coo(helm_op *op, const void *d_row, const void *d_col, long long nnz, void *d_bits, long long rows, int nrhs) {
+    if (!op || !d_bits || rows < 1 || nrhs < 1 || nrhs > 512 || nnz < 0 || (nnz > 0 && (!d_row || !d_col))) return HELM_ERR_ARG;
+    HIP_TRY(op, hipSetDevice(op->device));
+    HIP_TRY(op, hipMemsetAsync(d_bits, 0, (size_t)((rows + 3) / 4) * 4, op->stream));
+    if (nnz > 0) hipLaunchKernelGGL(k_support_from_coo, dim3((unsigned)std::min<long long>((nnz + 255) / 256, 4096)), dim3(256), 0, op->stream,
+                                    (const long long *)d_row, (const int *)d_col, nnz, rows, nrhs, (unsigned *)d_bits);
+    HIP_TRY(op, hipGetLastError());
+    HIP_TRY(op, hipStreamSynchronize(op->stream));
+    return HELM_OK;
+}
+
 // Pinned host memory for the caller's result arrays (recycled by size): device-to-host copies into it run at the PCIe rate, into
 // pageable memory at a fraction of it.
 extern "C" void *helm_host_alloc(size_t bytes) { return bytes ? helm_hostpool_alloc(bytes) : nullptr; }
@@ -1900,7 +1941,10 @@ extern "C" int helm_solve_coo(helm_op *op, const long long *row, const int *col,
     if (!op || !U || nrhs < 1 || rows < 1 || nnz < 0 || (nnz > 0 && (!row || !col || !val))) return HELM_ERR_ARG;
     HIP_TRY(op, hipSetDevice(op->device));
     const size_t bytes = (size_t)nrhs * rows * sizeof(cplx);
-    const size_t tb = (size_t)std::max<long long>(nnz, 1) * (sizeof(long long) + sizeof(int) + sizeof(cplx));
+    // (+ one byte per row behind the triplets: the support of the dense image, see below -- no allocation of its own)
+    const size_t tb0 = (((size_t)std::max<long long>(nnz, 1) * (sizeof(long long) + sizeof(int) + sizeof(cplx))) + 15) & ~(size_t)15;
+    const size_t bbytes = (size_t)((rows + 3) / 4) * 4;
+    const size_t tb = tb0 + bbytes;
     void *dR = helm_pool_alloc(op->device, bytes), *dU = helm_pool_alloc(op->device, bytes), *dT = helm_pool_alloc(op->device, tb);
     auto release = [&]() { hipStreamSynchronize(op->stream); helm_pool_free(op->device, dR, bytes); helm_pool_free(op->device, dU, bytes); helm_pool_free(op->device, dT, tb); };
     if (!dR || !dU || !dT) { release(); HELM_FAIL(op, HELM_ERR_DEVICE, "hipMalloc failed"); }
@@ -1919,6 +1963,10 @@ extern "C" int helm_solve_coo(helm_op *op, const long long *row, const int *col,
     const int flags = opts ? opts->flags : 0;
     if (!rc) rc = helm_launch_rhs_from_coo(op, d_row, d_col, d_val, nnz, (cplx *)dR, nrhs, rows, (flags & HELM_RHS_NODE_MAJOR) ? 1 : 0);
     if (!rc && hipStreamSynchronize(op->stream) != hipSuccess) rc = HELM_ERR_DEVICE;
+    // the dense image was made here from the triplets: its support is known exactly, the direct path need not look for it
+    void *dBits = (char *)dT + tb0;
+    if (!rc && nrhs <= 512 && (flags & HELM_NODE_MAJOR) == HELM_NODE_MAJOR && helm_rhs_support_from_coo(op, d_row, d_col, nnz, dBits, rows, nrhs) == HELM_OK)
+        (void)helm_set_rhs_support(op, dBits, rows, nrhs);
     if (!rc) rc = helm_solve_device(op, dR, dU, nrhs, rows, premul_re, premul_im, opts, info);
     if (rc >= 0 && hipMemcpy(U, dU, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = HELM_ERR_DEVICE;
     release();

@@ -343,6 +343,8 @@ struct GemmRows {
     // back substitution of the leaves, same flags read-only: where a leaf's flag is 0 its first k2 rows of B (its right-hand-side rows y_S) are all
     // zero in that block of columns, and the product starts at row k2 -- x_S = G x_B, 32 of the 81 columns of [F11^-1 | G]
     const int *act_ro = nullptr;
+    int hint = 0;               // (IDX 1 with act, leaf forward elimination) the flags were set from a declared support of the right-hand sides: a front without one is left
+                                // before it reads a byte
     int ntc = 0;                // store C with nontemporal stores (large HBM-bound launches whose output is not read again soon)
     int xcd_map = 0;            // regroup the workgroup ids so that the column tiles of a front share an XCD (zgemm3_body)
     int child_rows = 0;         // (fwd3, host-side bookkeeping) ring rows of a front's two children: what the gather has to read besides q_S
@@ -768,6 +770,13 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
             return;
         }
         if (byi == 0 && tid < ncl) R.act[node * R.nct + ct0 + tid] = 1;
+    }
+    if (IDX == 1 && R.act && R.hint) {                                   // declared support: a leaf none of whose blocks of 64 columns carries a right-hand side is not read
+        const int *fl = R.act + (long long)(R.first + R.z0 + bzi) * R.nct + (n0 >> 6);
+        const int ncl = ((Nn - n0 < TN ? Nn - n0 : TN) + 63) >> 6;
+        int any = 0;
+        for (int j = 0; j < ncl; ++j) any |= fl[j];
+        if (!any) return;
     }
     int nzb = 0;                                                         // (IDX 1 with act: leaf level) bit j: a nonzero right-hand-side entry in the j-th block of 64 columns
     __shared__ int2 sgr[IDX == 4 ? TM : 1], sgc[IDX == 4 ? TN : 1];
@@ -3315,6 +3324,7 @@ struct SolveCtx {
     const int4 *tab; cplx *Xt, *arenaV; int nrhs; dim3 rb; int use_idx;
     const cplx *Qt;       // node-major right-hand sides (read only); == Xt for an in-place solve
     int *act = nullptr; int nct = 0;     // sparse-right-hand-side flags of the forward pass (null: every front is computed)
+    int act_hint = 0;                    // the leaves' flags come from the support the caller declared (helm_set_rhs_support): no scan of q
     dim3 rgrid(long long rows) const { return dim3((unsigned)std::min<long long>((rows + rb.y - 1) / rb.y, 1 << 20)); }
 };
 
@@ -3368,7 +3378,7 @@ void forward_group_batched(helm_op *op, NdFactor *f, size_t gi, const SolveCtx &
         // leaves have no children: the outgoing ring part is -G21 x_S with x_S read straight from Xt
         GemmRows R; R.tabB = c.tab + g.roff; R.offB = 0; R.tab_stride = nmax; R.Bx = c.Qt; R.ldx = nrhs;
         static const int leaf_detect = getenv("HELM_ND_SPARSE_LEAF") ? atoi(getenv("HELM_ND_SPARSE_LEAF")) : 1;
-        R.act = (gemm_variant() == 7 && leaf_detect) ? c.act : nullptr; R.nct = c.nct; R.first = g.first;
+        R.act = (gemm_variant() == 7 && leaf_detect) ? c.act : nullptr; R.nct = c.nct; R.first = g.first; R.hint = R.act ? c.act_hint : 0;
         gemm(op, g.mmax, nrhs, g.smax, mone, f->d_fac + g.g21, g.smax, (long long)g.mmax * g.smax, nullptr, 0, 0, zero,
              V + (long long)g.smax * nrhs, nrhs, (long long)nmax * nrhs, g.cnt, &R);
         if (c.act && !R.act) hipMemsetAsync(c.act + (long long)g.first * c.nct, 1, (size_t)g.cnt * c.nct * sizeof(int), op->stream);
@@ -3588,6 +3598,25 @@ int nd_solve(helm_op *op, NdFactor *f, const cplx *Xin, cplx *Xout, int nrhs, cp
     return check_kernels(op, "solve kernels");
 }
 
+// act[node][b] = 1 for every leaf that holds a cell whose declared support has bit b (block b of 64 columns) set
+__global__ __launch_bounds__(256) void k_nd_support_act(const unsigned char *bits, const int *cellnode, int *act, int nct, long long N) {
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < N; c += (long long)gridDim.x * blockDim.x) {
+        const unsigned b = bits[c];
+        if (!b) continue;
+        const int nd = cellnode[c];
+        if (nd < 0) continue;                                  // separator cells: their fronts look at q themselves
+        for (int j = 0; j < nct; ++j) if ((b >> j) & 1) act[(long long)nd * nct + j] = 1;
+    }
+}
+// (HELM_ND_SUPPORT_CHECK=1) bad[0] = 1 when a right-hand side is nonzero outside the declared support
+__global__ __launch_bounds__(256) void k_nd_support_check(const unsigned char *bits, const cplx *Q, int ldq, int nrhs, long long N, int *bad) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < N * nrhs; e += (long long)gridDim.x * blockDim.x) {
+        const long long c = e / nrhs; const int j = (int)(e - c * nrhs);
+        const cplx v = Q[c * ldq + j];
+        if ((v.x != 0.0 || v.y != 0.0) && !((bits[c] >> (j >> 6)) & 1)) bad[0] = 1;
+    }
+}
+
 // node-major solve: Qt (cells x nrhs, read only) -> Xt (may alias Qt); arenaV: 2 * vregion * nrhs elements
 // Flags of the forward pass on sparse right-hand sides, zeroed on `st` (HELM_ND_SPARSE_RHS=0: every front is computed, as before round 4).
 // A survey's sources touch a handful of grid cells (81 per Kaiser-windowed source at the surface): below the few fronts that contain them the
@@ -3610,6 +3639,26 @@ static void arm_sparse_rhs(helm_op *op, NdFactor *f, SolveCtx &c, hipStream_t st
     if (hipMemsetAsync(f->d_act, 0, need * sizeof(int), st) != hipSuccess) { (void)hipGetLastError(); return; }
     c.act = f->d_act; c.nct = nct;
     f->act_nct = nct;
+    // Declared support (helm_set_rhs_support: one byte per cell, bit b = block b of 64 columns may be nonzero there; what helm_rhs_support_from_coo makes of
+    // the triplets of a scipy-sparse source matrix): the leaves' flags are set from it and the leaf level of the forward pass no longer reads q to find out --
+    // 3.2 of the 4.3 GB of a 1024^2 x 256 batch.  Only for the pass whose right-hand sides are the caller's own array (refinement passes solve for residuals).
+    if (op->rhs_bits && c.Qt == op->rhs_bits_q && c.nrhs == op->rhs_bits_nrhs && nct <= 8 && f->pd->d_cellnode && op->rhs_bits_rows == (long long)f->pd->plan.nz * f->pd->plan.nx) {
+        const long long N = op->rhs_bits_rows;
+        hipLaunchKernelGGL(k_nd_support_act, dim3((unsigned)std::min<long long>((N + 255) / 256, 4096)), dim3(256), 0, st, op->rhs_bits, (const int *)f->pd->d_cellnode, f->d_act, nct, N);
+        c.act_hint = 1;
+        if (getenv("HELM_ND_SUPPORT_CHECK") && atoi(getenv("HELM_ND_SUPPORT_CHECK"))) {
+            int *d_bad = (int *)helm_pool_alloc(op->device, sizeof(int));
+            if (d_bad) {
+                hipMemsetAsync(d_bad, 0, sizeof(int), st);
+                hipLaunchKernelGGL(k_nd_support_check, dim3(4096), dim3(256), 0, st, op->rhs_bits, c.Qt, c.nrhs, c.nrhs, N, d_bad);
+                int bad = 0;
+                hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st);
+                hipStreamSynchronize(st);
+                helm_pool_free(op->device, d_bad, sizeof(int));
+                if (bad) { helm_set_error(op, "a right-hand side is nonzero outside the support declared with helm_set_rhs_support"); op->rhs_bits_violated = 1; }
+            }
+        }
+    }
     // (tests) HELM_ND_POISON=1: the front-vector arena is filled with NaNs first, so that a read of rows no front has written shows up in the wavefield
     if (getenv("HELM_ND_POISON") && atoi(getenv("HELM_ND_POISON"))) (void)hipMemsetAsync(c.arenaV, 0xFF, (size_t)2 * f->pd->plan.vregion * c.nrhs * sizeof(cplx), st);
 }

@@ -99,6 +99,7 @@ struct helm_op {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     cplx *sk_buf = nullptr; size_t sk_bytes = 0;   // partial products of split-K launches (direct.hip gemm), from the pool
+    const unsigned char *rhs_bits = nullptr; const void *rhs_bits_q = nullptr; long long rhs_bits_rows = 0; int rhs_bits_nrhs = 0; int rhs_bits_violated = 0;   // declared support of the next solve's right-hand sides (helm_set_rhs_support; one shot)
     cplx *gjp_buf = nullptr; size_t gjp_bytes = 0; // alternating pivot-block inverses of the one-launch Gauss-Jordan step (direct.hip k_gj_step), from the pool
     hipStream_t side_stream = nullptr;    // second stream of the direct path (forward elimination behind the factorisation), on demand
     // helm_prefactor: the factorisation of the assembled operator enqueued on a high-priority stream of its own, so that it runs beside

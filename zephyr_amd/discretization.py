@@ -251,15 +251,19 @@ class BaseDiscretization(BaseModelDependent):
                                   % (rc, nrhs, self.rtol, worst, self.maxit))
         return U
 
-    def solveDevice(self, d_rhs, d_u, nrhs, rows=None, layout='rhs'):
+    def solveDevice(self, d_rhs, d_u, nrhs, rows=None, layout='rhs', support=None):
         '''Solve with right-hand sides and wavefields already resident in HBM.
 
         d_rhs / d_u: device pointers (ints) to complex128 buffers: layout 'rhs' = [nrhs][rows], each right-hand side contiguous;
         layout 'node' = [rows][nrhs], the reference's (N, nrhs) C-order arrays (no transposes inside the direct path).
+        support: what rhsSupportFromSparse made of the sparse matrix these right-hand sides were filled from (layout 'node' only; the caller's
+        guarantee that they are zero elsewhere; HELM_ND_SUPPORT_CHECK=1 verifies it).
         Returns the per-RHS info list; raises if a right-hand side misses the tolerance.'''
         lib = _lib.load()
         h = self.handle
         rows = int(self.nrow if rows is None else rows)
+        if support is not None and layout == 'node':
+            _lib.check(lib.helm_set_rhs_support(h, ctypes.c_void_p(support.data_ptr()), rows, int(nrhs)), h)
         info = (_lib.SolveInfo * nrhs)()
         opts = self._solve_opts()
         opts.flags = _lib.HELM_NODE_MAJOR if layout == 'node' else 0
@@ -294,6 +298,22 @@ class BaseDiscretization(BaseModelDependent):
         _lib.check(lib.helm_rhs_from_coo_device_layout(self.handle, ctypes.c_void_p(row.data_ptr()), ctypes.c_void_p(col.data_ptr()),
                                                        ctypes.c_void_p(val.data_ptr()), int(coo.nnz), ctypes.c_void_p(d_rhs), int(coo.shape[1]),
                                                        int(coo.shape[0]), _lib.HELM_RHS_NODE_MAJOR if layout == 'node' else 0), self.handle)
+
+    def rhsSupportFromSparse(self, q):
+        '''The support of the scipy-sparse right-hand-side matrix q (nrow x ncols, ncols <= 512) as solveDevice(..., support=) takes it: a uint8 device
+        tensor, one byte per row, bit b = block b of 64 columns has an entry in that row.  Where a source matrix is nonzero is part of the reference's
+        input (scipy-sparse sources, survey.py:86-89,162-188); with it the direct path does not read the dense right-hand sides to find out.'''
+        import torch
+        lib = _lib.load()
+        coo = sp.coo_matrix(q)
+        dev = torch.device('cuda', self.device)
+        row = torch.from_numpy(np.ascontiguousarray(coo.row, dtype=np.int64)).to(dev)
+        col = torch.from_numpy(np.ascontiguousarray(coo.col, dtype=np.int32)).to(dev)
+        bits = torch.zeros(((int(coo.shape[0]) + 3) // 4) * 4, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize(dev)
+        _lib.check(lib.helm_rhs_support_from_coo(self.handle, ctypes.c_void_p(row.data_ptr()), ctypes.c_void_p(col.data_ptr()), int(coo.nnz),
+                                                 ctypes.c_void_p(bits.data_ptr()), int(coo.shape[0]), int(coo.shape[1])), self.handle)
+        return bits
 
     def sampleDevice(self, d_u, nsrc, csr_dev, d_out):
         'd_out[nrec][nsrc] = R u for the CSR receiver matrix uploaded by the caller: csr_dev = (rowptr, col, val, nrec) device tensors'
