@@ -155,7 +155,7 @@ for the before / after comparison; their descriptions are in the git history of 
 
 | file | what |
 |---|---|
-| `r04_bench_driver_cmd.json` | the driver's command line, `python bench.py --steps 20 --warmup 5 --no-cpu` (all 16 frequencies): **{dd['value']:.0f} wavefields/s**, {dd['ms_per_step']:.1f} ms per item ({dd['unprofiled']['value']:.0f} with the per-launch events off; round 3: 9235 / 27.7 ms).  `every_front_computed` (HELM_ND_SPARSE_RHS=0: nothing skipped on the point sources): {dd['every_front_computed']['value']:.0f}; `strong_scaling_job` (the whole 4096-wavefield job once): {dd['strong_scaling_job']['seconds']:.3f} s = {dd['strong_scaling_job']['value']:.0f} wavefields/s.  `roofline` (separate serial pass, every booked flop executed): all `k_zgemm3` launches {Rd['achieved']:.1f} TFLOP/s = **{100 * Rd['frac']:.0f} %** of 78.6 ({Rd['launches_timed']} launches, avg {Rd['avg_launch_us']:.0f} us; launches of >= 1 GFLOP, {100 * Rd['launches_of_at_least_1_GFLOP']['share_of_gemm_time']:.0f} % of the GEMM time: {Rd['launches_of_at_least_1_GFLOP']['achieved']:.1f} TFLOP/s); against both roofs per launch {100 * Rd['two_roofs']['frac']:.0f} %; `stencil_roofline.frac` {dd['stencil_roofline']['frac']:.3f} |
+| `r04_bench_driver_cmd.json` | the driver's command line, `python bench.py --steps 20 --warmup 5 --no-cpu` (all 16 frequencies): **{dd['value']:.0f} wavefields/s**, {dd['ms_per_step']:.1f} ms per item ({dd['unprofiled']['value']:.0f} with the per-launch events off; round 3: 9235 / 27.7 ms).  `every_front_computed` (HELM_ND_SPARSE_RHS=0: nothing skipped on the point sources): {dd['every_front_computed']['value']:.0f}; `support_declared` (the sparse source matrix's support handed to the solver, `helm_set_rhs_support`: no scan of the dense right-hand sides; not the headline): {(dd.get('support_declared') or {}).get('value', float('nan')):.0f}; `strong_scaling_job` (the whole 4096-wavefield job once): {dd['strong_scaling_job']['seconds']:.3f} s = {dd['strong_scaling_job']['value']:.0f} wavefields/s.  `roofline` (separate serial pass, every booked flop executed): all `k_zgemm3` launches {Rd['achieved']:.1f} TFLOP/s = **{100 * Rd['frac']:.0f} %** of 78.6 ({Rd['launches_timed']} launches, avg {Rd['avg_launch_us']:.0f} us; launches of >= 1 GFLOP, {100 * Rd['launches_of_at_least_1_GFLOP']['share_of_gemm_time']:.0f} % of the GEMM time: {Rd['launches_of_at_least_1_GFLOP']['achieved']:.1f} TFLOP/s); against both roofs per launch {100 * Rd['two_roofs']['frac']:.0f} %; `stencil_roofline.frac` {dd['stencil_roofline']['frac']:.3f} |
 | `r04_bench_n1.json` | `python bench.py` (default: {d['steps']} timed items after {d['warmup']} warm-up items): {d['value']:.0f} wavefields/s, {d['ms_per_step']:.1f} ms per item ({d['unprofiled']['value']:.0f} with the events off); passes per wavefield {d['config']['solves_or_iterations_per_rhs_mean']:.2f}; `parity_vs_lu_max_rel` = {d['parity_vs_lu_max_rel']:.2e} (8 sources at 6 Hz against the SuperLU wavefields of the CPU leg).  `value_host_api` (MultiFreq * q, scipy-sparse sources in, numpy wavefields out over PCIe): **{ha['value']:.0f} wavefields/s**.  `config5`: **{c5['job_seconds']:.2f} s** at rtol 1e-8 through the device pipeline ({c5.get('job_seconds_one_after_the_other', 0):.2f} s one frequency after the other: {', '.join('%g Hz %.2f s / %d its' % (p['freq_hz'], p['seconds'], max(p['iterations'])) for p in c5['per_frequency'])}), **{c5.get('job_seconds_rtol1e10', float('nan')):.2f} s at rtol 1e-10**; 27-point apply {', '.join('%.0f' % (100 * a['frac_of_peak']) for a in c5['apply'])} % of 8 TB/s at B = 1 / 4 / 8 / 16.  CPU legs on the GPU box's own host: 1 core, M1-only LU {cb['value']:.2f} wavefields/s (assemble {cb['assemble_s']:.1f} s, factor {cb['factor_s']:.1f} s, {cb['per_rhs_s']:.3f} s per source); the faithful 2N x 2N system at 512^2: {c2.get('value', float('nan')):.2f}; 16 processes, one per frequency: {cpool.get('value', float('nan')):.1f} |
 | `r04_bench_serial_rocprofv3_kernel_stats.csv`, `r04_bench_serial_under_rocprofv3.json` | `HELM_ND_SPARSE_RHS=0 rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu --no-config5 --no-host-api --no-pipeline --steps 8 --warmup 2 --no-plain-pass`: the kernels with nothing else on the GPU and nothing skipped -- the run `roofline` must agree with.  `r04_bench_serial_sparse_rhs_rocprofv3_kernel_stats.csv`: the same with the skipping on (what a production item costs) |
 | `r04_bench_pipelined_rocprofv3_kernel_stats.csv`, `r04_bench_pipelined_under_rocprofv3.json` | the pipelined timed region under the profiler ({dp['value']:.0f} wavefields/s): durations stretched by the sharing |
