@@ -9,6 +9,8 @@ a true relative residual <= 1e-10, right-hand sides and wavefields resident in H
 dealt round-robin over ranks (weak scaling: every rank does `steps` items; no data-path collective).
 
 Prints ONE JSON line (rank 0).  `value` = wavefields completed by all ranks / max-over-ranks time.
+Extra passes over the same K items, reported beside it (never as `value`): `unprofiled` (per-launch events off), `every_front_computed` (nothing skipped
+on the point sources), `support_declared` (the sparse source matrix's support handed to the solver), `strong_scaling_job` (the 4096-wavefield job once).
 """
 import argparse
 import json
