@@ -778,6 +778,20 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
         for (int j = 0; j < ncl; ++j) any |= fl[j];
         if (!any) return;
     }
+    if (IDX == 1 && R.act && !R.hint && idxB && TN >= 64 && R.k2 == 0) {
+        // No declared support: the leaf has to look at its right-hand-side rows.  Through the slab pipeline below that is one exposed load latency per
+        // slab of 8 rows for what is nearly always a block of zeros; here every thread issues its share of the K x TN entries back to back and the
+        // workgroup leaves if none of them is nonzero (the flags stay 0, nothing is stored: the state the exit after the pipeline leaves behind).
+        int nzq = 0;
+        const int tot = K * TN;
+        #pragma unroll 7
+        for (int e = tid; e < tot; e += 256) {
+            const int k = e / TN, bc = e - k * TN;
+            const int r = kidx[k];
+            if (r >= 0 && n0 + bc < Nn) { const cplx v = R.Bx[(long long)r * R.ldx + n0 + bc]; nzq |= (v.x != 0.0 || v.y != 0.0) ? 1 : 0; }
+        }
+        if (!__syncthreads_or(nzq)) return;
+    }
     int nzb = 0;                                                         // (IDX 1 with act: leaf level) bit j: a nonzero right-hand-side entry in the j-th block of 64 columns
     __shared__ int2 sgr[IDX == 4 ? TM : 1], sgc[IDX == 4 ? TN : 1];
     const cplx *S0 = nullptr, *S1 = nullptr;
