@@ -820,6 +820,8 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
         for (int j = 0; j < NT; ++j) { cr[i][j] = (v4f64){0, 0, 0, 0}; ci[i][j] = (v4f64){0, 0, 0, 0}; }
     cplx xacc = cmake(0.0, 0.0);                                       // (XR) this thread's share of row TMM, column tid % TN
     const int xc = tid % TN, xh = tid / TN;
+    // (one register stage.  A second one -- the loads of slab k + 2 issued before slab k is multiplied -- was measured: 16-18 more registers take the 49 x 64 tile
+    // from four workgroups per compute unit to three, leaf back substitution 1.70 -> 1.96 ms, headline 13 900 -> 13 700: reverted)
     cplx ra[NA], rb[NB];
     auto fetch = [&](int k0) {
         #pragma unroll
