@@ -264,6 +264,48 @@ int helm_debug_ws_selftest(int ndev, int concurrent, long long bytes);
  * HELM_ALLOC_TRACE=1 prints): a job that booked its memory with helm_reserve must issue none. */
 int helm_debug_alloc_stats(int reset, long long *slow_calls, double *worst_ms);
 
+/* --- tuning ------------------------------------------------------------------------------
+ * The options of the library that are real options (round 5: the seventy-odd HELM_* environment switches of rounds 1-4 were the tuning
+ * interface; the measured-and-rejected ones are gone, HISTORY.md has what they measured).  Every field can still be given through the
+ * environment variable named beside it -- read when it is used, so a test may flip one between two calls -- and helm_set_tuning
+ * replaces the lot for the process (NULL: back to defaults + environment).  Process-wide, like the reference's module-level defaults
+ * (distributors.py:28-34); not per handle.  Diagnostics that change no result and no speed stay environment-only: HELM_ND_TRACE,
+ * HELM_ND_DEBUG, HELM_GEMM_LOG, HELM_MG3_TRACE, HELM_ALLOC_TRACE, and the test hooks behind HELM_TESTING=1 (HELM_ND_POISON,
+ * HELM_ND_SUPPORT_CHECK, HELM_LEAF_DBG, HELM_ND_INJECT_*). */
+typedef struct helm_tuning {
+    /* 2-D sparse direct path */
+    int    nd_leaf;            /* HELM_ND_LEAF           8     regions with both sides <= this are eliminated whole (leaf fronts) */
+    double nd_ws_gb;           /* HELM_ND_WS_GB          32    cap on the per-batch scratch of a direct solve; the batch is halved until it fits */
+    int    nd_sparse_rhs;      /* HELM_ND_SPARSE_RHS     1     forward pass skips fronts that see nothing but zeros (point sources) */
+    int    nd_stable;          /* HELM_ND_STABLE         1     ill-conditioned fronts are re-eliminated with a pivoted LU */
+    double nd_stable_thr;      /* HELM_ND_STABLE_THR     0     fixed condition-estimate threshold; 0: rtol / (nd_stable_safety * eps) */
+    double nd_stable_safety;   /* HELM_ND_STABLE_SAFETY  8 */
+    int    nd_fused_leaf;      /* HELM_ND_FUSEDLEAF      1     leaf level of the factorisation in one kernel */
+    int    nd_fused_leaf_min;  /* HELM_ND_FUSEDLEAF_MIN  2048  fewest leaves of a level for which it pays */
+    int    nd_gjstep;          /* HELM_ND_GJSTEP         1     one launch per block step of the blocked Gauss-Jordan inversion */
+    int    nd_gjstep_min;      /* HELM_ND_GJSTEP_MIN     512   smallest front inverted that way */
+    int    nd_overlap;         /* HELM_ND_OVERLAP_NM     1     first forward pass beside the factorisation (2: also while profiling) */
+    int    nd_xcd_map;         /* HELM_ND_XCDMAP         2     workgroup ids regrouped so that a front's tiles share an XCD (0 off, 1 column tiles only) */
+    int    nd_plans;           /* HELM_ND_PLANS          6     elimination-tree plans cached per device */
+    int    nd_direct_out;      /* HELM_ND_DIRECT_OUT     1     back substitution writes the caller's wavefield array itself (node-major calls) */
+    /* dispatch / memory */
+    int    auto_direct;        /* HELM_AUTO_DIRECT       1     HELM_AUTO takes the direct path in 2-D */
+    int    auto_mg3;           /* HELM_AUTO_MG3          1     HELM_AUTO takes the multigrid-preconditioned path in 3-D */
+    int    prof_ext;           /* HELM_PROF_EXT          1     profiled launches carry their own events (0: event records around them) */
+    int    ws_slots;           /* HELM_WS_SLOTS          3     shared scratch slots per device */
+    int    pf_prio;            /* HELM_PF_PRIO           1     stream priority of helm_prefactor (1 high, 0 normal, -1 low) */
+    /* 3-D multigrid */
+    int    mg3_keep;           /* HELM_MG3_KEEP          1     layer-preserving hierarchy (2: fail instead of retreating to the standard cycle) */
+    int    mg3_keep_levels;    /* HELM_MG3_KEEP_LEVELS   -1    coarsenings above the directly solved level; -1: chosen by the depth model */
+    int    mg3_galerkin;       /* HELM_MG3_GALERKIN      1     Galerkin operator on the directly solved level */
+    int    mg3_depth_model;    /* HELM_MG3_DEPTH_MODEL   1     trade set-up seconds against booked iteration counts */
+    int    mg3_bt_f32;         /* HELM_MG3_BT_F32        1     single-precision plane inverses of the block-tridiagonal coarse solve */
+    int    mg3_otf;            /* HELM_MG3_OTF           1     fine-level 27-point apply rebuilds its coefficients from c, rho and the PML profiles */
+    double mg3_omega;          /* HELM_MG3_OMEGA         0.9   Jacobi damping of the smoother */
+} helm_tuning;
+int helm_get_tuning(helm_tuning *out);          /* the values in force now (environment applied) */
+int helm_set_tuning(const helm_tuning *t);      /* NULL: defaults + environment again */
+
 /* --- diagnostics of the direct solver ---------------------------------------------------- */
 /* Elimination-tree plan of an (nz, nx) grid (host only, no GPU needed).  out == NULL: returns the number of fronts;
  * else writes 12 ints per front in processing order {z0, z1, x0, x1, cut, pos, s, m, kid0, kid1, smax, mmax}. */
@@ -275,8 +317,8 @@ int helm_direct_plan_front(int nz, int nx, int leaf, int node, long long *cells,
 int helm_debug_zgemm(int device, int M, int N, int K, const double *alpha, const double *A, const double *B,
                      const double *beta, double *C, int batch);
 int helm_debug_inverse(int device, int n, double *A, int batch);
-/* average milliseconds per launch of one strided-batched GEMM shape (random operands, `reps` timed launches) with tile-kernel
- * variant `variant` (-1: default; 0: first-generation tile kernel; 1: conflict-free double-buffered vector-FMA kernel; 7: matrix-core kernel) */
+/* average milliseconds per launch of one strided-batched GEMM shape (random operands, `reps` timed launches); variant < 16: the tile the
+ * library would choose, 16 (t + 1): tile configuration t (0 64x64 ... 7 16x64) forced */
 int helm_debug_zgemm_bench(int device, int M, int N, int K, int batch, int variant, int reps, double *ms_out);
 int helm_debug_inverse_bench(int device, int n, const double *A, int reps, int recurse_n, double *ms_out);
 

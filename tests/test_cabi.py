@@ -32,6 +32,34 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.Timing) == 104      # 11 + 2 (gemm_bytes, gemm_sol_ms) eight-byte fields
 
 
+def test_tuning_struct_round_trip(helm_lib, monkeypatch):
+    """helm_tuning (include/helm.h) <-> _lib.Tuning: the same field order, every field reachable through its environment variable (read when
+    used), helm_set_tuning replaces the lot and NULL restores defaults + environment.  Host-only: no GPU call."""
+    from zephyr_amd import _lib
+    text = open(os.path.join(ROOT, 'include', 'helm.h')).read()
+    body = text[text.index('typedef struct helm_tuning {'):text.index('} helm_tuning;')]
+    fields = re.findall(r'^\s*(int|double)\s+(\w+);', body, flags=re.M)
+    assert [n for _, n in fields] == [n for n, _ in _lib.Tuning._fields_]
+    assert [t for t, _ in fields] == ['int' if c is ctypes.c_int else 'double' for _, c in _lib.Tuning._fields_]
+    for k in list(os.environ):
+        if k.startswith('HELM_'):
+            monkeypatch.delenv(k)
+    t = _lib.tuning()
+    assert (t.nd_leaf, t.nd_ws_gb, t.nd_sparse_rhs, t.nd_gjstep_min, t.nd_plans, t.ws_slots, t.mg3_keep_levels) == (8, 32.0, 1, 512, 6, 3, -1)
+    assert t.mg3_omega == 0.9 and t.nd_stable_safety == 8.0                  # first and last doubles: the layouts agree end to end
+    monkeypatch.setenv('HELM_ND_LEAF', '6')
+    monkeypatch.setenv('HELM_MG3_OMEGA', '0.7')
+    t = _lib.tuning()
+    assert t.nd_leaf == 6 and t.mg3_omega == 0.7
+    t.nd_leaf = 5; t.nd_sparse_rhs = 0
+    _lib.set_tuning(t)
+    monkeypatch.setenv('HELM_ND_LEAF', '7')                                  # a set structure wins over the environment
+    u = _lib.tuning()
+    assert u.nd_leaf == 5 and u.nd_sparse_rhs == 0 and u.mg3_omega == 0.7
+    _lib.set_tuning(None)
+    assert _lib.tuning().nd_leaf == 7
+
+
 def test_code_object_is_gfx950():
     so = os.path.join(ROOT, 'zephyr_amd', 'libhelm.so')
     import __graft_entry__ as g

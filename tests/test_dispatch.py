@@ -239,3 +239,21 @@ def test_a_second_call_stops_the_workers_of_an_undrained_first_one(monkeypatch):
     for a, b in zip(second, serial):
         assert np.array_equal(a, b)
     del first
+
+
+def test_an_unstarted_result_superseded_by_a_later_call_refuses_to_start(monkeypatch):
+    """`g1 = A * r1; g2 = A * r2` and then iterating both must not start two sets of pipelines on the same (non-thread-safe)
+    handles: the second product owns them, the first one's token is stale and its first next() says so instead of starting workers."""
+    monkeypatch.setenv('HELM_DEVICES', '0,1')
+    g, sc = config()
+    serial = list(za.MultiFreq(dict(sc, parallel=False)) * g['q'])
+    mf = za.MultiFreq(sc)
+    first = mf * g['q']
+    second = mf * g['q']
+    before = threading.active_count()
+    with pytest.raises(RuntimeError, match='superseded'):
+        next(first)
+    assert threading.active_count() == before                  # nothing was started on behalf of the stale call
+    out = list(second)
+    for a, b in zip(out, serial):
+        assert np.array_equal(a, b)

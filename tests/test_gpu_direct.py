@@ -554,6 +554,49 @@ def test_declared_support_gives_the_wavefields_of_the_scan(helm_lib, monkeypatch
             op.solveDevice(R.data_ptr(), U1.data_ptr(), nsrc, N, layout='node', support=wrong_full)
     del op.factors
 
+@pytest.mark.parametrize('nsrc', [5, 130])
+def test_declared_support_may_be_a_superset_of_the_nonzeros(helm_lib, monkeypatch, nsrc):
+    """a bit of helm_set_rhs_support means the block MAY be nonzero, so supersets are legal -- every bit set on point sources (a
+    conservative caller), and a scipy matrix with explicit zero entries (muted source terms: helm_rhs_support_from_coo sets bits from the
+    triplets without looking at the values).  A leaf flagged without a nonzero must store its zeros: with the front-vector arena poisoned, rows
+    a parent reads on the word of a raised flag would otherwise be NaN.  Bit for bit the wavefields of the scanning solve."""
+    import torch
+    import scipy.sparse as sp
+    import zephyr_amd as za
+    nz, nx = 150, 170
+    N = nz * nx
+    rng = np.random.default_rng(150 + nsrc)
+    c = 1800. + 2000. * rng.random((nz, nx))
+    cfg = dict(nx=nx, nz=nz, dx=10., dz=10., c=c, freq=8., nPML=8, rtol=1e-10, method='direct', batch=256)
+    locs = np.stack([rng.uniform(100., 10. * nx - 100., nsrc), rng.uniform(20., 60., nsrc)], axis=1)
+    qs = sp.csc_matrix(za.SparseKaiserSource(cfg)(locs))
+    dev = torch.device('cuda', 0)
+    monkeypatch.setenv('HELM_ND_POISON', '1')
+    op = za.Eurus(cfg)
+    R = torch.zeros((N, nsrc), dtype=torch.complex128, device=dev)
+    op.rhsFromSparseDevice(qs, R.data_ptr(), layout='node')
+    U0 = torch.empty_like(R); U1 = torch.empty_like(R); U2 = torch.empty_like(R)
+    op.solveDevice(R.data_ptr(), U0.data_ptr(), nsrc, N, layout='node')                       # the library scans
+    exact = op.rhsSupportFromSparse(qs)
+    everything = torch.full_like(exact, (1 << ((nsrc + 63) // 64)) - 1)
+    monkeypatch.setenv('HELM_ND_SUPPORT_CHECK', '1')
+    op.solveDevice(R.data_ptr(), U1.data_ptr(), nsrc, N, layout='node', support=everything)
+    # explicit zeros: entries scattered over the grid (far from the sources too) whose value is 0.0
+    coo = qs.tocoo()
+    zr = rng.integers(0, N, 40 * nsrc); zc = rng.integers(0, nsrc, 40 * nsrc)
+    qz = sp.coo_matrix((np.concatenate([coo.data, np.zeros(zr.size, dtype=coo.data.dtype)]),
+                        (np.concatenate([coo.row, zr]), np.concatenate([coo.col, zc]))), shape=qs.shape)
+    bits_z = op.rhsSupportFromSparse(qz)
+    assert int(bits_z.count_nonzero()) > int(exact.count_nonzero())
+    op.solveDevice(R.data_ptr(), U2.data_ptr(), nsrc, N, layout='node', support=bits_z)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(torch.view_as_real(U1)).all()) and bool(torch.isfinite(torch.view_as_real(U2)).all())
+    assert torch.equal(torch.view_as_real(U0), torch.view_as_real(U1))
+    assert torch.equal(torch.view_as_real(U0), torch.view_as_real(U2))
+    assert all(i['status'] == 0 for i in op.lastInfo), op.lastInfo
+    del op.factors
+
+
 @pytest.mark.parametrize('nsrc', [3, 70, 200])
 def test_sparse_right_hand_sides_skip_nothing_that_matters(helm_lib, monkeypatch, nsrc):
     """The forward pass leaves out the fronts whose right-hand-side rows and whose children's rows are all zero in a block of 64 columns

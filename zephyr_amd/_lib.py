@@ -44,6 +44,17 @@ class Timing(ctypes.Structure):
                 ('gemm_bytes', ctypes.c_double), ('gemm_sol_ms', ctypes.c_double)]
 
 
+class Tuning(ctypes.Structure):
+    """helm_tuning of include/helm.h: the library's real options (each also an environment variable, named there)."""
+    _fields_ = [('nd_leaf', ctypes.c_int), ('nd_ws_gb', ctypes.c_double), ('nd_sparse_rhs', ctypes.c_int), ('nd_stable', ctypes.c_int),
+                ('nd_stable_thr', ctypes.c_double), ('nd_stable_safety', ctypes.c_double), ('nd_fused_leaf', ctypes.c_int),
+                ('nd_fused_leaf_min', ctypes.c_int), ('nd_gjstep', ctypes.c_int), ('nd_gjstep_min', ctypes.c_int), ('nd_overlap', ctypes.c_int),
+                ('nd_xcd_map', ctypes.c_int), ('nd_plans', ctypes.c_int), ('nd_direct_out', ctypes.c_int), ('auto_direct', ctypes.c_int),
+                ('auto_mg3', ctypes.c_int), ('prof_ext', ctypes.c_int), ('ws_slots', ctypes.c_int), ('pf_prio', ctypes.c_int),
+                ('mg3_keep', ctypes.c_int), ('mg3_keep_levels', ctypes.c_int), ('mg3_galerkin', ctypes.c_int), ('mg3_depth_model', ctypes.c_int),
+                ('mg3_bt_f32', ctypes.c_int), ('mg3_otf', ctypes.c_int), ('mg3_omega', ctypes.c_double)]
+
+
 # every symbol include/helm.h declares, with its ctypes signature
 _c_dp = ctypes.POINTER(ctypes.c_double)
 _SIGNATURES = {
@@ -83,6 +94,8 @@ _SIGNATURES = {
     'helm_set_profiling': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'helm_imaging_accumulate_device': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                                       ctypes.c_void_p, ctypes.c_void_p]),
+    'helm_get_tuning': (ctypes.c_int, [ctypes.POINTER(Tuning)]),
+    'helm_set_tuning': (ctypes.c_int, [ctypes.POINTER(Tuning)]),
     'helm_trim': (ctypes.c_int, []),
     'helm_host_trim': (ctypes.c_int, []),
     'helm_debug_ws_slots': (ctypes.c_int, [ctypes.c_int, ctypes.c_longlong]),
@@ -137,6 +150,18 @@ def load():
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+def tuning():
+    'the options in force (helm_get_tuning): a Tuning structure; change fields and hand it to set_tuning()'
+    t = Tuning()
+    check(load().helm_get_tuning(ctypes.byref(t)))
+    return t
+
+
+def set_tuning(t=None):
+    'replace the options for the process (None: defaults + environment again)'
+    check(load().helm_set_tuning(ctypes.byref(t) if t is not None else None))
 
 
 def last_error(handle=None):

@@ -18,27 +18,18 @@ class BaseModelDependent(AttributeMapper):
         'freeSurf':       (False,    '_freeSurf',  tuple),
     }
 
-    @property
-    def xorig(self):
-        return getattr(self, '_xorig', 0.)
+    # optional geometry keys and what they default to (base.py:31-65): a name means "the value of that attribute"
+    _GEOMETRY_DEFAULTS = (('xorig', 0.), ('zorig', 0.), ('dx', 1.), ('dz', 'dx'), ('freeSurf', (False, False, False, False)))
 
-    @property
-    def zorig(self):
-        return getattr(self, '_zorig', 0.)
-
-    @property
-    def dx(self):
-        return getattr(self, '_dx', 1.)
-
-    @property
-    def dz(self):
-        return getattr(self, '_dz', self.dx)
-
-    @property
-    def freeSurf(self):
-        if getattr(self, '_freeSurf', None) is None:
-            self._freeSurf = (False, False, False, False)
-        return self._freeSurf
+    def __getattr__(self, name):
+        # (reached only when `name` is not set: initMap stores a given value under '_' + name)
+        for key, default in type(self)._GEOMETRY_DEFAULTS:
+            if key == name:
+                given = self.__dict__.get('_' + name)
+                if given is not None:
+                    return given
+                return getattr(self, default) if isinstance(default, str) else default
+        raise AttributeError('%s has no attribute %r' % (type(self).__name__, name))
 
     @property
     def modelDims(self):

@@ -31,6 +31,55 @@ void helm_set_error(helm_op *op, const char *msg) {
 extern "C" const char *helm_last_error(const helm_op *op) { return op ? op->err.c_str() : g_last_error.c_str(); }
 extern "C" const char *helm_version(void) { return "libhelm 0.1 (gfx950)"; }
 
+// ---- tuning (include/helm.h: helm_tuning) ------------------------------------------------------------------------------------------------
+namespace {
+std::mutex g_tune_mu;
+bool g_tune_set = false;
+helm_tuning g_tune_user;
+int tune_i(const char *name, int d) { const char *v = getenv(name); return v ? atoi(v) : d; }
+double tune_d(const char *name, double d) { const char *v = getenv(name); return v ? atof(v) : d; }
+}
+helm_tuning helm_tuning_now() {
+    {
+        std::lock_guard<std::mutex> lk(g_tune_mu);
+        if (g_tune_set) return g_tune_user;
+    }
+    helm_tuning t;
+    t.nd_leaf = std::max(2, tune_i("HELM_ND_LEAF", 8));
+    t.nd_ws_gb = tune_d("HELM_ND_WS_GB", 32.0);
+    t.nd_sparse_rhs = tune_i("HELM_ND_SPARSE_RHS", 1);
+    t.nd_stable = tune_i("HELM_ND_STABLE", 1);
+    t.nd_stable_thr = tune_d("HELM_ND_STABLE_THR", 0.0);
+    t.nd_stable_safety = std::max(1.0, tune_d("HELM_ND_STABLE_SAFETY", 8.0));
+    t.nd_fused_leaf = tune_i("HELM_ND_FUSEDLEAF", 1);
+    t.nd_fused_leaf_min = tune_i("HELM_ND_FUSEDLEAF_MIN", 2048);
+    t.nd_gjstep = tune_i("HELM_ND_GJSTEP", 1);
+    t.nd_gjstep_min = tune_i("HELM_ND_GJSTEP_MIN", 512);
+    t.nd_overlap = tune_i("HELM_ND_OVERLAP_NM", 1);
+    t.nd_xcd_map = tune_i("HELM_ND_XCDMAP", 2);
+    t.nd_plans = std::max(1, tune_i("HELM_ND_PLANS", 6));
+    t.nd_direct_out = tune_i("HELM_ND_DIRECT_OUT", 1);
+    t.auto_direct = tune_i("HELM_AUTO_DIRECT", 1);
+    t.auto_mg3 = tune_i("HELM_AUTO_MG3", 1);
+    t.prof_ext = tune_i("HELM_PROF_EXT", 1);
+    t.ws_slots = tune_i("HELM_WS_SLOTS", 3);
+    { const int p = tune_i("HELM_PF_PRIO", 1); t.pf_prio = p > 0 ? 1 : (p < 0 ? -1 : 0); }
+    t.mg3_keep = tune_i("HELM_MG3_KEEP", 1);
+    t.mg3_keep_levels = tune_i("HELM_MG3_KEEP_LEVELS", -1);
+    t.mg3_galerkin = tune_i("HELM_MG3_GALERKIN", 1);
+    t.mg3_depth_model = tune_i("HELM_MG3_DEPTH_MODEL", 1);
+    t.mg3_bt_f32 = tune_i("HELM_MG3_BT_F32", 1);
+    t.mg3_otf = tune_i("HELM_MG3_OTF", 1);
+    t.mg3_omega = tune_d("HELM_MG3_OMEGA", 0.9);
+    return t;
+}
+extern "C" int helm_get_tuning(helm_tuning *out) { if (!out) return HELM_ERR_ARG; *out = helm_tuning_now(); return HELM_OK; }
+extern "C" int helm_set_tuning(const helm_tuning *t) {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    if (t) { g_tune_user = *t; g_tune_set = true; } else g_tune_set = false;
+    return HELM_OK;
+}
+
 extern "C" int helm_device_count(void) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -54,7 +103,7 @@ struct WsSlot { void *ptr = nullptr; size_t bytes = 0; bool busy = false; };
 struct WsDevice { WsSlot slot[WS_SLOTS_MAX]; };
 struct SharedWs { std::mutex mu; std::map<int, WsDevice> dev; };
 static SharedWs g_shared_ws;
-static int shared_ws_slots() { const char *e = getenv("HELM_WS_SLOTS"); const int n = e ? atoi(e) : 3; return n < 1 ? 1 : (n > WS_SLOTS_MAX ? WS_SLOTS_MAX : n); }
+static int shared_ws_slots() { const int n = helm_tuning_now().ws_slots; return n < 1 ? 1 : (n > WS_SLOTS_MAX ? WS_SLOTS_MAX : n); }
 static int g_live_handles = 0;     // guarded by g_shared_ws.mu
 
 // idle device buffers by (device, size); `held` and the cap are per device (r4: one sum over all GPUs hit a single device's cap with the second GPU's buffers)
@@ -244,7 +293,7 @@ void helm_pool_free(int device, void *p, size_t bytes) {
 
 
 // priority class of the factor stream of helm_prefactor (HELM_PF_PRIO: 1 highest, 0 normal, -1 lowest)
-static int pf_prio() { static const int p = getenv("HELM_PF_PRIO") ? atoi(getenv("HELM_PF_PRIO")) : 1; return p > 0 ? 1 : (p < 0 ? -1 : 0); }
+static int pf_prio() { return helm_tuning_now().pf_prio; }
 
 static helm_op *create_common(helm_op *op);
 
@@ -942,10 +991,9 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
         ~FactorOwner() { if (p) nd_free(p); }
     } fresh;
     if (need_factor) {
-        const char *e = getenv("HELM_ND_LEAF");
         f = new NdFactor();
         fresh.p = f;
-        rc = nd_get_plan(op, e ? std::max(2, atoi(e)) : 8, sys2 ? 2 : 1, &f->pd);
+        rc = nd_get_plan(op, helm_tuning_now().nd_leaf, sys2 ? 2 : 1, &f->pd);
         if (rc) return rc;
     }
     // per right-hand side: the node-major pipeline keeps q', x, the stored residual and the correction (4 N) beside the two front-vector
@@ -953,12 +1001,10 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
     const long long per_rhs = sys2 ? nd_solve_ws_elems(f->pd->plan, 1) + 2 * NV : 4 * N + 2 * f->pd->plan.vregion;
     int Bmax = o.batch > 0 ? o.batch : 256;
     if (Bmax > nrhs) Bmax = nrhs;
-    const char *capenv = getenv("HELM_ND_WS_GB");
-    const double cap = (capenv ? atof(capenv) : 32.0) * 1e9;
+    const double cap = helm_tuning_now().nd_ws_gb * 1e9;
     while (Bmax > 1 && (double)per_rhs * Bmax * sizeof(cplx) > cap) Bmax = (Bmax + 1) / 2;
-    // factorisation scratch sits behind the solve scratch (they are live together when HELM_ND_OVERLAP=1 runs the forward
-    // elimination of the first batch behind the factorisation on a second stream -- measured: no gain, the big forward GEMMs
-    // delay the factorisation's small launches by as much as they hide; off by default)
+    // factorisation scratch sits behind the solve scratch (they are live together when the forward elimination of the first batch runs
+    // beside the factorisation on a second stream, below)
     const long long fws = need_factor ? nd_factor_ws_elems(f->pd->plan) : 0LL;
     const long long ws_elems = per_rhs * Bmax + fws;
     WsLease lease(op, (size_t)ws_elems * sizeof(cplx));
@@ -968,16 +1014,14 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
         rc = helm_launch_rowscaled_system(op);      // which would mislead the magnitude-based pivoting): A_s = D A, A_s x = D q'
         if (rc) return rc;
     }
-    static const int overlap = getenv("HELM_ND_OVERLAP") ? atoi(getenv("HELM_ND_OVERLAP")) : 0;
-    static const int use_nm = getenv("HELM_ND_NM") ? atoi(getenv("HELM_ND_NM")) : 1;
     // node-major pipeline: the forward elimination of the first batch may run beside the factorisation (HELM_ND_OVERLAP_NM)
     // -- measured on the 16-frequency job: 44.9 -> 43.8 ms per work item; the factorisation itself stretches from 17.6 to 22.2 ms under
     // the competing launches but 5 ms of forward pass disappear behind it.  Not while per-launch profiling is on: HIP events around
     // kernels that share the chip with another stream measure the sharing, not the kernel (HELM_ND_OVERLAP_NM=2 forces it anyway).
-    static const int overlap_nm = getenv("HELM_ND_OVERLAP_NM") ? atoi(getenv("HELM_ND_OVERLAP_NM")) : 1;
-    const bool nm_overlap = need_factor && (overlap_nm == 2 || (overlap_nm == 1 && !op->profiling)) && use_nm && !sys2 && !overlap;
+    const int overlap_nm = helm_tuning_now().nd_overlap;
+    const bool nm_overlap = need_factor && (overlap_nm == 2 || (overlap_nm == 1 && !op->profiling)) && !sys2;
     bool factor_pending = need_factor;
-    if (need_factor && !overlap && !nm_overlap) {
+    if (need_factor && !nm_overlap) {
         hipEvent_t f0, f1;
         HIP_TRY(op, hipEventCreate(&f0)); HIP_TRY(op, hipEventCreate(&f1));
         hipEventRecord(f0, op->stream);
@@ -1008,7 +1052,7 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
     int unconverged = 0;
     // Node-major pipeline (single-block systems): the right-hand sides are transposed once on the way in (fused with premul /
     // the norm), stay [cell][rhs] through solve, true residual and refinement, and are transposed once on the way out.
-    const bool nm = use_nm && !sys2 && (!factor_pending || nm_overlap);
+    const bool nm = !sys2;        // (single-block systems; the coupled two-field system keeps its vectors rhs-major, below)
     // HELM_NODE_MAJOR (both buffers in the reference's (N, nrhs) layout; helm_solve_device only passes it for one batch of a single-block system):
     // the right-hand sides are used where they lie -- premul moves to the output, u = conj(premul A^-1 q), the relative residual does not see
     // it -- ||q||^2 comes out of the first residual launch, and the wavefield is written by the launch that checks it
@@ -1173,17 +1217,8 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
             }
             xin = x;
         }
-        if (factor_pending) {       // factorisation with the forward elimination of this batch following it level by level
-            float fms = 0.f;
-            rc = nd_factor_solve(op, block, f, ws_factor, sys2 ? op->d_S : nullptr, xin, x, n, nws, op->side_stream, &fms, cj);
-            if (rc) return rc;
-            op->direct[slot] = f; fresh.p = nullptr;
-            op->timing.factor_ms += fms;
-            factor_pending = false;
-        } else {
-            rc = nd_solve(op, f, xin, x, n, nws, cj);
-            if (rc) return rc;
-        }
+        rc = nd_solve(op, f, xin, x, n, nws, cj);           // (the factors exist: the coupled system is factored before its first batch, above)
+        if (rc) return rc;
         std::vector<double> relres(n, 0.0);
         std::vector<int> extra_solves(n, 0);
         double prev_worst = 0.0;
@@ -1303,8 +1338,7 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
     // AUTO: the sparse direct path wherever it applies (2-D single-block systems that fit), else / on failure the
     // multigrid-preconditioned Krylov path below
     if (o.method == HELM_AUTO && op->ny == 0 && !op->direct_failed) {
-        const char *e = getenv("HELM_AUTO_DIRECT");
-        if (!e || atoi(e) != 0) {
+        if (helm_tuning_now().auto_direct != 0) {
             std::vector<helm_solve_info> saved;
             if (info) saved.assign(info, info + nrhs);
             // what THIS call's direct pass found, apart from what earlier blocks of the same solve left in `info` (stacked Eurus: block 3, then 0)
@@ -1376,7 +1410,7 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
     if (rc) return rc;
     // preconditioner choice: multigrid for the main block when asked for (or AUTO on Eurus, where it is validated)
     bool use_mg = false;
-    static const int auto_mg3 = getenv("HELM_AUTO_MG3") ? atoi(getenv("HELM_AUTO_MG3")) : 1;
+    const int auto_mg3 = helm_tuning_now().auto_mg3;
     const bool mg3_ok = op->ny > 0 && (o.method == HELM_MG || (o.method == HELM_AUTO && auto_mg3 && std::min(op->nz, std::min(op->ny, op->nx)) >= 24));
     if (!sys2 && block == 0 && (mg3_ok || (op->ny == 0 && (o.method == HELM_MG || (o.method == HELM_AUTO && std::min(op->nz, op->nx) >= 32))))) {
         op->mg3_rhs_hint = nrhs;
@@ -1599,7 +1633,7 @@ void helm_pf_retire(helm_op *op) {
 // beside the Krylov iterations of frequency k on another handle.  nrhs: right-hand sides the solve will bring (batch width, depth decision).
 static int prefactor3d(helm_op *op, int nrhs) {
     if (op->mg3 || op->mg3_no_keep) return HELM_OK;
-    static const int auto_mg3 = getenv("HELM_AUTO_MG3") ? atoi(getenv("HELM_AUTO_MG3")) : 1;
+    const int auto_mg3 = helm_tuning_now().auto_mg3;
     if (!auto_mg3 || std::min(op->nz, std::min(op->ny, op->nx)) < 24) return HELM_OK;
     HIP_TRY(op, hipSetDevice(op->device));
     const int Bmax = std::max(1, std::min(nrhs > 0 ? nrhs : 16, 16));
@@ -1627,7 +1661,7 @@ static int prefactor3d(helm_op *op, int nrhs) {
 // so a factorisation that happens inside a solve needs no hint.
 extern "C" int helm_set_tolerance_hint(helm_op *op, double rtol) {
     if (!op || !(rtol > 0)) return HELM_ERR_ARG;
-    op->rtol_hint = rtol;
+    op->rtol_hint = rtol; op->rtol_hint_set = true;
     return HELM_OK;
 }
 
@@ -1644,7 +1678,7 @@ extern "C" int helm_prefactor(helm_op *op) {
     // a hint: only the single-block 2-D systems the direct path of HELM_AUTO / HELM_DIRECT factors once per frequency
     if (op->ny > 0 || op->direct_failed || op->direct[0] || op->pf_pending) return HELM_OK;
     if (op->variant == HELM_EURUS && !op->block_zero[2]) return HELM_OK;          // coupled TTI: row-equilibrated inside the solve
-    { const char *e = getenv("HELM_AUTO_DIRECT"); if (e && atoi(e) == 0) return HELM_OK; }
+    if (helm_tuning_now().auto_direct == 0) return HELM_OK;
     if (testing_hook("HELM_ND_INJECT_FAILURE")) return HELM_OK;
     HIP_TRY(op, hipSetDevice(op->device));
     if (!op->fstream) {
@@ -1655,8 +1689,7 @@ extern "C" int helm_prefactor(helm_op *op) {
     if (!op->pf_t0) HIP_TRY(op, hipEventCreate(&op->pf_t0));
     if (!op->pf_t1) HIP_TRY(op, hipEventCreate(&op->pf_t1));
     NdFactor *f = new NdFactor();
-    const char *e = getenv("HELM_ND_LEAF");
-    int rc = nd_get_plan(op, e ? std::max(2, atoi(e)) : 8, 1, &f->pd);
+    int rc = nd_get_plan(op, helm_tuning_now().nd_leaf, 1, &f->pd);
     if (rc) { nd_free(f); return rc; }
     const size_t wsb = (size_t)nd_factor_ws_elems(f->pd->plan) * sizeof(cplx);
     void *ws = helm_pool_alloc(op->device, wsb);
@@ -1697,15 +1730,14 @@ extern "C" int helm_reserve(helm_op *op, int nrhs, long long rows, int concurren
         for (void *p : got) helm_pool_free(op->device, p, bytes);
     }
     const bool direct2d = op->assembled && op->ny == 0 && !op->direct_failed && !(op->variant == HELM_EURUS && !op->block_zero[2]);
-    { const char *e = getenv("HELM_AUTO_DIRECT"); if (e && atoi(e) == 0) return HELM_OK; }
+    const helm_tuning tune = helm_tuning_now();
+    if (tune.auto_direct == 0) return HELM_OK;
     if (!direct2d) return HELM_OK;
     std::shared_ptr<NdPlanDev> pd;
-    const char *e = getenv("HELM_ND_LEAF");
-    if (nd_get_plan(op, e ? std::max(2, atoi(e)) : 8, 1, &pd) != HELM_OK || !pd) return HELM_OK;
+    if (nd_get_plan(op, tune.nd_leaf, 1, &pd) != HELM_OK || !pd) return HELM_OK;
     const long long per_rhs = 4 * op->N + 2 * pd->plan.vregion;
     int Bmax = std::min(nrhs, 256);
-    const char *capenv = getenv("HELM_ND_WS_GB");
-    const double cap = (capenv ? atof(capenv) : 32.0) * 1e9;
+    const double cap = tune.nd_ws_gb * 1e9;
     while (Bmax > 1 && (double)per_rhs * Bmax * sizeof(cplx) > cap) Bmax = (Bmax + 1) / 2;
     const size_t wsb = (size_t)per_rhs * Bmax * sizeof(cplx);
     const int ready = ws_table_reserve(g_shared_ws, op->device, wsb, concurrent, ws_dev_alloc, ws_dev_free);      // this device's own table: booking for one GPU never touches another's
@@ -1729,22 +1761,24 @@ extern "C" int helm_reserve(helm_op *op, int nrhs, long long rows, int concurren
 
 extern "C" int helm_solve_device(helm_op *op, const void *dRHS, void *dU, int nrhs, long long rows,
                                  double premul_re, double premul_im, const helm_solve_opts *opts, helm_solve_info *info) {
-    if (!op || !dRHS || !dU || nrhs < 1) return HELM_ERR_ARG;
+    if (!op) return HELM_ERR_ARG;
+    // a declared support (helm_set_rhs_support) belongs to THIS call's right-hand sides and to no later one -- whichever way the call ends, the
+    // early returns below included (the bits usually live in a buffer the caller recycles as soon as this returns)
+    struct SupportOneShot { helm_op *o; ~SupportOneShot() { o->rhs_bits = nullptr; o->rhs_bits_q = nullptr; o->rhs_bits_violated = 0; } } support_one_shot{op};
+    if (!dRHS || !dU || nrhs < 1) return HELM_ERR_ARG;
     if (!op->assembled) HELM_FAIL(op, HELM_ERR_STATE, "operator not assembled");
     const long long N = op->N;
     const bool stacked = (op->variant == HELM_EURUS && rows == 2 * N);
     if (rows != N && !stacked) HELM_FAIL(op, HELM_ERR_ARG, "dimension mismatch: rhs has %lld rows, operator has %lld%s", rows, N,
                                          op->variant == HELM_EURUS ? " (or 2N stacked)" : "");
     HIP_TRY(op, hipSetDevice(op->device));
-    // a declared support (helm_set_rhs_support) belongs to THIS call's right-hand sides and to no later one
-    struct SupportOneShot { helm_op *o; ~SupportOneShot() { o->rhs_bits = nullptr; o->rhs_bits_q = nullptr; o->rhs_bits_violated = 0; } } support_one_shot{op};
     if (op->rhs_bits && (op->rhs_bits_rows != rows || op->rhs_bits_nrhs != nrhs)) HELM_FAIL(op, HELM_ERR_ARG, "helm_set_rhs_support was given %lld rows x %d right-hand sides, this solve has %lld x %d", op->rhs_bits_rows, op->rhs_bits_nrhs, rows, nrhs);
     op->rhs_bits_q = op->rhs_bits ? dRHS : nullptr;
     helm_solve_opts o;
     if (opts) o = *opts; else { o.method = HELM_AUTO; o.rtol = 1e-10; o.maxit = 200000; o.check_every = 0; o.batch = 0; o.flags = 0; }
     if (!(o.rtol > 0)) o.rtol = 1e-10;
     if (o.maxit < 1) o.maxit = 200000;
-    if (!op->direct[0] && !op->pf_pending) op->rtol_hint = o.rtol;      // (factors that exist, or are on their way, were conditioned for the hint they were given)
+    if (!op->direct[0] && !op->pf_pending) { op->rtol_hint = o.rtol; op->rtol_hint_set = true; }      // (factors that exist, or are on their way, were conditioned for the hint they were given)
     if (info) for (int r = 0; r < nrhs; ++r) { info[r].iterations = 0; info[r].status = 0; info[r].restarts = 0; info[r].method = o.method; info[r].relres = 0.0; }
     const cplx premul = cmake(premul_re, premul_im);
 
@@ -1771,7 +1805,7 @@ extern "C" int helm_solve_device(helm_op *op, const void *dRHS, void *dU, int nr
     bool native_done = false;
     if (lay == HELM_NODE_MAJOR && op->ny == 0 && rows == N && !op->direct_failed && (o.method == HELM_AUTO || o.method == HELM_DIRECT) &&
         (op->variant == HELM_MINIZEPHYR || op->block_zero[2]) && !testing_hook("HELM_ND_INJECT_FAILURE") && !testing_hook("HELM_ND_INJECT_STALL") &&
-        !(getenv("HELM_AUTO_DIRECT") && atoi(getenv("HELM_AUTO_DIRECT")) == 0 && o.method == HELM_AUTO)) {
+        !(helm_tuning_now().auto_direct == 0 && o.method == HELM_AUTO)) {
         helm_solve_opts on = o; on.flags |= HELM_NODE_MAJOR;
         const int rcn = solve_block_direct(op, 0, (const cplx *)dRHS, nrhs, 0, premul, nullptr, nullptr, nrhs, on, info, 0, 0, (cplx *)dU);
         if (op->rhs_bits_violated) { cleanup(); return HELM_ERR_ARG; }          // (HELM_ND_SUPPORT_CHECK: the message is set)
@@ -1968,6 +2002,7 @@ extern "C" int helm_solve_coo(helm_op *op, const long long *row, const int *col,
     if (!rc && nrhs <= 512 && (flags & HELM_NODE_MAJOR) == HELM_NODE_MAJOR && helm_rhs_support_from_coo(op, d_row, d_col, nnz, dBits, rows, nrhs) == HELM_OK)
         (void)helm_set_rhs_support(op, dBits, rows, nrhs);
     if (!rc) rc = helm_solve_device(op, dR, dU, nrhs, rows, premul_re, premul_im, opts, info);
+    (void)helm_set_rhs_support(op, nullptr, 0, 0);          // (the bits live in dT, which goes back to the pool below: never leave a pointer to them behind)
     if (rc >= 0 && hipMemcpy(U, dU, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = HELM_ERR_DEVICE;
     release();
     return rc;

@@ -126,8 +126,6 @@ int nd_factor_enqueue(helm_op *op, int block, NdFactor *f, cplx *ws, const cplx 
 void nd_free(NdFactor *f);
 long long nd_solve_ws_elems(const NdPlan &P, int nrhs);
 int nd_solve(helm_op *op, NdFactor *f, const cplx *Xin, cplx *Xout, int nrhs, cplx *ws, int conj_out = 0);   // conj_out: Xout = conj(x)
-int nd_factor_solve(helm_op *op, int block, NdFactor *f, cplx *ws_factor, const cplx *planes, const cplx *Xin, cplx *Xout, int nrhs,
-                    cplx *ws_solve, hipStream_t side, float *factor_ms, int conj_out = 0);
 int nd_axpy_one(helm_op *op, cplx *y, const cplx *x, long long n, int conj = 0);
 // node-major pipeline (direct.hip): right-hand sides and solutions as [cell][rhs] between one transpose in and one out
 int nd_solve_nm(helm_op *op, NdFactor *f, const cplx *Qt, cplx *Xt, int nrhs, cplx *arenaV);

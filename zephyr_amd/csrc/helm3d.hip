@@ -283,8 +283,7 @@ int helm3d_launch_apply(helm_op *op, const ApplyArgs &a, hipEvent_t e0, hipEvent
     q.nz = op->nz; q.ny = op->ny; q.nx = op->nx; q.nrhs = a.nrhs;
     q.ntx = (op->nx + T3X - 1) / T3X; q.nty = (op->ny + T3Y - 1) / T3Y; q.nblk = q.ntx * q.nty * op->nz;
     q.scal = a.scal; q.part = a.part; q.dinv = a.dinv; q.omega_j = a.omega_j;
-    static const int zfast = getenv("HELM_3D_ZFAST") ? atoi(getenv("HELM_3D_ZFAST")) : 1;
-    q.zfast = zfast;
+    q.zfast = 1;
     int split = 1;
     if (q.nblk < 2048) { split = (2048 + q.nblk - 1) / q.nblk; if (split > a.nrhs) split = a.nrhs; if (split < 1) split = 1; }
     dim3 grid(q.nblk, split);

@@ -152,6 +152,7 @@ struct helm_op {
     std::vector<std::pair<int, double>> ev_pending;   // (event-pair index, bytes)
     std::vector<std::pair<int, double>> ev_pending_gemm;   // (event-pair index, flops) of the direct solver's GEMM launches / runs of launches
     std::vector<int> ev_pending_gemm_n;                    // launches covered by each pair
+    bool rtol_hint_set = false;                            // a caller or a solve has stated its tolerance on this handle (else rtol_hint is only the default)
     double rtol_hint = 1e-10;                              // tolerance the next factorisation is conditioned for (helm_set_tolerance_hint; every solve records its own)
     std::vector<long long> ev_pending_gemm_shape;          // (HELM_GEMM_LOG=1) M, N, K, batch, addressing mode of each record, five entries apiece
     std::vector<double> ev_pending_gemm_bytes, ev_pending_gemm_sol;   // operand bytes and roofline time (ms) of the same launches
@@ -169,6 +170,7 @@ struct helm_op {
     HELM_FAIL(op, HELM_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); } } while (0)
 
 void helm_set_error(helm_op *op, const char *msg);
+helm_tuning helm_tuning_now();                            // the options in force (helm_set_tuning, else defaults + environment; include/helm.h)
 
 // Size-keyed cache of large device buffers (coefficient planes, factors, per-call temporaries): a job walks through many
 // operators of identical shape, and hipMalloc/hipFree of GB-sized buffers cost milliseconds each.  helm_trim() empties it.

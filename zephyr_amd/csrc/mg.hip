@@ -55,8 +55,6 @@ struct MgPrecond {
 
 namespace {
 
-double env_double(const char *name, double dflt) { const char *v = getenv(name); return v ? atof(v) : dflt; }
-int env_int(const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; }
 
 __device__ inline bool active(const RhsScal *scal, int b) { return scal == nullptr || scal[b].status == ST_ACTIVE; }
 
@@ -461,17 +459,17 @@ int mg_setup(helm_op *op, int batch) {
     MgPrecond *P = new MgPrecond();
     op->mg = P;
     P->batch = batch;
-    P->f32 = env_int("HELM_MG_F32", 0) != 0;   // single-precision cycle: measured +10-25 % iterations, no net gain -> off
-    P->beta = env_double("HELM_MG_BETA", 0.6);   // 0.42 diverges on the 1024^2 model, 0.5-0.7 equivalent: keep a margin
-    P->omega_j = env_double("HELM_MG_OMEGA", 0.8);
-    P->cpml_m = env_double("HELM_MG_CPML", 30.0);
-    P->sweeps = env_int("HELM_MG_SWEEPS", 4);
-    P->wstrip = env_double("HELM_MG_WSTRIP", 1.0);
-    P->nu1 = env_int("HELM_MG_NU1", 1);
-    P->nu2 = env_int("HELM_MG_NU2", 1);
-    P->min_n = env_int("HELM_MG_MIN_N", 16);
-    P->fdepth = env_int("HELM_MG_FDEPTH", 3);
-    P->fuse = env_int("HELM_MG_FUSE", 0) != 0;   // measured: no gain (extra address math in the tile load offsets the saved pass)
+    P->f32 = false;   // single-precision cycle: measured +10-25 % iterations, no net gain -> off
+    P->beta = 0.6;   // 0.42 diverges on the 1024^2 model, 0.5-0.7 equivalent: keep a margin
+    P->omega_j = 0.8;
+    P->cpml_m = 30.0;
+    P->sweeps = 4;
+    P->wstrip = 1.0;
+    P->nu1 = 1;
+    P->nu2 = 1;
+    P->min_n = 16;
+    P->fdepth = 3;
+    P->fuse = false;   // measured: no gain (extra address math in the tile load offsets the saved pass)
     P->W = op->nPML + 2;
     if (2 * P->W + 2 > op->nx || 2 * P->W + 2 > op->nz) P->sweeps = 0;      // grid too small for a frame: plain cycle
 
@@ -481,7 +479,7 @@ int mg_setup(helm_op *op, int batch) {
     if (std::isfinite(op->a_tau) && op->a_tau != 0.0) inv_tau += 1.0 / op->a_tau;
     const double tauM = 1.0 / inv_tau;
     const double cpml_weak = op->variant == HELM_EURUS ? std::min(P->cpml_m, op->a_cpml) : 0.0;
-    const double mz_weak = env_double("HELM_MG_MZ_PMLSCALE", 0.1);
+    const double mz_weak = 0.1;
 
     // ---- levels (operators assembled in double precision by the regular assembly kernels) ----
     std::vector<cplx> c = op->h_c;
@@ -493,7 +491,7 @@ int mg_setup(helm_op *op, int batch) {
         L.op = helm_create(op->device, op->variant, nz, nx, dx, dz, -npml, op->fs);
         if (!L.op) { helm_set_error(op, helm_last_error(nullptr)); mg_destroy(op); return HELM_ERR_DEVICE; }
         if (op->variant == HELM_MINIZEPHYR) L.op->pml_scale = mz_weak;
-        L.op->diag_floor = env_double("HELM_MG_DIAGFLOOR", 0.5);
+        L.op->diag_floor = 0.5;
         P->lv.push_back(L);
         int rc = assemble_child(op, L.op, c, rho, th, ep, de, tauM, cpml_weak);
         if (rc) { helm_set_error(op, helm_last_error(L.op)); mg_destroy(op); return rc; }

@@ -57,9 +57,22 @@ double its_lookup(const helm_op *op, int depth, double ppwd, double rtol) {
     return it == g_its.end() || it->second.second == 0 ? -1.0 : it->second.first / it->second.second;
 }
 }
+// The tolerance class a set-up looks its iteration counts up under: the handle's stated tolerance (helm_set_tolerance_hint, or a solve on it), else --
+// a C caller that prefactors a fresh handle without stating one -- the tolerance of the last solve booked on this grid in the process, so that
+// what was recorded under the solves' real rtol is found again instead of the prior constants being used silently.
+namespace {
+std::map<std::tuple<int, int, int>, double> &g_last_rtol = *new std::map<std::tuple<int, int, int>, double>();       // (g_its_mu held)
+double lookup_rtol(const helm_op *op) {
+    if (op->rtol_hint_set) return op->rtol_hint;
+    std::lock_guard<std::mutex> lk(g_its_mu);
+    auto it = g_last_rtol.find(std::make_tuple(op->nz, op->ny, op->nx));
+    return it == g_last_rtol.end() ? op->rtol_hint : it->second;
+}
+}
 void mg3_record_iterations(helm_op *op, double mean_iterations, double rtol) {
     if (!op || !op->mg3 || !op->mg3->keep || !(mean_iterations > 0)) return;
     std::lock_guard<std::mutex> lk(g_its_mu);
+    g_last_rtol[std::make_tuple(op->nz, op->ny, op->nx)] = rtol;
     std::pair<double, int> &e = g_its[it_key(op, op->mg3->kept_levels, op->mg3->ppw_direct, rtol)];
     e.first += mean_iterations; e.second += 1;
 }
@@ -673,21 +686,19 @@ int bt_setup(helm_op *op, Bt3 &B, const Mg3Level &L, int batch) {
     const long long strides[3] = {(long long)L.ny * L.nx, L.nx, 1};
     int axis = 0;
     for (int a = 1; a < 3; ++a) if (dims[a] > dims[axis]) axis = a;       // planes normal to the longest axis are the smallest
-    axis = envi("HELM_MG3_BT_AXIS", axis);
     const int ia = axis == 0 ? 1 : 0, ib = axis == 2 ? 1 : 2;
     B.axis = axis; B.np = dims[axis]; B.na = dims[ia]; B.nb = dims[ib]; B.m = B.na * B.nb;
     B.ss = strides[axis]; B.sa = strides[ia]; B.sb = strides[ib]; B.N = L.N; B.batch = batch;
     B.mid = envi("HELM_MG3_BT_TWIST", 1) ? B.np / 2 : B.np - 1;
     // split-K: ~512 workgroups of 128 columns each (k_bt_apply); HELM_MG3_BT_GEMM=1 goes through the generic batched GEMM instead
-    B.own = envi("HELM_MG3_BT_GEMM", 0) == 0 && batch <= 16;
+    B.own = batch <= 16;
     B.ksplit = B.own ? std::max(1, std::min(16, 512 / ((B.m + 127) / 128))) : std::max(1, std::min(16, 255 / ((B.m + 63) / 64)));
-    B.ksplit = envi("HELM_MG3_BT_KSPLIT", B.ksplit);
     B.kc = (B.m + B.ksplit - 1) / B.ksplit;
     B.mpad = B.own ? B.m : B.kc * B.ksplit;          // (the generic GEMM wants equal K chunks: zero rows / columns up to mpad)
     B.nparts = B.ksplit;
     B.device = op->device;
     // single-precision plane inverses (default): only two double-precision planes per chain exist at a time during the set-up
-    B.f32 = B.own && envi("HELM_MG3_BT_F32", 1) != 0;
+    B.f32 = B.own && helm_tuning_now().mg3_bt_f32 != 0;
     B.ld32 = (B.m + 1) & ~1;
     const long long mm = (long long)B.m * B.m;
     const size_t wbytes = (size_t)mm * sizeof(cplx);
@@ -698,7 +709,7 @@ int bt_setup(helm_op *op, Bt3 &B, const Mg3Level &L, int batch) {
         size_t freeb = 0, totb = 0;
         hipMemGetInfo(&freeb, &totb);
         freeb += helm_pool_idle_bytes(op->device);       // (r4: idle buffers of the library's own pool are available to it)
-        const double cap = std::min(envd("HELM_MG3_BT_MAXGB", totb / 3.0e9) * 1e9, 0.95 * (double)freeb);     // (free memory: several 3-D handles may be alive)
+        const double cap = std::min(totb / 3.0, 0.95 * (double)freeb);     // (free memory: several 3-D handles may be alive)
         if ((double)(tb + B.tbytes32) > cap)
             HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "3-D multigrid: the plane inverses of the directly solved level (%.1f GB) exceed the budget of %.1f GB", (tb + B.tbytes32) / 1e9, cap / 1e9);
     }
@@ -707,16 +718,16 @@ int bt_setup(helm_op *op, Bt3 &B, const Mg3Level &L, int batch) {
     if (!B.aux) HELM_FAIL(op, HELM_ERR_DEVICE, "%s", helm_last_error(nullptr));
     // set-up: two inversions in flight pay while they are latency-bound (m = 1617 at 2 Hz: 0.37 -> 0.30 s); two saturating ones only get in each
     // other's way (m = 3713: 1.49 -> 1.93 s), so from the size at which the look-ahead Gauss-Jordan takes over both chains share one stream
-    const bool conc = B.m < envi("HELM_MG3_BT_CONC_N", 2048);
+    const bool conc = B.m < 2048;
     hipStream_t sts[2] = {op->stream, conc ? B.aux->stream : op->stream};
     helm_op *ctx[2] = {op, conc ? B.aux : op};
     B.Tinv = (cplx *)helm_pool_alloc(op->device, tb);
     if (B.f32) B.Tinv32 = (float2 *)helm_pool_alloc(op->device, B.tbytes32);
     cplx *W[2] = {(cplx *)helm_pool_alloc(op->device, wbytes), (cplx *)helm_pool_alloc(op->device, wbytes)};
-    bool ok = B.Tinv && W[0] && W[1] && (!B.f32 || B.Tinv32) && hipMalloc((void **)&B.Z, (size_t)B.np * batch * B.m * sizeof(cplx)) == hipSuccess;
+    bool ok = B.Tinv && W[0] && W[1] && (!B.f32 || B.Tinv32) && helm_malloc_retry(op->device, (void **)&B.Z, (size_t)B.np * batch * B.m * sizeof(cplx)) == hipSuccess;
     for (int c = 0; c < 2 && ok; ++c)
-        ok = hipMalloc((void **)&B.Y[c], (size_t)batch * B.mpad * sizeof(cplx)) == hipSuccess &&
-             hipMalloc((void **)&B.parts[c], (size_t)B.nparts * batch * B.m * sizeof(cplx)) == hipSuccess;
+        ok = helm_malloc_retry(op->device, (void **)&B.Y[c], (size_t)batch * B.mpad * sizeof(cplx)) == hipSuccess &&
+             helm_malloc_retry(op->device, (void **)&B.parts[c], (size_t)B.nparts * batch * B.m * sizeof(cplx)) == hipSuccess;
     for (int e = 0; e < 3 && ok; ++e) ok = hipEventCreateWithFlags(&B.ev[e], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         for (int c = 0; c < 2; ++c) if (W[c]) helm_pool_free(op->device, W[c], wbytes);
@@ -997,8 +1008,8 @@ double keep_direct_bytes(const helm_op *op, int l, int batch, int *np_out = null
     const double m = (double)out[(s + 1) % 3] * out[(s + 2) % 3];
     if (np_out) *np_out = out[s];
     if (m_out) *m_out = (int)m;
-    const bool own = envi("HELM_MG3_BT_GEMM", 0) == 0 && batch <= 16;
-    const bool f32 = own && envi("HELM_MG3_BT_F32", 1) != 0;
+    const bool own = batch <= 16;
+    const bool f32 = own && helm_tuning_now().mg3_bt_f32 != 0;
     if (f32) return (double)out[s] * m * m * sizeof(float2) + 4.0 * m * m * sizeof(cplx);        // + the set-up's double-precision ping-pong planes
     double mpad = m;
     if (!own) { const int ks = std::max(1, std::min(16, 255 / (((int)m + 63) / 64))); mpad = (double)(((int)m + ks - 1) / ks) * ks; }
@@ -1144,7 +1155,7 @@ int setup_keep(helm_op *op, Mg3Precond *P, int batch, int ncoarsen, double tauM)
     };
     Mg3Keep *K = new Mg3Keep();
     P->keep = K;
-    K->omega_l1 = envd("HELM_MG3_OMEGA_L1", 1.6);
+    K->omega_l1 = 1.6;
     K->device = op->device;
     std::complex<double> om(2.0 * M_PI * op->a_freq_re, 2.0 * M_PI * op->a_freq_im);
     om -= std::complex<double>(0.0, 1.0 / tauM);
@@ -1218,7 +1229,7 @@ int setup_keep(helm_op *op, Mg3Precond *P, int batch, int ncoarsen, double tauM)
         for (int a = 0; a < 3; ++a) ax[a] = cx[a];
     }
     lap("last level");
-    if (ncoarsen > 0 && envi("HELM_MG3_GALERKIN", 1)) {        // the directly solved level carries the Galerkin product of the level above it
+    if (ncoarsen > 0 && helm_tuning_now().mg3_galerkin) {        // the directly solved level carries the Galerkin product of the level above it
         const Mg3Level &Lf = P->lv[ncoarsen - 1]; Mg3Level &Lc = P->lv[ncoarsen];
         const int t = ncoarsen - 1;
         hipLaunchKernelGGL(k3_galerkin, dim3((unsigned)((Lc.N + 255) / 256)), dim3(256), 0, op->stream, (const cplx *)Lf.op->d_C, Lf.nz, Lf.ny, Lf.nx,
@@ -1266,8 +1277,8 @@ int mg3_setup(helm_op *op, int batch) {
     P->batch = batch;
     // Jacobi damping: measured at 256 x 256 x 128, 4 sources (tools/sweep3d.sh): 0.8 / 0.9 / 1.0 / 1.1 -> 10.9 / 9.6 / 10.0 / 16.4 s at 3 Hz and
     // 7.4 / 7.0 / 6.6 / 8.9 s at 5 Hz
-    P->omega_j = envd("HELM_MG3_OMEGA", 0.9);
-    P->nu1 = envi("HELM_MG3_NU1", 1); P->nu2 = envi("HELM_MG3_NU2", 1); P->min_n = envi("HELM_MG3_MIN_N", 8);
+    P->omega_j = helm_tuning_now().mg3_omega;
+    P->nu1 = 1; P->nu2 = 1; P->min_n = 8;
     const double omega = 2.0 * M_PI * std::abs(std::complex<double>(op->a_freq_re, op->a_freq_im));
     // shift: 0.6 at 10 grid points per wavelength, growing with the square of the oversampling up to 8 -- measured at
     // 256 x 256 x 128, 40-100 points per wavelength: beta 0.6 / 3 / 6 / 12 -> 26 / 16 / 14 / 14 s per 4 sources at 3 Hz
@@ -1290,7 +1301,7 @@ int mg3_setup(helm_op *op, int batch) {
     // Oversampled grids: the layer-preserving hierarchy with a direct solve where the interior still has >= 10 points per wavelength
     // (section above).  Falls back to the standard cycle when no level can be dropped or the plane inverses do not fit.
     {
-        const double ppwc = envd("HELM_MG3_PPWC", 9.9);
+        const double ppwc = 9.9;
         int ncoarsen = 0;
         while (ncoarsen < 5 && ppw / (double)(2 << ncoarsen) >= ppwc) ++ncoarsen;
         const int interior = std::min(op->nz, std::min(op->ny, op->nx)) - 2 * op->nPML;
@@ -1303,8 +1314,8 @@ int mg3_setup(helm_op *op, int batch) {
             freeb += helm_pool_idle_bytes(op->device);       // (r4: idle buffers of the library's own pool are available to it)
             // budget of the plane inverses: a third of the device, and never more than what is free now less the Krylov vectors of this call
             const double krylov = 11.0 * batch * (double)op->N * sizeof(cplx);
-            const double cap = std::min(envd("HELM_MG3_BT_MAXGB", totb / 3.0e9) * 1e9, std::max(0.0, (double)freeb - (op->d_ws ? 0.0 : krylov)));
-            const double ppwf = envd("HELM_MG3_PPWF", 6.0);
+            const double cap = std::min(totb / 3.0, std::max(0.0, (double)freeb - (op->d_ws ? 0.0 : krylov)));
+            const double ppwf = 6.0;
             while (ncoarsen < 5 && coarse_estimate(op, ncoarsen, batch, false).bytes > cap && ppw / (double)(2 << ncoarsen) >= ppwf && (interior >> (ncoarsen + 1)) >= 3) ++ncoarsen;
             // ... and one level deeper (down to 5 points) when that SAVES time for the right-hand sides of the call that builds the preconditioner:
             // the set-up of the deeper level is cheaper (np plane inversions of m^3 work each) but every right-hand side pays more iterations.
@@ -1316,7 +1327,7 @@ int mg3_setup(helm_op *op, int batch) {
             //                    on config 5 this reproduces the 2.6 ms per right-hand side and iteration measured there.
             //   extra          = +11 / +22 / +38 iterations with the Galerkin direct level at >= 8 / 6 / 5 points per wavelength -- a property of the
             //                    cycle, not of the machine: measured on config 5 (homogeneous) and on the heterogeneous probes of DESIGN.md 5.3.
-            if (op->mg3_rhs_hint > 0 && envi("HELM_MG3_DEPTH_MODEL", 1) && ncoarsen < 5 && (interior >> (ncoarsen + 1)) >= 3) {
+            if (op->mg3_rhs_hint > 0 && helm_tuning_now().mg3_depth_model && ncoarsen < 5 && (interior >> (ncoarsen + 1)) >= 3) {
                 const double ppwd = ppw / (double)(2 << ncoarsen);
                 if (ppwd >= 5.0) {
                     const CoarseEst e0 = coarse_estimate(op, ncoarsen, batch, true), e1 = coarse_estimate(op, ncoarsen + 1, batch, true);
@@ -1325,7 +1336,8 @@ int mg3_setup(helm_op *op, int batch) {
                     // iterations the deeper hierarchy costs per right-hand side: booked counts of both classes where this process has run them,
                     // the prior (+11 / +22 / +38) on top of the booked count of the other, or alone, where it has not
                     const double prior = ppwd >= 8.0 ? 11.0 : (ppwd >= 6.0 ? 22.0 : 38.0);
-                    const double its0 = its_lookup(op, ncoarsen, 2.0 * ppwd, op->rtol_hint), its1 = its_lookup(op, ncoarsen + 1, ppwd, op->rtol_hint);      // (ppwd: the DEEPER candidate's direct level)
+                    const double rt_cls = lookup_rtol(op);
+                    const double its0 = its_lookup(op, ncoarsen, 2.0 * ppwd, rt_cls), its1 = its_lookup(op, ncoarsen + 1, ppwd, rt_cls);      // (ppwd: the DEEPER candidate's direct level)
                     const double extra_its = (its0 > 0 && its1 > 0) ? std::max(0.0, its1 - its0) : prior;
                     const double t_iter = 18.0 * apply_seconds_per_rhs(op, batch);
                     const double paid = op->mg3_rhs_hint * extra_its * t_iter;
@@ -1341,14 +1353,14 @@ int mg3_setup(helm_op *op, int batch) {
                 }
             }
         }
-        ncoarsen = envi("HELM_MG3_KEEP_LEVELS", ncoarsen);
-        if (envi("HELM_MG3_KEEP", 1) && !op->mg3_no_keep && ncoarsen > 0 && op->a_cpml > 0 && omega > 0) {
+        { const int kl = helm_tuning_now().mg3_keep_levels; if (kl >= 0) ncoarsen = kl; }
+        if (helm_tuning_now().mg3_keep && !op->mg3_no_keep && ncoarsen > 0 && op->a_cpml > 0 && omega > 0) {
             const double betak = envd("HELM_MG3_BETA", 0.1);
             double inv_tau_k = omega * betak / 2.0;
             if (std::isfinite(op->a_tau) && op->a_tau != 0.0) inv_tau_k += 1.0 / op->a_tau;
             const int rck = setup_keep(op, P, batch, ncoarsen, 1.0 / inv_tau_k);
             if (rck == HELM_OK) { P->beta = betak; P->kept_levels = ncoarsen; P->ppw_direct = ppw / (double)(1 << ncoarsen); hipStreamSynchronize(op->stream); return HELM_OK; }
-            if (envi("HELM_MG3_KEEP", 1) == 2) { const std::string msg = op->err; mg3_destroy(op); helm_set_error(op, msg.c_str()); return rck; }
+            if (helm_tuning_now().mg3_keep == 2) { const std::string msg = op->err; mg3_destroy(op); helm_set_error(op, msg.c_str()); return rck; }
             // not this time: release what was built and go on with the standard hierarchy
             keep_free(P);
             for (Mg3Level &L : P->lv) {
@@ -1364,7 +1376,7 @@ int mg3_setup(helm_op *op, int batch) {
     // layer of the preconditioner: gamma / omega = 2 (measured at 256 x 256 x 128 with the shift above: 0.2 omega -> 26 / 14 / 8.8 s
     // per 4 sources at 2 / 3 / 5 Hz, 2 omega -> 22 / 10.5 / 7.4 s, 5 omega worse again, the true layer (300) does not converge;
     // with the small shift beta = 0.6 only gamma / omega <= 0.4 was stable)
-    P->cpml_m = envd("HELM_MG3_CPML", 2.0 * omega);
+    P->cpml_m = 2.0 * omega;
     const double cpml = std::min(P->cpml_m, op->a_cpml > 0 ? op->a_cpml : P->cpml_m);
     rc = helm_ensure_host_model(op);               // (the standard hierarchy injects its models on the host)
     if (rc) return rc;
@@ -1399,7 +1411,7 @@ int mg3_setup(helm_op *op, int batch) {
     P->nc = (int)Lc.N;
     cplx *A = nullptr, *W = nullptr;
     const size_t mb = (size_t)P->nc * P->nc * sizeof(cplx);
-    if (hipMalloc((void **)&A, mb) != hipSuccess || hipMalloc((void **)&W, mb) != hipSuccess || hipMalloc((void **)&P->cinvT, mb) != hipSuccess) {
+    if (helm_malloc_retry(op->device, (void **)&A, mb) != hipSuccess || helm_malloc_retry(op->device, (void **)&W, mb) != hipSuccess || helm_malloc_retry(op->device, (void **)&P->cinvT, mb) != hipSuccess) {
         hipFree(A); hipFree(W); return fail(HELM_ERR_DEVICE, "3-D multigrid: coarsest inverse does not fit");
     }
     hipMemsetAsync(A, 0, mb, op->stream);

@@ -1,0 +1,615 @@
+// Sparse direct solver for the 2-D 9-point operators: geometric nested dissection + multifrontal
+// factorisation with explicit front inverses, batched level by level.  This file: the factorisation.
+//
+// What it replaces: the reference hands A to a sparse LU (`problemo.BestSolver` -> SuperLU,
+// zephyr/backend/discretization.py:78-103) and re-uses the factors for every source.  This is the same
+// idea laid out for the GPU: the elimination tree of a regular grid is known in closed form, every front of
+// one tree level has the same (padded) shape, so each level is a handful of strided-batched dense kernels.
+//
+//   tree      recursive bisection of the (nz, nx) rectangle by one-cell-wide separator lines (a one-cell line
+//             separates a 9-point stencil); regions with both sides <= LEAF are eliminated whole.        nd_plan.hip
+//   front     [separator cells | ring of cells around the subtree's region] -- the ring cells are exactly the
+//             ancestors' separator cells the subtree touches.  Index <-> cell maps are closed-form (nd_local /
+//             nd_cell, direct.hpp), so no index lists are stored.
+//   factor    a front is written once in gather form (k_nd_build_front: stencil entries + the children's Schur complements);
+//             F11^-1 in place (nd_gj.hip), G21 = F21 F11^-1, Schur complement S = F22 - G21 F12 gathered by the product that
+//             forms it (nd_gemm.hip, IDX 4); the leaf level in one kernel straight from the coefficient planes (nd_leaf.hip);
+//             fronts whose F11 is too ill-conditioned for an explicit inverse are eliminated again with a pivoted LU (NdStable).
+//   solve     forward: front-local vectors travel up the tree exactly like the Schur complements;
+//             backward: x_S = F11^-1 (y_S - F12 x_B), top-down.  Pure GEMMs on node-major right-hand sides
+//             X[cell][rhs], no atomics, bit-reproducible.                                                 nd_passes.hip
+//   accuracy  the true residual q' - A x of what is returned is evaluated with the stencil (nd_resid.hip); right-hand sides
+//             above rtol take a step of iterative refinement (capi.hip).
+//
+// All dense arithmetic is fp64 complex on the matrix cores (v_mfma_f64_16x16x4_f64, nd_gemm_body.hpp).
+#include "nd_internal.hpp"
+
+// ---- kernels ---------------------------------------------------------------------------------------------------
+namespace {
+
+// The front [[F11, F12], [F21, F22]] is assembled where each block is needed afterwards: [F11 | F12] side by side in the factor
+// storage (rows of smax + mmax; F11 is inverted in place, F12 is kept -- for leaves it becomes -F11^-1 F12 after the Schur complement, so
+// that the back substitution of a leaf is ONE product [F11^-1 | -F11^-1 F12] [y_S; x_B]), [F21 | F22] in the scratch arena (F21 feeds G21, F22 becomes the Schur
+// complement the parent picks up).  (r, c): padded front coordinates.
+__device__ __forceinline__ cplx *front_entry(const NdDev &n, cplx *arenaF, cplx *fac, int r, int c) {
+    if (r < n.smax) {
+        return fac + n.finv_off + (long long)r * (n.smax + n.mmax) + c;        // [F11 | F12] share their rows
+    }
+    return arenaF + n.foff + (long long)(r - n.smax) * (n.smax + n.mmax) + c;
+}
+
+__global__ __launch_bounds__(256) void k_nd_assemble(const NdDev *nodes, int first, cplx *arenaF, cplx *fac, const cplx *planes, int nz, int nx) {
+    const NdDev n = nodes[first + blockIdx.y];
+    const long long N = (long long)nz * nx;
+    const int tot = n.s + n.m;
+    for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < n.smax; a += gridDim.x * blockDim.x)
+        if (a >= n.s) *front_entry(n, arenaF, fac, a, a) = cmake(1.0, 0.0);     // padded separator slots: identity
+    for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < tot; a += gridDim.x * blockDim.x) {
+        int z, x, ca;
+        nd_cell(n, a, z, x, ca);
+        const int ra = nd_pos(n, a);
+        // dof > 2 (column mode, the 3-D coarse solve): a cell is a column of dof unknowns along the slowest axis of a (dof, nz, nx) grid with a
+        // 27-point operator -- component ca couples to ca - 1, ca, ca + 1 of the nine neighbour columns; plane 9 (dc + 1) + 3 (dz + 1) + dx + 1
+        const int cb0 = n.dof > 2 ? max(ca - 1, 0) : 0, cb1 = n.dof > 2 ? min(ca + 1, n.dof - 1) : n.dof - 1;
+        for (int cb = cb0; cb <= cb1; ++cb) {
+            // dof 2: row component ca, column component cb -> Eurus block 2 ca + cb (M1 M2 / M3 M4), nine planes each
+            const cplx *pl = n.dof > 2 ? planes + (long long)(cb - ca + 1) * 9 * N * n.dof + (long long)ca * N
+                                       : planes + (long long)(n.dof == 2 ? 2 * ca + cb : 0) * 9 * N;
+            const long long pstride = n.dof > 2 ? N * n.dof : N;
+            #pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int z2 = z + k / 3 - 1, x2 = x + k % 3 - 1;
+                if (z2 < 0 || z2 >= nz || x2 < 0 || x2 >= nx) continue;
+                const int b = nd_local(n, nz, nx, z2, x2, cb);
+                if (b < 0 || (a >= n.s && b >= n.s)) continue;            // ring x ring entries belong to an ancestor
+                *front_entry(n, arenaF, fac, ra, nd_pos(n, b)) = pl[(long long)k * pstride + (long long)z * nx + x];
+            }
+        }
+    }
+}
+
+// parent front += Schur complement of child `slot`; the m x m entries of the child's F22 are spread over gridDim.x blocks
+// (every block rebuilds the child-ring -> parent-row map in LDS, so a block takes `chunk` entries: large enough to amortise that)
+__global__ __launch_bounds__(256) void k_nd_extend_add(const NdDev *nodes, int first, int slot, cplx *arenaF, cplx *fac, int nz, int nx, int chunk) {
+    extern __shared__ int map[];
+    const NdDev p = nodes[first + blockIdx.y];
+    if (p.kid[slot] < 0) return;
+    const NdDev c = nodes[p.kid[slot]];
+    const long long total = (long long)c.m * c.m;
+    if ((long long)blockIdx.x * chunk >= total) return;
+    for (int a = threadIdx.x; a < c.m; a += blockDim.x) {
+        int z, x, comp;
+        nd_cell(c, c.s + a, z, x, comp);
+        map[a] = nd_pos(p, nd_local(p, nz, nx, z, x, comp));
+    }
+    __syncthreads();
+    const cplx *Sc = arenaF + c.foff + c.smax;          // child's F22: row a at Sc + a * ldc
+    const int ldc = c.smax + c.mmax;
+    for (long long e0 = (long long)blockIdx.x * chunk; e0 < total; e0 += (long long)gridDim.x * chunk) {
+        const long long e1 = e0 + chunk < total ? e0 + chunk : total;
+        for (long long e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+            const int a = (int)(e / c.m), b2 = (int)(e - (long long)a * c.m);
+            cplx *dst = front_entry(p, arenaF, fac, map[a], map[b2]);
+            *dst = cadd(*dst, Sc[(long long)a * ldc + b2]);
+        }
+    }
+}
+
+// One pass that WRITES every entry of a front exactly once (gather form of k_nd_assemble + the two k_nd_extend_add + the three
+// memsets they needed):  entry (r, c) = [stencil coefficient of the two cells, unless both lie on the ring]
+//                                       + child 0's Schur complement entry + child 1's, where both cells lie on that child's ring
+// (child 0 first: same summation order as the scatter form, bit for bit), identity on the padded separator diagonal, zero on
+// every other padded slot.  The inverse maps are the same closed-form nd_cell / nd_local; a workgroup tabulates them for the
+// front's rows once in LDS and then streams `rb` rows.  Traffic per level: children's F22 read once, the fronts written once
+// (the scatter form read-modify-wrote the parents twice on top of the memsets).
+__global__ __launch_bounds__(256) void k_nd_build_front(const NdDev *nodes, int first, cplx *arenaF, cplx *fac, const cplx *planes, int nz, int nx, int rb,
+                                                        const NdDev *ovr = nullptr, int skip22 = 0) {
+    extern __shared__ int2 finfo[];        // per padded row: x = z | x << 16 (-1: padding), y = (k0 + 1) | (k1 + 1) << 14 | comp << 28
+    const NdDev n = ovr ? *ovr : nodes[first + blockIdx.y];      // (ovr: one front rebuilt with its [F11 | F12] rows redirected, see NdStable)
+    const int nmax = n.smax + n.mmax;
+    const int r0 = blockIdx.x * rb;
+    if (r0 >= nmax) return;
+    const bool h0 = n.kid[0] >= 0, h1 = n.kid[1] >= 0;
+    NdDev c0 = NdDev(), c1 = NdDev();
+    if (h0) c0 = nodes[n.kid[0]];
+    if (h1) c1 = nodes[n.kid[1]];
+    const int tid = threadIdx.x;
+    for (int r = tid; r < nmax; r += 256) {
+        int a = -1;
+        if (r < n.s) a = r;
+        else if (r >= n.smax && r - n.smax < n.m) a = n.s + r - n.smax;
+        int2 e = make_int2(-1, 0);
+        if (a >= 0) {
+            int z, x, comp;
+            nd_cell(n, a, z, x, comp);
+            int k0 = 0, k1 = 0;
+            if (h0) { const int la = nd_local(c0, nz, nx, z, x, comp); if (la >= c0.s) k0 = la - c0.s + 1; }
+            if (h1) { const int la = nd_local(c1, nz, nx, z, x, comp); if (la >= c1.s) k1 = la - c1.s + 1; }
+            if (n.dof > 2) { e.x = z | (x << 12) | (comp << 24); e.y = k0 | (k1 << 16); }      // (column mode: up to 127 components, rings up to 65534)
+            else { e.x = z | (x << 16); e.y = k0 | (k1 << 14) | (comp << 28); }
+        }
+        finfo[r] = e;
+    }
+    __syncthreads();
+    const long long N = (long long)nz * nx;
+    const cplx *S0 = h0 ? arenaF + c0.foff + c0.smax : nullptr, *S1 = h1 ? arenaF + c1.foff + c1.smax : nullptr;
+    const int ld0 = c0.smax + c0.mmax, ld1 = c1.smax + c1.mmax;
+    const int r1 = r0 + rb < nmax ? r0 + rb : nmax;
+    const int tx = tid & 63, ty = tid >> 6;
+    for (int r = r0 + ty; r < r1; r += 4) {
+        const int2 ia = finfo[r];
+        const bool colmode = n.dof > 2;
+        const int za = colmode ? (ia.x & 0xfff) : (ia.x & 0xffff), xa = colmode ? ((ia.x >> 12) & 0xfff) : (ia.x >> 16);
+        const int ca = colmode ? ((ia.x >> 24) & 0x7f) : ((ia.y >> 28) & 1);
+        const int a0 = (colmode ? (ia.y & 0xffff) : (ia.y & 0x3fff)) - 1, a1 = (colmode ? ((ia.y >> 16) & 0xffff) : ((ia.y >> 14) & 0x3fff)) - 1;
+        // skip22: the ring x ring block (the sum of the children's Schur complements, most of a front below the tree top) is not
+        // materialised -- the Schur-complement product gathers it itself (k_zgemm2<.., 4, ..>) and writes S where F22 would have been
+        const int cend = (skip22 && r >= n.smax) ? n.smax : nmax;
+        for (int c = tx; c < cend; c += 64) {
+            const int2 ib = finfo[c];
+            cplx v = cmake(0.0, 0.0);
+            if (ia.x < 0 || ib.x < 0) { if (r == c && r < n.smax) v = cmake(1.0, 0.0); }
+            else {
+                if (r < n.smax || c < n.smax) {              // ring x ring entries belong to an ancestor
+                    const int zb = colmode ? (ib.x & 0xfff) : (ib.x & 0xffff), xb = colmode ? ((ib.x >> 12) & 0xfff) : (ib.x >> 16);
+                    const int dz = zb - za, dx = xb - xa;
+                    if (dz >= -1 && dz <= 1 && dx >= -1 && dx <= 1) {
+                        if (colmode) {
+                            const int dc = ((ib.x >> 24) & 0x7f) - ca;
+                            if (dc >= -1 && dc <= 1) v = planes[((long long)(dc + 1) * 9 + (dz + 1) * 3 + dx + 1) * N * n.dof + (long long)ca * N + (long long)za * nx + xa];
+                        } else {
+                            const int blk = n.dof == 2 ? 2 * ca + ((ib.y >> 28) & 1) : 0;
+                            v = planes[((long long)blk * 9 + (dz + 1) * 3 + dx + 1) * N + (long long)za * nx + xa];
+                        }
+                    }
+                }
+                const int b0 = (colmode ? (ib.y & 0xffff) : (ib.y & 0x3fff)) - 1, b1 = (colmode ? ((ib.y >> 16) & 0xffff) : ((ib.y >> 14) & 0x3fff)) - 1;
+                if (a0 >= 0 && b0 >= 0) v = cadd(v, S0[(long long)a0 * ld0 + b0]);
+                if (a1 >= 0 && b1 >= 0) v = cadd(v, S1[(long long)a1 * ld1 + b1]);
+            }
+            *front_entry(n, arenaF, fac, r, c) = v;
+        }
+    }
+}
+
+// ---- ill-conditioned fronts (NdStable) -------------------------------------------------------------------------------------------------
+// infinity norm (largest absolute row sum, |z| taken as |re| + |im|) of the s x s pivot block of every front of a group -- before the
+// inversion: F11, after it: F11^-1; their product is the condition estimate.  (The max-entry norm was tried first: for a near-singular
+// front F11^-1 ~ u v^T / sigma with u, v spread over all unknowns, and max |entry| then underestimates the norm by the front's size --
+// the worst front of the 8-Hz bench operator, cond 1.1e6, came out as 2.5e4 and stayed below the threshold.)
+// (over the front's own s x s unknowns: the identity that pads a smaller front to the group's size is not part of its conditioning)
+__global__ __launch_bounds__(256) void k_front_absmax(const cplx *M0, int ld, long long stride, const NdDev *nodes, double *out) {
+    __shared__ double red[4];
+    const cplx *M = M0 + (long long)blockIdx.x * stride;
+    const int n = nodes[blockIdx.x].s;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double best = 0.0;
+    for (int i = wv; i < n; i += 4) {                      // a wave per row: coalesced along the row
+        double v = 0.0;
+        for (int j = lane; j < n; j += 64) { const cplx a = M[(long long)i * ld + j]; v += fabs(a.x) + fabs(a.y); }
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        v = __shfl(v, 0);
+        best = fmax(best, v);
+    }
+    if (lane == 0) red[wv] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+// list[0] = number of fronts with  scale * a[j] * b[j] > thr  (capped), list[1..] = their positions in the group, worst first is not needed
+__global__ void k_front_flag(const double *a, const double *b, int cnt, double scale, double thr, int *list, int cap) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += gridDim.x * blockDim.x)
+        if (!(scale * a[j] * b[j] <= thr)) {                                                               // (NaN counts as flagged)
+            const int slot = atomicAdd(list, 1);
+            if (slot < cap) list[1 + slot] = j;
+        }
+}
+// the same for n <= 64 with the matrix held in LDS (every elimination step is then a few hundred nanoseconds instead of several global round trips)
+__global__ __launch_bounds__(256) void k_lu_factor64(cplx *A0, int ld, int n, int *piv) {
+    __shared__ cplx A[64][65];
+    __shared__ double rv[256];
+    __shared__ int ri[256];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < n * n; e += 256) A[e / n][e % n] = A0[(long long)(e / n) * ld + e % n];
+    __syncthreads();
+    for (int k = 0; k < n; ++k) {
+        double best = -1.0; int bi = k;
+        for (int i = k + tid; i < n; i += 256) { const double v = cabs2(A[i][k]); if (v > best) { best = v; bi = i; } }
+        rv[tid] = best; ri[tid] = bi;
+        __syncthreads();
+        for (int off = 32; off > 0; off >>= 1) {          // (at most 64 candidates: the first wave's entries)
+            if (tid < off && (rv[tid + off] > rv[tid] || (rv[tid + off] == rv[tid] && ri[tid + off] < ri[tid]))) { rv[tid] = rv[tid + off]; ri[tid] = ri[tid + off]; }
+            __syncthreads();
+        }
+        const int p = ri[0];
+        if (tid == 0) piv[k] = p;
+        if (p != k && tid < n) { const cplx t = A[k][tid]; A[k][tid] = A[p][tid]; A[p][tid] = t; }
+        __syncthreads();
+        const cplx d = crecip(A[k][k]);
+        if (tid > k && tid < n) A[tid][k] = cmul(A[tid][k], d);
+        __syncthreads();
+        const int w = n - k - 1;
+        for (int e = tid; e < w * w; e += 256) {
+            const int i = k + 1 + e / w, j = k + 1 + e % w;
+            const cplx l = A[i][k], u = A[k][j];
+            cplx a = A[i][j];
+            a.x = fma(-l.x, u.x, a.x); a.x = fma(l.y, u.y, a.x);
+            a.y = fma(-l.x, u.y, a.y); a.y = fma(-l.y, u.x, a.y);
+            A[i][j] = a;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < n * n; e += 256) A0[(long long)(e / n) * ld + e % n] = A[e / n][e % n];
+}
+// LU with partial pivoting of one n x n matrix in global memory (one workgroup; the matrix is small and lives in L2)
+__global__ __launch_bounds__(256) void k_lu_factor(cplx *A, int ld, int n, int *piv) {
+    __shared__ double rv[256];
+    __shared__ int ri[256];
+    __shared__ int psh;
+    const int tid = threadIdx.x;
+    for (int k = 0; k < n; ++k) {
+        double best = -1.0; int bi = k;
+        for (int i = k + tid; i < n; i += 256) { const double v = cabs2(A[(long long)i * ld + k]); if (v > best) { best = v; bi = i; } }
+        rv[tid] = best; ri[tid] = bi;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off && (rv[tid + off] > rv[tid] || (rv[tid + off] == rv[tid] && ri[tid + off] < ri[tid]))) { rv[tid] = rv[tid + off]; ri[tid] = ri[tid + off]; }
+            __syncthreads();
+        }
+        if (tid == 0) { psh = ri[0]; piv[k] = ri[0]; }
+        __syncthreads();
+        const int p = psh;
+        if (p != k) for (int j = tid; j < n; j += 256) { const cplx t = A[(long long)k * ld + j]; A[(long long)k * ld + j] = A[(long long)p * ld + j]; A[(long long)p * ld + j] = t; }
+        __syncthreads();
+        const cplx d = crecip(A[(long long)k * ld + k]);
+        for (int i = k + 1 + tid; i < n; i += 256) A[(long long)i * ld + k] = cmul(A[(long long)i * ld + k], d);
+        __syncthreads();
+        const int w = n - k - 1;
+        for (int e = tid; e < w * w; e += 256) {
+            const int i = k + 1 + e / w, j = k + 1 + e % w;
+            const cplx l = A[(long long)i * ld + k], u = A[(long long)k * ld + j];
+            cplx a = A[(long long)i * ld + j];
+            a.x = fma(-l.x, u.x, a.x); a.x = fma(l.y, u.y, a.x);
+            a.y = fma(-l.x, u.y, a.y); a.y = fma(-l.y, u.x, a.y);
+            A[(long long)i * ld + j] = a;
+        }
+        __syncthreads();
+    }
+}
+// B <- (L U)^-1 P B in place (B row-major, leading dimension ldb; n <= 128).  A workgroup takes 16 columns into LDS; a wave owns four of
+// them, 16 lanes per column: a row's dot product against the rows already solved is split over the 16 lanes (k = p, p + 16, ...) and summed
+// with four shuffles.  Everything a wave touches in LDS is its own four columns, so there is no barrier inside the substitutions (LDS
+// operations of a wave execute in order); the factor's row i + 1 is in flight from L2 while row i is being reduced.
+__global__ __launch_bounds__(256) void k_lu_solve(const cplx *__restrict__ LU, int ld, int n, const int *__restrict__ piv, cplx *B, int ldb, int ncols) {
+    __shared__ cplx Bt[LUS_NMAX][16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int cl = wv * 4 + (lane >> 4), p = lane & 15;          // local column 0..15, part 0..15
+    const int j0 = blockIdx.x * 16;
+    for (int e = tid; e < n * 16; e += 256) { const int i = e >> 4, c = e & 15; Bt[i][c] = j0 + c < ncols ? B[(long long)i * ldb + j0 + c] : cmake(0.0, 0.0); }
+    __syncthreads();
+    if (p == 0) for (int k = 0; k < n; ++k) { const int q = piv[k]; if (q != k) { const cplx t = Bt[k][cl]; Bt[k][cl] = Bt[q][cl]; Bt[q][cl] = t; } }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int NK = LUS_NMAX / 16;
+    cplx cur[NK], nxt[NK];
+    auto load_row = [&](cplx (&dst)[NK], int i, int klo, int khi) {        // entries k in [klo, khi), k = p + 16 q
+        #pragma unroll
+        for (int q = 0; q < NK; ++q) { const int k = p + 16 * q; dst[q] = (i >= 0 && i < n && k >= klo && k < khi) ? LU[(long long)i * ld + k] : cmake(0.0, 0.0); }
+    };
+    // L y = P b (unit lower triangle): rows top-down
+    load_row(cur, 1, 0, 1);
+    for (int i = 1; i < n; ++i) {
+        load_row(nxt, i + 1, 0, i + 1);
+        cplx acc = cmake(0.0, 0.0);
+        #pragma unroll
+        for (int q = 0; q < NK; ++q) { const int k = p + 16 * q; if (k < i) cfma(acc, cur[q], Bt[k][cl]); }
+        #pragma unroll
+        for (int off = 8; off > 0; off >>= 1) { acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off); }
+        if (p == 0) Bt[i][cl] = csub(Bt[i][cl], acc);
+        __builtin_amdgcn_wave_barrier();
+        #pragma unroll
+        for (int q = 0; q < NK; ++q) cur[q] = nxt[q];
+    }
+    // U x = y: rows bottom-up
+    load_row(cur, n - 1, n - 1, n);
+    for (int i = n - 1; i >= 0; --i) {
+        load_row(nxt, i - 1, i - 1, n);
+        cplx acc = cmake(0.0, 0.0), d = cmake(1.0, 0.0);
+        #pragma unroll
+        for (int q = 0; q < NK; ++q) { const int k = p + 16 * q; if (k > i && k < n) cfma(acc, cur[q], Bt[k][cl]); if (k == i) d = cur[q]; }
+        #pragma unroll
+        for (int off = 8; off > 0; off >>= 1) { acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off); }
+        // the diagonal entry sits with the lane whose k == i: hand it to lane 0 of the group
+        const int src = (lane & 48) | (i & 15);
+        const double dx = __shfl(d.x, src), dy = __shfl(d.y, src);
+        if (p == 0) Bt[i][cl] = cmul(csub(Bt[i][cl], acc), crecip(cmake(dx, dy)));
+        __builtin_amdgcn_wave_barrier();
+        #pragma unroll
+        for (int q = 0; q < NK; ++q) cur[q] = nxt[q];
+    }
+    __syncthreads();
+    for (int e = tid; e < n * 16; e += 256) { const int i = e >> 4, c = e & 15; if (j0 + c < ncols) B[(long long)i * ldb + j0 + c] = Bt[i][c]; }
+}
+
+}  // namespace
+
+void launch_lu_solve(hipStream_t st, const cplx *LU, int ld, int n, const int *piv, cplx *B, int ldb, int ncols) {
+    hipLaunchKernelGGL(k_lu_solve, dim3((ncols + 15) / 16), dim3(256), 0, st, LU, ld, n, piv, B, ldb, ncols);
+}
+
+// ---- factorisation ---------------------------------------------------------------------------------------------
+static void stable_free(NdFactor *f) {
+    const int dev = f->pd ? f->pd->device : 0;
+    for (NdStable &st : f->stable) {
+        const size_t nmax = (size_t)st.smax + st.mmax;
+        helm_pool_free(dev, st.lu, (size_t)st.smax * nmax * sizeof(cplx));
+        helm_pool_free(dev, st.f21, (size_t)std::max(1, st.mmax) * st.smax * sizeof(cplx));
+        helm_pool_free(dev, st.piv, (size_t)st.smax * sizeof(int));
+        helm_pool_free(dev, st.d_node, sizeof(NdDev));
+        helm_pool_free(dev, st.vs, st.vs_elems * sizeof(cplx));
+    }
+    f->stable.clear();
+}
+
+void nd_free(NdFactor *f) {
+    if (!f) return;
+    stable_free(f);
+    if (f->d_est) helm_pool_free(f->pd ? f->pd->device : 0, f->d_est, f->est_elems * sizeof(double));
+    if (f->d_leafflag) helm_pool_free(f->pd ? f->pd->device : 0, f->d_leafflag, f->leafflag_elems * sizeof(int));
+    if (f->d_act) helm_pool_free(f->pd ? f->pd->device : 0, f->d_act, f->act_elems * sizeof(int));
+    if (f->d_qmask) helm_pool_free(f->pd ? f->pd->device : 0, f->d_qmask, f->qmask_elems);
+    if (f->d_fac) helm_pool_free(f->pd ? f->pd->device : 0, f->d_fac, (size_t)f->pd->plan.fac_elems * sizeof(cplx));
+    delete f;
+}
+
+// Fronts that keep G = -F11^-1 F12 where F12 was, so that their back substitution is ONE product [F11^-1 | G] [y_S; x_B]: the leaves.
+// (Round 4 measured the same for every separator front of at most 64 unknowns: the 64-row tile pads the 8-, 16- and 32-row fronts of levels
+// 13-10 eight-, four- and two-fold on the matrix cores, 5.5 -> 6.7 ms per pass; removed.)
+bool merged_group(const NdPlan &P, const NdGroup &g) { (void)P; return g.mmax > 0 && g.leaf; }
+
+namespace {
+
+// ---- ill-conditioned fronts: detection and re-elimination with a pivoted LU (see NdStable in direct.hpp) -------------------------------------
+// ON by default (HELM_ND_STABLE=0 switches it off).  Measured on the 16-frequency bench job (MI355X, round 3): every wavefield meets rtol
+// 1e-10 in ONE pass (passes per wavefield 1.15 -> 1.00, worst first-pass residual 7e-9 -> 3e-11) and the job runs at 9180 against 8170
+// wavefields/s: detection costs 0.5-0.9 ms per factorisation (two norm kernels and one 4-byte read-back per watched tree level), a treated
+// front ~0.15 ms at factor time and per pass, 0-15 fronts per frequency are taken, and 5 of 16 frequencies save a refinement pass of 8-20 ms.
+// (A first version with one thread per column in the triangular solves and a threshold of 2e4 that also watched the leaves was correct but
+// slower than doing nothing: 7775 wavefields/s.)
+// A front is taken when its condition estimate ||F11||_inf ||F11^-1||_inf exceeds rtol / (8 eps) (see stabilise_group; 1.1e5 at rtol 1e-10: at
+// 1024^2 / 9 Hz a handful of 32 767 fronts, which between them are the difference between a first-pass residual of 4e-9 and 2e-12; a typical
+// leaf sits at 20-40, the tree top at 50-1000).
+// Fronts of more than HELM_ND_STABLE_SMAX (128) separator unknowns are left alone: the one-workgroup LU would cost more than the
+// refinement pass it saves, and none that large has been seen ill-conditioned (the tree top sits at cond 50-1000)
+bool stable_enabled(const NdPlan &P) {
+    // one unknown per cell only: the fix-ups of the passes gather a front's right-hand-side rows again, which the in-place passes of the
+    // coupled system's rhs-major path have overwritten by then
+    return helm_tuning_now().nd_stable != 0 && P.dof == 1;
+}
+int ensure_est(helm_op *op, NdFactor *f, int cnt) {
+    const size_t need = 2 * (size_t)cnt + (ND_STABLE_CAP + 2) / 2 + 8;         // two doubles per front + the flag list (ints) behind them
+    if (f->est_elems >= need) return HELM_OK;
+    if (f->d_est) { hipStreamSynchronize(op->stream); helm_pool_free(op->device, f->d_est, f->est_elems * sizeof(double)); f->d_est = nullptr; f->est_elems = 0; }
+    int maxcnt = cnt;
+    for (const NdGroup &g : f->pd->plan.groups) maxcnt = std::max(maxcnt, g.cnt);
+    const size_t elems = 2 * (size_t)maxcnt + (ND_STABLE_CAP + 2) / 2 + 8;
+    f->d_est = (double *)helm_pool_alloc(op->device, elems * sizeof(double));
+    if (!f->d_est) return HELM_ERR_DEVICE;
+    f->est_elems = elems;
+    return HELM_OK;
+}
+
+// after the batched elimination of group gi: find its ill-conditioned fronts (one small read-back per group) and eliminate each of them again
+int stabilise_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, const cplx *planes) {
+    const NdPlan &P = f->pd->plan;
+    const NdGroup &g = P.groups[gi];
+    hipStream_t st = op->stream;
+    // Which fronts are taken follows from the tolerance the factors are built for, not from a constant fitted to one model: an explicit inverse of a
+    // front with condition number kappa leaves a first-pass residual of about kappa * eps (measured front by front, DESIGN.md 5.1: 8.8e5 -> 4e-9),
+    // and it has to stay below rtol with a margin for the handful of such fronts that add up and for what the estimate ||F11||_inf ||F11^-1||_inf
+    // misses:   kappa_max = rtol / (HELM_ND_STABLE_SAFETY * eps),  safety 8 by default  ->  1.1e5 at the 1e-10 of the reference parity tests, 1.1e7
+    // at 1e-8, 1.1e3 at 1e-12 (where most fronts of the middle levels would be taken: the floor of 2e3 keeps the treatment a handful-of-fronts
+    // affair and leaves the rest to the refinement pass, which always exists).  HELM_ND_STABLE_THR overrides with a fixed number.
+    const helm_tuning tune = helm_tuning_now();
+    const double safety = tune.nd_stable_safety;
+    const double rt = op->rtol_hint > 0 ? op->rtol_hint : 1e-10;
+    const double thr = tune.nd_stable_thr > 0 ? tune.nd_stable_thr : std::min(1e9, std::max(2e3, rt / (safety * 1.1102230246251565e-16)));
+    const int nmax = g.smax + g.mmax;
+    int *d_list = (int *)(f->d_est + 2 * (size_t)g.cnt);
+    HIP_TRY(op, hipMemsetAsync(d_list, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_front_flag, dim3((g.cnt + 255) / 256), dim3(256), 0, st, (const double *)f->d_est, (const double *)(f->d_est + g.cnt), g.cnt, 1.0, thr, d_list, ND_STABLE_CAP);
+    int h_list[ND_STABLE_CAP + 1];
+    HIP_TRY(op, hipMemcpyAsync(h_list, d_list, sizeof(h_list), hipMemcpyDeviceToHost, st));
+    HIP_TRY(op, hipStreamSynchronize(st));
+    const int nflag = std::max(0, std::min(h_list[0], ND_STABLE_CAP));
+    std::sort(h_list + 1, h_list + 1 + nflag);                                   // (the atomics hand the slots out in no particular order)
+    if (getenv("HELM_ND_DEBUG") && atoi(getenv("HELM_ND_DEBUG")) >= 2) {
+        std::vector<double> h(2 * (size_t)g.cnt);
+        hipMemcpy(h.data(), f->d_est, h.size() * sizeof(double), hipMemcpyDeviceToHost);
+        double worst = 0; int wj = 0;
+        for (int j = 0; j < g.cnt; ++j) { const double e = h[j] * h[g.cnt + j]; if (!(e <= worst)) { worst = e; wj = j; } }
+        fprintf(stderr, "[helm direct] level %d s %d cnt %d: estimate of front 0 = %.3e * %.3e; worst %.3e at %d; flagged %d\n", g.level, g.smax, g.cnt, h[0], h[g.cnt], worst, wj, h_list[0]);
+    }
+    if ((long long)g.smax * g.mmax > P.work_elems) return HELM_OK;               // (no room for the s x m solve: leave the group as it is)
+    const cplx one = cmake(1, 0), mone = cmake(-1, 0);
+    for (int q = 0; q < nflag; ++q) {
+        const int j = h_list[1 + q];
+        NdStable S;
+        S.node = g.first + j; S.group = gi; S.smax = g.smax; S.mmax = g.mmax;
+        S.lu = (cplx *)helm_pool_alloc(op->device, (size_t)g.smax * nmax * sizeof(cplx));
+        S.f21 = (cplx *)helm_pool_alloc(op->device, (size_t)std::max(1, g.mmax) * g.smax * sizeof(cplx));
+        S.piv = (int *)helm_pool_alloc(op->device, (size_t)g.smax * sizeof(int));
+        S.d_node = (NdDev *)helm_pool_alloc(op->device, sizeof(NdDev));
+        f->stable.push_back(S);                                                   // (owned by the factor from here on: freed by nd_free on every path)
+        if (!S.lu || !S.f21 || !S.piv || !S.d_node) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: allocation for an ill-conditioned front failed");
+        NdDev n = P.nodes[S.node];
+        const long long foff = n.foff;
+        n.finv_off = 0; n.f12_off = g.smax;                                       // [F11 | F12] rows go to S.lu, [F21 | F22] back to the arena
+        HIP_TRY(op, hipMemcpyAsync(S.d_node, &n, sizeof(NdDev), hipMemcpyHostToDevice, st));
+        HIP_TRY(op, hipStreamSynchronize(st));                                    // (n is a stack copy)
+        const int rb = std::max(std::min(nmax, 4), (nmax + 2047) / 2048);
+        hipLaunchKernelGGL(k_nd_build_front, dim3((nmax + rb - 1) / rb, 1), dim3(256), (size_t)nmax * sizeof(int2), st, f->pd->d_nodes, 0, arenaF, S.lu, planes, P.nz, P.nx, rb,
+                           (const NdDev *)S.d_node);
+        cplx *F21 = arenaF + foff, *F22 = arenaF + foff + g.smax;
+        HIP_TRY(op, hipMemcpy2DAsync(S.f21, (size_t)g.smax * sizeof(cplx), F21, (size_t)nmax * sizeof(cplx), (size_t)g.smax * sizeof(cplx), (size_t)g.mmax, hipMemcpyDeviceToDevice, st));
+        if (g.smax <= 64) hipLaunchKernelGGL(k_lu_factor64, dim3(1), dim3(256), 0, st, S.lu, nmax, g.smax, S.piv);
+        else hipLaunchKernelGGL(k_lu_factor, dim3(1), dim3(256), 0, st, S.lu, nmax, g.smax, S.piv);
+        // Schur complement through the same factors: F22 -= F21 (F11^-1 F12)
+        HIP_TRY(op, hipMemcpy2DAsync(work, (size_t)g.mmax * sizeof(cplx), S.lu + g.smax, (size_t)nmax * sizeof(cplx), (size_t)g.mmax * sizeof(cplx), (size_t)g.smax, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_lu_solve, dim3((g.mmax + 15) / 16), dim3(256), 0, st, (const cplx *)S.lu, nmax, g.smax, (const int *)S.piv, work, g.mmax, g.mmax);
+        gemm(op, g.mmax, g.mmax, g.smax, mone, S.f21, g.smax, 0, work, g.mmax, 0, one, F22, nmax, 0, 1, nullptr);
+    }
+    const int dbg = getenv("HELM_ND_DEBUG") ? atoi(getenv("HELM_ND_DEBUG")) : 0;       // (read per call: a test switches it on)
+    if (dbg && nflag) fprintf(stderr, "[helm direct] level %d (%s, s = %d, m = %d): %d ill-conditioned front(s) re-eliminated with a pivoted LU\n", g.level, g.leaf ? "leaves" : "separators", g.smax, g.mmax, nflag);
+    return check_kernels(op, "re-elimination of ill-conditioned fronts");
+}
+
+}  // namespace
+
+// factorisation of one group (tree level x kind) on op->stream
+int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, const cplx *planes) {
+    const NdPlan &P = f->pd->plan;
+    const NdDev *d_nodes = f->pd->d_nodes;
+    hipStream_t st = op->stream;
+    const cplx one = cmake(1, 0), mone = cmake(-1, 0), zero = cmake(0, 0);
+    const NdGroup &g = P.groups[gi];
+    const int nmax = g.smax + g.mmax;
+    const long long fs = (long long)g.mmax * nmax;              // scratch per front: [F21 | F22]
+    const long long s11 = (long long)g.smax * g.smax, s12 = (long long)g.smax * g.mmax, s1 = (long long)g.smax * nmax;   // s1: stride of [F11 | F12]
+    cplx *F = arenaF + g.foff;
+    cplx *Finv = f->d_fac + g.finv, *G21 = f->d_fac + g.g21, *F12 = f->d_fac + g.f12;
+    // leaves of one unknown per cell and at most 8 x 8 cells: the whole leaf level in one kernel (k_leaf_factor; HELM_ND_FUSEDLEAF=0: the batched path)
+    const helm_tuning tune = helm_tuning_now();
+    const int fused_leaf = tune.nd_fused_leaf;
+    // (a leaf takes ~0.3 ms from end to end in that kernel -- a chain of 49 elimination steps, then 2 x 49 substitution rows -- which thousands of
+    // leaves in flight hide and a few hundred do not: the handful of larger leaves of a level stay on the batched path, HELM_ND_FUSEDLEAF_MIN)
+    const int fused_leaf_min = tune.nd_fused_leaf_min;
+    if (fused_leaf && g.leaf && g.cnt >= fused_leaf_min && P.dof == 1 && P.leaf <= 8 && g.smax <= 64 && g.mmax > 0 && g.mmax <= LEAF_MP) {
+        if (f->leafflag_elems < (size_t)g.cnt) {
+            if (f->d_leafflag) { hipStreamSynchronize(st); helm_pool_free(op->device, f->d_leafflag, f->leafflag_elems * sizeof(int)); f->d_leafflag = nullptr; f->leafflag_elems = 0; }
+            int maxcnt = g.cnt;
+            for (const NdGroup &q : P.groups) if (q.leaf) maxcnt = std::max(maxcnt, q.cnt);
+            f->d_leafflag = (int *)helm_pool_alloc(op->device, (size_t)maxcnt * sizeof(int));
+            if (!f->d_leafflag) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: allocation of the leaf flags failed");
+            f->leafflag_elems = (size_t)maxcnt;
+        }
+        const int leaf_dbg = getenv("HELM_LEAF_DBG") ? atoi(getenv("HELM_LEAF_DBG")) : 0;       // (timing experiments: 1 no LU, 2 no substitution, 4 no G21 / S; test: 8 every leaf re-done by the pivoted kernel)
+        for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
+            const int nb = std::min(65535, g.cnt - j0);
+            cplx *g21b = G21 + (long long)j0 * g.mmax * g.smax;
+            launch_leaf_factor(st, g.smax, nb, d_nodes, g.first + j0, arenaF, f->d_fac, g21b, planes, P.nz, P.nx, f->d_leafflag + j0, leaf_dbg);
+        }
+        f->flops += (double)g.cnt * 8.0 * (2.0 * LEAF_BW * g.smax * (g.smax + g.mmax) + 3.0 * g.mmax * (g.smax + g.mmax));
+        return HELM_OK;
+    }
+    // the ring x ring block of a non-leaf front stays unbuilt: its Schur-complement product gathers the children's contributions itself
+    bool schur_gather = false;
+    const bool packs = P.dof <= 2 ? (nmax < (1 << 14) && P.nz < 65536 && P.nx < 32768) : (nmax < 65535 && P.nz < 4096 && P.nx < 4096 && P.dof < 128);
+    if ((size_t)nmax * sizeof(int2) <= 64 * 1024 && packs)
+        schur_gather = !g.leaf && g.mmax > 0 && P.dof == 1;
+    if ((size_t)nmax * sizeof(int2) <= 64 * 1024 && packs) {      // (its row table must fit the 64 KB of LDS a launch gets by default: larger fronts take the unfused path)
+        // rows per workgroup: whole fronts while there are thousands of them, a few rows each for the handful of big ones at the top
+        const int want = std::max(1, 2048 / g.cnt);
+        const int rb = std::max(std::min(nmax, 4), (nmax + want - 1) / want);
+        for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
+            const int nb = std::min(65535, g.cnt - j0);
+            hipLaunchKernelGGL(k_nd_build_front, dim3((nmax + rb - 1) / rb, nb), dim3(256), (size_t)nmax * sizeof(int2), st, d_nodes, g.first + j0, arenaF, f->d_fac, planes,
+                               P.nz, P.nx, rb, (const NdDev *)nullptr, schur_gather ? 1 : 0);
+        }
+    } else {
+        if (fs > 0) HIP_TRY(op, hipMemsetAsync(F, 0, (size_t)g.cnt * fs * sizeof(cplx), st));
+        HIP_TRY(op, hipMemsetAsync(Finv, 0, (size_t)g.cnt * s1 * sizeof(cplx), st));
+        for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
+            const int nb = std::min(65535, g.cnt - j0);
+            hipLaunchKernelGGL(k_nd_assemble, dim3((nmax + 255) / 256, nb), dim3(256), 0, st, d_nodes, g.first + j0, arenaF, f->d_fac, planes, P.nz, P.nx);
+        }
+        if (!g.leaf) {
+            // children's ring sizes are bounded by this group's front size
+            const size_t shm = (size_t)(2 * nmax + 8) * sizeof(int);
+            for (int slot = 0; slot < 2; ++slot)
+                for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
+                    const int nb = std::min(65535, g.cnt - j0);
+                    // a chunk is at least 16 entries per map entry the block has to build, and enough chunks to fill the chip
+                    const long long total = (long long)nmax * nmax;
+                    const int chunk = (int)std::max<long long>(4096, std::min<long long>(total, std::max<long long>(16LL * nmax, total / std::max(1, 2048 / nb))));
+                    const int gx = (int)std::max<long long>(1, std::min<long long>((total + chunk - 1) / chunk, 65535));
+                    hipLaunchKernelGGL(k_nd_extend_add, dim3(gx, nb), dim3(256), shm, st, d_nodes, g.first + j0, slot, arenaF, f->d_fac, P.nz, P.nx, chunk);
+                }
+        }
+    }
+    // (wider pivot windows -- 64-wide base blocks for the leaves, the upper levels or the tree top -- were measured in round 2 and do not move the
+    // first-pass residual: it is not a pivoting artefact but near-resonant subdomains, which the NdStable treatment below handles)
+    const int stable_smax = 128;      // larger fronts are left alone: the one-workgroup LU would cost more than the refinement pass it saves, none that large has been seen ill-conditioned
+    // (leaves are not watched: 20-40 typically, below 6e3 in every operator examined, and their level is the one where two more passes over
+    // every front cost something)
+    const bool watch = stable_enabled(P) && !g.leaf && g.mmax > 0 && g.smax <= std::min(stable_smax, LUS_NMAX) && ensure_est(op, f, g.cnt) == HELM_OK;
+    if (watch) for (int j0 = 0; j0 < g.cnt; j0 += 65535)
+        hipLaunchKernelGGL(k_front_absmax, dim3(std::min(65535, g.cnt - j0)), dim3(256), 0, st, Finv + (long long)j0 * s1, nmax, s1, d_nodes + g.first + j0, f->d_est + j0);
+    invert(op, Finv, nmax, s1, g.smax, g.cnt, work, s11, P.dof, 0);      // F11 -> F11^-1 where it stays
+    if (watch) for (int j0 = 0; j0 < g.cnt; j0 += 65535)
+        hipLaunchKernelGGL(k_front_absmax, dim3(std::min(65535, g.cnt - j0)), dim3(256), 0, st, Finv + (long long)j0 * s1, nmax, s1, d_nodes + g.first + j0, f->d_est + g.cnt + j0);
+    if (g.mmax > 0) {
+        // G21 = F21 F11^-1 ; F22 -= G21 F12
+        gemm(op, g.mmax, g.smax, g.smax, one, F, nmax, fs, Finv, nmax, s1, zero, G21, g.smax, (long long)g.mmax * g.smax, g.cnt);
+        if (schur_gather) {
+            GemmRows R; R.schur4 = 1; R.nodes = d_nodes; R.first = g.first; R.arenaS = arenaF; R.tabCi = f->pd->d_tab + g.roff; R.tab_stride = nmax;
+            gemm(op, g.mmax, g.mmax, g.smax, mone, G21, g.smax, (long long)g.mmax * g.smax, F12, nmax, s1, zero, F + g.smax, nmax, fs, g.cnt, &R);
+        } else
+        gemm(op, g.mmax, g.mmax, g.smax, mone, G21, g.smax, (long long)g.mmax * g.smax, F12, nmax, s1, one, F + g.smax, nmax, fs, g.cnt);
+        if (merged_group(P, g)) {
+            // leaves (and small separator fronts): F12 <- -F11^-1 F12, in place where a front is one 64-row tile (GemmRows::tm64), else through the inversion workspace
+            if (g.smax <= 64) {
+                GemmRows R; R.dense = 1; R.tm64 = 1;
+                gemm(op, g.smax, g.mmax, g.smax, mone, Finv, nmax, s1, F12, nmax, s1, zero, F12, nmax, s1, g.cnt, &R);
+            } else {
+                gemm(op, g.smax, g.mmax, g.smax, mone, Finv, nmax, s1, F12, nmax, s1, zero, work, g.mmax, s12, g.cnt);
+                HIP_TRY(op, hipMemcpy2DAsync(F12, (size_t)nmax * sizeof(cplx), work, (size_t)g.mmax * sizeof(cplx), (size_t)g.mmax * sizeof(cplx),
+                                             (size_t)g.cnt * g.smax, hipMemcpyDeviceToDevice, st));
+            }
+        }
+    }
+    f->flops += (double)g.cnt * 8.0 * (2.0 * g.smax * g.smax * g.smax + (double)g.smax * g.smax * g.mmax + (double)g.smax * g.mmax * g.mmax);
+    if (watch) return stabilise_group(op, f, gi, arenaF, work, planes);
+    return HELM_OK;
+}
+
+int factor_prologue(helm_op *op, int block, NdFactor *f, const cplx *planes_in, const cplx **planes) {
+    const NdPlan &P = f->pd->plan;
+    if (!f->d_fac) {
+        f->d_fac = (cplx *)helm_pool_alloc(op->device, (size_t)P.fac_elems * sizeof(cplx));
+        if (!f->d_fac) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: cannot allocate %.1f GB for the factors", P.fac_elems * 16e-9);
+    }
+    *planes = planes_in ? planes_in : (P.dof == 2 ? op->d_C : op->d_C + (long long)block * op->nplanes * op->N);
+    f->block = block; f->flops = 0;
+    return HELM_OK;
+}
+
+long long nd_factor_ws_elems(const NdPlan &P) { return 2 * P.fregion + P.work_elems; }
+
+// ws: nd_factor_ws_elems(plan) elements of scratch (fronts of two adjacent levels + inversion workspace)
+int nd_factor(helm_op *op, int block, NdFactor *f, cplx *ws, const cplx *planes_in) {
+    const NdPlan &P = f->pd->plan;
+    const cplx *planes = nullptr;
+    int rc = factor_prologue(op, block, f, planes_in, &planes);
+    if (rc) return rc;
+    GroupTrace tr(op->stream, "factor");
+    for (size_t gi = 0; gi < P.groups.size(); ++gi) {
+        rc = factor_group(op, f, gi, ws, ws + 2 * P.fregion, planes);
+        if (rc) return rc;
+        tr.mark();
+    }
+    tr.report(P, false);
+    HIP_TRY(op, hipStreamSynchronize(op->stream));
+    return check_kernels(op, "factorisation kernels");
+}
+
+// Launches of the factorisation on op->stream without waiting for them (helm_prefactor): the caller orders later work behind an event
+int nd_factor_enqueue(helm_op *op, int block, NdFactor *f, cplx *ws, const cplx *planes_in) {
+    const NdPlan &P = f->pd->plan;
+    const cplx *planes = nullptr;
+    int rc = factor_prologue(op, block, f, planes_in, &planes);
+    if (rc) return rc;
+    for (size_t gi = 0; gi < P.groups.size(); ++gi) {
+        rc = factor_group(op, f, gi, ws, ws + 2 * P.fregion, planes);
+        if (rc) return rc;
+    }
+    return check_kernels(op, "factorisation kernels");
+}

@@ -158,8 +158,11 @@ class BaseMPDist(BaseDist):
         subs = self.subProblems
         if not self.parallel:
             return (self._scaled(sub * get(i)) for i, sub in enumerate(subs))
-        # a previous call whose results were not drained must not keep driving the same operator handles (they are not thread-safe)
+        # a previous call whose results were not drained must not keep driving the same operator handles (they are not thread-safe): its workers
+        # are stopped, and if it has not started any yet its generation token is stale from here on -- its first next() raises instead of
+        # starting a second set of pipelines on the handles this call owns
         self._stop_workers()
+        gen = self.__dict__['_generation'] = self.__dict__.get('_generation', 0) + 1
         # every right-hand side is taken now, in order, like the reference's apply_async loop (distributors.py:161-166)
         devs = self.devices
         nd = len(devs)
@@ -202,6 +205,9 @@ class BaseMPDist(BaseDist):
         strict = any(getattr(s_, 'heavyPrepare', False) for s_ in subs[:1])      # (3-D operators build their preconditioner in the prepare step: strictly one item ahead of the solve)
 
         def start():
+            if self.__dict__.get('_generation') != gen:
+                raise RuntimeError('this result was superseded by a later `wrapper * rhs` on the same wrapper before it was iterated: '
+                                   'drain (or drop) one product before forming the next -- the operator handles serve one call at a time')
             # what `wpd` concurrent solves on a GPU take from the library's pools is brought into being before the workers start: a
             # hipMalloc issued beside running kernels and copies can take a second (helm_reserve)
             booked = {}

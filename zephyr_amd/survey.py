@@ -26,9 +26,28 @@ class HelmBaseSurvey(BaseSCCache):
         self.prob = None
 
     # ---- geometry ------------------------------------------------------------------------------
-    @property
-    def nfreq(self):
-        return len(self.freqs)
+    # What the reference spells out as one property per key (survey.py:52-107) is a table here: attribute -> (key of `geom`, default when the
+    # key is absent).  Defaults that depend on the survey are callables of it.
+    _GEOM_FIELDS = {
+        'mode':    ('mode',   'fixed'),
+        'sLocs':   ('src',    None),
+        'rLocs':   ('rec',    None),
+        'ssTerms': ('sterms', lambda sv: np.ones((sv.nsrc,), dtype=np.complex128)),
+        'srTerms': ('rterms', lambda sv: np.ones((sv.nrec,), dtype=np.complex128)),
+    }
+
+    def __getattr__(self, name):
+        # (only reached for names that are not instance / class attributes)
+        fields = type(self)._GEOM_FIELDS
+        if name in fields:
+            key, default = fields[name]
+            geom = self.__dict__.get('_geom')
+            if geom is None:
+                raise AttributeError(name)
+            if key in geom:
+                return geom[key]
+            return default(self) if callable(default) else default
+        raise AttributeError('%s has no attribute %r' % (type(self).__name__, name))
 
     @property
     def geom(self):
@@ -41,63 +60,49 @@ class HelmBaseSurvey(BaseSCCache):
         self._geom = value
 
     @property
-    def mode(self):
-        return self.geom.get('mode', 'fixed')
-
-    @property
-    def sLocs(self):
-        return self.geom.get('src')
-
-    @property
-    def rLocs(self):
-        return self.geom.get('rec')
-
-    @property
-    def ssTerms(self):
-        return self.geom.get('sterms', np.ones((self.nsrc,), dtype=np.complex128))
-
-    @property
-    def srTerms(self):
-        return self.geom.get('rterms', np.ones((self.nrec,), dtype=np.complex128))
+    def nfreq(self):
+        return len(self.freqs)
 
     @property
     def tsTerms(self):
-        return getattr(self, '_sterms', np.ones(self.nfreq, dtype=np.complex128))
+        return self.__dict__.get('_sterms', np.ones(self.nfreq, dtype=np.complex128))
 
-    @property
-    def nsrc(self):
-        return 0 if self.sLocs is None else self.sLocs.shape[0]
+    @staticmethod
+    def _rows(locs):
+        return 0 if locs is None else locs.shape[0]
 
-    @property
-    def nrec(self):
-        return 0 if self.rLocs is None else self.rLocs.shape[0]
-
-    @property
-    def nD(self):
-        return self.nsrc * self.nrec * self.nfreq
+    nsrc = property(lambda self: self._rows(self.sLocs))
+    nrec = property(lambda self: self._rows(self.rLocs))
+    nD = property(lambda self: self.nsrc * self.nrec * self.nfreq)
 
     @property
     def RHSGenerator(self):
-        if not hasattr(self, '_RHSGenerator'):
-            self._RHSGenerator = self.geom.get('GeneratorClass', SparseKaiserSource)
-        return self._RHSGenerator
+        gen = self.__dict__.get('_RHSGenerator')
+        if gen is None:
+            gen = self._RHSGenerator = self.geom.get('GeneratorClass', SparseKaiserSource)
+        return gen
 
     # ---- source / receiver vectors (survey.py:109-128) ------------------------------------------------
+    def _weightedColumns(self, locs, terms):
+        'one column per location from the survey\'s source generator, column j scaled by terms[j]'
+        return self.RHSGenerator(self.systemConfig)(locs) * sp.diags((terms,), (0,))
+
     def sVecs(self):
-        if not hasattr(self, '_sVecs'):
-            self._sVecs = self.RHSGenerator(self.systemConfig)(self.sLocs) * sp.diags((self.ssTerms,), (0,))
-        return self._sVecs
+        'source matrix S diag(ssTerms), (N, nsrc); made once'
+        cache = self.__dict__.setdefault('_vecCache', {})
+        if 'S' not in cache:
+            cache['S'] = self._weightedColumns(self.sLocs, self.ssTerms)
+        return cache['S']
 
     def rVec(self, isrc):
-        if self.mode == 'fixed':
-            if not hasattr(self, '_rVecs'):
-                self._rVecs = (self.RHSGenerator(self.systemConfig)(self.rLocs) * sp.diags((self.srTerms,), (0,))).T
-            return self._rVecs
-        if not hasattr(self, '_rVecs'):
-            self._rVecs = {}
-        if isrc not in self._rVecs:
-            self._rVecs[isrc] = (self.RHSGenerator(self.systemConfig)(self.rLocs + self.sLocs[isrc]) * sp.diags((self.srTerms,), (0,))).T
-        return self._rVecs[isrc]
+        'receiver sampling matrix of source isrc, (nrec, N): one for all sources with a fixed array, one per source when the array moves with it'
+        cache = self.__dict__.setdefault('_vecCache', {})
+        moving = self.mode != 'fixed'
+        key = ('R', isrc) if moving else 'R'
+        if key not in cache:
+            where = self.rLocs + self.sLocs[isrc] if moving else self.rLocs
+            cache[key] = self._weightedColumns(where, self.srTerms).T
+        return cache[key]
 
     def rVecs(self, ifreq):
         return (self.rVec(i) for i in range(self.nsrc))
