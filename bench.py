@@ -294,6 +294,159 @@ def config5_leg(local, rtol=1e-8, nsrc=16, freqs=(2., 3., 4., 5.), grid=(128, 25
     return out
 
 
+def config2_leg(local, rtol=1e-10, method='auto'):
+    """BASELINE configs[1]: Eurus isotropic 512 x 512 synthetic Marmousi slice (dx = dz = 10 m), 8 frequencies linspace(3, 10, 8) Hz x 64
+    Kaiser-windowed sources at z = 20 m, fp64, one GPU.  Three figures: the job with right-hand sides and wavefields resident in HBM through the device pipeline
+    (the headline's call shape at config 2's sizes), the same job through the reference's call shape `MultiFreq(cfg) * q` (scipy-sparse in, numpy out over PCIe),
+    and the products' roofline fraction in a serial pass with nothing skipped."""
+    import torch
+    from zephyr_amd import Eurus, MultiFreq, SparseKaiserSource, dispatch, _lib
+    _lib.load().helm_trim()
+    n, dx, nf, ns = 512, 10.0, 8, 64
+    cfg = build_config(n, dx)
+    freqs = np.linspace(3.0, 10.0, nf)
+    locs = np.stack([np.linspace(200.0, 4920.0, ns), np.full(ns, 20.0)], axis=1)
+    qs = SparseKaiserSource(cfg)(locs)
+    N = n * n
+    dev = torch.device('cuda', local)
+    d_rhs = torch.from_numpy(np.ascontiguousarray(qs.toarray())).to(dev)
+    d_u = torch.empty((N, ns), dtype=torch.complex128, device=dev)
+
+    def prep(f, profile):
+        op = Eurus(dict(cfg, freq=float(f), rtol=rtol, maxit=400000, method=method, batch=ns, device=local))
+        op.setProfiling(profile)
+        if not profile:
+            op.prefactor()
+        return op
+
+    def solve(op):
+        info = op.solveDevice(d_rhs.data_ptr(), d_u.data_ptr(), ns, N, layout='node')
+        t = op.lastTiming()
+        del op.factors
+        return info, t
+
+    def job(profile=False):
+        items = [dispatch.WorkItem(solve, (lambda f=f: prep(f, profile))) for f in freqs]
+        if profile:
+            return [solve(prep(f, True)) for f in freqs]
+        return list(dispatch.pipelined(items, device=local, lookahead=1))
+    job()                                                     # untimed: pools, plan, pinned records
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 3
+    res = None
+    for _ in range(reps):
+        res = job()
+    torch.cuda.synchronize()
+    tj = (time.perf_counter() - t0) / reps
+    worst = max(i['relres'] for info, _ in res for i in info)
+    passes = max(i['iterations'] for info, _ in res for i in info)
+    os.environ['HELM_ND_SPARSE_RHS'] = '0'
+    try:
+        prof = job(profile=True)
+    finally:
+        os.environ.pop('HELM_ND_SPARSE_RHS', None)
+    gms = sum(t['gemm_ms'] for _, t in prof); gfl = sum(t['gemm_flops'] for _, t in prof)
+    out = {'workload': 'Eurus 2D isotropic 512x512 synthetic-Marmousi slice (dx=10 m), 8 freqs 3-10 Hz x 64 Kaiser sources at z=20 m, fp64, 1 GPU',
+           'wavefields': nf * ns, 'device_job_seconds': tj, 'device_wfs': nf * ns / tj, 'device_ms_per_item': 1e3 * tj / nf,
+           'worst_relres': worst, 'max_passes': passes,
+           'gemm_tflops_serial': gfl / (gms * 1e-3) / 1e12 if gms > 0 else None, 'gemm_frac_serial': gfl / (gms * 1e-3) / 1e12 / F64_PEAK_TFLOPS if gms > 0 else None}
+    del d_rhs, d_u
+    try:
+        sch = dict(cfg, freqs=[float(f) for f in freqs], Disc=Eurus, rtol=rtol, maxit=400000, method=method, batch=ns, device=local)
+        mfw = MultiFreq(dict(sch))
+        for u in mfw * qs:
+            del u
+        del mfw.factors
+        mf = MultiFreq(sch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        chk = 0.0
+        for u in mf * qs:
+            chk += float(abs(u[N // 2 + 7, 0]))
+            del u
+        th = time.perf_counter() - t0
+        del mf.factors
+        out['host_api_seconds'] = th
+        out['host_api_wfs'] = nf * ns / th
+    except Exception as exc:
+        out['host_api_wfs'] = None
+        out['host_api_error'] = str(exc)
+    return out
+
+
+def config4_leg(local, world, rank, dist, backend):
+    """BASELINE configs[3]: one FWI gradient on the 512 x 512 model -- `dpred` of the 25-point-smoothed "current" model, the residual against
+    the "true" model's data on 128 receivers at z = 20 m, `Jtvec` in the mux form (forward and back-propagated sources solved together, imaging condition on the
+    device: zephyr/middleware/problem.py:124-164).  8 frequencies x 64 sources.  Under N ranks the frequencies are sharded over the ranks (zephyr_amd.parallel)
+    and the gradient is summed with ONE all-reduce (problem.py:152,162); the seconds are the slowest rank's."""
+    import torch
+    import zephyr_amd as za
+    from zephyr_amd import parallel, _lib
+    from zephyr_amd.models import marmousi_like, box_smooth
+    from zephyr_amd.problem import Helm2DProblem
+    from zephyr_amd.survey import Helm2DSurvey
+    _lib.load().helm_trim()
+    n, dx, nf, ns, nr = 512, 10.0, 8, 64, 128
+    ctrue = marmousi_like(n, n, dx)
+    ccur = box_smooth(ctrue, 12)                              # 25-point box: 3-pt -> 25-pt smoothed "current" model
+    freqs = list(np.linspace(3.0, 10.0, nf))
+    src = np.stack([np.linspace(200.0, 4920.0, ns), np.full(ns, 20.0)], axis=1)
+    rec = np.stack([np.linspace(100.0, dx * n - 100.0, nr), np.full(nr, 20.0)], axis=1)
+    base = dict(nx=n, nz=n, dx=dx, dz=dx, freqs=freqs, Disc=za.Eurus, geom=dict(src=src, rec=rec, mode='fixed'), batch=ns, device=local)
+    dev = torch.device('cuda', local)
+
+    def pair(c):
+        sc = dict(base, c=c)
+        p, sv = Helm2DProblem(sc), Helm2DSurvey(sc)
+        p.pair(sv)
+        return p, sv
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    def slowest(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    ptrue, strue = pair(ctrue)
+    dobs = strue.dpred()                                       # (also the warm-up of the pools for the timed calls below)
+    del ptrue.factors
+    pcur, scur = pair(ccur)
+    sync(); t0 = time.perf_counter()
+    dcur = scur.dpred()
+    sync(); t_fwd = slowest(time.perf_counter() - t0)
+    resid = dcur - dobs
+    g0 = pcur.Jtvec(None, resid)                               # (first call: the 2 x 64-column buffers come into being)
+    sync(); t0 = time.perf_counter()
+    g = pcur.Jtvec(None, resid)
+    sync(); t_grad = slowest(time.perf_counter() - t0)
+    del pcur.factors
+    out = {'workload': 'FWI gradient step on 512x512 (true: synthetic Marmousi slice, current: its 25-pt box smooth), 8 freqs 3-10 Hz x 64 sources, 128 receivers at z=20 m; '
+                       'dpred + Jtvec (mux form, device imaging); frequencies sharded over %d rank(s), one all-reduce of the gradient' % world,
+           'dpred_seconds': t_fwd, 'jtvec_seconds': t_grad, 'wavefields_per_s_forward': nf * ns / t_fwd, 'wavefields_per_s_gradient': 2 * nf * ns / t_grad,
+           'gradient_norm': float(np.linalg.norm(g)), 'gradient_repeatable_rel': float(np.linalg.norm(g - g0) / max(np.linalg.norm(g), 1e-300)),
+           'residual_norm': float(np.linalg.norm(resid))}
+    # the collective on its own: N x 16 B complex128 at 512^2 and 1024^2, in place on the device (what _JtvecDevice issues once per gradient)
+    for side in (512, 1024):
+        key = 'gradient_allreduce_ms_%d' % side
+        if world == 1:
+            out[key] = 0.0
+            continue
+        G = torch.ones(side * side, dtype=torch.complex128, device=dev)
+        parallel.allreduce_sum_device(G); sync()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            parallel.allreduce_sum_device(G)
+        sync()
+        out[key] = slowest(1e3 * (time.perf_counter() - t0) / 5)
+    return out
+
+
 def spawn_ranks(ngpus, argv):
     """`python bench.py --gpus N` without a launcher: start N rank processes (one per GPU, RCCL rendezvous on 127.0.0.1) BEFORE
     anything in this process touches the GPU, relay rank 0's JSON line, fail if any rank fails.  (The driver's
@@ -346,6 +499,8 @@ def main():
                          "split over the ranks, frequency-major, one number for the whole job")
     ap.add_argument('--no-config5', action='store_true', help='skip the 3-D leg (BASELINE configs[4]: 256x256x128, 4 freqs x 16 sources; ~15 s)')
     ap.add_argument('--config5-rtol', type=float, default=1e-8)
+    ap.add_argument('--no-config2', action='store_true', help='skip the config-2 leg (512^2, 8 freqs x 64 sources; ~10 s)')
+    ap.add_argument('--no-config4', action='store_true', help='skip the config-4 leg (FWI gradient step at 512^2; ~15 s)')
     ap.add_argument('--streams', type=int, default=1, help='work items in flight per GPU (host threads, one operator handle / HIP stream each)')
     args = ap.parse_args()
 
@@ -424,7 +579,16 @@ def main():
         tl.append(('prepare done', w, time.perf_counter()))
         return op
 
+    nsolvers = max(1, int(os.environ.get('HELM_BENCH_SOLVERS', '1')))       # solve threads of the device pipeline (each writes its own wavefield array)
+    u_bufs = {}
+
     def solve_item(w, op, ubuf=None):
+        if ubuf is None and nsolvers > 1:
+            import threading
+            key = threading.get_ident()
+            if key not in u_bufs:
+                u_bufs[key] = d_u if not u_bufs else torch.empty_like(d_u)
+            ubuf = u_bufs[key]
         ubuf = d_u if ubuf is None else ubuf
         fi, bi = work_item(w, nb)
         tl.append(('solve starts', w, time.perf_counter()))
@@ -445,7 +609,8 @@ def main():
             return [run_item(w, profile) for w in ws]
         from zephyr_amd import dispatch
         items = [dispatch.WorkItem((lambda op, w=w: solve_item(w, op)), (lambda w=w: prepare_item(w, profile))) for w in ws]
-        return list(dispatch.pipelined(items, device=local, lookahead=int(os.environ.get('HELM_BENCH_LOOKAHEAD', '1')), strict=os.environ.get('HELM_BENCH_STRICT', '0') == '1'))
+        return list(dispatch.pipelined(items, device=local, lookahead=int(os.environ.get('HELM_BENCH_LOOKAHEAD', '1')), strict=os.environ.get('HELM_BENCH_STRICT', '0') == '1',
+                                       solvers=nsolvers))
 
     def barrier():
         torch.cuda.synchronize()
@@ -501,6 +666,7 @@ def main():
     agg = aggregate(results)
     barrier()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     item_done_ms = [round(1e3 * (x - t0), 2) for x in stamps]
     first_items = [(a, int(w_), round(1e3 * (t_ - t0), 2)) for a, w_, t_ in sorted(tl, key=lambda m: m[2])][:12]
 
@@ -574,6 +740,27 @@ def main():
                       'what': 'the whole 16-frequency job (every frequency x %d sources), its work items round-robin over the %d rank(s); max over ranks' % (B * nb, world)}
     wavefields = (NFREQ * nb * B) if args.scaling == 'strong' else world * args.steps * B
     value = wavefields / elapsed
+
+    # multi-GPU readiness, verifiable from the line of an N-rank run: how many ranks the collective library really joined (an all-reduce of ones),
+    # every rank's own seconds per step (the headline takes the slowest), and -- in config4_leg -- the gradient all-reduce on its own
+    ranks_seen, rank_ms = 1, [1e3 * elapsed_local / nsteps]
+    if world > 1:
+        one = torch.ones(1, dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        ranks_seen = int(round(float(one.item())))
+        mine = torch.tensor([1e3 * elapsed_local / nsteps], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [float(t.item()) for t in every]
+    # config 4 on every rank (its frequencies are sharded over the ranks and the gradient crosses the all-reduce)
+    c4 = None
+    if not args.no_config4 and args.method in ('auto', 'direct'):
+        try:
+            c4 = config4_leg(local, world, rank, dist, backend)
+        except Exception as exc:
+            if world > 1:
+                raise                     # (a rank that drops out of a collective leg must not leave the others waiting silently)
+            c4 = 'failed: %s' % exc
 
     out = None
     if rank == 0:
@@ -649,12 +836,10 @@ def main():
                                                       'stream, beside the previous item) is no longer inside it' if args.pipeline else 'serial: the factorisation is inside solve_call'}},
         }
         if direct:
-            gv = int(os.environ.get('HELM_ND_GEMMV', '7'))
-            out['roofline'] = {'bound': 'mfma' if gv == 7 else 'fp64-valu',
+            out['roofline'] = {'bound': 'mfma',
                                'kernel': ('k_zgemm3 (strided-batched complex128 GEMM of the multifrontal factorisation and triangular solves on the matrix cores: four real '
                                           'v_mfma_f64_16x16x4_f64 per complex 16x16x4 block; peak = the dense fp64 MFMA rate of MI355X, 78.6 TFLOP/s, which '
-                                          'tools/fp64_clock.hip reaches to 99 % from two waves per SIMD up)' if gv == 7 else
-                                          'k_zgemm2 (the same products with fp64 FMAs on the vector ALUs, HELM_ND_GEMMV=%d; that instruction mix saturates at 55 TFLOP/s)' % gv),
+                                          'tools/fp64_clock.hip reaches to 99 % from two waves per SIMD up)'),
                                'flops_formula': '8*M*N*K per batch item (4 real multiply-adds per complex one)', 'measured_on': where, 'traffic': None}
             out['roofline'].update(gemm_block(agg_k))
             if agg_k is not agg:
@@ -778,6 +963,15 @@ def main():
             except Exception as exc:
                 out['value_host_api'] = 'failed: %s' % exc
             d_u = torch.empty((N, B) if node else (B, N), dtype=torch.complex128, device=dev)
+        out['config4'] = c4
+        if world == 1 and not args.no_config2 and direct:
+            try:
+                del d_u
+                torch.cuda.empty_cache()
+                out['config2'] = config2_leg(local, rtol=args.rtol, method=args.method)
+            except Exception as exc:
+                out['config2'] = 'failed: %s' % exc
+            d_u = torch.empty((N, B) if node else (B, N), dtype=torch.complex128, device=dev)
         if world == 1 and not args.no_config5 and n == 1024:
             try:
                 del d_u
@@ -817,26 +1011,48 @@ def main():
                     out['cpu_baseline_pool'] = cpu_baseline_pool(cfg, freqs)
                 except Exception as exc:
                     out['cpu_baseline_pool'] = 'failed: %s' % exc
-        # the driver's record keeps `config` whole and only the NAMES of the other keys: the scalars a reader of BENCH_rNN.json needs go in there too
+        # The driver's record keeps the SCALAR entries of `config` (strings, numbers) and only the names of every other key: round 4's nested
+        # `driver_visible` dict, the grid list and the per-step dict were dropped.  So every figure a reader of BENCH_rNN.json / SCALE_rNN.json needs is a
+        # flat scalar key of `config` here; lists and dicts live at the top level of the line.
         try:
-            c5 = out.get('config5') if isinstance(out.get('config5'), dict) else None
-            vis = {'roofline_frac_serial': out['roofline'].get('frac'),
-                   'roofline_in_pipeline_frac': (out['roofline'].get('in_pipeline') or {}).get('frac'),
-                   'roofline_two_roofs_frac': (out['roofline'].get('two_roofs') or {}).get('frac'),
-                   'stencil_frac': (out.get('stencil_roofline') or out['roofline']).get('frac'),
-                   'unprofiled_value': (out.get('unprofiled') or {}).get('value'),
-                   'every_front_computed_value': (out.get('every_front_computed') or {}).get('value'),
-                   'support_declared_value': (out.get('support_declared') or {}).get('value'),
-                   'strong_job_value': (out.get('strong_scaling_job') or {}).get('value'), 'strong_job_seconds': (out.get('strong_scaling_job') or {}).get('seconds'),
-                   'value_host_api': out['value_host_api'].get('value') if isinstance(out.get('value_host_api'), dict) else None,
-                   'config5_job_seconds': c5.get('job_seconds') if c5 else None, 'config5_rtol': c5.get('rtol') if c5 else None,
-                   'config5_job_seconds_rtol1e10': c5.get('job_seconds_rtol1e10') if c5 else None,
-                   'config5_apply_frac_B16': next((a.get('frac_of_peak') for a in (c5.get('apply') or []) if a.get('B') == 16), None) if c5 else None,
-                   'parity_vs_lu_max_rel': out.get('parity_vs_lu_max_rel'),
-                   'cpu_baseline_value': out['cpu_baseline'].get('value') if isinstance(out.get('cpu_baseline'), dict) else None}
-            out['config']['driver_visible'] = {k: (float('%.5g' % v) if isinstance(v, float) else v) for k, v in vis.items()}
+            cfgd = out['config']
+            for k in ('grid', 'freqs_hz_this_run', 'device_ms_per_step'):
+                out['detail_' + k] = cfgd.pop(k, None)
+            dms = out.get('detail_device_ms_per_step') or {}
+            c2 = out.get('config2') if isinstance(out.get('config2'), dict) else {}
+            c4d = c4 if isinstance(c4, dict) else {}
+            c5 = out.get('config5') if isinstance(out.get('config5'), dict) else {}
+            rl = out['roofline']
+            flat = {
+                'grid_n': n, 'freqs_this_run': len(agg['freqs']),
+                'device_ms_solve_call': dms.get('solve_call'), 'device_ms_factorisation': dms.get('of_which_factorisation'),
+                'roofline_frac_serial': rl.get('frac'), 'in_pipeline_frac': (rl.get('in_pipeline') or {}).get('frac'),
+                'two_roofs_frac': (rl.get('two_roofs') or {}).get('frac'), 'gemm_avg_launch_us': rl.get('avg_launch_us'),
+                'stencil_frac': (out.get('stencil_roofline') or rl).get('frac'),
+                'unprofiled_wfs': (out.get('unprofiled') or {}).get('value'),
+                'dense_rhs_wfs': (out.get('every_front_computed') or {}).get('value'),
+                'support_declared_wfs': (out.get('support_declared') or {}).get('value'),
+                'strong_job_wfs': (out.get('strong_scaling_job') or {}).get('value'), 'strong_job_s': (out.get('strong_scaling_job') or {}).get('seconds'),
+                'host_api_wfs': out['value_host_api'].get('value') if isinstance(out.get('value_host_api'), dict) else None,
+                'c2_wfs_device': c2.get('device_wfs'), 'c2_ms_per_item': c2.get('device_ms_per_item'), 'c2_wfs_host_api': c2.get('host_api_wfs'),
+                'c2_gemm_frac': c2.get('gemm_frac_serial'), 'c2_worst_relres': c2.get('worst_relres'),
+                'c4_dpred_s': c4d.get('dpred_seconds'), 'c4_jtvec_s': c4d.get('jtvec_seconds'),
+                'c4_allreduce_ms_512': c4d.get('gradient_allreduce_ms_512'), 'c4_allreduce_ms_1024': c4d.get('gradient_allreduce_ms_1024'),
+                'gradient_allreduce_ms': c4d.get('gradient_allreduce_ms_512'),
+                'c5_job_s': c5.get('job_seconds'), 'c5_rtol': c5.get('rtol'), 'c5_job_s_rtol1e10': c5.get('job_seconds_rtol1e10'),
+                'c5_apply_frac_B16': next((a_.get('frac_of_peak') for a_ in (c5.get('apply') or []) if a_.get('B') == 16), None),
+                'c5_apply_us_B16': next((a_.get('us') for a_ in (c5.get('apply') or []) if a_.get('B') == 16), None),
+                'parity_vs_lu_max_rel': out.get('parity_vs_lu_max_rel'),
+                'cpu_baseline_wfs': out['cpu_baseline'].get('value') if isinstance(out.get('cpu_baseline'), dict) else None,
+                'rccl_ranks_seen': ranks_seen, 'collective_backend': backend if world > 1 else 'none',
+                'ms_per_step_slowest_rank': max(rank_ms), 'ms_per_step_fastest_rank': min(rank_ms),
+            }
+            for r_, ms_ in enumerate(rank_ms):
+                flat['ms_per_step_rank%d' % r_] = ms_
+            for k, v in flat.items():
+                cfgd[k] = float('%.6g' % v) if isinstance(v, float) else v
         except Exception as exc:
-            out['config']['driver_visible'] = 'failed: %s' % exc
+            out['config']['flat_keys_error'] = str(exc)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -11,6 +11,7 @@ A job is a plain dict (picklable):
                            'minizephyr'
     src                    (nsrc, 2) source locations (x, z); sources are SparseKaiserSource columns
     tti                    optional True: smooth tilted-transverse-isotropy fields (tti_fields) -> the coupled system, eps != delta
+    rhsfile                optional .npy with dense right-hand-side columns (N, k) that REPLACE the Kaiser sources of `src` (dense-rhs parity)
     ufile                  .npy with the GPU wavefields (N, ncols), or None
     rec                    optional (nrec, 2): also return the projected data R u_lu
     resid                  optional (nrec, nsrc): back-propagate it and return this frequency's gradient term
@@ -68,7 +69,7 @@ def lu_job(job):
     op.factor()
     t2 = time.perf_counter()
     S = SparseKaiserSource(cfg)
-    q = S(np.asarray(job['src']))
+    q = np.load(job['rhsfile']) if job.get('rhsfile') else S(np.asarray(job['src']))
     nsrc = q.shape[1]
     out = dict(freq=f)
     rhs = q

@@ -47,3 +47,14 @@ def test_bench_gpus_2_runs_two_ranks(helm_lib):
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['steps'] == 2 and rec['scaling'] == 'weak'
     assert rec['value'] > 0 and abs(rec['value'] - 2 * 2 * 256 / (rec['ms_per_step'] * 2e-3)) < 1e-6 * rec['value']
+    # what the next multi-GPU run of the driver can be checked against: flat scalars of `config` (the driver keeps those and nothing nested)
+    cfg = rec['config']
+    assert all(isinstance(v, (str, int, float, type(None))) for v in cfg.values()), [k for k, v in cfg.items() if isinstance(v, (list, dict))]
+    assert cfg['rccl_ranks_seen'] == 2 and cfg['collective_backend'] == 'gloo'
+    assert cfg['ms_per_step_rank0'] > 0 and cfg['ms_per_step_rank1'] > 0
+    assert abs(cfg['ms_per_step_slowest_rank'] - max(cfg['ms_per_step_rank0'], cfg['ms_per_step_rank1'])) < 1e-9
+    assert cfg['ms_per_step_slowest_rank'] <= rec['ms_per_step'] * 1.05          # the headline takes the slowest rank (+ the closing barrier)
+    # config 4 ran sharded over the two ranks: both legs timed, the gradient crossed a real two-rank all-reduce
+    assert cfg['c4_dpred_s'] > 0 and cfg['c4_jtvec_s'] > 0 and cfg['c4_allreduce_ms_512'] > 0 and cfg['c4_allreduce_ms_1024'] > 0
+    assert cfg['strong_job_wfs'] > 0
+    assert rec['config4']['gradient_repeatable_rel'] <= 1e-12

@@ -142,6 +142,97 @@ def test_config3_eurus_1024_two_pass_frequencies_match_sparse_lu(helm_lib, shm_d
     assert max(worst) <= 1e-7, worst
 
 
+def test_config3_all_16_frequencies_headline_path_matches_sparse_lu(helm_lib, shm_dir, monkeypatch):
+    """the whole config-3 job against SuperLU, through the HEADLINE path -- every one of the 16 frequencies solved as bench.py does it
+    (256 Kaiser sources, node-major device buffers: sparse-rhs skipping, 49 x 64 tile, fused leaf level, one-launch block steps, direct output) and 4 of
+    its 256 wavefields, one per block of 64 columns, compared with the LU of the reference-identical matrix (discretization.py:78-103).  In the same
+    sweep of 16 host processes: one DENSE random 256-column batch at 6.5 Hz (the path that skips nothing), and at 5.5 Hz the bit-for-bit check of the
+    skipping at full size (HELM_ND_SPARSE_RHS=1 against 0, arena poisoned)."""
+    import torch
+    import zephyr_amd as za
+    from zephyr_amd.models import marmousi_like
+    n, dx, nsrc = 1024, 9., 256
+    N = n * n
+    freqs = [float(f) for f in np.linspace(2.0, 9.5, 16)]
+    c = marmousi_like(n, n, dx).astype(np.complex128)
+    xs = np.linspace(0.04 * n * dx, 0.96 * n * dx, nsrc)
+    src = np.stack([xs, np.full(nsrc, 20.)], 1)
+    cfg = dict(nx=n, nz=n, dx=dx, dz=dx, c=c, nPML=10, cPML=1e3, rtol=1e-10, method='direct', batch=nsrc)
+    qs = za.SparseKaiserSource(cfg)(src)
+    dev = torch.device('cuda', 0)
+    R = torch.from_numpy(np.ascontiguousarray(qs.toarray())).to(dev)
+    U = torch.empty((N, nsrc), dtype=torch.complex128, device=dev)
+    cols = [5, 70, 135, 250]                                                   # one source in each block of 64 columns
+    jobs, passes = [], []
+    for i, f in enumerate(freqs):
+        op = za.Eurus(dict(cfg, freq=f))
+        op.solveDevice(R.data_ptr(), U.data_ptr(), nsrc, N, layout='node')
+        torch.cuda.synchronize()
+        assert all(it['status'] == 0 and it['relres'] <= 1e-10 and it['method'] == 4 for it in op.lastInfo), (f, op.lastInfo[:2])
+        passes.append(max(it['iterations'] for it in op.lastInfo))
+        path = os.path.join(shm_dir, 'u%d.npy' % i)
+        np.save(path, U[:, cols].cpu().numpy())
+        del op.factors
+        jobs.append(dict(n=n, dx=dx, model=('marmousi', 0), freq=f, system='eurus_m1', src=src[cols], ufile=path))
+    # a dense batch: every column random, the forward pass raises every flag itself; 4 of its columns go to the LU
+    rng = np.random.default_rng(65)
+    Rd = torch.from_numpy(rng.standard_normal((N, nsrc)) + 1j * rng.standard_normal((N, nsrc))).to(dev)
+    op = za.Eurus(dict(cfg, freq=6.5))
+    op.solveDevice(Rd.data_ptr(), U.data_ptr(), nsrc, N, layout='node')
+    torch.cuda.synchronize()
+    assert all(it['status'] == 0 and it['relres'] <= 1e-10 for it in op.lastInfo), op.lastInfo[:2]
+    np.save(os.path.join(shm_dir, 'qd.npy'), Rd[:, cols].cpu().numpy())
+    np.save(os.path.join(shm_dir, 'ud.npy'), U[:, cols].cpu().numpy())
+    jobs.append(dict(n=n, dx=dx, model=('marmousi', 0), freq=6.5, system='eurus_m1', src=src[cols], rhsfile=os.path.join(shm_dir, 'qd.npy'),
+                     ufile=os.path.join(shm_dir, 'ud.npy')))
+    del op.factors, Rd
+    # the skipping at full size, bit for bit (while the host factors)
+    monkeypatch.setenv('HELM_ND_POISON', '1')
+    got = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('HELM_ND_SPARSE_RHS', mode)
+        op = za.Eurus(dict(cfg, freq=5.5))
+        Um = torch.empty_like(U)
+        op.solveDevice(R.data_ptr(), Um.data_ptr(), nsrc, N, layout='node')
+        torch.cuda.synchronize()
+        got[mode] = Um
+        del op.factors
+    assert torch.equal(torch.view_as_real(got['1']), torch.view_as_real(got['0']))
+    assert bool(torch.isfinite(torch.view_as_real(got['1'])).all())
+    del got, U, R
+    nproc = max(1, min(len(jobs), (os.cpu_count() or 2) // 2, 17))
+    res = lu_worker.run_jobs(jobs, nproc=nproc)
+    worst = [max(r['err']) for r in res]
+    print('config 3, all 16 frequencies x 4 of 256 sources (headline path): rel-L2 vs LU %s; dense batch %.2e; passes %s; %d LU processes'
+          % (['%.1e' % w for w in worst[:16]], worst[16], passes, nproc))
+    assert max(worst) <= 1e-7, worst
+
+
+def test_config4_back_source_path_at_1024_matches_oracle_gradient(helm_lib):
+    """the gradient path (forward + back-propagated sources solved together, device imaging: problem.py:124-164) at the 1024^2 grid
+    for one frequency -- back-sources are R^T resid columns, 96 receiver patches each, not the surface point sources of the forward pass."""
+    import zephyr_amd as za
+    from zephyr_amd.models import marmousi_like
+    from zephyr_amd.problem import Helm2DProblem
+    from zephyr_amd.survey import Helm2DSurvey
+    n, dx, f, ns, nr = 1024, 9., 6.0, 48, 96
+    c = marmousi_like(n, n, dx)
+    src = np.stack([np.linspace(400., dx * n - 400., ns), np.full(ns, 20.)], 1)
+    rec = np.stack([np.linspace(150., dx * n - 150., nr), np.full(nr, 20.)], 1)
+    sc = dict(nx=n, nz=n, dx=dx, dz=dx, c=c, nPML=10, cPML=1e3, freqs=[f], Disc=za.Eurus, geom=dict(src=src, rec=rec, mode='fixed'), rtol=1e-10)
+    prob, surv = Helm2DProblem(sc), Helm2DSurvey(sc)
+    prob.pair(surv)
+    rng = np.random.default_rng(1024)
+    resid = rng.standard_normal((nr, ns, 1)) + 1j * rng.standard_normal((nr, ns, 1))
+    assert prob._deviceGradientAvailable()
+    g_dev = prob.Jtvec(None, resid.ravel())
+    res = lu_worker.run_jobs([dict(n=n, dx=dx, model=('marmousi', 0), freq=f, system='eurus_m1', src=src, rec=rec, resid=np.ascontiguousarray(resid[:, :, 0]))], nproc=1)
+    err = nrm(g_dev, res[0]['grad'])
+    print('config-4 path at 1024^2, %.1f Hz, %d sources + %d back-sources: gradient rel-L2 vs oracle %.2e' % (f, ns, ns, err))
+    assert err <= 1e-6
+    del prob.factors
+
+
 def test_coupled_tti_512_matches_2n_sparse_lu(helm_lib, shm_dir):
     """Row f1 at scale: the coupled two-field Eurus system (eps != delta, eurus.py:279-295,430-464) on the 512^2 model against the
     sparse LU of the reference-identical 2N x 2N matrix.  The true residual of this ill-conditioned system has an fp64 floor above

@@ -130,3 +130,68 @@ def test_operator_times_sparse_and_dense_rhs(helm_lib):
     assert big.nbytes >= (1 << 20) and big.base is not None
     with pytest.raises(ValueError):
         za.MiniZephyr(cfg) * sp.csr_matrix(qs)[:-1]
+
+
+@pytest.mark.parametrize('cls_name,premul', [('Eurus', None), ('MiniZephyrHD', None), ('MiniZephyr', 0.3 - 1.7j)])
+def test_direct_output_writes_the_wavefields_of_the_two_step_path(helm_lib, monkeypatch, cls_name, premul):
+    """Round 5 (helm_tuning.nd_direct_out): for a full-width node-major batch the back substitution writes u = conj(premul x) into the caller's array
+    itself -- leaf cells there only, separator cells there and in the scratch the levels below read -- and the residual launch reads the caller's
+    array instead of storing it.  Bit for bit the wavefields of the path that stores them from the residual launch (HELM_ND_DIRECT_OUT=0), with point
+    sources, a dense column and an all-zero one, sparse-rhs skipping on and off; the reported residual is the same number (identical when premul = 1)."""
+    import zephyr_amd as za
+    nz, nx, nrhs = 150, 170, 200
+    rng = np.random.default_rng(11)
+    c = 1800. + 2000. * rng.random((nz, nx))
+    cfg = dict(nx=nx, nz=nz, dx=10., dz=10., c=c, freq=8., nPML=8, rtol=1e-10, method='direct', batch=256)
+    if premul is not None:
+        cfg['premul'] = premul
+    locs = np.stack([rng.uniform(100., 10. * nx - 100., nrhs), rng.uniform(20., 60., nrhs)], axis=1)
+    q = za.SparseKaiserSource(cfg)(locs).toarray()
+    q[:, 3] = 0.0
+    q[:, -1] = rng.standard_normal(nz * nx) + 1j * rng.standard_normal(nz * nx)
+    q[:, 5] *= (0.2 + 0.9j)                                    # a complex source term
+    monkeypatch.setenv('HELM_ND_POISON', '1')
+    for sparse in ('1', '0'):
+        monkeypatch.setenv('HELM_ND_SPARSE_RHS', sparse)
+        out, info = {}, {}
+        for mode in ('1', '0'):
+            monkeypatch.setenv('HELM_ND_DIRECT_OUT', mode)
+            op = getattr(za, cls_name)(cfg)
+            out[mode] = device_solve(op, q, 'node')
+            info[mode] = [dict(i) for i in op.lastInfo]
+            del op.factors
+        assert np.array_equal(out['1'], out['0']), (sparse, nrm(out['1'], out['0']))
+        assert not np.any(out['1'][:, 3])
+        for a, b in zip(info['1'], info['0']):
+            assert a['status'] == b['status'] == 0 and a['iterations'] == b['iterations'] == 1
+            assert abs(a['relres'] - b['relres']) <= 1e-3 * max(b['relres'], 1e-300) + 1e-18
+    op = getattr(za, cls_name)(cfg)
+    C = ho.minizephyr_coefficients(nz, nx, op.c, op.rho, complex(op.freq), dx=10., dz=10., nPML=8) if cls_name.startswith('Mini') else None
+    ref = (ho.DirectOperator(C, premul=op.premul) if C is not None else
+           ho.DirectOperator(ho.eurus_coefficients(nz, nx, c, op.rho, 8., dx=10., dz=10., nPML=8), eurus=True)) * q[:, [0, 5, nrhs - 1]]
+    assert nrm(out['1'][:, [0, 5, nrhs - 1]], ref) <= 1e-7
+
+
+def test_direct_output_hands_x_back_when_a_refinement_pass_is_needed(helm_lib, monkeypatch):
+    """With the pivoted-LU treatment of ill-conditioned fronts off, the 512^2 model at 16 Hz needs a second pass: the first residual check reads the
+    caller's array (direct output), x is rebuilt from it for the refinement pass, and the final wavefields are those of the two-step path to rounding
+    (premul != 1: the rebuilt x differs from the original in its last bits, which the refinement pass then removes to rtol)."""
+    import zephyr_amd as za
+    from zephyr_amd.models import marmousi_like
+    n, nrhs, dx = 512, 160, 9.0
+    c = marmousi_like(n, n, dx)
+    cfg = dict(nx=n, nz=n, dx=dx, dz=dx, c=c, freq=16., nPML=10, cPML=1e3, rtol=1e-12, method='direct', batch=256, premul=0.8 + 0.3j)
+    locs = np.stack([np.linspace(300., dx * n - 300., nrhs), np.full(nrhs, 20.)], axis=1)
+    q = za.SparseKaiserSource(cfg)(locs).toarray()
+    q[(n // 2) * n + n // 3, 1] = 1j; q[40 * n + 400, 2] = 1. - 1j          # two sources inside the model as well
+    monkeypatch.setenv('HELM_ND_STABLE', '0')
+    out, passes = {}, {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('HELM_ND_DIRECT_OUT', mode)
+        op = za.Eurus(cfg)
+        out[mode] = device_solve(op, q, 'node')
+        passes[mode] = max(i['iterations'] for i in op.lastInfo)
+        assert all(i['status'] in (0, 3) and i['relres'] <= 1e-10 for i in op.lastInfo), op.lastInfo[:3]
+        del op.factors
+    assert passes['1'] >= 2 and passes['0'] >= 2, passes             # (the case does exercise the hand-back)
+    assert nrm(out['1'], out['0']) <= 1e-9

@@ -345,6 +345,8 @@ extern "C" void helm_destroy(helm_op *op) {
     if (op->stream) hipStreamSynchronize(op->stream);
     helm_pool_free(op->device, op->d_c, (size_t)op->N * sizeof(cplx)); helm_pool_free(op->device, op->d_rho, (size_t)op->N * sizeof(double));
     hipFree(op->d_theta); hipFree(op->d_eps); hipFree(op->d_delta);
+    helm_pool_free(op->device, op->d_K3, (size_t)op->N * sizeof(cplx)); helm_pool_free(op->device, op->d_b3, (size_t)op->N * sizeof(double));
+    helm_pool_free(op->device, op->d_L3, op->l3_elems * sizeof(cplx));
     {
         const size_t pb = (size_t)op->nblocks * op->nplanes * (size_t)op->N * sizeof(cplx);
         helm_pool_free(op->device, op->d_C, pb); helm_pool_free(op->device, op->d_Cs, pb);
@@ -361,7 +363,7 @@ extern "C" void helm_destroy(helm_op *op) {
     if (op->pf_done) hipEventDestroy(op->pf_done);
     if (op->pf_t0) hipEventDestroy(op->pf_t0);
     if (op->pf_t1) hipEventDestroy(op->pf_t1);
-    if (op->fstream) helm_stream_release(op->device, pf_prio(), op->fstream);
+    if (op->fstream) helm_stream_release(op->device, op->fstream_prio, op->fstream);
     {   // timing events go back to the process-wide free list
         std::lock_guard<std::mutex> lk(g_pool.mu);
         std::vector<hipEvent_t> &idle = g_idle_events[op->device];
@@ -1079,17 +1081,27 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
         bool have_qnorm = !native_nm;
         NdResidExtra rex;
         if (native_nm) { rex.Uout = dUconj; rex.ldu = n; rex.oscale = premul; }
+        // direct output (helm_tuning.nd_direct_out; full-width batches, whose residual kernel can read the caller's array): the back substitution writes
+        // u = conj(premul x) into dUconj itself and the residual launch below stores nothing -- x_in_u until a refinement pass needs x back in Xt
+        NdDirectOut dout;
+        bool x_in_u = native_nm && n > 128 && helm_tuning_now().nd_direct_out != 0;
+        if (x_in_u) { dout.U = dUconj; dout.oscale = premul; }
         if (factor_pending) {
             float fms = 0.f;
-            rc = nd_factor_solve_nm(op, block, f, ws_factor, nullptr, Qt, Xt, n, arenaV, op->side_stream, &fms);
+            rc = nd_factor_solve_nm(op, block, f, ws_factor, nullptr, Qt, Xt, n, arenaV, op->side_stream, &fms, x_in_u ? &dout : nullptr);
             if (rc) return rc;
             op->direct[slot] = f; fresh.p = nullptr;
             op->timing.factor_ms += fms;
             factor_pending = false;
         } else {
-            rc = nd_solve_nm(op, f, Qt, Xt, n, arenaV);
+            rc = nd_solve_nm(op, f, Qt, Xt, n, arenaV, x_in_u ? &dout : nullptr);
             if (rc) return rc;
         }
+        auto recover_x = [&]() -> int {            // x of every cell back in Xt (the residual of what follows is evaluated from Xt again, ||q||^2 unscaled)
+            if (!x_in_u) return HELM_OK;
+            x_in_u = false; have_qnorm = false;
+            return nd_recover_x(op, dUconj, Xt, (long long)n * N, premul);
+        };
         // where the right-hand sides of this batch can be nonzero at all (the flags of the sparse forward pass just run on Qt): the residual
         // launches read q only there -- every later evaluation too, Qt does not change
         rex.qmask = nd_rhs_mask(op, f);
@@ -1099,7 +1111,12 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
         // every pass ends with the TRUE residual q' - A x of the vector that is returned (norms only); q' is kept for that
         auto true_residual_norms = [&]() -> int {
             rex.qnorm = have_qnorm ? 0 : 1;
-            int r1 = nd_resid_nm(op, planes, Xt, n, Qt, n, nullptr, n, 0, nullptr, (double *)op->d_part, nblk, &nb_part, (native_nm || rex.qmask) ? &rex : nullptr);
+            int r1;
+            if (x_in_u) {
+                NdResidExtra ru = rex; ru.Uout = nullptr; ru.xin_is_u = 1;
+                r1 = nd_resid_nm(op, planes, dUconj, n, Qt, n, nullptr, n, 0, nullptr, (double *)op->d_part, nblk, &nb_part, &ru);
+            } else
+            r1 = nd_resid_nm(op, planes, Xt, n, Qt, n, nullptr, n, 0, nullptr, (double *)op->d_part, nblk, &nb_part, (native_nm || rex.qmask) ? &rex : nullptr);
             if (r1) return r1;
             helm_launch_fin_ex(op, have_qnorm ? FIN_NORM : FIN_NORM2, n, nb_part, nullptr, d_aux);
             have_qnorm = true;
@@ -1122,6 +1139,8 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
             prev_worst = worst;
             if (all_ok || round >= max_refine || stalled) break;
             // r = q' - A x stored (Rt), dx = A^-1 r, x += dx
+            rc = recover_x();
+            if (rc) return rc;
             rc = nd_resid_nm(op, planes, Xt, n, Qt, n, nullptr, n, 1, Rt, (double *)op->d_part, nblk, &nb_part);
             if (rc) return rc;
             std::vector<int> bad;
@@ -1161,7 +1180,8 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
             const size_t pbytes = (size_t)op->nplanes * N * sizeof(cplx);
             cplx *absP = any ? (cplx *)helm_pool_alloc(op->device, pbytes) : nullptr;
             if (any && absP) {
-                rc = helm_launch_abs(op, planes, absP, (long long)op->nplanes * N, 1.0);
+                rc = recover_x();
+                if (!rc) rc = helm_launch_abs(op, planes, absP, (long long)op->nplanes * N, 1.0);
                 if (!rc) rc = helm_launch_abs(op, Xt, Dt, (long long)n * N, 1.0);
                 if (!rc && hipMemsetAsync(Rt, 0, (size_t)n * N * sizeof(cplx), op->stream) != hipSuccess) rc = HELM_ERR_DEVICE;
                 if (!rc) rc = nd_resid_nm(op, absP, Dt, n, Rt, n, nullptr, n, 0, nullptr, (double *)op->d_part, nblk, &nb_part);      // -|A||x|
@@ -1682,7 +1702,8 @@ extern "C" int helm_prefactor(helm_op *op) {
     if (testing_hook("HELM_ND_INJECT_FAILURE")) return HELM_OK;
     HIP_TRY(op, hipSetDevice(op->device));
     if (!op->fstream) {
-        op->fstream = helm_stream_acquire(op->device, pf_prio());
+        op->fstream_prio = pf_prio();
+        op->fstream = helm_stream_acquire(op->device, op->fstream_prio);
         if (!op->fstream) HELM_FAIL(op, HELM_ERR_DEVICE, "hipStreamCreate failed");
     }
     if (!op->pf_done) HIP_TRY(op, hipEventCreateWithFlags(&op->pf_done, hipEventDisableTiming));

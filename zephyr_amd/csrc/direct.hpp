@@ -128,9 +128,14 @@ long long nd_solve_ws_elems(const NdPlan &P, int nrhs);
 int nd_solve(helm_op *op, NdFactor *f, const cplx *Xin, cplx *Xout, int nrhs, cplx *ws, int conj_out = 0);   // conj_out: Xout = conj(x)
 int nd_axpy_one(helm_op *op, cplx *y, const cplx *x, long long n, int conj = 0);
 // node-major pipeline (direct.hip): right-hand sides and solutions as [cell][rhs] between one transpose in and one out
-int nd_solve_nm(helm_op *op, NdFactor *f, const cplx *Qt, cplx *Xt, int nrhs, cplx *arenaV);
+// Direct output (round 5): the back substitution leaves u = conj(oscale x) in the caller's node-major wavefield array U[cell][nrhs] itself -- leaf cells
+// there alone (nothing on the GPU needs their x again), separator cells there and in Xt -- so that the residual check reads U and stores nothing
+// (4.3 of its 13 GB at 1024^2 x 256).  Afterwards Xt holds x only for the separator cells; nd_recover_x rebuilds the rest from U if a refinement pass needs it.
+struct NdDirectOut { cplx *U = nullptr; cplx oscale = {1.0, 0.0}; };
+int nd_solve_nm(helm_op *op, NdFactor *f, const cplx *Qt, cplx *Xt, int nrhs, cplx *arenaV, const NdDirectOut *dout = nullptr);
 int nd_factor_solve_nm(helm_op *op, int block, NdFactor *f, cplx *ws_factor, const cplx *planes, const cplx *Qt, cplx *Xt, int nrhs, cplx *arenaV,
-                       hipStream_t side, float *factor_ms);
+                       hipStream_t side, float *factor_ms, const NdDirectOut *dout = nullptr);
+int nd_recover_x(helm_op *op, const cplx *U, cplx *Xt, long long elems, cplx oscale);       // Xt = conj(U) / oscale
 int nd_prep_transpose_norm(helm_op *op, const cplx *rhs, long long rhs_ld, long long row_off, cplx premul, const cplx *sub, cplx *Qt, long long N, int nrhs,
                            double *part, int nblk_cap, int *nblk_out);     // nblk_cap: partials per right-hand side the buffer has room for
 // per-cell mask of where the right-hand sides of the last nd_solve_nm / nd_factor_solve_nm on f can be nonzero (leaf cells: the leaf's flag of the
@@ -141,6 +146,7 @@ struct NdResidExtra {      // optional by-products of the residual launch (node-
     cplx *Uout = nullptr; int ldu = 0;   // Uout[cell][j] = conj(oscale * xin[cell][j])
     cplx oscale = {1.0, 0.0};
     const unsigned char *qmask = nullptr;   // nd_rhs_mask of the q passed in: cells and blocks of 64 columns whose bit is 0 are not read (they hold zeros)
+    int xin_is_u = 0;                    // Xin is the caller's wavefield array u = conj(oscale x) (direct output): evaluated as oscale q - A conj(u), same relative residual
 };
 int nd_resid_nm(helm_op *op, const cplx *planes, const cplx *Xin, int ldin, cplx *Q, int ldq, const int *qmap, int ncol, int store, cplx *Rout,
                 double *part, int nblk_cap, int *nblk_out, const NdResidExtra *ex = nullptr);      // r = q - A xin; store: r -> Rout (null: over q)

@@ -16,6 +16,32 @@ namespace {
 
 __device__ inline int clampi3(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// one coefficient of the 27-point operator from what it depends on -- used by the assembly kernel (planes) AND by the on-the-fly apply, with the
+// floating-point contraction pinned so that both produce the same bits whatever surrounds the call
+//   out = bbar (lx' + ly' + lz') + K mass,  lx' = Lx[ox] my mz / dx^2 ..., bbar = (b_i + b_j) / 2, mass = [o == 0] blend + (1 - blend) mx my mz
+__device__ __forceinline__ cplx coeff3(int ox, int oy, int oz, cplx Lxo, cplx Lyo, cplx Lzo, double idx2, double idy2, double idz2,
+                                       double b0, double bj, cplx Knb, double blend) {
+#pragma clang fp contract(off)
+    const double bbar = (b0 + bj) / 2.0;
+    const double mx = ox == 0 ? 2.0 / 3.0 : 1.0 / 6.0, my = oy == 0 ? 2.0 / 3.0 : 1.0 / 6.0, mz = oz == 0 ? 2.0 / 3.0 : 1.0 / 6.0;
+    const double sx = my * mz * idx2, sy = mx * mz * idy2, sz = mx * my * idz2;
+    const double mass = ((ox == 0 && oy == 0 && oz == 0) ? blend : 0.0) + (1.0 - blend) * mx * my * mz;
+    const double lre = (Lxo.x * sx + Lyo.x * sy) + Lzo.x * sz, lim = (Lxo.y * sx + Lyo.y * sy) + Lzo.y * sz;
+    return cmake(lre * bbar + Knb.x * mass, lim * bbar + Knb.y * mass);
+}
+
+// K = om^2 / (rho c^2) of one point (Smith's division, as cdiv), contraction pinned for the same reason
+__device__ __forceinline__ cplx kfield3(cplx om2, cplx cj, double rj) {
+#pragma clang fp contract(off)
+    const double br = (cj.x * cj.x - cj.y * cj.y) * rj, bi = (cj.x * cj.y + cj.y * cj.x) * rj;
+    if (fabs(br) >= fabs(bi)) {
+        const double r = bi / br, d = br + bi * r;
+        return cmake((om2.x + om2.y * r) / d, (om2.y - om2.x * r) / d);
+    }
+    const double r = br / bi, d = br * r + bi;
+    return cmake((om2.x * r + om2.y) / d, (om2.y * r - om2.x) / d);
+}
+
 struct Asm3Params {
     int nz, ny, nx;
     double dx, dy, dz;
@@ -49,17 +75,25 @@ __global__ __launch_bounds__(256) void k_assemble_3d(Asm3Params P, const cplx *_
                     const long long j = ((long long)jz * P.ny + jy) * P.nx + jx;
                     const double rj = rho[j];
                     const cplx cj = c[j];
-                    const double bbar = (b0 + 1.0 / rj) / 2.0;
-                    const cplx Knb = cdiv(om2, cscale(cmul(cj, cj), rj));
-                    const double mx = ox == 0 ? 2.0 / 3.0 : 1.0 / 6.0, my = oy == 0 ? 2.0 / 3.0 : 1.0 / 6.0, mz = oz == 0 ? 2.0 / 3.0 : 1.0 / 6.0;
-                    const cplx lx = cscale(Lx[(long long)(ox + 1) * P.nx + ix], my * mz * idx2);
-                    const cplx ly = cscale(Ly[(long long)(oy + 1) * P.ny + iy], mx * mz * idy2);
-                    const cplx lz = cscale(Lz[(long long)(oz + 1) * P.nz + iz], mx * my * idz2);
-                    const double mass = ((k == 13) ? P.blend : 0.0) + (1.0 - P.blend) * mx * my * mz;
-                    out = cadd(cscale(cadd(cadd(lx, ly), lz), bbar), cscale(Knb, mass));
+                    const cplx Knb = kfield3(om2, cj, rj);
+                    out = coeff3(ox, oy, oz, Lx[(long long)(ox + 1) * P.nx + ix], Ly[(long long)(oy + 1) * P.ny + iy], Lz[(long long)(oz + 1) * P.nz + iz],
+                                 idx2, idy2, idz2, b0, 1.0 / rj, Knb, P.blend);
                 }
                 C[(long long)k * N + i] = out;
             }
+}
+
+// K = om^2 / (rho c^2) and b = 1 / rho per point, with the very expressions k_assemble_3d uses for a neighbour: the on-the-fly kernel below then rebuilds
+// every coefficient bit for bit
+__global__ __launch_bounds__(256) void k_kb_3d(Asm3Params P, const cplx *__restrict__ c, const double *__restrict__ rho, cplx *__restrict__ K, double *__restrict__ b) {
+    const long long N = (long long)P.nz * P.ny * P.nx;
+    const cplx om2 = cmul(P.om, P.om);
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < N; j += (long long)gridDim.x * blockDim.x) {
+        const double rj = rho[j];
+        const cplx cj = c[j];
+        K[j] = kfield3(om2, cj, rj);
+        b[j] = 1.0 / rj;
+    }
 }
 
 // ---- batched 27-point apply -----------------------------------------------------------------------
@@ -75,6 +109,9 @@ struct Stencil3Params {
     double *part;
     const cplx *dinv;        // EPI_JACOBI: 1 / diagonal
     double omega_j;
+    // OTF: the coefficients are rebuilt from K, b (per point) and the per-axis factor tables instead of being read from the 27 planes
+    const cplx *K3; const double *b3; const cplx *Lx, *Ly, *Lz;
+    double idx2, idy2, idz2, blend;
 };
 
 __device__ inline double wave_sum3(double v) {
@@ -91,7 +128,12 @@ __device__ inline int xcd_swizzle3(int bid, int nblk) {
 
 constexpr int T3X = 64, T3Y = 4;
 
-template <bool SCALED, int EPI>
+// OTF (round 5): the thread's 27 coefficients are not read from the stored planes (432 B per point: 46 % of the launch's bytes at 16 right-hand sides, and
+// SURVEY.md 7 hard-part 6 calls rebuilding them mandatory) but rebuilt once, before the right-hand-side loop, from K = om^2 / (rho c^2) and b = 1 / rho of the
+// 3 x 3 x 3 neighbourhood -- staged through the tile's own LDS buffers, 24 B per point with halo -- and the three 1-D factor tables: the same expressions in
+// the same order as k_assemble_3d, so the apply is bit for bit the stored-plane apply.  Amortised over the right-hand sides of the launch (helm3d_launch_apply
+// takes this path from 4 right-hand sides up); the coarse levels that carry a Galerkin operator keep their stored planes.
+template <bool SCALED, int EPI, bool OTF = false>
 __global__ __launch_bounds__(256) void k_stencil3(Stencil3Params q) {
     constexpr int LW = T3X + 2, LH = T3Y + 2;          // one staged plane: LH rows of LW
     constexpr int PLANE = LW * LH;                      // 396 elements
@@ -117,10 +159,50 @@ __global__ __launch_bounds__(256) void k_stencil3(Stencil3Params q) {
     const long long idx = ((long long)iz * ny + row) * nx + col;
 
     cplx cf[27];
+    if (!OTF) {
 #pragma unroll
-    for (int k = 0; k < 27; ++k) {
-        if (SCALED && k == 13) cf[k] = cmake(1.0, 0.0);
-        else cf[k] = ok ? q.planes[(long long)k * N + idx] : cmake(0.0, 0.0);
+        for (int k = 0; k < 27; ++k) {
+            if (SCALED && k == 13) cf[k] = cmake(1.0, 0.0);
+            else cf[k] = ok ? q.planes[(long long)k * N + idx] : cmake(0.0, 0.0);
+        }
+    } else {
+        // K of the three planes with halo into tile[0], b into tile[1] (as doubles), then every thread reads its 27 neighbours
+        cplx *Kt = &tile[0][0];
+        double *bt = reinterpret_cast<double *>(&tile[1][0]);
+        for (int e = tid; e < NEL; e += 256) {
+            const int p = e / PLANE, rem = e - p * PLANE, r = rem / LW, cc = rem - r * LW;
+            const int gz = iz - 1 + p, gy = y0 - 1 + r, gx = x0 - 1 + cc;
+            cplx kv = cmake(0.0, 0.0); double bv = 0.0;
+            if (gz >= 0 && gz < nz && gy >= 0 && gy < ny && gx >= 0 && gx < nx) { const long long j = ((long long)gz * ny + gy) * nx + gx; kv = q.K3[j]; bv = q.b3[j]; }
+            Kt[e] = kv; bt[e] = bv;
+        }
+        __syncthreads();
+        const bool edge = !ok || col == 0 || col == nx - 1 || row == 0 || row == ny - 1 || iz == 0 || iz == nz - 1;
+        const int ce = (wy + 1) * LW + lane + 1;                    // this thread's own cell in a staged plane
+        const double b0 = bt[PLANE + ce];
+        cplx lxv[3], lyv[3], lzv[3];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            lxv[o] = ok ? q.Lx[(long long)o * nx + col] : cmake(0.0, 0.0);
+            lyv[o] = ok ? q.Ly[(long long)o * ny + row] : cmake(0.0, 0.0);
+            lzv[o] = q.Lz[(long long)o * nz + iz];
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    const int k = 9 * p + 3 * r + cc;
+                    cplx out;
+                    if (edge) out = (k == 13 && ok) ? cmake(1.0, 0.0) : cmake(0.0, 0.0);
+                    else {
+                        const int e = p * PLANE + (wy + r) * LW + lane + cc;
+                        out = coeff3(cc - 1, r - 1, p - 1, lxv[cc], lyv[r], lzv[p], q.idx2, q.idy2, q.idz2, b0, bt[e], Kt[e], q.blend);
+                    }
+                    cf[k] = out;
+                }
+        __syncthreads();                                            // the tile buffers go back to the right-hand sides
     }
 
     // staging map: element e of the 3-plane tile -> (plane p, tile row r, tile column cc)
@@ -163,7 +245,7 @@ __global__ __launch_bounds__(256) void k_stencil3(Stencil3Params q) {
         cplx acc = cmake(0.0, 0.0), xc = cmake(0.0, 0.0);
         const cplx *tb = &tile[buf][wy * LW + lane];
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < 3; ++p) {
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -174,6 +256,7 @@ __global__ __launch_bounds__(256) void k_stencil3(Stencil3Params q) {
                     else cfma(acc, cf[k], xv);
                     if (k == 13) xc = xv;
                 }
+        }
         double dsum[4] = {0.0, 0.0, 0.0, 0.0};
         if (ok) {
             cplx y = acc;
@@ -242,7 +325,11 @@ int helm3d_launch_assemble(helm_op *op, double freq_re, double freq_im, double t
     // levels of the layer-preserving multigrid hierarchy (mg3d.hip) bring their own factors: non-uniform node spacing, 1/h^2 included
     const bool over = op->lap_override.size() == all.size();
     if (over) all = op->lap_override;
-    cplx *d_L = (cplx *)helm_pool_alloc(op->device, all.size() * sizeof(cplx));
+    // (the factor tables stay on the operator: the on-the-fly apply reads them at every launch)
+    op->otf3 = false;
+    if (op->d_L3 && op->l3_elems != all.size()) { helm_pool_free(op->device, op->d_L3, op->l3_elems * sizeof(cplx)); op->d_L3 = nullptr; op->l3_elems = 0; }
+    if (!op->d_L3) { op->d_L3 = (cplx *)helm_pool_alloc(op->device, all.size() * sizeof(cplx)); op->l3_elems = op->d_L3 ? all.size() : 0; }
+    cplx *d_L = op->d_L3;
     if (!d_L) HELM_FAIL(op, HELM_ERR_DEVICE, "hipMalloc of the stretch profiles failed");
     HIP_TRY(op, hipMemcpyAsync(d_L, all.data(), all.size() * sizeof(cplx), hipMemcpyHostToDevice, op->stream));
     Asm3Params P;
@@ -253,13 +340,34 @@ int helm3d_launch_assemble(helm_op *op, double freq_re, double freq_im, double t
     hipLaunchKernelGGL(k_assemble_3d, dim3(blocks), dim3(256), 0, op->stream, P, (const cplx *)op->d_c, (const double *)op->d_rho,
                        (const cplx *)d_L, (const cplx *)(d_L + 3 * (size_t)op->nx), (const cplx *)(d_L + 3 * (size_t)op->nx + 3 * (size_t)op->ny), op->d_C);
     HIP_TRY(op, hipGetLastError());
+    // K and b for the on-the-fly apply (24 B per point; a handle that cannot have them simply keeps reading its planes)
+    if (!op->d_K3) op->d_K3 = (cplx *)helm_pool_alloc(op->device, (size_t)op->N * sizeof(cplx));
+    if (!op->d_b3) op->d_b3 = (double *)helm_pool_alloc(op->device, (size_t)op->N * sizeof(double));
+    if (op->d_K3 && op->d_b3) {
+        hipLaunchKernelGGL(k_kb_3d, dim3((unsigned)std::min<long long>(blocks, 65535)), dim3(256), 0, op->stream, P, (const cplx *)op->d_c, (const double *)op->d_rho, op->d_K3, op->d_b3);
+        HIP_TRY(op, hipGetLastError());
+        op->otf_idx2 = 1.0 / (P.dx * P.dx); op->otf_idy2 = 1.0 / (P.dy * P.dy); op->otf_idz2 = 1.0 / (P.dz * P.dz); op->otf_blend = P.blend;
+        op->otf3 = true;
+    }
     HIP_TRY(op, hipStreamSynchronize(op->stream));
-    helm_pool_free(op->device, d_L, all.size() * sizeof(cplx));
     return HELM_OK;
 }
 
 int helm3d_apply_num_blocks(const helm_op *op) {
     return ((op->nx + T3X - 1) / T3X) * ((op->ny + T3Y - 1) / T3Y) * op->nz;
+}
+
+static void launch3_otf(hipStream_t st, dim3 grid, const Stencil3Params &q, int epi) {
+    switch (epi) {
+    case EPI_NONE: hipLaunchKernelGGL((k_stencil3<false, EPI_NONE, true>), grid, dim3(256), 0, st, q); break;
+    case EPI_DOT_W: hipLaunchKernelGGL((k_stencil3<false, EPI_DOT_W, true>), grid, dim3(256), 0, st, q); break;
+    case EPI_DOT_XY: hipLaunchKernelGGL((k_stencil3<false, EPI_DOT_XY, true>), grid, dim3(256), 0, st, q); break;
+    case EPI_DOT_YY: hipLaunchKernelGGL((k_stencil3<false, EPI_DOT_YY, true>), grid, dim3(256), 0, st, q); break;
+    case EPI_RESID: hipLaunchKernelGGL((k_stencil3<false, EPI_RESID, true>), grid, dim3(256), 0, st, q); break;
+    case EPI_DOT_WY: hipLaunchKernelGGL((k_stencil3<false, EPI_DOT_WY, true>), grid, dim3(256), 0, st, q); break;
+    case EPI_JACOBI: hipLaunchKernelGGL((k_stencil3<false, EPI_JACOBI, true>), grid, dim3(256), 0, st, q); break;
+    default: break;
+    }
 }
 
 template <bool SCALED>
@@ -287,8 +395,16 @@ int helm3d_launch_apply(helm_op *op, const ApplyArgs &a, hipEvent_t e0, hipEvent
     int split = 1;
     if (q.nblk < 2048) { split = (2048 + q.nblk - 1) / q.nblk; if (split > a.nrhs) split = a.nrhs; if (split < 1) split = 1; }
     dim3 grid(q.nblk, split);
+    // coefficients on the fly: this operator's own planes (not a caller's override), unscaled, enough right-hand sides per workgroup to amortise the rebuild
+    const int per_wg = (a.nrhs + split - 1) / split;
+    const int otf_mode = helm_tuning_now().mg3_otf;            // 0 off, 1 where it pays, 2 wherever it is possible (tests)
+    const bool otf = op->otf3 && a.planes == op->d_C && !a.scaled && (otf_mode == 2 || (otf_mode == 1 && per_wg >= 4));
+    q.K3 = op->d_K3; q.b3 = op->d_b3; q.Lx = op->d_L3; q.Ly = op->d_L3 ? op->d_L3 + 3 * (size_t)op->nx : nullptr;
+    q.Lz = op->d_L3 ? op->d_L3 + 3 * (size_t)op->nx + 3 * (size_t)op->ny : nullptr;
+    q.idx2 = op->otf_idx2; q.idy2 = op->otf_idy2; q.idz2 = op->otf_idz2; q.blend = op->otf_blend;
     if (e0) hipEventRecord(e0, op->stream);
-    if (a.scaled) launch3_epi<true>(op->stream, grid, q, a.epi);
+    if (otf) launch3_otf(op->stream, grid, q, a.epi);
+    else if (a.scaled) launch3_epi<true>(op->stream, grid, q, a.epi);
     else launch3_epi<false>(op->stream, grid, q, a.epi);
     if (e1) hipEventRecord(e1, op->stream);
     HIP_TRY(op, hipGetLastError());

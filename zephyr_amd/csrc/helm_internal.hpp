@@ -111,6 +111,11 @@ struct helm_op {
 
     // model
     cplx *d_c = nullptr;
+    // 3-D operator, coefficients rebuilt on the fly (helm3d.hip, k_stencil3<.., OTF>): K = om^2 / (rho c^2) and b = 1 / rho per point (24 B instead of the 432 B
+    // of the 27 stored planes) and the three per-axis factor tables Lx | Ly | Lz (3 n each); valid while otf3 is set (cleared when something else writes d_C)
+    cplx *d_K3 = nullptr; double *d_b3 = nullptr; cplx *d_L3 = nullptr; size_t l3_elems = 0;
+    bool otf3 = false; double otf_idx2 = 0, otf_idy2 = 0, otf_idz2 = 0, otf_blend = 0.5;
+    int fstream_prio = 0;                                  // priority class fstream was acquired with (it goes back to that class's free list)
     double *d_rho = nullptr, *d_theta = nullptr, *d_eps = nullptr, *d_delta = nullptr;
     bool has_model = false, aniso = false;
 

@@ -1232,6 +1232,7 @@ int setup_keep(helm_op *op, Mg3Precond *P, int batch, int ncoarsen, double tauM)
     if (ncoarsen > 0 && helm_tuning_now().mg3_galerkin) {        // the directly solved level carries the Galerkin product of the level above it
         const Mg3Level &Lf = P->lv[ncoarsen - 1]; Mg3Level &Lc = P->lv[ncoarsen];
         const int t = ncoarsen - 1;
+        Lc.op->otf3 = false;            // (the coarse level's planes are the Galerkin product from here on, not what its c, rho and factor tables would rebuild)
         hipLaunchKernelGGL(k3_galerkin, dim3((unsigned)((Lc.N + 255) / 256)), dim3(256), 0, op->stream, (const cplx *)Lf.op->d_C, Lf.nz, Lf.ny, Lf.nx,
                            Lc.op->d_C, Lc.nz, Lc.ny, Lc.nx, (const RTab *)K->rt[0][t], (const RTab *)K->rt[1][t], (const RTab *)K->rt[2][t],
                            (const PTab *)K->pt[0][t], (const PTab *)K->pt[1][t], (const PTab *)K->pt[2][t]);

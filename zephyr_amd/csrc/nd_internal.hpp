@@ -46,6 +46,10 @@ struct GemmRows {
     int ntc = 0;                // store C with nontemporal stores (large HBM-bound launches whose output is not read again soon)
     int xcd_map = 0;            // regroup the workgroup ids so that the column tiles of a front share an XCD (zgemm3_body)
     int child_rows = 0;         // (fwd3, host-side bookkeeping) ring rows of a front's two children: what the gather has to read besides q_S
+    // Direct output (IDX 1 with tabCo, back substitution of a node-major call): the caller's wavefield array takes u = conj(oscale x) from the launch that
+    // computes x -- cj_out: the rows stored through tabCo are written as u (leaves: nobody reads their x on the GPU again but the residual check, which takes
+    // it from the caller's array); Cox2: a second, transformed copy of every stored row beside the plain one in Cox (separator rows: the children below still need x)
+    int cj_out = 0; cplx oscale = {1.0, 0.0}; cplx *Cox2 = nullptr;
 };
 #define GB_KIDX 512       // largest K with indexed B rows
 // Addressing modes of the tile kernel (template parameter IDX):

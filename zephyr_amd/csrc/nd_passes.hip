@@ -51,7 +51,9 @@ __global__ __launch_bounds__(256) void k_nd_bwd_gather(const int4 *tab, cplx *V,
 }
 
 // backward pass: Xt[separator cells] = XS (cnt x smax rows)
-__global__ __launch_bounds__(256) void k_nd_bwd_store(const int4 *tab, const cplx *XS, cplx *Xt, long long rows, int smax, int nmax, int nrhs) {
+// (U2 != null: the caller's wavefield array takes conj(oscale x) of the same rows, see GemmRows::Cox2)
+__global__ __launch_bounds__(256) void k_nd_bwd_store(const int4 *tab, const cplx *XS, cplx *Xt, long long rows, int smax, int nmax, int nrhs,
+                                                      cplx *U2 = nullptr, cplx oscale = {1.0, 0.0}) {
     for (long long row = (long long)blockIdx.x * blockDim.y + threadIdx.y; row < rows; row += (long long)gridDim.x * blockDim.y) {
         const long long j = row / smax;
         const int a = (int)(row - j * smax);
@@ -60,6 +62,10 @@ __global__ __launch_bounds__(256) void k_nd_bwd_store(const int4 *tab, const cpl
         const cplx *src = XS + row * nrhs;
         cplx *dst = Xt + (long long)e.x * nrhs;
         for (int r = threadIdx.x; r < nrhs; r += blockDim.x) dst[r] = src[r];
+        if (U2) {
+            cplx *d2 = U2 + (long long)e.x * nrhs;
+            for (int r = threadIdx.x; r < nrhs; r += blockDim.x) d2[r] = cconj(cmul(oscale, src[r]));
+        }
     }
 }
 
@@ -68,6 +74,7 @@ struct SolveCtx {
     const cplx *Qt;       // node-major right-hand sides (read only); == Xt for an in-place solve
     int *act = nullptr; int nct = 0;     // sparse-right-hand-side flags of the forward pass (null: every front is computed)
     int act_hint = 0;                    // the leaves' flags come from the support the caller declared (helm_set_rhs_support): no scan of q
+    cplx *Uout = nullptr; cplx oscale = {1.0, 0.0};      // direct output (NdDirectOut): the back substitution leaves u = conj(oscale x) in the caller's array [cell][nrhs]
     dim3 rgrid(long long rows) const { return dim3((unsigned)std::min<long long>((rows + rb.y - 1) / rb.y, 1 << 20)); }
 };
 
@@ -170,7 +177,7 @@ int backward_stable(helm_op *op, NdFactor *f, size_t gk, const SolveCtx &c, bool
         } else {
             if (S.mmax > 0) gemm(op, S.smax, nrhs, S.mmax, mone, S.lu + S.smax, nmax, 0, S.vs + (long long)S.smax * nrhs, nrhs, 0, one, S.vs, nrhs, 0, 1);
             launch_lu_solve(op->stream, S.lu, nmax, S.smax, S.piv, S.vs, nrhs, nrhs);
-            hipLaunchKernelGGL(k_nd_bwd_store, c.rgrid(S.smax), c.rb, 0, op->stream, c.tab + n.roff, (const cplx *)S.vs, c.Xt, (long long)S.smax, S.smax, nmax, nrhs);
+            hipLaunchKernelGGL(k_nd_bwd_store, c.rgrid(S.smax), c.rb, 0, op->stream, c.tab + n.roff, (const cplx *)S.vs, c.Xt, (long long)S.smax, S.smax, nmax, nrhs, c.Uout, c.oscale);
         }
     }
     return HELM_OK;
@@ -192,7 +199,7 @@ void backward_group_batched(helm_op *op, NdFactor *f, size_t gk, const SolveCtx 
     const long long rows = (long long)g.cnt * nmax;
     const long long s1 = (long long)g.smax * nmax;                 // stride of a front's [F11^-1 | F12] rows
     const cplx *Finv = f->d_fac + g.finv, *F12 = f->d_fac + g.f12;
-    // leaves under HELM_ND_MERGED_LEAF hold G = -F11^-1 F12 in place of F12: x_S = F11^-1 y_S + G x_B
+    // leaves hold G = -F11^-1 F12 in place of F12: x_S = F11^-1 y_S + G x_B
     const bool gform = merged_group(P, g);
     cplx *V = c.arenaV + g.voff * nrhs;
     // the other region is free in this pass: separator results go there
@@ -204,8 +211,9 @@ void backward_group_batched(helm_op *op, NdFactor *f, size_t gk, const SolveCtx 
             // leaves: x_S = [F11^-1 | G] [y_S; x_B] in ONE product -- y_S rows from the right-hand sides, x_B rows from Xt; the result goes
             // straight to the Xt rows (no intermediate: 2 x 3.2 GB less per pass at 1024^2 x 256)
             GemmRows R; R.tabB = c.tab + g.roff; R.offB = 0; R.tabCo = c.tab + g.roff; R.offCo = 0; R.tab_stride = nmax;
-            R.Bx = c.Xt; R.Bx2 = g.leaf ? c.Qt : (const cplx *)c.Xt; R.k2 = g.smax; R.Cox = c.Xt; R.ldx = nrhs;      // (a separator front's y_S was left in Xt by the forward pass)
-            if (!g.leaf) R.tm64 = 1;                                                 // one row tile per front: the product overwrites rows it reads
+            R.Bx = c.Xt; R.Bx2 = c.Qt; R.k2 = g.smax; R.Cox = c.Xt; R.ldx = nrhs;
+            // direct output: nothing on the GPU reads a leaf cell's x again but the residual check -- the rows go to the caller's array as u = conj(oscale x)
+            if (c.Uout) { R.Cox = c.Uout; R.cj_out = 1; R.oscale = c.oscale; }
             R.act_ro = g.leaf ? c.act : nullptr; R.nct = c.nct; R.first = g.first;
             gemm(op, g.smax, nrhs, nmax, one, Finv, nmax, s1, nullptr, 0, 0, zero, nullptr, 0, 0, g.cnt, &R);
             return;
@@ -223,6 +231,7 @@ void backward_group_batched(helm_op *op, NdFactor *f, size_t gk, const SolveCtx 
         R1.Bx = c.Xt; R1.Cix = g.leaf ? c.Qt : c.Xt; R1.ldx = nrhs;      // a leaf's y_S is still the right-hand side itself
         gemm(op, g.smax, nrhs, g.mmax, mone, F12, nmax, s1, nullptr, 0, 0, one, V, nrhs, (long long)g.smax * nrhs, g.cnt, &R1);
         GemmRows R2; R2.tabCo = c.tab + g.roff; R2.offCo = 0; R2.tab_stride = nmax; R2.Cox = c.Xt; R2.ldx = nrhs;
+        if (c.Uout) { R2.Cox2 = c.Uout; R2.oscale = c.oscale; }        // (separator rows: x stays in Xt for the levels below, u goes to the caller's array beside it)
         gemm(op, g.smax, nrhs, g.smax, one, Finv, nmax, s1, V, nrhs, (long long)g.smax * nrhs, zero, nullptr, 0, 0, g.cnt, &R2);
         return;
     }
@@ -236,7 +245,7 @@ void backward_group_batched(helm_op *op, NdFactor *f, size_t gk, const SolveCtx 
         gemm(op, g.smax, nrhs, g.smax, one, Finv, nmax, s1, V, nrhs, (long long)nmax * nrhs, zero, XS, nrhs, (long long)g.smax * nrhs, g.cnt);
     }
     const long long srows = (long long)g.cnt * g.smax;
-    hipLaunchKernelGGL(k_nd_bwd_store, c.rgrid(srows), c.rb, 0, op->stream, c.tab + g.roff, XS, c.Xt, srows, g.smax, nmax, nrhs);
+    hipLaunchKernelGGL(k_nd_bwd_store, c.rgrid(srows), c.rb, 0, op->stream, c.tab + g.roff, XS, c.Xt, srows, g.smax, nmax, nrhs, c.Uout, c.oscale);
 }
 
 }  // namespace
@@ -343,10 +352,11 @@ const unsigned char *nd_rhs_mask(helm_op *op, NdFactor *f) {
     return f->d_qmask;
 }
 
-int nd_solve_nm(helm_op *op, NdFactor *f, const cplx *Qt, cplx *Xt, int nrhs, cplx *arenaV) {
+int nd_solve_nm(helm_op *op, NdFactor *f, const cplx *Qt, cplx *Xt, int nrhs, cplx *arenaV, const NdDirectOut *dout) {
     const NdPlan &P = f->pd->plan;
     SolveCtx c = solve_ctx(f, Xt, nrhs);
     c.Qt = Qt; c.Xt = Xt; c.arenaV = arenaV;
+    if (dout && dout->U && P.dof == 1 && Qt != Xt) { c.Uout = dout->U; c.oscale = dout->oscale; }
     arm_sparse_rhs(op, f, c, op->stream);
     GroupTrace tf(op->stream, "forward");
     for (size_t gi = 0; gi < P.groups.size(); ++gi) { forward_group(op, f, gi, c); tf.mark(); }
@@ -375,7 +385,7 @@ struct EventSet {
 // small dependent launches (80 block steps of a 16-workgroup panel kernel + one update each) that leaves most of the chip idle; the
 // forward pass of the lower levels (big HBM-bound launches) fills it, and the priorities keep it from delaying the chain.
 int nd_factor_solve_nm(helm_op *op, int block, NdFactor *f, cplx *ws_factor, const cplx *planes_in, const cplx *Qt, cplx *Xt, int nrhs, cplx *arenaV,
-                       hipStream_t side, float *factor_ms) {
+                       hipStream_t side, float *factor_ms, const NdDirectOut *dout) {
     const NdPlan &P = f->pd->plan;
     hipStream_t main = op->stream;
     const cplx *planes = nullptr;
@@ -383,6 +393,7 @@ int nd_factor_solve_nm(helm_op *op, int block, NdFactor *f, cplx *ws_factor, con
     if (rc) return rc;
     SolveCtx c = solve_ctx(f, Xt, nrhs);
     c.Qt = Qt; c.Xt = Xt; c.arenaV = arenaV;
+    if (dout && dout->U && P.dof == 1 && Qt != Xt) { c.Uout = dout->U; c.oscale = dout->oscale; }
     const size_t ng = P.groups.size();
     EventSet evs;
     if (!evs.create(ng + 2, 2)) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: hipEventCreate failed");

@@ -176,7 +176,11 @@ template <int RPT, int NT_STORE>
 __global__ __launch_bounds__(256) void k_resid_nm_lds(const cplx *__restrict__ planes, int nz, int nx, const cplx *__restrict__ Xin, int ldin,
                                                       cplx *__restrict__ Q, int ldq, const int *__restrict__ qmap, int ncol, int store,
                                                       cplx *__restrict__ Rout, double *__restrict__ part, int nblk, int ntiles,
-                                                      int qnorm, cplx *__restrict__ Uout, int ldu, cplx oscale, const unsigned char *__restrict__ qm) {
+                                                      int qnorm, cplx *__restrict__ Uout, int ldu, cplx oscale, const unsigned char *__restrict__ qm, int xin_is_u) {
+    // xin_is_u: Xin holds u = conj(oscale x) (the back substitution wrote the caller's array itself): the window takes conj(u) = oscale x and q is scaled to
+    // match -- r_s = oscale q - A (oscale x) = oscale r, the relative residual is the same number (bit for bit when oscale = 1)
+    const double xsg = xin_is_u ? -1.0 : 1.0;
+    const bool qsc = xin_is_u && !(oscale.x == 1.0 && oscale.y == 0.0);
     __shared__ cplx cs[9][RPT][RESID_SEG];
     const int j = threadIdx.x;
     const bool act = j < ncol;
@@ -208,6 +212,7 @@ __global__ __launch_bounds__(256) void k_resid_nm_lds(const cplx *__restrict__ p
             win[d][1] = (zin && x0 - 1 >= 0) ? Xin[((long long)zz * nx + x0 - 1) * ldin + j] : cmake(0.0, 0.0);
             win[d][2] = zin ? Xin[((long long)zz * nx + x0) * ldin + j] : cmake(0.0, 0.0);
             pre[d] = (zin && x0 + 1 < nx) ? Xin[((long long)zz * nx + x0 + 1) * ldin + j] : cmake(0.0, 0.0);
+            win[d][1].y *= xsg; win[d][2].y *= xsg; pre[d].y *= xsg;
         }
         // qm (sparse right-hand sides): a byte per cell, bit = this wave's block of 64 columns may hold a nonzero there; a 0 bit means q is not read.
         // The bytes run one column ahead of the q loads they gate (mk: column x + 1, fetched while column x is worked on).
@@ -228,6 +233,7 @@ __global__ __launch_bounds__(256) void k_resid_nm_lds(const cplx *__restrict__ p
                 win[d][0] = win[d][1]; win[d][1] = win[d][2]; win[d][2] = pre[d];
                 cplx v = cmake(0.0, 0.0);
                 if (zz >= 0 && zz < nz && x + 1 < x1 && x + 2 < nx) v = Xin[((long long)zz * nx + x + 2) * ldin + j];
+                v.y *= xsg;
                 pre[d] = v;
             }
             #pragma unroll
@@ -244,6 +250,7 @@ __global__ __launch_bounds__(256) void k_resid_nm_lds(const cplx *__restrict__ p
                 if (z >= nz) break;
                 const long long cell = (long long)z * nx + x;
                 cplx r = qc[o];
+                if (qsc) r = cmul(oscale, r);
                 if (qnorm) accq += cabs2(r);
                 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
@@ -285,6 +292,11 @@ __global__ __launch_bounds__(256) void k_pack_cols(const cplx *__restrict__ Qt, 
     }
 }
 
+__global__ void k_recover_x(const cplx *__restrict__ U, cplx *__restrict__ X, long long n, cplx inv) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        X[i] = cmul(inv, cconj(U[i]));
+}
+
 // y += x, or y += conj(x) when y holds the conjugated wavefield  (refinement update), n elements
 __global__ void k_axpy_one(cplx *y, const cplx *x, long long n, int conj) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
@@ -315,6 +327,7 @@ int nd_resid_nm(helm_op *op, const cplx *planes, const cplx *Xin, int ldin, cplx
     const int ldu = ex ? ex->ldu : 0;
     const cplx oscale = ex ? ex->oscale : cmake(1.0, 0.0);
     const unsigned char *qmask = (ex && !qmap) ? ex->qmask : nullptr;
+    const int xin_is_u = ex ? ex->xin_is_u : 0;
     int lx = 64;
     while (lx < ncol && lx < 256) lx <<= 1;
     const int ly = 256 / lx;
@@ -335,7 +348,8 @@ int nd_resid_nm(helm_op *op, const cplx *planes, const cplx *Xin, int ldin, cplx
         if (ly == 1)        // full-width batches: four waves share a tile, its coefficients staged in LDS; the wavefield (read by nobody on the GPU) stored nontemporally
             hipLaunchKernelGGL((k_resid_nm_lds<4, 1>), dim3(nblk), dim3(256, 1), 0, op->stream, planes, op->nz, op->nx, Xin + c0, ldin, Q + (qmap ? 0 : c0), ldq,
                                qmap ? qmap + c0 : nullptr, nc, store, Rout ? Rout + (qmap ? 0 : c0) : nullptr, part + (long long)c0 * 4 * nblk, nblk, ntiles,
-                               qnorm, Uout ? Uout + c0 : nullptr, ldu, oscale, c0 == 0 ? qmask : nullptr);
+                               qnorm, Uout ? Uout + c0 : nullptr, ldu, oscale, c0 == 0 ? qmask : nullptr, xin_is_u);
+        else if (xin_is_u) HELM_FAIL(op, HELM_ERR_STATE, "node-major residual: direct output needs the full-width kernel");
         else
             hipLaunchKernelGGL(k_resid_nm<4>, dim3(nblk), dim3(lx, ly), 0, op->stream, planes, op->nz, op->nx, Xin + c0, ldin, Q + (qmap ? 0 : c0), ldq,
                                qmap ? qmap + c0 : nullptr, nc, store, Rout ? Rout + (qmap ? 0 : c0) : nullptr, part + (long long)c0 * 4 * nblk, nblk, seg, ntiles,
@@ -351,6 +365,14 @@ int nd_resid_nm(helm_op *op, const cplx *planes, const cplx *Xin, int ldin, cplx
     }
     *nblk_out = nblk;
     return check_kernels(op, "node-major residual");
+}
+
+// Xt = conj(U) / oscale (direct output: a refinement pass needs x of every cell back where the passes expect it)
+int nd_recover_x(helm_op *op, const cplx *U, cplx *Xt, long long elems, cplx oscale) {
+    const double d = oscale.x * oscale.x + oscale.y * oscale.y;
+    const cplx inv = cmake(oscale.x / d, -oscale.y / d);
+    hipLaunchKernelGGL(k_recover_x, dim3((unsigned)std::min<long long>((elems + 255) / 256, 65535)), dim3(256), 0, op->stream, U, Xt, elems, inv);
+    return check_kernels(op, "recovering x from the wavefield array");
 }
 
 int nd_scatter_add_cols(helm_op *op, cplx *Xt, int ldq, const int *d_cols, int k, const cplx *Dp, long long N) {

@@ -92,10 +92,14 @@ class WorkItem(object):
 class DevicePipeline(object):
     """Two threads for one GPU: items are prepared up to `lookahead` ahead of the one being solved."""
 
-    def __init__(self, device, lookahead=1, strict=False):
+    def __init__(self, device, lookahead=1, strict=False, solvers=1):
         self.device = device
         self.lookahead = max(0, int(lookahead))
         self.strict = bool(strict)
+        # solvers > 1: that many solve threads take the prepared items in turn, so that the launches of item k+1's solve are already queued while the
+        # host still waits for the residual norms of item k (every solve ends with a read-back the host has to look at).  The items of one pipeline
+        # must then not share buffers they write (each solve thread's items run one after the other, those of different threads side by side).
+        self.solvers = 1 if self.strict else max(1, int(solvers))
         self._threads = []
 
     def start(self, items):
@@ -108,16 +112,21 @@ class DevicePipeline(object):
             t.start()
             self._threads = [t]
             return
-        ready = queue.Queue(maxsize=self.lookahead)
+        ready = queue.Queue(maxsize=max(self.lookahead, self.solvers))
         # strict: item k+1 is prepared while item k is being solved and not before (a queue of one lets the prepare thread start on item k+2
         # as soon as item k+1 waits in it) -- for operators whose preparation is heavy on the GPU and in memory (3-D preconditioners)
         gate = threading.Semaphore(1) if self.strict else None
         tp = threading.Thread(target=self._prepare_loop, args=(items, ready, gate), name='helm-prep%d' % self.device)
-        ts = threading.Thread(target=self._solve_loop, args=(len(items), ready, gate), name='helm-solve%d' % self.device)
-        for t in (tp, ts):
+        if self.solvers == 1:
+            tss = [threading.Thread(target=self._solve_loop, args=(len(items), ready, gate), name='helm-solve%d' % self.device)]
+        else:
+            left = [len(items)]
+            lock = threading.Lock()
+            tss = [threading.Thread(target=self._solve_shared, args=(left, lock, ready), name='helm-solve%d.%d' % (self.device, k)) for k in range(self.solvers)]
+        for t in [tp] + tss:
             t.daemon = True
             t.start()
-        self._threads = [tp, ts]
+        self._threads = [tp] + tss
 
     def join(self):
         for t in self._threads:
@@ -166,6 +175,16 @@ class DevicePipeline(object):
             self._run_solve(item)
 
 
+    def _solve_shared(self, left, lock, ready):
+        'one of several solve threads: takes the next prepared item as long as there is one left to take'
+        while True:
+            with lock:
+                if left[0] <= 0:
+                    return
+                left[0] -= 1
+            self._run_solve(ready.get())
+
+
 def dispatch(workers, lookahead=1, strict=False):
     """Start one DevicePipeline per worker.  workers: [(device, [WorkItem, ...]), ...] (each list in the order it should run;
     the same device may appear twice: two pipelines then share that GPU).  Returns the pipelines (join() them, or just wait on
@@ -180,11 +199,11 @@ def dispatch(workers, lookahead=1, strict=False):
     return pipes
 
 
-def pipelined(items, device=0, lookahead=1, strict=False):
+def pipelined(items, device=0, lookahead=1, strict=False, solvers=1):
     """Run `items` on one device with prepare-ahead and yield their results in order (exceptions surface where the
     failing item's result is consumed)."""
     items = list(items)
-    pipe = DevicePipeline(device, lookahead, strict)
+    pipe = DevicePipeline(device, lookahead, strict, solvers)
     pipe.start(items)
     try:
         for item in items:
