@@ -283,7 +283,7 @@ typedef struct helm_tuning {
     int    nd_fused_leaf;      /* HELM_ND_FUSEDLEAF      1     leaf level of the factorisation in one kernel */
     int    nd_fused_leaf_min;  /* HELM_ND_FUSEDLEAF_MIN  2048  fewest leaves of a level for which it pays */
     int    nd_gjstep;          /* HELM_ND_GJSTEP         1     one launch per block step of the blocked Gauss-Jordan inversion */
-    int    nd_gjstep_min;      /* HELM_ND_GJSTEP_MIN     512   smallest front inverted that way */
+    int    nd_gjstep_min;      /* HELM_ND_GJSTEP_MIN     128   smallest front inverted that way (r5: 512 -> 128, headline +1.3 %) */
     int    nd_overlap;         /* HELM_ND_OVERLAP_NM     1     first forward pass beside the factorisation (2: also while profiling) */
     int    nd_xcd_map;         /* HELM_ND_XCDMAP         2     workgroup ids regrouped so that a front's tiles share an XCD (0 off, 1 column tiles only) */
     int    nd_plans;           /* HELM_ND_PLANS          6     elimination-tree plans cached per device */
@@ -300,7 +300,7 @@ typedef struct helm_tuning {
     int    mg3_galerkin;       /* HELM_MG3_GALERKIN      1     Galerkin operator on the directly solved level */
     int    mg3_depth_model;    /* HELM_MG3_DEPTH_MODEL   1     trade set-up seconds against booked iteration counts */
     int    mg3_bt_f32;         /* HELM_MG3_BT_F32        1     single-precision plane inverses of the block-tridiagonal coarse solve */
-    int    mg3_otf;            /* HELM_MG3_OTF           1     27-point apply rebuilds its coefficients from c, rho and the PML profiles (1: from 4 right-hand sides per workgroup up, 2: always) */
+    int    mg3_otf;            /* HELM_MG3_OTF           1     27-point apply rebuilds its coefficients from c, rho and the PML profiles (1: from 4 right-hand sides per workgroup up with the lane-shifted kernel, 2: always; 3 / 4: the same with the 27-LDS-reads kernel) */
     double mg3_omega;          /* HELM_MG3_OMEGA         0.9   Jacobi damping of the smoother */
 } helm_tuning;
 int helm_get_tuning(helm_tuning *out);          /* the values in force now (environment applied) */

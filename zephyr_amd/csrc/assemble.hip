@@ -358,12 +358,13 @@ int helm_launch_assemble(helm_op *op, double freq_re, double freq_im, double tau
         HIP_TRY(op, hipMemcpyAsync(d_xi, h.data(), bytes, hipMemcpyHostToDevice, op->stream));
         EuParams P;
         P.nz = nz; P.nx = nx; P.dx = op->dx; P.dz = op->dz; P.om = om; P.aniso = op->aniso ? 1 : 0;
-        P.nblk_out = op->block0_only ? 1 : 4;
+        P.nblk_out = op->block0_only ? 1 : (op->asm_nblk == 1 ? 1 : 4);
         hipLaunchKernelGGL(k_assemble_eurus, dim3(blocks), dim3(threads), 0, op->stream, P, op->d_c, op->d_rho,
                            op->d_theta, op->d_eps, op->d_delta, d_xi, d_xi + nx + 2, op->d_C);
         HIP_TRY(op, hipGetLastError());
         HIP_TRY(op, hipStreamSynchronize(op->stream));
         helm_pool_free(op->device, d_xi, bytes);
+        op->blocks_ready = P.nblk_out;
     }
     return HELM_OK;
 }

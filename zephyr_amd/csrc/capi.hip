@@ -54,7 +54,7 @@ helm_tuning helm_tuning_now() {
     t.nd_fused_leaf = tune_i("HELM_ND_FUSEDLEAF", 1);
     t.nd_fused_leaf_min = tune_i("HELM_ND_FUSEDLEAF_MIN", 2048);
     t.nd_gjstep = tune_i("HELM_ND_GJSTEP", 1);
-    t.nd_gjstep_min = tune_i("HELM_ND_GJSTEP_MIN", 512);
+    t.nd_gjstep_min = tune_i("HELM_ND_GJSTEP_MIN", 128);
     t.nd_overlap = tune_i("HELM_ND_OVERLAP_NM", 1);
     t.nd_xcd_map = tune_i("HELM_ND_XCDMAP", 2);
     t.nd_plans = std::max(1, tune_i("HELM_ND_PLANS", 6));
@@ -507,6 +507,10 @@ extern "C" int helm_assemble(helm_op *op, double freq_re, double freq_im, double
     if (!op->has_model) HELM_FAIL(op, HELM_ERR_STATE, "helm_set_model must be called before helm_assemble");
     HIP_TRY(op, hipSetDevice(op->device));
     helm_pf_retire(op);                          // a factorisation still in flight belongs to the operator that is being replaced
+    // Eurus with eps == delta is block-triangular and an N-row right-hand side (what the surveys bring, eurus.py:512-533) touches M1 alone: M2 .. M4 -- three
+    // quarters of the 604 MB the assembly writes at 1024^2 -- are built when something asks for them (helm_need_all_blocks: a stacked 2N right-hand side,
+    // helm_get_diagonals, an apply of another block, the scaled planes of the Krylov paths)
+    op->asm_nblk = (op->variant == HELM_EURUS && op->block_zero[2] && !op->block0_only && helm_tuning_now().auto_direct != 0) ? 1 : 4;
     int rc = op->ny > 0 ? helm3d_launch_assemble(op, freq_re, freq_im, tau, cPML) : helm_launch_assemble(op, freq_re, freq_im, tau, ky, cPML);
     if (rc) return rc;
     op->scaled_ok = false;
@@ -521,8 +525,15 @@ extern "C" int helm_assemble(helm_op *op, double freq_re, double freq_im, double
     return HELM_OK;
 }
 
+int helm_need_all_blocks(helm_op *op) {
+    if (op->variant != HELM_EURUS || op->block0_only || op->ny > 0 || !op->assembled || op->blocks_ready >= op->nblocks) return HELM_OK;
+    op->asm_nblk = 4;                            // (M1 is written again with the same values: a factorisation reading it meanwhile sees no change)
+    return helm_launch_assemble(op, op->a_freq_re, op->a_freq_im, op->a_tau, op->a_ky, op->a_cpml);
+}
+
 int helm_ensure_scaled(helm_op *op) {
     if (op->scaled_ok) return HELM_OK;
+    { const int rcb = helm_need_all_blocks(op); if (rcb) return rcb; }
     const size_t N = (size_t)op->N;
     if (!op->d_Cs) op->d_Cs = (cplx *)helm_pool_alloc(op->device, (size_t)op->nblocks * op->nplanes * N * sizeof(cplx));
     if (!op->d_dinv) op->d_dinv = (cplx *)helm_pool_alloc(op->device, (size_t)op->nblocks * N * sizeof(cplx));
@@ -537,6 +548,7 @@ extern "C" int helm_get_diagonals(helm_op *op, double *out) {
     if (!op || !out) return HELM_ERR_ARG;
     if (!op->assembled) HELM_FAIL(op, HELM_ERR_STATE, "operator not assembled");
     HIP_TRY(op, hipSetDevice(op->device));
+    { const int rcb = helm_need_all_blocks(op); if (rcb) return rcb; }
     HIP_TRY(op, hipMemcpy(out, op->d_C, (size_t)op->nblocks * op->nplanes * op->N * sizeof(cplx), hipMemcpyDeviceToHost));
     return HELM_OK;
 }
@@ -618,6 +630,7 @@ extern "C" int helm_apply_device(helm_op *op, int block, int adjoint, const void
     if (!op || !dX || !dY || nrhs < 1 || block < 0 || block >= op->nblocks) return HELM_ERR_ARG;
     if (!op->assembled) HELM_FAIL(op, HELM_ERR_STATE, "operator not assembled");
     HIP_TRY(op, hipSetDevice(op->device));
+    if (block > 0) { const int rcb = helm_need_all_blocks(op); if (rcb) return rcb; }
     timing_begin(op);
     ApplyArgs a = ApplyArgs();
     a.planes = op->d_C + (long long)block * op->nplanes * op->N; a.X = (const cplx *)dX; a.Y = (cplx *)dY; a.W = nullptr;
@@ -1793,6 +1806,7 @@ extern "C" int helm_solve_device(helm_op *op, const void *dRHS, void *dU, int nr
     if (rows != N && !stacked) HELM_FAIL(op, HELM_ERR_ARG, "dimension mismatch: rhs has %lld rows, operator has %lld%s", rows, N,
                                          op->variant == HELM_EURUS ? " (or 2N stacked)" : "");
     HIP_TRY(op, hipSetDevice(op->device));
+    if (stacked) { const int rcb = helm_need_all_blocks(op); if (rcb) return rcb; }      // (u = M1^-1 (q1 - M2 M4^-1 q2): M2 and M4 are needed now)
     if (op->rhs_bits && (op->rhs_bits_rows != rows || op->rhs_bits_nrhs != nrhs)) HELM_FAIL(op, HELM_ERR_ARG, "helm_set_rhs_support was given %lld rows x %d right-hand sides, this solve has %lld x %d", op->rhs_bits_rows, op->rhs_bits_nrhs, rows, nrhs);
     op->rhs_bits_q = op->rhs_bits ? dRHS : nullptr;
     helm_solve_opts o;

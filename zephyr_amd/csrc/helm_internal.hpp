@@ -18,6 +18,13 @@ __host__ __device__ inline cplx cadd(cplx a, cplx b) { return cmake(a.x + b.x, a
 __host__ __device__ inline cplx csub(cplx a, cplx b) { return cmake(a.x - b.x, a.y - b.y); }
 __host__ __device__ inline cplx cmul(cplx a, cplx b) { return cmake(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __host__ __device__ inline cplx cscale(cplx a, double s) { return cmake(a.x * s, a.y * s); }
+// conj(s * x) with the floating-point contraction pinned: the wavefield u = conj(premul x) is formed by different kernels on different paths (the residual launch,
+// the epilogue of the back substitution, the transposes) and has to come out bit for bit the same from all of them
+__host__ __device__ inline cplx conj_scaled(cplx s, cplx x) {
+    // (explicit fused operations: nothing is left for the compiler to contract one way in one kernel and another way in the next)
+    const double re = fma(s.x, x.x, -(s.y * x.y)), im = fma(s.x, x.y, s.y * x.x);
+    return cmake(re, -im);
+}
 __host__ __device__ inline cplx cconj(cplx a) { return cmake(a.x, -a.y); }
 __host__ __device__ inline cplx cneg(cplx a) { return cmake(-a.x, -a.y); }
 __host__ __device__ inline double cabs2(cplx a) { return a.x * a.x + a.y * a.y; }
@@ -142,6 +149,7 @@ struct helm_op {
     cplx *d_S = nullptr;      // coupled Eurus system: the four blocks scaled by the inverse 2-norm of their system row (36N), on demand
     double *d_rs = nullptr;   // 2N inverse row norms of the 2N x 2N system
     bool assembled = false;
+    int asm_nblk = 4, blocks_ready = 0;   // Eurus: blocks the next assembly writes (1: M1 only -- the block-triangular N-row solve needs nothing else) / blocks d_C holds now
     bool scaled_ok = false;       // d_Cs / d_dinv hold the current operator (made on demand: only the Krylov paths need them)
     bool block_zero[4] = {false, false, false, false};   // block is identically zero (e.g. Eurus M3 isotropic)
 
@@ -189,6 +197,7 @@ hipStream_t helm_stream_acquire(int device, int prio);    // prio 0 normal, 1 hi
 void helm_stream_release(int device, int prio, hipStream_t s);
 void helm_pf_retire(helm_op *op);                         // wait for / book / clean up a factorisation started by helm_prefactor
 int helm_ensure_scaled(helm_op *op);
+int helm_need_all_blocks(helm_op *op);                   // Eurus operators assembled lazily (M1 only): bring M2..M4 into being before anything reads them
 int helm_events_grow(helm_op *op, int n);                 // n more timing events for the handle (recycled across handles)                      // d_Cs, d_dinv for the operator currently assembled
 
 // ---- multigrid preconditioner (mg.hip) ---------------------------------------------------------

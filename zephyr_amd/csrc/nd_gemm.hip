@@ -93,7 +93,9 @@ int choose_tile(int M, int Nn, int K, int batch, const GemmRows *rows, bool *lat
     if (rows && rows->fwd3 && M <= 64 && !*latency_mode) vsel = 0;
     // rank-32 updates of one large matrix (blocked Gauss-Jordan of the 3-D plane inverses): HBM-bound, the 64 x 32 tile is the fastest
     if (rows && rows->dense && K <= 32 && !*latency_mode && batch == 1) vsel = 3;
-    if (g_gemm_tile >= 0) { vsel = g_gemm_tile & 7; *latency_mode = false; }
+    // (round 5 measured a 128 x 64 tile -- WM x WN = 2 x 2 waves of 4 x 2 blocks, 216-224 VGPRs -- on the large Schur / G21 products: 56.8 against 57.5 TFLOP/s on
+    // 1024 x 1024 x 256 x 16, 46 against 52 on the 1281-row fronts, headline -1.6 %: the 64 x 64 tile is not bound by its operand traffic; HISTORY.md / profiles/r05_zgemm_lab.txt)
+    if (g_gemm_tile >= 0) { vsel = g_gemm_tile & 15; *latency_mode = false; }
     // the fused update + sweep launch exists for two tiles: 64 x 32 (large matrices) and the 32 x 32 latency tile (under-filled launches)
     if (rows && rows->la) vsel = *latency_mode ? 6 : 3;
     if (rows && rows->tm64 && M <= 64) { vsel = Nn <= 32 ? 3 : 0; *latency_mode = false; }
@@ -180,6 +182,7 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
             case 5: ZG_MFMA(1, 4, 1, 2, 8); break;
             case 6: ZG_MFMA(2, 2, 1, 1, 8); break;
             case 8: ZG_MFMA(4, 1, 2, 1, 8); break;
+            case 9: ZG_MFMA(2, 2, 4, 2, 8); break;        // 128 x 64 (tools/zgemm_lab.py only)
             default: ZG_MFMA(1, 4, 1, 1, 8); break;
         }
 #undef ZG_MFMA

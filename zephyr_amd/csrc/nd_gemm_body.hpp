@@ -356,10 +356,10 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
                 cplx v = cmul(alpha, cmake(cr[i][j][q], ci[i][j][q]));
                 if (IDX == 4) v = cadd(cv[q][j], v);
                 else v = cadd(v, cmul(beta, cv[q][j]));
-                if (IDX == 1 && R.cj_out) v = cconj(cmul(R.oscale, v));
+                if (IDX == 1 && R.cj_out) v = conj_scaled(R.oscale, v);
                 if (R.ntc) __builtin_nontemporal_store((v2f64){v.x, v.y}, reinterpret_cast<v2f64 *>(dstq[q] + cc)); else dstq[q][cc] = v;
                 if (IDX == 1 && R.Cox2) {                         // (the caller's wavefield array: written once, read by the residual check only)
-                    const cplx u = cconj(cmul(R.oscale, v));
+                    const cplx u = conj_scaled(R.oscale, v);
                     __builtin_nontemporal_store((v2f64){u.x, u.y}, reinterpret_cast<v2f64 *>(dstq[q] + (R.Cox2 - R.Cox) + cc));
                 }
             }
@@ -389,9 +389,9 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
             if (keep) {
                 cplx v = cmul(alpha, xacc);
                 if (!b0 && cin) v = cadd(v, cmul(beta, cin[cc]));
-                if (IDX == 1 && R.cj_out) v = cconj(cmul(R.oscale, v));
+                if (IDX == 1 && R.cj_out) v = conj_scaled(R.oscale, v);
                 dst[cc] = v;
-                if (IDX == 1 && R.Cox2 && R.tabCo) { const cplx u = cconj(cmul(R.oscale, v)); dst[(R.Cox2 - R.Cox) + cc] = u; }
+                if (IDX == 1 && R.Cox2 && R.tabCo) { const cplx u = conj_scaled(R.oscale, v); dst[(R.Cox2 - R.Cox) + cc] = u; }
             }
         }
     }

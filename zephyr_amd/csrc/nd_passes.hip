@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void k_nd_bwd_store(const int4 *tab, const cpl
         for (int r = threadIdx.x; r < nrhs; r += blockDim.x) dst[r] = src[r];
         if (U2) {
             cplx *d2 = U2 + (long long)e.x * nrhs;
-            for (int r = threadIdx.x; r < nrhs; r += blockDim.x) d2[r] = cconj(cmul(oscale, src[r]));
+            for (int r = threadIdx.x; r < nrhs; r += blockDim.x) d2[r] = conj_scaled(oscale, src[r]);
         }
     }
 }

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_resid_nm(const cplx *__restrict__ plane
                     r.y = fma(-c.x, xv.y, r.y); r.y = fma(-c.y, xv.x, r.y);
                 }
                 if (store) (Rout ? Rout : Q)[cell * ldq + col] = r;
-                if (Uout) Uout[cell * ldu + j] = cconj(cmul(oscale, win[o + 1][1]));
+                if (Uout) Uout[cell * ldu + j] = conj_scaled(oscale, win[o + 1][1]);
                 acc += cabs2(r);
             }
         }
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void k_resid_nm_lds(const cplx *__restrict__ p
                 }
                 if (store) (Rout ? Rout : Q)[cell * ldq + col] = r;
                 if (Uout) {                                   // written once, read by nobody on the GPU: past the caches
-                    const cplx u = cconj(cmul(oscale, win[o + 1][1]));
+                    const cplx u = conj_scaled(oscale, win[o + 1][1]);
                     if (NT_STORE) __builtin_nontemporal_store((v2f64){u.x, u.y}, reinterpret_cast<v2f64 *>(Uout + cell * ldu + j));
                     else Uout[cell * ldu + j] = u;
                 }

@@ -136,7 +136,11 @@ class HelmBaseSurvey(BaseSCCache):
         return data
 
     def getResidualSources(self, resid):
-        'back-sources qb[f][:, s] = R_s^T resid[:, s, f] (survey.py:171-188)'
+        """back-sources qb[f][:, s] = R_s^T resid[:, s, f] (survey.py:171-188).  With a fixed receiver array every source shares one R, and the nsrc
+        sparse products per frequency of the reference collapse into one, R^T (resid[:, :, f]) -- the same columns, built in one call."""
+        if self.mode == 'fixed':
+            Rt = sp.csc_matrix(self.rVec(0).T)
+            return [sp.csr_matrix(Rt * sp.csc_matrix(np.ascontiguousarray(resid[:, :, ifreq]))) for ifreq in range(self.nfreq)]
         return [sp.hstack([self.rVec(isrc).T * sp.csc_matrix(resid[:, isrc, ifreq].reshape((self.nrec, 1)))
                            for isrc in range(self.nsrc)])
                 for ifreq in range(self.nfreq)]
