@@ -300,7 +300,7 @@ typedef struct helm_tuning {
     int    mg3_galerkin;       /* HELM_MG3_GALERKIN      1     Galerkin operator on the directly solved level */
     int    mg3_depth_model;    /* HELM_MG3_DEPTH_MODEL   1     trade set-up seconds against booked iteration counts */
     int    mg3_bt_f32;         /* HELM_MG3_BT_F32        1     single-precision plane inverses of the block-tridiagonal coarse solve */
-    int    mg3_otf;            /* HELM_MG3_OTF           1     27-point apply rebuilds its coefficients from c, rho and the PML profiles (1: from 4 right-hand sides per workgroup up with the lane-shifted kernel, 2: always; 3 / 4: the same with the 27-LDS-reads kernel) */
+    int    mg3_otf;            /* HELM_MG3_OTF           1     27-point apply rebuilds its coefficients from c, rho and the PML profiles (1: from 4 right-hand sides per workgroup up, 2: always) */
     double mg3_omega;          /* HELM_MG3_OMEGA         0.9   Jacobi damping of the smoother */
 } helm_tuning;
 int helm_get_tuning(helm_tuning *out);          /* the values in force now (environment applied) */

@@ -33,9 +33,8 @@ def test_3d_coefficients_and_apply_match_oracle(helm_lib):
 def test_3d_apply_with_coefficients_rebuilt_on_the_fly(helm_lib, monkeypatch, nrhs):
     """Round 5 (SURVEY.md 7 hard-part 6): from 4 right-hand sides up the 27-point apply rebuilds its coefficients from K = om^2 / (rho c^2),
     b = 1 / rho (24 B per point through the tile's LDS) and the three per-axis factor tables instead of reading 27 stored planes (432 B per point).  Against
-    oracle/helm3d_oracle.py to 1e-12 on a heterogeneous, complex-velocity model with anisotropic spacing and damping; the kernel that keeps the 27 LDS reads
-    is BIT FOR BIT the stored-plane apply (both build a coefficient with the same contraction-pinned function), the lane-shifted kernel (three partial sums per
-    lane, two of them exchanged with the neighbour lanes by DPP) agrees to rounding."""
+    oracle/helm3d_oracle.py to 1e-12 on a heterogeneous, complex-velocity model with anisotropic spacing and damping, and BIT FOR BIT the stored-plane apply
+    (HELM_MG3_OTF=0): both build a coefficient with the same contraction-pinned function."""
     import zephyr_amd as za
     nz, ny, nx = 20, 26, 70                  # x not a multiple of the 64-wide tile, y not a multiple of 4
     rng = np.random.default_rng(50 + nrhs)
@@ -46,15 +45,13 @@ def test_3d_apply_with_coefficients_rebuilt_on_the_fly(helm_lib, monkeypatch, nr
     X = rng.standard_normal((nz * ny * nx, nrhs)) + 1j * rng.standard_normal((nz * ny * nx, nrhs))
     ref = h3.stencil_apply3(C, X)
     out = {}
-    # 2: the lane-shifted kernel wherever possible (1, the default: from 4 right-hand sides per workgroup up); 4: the 27-reads kernel on the fly; 0: stored planes
-    for mode in ('2', '4', '0'):
+    for mode in ('2', '0'):                    # 2: on the fly whatever the batch width (1, the default: from 4 right-hand sides per workgroup up); 0: stored planes
         monkeypatch.setenv('HELM_MG3_OTF', mode)
         op = za.Helm3D(cfg)
         assert np.abs(op.diagonals() - C).max() <= 1e-12 * np.abs(C).max()
         out[mode] = op.applyForward(X)
         assert np.abs(out[mode] - ref).max() <= 1e-12 * np.abs(ref).max(), mode
-    assert np.array_equal(out['4'], out['0'])                   # same kernel body, coefficients rebuilt bit for bit
-    assert np.abs(out['2'] - out['0']).max() <= 1e-13 * np.abs(ref).max()       # another order of summation (three partial sums per lane)
+    assert np.array_equal(out['2'], out['0'])                   # same kernel body, coefficients rebuilt bit for bit
 
 
 def test_3d_solve_matches_sparse_lu(helm_lib):

@@ -291,171 +291,11 @@ __global__ __launch_bounds__(256) void k_stencil3(Stencil3Params q) {
     }
 }
 
-// ---- the same apply with lane-shifted partial sums (round 5) --------------------------------------------------------------------------------
-// In k_stencil3 a thread reads its 27 neighbours from LDS: 27 x 16 B per output and right-hand side, and at 8-16 right-hand sides the LDS pipe, not HBM,
-// bounds the kernel.  Here the lanes of a wave are 64 consecutive x and a thread reads only the nine values of ITS OWN x column, (oy, oz) in 3 x 3, and
-// forms three sums with them:
-//     A_j = sum c_j(0, oy, oz) v_j          its own output's centre-column terms
-//     P_j = sum c_{j-1}(+1, oy, oz) v_j     what x_j contributes to the output one lane down
-//     M_j = sum c_{j+1}(-1, oy, oz) v_j     what it contributes to the output one lane up
-// and the output is  y_j = A_j + P_{j+1} + M_{j-1}: two complex values cross lanes (eight v_mov_b32_dpp wave_shl / wave_shr) instead of eighteen operands
-// crossing LDS.  A thread therefore holds its NEIGHBOURS' coefficients for the P and M sums (27 in all, as before), rebuilt on the fly like in
-// k_stencil3<.., OTF>.  Lanes 0 and 63 of a wave are halo lanes: they load their column and feed their neighbour, and have no output -- a wave covers
-// 62 outputs in x, the code is the same for every lane and no halo column goes through a conditional load.
-constexpr int T3W = 62;
-__device__ __forceinline__ cplx wave_from_next(cplx src) {              // lane l <- lane l + 1 (lane 63: 0)
-    const int4 v = *reinterpret_cast<const int4 *>(&src);
-    int4 r;
-    r.x = __builtin_amdgcn_update_dpp(0, v.x, 0x130, 0xf, 0xf, false); r.y = __builtin_amdgcn_update_dpp(0, v.y, 0x130, 0xf, 0xf, false);
-    r.z = __builtin_amdgcn_update_dpp(0, v.z, 0x130, 0xf, 0xf, false); r.w = __builtin_amdgcn_update_dpp(0, v.w, 0x130, 0xf, 0xf, false);
-    return *reinterpret_cast<const cplx *>(&r);
-}
-__device__ __forceinline__ cplx wave_from_prev(cplx src) {              // lane l <- lane l - 1 (lane 0: 0)
-    const int4 v = *reinterpret_cast<const int4 *>(&src);
-    int4 r;
-    r.x = __builtin_amdgcn_update_dpp(0, v.x, 0x138, 0xf, 0xf, false); r.y = __builtin_amdgcn_update_dpp(0, v.y, 0x138, 0xf, 0xf, false);
-    r.z = __builtin_amdgcn_update_dpp(0, v.z, 0x138, 0xf, 0xf, false); r.w = __builtin_amdgcn_update_dpp(0, v.w, 0x138, 0xf, 0xf, false);
-    return *reinterpret_cast<const cplx *>(&r);
-}
-
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void k_stencil3w(Stencil3Params q) {
-    constexpr int LW = 64, LH = T3Y + 2;                // one staged plane: LH rows of the wave's 64 columns (x0 - 1 ... x0 + 62)
-    constexpr int PLANE = LW * LH;                      // 384 elements
-    constexpr int NEL = 3 * PLANE;
-    constexpr int NLOAD = (NEL + 255) / 256;
-    __shared__ __attribute__((aligned(16))) cplx tile[2][NEL];
-    __shared__ double red[16];
-    const int tid = threadIdx.x, lane = tid & 63, wy = tid >> 6;
-    const int t = xcd_swizzle3(blockIdx.x, q.nblk);
-    const int iz = t % q.nz, tx = (t / q.nz) % q.ntx, ty = t / (q.nz * q.ntx);        // z fastest (see k_stencil3)
-    const int x0 = tx * T3W, y0 = ty * T3Y;
-    const int nz = q.nz, ny = q.ny, nx = q.nx;
-    const int col = x0 - 1 + lane, row = y0 + wy;
-    const bool in0 = col >= 0 && col < nx && row < ny;                                   // this lane's own point exists
-    const bool ok = in0 && lane >= 1 && lane <= T3W;                                     // ... and is one of the wave's outputs
-    const long long idx = ((long long)iz * ny + row) * nx + col;
-
-    cplx c0[9], cp[9], cm[9];
-    {
-        cplx *Kt = &tile[0][0];
-        double *bt = reinterpret_cast<double *>(&tile[1][0]);
-        for (int e = tid; e < NEL; e += 256) {
-            const int p = e / PLANE, rem = e - p * PLANE, r = rem / LW, cc = rem - r * LW;
-            const int gz = iz - 1 + p, gy = y0 - 1 + r, gx = x0 - 1 + cc;
-            cplx kv = cmake(0.0, 0.0); double bv = 0.0;
-            if (gz >= 0 && gz < nz && gy >= 0 && gy < ny && gx >= 0 && gx < nx) { const long long j = ((long long)gz * ny + gy) * nx + gx; kv = q.K3[j]; bv = q.b3[j]; }
-            Kt[e] = kv; bt[e] = bv;
-        }
-        __syncthreads();
-        const bool inner_yz = row > 0 && row < ny - 1 && iz > 0 && iz < nz - 1;             // (edge points are identity rows)
-        const bool live0 = in0 && inner_yz && col > 0 && col < nx - 1;
-        const bool liveL = lane >= 1 && row < ny && inner_yz && col - 1 > 0 && col - 1 < nx - 1;       // the point one lane down is an interior point
-        const bool liveR = lane <= 62 && row < ny && inner_yz && col + 1 > 0 && col + 1 < nx - 1;
-        const int ce = PLANE + (wy + 1) * LW + lane;                // this lane's own cell in the middle staged plane
-        const double b0 = bt[ce], bL = bt[lane >= 1 ? ce - 1 : ce], bR = bt[lane <= 62 ? ce + 1 : ce];
-        const cplx zero = cmake(0.0, 0.0);
-        cplx lyv[3], lzv[3];
-#pragma unroll
-        for (int o = 0; o < 3; ++o) { lyv[o] = row < ny ? q.Ly[(long long)o * ny + row] : zero; lzv[o] = q.Lz[(long long)o * nz + iz]; }
-        const cplx lx0 = live0 ? q.Lx[(long long)nx + col] : zero;                          // Lx(0) at col
-        const cplx lxL = liveL ? q.Lx[2LL * nx + col - 1] : zero;                           // Lx(+1) at col - 1
-        const cplx lxR = liveR ? q.Lx[col + 1] : zero;                                      // Lx(-1) at col + 1
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const int pr = 3 * p + r;
-                const int e = p * PLANE + (wy + r) * LW + lane;                  // the neighbour (., oy, oz) in this lane's own column
-                const double bj = bt[e]; const cplx Kj = Kt[e];
-                if (live0) c0[pr] = coeff3(0, r - 1, p - 1, lx0, lyv[r], lzv[p], q.idx2, q.idy2, q.idz2, b0, bj, Kj, q.blend);
-                else c0[pr] = (pr == 4 && in0) ? cmake(1.0, 0.0) : zero;
-                cp[pr] = liveL ? coeff3(1, r - 1, p - 1, lxL, lyv[r], lzv[p], q.idx2, q.idy2, q.idz2, bL, bj, Kj, q.blend) : zero;
-                cm[pr] = liveR ? coeff3(-1, r - 1, p - 1, lxR, lyv[r], lzv[p], q.idx2, q.idy2, q.idz2, bR, bj, Kj, q.blend) : zero;
-            }
-        __syncthreads();                                            // the tile buffers go back to the right-hand sides
-    }
-
-    cplx pre[NLOAD];
-    auto prefetch = [&](int b) {
-        const cplx *Xb = q.X + (long long)b * q.ld;
-#pragma unroll
-        for (int l = 0; l < NLOAD; ++l) {
-            const int e = tid + 256 * l;
-            cplx v = cmake(0.0, 0.0);
-            if (e < NEL) {
-                const int p = e / PLANE, rem = e - p * PLANE, r = rem / LW, cc = rem - r * LW;
-                const int gz = iz - 1 + p, gy = y0 - 1 + r, gx = x0 - 1 + cc;
-                if (gz >= 0 && gz < nz && gy >= 0 && gy < ny && gx >= 0 && gx < nx) v = Xb[((long long)gz * ny + gy) * nx + gx];
-            }
-            pre[l] = v;
-        }
-    };
-    auto stage = [&](int buf) {
-#pragma unroll
-        for (int l = 0; l < NLOAD; ++l) {
-            const int e = tid + 256 * l;
-            if (e < NEL) tile[buf][e] = pre[l];
-        }
-    };
-    const int bstep = gridDim.y;
-    int b = blockIdx.y;
-    auto active = [&](int bb) { return q.scal == nullptr || q.scal[bb].status == ST_ACTIVE; };
-    while (b < q.nrhs && !active(b)) b += bstep;
-    if (b < q.nrhs) prefetch(b);
-    int buf = 0;
-    while (b < q.nrhs) {
-        stage(buf);
-        int bn = b + bstep;
-        while (bn < q.nrhs && !active(bn)) bn += bstep;
-        if (bn < q.nrhs) prefetch(bn);
-        __syncthreads();
-        cplx sa = cmake(0.0, 0.0), sp_ = cmake(0.0, 0.0), sm = cmake(0.0, 0.0), xc = cmake(0.0, 0.0);
-        const cplx *tb = &tile[buf][wy * LW + lane];
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const int pr = 3 * p + r;
-                const cplx xv = tb[p * PLANE + r * LW];
-                cfma(sa, c0[pr], xv);
-                cfma(sp_, cp[pr], xv);
-                cfma(sm, cm[pr], xv);
-                if (pr == 4) xc = xv;
-            }
-        const cplx acc = cadd(sa, cadd(wave_from_next(sp_), wave_from_prev(sm)));
-        double dsum[4] = {0.0, 0.0, 0.0, 0.0};
-        if (ok) {
-            cplx y = acc;
-            const long long g = (long long)b * q.ld + idx;
-            if (EPI == EPI_RESID) { const cplx w = q.W[g]; y = csub(w, y); dsum[0] += cabs2(y); }
-            else if (EPI == EPI_DOT_W) { const cplx w = q.W[g]; dsum[0] += w.x * y.x + w.y * y.y; dsum[1] += w.x * y.y - w.y * y.x; }
-            else if (EPI == EPI_DOT_XY) { dsum[0] += y.x * xc.x + y.y * xc.y; dsum[1] += y.x * xc.y - y.y * xc.x; dsum[2] += cabs2(y); }
-            else if (EPI == EPI_DOT_YY) { dsum[0] += cabs2(y); }
-            else if (EPI == EPI_DOT_WY) { const cplx w = q.W[g]; dsum[0] += y.x * w.x + y.y * w.y; dsum[1] += y.x * w.y - y.y * w.x; dsum[2] += cabs2(y); }
-            else if (EPI == EPI_JACOBI) { const cplx res = csub(q.W[g], y); y = xc; cfma(y, cscale(q.dinv[idx], q.omega_j), res); }
-            q.Y[g] = y;
-        }
-        if (EPI != EPI_NONE && EPI != EPI_JACOBI) {
-            const int wave = tid >> 6;
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) dsum[qq] = wave_sum3(dsum[qq]);
-            if (lane == 0) { red[wave * 4 + 0] = dsum[0]; red[wave * 4 + 1] = dsum[1]; red[wave * 4 + 2] = dsum[2]; red[wave * 4 + 3] = dsum[3]; }
-            __syncthreads();
-            if (tid == 0) {
-                double *pp = q.part + ((long long)b * 4) * q.npart + blockIdx.x;
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) pp[(long long)qq * q.npart] = (red[qq] + red[4 + qq]) + (red[8 + qq] + red[12 + qq]);
-                if (q.nblk + (int)blockIdx.x < q.npart)
-#pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) pp[(long long)qq * q.npart + q.nblk] = 0.0;
-            }
-            __syncthreads();
-        }
-        buf ^= 1;
-        b = bn;
-    }
-}
+// (Round 5 measured a lane-shifted form of this kernel -- a thread reads only the nine values of its own x column from LDS and forms three partial sums, two
+// of which cross to the neighbour lanes as v_mov_b32_dpp wave_shl / wave_shr values; lanes 0 and 63 as halo lanes, 62 outputs per wave -- 9 LDS reads per output
+// instead of 27: 2426 us at 16 right-hand sides against 2188 us for the kernel above, 1493 against 1348 at 8.  A third of the LDS traffic bought 10 % per tile,
+// the 62-wide tiling costs 25 % more tiles at nx = 256: the launch is bound by the latency of staging 3 x 396 elements per 256 outputs with one right-hand side
+// of prefetch in flight at two workgroups per compute unit (the 27 coefficients are 108 of the 203-210 VGPRs), not by LDS reads.  Removed; HISTORY.md.)
 
 void profile3(int n, int npml, double h, double cpml, std::complex<double> om, std::vector<cplx> &Lt) {
     // padded stretch profile xi and the three Laplacian factor arrays L(-1), L(0), L(+1)
@@ -524,22 +364,7 @@ int helm3d_launch_assemble(helm_op *op, double freq_re, double freq_im, double t
 }
 
 int helm3d_apply_num_blocks(const helm_op *op) {
-    // partial sums per right-hand side a reduction after an apply reads: the larger of the two kernels' workgroup counts (the other zeroes the rest)
-    const int nty = (op->ny + T3Y - 1) / T3Y;
-    return std::max((op->nx + T3X - 1) / T3X, (op->nx + T3W - 1) / T3W) * nty * op->nz;
-}
-
-static void launch3_w(hipStream_t st, dim3 grid, const Stencil3Params &q, int epi) {
-    switch (epi) {
-    case EPI_NONE: hipLaunchKernelGGL((k_stencil3w<EPI_NONE>), grid, dim3(256), 0, st, q); break;
-    case EPI_DOT_W: hipLaunchKernelGGL((k_stencil3w<EPI_DOT_W>), grid, dim3(256), 0, st, q); break;
-    case EPI_DOT_XY: hipLaunchKernelGGL((k_stencil3w<EPI_DOT_XY>), grid, dim3(256), 0, st, q); break;
-    case EPI_DOT_YY: hipLaunchKernelGGL((k_stencil3w<EPI_DOT_YY>), grid, dim3(256), 0, st, q); break;
-    case EPI_RESID: hipLaunchKernelGGL((k_stencil3w<EPI_RESID>), grid, dim3(256), 0, st, q); break;
-    case EPI_DOT_WY: hipLaunchKernelGGL((k_stencil3w<EPI_DOT_WY>), grid, dim3(256), 0, st, q); break;
-    case EPI_JACOBI: hipLaunchKernelGGL((k_stencil3w<EPI_JACOBI>), grid, dim3(256), 0, st, q); break;
-    default: break;
-    }
+    return ((op->nx + T3X - 1) / T3X) * ((op->ny + T3Y - 1) / T3Y) * op->nz;
 }
 
 static void launch3_otf(hipStream_t st, dim3 grid, const Stencil3Params &q, int epi) {
@@ -582,22 +407,15 @@ int helm3d_launch_apply(helm_op *op, const ApplyArgs &a, hipEvent_t e0, hipEvent
     dim3 grid(q.nblk, split);
     // coefficients on the fly: this operator's own planes (not a caller's override), unscaled, enough right-hand sides per workgroup to amortise the rebuild
     const int per_wg = (a.nrhs + split - 1) / split;
-    // mg3_otf: 0 stored planes; 1 on the fly where it pays (from 4 right-hand sides per workgroup up) with the lane-shifted kernel; 2 the same wherever it is
-    // possible (tests); 3 / 4: like 1 / 2 with the 27-reads-from-LDS kernel (k_stencil3<.., OTF>)
+    // mg3_otf: 0 stored planes; 1 on the fly where it pays (from 4 right-hand sides per workgroup up); 2 wherever it is possible (tests)
     const int otf_mode = helm_tuning_now().mg3_otf;
-    const bool otf = op->otf3 && a.planes == op->d_C && !a.scaled && (otf_mode == 2 || otf_mode == 4 || ((otf_mode == 1 || otf_mode == 3) && per_wg >= 4));
-    const bool wshift = otf && otf_mode <= 2;
+    const bool otf = op->otf3 && a.planes == op->d_C && !a.scaled && (otf_mode == 2 || (otf_mode == 1 && per_wg >= 4));
     q.K3 = op->d_K3; q.b3 = op->d_b3; q.Lx = op->d_L3; q.Ly = op->d_L3 ? op->d_L3 + 3 * (size_t)op->nx : nullptr;
     q.Lz = op->d_L3 ? op->d_L3 + 3 * (size_t)op->nx + 3 * (size_t)op->ny : nullptr;
     q.idx2 = op->otf_idx2; q.idy2 = op->otf_idy2; q.idz2 = op->otf_idz2; q.blend = op->otf_blend;
     q.npart = helm3d_apply_num_blocks(op);
-    if (wshift) {
-        q.ntx = (op->nx + T3W - 1) / T3W; q.nblk = q.ntx * q.nty * op->nz;
-        grid = dim3(q.nblk, split);
-    }
     if (e0) hipEventRecord(e0, op->stream);
-    if (wshift) launch3_w(op->stream, grid, q, a.epi);
-    else if (otf) launch3_otf(op->stream, grid, q, a.epi);
+    if (otf) launch3_otf(op->stream, grid, q, a.epi);
     else if (a.scaled) launch3_epi<true>(op->stream, grid, q, a.epi);
     else launch3_epi<false>(op->stream, grid, q, a.epi);
     if (e1) hipEventRecord(e1, op->stream);

@@ -288,16 +288,28 @@ class BaseDiscretization(BaseModelDependent):
         matrix q (nrow x ncols) without densifying it on the host: only the COO triplets cross PCIe.'''
         import torch
         lib = _lib.load()
-        coo = sp.coo_matrix(q)
-        coo.sum_duplicates()
+        if isinstance(q, tuple):                 # (rows, cols, values, shape): triplets the caller has made itself, no two of them at the same place
+            r_, c_, v_, shape = q
+            nnz = int(len(v_))
+        else:
+            # duplicates are summed where they can exist at all: a CSR / CSC matrix in canonical form has none, and its COO view needs no sort
+            if sp.isspmatrix_csr(q) or sp.isspmatrix_csc(q):
+                if not q.has_canonical_format:
+                    q = q.copy()
+                    q.sum_duplicates()
+                coo = q.tocoo(copy=False)
+            else:
+                coo = sp.coo_matrix(q)
+                coo.sum_duplicates()
+            r_, c_, v_, shape, nnz = coo.row, coo.col, coo.data, coo.shape, int(coo.nnz)
         dev = torch.device('cuda', self.device)
-        row = torch.from_numpy(np.ascontiguousarray(coo.row, dtype=np.int64)).to(dev)
-        col = torch.from_numpy(np.ascontiguousarray(coo.col, dtype=np.int32)).to(dev)
-        val = torch.from_numpy(np.ascontiguousarray(coo.data, dtype=np.complex128)).to(dev)
-        torch.cuda.synchronize(dev)
+        row = torch.from_numpy(np.ascontiguousarray(r_, dtype=np.int64)).to(dev)
+        col = torch.from_numpy(np.ascontiguousarray(c_, dtype=np.int32)).to(dev)
+        val = torch.from_numpy(np.ascontiguousarray(v_, dtype=np.complex128)).to(dev)
+        torch.cuda.current_stream(dev).synchronize()        # (the copies of THIS thread: a device-wide synchronisation would wait for the other workers' kernels too)
         _lib.check(lib.helm_rhs_from_coo_device_layout(self.handle, ctypes.c_void_p(row.data_ptr()), ctypes.c_void_p(col.data_ptr()),
-                                                       ctypes.c_void_p(val.data_ptr()), int(coo.nnz), ctypes.c_void_p(d_rhs), int(coo.shape[1]),
-                                                       int(coo.shape[0]), _lib.HELM_RHS_NODE_MAJOR if layout == 'node' else 0), self.handle)
+                                                       ctypes.c_void_p(val.data_ptr()), nnz, ctypes.c_void_p(d_rhs), int(shape[1]),
+                                                       int(shape[0]), _lib.HELM_RHS_NODE_MAJOR if layout == 'node' else 0), self.handle)
 
     def rhsSupportFromSparse(self, q):
         '''The support of the scipy-sparse right-hand-side matrix q (nrow x ncols, ncols <= 512) as solveDevice(..., support=) takes it: a uint8 device

@@ -298,10 +298,19 @@ class HelmBaseProblem(BaseModelDependent, BaseSCCache):
                 state['R'] = torch.empty((2 * k, N), dtype=torch.complex128, device=dev)
                 state['cap'] = 2 * k
             U, R = state['U'], state['R']
-            qfi, qbi = sp.csc_matrix(qf[ifreq]), sp.csc_matrix(qb[ifreq])
-            op.rhsFromSparseDevice(sp.hstack((qfi[:, c0:c1], qbi[:, c0:c1])), R.data_ptr())      # sparse triplets up, dense on the device
+            # [qf | qb] of the item's sources as triplets, made from the two matrices' own arrays (no format conversion, no sort of 10^5..10^6 entries)
+            parts = []
+            for off, m in ((0, qf[ifreq] if isinstance(qf, (list, tuple)) else qf), (k, qb[ifreq])):
+                mc = m if (c0 == 0 and c1 == m.shape[1]) else sp.csc_matrix(m)[:, c0:c1]
+                if not (sp.isspmatrix_csr(mc) or sp.isspmatrix_csc(mc)) or not mc.has_canonical_format:
+                    mc = sp.csr_matrix(mc)
+                    mc.sum_duplicates()
+                coo = mc.tocoo(copy=False)
+                parts.append((coo.row, coo.col + off, coo.data))
+            trip = (np.concatenate([p_[0] for p_ in parts]), np.concatenate([p_[1] for p_ in parts]), np.concatenate([p_[2] for p_ in parts]), (N, 2 * k))
+            op.rhsFromSparseDevice(trip, R.data_ptr())      # sparse triplets up, dense on the device
             scaler = torch.from_numpy(np.ascontiguousarray(self.gradientScaler(ifreq) * scale * scale)).to(dev)
-            torch.cuda.synchronize(dev)
+            torch.cuda.current_stream(dev).synchronize()
             op.solveDevice(R.data_ptr(), U.data_ptr(), 2 * k, N)
             op.imagingAccumulateDevice(U.data_ptr(), U.data_ptr() + k * N * 16, k, scaler.data_ptr(), state['G'].data_ptr())
             return None
@@ -352,8 +361,7 @@ class HelmBaseProblem(BaseModelDependent, BaseSCCache):
             q = qf[ifreq] if isinstance(qf, (list, tuple)) else qf
             op.rhsFromSparseDevice(sp.csc_matrix(q)[:, c0:c1], R.data_ptr())
             op.solveDevice(R.data_ptr(), U.data_ptr(), k, N)
-            op.sampleDevice(U.data_ptr(), k, state['csr'], out.data_ptr())
-            torch.cuda.synchronize(dev)
+            op.sampleDevice(U.data_ptr(), k, state['csr'], out.data_ptr())      # (returns when the samples are there: helm_sample_device waits for its own stream)
             data[:, c0:c1, ifreq] = scale * out.cpu().numpy()          # (disjoint slices per item: no two workers write the same entries)
             return None
         self._runOnDevices(devs, items, one)
