@@ -164,8 +164,10 @@ def test_direct_output_writes_the_wavefields_of_the_two_step_path(helm_lib, monk
             bad = np.argwhere(out['1'] != out['0'])
             where = [(int(c // nx), int(c % nx), int(j), complex(out['1'][c, j]), complex(out['0'][c, j])) for c, j in bad[:8]]
             cols = sorted(set(int(j) for _, j in bad))[:12]
-            raise AssertionError('direct output differs from the two-step path (sparse=%s): %d of %d entries, relative %.2e; columns %s; first (z, x, col, direct, two-step): %s'
-                                 % (sparse, len(bad), out['1'].size, nrm(out['1'], out['0']), cols, where))
+            its = {m: sorted(set(i['iterations'] for i in info[m])) for m in info}
+            rr = {m: (min(i['relres'] for i in info[m]), max(i['relres'] for i in info[m])) for m in info}
+            raise AssertionError('direct output differs from the two-step path (sparse=%s): %d of %d entries, relative %.2e; passes %s; relres range %s; columns %s; first (z, x, col, direct, two-step): %s'
+                                 % (sparse, len(bad), out['1'].size, nrm(out['1'], out['0']), its, rr, cols, where[:3]))
         assert not np.any(out['1'][:, 3])
         for a, b in zip(info['1'], info['0']):
             assert a['status'] == b['status'] == 0 and a['iterations'] == b['iterations'] == 1

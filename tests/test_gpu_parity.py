@@ -51,6 +51,41 @@ def test_eurus_coefficients(helm_lib, aniso):
             assert coef_close(got[m, k], ref[m, k]), 'block %d plane %d' % (m, k)
 
 
+def test_eurus_blocks_assembled_on_demand(helm_lib):
+    """Round 5: an isotropic (eps == delta) Eurus operator is block-triangular and an N-row right-hand side touches M1 alone, so helm_assemble builds M1 only;
+    M2 .. M4 come into being when something asks for them.  Order of use must not matter: solve first, then the planes of all four blocks, an apply of
+    block 3 and a stacked 2N right-hand side -- each against the oracle (eurus.py:430-464,512-533)."""
+    from zephyr_amd import Eurus
+    nz, nx = 44, 52
+    c, rho = hetero_model(nz, nx)
+    rng = np.random.default_rng(8)
+    ell = 0.15 * rng.random((nz, nx))                     # elliptical: eps == delta != 0, M3 == 0
+    cfg = dict(nx=nx, nz=nz, dx=8., dz=8., c=c, rho=rho, freq=11., nPML=6, cPML=600., eps=ell, delta=ell, rtol=1e-10)
+    C4 = ho.eurus_coefficients(nz, nx, c, rho, 11., dx=8., dz=8., nPML=6, cPML=600., eps=ell, delta=ell)
+    ref_op = ho.DirectOperator(C4, eurus=True)
+    N = nz * nx
+    q = np.zeros((N, 2), complex)
+    q[(nz // 2) * nx + nx // 3, 0] = 1.; q[7 * nx + 30, 1] = 1j
+    op = Eurus(cfg)
+    u = op * q                                            # N-row right-hand sides: M1 only
+    assert np.linalg.norm(u - ref_op * q) <= 1e-7 * np.linalg.norm(u)
+    x = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    y3 = op.applyForward(x, block=3)                      # M4 x: the other blocks are built here
+    assert np.abs(y3 - ho.stencil_apply(C4[3], x)).max() <= 1e-12 * np.abs(y3).max()
+    got = op.diagonals()
+    for m in range(4):
+        for k in range(9):
+            assert coef_close(got[m, k], C4[m, k]), 'block %d plane %d' % (m, k)
+    q2 = np.zeros((2 * N, 2), complex)
+    q2[:N] = q; q2[N + 9 * nx + 11, 0] = 0.5 - 1j
+    op2 = Eurus(cfg)                                      # a fresh operator whose FIRST use is the stacked right-hand side
+    u2 = op2 * q2
+    r2 = ref_op * q2
+    assert u2.shape == r2.shape and np.linalg.norm(u2 - r2) <= 1e-7 * np.linalg.norm(r2)
+    u1 = op2 * q                                          # and the N-row solve afterwards, on the same handle
+    assert np.linalg.norm(u1 - ref_op * q) <= 1e-7 * np.linalg.norm(u1)
+
+
 @pytest.mark.parametrize('shape', [(40, 50), (64, 64), (70, 130), (129, 67)])
 @pytest.mark.parametrize('nrhs', [1, 5])
 def test_apply_matches_oracle(helm_lib, shape, nrhs):

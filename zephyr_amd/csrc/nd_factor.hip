@@ -289,41 +289,55 @@ __global__ __launch_bounds__(256) void k_lu_solve(const cplx *__restrict__ LU, i
     if (p == 0) for (int k = 0; k < n; ++k) { const int q = piv[k]; if (q != k) { const cplx t = Bt[k][cl]; Bt[k][cl] = Bt[q][cl]; Bt[q][cl] = t; } }
     __builtin_amdgcn_wave_barrier();
     constexpr int NK = LUS_NMAX / 16;
-    cplx cur[NK], nxt[NK];
+    // The factor's rows come from L2 (a 128-wide front's L\U is 256 KB: no room in LDS beside the columns), one row per elimination step: with one row of
+    // prefetch the step waited for its row (160 us per launch at n = 128, 2 n dependent steps of ~0.6 us).  Four rows are kept in flight in a ring of
+    // register sets, slot u of an unrolled group of four steps.
+    constexpr int PD = 4;
+    cplx rb[PD][NK];
     auto load_row = [&](cplx (&dst)[NK], int i, int klo, int khi) {        // entries k in [klo, khi), k = p + 16 q
         #pragma unroll
         for (int q = 0; q < NK; ++q) { const int k = p + 16 * q; dst[q] = (i >= 0 && i < n && k >= klo && k < khi) ? LU[(long long)i * ld + k] : cmake(0.0, 0.0); }
     };
     // L y = P b (unit lower triangle): rows top-down
-    load_row(cur, 1, 0, 1);
-    for (int i = 1; i < n; ++i) {
-        load_row(nxt, i + 1, 0, i + 1);
-        cplx acc = cmake(0.0, 0.0);
+    #pragma unroll
+    for (int u = 0; u < PD; ++u) load_row(rb[u], 1 + u, 0, 1 + u);
+    for (int i0 = 1; i0 < n; i0 += PD) {
         #pragma unroll
-        for (int q = 0; q < NK; ++q) { const int k = p + 16 * q; if (k < i) cfma(acc, cur[q], Bt[k][cl]); }
-        #pragma unroll
-        for (int off = 8; off > 0; off >>= 1) { acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off); }
-        if (p == 0) Bt[i][cl] = csub(Bt[i][cl], acc);
-        __builtin_amdgcn_wave_barrier();
-        #pragma unroll
-        for (int q = 0; q < NK; ++q) cur[q] = nxt[q];
+        for (int u = 0; u < PD; ++u) {
+            const int i = i0 + u;
+            if (i < n) {                                                     // (uniform across the workgroup)
+                cplx acc = cmake(0.0, 0.0);
+                #pragma unroll
+                for (int q = 0; q < NK; ++q) { const int k = p + 16 * q; if (k < i) cfma(acc, rb[u][q], Bt[k][cl]); }
+                load_row(rb[u], i + PD, 0, i + PD);
+                #pragma unroll
+                for (int off = 8; off > 0; off >>= 1) { acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off); }
+                if (p == 0) Bt[i][cl] = csub(Bt[i][cl], acc);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
     }
     // U x = y: rows bottom-up
-    load_row(cur, n - 1, n - 1, n);
-    for (int i = n - 1; i >= 0; --i) {
-        load_row(nxt, i - 1, i - 1, n);
-        cplx acc = cmake(0.0, 0.0), d = cmake(1.0, 0.0);
+    #pragma unroll
+    for (int u = 0; u < PD; ++u) load_row(rb[u], n - 1 - u, n - 1 - u, n);
+    for (int i0 = n - 1; i0 >= 0; i0 -= PD) {
         #pragma unroll
-        for (int q = 0; q < NK; ++q) { const int k = p + 16 * q; if (k > i && k < n) cfma(acc, cur[q], Bt[k][cl]); if (k == i) d = cur[q]; }
-        #pragma unroll
-        for (int off = 8; off > 0; off >>= 1) { acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off); }
-        // the diagonal entry sits with the lane whose k == i: hand it to lane 0 of the group
-        const int src = (lane & 48) | (i & 15);
-        const double dx = __shfl(d.x, src), dy = __shfl(d.y, src);
-        if (p == 0) Bt[i][cl] = cmul(csub(Bt[i][cl], acc), crecip(cmake(dx, dy)));
-        __builtin_amdgcn_wave_barrier();
-        #pragma unroll
-        for (int q = 0; q < NK; ++q) cur[q] = nxt[q];
+        for (int u = 0; u < PD; ++u) {
+            const int i = i0 - u;
+            if (i >= 0) {
+                cplx acc = cmake(0.0, 0.0), d = cmake(1.0, 0.0);
+                #pragma unroll
+                for (int q = 0; q < NK; ++q) { const int k = p + 16 * q; if (k > i && k < n) cfma(acc, rb[u][q], Bt[k][cl]); if (k == i) d = rb[u][q]; }
+                load_row(rb[u], i - PD, i - PD, n);
+                #pragma unroll
+                for (int off = 8; off > 0; off >>= 1) { acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off); }
+                // the diagonal entry sits with the lane whose k == i: hand it to lane 0 of the group
+                const int src = (lane & 48) | (i & 15);
+                const double dx = __shfl(d.x, src), dy = __shfl(d.y, src);
+                if (p == 0) Bt[i][cl] = cmul(csub(Bt[i][cl], acc), crecip(cmake(dx, dy)));
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
     }
     __syncthreads();
     for (int e = tid; e < n * 16; e += 256) { const int i = e >> 4, c = e & 15; if (j0 + c < ncols) B[(long long)i * ldb + j0 + c] = Bt[i][c]; }
