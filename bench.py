@@ -569,16 +569,8 @@ def main():
     stamps = []                          # completion time of every work item (diagnostics: `item_done_ms` of the timed region)
     tl = []                              # (what, item, time) marks of the prepare / solve steps (`first_items_timeline_ms`)
 
-    retired, retire_later = [], [False]
-
-    def drop_retired(keep=0):
-        while len(retired) > keep:
-            old = retired.pop(0)
-            del old.factors
-
     def prepare_item(w, profile):
         'create the operator of work item w, assemble it on the GPU (inside the timed region) and start its factorisation'
-        drop_retired()                   # operators whose wavefields have been delivered: handle, factors and pools go back here, off the solve thread
         fi, bi = work_item(w, nb)
         tl.append(('prepare starts', w, time.perf_counter()))
         sc = dict(cfg)
@@ -606,10 +598,7 @@ def main():
         rhs_ptr = d_rhs.data_ptr() + (0 if node else bi * B * N * 16)
         info = op.solveDevice(rhs_ptr, ubuf.data_ptr(), B, N, layout='node' if node else 'rhs', support=d_support if (use_support[0] and node) else None)
         t = op.lastTiming()
-        if retire_later[0]:
-            retired.append(op)           # pipelined: the prepare thread destroys it (beside the next solve instead of between two solves)
-        else:
-            del op.factors               # nothing is carried over between steps
+        del op.factors                   # nothing is carried over between steps
         stamps.append(time.perf_counter())
         return fi, info, t
 
@@ -623,14 +612,8 @@ def main():
             return [run_item(w, profile) for w in ws]
         from zephyr_amd import dispatch
         items = [dispatch.WorkItem((lambda op, w=w: solve_item(w, op)), (lambda w=w: prepare_item(w, profile))) for w in ws]
-        retire_later[0] = os.environ.get('HELM_BENCH_RETIRE', '1') != '0'
-        try:
-            out_ = list(dispatch.pipelined(items, device=local, lookahead=int(os.environ.get('HELM_BENCH_LOOKAHEAD', '1')), strict=os.environ.get('HELM_BENCH_STRICT', '0') == '1',
-                                           solvers=nsolvers))
-        finally:
-            retire_later[0] = False
-            drop_retired()               # (inside the timed region: every operator of the K items is gone when the clock stops)
-        return out_
+        return list(dispatch.pipelined(items, device=local, lookahead=int(os.environ.get('HELM_BENCH_LOOKAHEAD', '1')), strict=os.environ.get('HELM_BENCH_STRICT', '0') == '1',
+                                       solvers=nsolvers))
 
     def barrier():
         torch.cuda.synchronize()

@@ -137,7 +137,7 @@ def test_direct_output_writes_the_wavefields_of_the_two_step_path(helm_lib, monk
     """Round 5 (helm_tuning.nd_direct_out): for a full-width node-major batch the back substitution writes u = conj(premul x) into the caller's array
     itself -- leaf cells there only, separator cells there and in the scratch the levels below read -- and the residual launch reads the caller's
     array instead of storing it.  Bit for bit the wavefields of the path that stores them from the residual launch (HELM_ND_DIRECT_OUT=0), with point
-    sources, a dense column and an all-zero one, sparse-rhs skipping on and off; the reported residual is the same number (identical when premul = 1)."""
+    sources, a dense column and an all-zero one, sparse-rhs skipping on and off; the reported residual is the same number up to the rounding of u."""
     import zephyr_amd as za
     nz, nx, nrhs = 150, 170, 200
     rng = np.random.default_rng(11)
@@ -167,11 +167,13 @@ def test_direct_output_writes_the_wavefields_of_the_two_step_path(helm_lib, monk
             its = {m: sorted(set(i['iterations'] for i in info[m])) for m in info}
             rr = {m: (min(i['relres'] for i in info[m]), max(i['relres'] for i in info[m])) for m in info}
             raise AssertionError('direct output differs from the two-step path (sparse=%s): %d of %d entries, relative %.2e; passes %s; relres range %s; columns %s; first (z, x, col, direct, two-step): %s'
-                                 % (sparse, len(bad), out['1'].size, nrm(out['1'], out['0']), its, rr, cols, where[:3]))
+                                 % (sparse, len(bad), out['1'].size, nrm(out['1'], out['0']), its, rr, cols, where[:2]))
         assert not np.any(out['1'][:, 3])
         for a, b in zip(info['1'], info['0']):
             assert a['status'] == b['status'] == 0 and a['iterations'] == b['iterations'] == 1
-            assert abs(a['relres'] - b['relres']) <= 1e-3 * max(b['relres'], 1e-300) + 1e-18
+            # the residual launch reads conj(premul x) rounded to the caller's array where the two-step path had x itself (premul != 1, which the HD
+            # classes also have): residuals of a few 1e-15 then differ in their leading digits, larger ones agree
+            assert abs(a['relres'] - b['relres']) <= 1e-3 * b['relres'] + 1e-14
     op = getattr(za, cls_name)(cfg)
     C = ho.minizephyr_coefficients(nz, nx, op.c, op.rho, complex(op.freq), dx=10., dz=10., nPML=8) if cls_name.startswith('Mini') else None
     ref = (ho.DirectOperator(C, premul=op.premul) if C is not None else
