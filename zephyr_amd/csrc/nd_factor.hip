@@ -23,6 +23,8 @@
 //
 // All dense arithmetic is fp64 complex on the matrix cores (v_mfma_f64_16x16x4_f64, nd_gemm_body.hpp).
 #include "nd_internal.hpp"
+#include <map>
+#include <cstring>
 
 // ---- kernels ---------------------------------------------------------------------------------------------------
 namespace {
@@ -136,38 +138,74 @@ __global__ __launch_bounds__(256) void k_nd_build_front(const NdDev *nodes, int 
     const int ld0 = c0.smax + c0.mmax, ld1 = c1.smax + c1.mmax;
     const int r1 = r0 + rb < nmax ? r0 + rb : nmax;
     const int tx = tid & 63, ty = tid >> 6;
-    for (int r = r0 + ty; r < r1; r += 4) {
-        const int2 ia = finfo[r];
-        const bool colmode = n.dof > 2;
+    const bool colmode = n.dof > 2;
+    // entry (r, c) of the front from the row table: stencil coefficient + the two children's Schur-complement entries
+    auto value = [&](int r, int c, const int2 ia, const int2 ib) -> cplx {
+        cplx v = cmake(0.0, 0.0);
+        if (ia.x < 0 || ib.x < 0) { if (r == c && r < n.smax) v = cmake(1.0, 0.0); return v; }
         const int za = colmode ? (ia.x & 0xfff) : (ia.x & 0xffff), xa = colmode ? ((ia.x >> 12) & 0xfff) : (ia.x >> 16);
         const int ca = colmode ? ((ia.x >> 24) & 0x7f) : ((ia.y >> 28) & 1);
         const int a0 = (colmode ? (ia.y & 0xffff) : (ia.y & 0x3fff)) - 1, a1 = (colmode ? ((ia.y >> 16) & 0xffff) : ((ia.y >> 14) & 0x3fff)) - 1;
-        // skip22: the ring x ring block (the sum of the children's Schur complements, most of a front below the tree top) is not
-        // materialised -- the Schur-complement product gathers it itself (k_zgemm2<.., 4, ..>) and writes S where F22 would have been
-        const int cend = (skip22 && r >= n.smax) ? n.smax : nmax;
-        for (int c = tx; c < cend; c += 64) {
-            const int2 ib = finfo[c];
-            cplx v = cmake(0.0, 0.0);
-            if (ia.x < 0 || ib.x < 0) { if (r == c && r < n.smax) v = cmake(1.0, 0.0); }
-            else {
-                if (r < n.smax || c < n.smax) {              // ring x ring entries belong to an ancestor
-                    const int zb = colmode ? (ib.x & 0xfff) : (ib.x & 0xffff), xb = colmode ? ((ib.x >> 12) & 0xfff) : (ib.x >> 16);
-                    const int dz = zb - za, dx = xb - xa;
-                    if (dz >= -1 && dz <= 1 && dx >= -1 && dx <= 1) {
-                        if (colmode) {
-                            const int dc = ((ib.x >> 24) & 0x7f) - ca;
-                            if (dc >= -1 && dc <= 1) v = planes[((long long)(dc + 1) * 9 + (dz + 1) * 3 + dx + 1) * N * n.dof + (long long)ca * N + (long long)za * nx + xa];
-                        } else {
-                            const int blk = n.dof == 2 ? 2 * ca + ((ib.y >> 28) & 1) : 0;
-                            v = planes[((long long)blk * 9 + (dz + 1) * 3 + dx + 1) * N + (long long)za * nx + xa];
-                        }
-                    }
+        if (r < n.smax || c < n.smax) {              // ring x ring entries belong to an ancestor
+            const int zb = colmode ? (ib.x & 0xfff) : (ib.x & 0xffff), xb = colmode ? ((ib.x >> 12) & 0xfff) : (ib.x >> 16);
+            const int dz = zb - za, dx = xb - xa;
+            if (dz >= -1 && dz <= 1 && dx >= -1 && dx <= 1) {
+                if (colmode) {
+                    const int dc = ((ib.x >> 24) & 0x7f) - ca;
+                    if (dc >= -1 && dc <= 1) v = planes[((long long)(dc + 1) * 9 + (dz + 1) * 3 + dx + 1) * N * n.dof + (long long)ca * N + (long long)za * nx + xa];
+                } else {
+                    const int blk = n.dof == 2 ? 2 * ca + ((ib.y >> 28) & 1) : 0;
+                    v = planes[((long long)blk * 9 + (dz + 1) * 3 + dx + 1) * N + (long long)za * nx + xa];
                 }
-                const int b0 = (colmode ? (ib.y & 0xffff) : (ib.y & 0x3fff)) - 1, b1 = (colmode ? ((ib.y >> 16) & 0xffff) : ((ib.y >> 14) & 0x3fff)) - 1;
-                if (a0 >= 0 && b0 >= 0) v = cadd(v, S0[(long long)a0 * ld0 + b0]);
-                if (a1 >= 0 && b1 >= 0) v = cadd(v, S1[(long long)a1 * ld1 + b1]);
             }
-            *front_entry(n, arenaF, fac, r, c) = v;
+        }
+        const int b0 = (colmode ? (ib.y & 0xffff) : (ib.y & 0x3fff)) - 1, b1 = (colmode ? ((ib.y >> 16) & 0xffff) : ((ib.y >> 14) & 0x3fff)) - 1;
+        if (a0 >= 0 && b0 >= 0) v = cadd(v, S0[(long long)a0 * ld0 + b0]);
+        if (a1 >= 0 && b1 >= 0) v = cadd(v, S1[(long long)a1 * ld1 + b1]);
+        return v;
+    };
+    // skip22: the ring x ring block (the sum of the children's Schur complements, most of a front below the tree top) is not
+    // materialised -- the Schur-complement product gathers it itself (k_zgemm3<.., 4, ..>) and writes S where F22 would have been
+    // Four entries per lane are gathered before any of them is stored (round 5): the children's blocks and the front live in one arena, so the compiler
+    // keeps every load behind the previous store, and a wave that took one entry per lane at a time paid a full memory round trip per row of a small
+    // front (14 in a row at the 8192-front level: ~100 us for 110 MB) or per 64 columns of a large one.  Small fronts: four rows at once; others: four
+    // column blocks of one row.
+    if (nmax <= 64) {
+        for (int rq = r0 + ty; rq < r1; rq += 16) {
+            cplx v[4]; int2 ia[4];
+            const int c = tx;
+            const int2 ib = c < nmax ? finfo[c] : make_int2(-1, 0);
+            #pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = rq + 4 * k;
+                ia[k] = r < r1 ? finfo[r] : make_int2(-1, 0);
+                const int cend = (skip22 && r >= n.smax) ? n.smax : nmax;
+                v[k] = (r < r1 && c < cend) ? value(r, c, ia[k], ib) : cmake(0.0, 0.0);
+            }
+            #pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = rq + 4 * k;
+                const int cend = (skip22 && r >= n.smax) ? n.smax : nmax;
+                if (r < r1 && c < cend) *front_entry(n, arenaF, fac, r, c) = v[k];
+            }
+        }
+        return;
+    }
+    for (int r = r0 + ty; r < r1; r += 4) {
+        const int2 ia = finfo[r];
+        const int cend = (skip22 && r >= n.smax) ? n.smax : nmax;
+        for (int cq = tx; cq < cend; cq += 256) {
+            cplx v[4];
+            #pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = cq + 64 * k;
+                v[k] = c < cend ? value(r, c, ia, finfo[c < nmax ? c : 0]) : cmake(0.0, 0.0);
+            }
+            #pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = cq + 64 * k;
+                if (c < cend) *front_entry(n, arenaF, fac, r, c) = v[k];
+            }
         }
     }
 }
@@ -426,33 +464,64 @@ int ensure_est(helm_op *op, NdFactor *f, int stable_smax) {
     return HELM_OK;
 }
 
-// after the batched elimination of group gi: find its ill-conditioned fronts (one small read-back per group) and eliminate each of them again
-int stabilise_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, const cplx *planes) {
+// The list of a group's ill-conditioned fronts comes back through a pinned buffer and an event of the calling thread (one per device): flag_group
+// enqueues the flagging and the copy right after the inversion, the group's products are enqueued behind them, and stabilise_group waits for the
+// EVENT only -- the list is on the host while the products still run, and with nothing flagged (the usual case) the next group is enqueued without the
+// stream ever running dry.  (Rounds 3-4: hipStreamSynchronize after the products, once per watched group -- the factorisation stream idled for a host
+// round trip 11 times per operator, and in the pipelined job the factorisation span is what a step waits for.)
+struct FlagSlot { int *host = nullptr; hipEvent_t ev = nullptr; };
+FlagSlot *flag_slot(int device) {
+    thread_local std::map<int, FlagSlot> slots;
+    FlagSlot &s = slots[device];
+    if (!s.host) {
+        if (hipHostMalloc((void **)&s.host, (ND_STABLE_CAP + 1) * sizeof(int), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); s.host = nullptr; return nullptr; }
+        if (hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); hipHostFree(s.host); s.host = nullptr; return nullptr; }
+    }
+    return &s;
+}
+
+// after the inversion of group gi: flag its ill-conditioned fronts and start the list on its way to the host
+int flag_group(helm_op *op, NdFactor *f, size_t gi) {
     const NdPlan &P = f->pd->plan;
     const NdGroup &g = P.groups[gi];
     hipStream_t st = op->stream;
     // Which fronts are taken follows from the tolerance the factors are built for, not from a constant fitted to one model: an explicit inverse of a
     // front with condition number kappa leaves a first-pass residual of about kappa * eps (measured front by front, DESIGN.md 5.1: 8.8e5 -> 4e-9),
-    // and it has to stay below rtol with a margin for the handful of such fronts that add up and for what the estimate ||F11||_inf ||F11^-1||_inf
-    // misses:   kappa_max = rtol / (HELM_ND_STABLE_SAFETY * eps),  safety 8 by default  ->  1.1e5 at the 1e-10 of the reference parity tests, 1.1e7
+    // and it has to stay below rtol with a margin for the handful of such fronts that add up and for what the estimate misses:
+    //   kappa_max = rtol / (HELM_ND_STABLE_SAFETY * eps),  safety 8 by default  ->  1.1e5 at the 1e-10 of the reference parity tests, 1.1e7
     // at 1e-8, 1.1e3 at 1e-12 (where most fronts of the middle levels would be taken: the floor of 2e3 keeps the treatment a handful-of-fronts
     // affair and leaves the rest to the refinement pass, which always exists).  HELM_ND_STABLE_THR overrides with a fixed number.
     const helm_tuning tune = helm_tuning_now();
     const double safety = tune.nd_stable_safety;
     const double rt = op->rtol_hint > 0 ? op->rtol_hint : 1e-10;
     const double thr = tune.nd_stable_thr > 0 ? tune.nd_stable_thr : std::min(1e9, std::max(2e3, rt / (safety * 1.1102230246251565e-16)));
-    const int nmax = g.smax + g.mmax;
+    FlagSlot *slot = flag_slot(op->device);
+    if (!slot) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: no pinned buffer for the list of ill-conditioned fronts");
     int *d_list = (int *)(f->d_est + 2 * (size_t)g.cnt);
     HIP_TRY(op, hipMemsetAsync(d_list, 0, sizeof(int), st));
     hipLaunchKernelGGL(k_front_flag, dim3((g.cnt + 255) / 256), dim3(256), 0, st, (const double *)f->d_est, (const double *)(f->d_est + g.cnt), g.cnt, 1.0, thr, d_list, ND_STABLE_CAP);
+    HIP_TRY(op, hipMemcpyAsync(slot->host, d_list, (ND_STABLE_CAP + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(op, hipEventRecord(slot->ev, st));
+    return HELM_OK;
+}
+
+// after the batched elimination of group gi (whose list flag_group has requested): eliminate each of its ill-conditioned fronts again
+int stabilise_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, const cplx *planes) {
+    const NdPlan &P = f->pd->plan;
+    const NdGroup &g = P.groups[gi];
+    hipStream_t st = op->stream;
+    const int nmax = g.smax + g.mmax;
+    FlagSlot *slot = flag_slot(op->device);
+    if (!slot) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: no pinned buffer for the list of ill-conditioned fronts");
+    HIP_TRY(op, hipEventSynchronize(slot->ev));
     int h_list[ND_STABLE_CAP + 1];
-    HIP_TRY(op, hipMemcpyAsync(h_list, d_list, sizeof(h_list), hipMemcpyDeviceToHost, st));
-    HIP_TRY(op, hipStreamSynchronize(st));
+    memcpy(h_list, slot->host, sizeof(h_list));
     const int nflag = std::max(0, std::min(h_list[0], ND_STABLE_CAP));
     if (h_list[0] > ND_STABLE_CAP) {
         // more flagged fronts than are treated per group: which of them made it into the list is up to the order the atomics ran in, and the factors would
         // differ from one factorisation of the same operator to the next.  Take the worst ND_STABLE_CAP by estimate instead (ties: lower position).
         std::vector<double> est((size_t)g.cnt);
+        HIP_TRY(op, hipStreamSynchronize(st));
         HIP_TRY(op, hipMemcpy(est.data(), f->d_est + g.cnt, est.size() * sizeof(double), hipMemcpyDeviceToHost));
         std::vector<int> order((size_t)g.cnt);
         for (int j = 0; j < g.cnt; ++j) order[j] = j;
@@ -466,6 +535,7 @@ int stabilise_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *wor
     std::sort(h_list + 1, h_list + 1 + nflag);                                   // (the atomics hand the slots out in no particular order)
     if (getenv("HELM_ND_DEBUG") && atoi(getenv("HELM_ND_DEBUG")) >= 2) {
         std::vector<double> h(2 * (size_t)g.cnt);
+        hipStreamSynchronize(st);
         hipMemcpy(h.data(), f->d_est, h.size() * sizeof(double), hipMemcpyDeviceToHost);
         double worst = 0; int wj = 0;
         for (int j = 0; j < g.cnt; ++j) { const double e = h[j] * h[g.cnt + j]; if (!(e <= worst)) { worst = e; wj = j; } }
@@ -607,6 +677,7 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
     if (watch) for (int j0 = 0; j0 < g.cnt; j0 += 65535)
         hipLaunchKernelGGL(k_front_cond<1>, dim3(std::min(65535, g.cnt - j0)), dim3(256), 0, st, Finv + (long long)j0 * s1, nmax, s1, d_nodes + g.first + j0, f->d_est + g.cnt + j0,
                            est_rows + (long long)j0 * g.smax, g.smax);
+    if (watch) { const int rcf = flag_group(op, f, gi); if (rcf) return rcf; }      // (the list travels while the products below run)
     if (g.mmax > 0) {
         // G21 = F21 F11^-1 ; F22 -= G21 F12
         gemm(op, g.mmax, g.smax, g.smax, one, F, nmax, fs, Finv, nmax, s1, zero, G21, g.smax, (long long)g.mmax * g.smax, g.cnt);

@@ -144,20 +144,9 @@ struct Gj32w {
     int sigma[32];       // pivot row of step k
     int sinv[32];        // step at which row r was the pivot
 };
-__global__ __launch_bounds__(256) void k_gj32w_inverse(cplx *A0, int ld, long long stride, int n, int nmat) {
-    __shared__ Gj32w SW[4];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int mat = blockIdx.x * 4 + w;
-    if (mat >= nmat) return;                       // whole waves leave together (no block-level barrier below)
-    Gj32w &S = SW[w];
-    cplx *A = A0 + (long long)mat * stride;
-    const int r = lane & 31, h = lane >> 5;
-    cplx a[16];
-    #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        const int j = 16 * h + c;
-        a[c] = (r < n && j < n) ? A[(long long)r * ld + j] : cmake(r == j ? 1.0 : 0.0, 0.0);
-    }
+// the elimination itself: lane (r, h) holds a[c] = entry (r, 16 h + c) of the block padded with the identity; on return the storage rows of the inverse
+// (see k_gj32w_inverse for the permutation that undoes the implicit pivoting)
+__device__ __forceinline__ void gj32w_core(cplx (&a)[16], Gj32w &S, int n, int r, int h) {
     bool used = r >= n;                            // padding rows never pivot
     if (h == 0) { S.sigma[r] = r; S.sinv[r] = r; }  // (a singular block may leave entries unset: keep every index in range)
     // The pivot row is NOT scaled when it is chosen: the other rows are eliminated with the multiplier f / d against the unscaled row,
@@ -206,6 +195,23 @@ __global__ __launch_bounds__(256) void k_gj32w_inverse(cplx *A0, int ld, long lo
     }
     #pragma unroll
     for (int c = 0; c < 16; ++c) a[c] = cmul(a[c], srow);
+}
+
+__global__ __launch_bounds__(256) void k_gj32w_inverse(cplx *A0, int ld, long long stride, int n, int nmat) {
+    __shared__ Gj32w SW[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int mat = blockIdx.x * 4 + w;
+    if (mat >= nmat) return;                       // whole waves leave together (no block-level barrier below)
+    Gj32w &S = SW[w];
+    cplx *A = A0 + (long long)mat * stride;
+    const int r = lane & 31, h = lane >> 5;
+    cplx a[16];
+    #pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int j = 16 * h + c;
+        a[c] = (r < n && j < n) ? A[(long long)r * ld + j] : cmake(r == j ? 1.0 : 0.0, 0.0);
+    }
+    gj32w_core(a, S, n, r, h);
     // inv[i][sigma(kcol)] = R[sigma(i)][kcol]: this lane holds storage row r = sigma(i), i.e. output row i = sinv[r]
     if (r < n) {
         const int i = S.sinv[r] & 31;
@@ -429,41 +435,50 @@ __global__ __launch_bounds__(256, 2) void k_gj_step(GjStepArgs a) {
         Gj32 &S = *reinterpret_cast<Gj32 *>(lds);
         int *cperm = reinterpret_cast<int *>(lds + sizeof(Gj32));
         const int i = tid >> 3, j0 = (tid & 7) * 4;
-        cplx v[4], lreg[4];
+        // The step applied to the next pivot block privately:  T11 - C_k (P * rows_k)  with two 32^3 products.  Round 5: both on the matrix cores (wave w owns
+        // the 16 x 16 block (w >> 1, w & 1) of each product; fragments as in the tiles below) -- with one multiply-add per thread and entry they took 5 of a
+        // step's 36 us, and the sweep of the next block is what a step waits for.
+        const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+        const int br = wave >> 1, bc = wave & 1;
+        cplx lreg[4], vm[4];
         #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int j = j0 + q;
             X0[i][j] = (i < nb && j < nb1) ? Ta[(long long)(k0 + i) * lda + k1 + j] : cmake(0.0, 0.0);       // pivot rows, columns of the next block
             X1[i][j] = (i < nb && j < nb) ? P[i * PNB + j] : cmake(0.0, 0.0);
             lreg[q] = (i < nb1 && j < nb) ? Ta[(long long)(k1 + i) * lda + k0 + j] : cmake(0.0, 0.0);        // C_k, rows of the next block
-            v[q] = (i < nb1 && j < nb1) ? Ta[(long long)(k1 + i) * lda + k1 + j] : cmake(i == j ? 1.0 : 0.0, 0.0);
+            const int mr = 16 * br + lq + 4 * q, mc = 16 * bc + lr;                                          // the next block itself, in the layout the products come out in
+            vm[q] = (mr < nb1 && mc < nb1) ? Ta[(long long)(k1 + mr) * lda + k1 + mc] : cmake(mr == mc ? 1.0 : 0.0, 0.0);
         }
         __syncthreads();
-        cplx acc[4];
+        v4f64 er = {0.0, 0.0, 0.0, 0.0}, ei = {0.0, 0.0, 0.0, 0.0};
         #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = cmake(0.0, 0.0);
-        #pragma unroll 2
-        for (int p = 0; p < PNB; ++p) {
-            const cplx x = X1[i][p];
-            #pragma unroll
-            for (int q = 0; q < 4; ++q) cfma(acc[q], x, X0[p][j0 + q]);
+        for (int ks = 0; ks < PNB / 4; ++ks) {                // R_k (columns of the next block) = P * rows_k
+            const cplx x = X1[16 * br + lr][4 * ks + lq], y = X0[4 * ks + lq][16 * bc + lr];
+            er = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, y.x, er, 0, 0, 0);
+            ei = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, y.y, ei, 0, 0, 0);
+            er = __builtin_amdgcn_mfma_f64_16x16x4f64(-x.y, y.y, er, 0, 0, 0);
+            ei = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, y.x, ei, 0, 0, 0);
         }
         __syncthreads();
         #pragma unroll
-        for (int q = 0; q < 4; ++q) { X0[i][j0 + q] = acc[q]; X1[i][j0 + q] = lreg[q]; acc[q] = cmake(0.0, 0.0); }      // R_k (columns of the next block), C_k
+        for (int q = 0; q < 4; ++q) { X0[16 * br + lq + 4 * q][16 * bc + lr] = cmake(er[q], ei[q]); X1[i][j0 + q] = lreg[q]; }
         __syncthreads();
-        #pragma unroll 2
-        for (int p = 0; p < PNB; ++p) {
-            const cplx x = X1[i][p];
-            #pragma unroll
-            for (int q = 0; q < 4; ++q) cfma(acc[q], x, X0[p][j0 + q]);
-        }
+        er = v4f64{0.0, 0.0, 0.0, 0.0}; ei = v4f64{0.0, 0.0, 0.0, 0.0};
         #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = csub(v[q], acc[q]);
+        for (int ks = 0; ks < PNB / 4; ++ks) {                // C_k * R_k
+            const cplx x = X1[16 * br + lr][4 * ks + lq], y = X0[4 * ks + lq][16 * bc + lr];
+            er = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, y.x, er, 0, 0, 0);
+            ei = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, y.y, ei, 0, 0, 0);
+            er = __builtin_amdgcn_mfma_f64_16x16x4f64(-x.y, y.y, er, 0, 0, 0);
+            ei = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, y.x, ei, 0, 0, 0);
+        }
         __syncthreads();                                     // the two blocks are read: S takes their place
         #pragma unroll
-        for (int q = 0; q < 4; ++q) S.a[i][j0 + q] = v[q];
+        for (int q = 0; q < 4; ++q) S.a[16 * br + lq + 4 * q][16 * bc + lr] = csub(vm[q], cmake(er[q], ei[q]));
         __syncthreads();
+        // (round 5, measured and not kept: the sweep by one wave with the block in registers (gj32w_core) while the other three waves leave -- 36 -> 43 us
+        // per step of the 1024-wide front: a wave that issues all 64 multiply-adds of a step itself takes longer than four waves and a barrier)
         gj32(S, nb1, tid);
         if (tid < PNB) cperm[tid] = S.piv[tid] & 31;         // P[r][sigma(j)] = S.a[sigma(r)][j]
         __syncthreads();

@@ -186,7 +186,7 @@ inline int check_kernels(helm_op *op, const char *what) {
 // HELM_ND_TRACE=1: per-group device time of the factorisation / forward / backward sweeps on stderr (diagnostics only)
 struct GroupTrace {
     bool on; hipStream_t st; std::vector<hipEvent_t> ev; const char *what;
-    GroupTrace(hipStream_t s, const char *w) : st(s), what(w) { static const int t = getenv("HELM_ND_TRACE") ? atoi(getenv("HELM_ND_TRACE")) : 0; on = t != 0; mark(); }
+    GroupTrace(hipStream_t s, const char *w) : st(s), what(w) { const int t = getenv("HELM_ND_TRACE") ? atoi(getenv("HELM_ND_TRACE")) : 0; on = t != 0; mark(); }
     void mark() { if (!on) return; hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, st); ev.push_back(e); }
     void report(const NdPlan &P, bool reverse) {
         if (!on) return;
