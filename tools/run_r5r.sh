@@ -14,16 +14,14 @@ import json, sys
 try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
     c = d['config']
-    print('%-22s value %8.0f  ms/step %6.2f  unprofiled %8.0f  strong %8.0f' % (sys.argv[2], d['value'], d['ms_per_step'], c.get('unprofiled_wfs') or 0, c.get('strong_job_wfs') or 0))
+    print('%-22s value %8.0f  ms/step %6.2f  unprofiled %8.0f  strong %8.0f  passes %s' % (sys.argv[2], d['value'], d['ms_per_step'], c.get('unprofiled_wfs') or 0, c.get('strong_job_wfs') or 0, c.get('solves_or_iterations_per_rhs_max')))
 except Exception as e:
     print(sys.argv[2], 'failed', e)
 PY
 }
 run warm A=1
-run default_1 A=1
-run look2_1 HELM_BENCH_LOOKAHEAD=2
-run default_2 A=1
-run look2_2 HELM_BENCH_LOOKAHEAD=2
-run look3 HELM_BENCH_LOOKAHEAD=3
-run prio0 HELM_PF_PRIO=0
-run look2_prio0 HELM_PF_PRIO=0 HELM_BENCH_LOOKAHEAD=2
+run d1 A=1
+run d2 A=1
+run d3 A=1
+F=2.0,2.5,3.0,3.5,4.0,4.5,5.0,5.5,6.0,6.5,7.0,7.5,8.0,8.5,9.0,9.5
+HELM_ND_DEBUG=1 timeout 600 python3 tools/bench_direct.py --freqs $F 2>&1 | grep -E "re-eliminated|pass 2" | sort | uniq -c | sort -rn | head -30

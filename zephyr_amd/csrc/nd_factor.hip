@@ -211,33 +211,52 @@ __global__ __launch_bounds__(256) void k_nd_build_front(const NdDev *nodes, int 
 }
 
 // ---- ill-conditioned fronts (NdStable) -------------------------------------------------------------------------------------------------
-// Condition estimate of the s x s pivot block of every front of a group, ROW-EQUILIBRATED:  kappa = || (D^-1 F11)^-1 ||_inf with D = diag(row sums of
-// |F11|), so that || D^-1 F11 ||_inf = 1 and  kappa = max_i sum_j |F11^-1|_ij d_j.  Two launches around the inversion:
-//   AFTER = 0 (before it)   d_j = sum_c |F11|_jc  ->  rows[front * smax + j]            (|z| taken as |re| + |im|), out[front] = 1
-//   AFTER = 1 (after it)    out[front] = max_i sum_j |F11^-1|_ij d_j
-// (Rounds 3-4 multiplied the two plain infinity norms.  That counts the SCALING of the rows as ill-conditioning: the MiniZephyr system keeps identity
-// rows on the outer boundary -- norm 1 -- beside interior rows of norm 1e-5, every front that touches the boundary came out at 1e6 and was handed to the
-// pivoted LU, all fronts of a small model; found in round 5 through the run-to-run differences the overflowing flag list then caused.  An explicit
-// inverse loses accuracy with the conditioning that row scaling cannot remove, which is what this measures.  The max-entry norm was tried first in
-// round 3: for a near-singular front F11^-1 ~ u v^T / sigma with u, v spread over all unknowns, and max |entry| underestimates the norm by the front's size.)
-// (over the front's own s x s unknowns: the identity that pads a smaller front to the group's size is not part of its conditioning)
+// Condition estimate of the s x s pivot block of every front of a group: ||F11||_inf ||F11^-1||_inf (|z| taken as |re| + |im|), two launches around
+// the inversion -- with DECOUPLED rows taken out of the norms.  A row of F11 whose only entry is its diagonal (the MiniZephyr system keeps identity rows
+// on the outer boundary, norm 1 beside interior rows of norm 1e-5) is eliminated exactly whatever its scale, but counted as it stands it multiplies the
+// product of the norms by that scale ratio: every front touching the boundary came out at 1e6 and was handed to the pivoted LU -- all fronts of a small
+// model, more than a group treats, and which made it into the list depended on the order the flagging threads ran in (round 5, found through run-to-run
+// differences in the last bits).  Such a row j is weighted  w_j = d_j / a  (d_j its norm, a the largest norm among the coupled rows), the others w_j = 1:
+//   AFTER = 0 (before the inversion)   out[front] = a,  rows[front * smax + j] = w_j
+//   AFTER = 1 (after it)               out[front] = max_i sum_j |F11^-1|_ij w_j
+// With no decoupled row (every Eurus front) this IS the product of the two infinity norms the threshold was calibrated on in rounds 3-4.  (Full row
+// equilibration, w_j = d_j for every row, was tried first in round 5: it halves the estimate of exactly the fronts that matter -- the 1024^2 operator at
+// 8 Hz kept a front at 1.0e5 under the 1.1e5 threshold and paid a refinement pass, first-pass residual 6.8e-9 -- because the pivot search inside a
+// 32-wide block is by absolute size, so the gradual row scaling of the PML does cost accuracy and belongs in the estimate.)
+// (The max-entry norm was tried first in round 3: for a near-singular front F11^-1 ~ u v^T / sigma with u, v spread over all unknowns, and max |entry|
+// underestimates the norm by the front's size.  Over the front's own s x s unknowns: the identity that pads a smaller front is not part of it.)
 template <int AFTER>
 __global__ __launch_bounds__(256) void k_front_cond(const cplx *M0, int ld, long long stride, const NdDev *nodes, double *out, double *rows, int smax) {
     __shared__ double red[4];
+    __shared__ double dsh[LUS_NMAX];
+    __shared__ unsigned char lone[LUS_NMAX];
     const cplx *M = M0 + (long long)blockIdx.x * stride;
-    double *d = rows + (long long)blockIdx.x * smax;
+    double *w = rows + (long long)blockIdx.x * smax;
     const int n = nodes[blockIdx.x].s;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double best = 0.0;
     for (int i = wv; i < n; i += 4) {                      // a wave per row: coalesced along the row
-        double v = 0.0;
-        for (int j = lane; j < n; j += 64) { const cplx a = M[(long long)i * ld + j]; v += (fabs(a.x) + fabs(a.y)) * (AFTER ? d[j] : 1.0); }
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        double v = 0.0, off = 0.0;
+        for (int j = lane; j < n; j += 64) {
+            const cplx a = M[(long long)i * ld + j];
+            const double m = fabs(a.x) + fabs(a.y);
+            v += AFTER ? m * w[j] : m;
+            if (!AFTER && j != i) off += m;
+        }
+        for (int o = 32; o > 0; o >>= 1) { v += __shfl_down(v, o); if (!AFTER) off += __shfl_down(off, o); }
         v = __shfl(v, 0);
-        if (!AFTER && lane == 0) d[i] = v;
+        if (!AFTER && lane == 0) { dsh[i] = v; lone[i] = off == 0.0; }
         best = fmax(best, v);
     }
-    if (!AFTER) { if (threadIdx.x == 0) out[blockIdx.x] = 1.0; return; }
+    if (!AFTER) {
+        __syncthreads();
+        double a = 0.0, any = 0.0;
+        for (int i = 0; i < n; ++i) { any = fmax(any, dsh[i]); if (!lone[i]) a = fmax(a, dsh[i]); }      // (n <= 128, every thread the same loop: no second reduction)
+        if (!(a > 0.0)) a = any > 0.0 ? any : 1.0;           // nothing but decoupled rows
+        for (int i = threadIdx.x; i < n; i += 256) w[i] = lone[i] ? dsh[i] / a : 1.0;
+        if (threadIdx.x == 0) out[blockIdx.x] = a;
+        return;
+    }
     if (lane == 0) red[wv] = best;
     __syncthreads();
     if (threadIdx.x == 0) out[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
