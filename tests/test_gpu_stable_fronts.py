@@ -71,13 +71,13 @@ def test_the_threshold_follows_the_requested_tolerance(helm_lib, monkeypatch, ca
     assert counts[1e-12] > counts[1e-8], counts
 
 
-def test_row_scaling_is_not_taken_for_ill_conditioning_and_factors_are_reproducible(helm_lib, monkeypatch, capfd):
+def test_decoupled_rows_are_not_taken_for_ill_conditioning_and_factors_are_reproducible(helm_lib, monkeypatch, capfd):
     """Round 5.  The MiniZephyr system keeps identity rows on the outer boundary (norm 1) beside interior rows of norm 1e-5 (minizephyr.py:246-262 as
     restated by the oracle).  The product of the two plain infinity norms counted that scaling as a condition number of 1e6: every front touching the
     boundary was handed to the pivoted LU -- on a small model all of them, more than the 32 a group treats, and which 32 made it into the list depended on
-    the order the flagging threads ran in, so two factorisations of one operator differed in their last bits.  The estimate is row-equilibrated now and an
-    overflowing list is cut by estimate: (a) a well-conditioned MiniZephyr operator has no front treated; (b) with the threshold forced so low that every
-    group overflows, eight factorisations of one operator give bit-identical wavefields."""
+    the order the flagging threads ran in, so two factorisations of one operator differed in their last bits.  Decoupled (diagonal-only) rows are taken out
+    of the norms now and an overflowing list is cut by estimate: (a) a well-conditioned MiniZephyr operator has no front treated; (b) with the threshold
+    forced so low that every group overflows, eight factorisations of one operator give bit-identical wavefields."""
     import hashlib
     import re
     import torch
