@@ -59,7 +59,6 @@ struct NdStable {
     cplx *lu = nullptr;          // [smax][smax + mmax]: L\U of F11 in the first smax columns, the original F12 beside it
     cplx *f21 = nullptr;         // [mmax][smax]: the original F21
     int *piv = nullptr;          // [smax] row exchanges
-    NdDev *d_node = nullptr;     // the front's node record with its [F11 | F12] rows redirected to `lu` (rebuild pass)
     cplx *vs = nullptr; size_t vs_elems = 0;     // back-substitution scratch [smax + mmax][nrhs], grown on demand
 };
 

@@ -105,9 +105,9 @@ __global__ __launch_bounds__(256) void k_nd_extend_add(const NdDev *nodes, int f
 // front's rows once in LDS and then streams `rb` rows.  Traffic per level: children's F22 read once, the fronts written once
 // (the scatter form read-modify-wrote the parents twice on top of the memsets).
 __global__ __launch_bounds__(256) void k_nd_build_front(const NdDev *nodes, int first, cplx *arenaF, cplx *fac, const cplx *planes, int nz, int nx, int rb,
-                                                        const NdDev *ovr = nullptr, int skip22 = 0) {
+                                                        int skip22, int use_ovr, NdDev ovr) {
     extern __shared__ int2 finfo[];        // per padded row: x = z | x << 16 (-1: padding), y = (k0 + 1) | (k1 + 1) << 14 | comp << 28
-    const NdDev n = ovr ? *ovr : nodes[first + blockIdx.y];      // (ovr: one front rebuilt with its [F11 | F12] rows redirected, see NdStable)
+    const NdDev n = use_ovr ? ovr : nodes[first + blockIdx.y];   // (ovr, a launch argument: one front rebuilt with its [F11 | F12] rows redirected, see NdStable)
     const int nmax = n.smax + n.mmax;
     const int r0 = blockIdx.x * rb;
     if (r0 >= nmax) return;
@@ -423,7 +423,6 @@ static void stable_free(NdFactor *f) {
         helm_pool_free(dev, st.lu, (size_t)st.smax * nmax * sizeof(cplx));
         helm_pool_free(dev, st.f21, (size_t)std::max(1, st.mmax) * st.smax * sizeof(cplx));
         helm_pool_free(dev, st.piv, (size_t)st.smax * sizeof(int));
-        helm_pool_free(dev, st.d_node, sizeof(NdDev));
         helm_pool_free(dev, st.vs, st.vs_elems * sizeof(cplx));
     }
     f->stable.clear();
@@ -575,17 +574,14 @@ int stabilise_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *wor
         S.lu = (cplx *)helm_pool_alloc(op->device, (size_t)g.smax * nmax * sizeof(cplx));
         S.f21 = (cplx *)helm_pool_alloc(op->device, (size_t)std::max(1, g.mmax) * g.smax * sizeof(cplx));
         S.piv = (int *)helm_pool_alloc(op->device, (size_t)g.smax * sizeof(int));
-        S.d_node = (NdDev *)helm_pool_alloc(op->device, sizeof(NdDev));
         f->stable.push_back(S);                                                   // (owned by the factor from here on: freed by nd_free on every path)
-        if (!S.lu || !S.f21 || !S.piv || !S.d_node) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: allocation for an ill-conditioned front failed");
+        if (!S.lu || !S.f21 || !S.piv) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: allocation for an ill-conditioned front failed");
         NdDev n = P.nodes[S.node];
         const long long foff = n.foff;
         n.finv_off = 0; n.f12_off = g.smax;                                       // [F11 | F12] rows go to S.lu, [F21 | F22] back to the arena
-        HIP_TRY(op, hipMemcpyAsync(S.d_node, &n, sizeof(NdDev), hipMemcpyHostToDevice, st));
-        HIP_TRY(op, hipStreamSynchronize(st));                                    // (n is a stack copy)
         const int rb = std::max(std::min(nmax, 4), (nmax + 2047) / 2048);
         hipLaunchKernelGGL(k_nd_build_front, dim3((nmax + rb - 1) / rb, 1), dim3(256), (size_t)nmax * sizeof(int2), st, f->pd->d_nodes, 0, arenaF, S.lu, planes, P.nz, P.nx, rb,
-                           (const NdDev *)S.d_node);
+                           0, 1, n);                                                 // (the redirected node travels as a launch argument: no copy, no host wait)
         cplx *F21 = arenaF + foff, *F22 = arenaF + foff + g.smax;
         HIP_TRY(op, hipMemcpy2DAsync(S.f21, (size_t)g.smax * sizeof(cplx), F21, (size_t)nmax * sizeof(cplx), (size_t)g.smax * sizeof(cplx), (size_t)g.mmax, hipMemcpyDeviceToDevice, st));
         if (g.smax <= 64) hipLaunchKernelGGL(k_lu_factor64, dim3(1), dim3(256), 0, st, S.lu, nmax, g.smax, S.piv);
@@ -665,7 +661,7 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
         for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
             const int nb = std::min(65535, g.cnt - j0);
             hipLaunchKernelGGL(k_nd_build_front, dim3((nmax + rb - 1) / rb, nb), dim3(256), (size_t)nmax * sizeof(int2), st, d_nodes, g.first + j0, arenaF, f->d_fac, planes,
-                               P.nz, P.nx, rb, (const NdDev *)nullptr, schur_gather ? 1 : 0);
+                               P.nz, P.nx, rb, schur_gather ? 1 : 0, 0, NdDev());
         }
     } else {
         if (fs > 0) HIP_TRY(op, hipMemsetAsync(F, 0, (size_t)g.cnt * fs * sizeof(cplx), st));
