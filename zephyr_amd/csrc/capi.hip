@@ -59,6 +59,7 @@ helm_tuning helm_tuning_now() {
     t.nd_xcd_map = tune_i("HELM_ND_XCDMAP", 2);
     t.nd_plans = std::max(1, tune_i("HELM_ND_PLANS", 6));
     t.nd_direct_out = tune_i("HELM_ND_DIRECT_OUT", 1);
+    t.nd_leaf_idle = tune_i("HELM_ND_LEAF_IDLE", 1);
     t.auto_direct = tune_i("HELM_AUTO_DIRECT", 1);
     t.auto_mg3 = tune_i("HELM_AUTO_MG3", 1);
     t.prof_ext = tune_i("HELM_PROF_EXT", 1);

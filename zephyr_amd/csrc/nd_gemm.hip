@@ -41,6 +41,118 @@ void launch_mfma(hipStream_t st, int idx, int nb, int M, int Nn, int K, cplx alp
     else ZG_LAUNCH((k_zgemm3<WM, WN, MT, NT, 0, KS, OCC>), grid, M, Nn, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, R);
 }
 
+// Leaf back substitution where a leaf has no right-hand side in a block of 64 columns (round 5) -- nearly every (leaf, block) pair of a survey's
+// point sources.  There x_S = G x_B: 32 ring rows against the last 33 columns of [F11^-1 | G].  Through the slab pipeline of the tile kernel that is
+// five slabs, i.e. five exposed load latencies in a row (row-table look-up, then one per slab; ~28 us per workgroup for 106 KB, the launch at 45 % of its
+// traffic).  Here a workgroup issues EVERYTHING it will read back to back: the nine row-table entries a lane needs, then its nine B fragments straight into
+// the registers the matrix instructions take them from (lane l of wave w: row 4 kg + l / 16, column 16 w + l % 16 -- a fragment IS a row-major 4 x 16
+// piece of B, no LDS), and the 49 x 36 piece of A through registers into a fragment-ordered LDS image (one barrier).  Same k groups of four (aligned at
+// 48 = 8 (k2 / 8), the y_S row 48 taken as the zero it is), same order of the matrix instructions per accumulator, same order of the vector-ALU sums of
+// row 49 as zgemm3_body<1, 4, 3, 1, 1, 8, 1>: the results are bit for bit those of the tile kernel started at row 48, which are bit for bit those of
+// the full product (tests/test_gpu_direct.py, sparse right-hand sides).  The tile kernel takes the blocks whose flag is up (GemmRows::idle_done).
+constexpr int LBI_KG = 9;                                            // k groups of four from kbeg on: covers K - kbeg <= 36
+__global__ __launch_bounds__(256, 3) void k_leaf_bwd_idle(int M, int Nn, int K, cplx alpha, const cplx *A0, int lda, long long sa, cplx beta, GemmRows R) {
+    constexpr int FA = 4, TMM = 48, TN = 64;
+    __shared__ cplx As[LBI_KG * FA * 64];
+    int bxi = blockIdx.x, bzi = blockIdx.z;
+    if (gridDim.x > 1 && gridDim.z >= 16 && R.xcd_map) {              // the four column blocks of a leaf on one XCD (see zgemm3_body)
+        const int nt = gridDim.x, nbz = gridDim.z;
+        const int L = blockIdx.x + nt * blockIdx.z;
+        const int full = (nbz / 8) * 8 * nt;
+        if (L < full) { const int grp = L / (8 * nt), w = L % (8 * nt); bzi = grp * 8 + (w & 7); bxi = w >> 3; }
+        else { bzi = (nbz / 8) * 8 + (L - full) / nt; bxi = (L - full) % nt; }
+    }
+    const int n0 = bxi * TN;
+    if (R.act_ro[(long long)(R.first + R.z0 + bzi) * R.nct + (n0 >> 6)]) return;      // a right-hand side in this block: the tile kernel's
+    const cplx *A = A0 + (long long)bzi * sa;
+    const int tid = threadIdx.x, wn = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+    const long long trow = (long long)(R.z0 + bzi) * R.tab_stride;
+    const int kbeg = (R.k2 / 8) * 8;
+    // row-table entries: the B rows of this lane's k, the C rows of its outputs
+    int rk[LBI_KG], ro[3][4], ro48 = -1;
+    #pragma unroll
+    for (int kg = 0; kg < LBI_KG; ++kg) {
+        const int k = kbeg + 4 * kg + lq;
+        rk[kg] = (k >= R.k2 && k < K) ? R.tabB[trow + R.offB + k].x : -1;          // (k < k2: a y_S row of a block without right-hand side -- zero)
+    }
+    #pragma unroll
+    for (int i = 0; i < 3; ++i)
+        #pragma unroll
+        for (int q = 0; q < 4; ++q) { const int r = 16 * i + lq + 4 * q; ro[i][q] = r < M ? R.tabCo[trow + R.offCo + r].x : -1; }
+    if (TMM < M) ro48 = R.tabCo[trow + R.offCo + TMM].x;
+    // A: rows 0 .. 48, columns kbeg .. kbeg + 35
+    constexpr int NA = (49 * 4 * LBI_KG + 255) / 256;
+    cplx ra[NA];
+    #pragma unroll
+    for (int e = 0; e < NA; ++e) {
+        const int idx = tid + e * 256;
+        const int ar = idx / (4 * LBI_KG), ak = idx % (4 * LBI_KG);
+        cplx v = cmake(0.0, 0.0);
+        if (ar < 49 && ar < M && kbeg + ak < K) v = A[(long long)ar * lda + kbeg + ak];
+        ra[e] = v;
+    }
+    const int cc = n0 + 16 * wn + lr;
+    cplx breg[LBI_KG];
+    #pragma unroll
+    for (int kg = 0; kg < LBI_KG; ++kg) breg[kg] = (rk[kg] >= 0 && cc < Nn) ? R.Bx[(long long)rk[kg] * R.ldx + cc] : cmake(0.0, 0.0);
+    #pragma unroll
+    for (int e = 0; e < NA; ++e) {
+        const int idx = tid + e * 256;
+        const int ar = idx / (4 * LBI_KG), ak = idx % (4 * LBI_KG);
+        if (ar < 49) As[((ak >> 2) * FA + (ar >> 4)) * 64 + (ak & 3) * 16 + ((ar & 15) ^ (ak & 3) ^ (((ak >> 2) & 1) << 2))] = ra[e];
+    }
+    __syncthreads();
+    v4f64 cr[3], ci[3];
+    #pragma unroll
+    for (int i = 0; i < 3; ++i) { cr[i] = (v4f64){0, 0, 0, 0}; ci[i] = (v4f64){0, 0, 0, 0}; }
+    cplx xacc = cmake(0.0, 0.0);
+    #pragma unroll
+    for (int kg = 0; kg < LBI_KG; ++kg) {
+        if (kbeg + 4 * kg >= K) break;                                 // (a k group that is all padding)
+        cplx a[3];
+        const cplx b = breg[kg];
+        #pragma unroll
+        for (int i = 0; i < 3; ++i) a[i] = As[(kg * FA + i) * 64 + lq * 16 + (lr ^ lq ^ ((kg & 1) << 2))];
+        #pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            cr[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b.x, cr[i], 0, 0, 0);
+            ci[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b.y, ci[i], 0, 0, 0);
+        }
+        #pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double nai = -a[i].y;
+            cr[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, b.y, cr[i], 0, 0, 0);
+            ci[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b.x, ci[i], 0, 0, 0);
+        }
+        // row 49 on the vector ALUs: this lane's share of the k range is k = 4 kg + lq (the tile kernel's thread (column, share lq) takes the same k in the same order)
+        const cplx av = As[(kg * FA + FA - 1) * 64 + lq * 16 + (lq ^ ((kg & 1) << 2))];
+        cfma(xacc, av, b);
+    }
+    const cplx zero = cmake(0.0, 0.0);
+    #pragma unroll
+    for (int i = 0; i < 3; ++i)
+        #pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (ro[i][q] < 0 || cc >= Nn) continue;
+            cplx v = cmul(alpha, cmake(cr[i][q], ci[i][q]));
+            v = cadd(v, cmul(beta, zero));
+            if (R.cj_out) v = conj_scaled(R.oscale, v);
+            cplx *dst = R.Cox + (long long)ro[i][q] * R.ldx + cc;
+            if (R.ntc) __builtin_nontemporal_store((v2f64){v.x, v.y}, reinterpret_cast<v2f64 *>(dst)); else *dst = v;
+        }
+    // row 49: the four shares of a column sit in lanes lr, lr + 16, lr + 32, lr + 48 of this wave; added up in the tile kernel's order
+    {
+        cplx s = cmake(__shfl(xacc.x, lr), __shfl(xacc.y, lr));
+        #pragma unroll
+        for (int h = 1; h < 4; ++h) s = cadd(s, cmake(__shfl(xacc.x, lr + 16 * h), __shfl(xacc.y, lr + 16 * h)));
+        if (lq == 0 && TMM < M && ro48 >= 0 && cc < Nn) {
+            cplx v = cmul(alpha, s);
+            if (R.cj_out) v = conj_scaled(R.oscale, v);
+            R.Cox[(long long)ro48 * R.ldx + cc] = v;
+        }
+    }
+}
+
 // C = beta C + alpha (sum of the ksplit partial products of a split launch); parts: [chunk][matrix][M x Nn]
 __global__ __launch_bounds__(256) void k_splitk_reduce(const cplx *__restrict__ parts, int ksplit, long long pstride, int M, int Nn, cplx alpha, cplx beta,
                                                        cplx *__restrict__ C, int ldc, long long sc, long long total) {
@@ -160,6 +272,13 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
         if (rows && !rows->dense && !rows->schur4 && nb >= 64) R.ntc = 1;
         const cplx *Ab = A + b0 * sa, *Bb = B ? B + b0 * sb : B;
         cplx *Cb = C ? C + b0 * sc : C;
+        // leaf back substitution on sparse right-hand sides: the (leaf, block of 64 columns) pairs without a right-hand side go to k_leaf_bwd_idle
+        if (idxmode == 1 && M == 49 && rows->act_ro && rows->k2 > 0 && K - (rows->k2 / 8) * 8 <= 4 * LBI_KG && Nn % 64 == 0 && rows->tabB && rows->tabCo && !rows->tabCi &&
+            !rows->Cox2 && beta.x == 0.0 && beta.y == 0.0 && g_gemm_tile < 0 && R.zr1 == 0 && R.zc1 == 0 && R.sk1 == 0 && helm_tuning_now().nd_leaf_idle != 0) {
+            R.idle_done = 1;
+            ExtArm arm2(op, ext, 0.0, 0.0, M, Nn, K, nb, 6);          // (booked with its time and no flops: the tile launch below carries the product's)
+            ZG_LAUNCH(k_leaf_bwd_idle, dim3(Nn / 64, 1, nb), M, Nn, K, alpha, Ab, lda, sa, beta, R);
+        }
         ExtArm arm(op, ext, 8.0 * M * (double)Nn * K * nb, gemm_operand_bytes(M, Nn, K, beta, rows) * nb, M, Nn, K, nb, idxmode ? idxmode : (rows && rows->la ? 5 : 0));
 #define ZG_ARGS st, idxmode, nb, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R
 #define ZG_MFMA(WM_, WN_, MT_, NT_, KS_) launch_mfma<WM_, WN_, MT_, NT_, KS_>(ZG_ARGS)

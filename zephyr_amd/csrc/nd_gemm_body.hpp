@@ -217,6 +217,7 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
         const int ncl = ((Nn - n0 < TN ? Nn - n0 : TN) + 63) >> 6;
         int any = 0;
         for (int j = 0; j < ncl; ++j) any |= fl[j];
+        if (!any && R.idle_done) return;                              // (uniform across the workgroup)
         if (!any) kbeg = (R.k2 / KS) * KS;
     }
     fetch(kbeg);

@@ -41,6 +41,7 @@ struct GemmRows {
     // back substitution of the leaves, same flags read-only: where a leaf's flag is 0 its first k2 rows of B (its right-hand-side rows y_S) are all
     // zero in that block of columns, and the product starts at row k2 -- x_S = G x_B, 32 of the 81 columns of [F11^-1 | G]
     const int *act_ro = nullptr;
+    int idle_done = 0;          // (with act_ro) the blocks whose flag is 0 have been taken by k_leaf_bwd_idle: the tile kernel leaves them alone
     int hint = 0;               // (IDX 1 with act, leaf forward elimination) the flags were set from a declared support of the right-hand sides: a front without one is left
                                 // before it reads a byte
     int ntc = 0;                // store C with nontemporal stores (large HBM-bound launches whose output is not read again soon)
