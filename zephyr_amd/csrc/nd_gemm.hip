@@ -153,6 +153,75 @@ __global__ __launch_bounds__(256, 3) void k_leaf_bwd_idle(int M, int Nn, int K, 
     }
 }
 
+// The same idea for the one-product back substitution of the small separator fronts (at most 16 unknowns: x_S = [F11^-1 | G][y_S; x_B] with K = s + m of
+// 56 or 80): one block row of the matrix cores, the KGN B fragments of a lane loaded straight into registers through the row table (rows k < k2 from Bx2),
+// A (16 x 4 KGN) through one LDS image, every load in flight at once instead of 7-10 slabs one after the other.  Reads all its rows before it stores any
+// (y_S -> x_S in place in Xt); stores as the tile kernel does (Cox, and Cox2 = conj(oscale x) beside it for the caller's wavefield array).
+template <int KGN>
+__global__ __launch_bounds__(256, 3) void k_rowtab_small(int M, int Nn, int K, cplx alpha, const cplx *A0, int lda, long long sa, GemmRows R) {
+    constexpr int TN = 64;
+    __shared__ cplx As[KGN * 64];
+    int bxi = blockIdx.x, bzi = blockIdx.z;
+    if (gridDim.x > 1 && gridDim.z >= 16 && R.xcd_map) {              // the column blocks of a front on one XCD (see zgemm3_body)
+        const int nt = gridDim.x, nbz = gridDim.z;
+        const int L = blockIdx.x + nt * blockIdx.z;
+        const int full = (nbz / 8) * 8 * nt;
+        if (L < full) { const int grp = L / (8 * nt), w = L % (8 * nt); bzi = grp * 8 + (w & 7); bxi = w >> 3; }
+        else { bzi = (nbz / 8) * 8 + (L - full) / nt; bxi = (L - full) % nt; }
+    }
+    const int n0 = bxi * TN;
+    const cplx *A = A0 + (long long)bzi * sa;
+    const int tid = threadIdx.x, wn = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+    const long long trow = (long long)(R.z0 + bzi) * R.tab_stride;
+    int rk[KGN], ro[4];
+    #pragma unroll
+    for (int kg = 0; kg < KGN; ++kg) { const int k = 4 * kg + lq; rk[kg] = k < K ? R.tabB[trow + R.offB + k].x : -1; }
+    #pragma unroll
+    for (int q = 0; q < 4; ++q) { const int r = lq + 4 * q; ro[q] = r < M ? R.tabCo[trow + R.offCo + r].x : -1; }
+    constexpr int NA = (16 * 4 * KGN + 255) / 256;
+    cplx ra[NA];
+    #pragma unroll
+    for (int e = 0; e < NA; ++e) {
+        const int idx = tid + e * 256;
+        const int ar = idx / (4 * KGN), ak = idx % (4 * KGN);
+        cplx v = cmake(0.0, 0.0);
+        if (ar < 16 && ar < M && ak < K) v = A[(long long)ar * lda + ak];
+        ra[e] = v;
+    }
+    const int cc = n0 + 16 * wn + lr;
+    cplx breg[KGN];
+    #pragma unroll
+    for (int kg = 0; kg < KGN; ++kg) {
+        const int k = 4 * kg + lq;
+        breg[kg] = (rk[kg] >= 0 && cc < Nn) ? (k < R.k2 ? R.Bx2 : R.Bx)[(long long)rk[kg] * R.ldx + cc] : cmake(0.0, 0.0);
+    }
+    #pragma unroll
+    for (int e = 0; e < NA; ++e) {
+        const int idx = tid + e * 256;
+        const int ar = idx / (4 * KGN), ak = idx % (4 * KGN);
+        if (ar < 16) As[(ak >> 2) * 64 + (ak & 3) * 16 + ar] = ra[e];
+    }
+    __syncthreads();
+    v4f64 cr = {0, 0, 0, 0}, ci = {0, 0, 0, 0};
+    #pragma unroll
+    for (int kg = 0; kg < KGN; ++kg) {
+        const cplx a = As[kg * 64 + lq * 16 + lr], b = breg[kg];          // (k groups past K hold zeros)
+        cr = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, cr, 0, 0, 0);
+        ci = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.y, ci, 0, 0, 0);
+        cr = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.y, b.y, cr, 0, 0, 0);
+        ci = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.x, ci, 0, 0, 0);
+    }
+    #pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (ro[q] < 0 || cc >= Nn) continue;
+        cplx v = cmul(alpha, cmake(cr[q], ci[q]));
+        if (R.cj_out) v = conj_scaled(R.oscale, v);
+        cplx *dst = R.Cox + (long long)ro[q] * R.ldx + cc;
+        if (R.ntc) __builtin_nontemporal_store((v2f64){v.x, v.y}, reinterpret_cast<v2f64 *>(dst)); else *dst = v;
+        if (R.Cox2) { const cplx u = conj_scaled(R.oscale, v); __builtin_nontemporal_store((v2f64){u.x, u.y}, reinterpret_cast<v2f64 *>(dst + (R.Cox2 - R.Cox))); }
+    }
+}
+
 // C = beta C + alpha (sum of the ksplit partial products of a split launch); parts: [chunk][matrix][M x Nn]
 __global__ __launch_bounds__(256) void k_splitk_reduce(const cplx *__restrict__ parts, int ksplit, long long pstride, int M, int Nn, cplx alpha, cplx beta,
                                                        cplx *__restrict__ C, int ldc, long long sc, long long total) {
@@ -280,6 +349,13 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
             ZG_LAUNCH(k_leaf_bwd_idle, dim3(Nn / 64, 1, nb), M, Nn, K, alpha, Ab, lda, sa, beta, R);
         }
         ExtArm arm(op, ext, 8.0 * M * (double)Nn * K * nb, gemm_operand_bytes(M, Nn, K, beta, rows) * nb, M, Nn, K, nb, idxmode ? idxmode : (rows && rows->la ? 5 : 0));
+        // one-product back substitution of the small separator fronts: every load in flight at once (k_rowtab_small)
+        if (idxmode == 1 && M <= 16 && K <= 80 && nb >= 256 && Nn % 64 == 0 && rows->tabB && rows->tabCo && !rows->tabCi && !rows->act && !rows->act_ro && rows->Bx2 &&
+            beta.x == 0.0 && beta.y == 0.0 && g_gemm_tile < 0 && R.zr1 == 0 && R.zc1 == 0 && R.sk1 == 0 && helm_tuning_now().nd_leaf_idle != 0) {
+            if (K <= 56) ZG_LAUNCH(k_rowtab_small<14>, dim3(Nn / 64, 1, nb), M, Nn, K, alpha, Ab, lda, sa, R);
+            else ZG_LAUNCH(k_rowtab_small<20>, dim3(Nn / 64, 1, nb), M, Nn, K, alpha, Ab, lda, sa, R);
+            continue;
+        }
 #define ZG_ARGS st, idxmode, nb, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R
 #define ZG_MFMA(WM_, WN_, MT_, NT_, KS_) launch_mfma<WM_, WN_, MT_, NT_, KS_>(ZG_ARGS)
         if (rows && rows->la) {           // update + pivot sweep of the next block in one launch
