@@ -288,7 +288,7 @@ typedef struct helm_tuning {
     int    nd_xcd_map;         /* HELM_ND_XCDMAP         2     workgroup ids regrouped so that a front's tiles share an XCD (0 off, 1 column tiles only) */
     int    nd_plans;           /* HELM_ND_PLANS          6     elimination-tree plans cached per device */
     int    nd_direct_out;      /* HELM_ND_DIRECT_OUT     1     back substitution writes the caller's wavefield array itself (node-major calls) */
-    int    nd_leaf_idle;       /* HELM_ND_LEAF_IDLE      1     leaf back substitution: blocks of 64 columns without a right-hand side in a leaf go to a kernel that issues all its loads at once */
+    int    nd_leaf_idle;       /* HELM_ND_LEAF_IDLE      1     sparse right-hand sides: idle leaf blocks and small separator fronts of the back substitution go to kernels that issue all their loads at once; the forward pass deals its separator levels from lists of active (front, block) pairs */
     /* dispatch / memory */
     int    auto_direct;        /* HELM_AUTO_DIRECT       1     HELM_AUTO takes the direct path in 2-D */
     int    auto_mg3;           /* HELM_AUTO_MG3          1     HELM_AUTO takes the multigrid-preconditioned path in 3-D */

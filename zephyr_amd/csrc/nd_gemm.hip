@@ -367,6 +367,10 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
         // computed, 1.89 -> 1.70 on point sources; a K slab of 16 halves the occupancy again: 3.7 / 4.7 ms)
         const bool plain = !rows || (!rows->schur4 && !rows->fwd3 && !rows->ksplit && rows->zr1 == 0 && rows->zc1 == 0 && rows->sk1 == 0);
         if (M == 49 && Nn >= 64 && plain && idxmode <= 1 && g_gemm_tile < 0) { launch_mfma_xr<3, 1, 8>(ZG_ARGS); continue; }
+        if (idxmode == 2 && rows->list) {             // forward gather dealt from the level's list of active (front, block) pairs: 64 x 64 tiles, one x per pair
+            ZG_LAUNCH((k_zgemm3<2, 2, 2, 2, 2, 8, 2>), dim3((unsigned)nb * (unsigned)R.nct, (M + 63) / 64, 1), M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R);
+            continue;
+        }
         if (latency_mode) { if (vsel == 6) ZG_MFMA(2, 2, 1, 1, 16); else ZG_MFMA(1, 4, 1, 1, 16); continue; }
         switch (vsel) {
             case 0: ZG_MFMA(2, 2, 2, 2, 8); break;

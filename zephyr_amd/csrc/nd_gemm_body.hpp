@@ -55,6 +55,11 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
         else { bzi = (nbz / 8) * 8 + (L - full) / nt; tile = (L - full) % nt; }
         bxi = tile % nxt; byi = tile / nxt;
     }
+    if (IDX == 2 && R.list) {                            // the launch is dealt from a list of the pairs that have work (see GemmRows::list)
+        if ((int)blockIdx.x >= *R.lcount) return;
+        const int pair = R.list[blockIdx.x];
+        bzi = pair / R.nct; bxi = pair % R.nct; byi = blockIdx.y;
+    }
     int zb = bzi;
     if (IDX == 0 && R.ksplit > 1) {                      // this workgroup's share of the inner dimension
         const int kch = zb % R.ksplit;
@@ -94,13 +99,13 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
         // (over whole blocks of 64 columns: the workgroups of a tile narrower than that share a flag and must all come to the same verdict)
         constexpr int TS = TN < 64 ? 64 : TN;
         const int ns0 = TN < 64 ? (n0 & ~63) : n0;
-        if (!(am0 | am1))
+        if (!(am0 | am1) && !R.list)
             for (int e = tid; e < K * TS; e += 256) {
                 const int k = e / TS, bc = e % TS;
                 const int4 t4 = kidx4[k];
                 if (t4.w && ns0 + bc < Nn) { const cplx v = R.Bx[(long long)t4.x * R.ldx + ns0 + bc]; nzq |= (v.x != 0.0 || v.y != 0.0); }
             }
-        if (!(am0 | am1) && !__syncthreads_or(nzq)) {
+        if (!R.list && !(am0 | am1) && !__syncthreads_or(nzq)) {
             if (byi == 0 && R.Cox)                                // y_S = 0 where the back substitution will look for it
                 for (int e = tid; e < K * TN; e += 256) {
                     const int k = e / TN, bc = e % TN;
@@ -109,7 +114,7 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
                 }
             return;
         }
-        if (byi == 0 && tid < ncl) R.act[node * R.nct + ct0 + tid] = 1;
+        if (!R.list && byi == 0 && tid < ncl) R.act[node * R.nct + ct0 + tid] = 1;      // (list: k_fwd_flags has raised it)
     }
     if (IDX == 1 && R.act && R.hint) {                                   // declared support: a leaf none of whose blocks of 64 columns carries a right-hand side is not read
         const int *fl = R.act + (long long)(R.first + R.z0 + bzi) * R.nct + (n0 >> 6);

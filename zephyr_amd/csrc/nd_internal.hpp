@@ -38,6 +38,9 @@ struct GemmRows {
     // outgoing rows were computed for that block of 64 columns -- a front whose own right-hand-side rows and whose children's rows are all zero
     // there has nothing to add, writes zeros for its y_S rows and leaves its ring rows unwritten (its parent reads the flag, not the rows)
     int *act = nullptr; int nct = 0;
+    // (fwd3, r5) the (front, block of 64 columns) pairs of this level that have anything to do, found by k_fwd_flags before the launch: workgroup x takes
+    // pair list[x] (front = pair / nct, block = pair % nct), workgroups from *lcount on leave at once; 64-column tiles only
+    const int *list = nullptr, *lcount = nullptr;
     // back substitution of the leaves, same flags read-only: where a leaf's flag is 0 its first k2 rows of B (its right-hand-side rows y_S) are all
     // zero in that block of columns, and the product starts at row k2 -- x_S = G x_B, 32 of the 81 columns of [F11^-1 | G]
     const int *act_ro = nullptr;

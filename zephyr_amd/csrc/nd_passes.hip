@@ -69,11 +69,61 @@ __global__ __launch_bounds__(256) void k_nd_bwd_store(const int4 *tab, const cpl
     }
 }
 
+// Forward pass on sparse right-hand sides, separator levels (round 5): which (front, block of 64 columns) pairs of a level have anything to do -- a child with
+// outgoing rows there, or a nonzero among the front's own right-hand-side rows -- decided by ONE WAVE per pair before the level's product is launched.
+// The product's workgroups hold 144 registers per lane (three per compute unit): with the decision inside them, a level of 8192 fronts x 4 blocks cost
+// 200 us whether 8192 or 8 of its fronts had work (43 rounds of workgroups that fetch a node record, two flags and eight rows and leave).  Here 32 waves
+// per compute unit do the looking, the pairs with work go on a list (in no particular order: every pair is computed by itself), the others get the zeros
+// the back substitution expects in their y_S rows, and the product is dealt from the list.
+// NR rows per wave, WPP waves per pair (a workgroup of four waves takes 4 / WPP pairs).  All row-table entries of a wave are requested first, then all the
+// right-hand-side values they point to (masked rows read a zero instead of being branched around): two memory round trips per wave, beside the two of the
+// children's flags -- a first version with `if (valid) load` inside the row loop paid two per ROW (117 us for the 8192-front level).
+static __device__ cplx g_fwd_zero[4];
+template <int NR, int WPP>
+__global__ __launch_bounds__(256) void k_fwd_flags(const int4 *__restrict__ tab, int nmax, int smax, const NdDev *__restrict__ nodes, int first, int cnt, int nct,
+                                                   int *__restrict__ act, const cplx *__restrict__ Q, cplx *__restrict__ Xt, int ldx, int nrhs,
+                                                   int *__restrict__ count, int *__restrict__ list) {
+    __shared__ int wnz[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = blockIdx.x * (4 / WPP) + wave / WPP, part = wave % WPP;
+    const bool live = pair < cnt * nct;
+    const int j = live ? pair / nct : 0, b = live ? pair - j * nct : 0;
+    const int k0 = nodes[first + j].kid[0], k1 = nodes[first + j].kid[1];
+    const int a0 = k0 >= 0 ? act[(long long)k0 * nct + b] : 0, a1 = k1 >= 0 ? act[(long long)k1 * nct + b] : 0;
+    const int col = 64 * b + lane;
+    const int4 *t = tab + (long long)j * nmax;
+    int rows[NR];
+    #pragma unroll
+    for (int i = 0; i < NR; ++i) { const int r = part + WPP * i; const int4 e = (live && r < smax) ? t[r] : make_int4(-1, -1, -1, 0); rows[i] = (e.w && col < nrhs) ? e.x : -1; }
+    cplx v[NR];
+    #pragma unroll
+    for (int i = 0; i < NR; ++i) v[i] = *(rows[i] >= 0 ? Q + (long long)rows[i] * ldx + col : g_fwd_zero);
+    int nz = 0;
+    #pragma unroll
+    for (int i = 0; i < NR; ++i) nz |= (v[i].x != 0.0 || v[i].y != 0.0) ? 1 : 0;
+    int anyw = __any(nz) ? 1 : 0;
+    if (WPP > 1) {
+        if (lane == 0) wnz[wave] = anyw;
+        __syncthreads();
+        anyw = 0;
+        #pragma unroll
+        for (int q = 0; q < WPP; ++q) anyw |= wnz[(wave / WPP) * WPP + q];
+    }
+    if (!live) return;
+    if (a0 || a1 || anyw) {
+        if (part == 0 && lane == 0) { act[(long long)(first + j) * nct + b] = 1; list[atomicAdd(count, 1)] = pair; }
+        return;
+    }
+    #pragma unroll
+    for (int i = 0; i < NR; ++i) if (rows[i] >= 0) Xt[(long long)rows[i] * ldx + col] = cmake(0.0, 0.0);      // y_S = 0 where the back substitution will look for it
+}
+
 struct SolveCtx {
     const int4 *tab; cplx *Xt, *arenaV; int nrhs; dim3 rb; int use_idx;
     const cplx *Qt;       // node-major right-hand sides (read only); == Xt for an in-place solve
     int *act = nullptr; int nct = 0;     // sparse-right-hand-side flags of the forward pass (null: every front is computed)
     int act_hint = 0;                    // the leaves' flags come from the support the caller declared (helm_set_rhs_support): no scan of q
+    int *fcount = nullptr, *flist = nullptr;      // (with act) per group: number of active (front, block) pairs of a separator level; the list of the level at hand
     cplx *Uout = nullptr; cplx oscale = {1.0, 0.0};      // direct output (NdDirectOut): the back substitution leaves u = conj(oscale x) in the caller's array [cell][nrhs]
     dim3 rgrid(long long rows) const { return dim3((unsigned)std::min<long long>((rows + rb.y - 1) / rb.y, 1 << 20)); }
 };
@@ -141,6 +191,15 @@ void forward_group_batched(helm_op *op, NdFactor *f, size_t gi, const SolveCtx &
         GemmRows R; R.fwd3 = 1; R.tabB = c.tab + g.roff; R.offB = 0; R.tabCi = c.tab + g.roff; R.offCi = g.smax; R.tab_stride = nmax;
         R.Bx = c.Qt; R.Cix = c.arenaV; R.Cox = c.Xt; R.ldx = nrhs;
         R.act = c.act; R.nct = c.nct; R.first = g.first; R.nodes = f->pd->d_nodes;
+        if (c.act && c.flist && g.cnt <= 65535 && g.smax <= 128 && helm_tuning_now().nd_leaf_idle != 0) {      // who has work: decided before the launch, which is dealt from the list
+            const int pairs = g.cnt * c.nct;
+#define FWD_FLAGS(NR_, WPP_) hipLaunchKernelGGL((k_fwd_flags<NR_, WPP_>), dim3((pairs + 4 / WPP_ - 1) / (4 / WPP_)), dim3(256), 0, op->stream, c.tab + g.roff, nmax, g.smax, \
+                                                (const NdDev *)f->pd->d_nodes, g.first, g.cnt, c.nct, c.act, c.Qt, c.Xt, nrhs, nrhs, c.fcount + gi, c.flist)
+            if (g.smax <= 8) FWD_FLAGS(8, 1); else if (g.smax <= 16) FWD_FLAGS(16, 1); else if (g.smax <= 32) FWD_FLAGS(16, 2); else if (g.smax <= 64) FWD_FLAGS(16, 4);
+            else FWD_FLAGS(32, 4);
+#undef FWD_FLAGS
+            R.list = c.flist; R.lcount = c.fcount + gi;
+        }
         { const NdDev &n0 = P.nodes[g.first]; R.child_rows = (n0.kid[0] >= 0 ? P.nodes[n0.kid[0]].mmax : 0) + (n0.kid[1] >= 0 ? P.nodes[n0.kid[1]].mmax : 0); }
         gemm(op, g.mmax, nrhs, g.smax, mone, f->d_fac + g.g21, g.smax, (long long)g.mmax * g.smax, nullptr, 0, 0, one,
              V + (long long)g.smax * nrhs, nrhs, (long long)nmax * nrhs, g.cnt, &R);
@@ -307,16 +366,21 @@ static void arm_sparse_rhs(helm_op *op, NdFactor *f, SolveCtx &c, hipStream_t st
     f->act_nct = 0;
     if (!on || c.Qt == c.Xt || f->pd->plan.dof != 1) return;
     const int nct = (c.nrhs + 63) / 64;
-    const size_t need = f->pd->plan.nodes.size() * (size_t)nct;
-    if (f->act_elems < need) {
+    // layout: [flags: fronts x nct][active-pair counts: one per group][the list of the level at hand: largest cnt x nct]
+    const size_t nflags = f->pd->plan.nodes.size() * (size_t)nct, ngroups = f->pd->plan.groups.size();
+    size_t maxpairs = 1;
+    for (const NdGroup &g : f->pd->plan.groups) if (!g.leaf) maxpairs = std::max(maxpairs, (size_t)g.cnt * (size_t)std::max(4, nct));
+    const size_t need = nflags + ngroups;
+    if (f->act_elems < need + maxpairs) {
         if (f->d_act) { hipStreamSynchronize(st); helm_pool_free(op->device, f->d_act, f->act_elems * sizeof(int)); f->d_act = nullptr; f->act_elems = 0; }
-        const size_t want = f->pd->plan.nodes.size() * (size_t)std::max(4, nct);
+        const size_t want = f->pd->plan.nodes.size() * (size_t)std::max(4, nct) + ngroups + maxpairs;
         f->d_act = (int *)helm_pool_alloc(op->device, want * sizeof(int));
         if (!f->d_act) return;
         f->act_elems = want;
     }
     if (hipMemsetAsync(f->d_act, 0, need * sizeof(int), st) != hipSuccess) { (void)hipGetLastError(); return; }
     c.act = f->d_act; c.nct = nct;
+    c.fcount = f->d_act + nflags; c.flist = f->d_act + nflags + ngroups;
     f->act_nct = nct;
     // Declared support (helm_set_rhs_support: one byte per cell, bit b = block b of 64 columns may be nonzero there; what helm_rhs_support_from_coo makes of
     // the triplets of a scipy-sparse source matrix): the leaves' flags are set from it and the leaf level of the forward pass no longer reads q to find out --
