@@ -82,7 +82,7 @@ static __device__ cplx g_fwd_zero[4];
 template <int NR, int WPP>
 __global__ __launch_bounds__(256) void k_fwd_flags(const int4 *__restrict__ tab, int nmax, int smax, const NdDev *__restrict__ nodes, int first, int cnt, int nct,
                                                    int *__restrict__ act, const cplx *__restrict__ Q, cplx *__restrict__ Xt, int ldx, int nrhs,
-                                                   int *__restrict__ count, int *__restrict__ list) {
+                                                   int *__restrict__ count, int *__restrict__ list, int leaf) {
     __shared__ int wnz[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pair = blockIdx.x * (4 / WPP) + wave / WPP, part = wave % WPP;
@@ -111,9 +111,10 @@ __global__ __launch_bounds__(256) void k_fwd_flags(const int4 *__restrict__ tab,
     }
     if (!live) return;
     if (a0 || a1 || anyw) {
-        if (part == 0 && lane == 0) { act[(long long)(first + j) * nct + b] = 1; list[atomicAdd(count, 1)] = pair; }
+        if (part == 0 && lane == 0) { act[(long long)(first + j) * nct + b] = 1; if (!leaf) list[atomicAdd(count, 1)] = pair; }
         return;
     }
+    if (leaf) return;                                      // (a leaf's y_S is the right-hand side itself: nothing to zero, and its product leaves on the flag)
     #pragma unroll
     for (int i = 0; i < NR; ++i) if (rows[i] >= 0) Xt[(long long)rows[i] * ldx + col] = cmake(0.0, 0.0);      // y_S = 0 where the back substitution will look for it
 }
@@ -178,6 +179,17 @@ void forward_group_batched(helm_op *op, NdFactor *f, size_t gi, const SolveCtx &
         // leaves have no children: the outgoing ring part is -G21 x_S with x_S read straight from Xt
         GemmRows R; R.tabB = c.tab + g.roff; R.offB = 0; R.tab_stride = nmax; R.Bx = c.Qt; R.ldx = nrhs;
         R.act = c.act; R.nct = c.nct; R.first = g.first; R.hint = R.act ? c.act_hint : 0;
+        // r5: without a declared support the leaves' flags are found by k_fwd_flags (a wave pair per leaf and block of 64 columns, every load in flight at
+        // once) and the product then behaves as with a declared one: a workgroup whose flags are down leaves on one load.  (It used to find out itself:
+        // 753 us for the 3.2 GB of leaf rows, 54 % of the HBM rate, from workgroups of 134 registers per lane.)
+        if (R.act && !R.hint && c.flist && g.smax <= 64 && c.Qt != c.Xt && helm_tuning_now().nd_leaf_idle != 0) {
+            for (int j0 = 0; j0 < g.cnt; j0 += 32768) {
+                const int nbj = std::min(32768, g.cnt - j0), pairs = nbj * c.nct;
+                hipLaunchKernelGGL((k_fwd_flags<32, 2>), dim3((pairs + 1) / 2), dim3(256), 0, op->stream, c.tab + g.roff + (long long)j0 * nmax, nmax, g.smax,
+                                   (const NdDev *)f->pd->d_nodes, g.first + j0, nbj, c.nct, c.act, c.Qt, c.Xt, nrhs, nrhs, c.fcount + gi, c.flist, 1);
+            }
+            R.hint = 1;
+        }
         gemm(op, g.mmax, nrhs, g.smax, mone, f->d_fac + g.g21, g.smax, (long long)g.mmax * g.smax, nullptr, 0, 0, zero,
              V + (long long)g.smax * nrhs, nrhs, (long long)nmax * nrhs, g.cnt, &R);
         if (c.act && !R.act) hipMemsetAsync(c.act + (long long)g.first * c.nct, 1, (size_t)g.cnt * c.nct * sizeof(int), op->stream);
@@ -194,7 +206,7 @@ void forward_group_batched(helm_op *op, NdFactor *f, size_t gi, const SolveCtx &
         if (c.act && c.flist && g.cnt <= 65535 && g.smax <= 128 && helm_tuning_now().nd_leaf_idle != 0) {      // who has work: decided before the launch, which is dealt from the list
             const int pairs = g.cnt * c.nct;
 #define FWD_FLAGS(NR_, WPP_) hipLaunchKernelGGL((k_fwd_flags<NR_, WPP_>), dim3((pairs + 4 / WPP_ - 1) / (4 / WPP_)), dim3(256), 0, op->stream, c.tab + g.roff, nmax, g.smax, \
-                                                (const NdDev *)f->pd->d_nodes, g.first, g.cnt, c.nct, c.act, c.Qt, c.Xt, nrhs, nrhs, c.fcount + gi, c.flist)
+                                                (const NdDev *)f->pd->d_nodes, g.first, g.cnt, c.nct, c.act, c.Qt, c.Xt, nrhs, nrhs, c.fcount + gi, c.flist, 0)
             if (g.smax <= 8) FWD_FLAGS(8, 1); else if (g.smax <= 16) FWD_FLAGS(16, 1); else if (g.smax <= 32) FWD_FLAGS(16, 2); else if (g.smax <= 64) FWD_FLAGS(16, 4);
             else FWD_FLAGS(32, 4);
 #undef FWD_FLAGS
