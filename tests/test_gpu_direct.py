@@ -625,3 +625,40 @@ def test_sparse_right_hand_sides_skip_nothing_that_matters(helm_lib, monkeypatch
     assert not np.any(out['1'][:, 1])
     ref = ho.DirectOperator(ho.eurus_coefficients(nz, nx, c, za.Eurus(cfg).rho, 8., dx=10., dz=10., nPML=8), eurus=True) * q[:, [0, 2, nsrc - 1]]
     assert nrm(out['1'][:, [0, 2, nsrc - 1]], ref) <= 1e-7
+
+
+def test_short_product_kernels_and_listed_levels_change_no_bit(helm_lib, monkeypatch):
+    """Round 5 (helm_tuning.nd_leaf_idle).  On sparse right-hand sides three things leave the tile kernel's slab pipeline: the leaf back substitution of
+    the (leaf, 64-column block) pairs without a right-hand side (k_leaf_bwd_idle), the one-product back substitution of the separator fronts of 8 and 16
+    unknowns (k_rowtab_small), and the decision which pairs of a separator level have work (k_fwd_flags + a product dealt from the list).  Same k groups,
+    same order of the matrix instructions per accumulator: on a 256^2 grid (49-unknown leaves, levels of >= 256 fronts) with 128 right-hand sides -- point
+    sources, an empty block of 64 columns' worth of zeros in the second half, a dense column -- the wavefields are bit for bit those of the library with the
+    switch off, and those of the pass that computes every front (arena poisoned with NaNs)."""
+    import zephyr_amd as za
+    import torch
+    n, nrhs = 256, 128
+    rng = np.random.default_rng(5)
+    c = 1800. + 2000. * rng.random((n, n))
+    cfg = dict(nx=n, nz=n, dx=10., dz=10., c=c, freq=7., nPML=8, rtol=1e-10, method='direct', batch=256)
+    locs = np.stack([rng.uniform(100., 10. * n - 100., nrhs), rng.uniform(20., 60., nrhs)], axis=1)
+    q = za.SparseKaiserSource(cfg)(locs).toarray()
+    q[:, 70:128] = 0.0
+    q[:, 5] = rng.standard_normal(n * n) + 1j * rng.standard_normal(n * n)
+    q = np.ascontiguousarray(q)
+    monkeypatch.setenv('HELM_ND_POISON', '1')
+    out = {}
+    for idle, sparse in (('1', '1'), ('0', '1'), ('1', '0')):
+        monkeypatch.setenv('HELM_ND_LEAF_IDLE', idle)
+        monkeypatch.setenv('HELM_ND_SPARSE_RHS', sparse)
+        op = za.Eurus(cfg)
+        R = torch.from_numpy(q).cuda()
+        U = torch.empty_like(R)
+        op.solveDevice(R.data_ptr(), U.data_ptr(), nrhs, n * n, layout='node')
+        torch.cuda.synchronize()
+        out[idle + sparse] = U.cpu().numpy()
+        assert all(i['status'] == 0 and i['iterations'] == 1 for j, i in enumerate(op.lastInfo) if np.any(q[:, j])), op.lastInfo[:3]
+        del op.factors
+    assert np.isfinite(out['11']).all()
+    assert np.array_equal(out['11'], out['01'])
+    assert np.array_equal(out['11'], out['10'])
+    assert not np.any(out['11'][:, 100])
