@@ -442,13 +442,7 @@ void nd_free(NdFactor *f) {
 // Fronts that keep G = -F11^-1 F12 where F12 was, so that their back substitution is ONE product [F11^-1 | G] [y_S; x_B]: the leaves.
 // (Round 4 measured the same for every separator front of at most 64 unknowns: the 64-row tile pads the 8-, 16- and 32-row fronts of levels
 // 13-10 eight-, four- and two-fold on the matrix cores, 5.5 -> 6.7 ms per pass; removed.)
-// (Round 5: also the separator fronts of at most 16 unknowns with one unknown per cell -- levels 13-11 at 1024^2.  A front is then ONE 16-row tile of the
-// row-table product: it reads all its rows before it stores any, so y_S -> x_S happens in place in Xt, and the second launch of those levels goes.)
-bool merged_group(const NdPlan &P, const NdGroup &g) {
-    if (g.mmax <= 0) return false;
-    if (g.leaf) return true;
-    return P.dof == 1 && g.smax <= 16 && g.smax + g.mmax <= GB_KIDX;      // (measured at 1024^2 x 256: back substitution 5.27 -> 5.07 ms per pass)
-}
+bool merged_group(const NdPlan &P, const NdGroup &g) { (void)P; return g.mmax > 0 && g.leaf; }
 
 namespace {
 

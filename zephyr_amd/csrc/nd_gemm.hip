@@ -153,14 +153,19 @@ __global__ __launch_bounds__(256, 3) void k_leaf_bwd_idle(int M, int Nn, int K, 
     }
 }
 
-// The same idea for the one-product back substitution of the small separator fronts (at most 16 unknowns: x_S = [F11^-1 | G][y_S; x_B] with K = s + m of
-// 56 or 80): one block row of the matrix cores, the KGN B fragments of a lane loaded straight into registers through the row table (rows k < k2 from Bx2),
-// A (16 x 4 KGN) through one LDS image, every load in flight at once instead of 7-10 slabs one after the other.  Reads all its rows before it stores any
-// (y_S -> x_S in place in Xt); stores as the tile kernel does (Cox, and Cox2 = conj(oscale x) beside it for the caller's wavefield array).
+// The same idea for the back substitution of the small separator fronts (at most 16 unknowns, rings of up to 96):  x_S = F11^-1 (y_S - F12 x_B)  in ONE
+// launch instead of two, with every load of a workgroup in flight at once.  A lane's KGN fragments of x_B go straight into registers through the row
+// table; F12 (16 x m) and F11^-1 (16 x 16) go through one LDS image each.  The first product leaves t = y_S - F12 x_B in the layout the matrix cores write
+// -- rows l / 16 + 4 q of column l % 16 -- and that IS the fragment layout of a B operand with k group q, so the second product takes t from the registers
+// it is in.  Same k groups, same order of instructions and of the alpha / beta arithmetic as the two launches of the tile kernel it replaces
+// (t = -1 acc + 1 y_S; x = 1 acc' + 0): bit for bit their result.  Reads all its rows before it stores any (y_S -> x_S in place in Xt).
+// (A first version kept G = -F11^-1 F12 where F12 was, the leaves' one-product form: one more product per level at factor time, 0.1-0.15 ms each on the
+// critical path of the pipelined job, for 0.06-0.1 ms per pass.)
 template <int KGN>
-__global__ __launch_bounds__(256, 3) void k_rowtab_small(int M, int Nn, int K, cplx alpha, const cplx *A0, int lda, long long sa, GemmRows R) {
+__global__ __launch_bounds__(256, 3) void k_sep_bwd_small(int M, int Nn, int Km, const cplx *Finv0, const cplx *F120, int lda, long long sa, GemmRows R) {
     constexpr int TN = 64;
     __shared__ cplx As[KGN * 64];
+    __shared__ cplx Fs[4 * 64];
     int bxi = blockIdx.x, bzi = blockIdx.z;
     if (gridDim.x > 1 && gridDim.z >= 16 && R.xcd_map) {              // the column blocks of a front on one XCD (see zgemm3_body)
         const int nt = gridDim.x, nbz = gridDim.z;
@@ -170,12 +175,12 @@ __global__ __launch_bounds__(256, 3) void k_rowtab_small(int M, int Nn, int K, c
         else { bzi = (nbz / 8) * 8 + (L - full) / nt; bxi = (L - full) % nt; }
     }
     const int n0 = bxi * TN;
-    const cplx *A = A0 + (long long)bzi * sa;
+    const cplx *Finv = Finv0 + (long long)bzi * sa, *F12 = F120 + (long long)bzi * sa;
     const int tid = threadIdx.x, wn = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
     const long long trow = (long long)(R.z0 + bzi) * R.tab_stride;
     int rk[KGN], ro[4];
     #pragma unroll
-    for (int kg = 0; kg < KGN; ++kg) { const int k = 4 * kg + lq; rk[kg] = k < K ? R.tabB[trow + R.offB + k].x : -1; }
+    for (int kg = 0; kg < KGN; ++kg) { const int k = 4 * kg + lq; rk[kg] = k < Km ? R.tabB[trow + R.offB + k].x : -1; }      // ring rows (offB = the front's separator size)
     #pragma unroll
     for (int q = 0; q < 4; ++q) { const int r = lq + 4 * q; ro[q] = r < M ? R.tabCo[trow + R.offCo + r].x : -1; }
     constexpr int NA = (16 * 4 * KGN + 255) / 256;
@@ -185,37 +190,55 @@ __global__ __launch_bounds__(256, 3) void k_rowtab_small(int M, int Nn, int K, c
         const int idx = tid + e * 256;
         const int ar = idx / (4 * KGN), ak = idx % (4 * KGN);
         cplx v = cmake(0.0, 0.0);
-        if (ar < 16 && ar < M && ak < K) v = A[(long long)ar * lda + ak];
+        if (ar < 16 && ar < M && ak < Km) v = F12[(long long)ar * lda + ak];
         ra[e] = v;
     }
+    cplx rf = cmake(0.0, 0.0);
+    { const int ar = tid >> 4, ak = tid & 15; if (ar < M && ak < M) rf = Finv[(long long)ar * lda + ak]; }
     const int cc = n0 + 16 * wn + lr;
-    cplx breg[KGN];
+    cplx breg[KGN], ys[4];
     #pragma unroll
-    for (int kg = 0; kg < KGN; ++kg) {
-        const int k = 4 * kg + lq;
-        breg[kg] = (rk[kg] >= 0 && cc < Nn) ? (k < R.k2 ? R.Bx2 : R.Bx)[(long long)rk[kg] * R.ldx + cc] : cmake(0.0, 0.0);
-    }
+    for (int kg = 0; kg < KGN; ++kg) breg[kg] = (rk[kg] >= 0 && cc < Nn) ? R.Bx[(long long)rk[kg] * R.ldx + cc] : cmake(0.0, 0.0);
+    #pragma unroll
+    for (int q = 0; q < 4; ++q) ys[q] = (ro[q] >= 0 && cc < Nn) ? R.Cix[(long long)ro[q] * R.ldx + cc] : cmake(0.0, 0.0);
     #pragma unroll
     for (int e = 0; e < NA; ++e) {
         const int idx = tid + e * 256;
         const int ar = idx / (4 * KGN), ak = idx % (4 * KGN);
         if (ar < 16) As[(ak >> 2) * 64 + (ak & 3) * 16 + ar] = ra[e];
     }
+    { const int ar = tid >> 4, ak = tid & 15; Fs[(ak >> 2) * 64 + (ak & 3) * 16 + ar] = rf; }
     __syncthreads();
     v4f64 cr = {0, 0, 0, 0}, ci = {0, 0, 0, 0};
     #pragma unroll
     for (int kg = 0; kg < KGN; ++kg) {
-        const cplx a = As[kg * 64 + lq * 16 + lr], b = breg[kg];          // (k groups past K hold zeros)
+        const cplx a = As[kg * 64 + lq * 16 + lr], b = breg[kg];          // (k groups past the ring hold zeros)
         cr = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, cr, 0, 0, 0);
         ci = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.y, ci, 0, 0, 0);
         cr = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.y, b.y, cr, 0, 0, 0);
         ci = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.x, ci, 0, 0, 0);
     }
+    // t = y_S - F12 x_B as the tile kernel forms it (alpha = -1, beta = 1)
+    const cplx one = cmake(1.0, 0.0), mone = cmake(-1.0, 0.0), zero = cmake(0.0, 0.0);
+    cplx t[4];
+    #pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = cadd(cmul(mone, cmake(cr[q], ci[q])), cmul(one, ys[q]));
+    // x_S = F11^-1 t: row l / 16 + 4 q of t is row (k group q, k = l / 16) of a B operand
+    v4f64 xr = {0, 0, 0, 0}, xi = {0, 0, 0, 0};
+    #pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (4 * q >= M) break;
+        const cplx a = Fs[q * 64 + lq * 16 + lr], b = t[q];
+        xr = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, xr, 0, 0, 0);
+        xi = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.y, xi, 0, 0, 0);
+        xr = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.y, b.y, xr, 0, 0, 0);
+        xi = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.x, xi, 0, 0, 0);
+    }
     #pragma unroll
     for (int q = 0; q < 4; ++q) {
         if (ro[q] < 0 || cc >= Nn) continue;
-        cplx v = cmul(alpha, cmake(cr[q], ci[q]));
-        if (R.cj_out) v = conj_scaled(R.oscale, v);
+        cplx v = cmul(one, cmake(xr[q], xi[q]));
+        v = cadd(v, cmul(zero, zero));
         cplx *dst = R.Cox + (long long)ro[q] * R.ldx + cc;
         if (R.ntc) __builtin_nontemporal_store((v2f64){v.x, v.y}, reinterpret_cast<v2f64 *>(dst)); else *dst = v;
         if (R.Cox2) { const cplx u = conj_scaled(R.oscale, v); __builtin_nontemporal_store((v2f64){u.x, u.y}, reinterpret_cast<v2f64 *>(dst + (R.Cox2 - R.Cox))); }
@@ -279,7 +302,9 @@ int choose_tile(int M, int Nn, int K, int batch, const GemmRows *rows, bool *lat
     if (g_gemm_tile >= 0) { vsel = g_gemm_tile & 15; *latency_mode = false; }
     // the fused update + sweep launch exists for two tiles: 64 x 32 (large matrices) and the 32 x 32 latency tile (under-filled launches)
     if (rows && rows->la) vsel = *latency_mode ? 6 : 3;
-    if (rows && rows->tm64 && M <= 64) { vsel = Nn <= 32 ? 3 : 0; *latency_mode = false; }
+    // (one row tile per matrix, so that C may overwrite B; fronts of at most 16 rows -- the small separator fronts of the one-product back substitution -- take
+    // the 16 x 64 tile: the 64-row tile cost those levels 0.15 ms each at factor time for a product of a few MFLOP)
+    if (rows && rows->tm64 && M <= 64) { vsel = M <= 16 ? 7 : (Nn <= 32 ? 3 : 0); *latency_mode = false; }
     return vsel;
 }
 
@@ -349,13 +374,6 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
             ZG_LAUNCH(k_leaf_bwd_idle, dim3(Nn / 64, 1, nb), M, Nn, K, alpha, Ab, lda, sa, beta, R);
         }
         ExtArm arm(op, ext, 8.0 * M * (double)Nn * K * nb, gemm_operand_bytes(M, Nn, K, beta, rows) * nb, M, Nn, K, nb, idxmode ? idxmode : (rows && rows->la ? 5 : 0));
-        // one-product back substitution of the small separator fronts: every load in flight at once (k_rowtab_small)
-        if (idxmode == 1 && M <= 16 && K <= 80 && nb >= 256 && Nn % 64 == 0 && rows->tabB && rows->tabCo && !rows->tabCi && !rows->act && !rows->act_ro && rows->Bx2 &&
-            beta.x == 0.0 && beta.y == 0.0 && g_gemm_tile < 0 && R.zr1 == 0 && R.zc1 == 0 && R.sk1 == 0 && helm_tuning_now().nd_leaf_idle != 0) {
-            if (K <= 56) ZG_LAUNCH(k_rowtab_small<14>, dim3(Nn / 64, 1, nb), M, Nn, K, alpha, Ab, lda, sa, R);
-            else ZG_LAUNCH(k_rowtab_small<20>, dim3(Nn / 64, 1, nb), M, Nn, K, alpha, Ab, lda, sa, R);
-            continue;
-        }
 #define ZG_ARGS st, idxmode, nb, M, Nn, K, alpha, Ab, lda, sa, Bb, ldb, sb, beta, Cb, ldc, sc, R
 #define ZG_MFMA(WM_, WN_, MT_, NT_, KS_) launch_mfma<WM_, WN_, MT_, NT_, KS_>(ZG_ARGS)
         if (rows && rows->la) {           // update + pivot sweep of the next block in one launch
@@ -401,6 +419,41 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
         op->ev_used += 2;
     }
     return 0;
+}
+
+// Back substitution of a group of small separator fronts in one launch (k_sep_bwd_small); false: not a case for it, the caller issues the two products.
+// rows: tabB / offB = the ring rows, tabCo / offCo = the separator rows (Cix: where y_S is read, Cox: where x_S goes, Cox2: its transformed copy).
+bool gemm_sep_bwd_small(helm_op *op, int smax, int mmax, int nrhs, const cplx *Finv, const cplx *F12, int lda, long long sa, int batch, const GemmRows &rows) {
+    if (!op || smax > 16 || mmax > 96 || batch < 256 || batch > 65535 || nrhs % 64 != 0 || !rows.tabB || !rows.tabCo || !rows.Cix || !rows.Cox || g_gemm_tile >= 0 ||
+        helm_tuning_now().nd_leaf_idle == 0) return false;
+    hipStream_t st = op->stream;
+    const bool ext = op->profiling && helm_tuning_now().prof_ext != 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (!ext && op->profiling) {
+        if (op->ev_used + 2 > op->ev_pool.size() && op->ev_pool.size() < 16384) (void)helm_events_grow(op, 64);
+        if (op->ev_used + 2 <= op->ev_pool.size()) { e0 = op->ev_pool[op->ev_used]; e1 = op->ev_pool[op->ev_used + 1]; }
+    }
+    if (e0) hipEventRecord(e0, st);
+    GemmRows R = rows;
+    R.z0 = 0; R.xcd_map = helm_tuning_now().nd_xcd_map; R.ntc = 1;
+    const double flops = 8.0 * smax * (double)nrhs * (mmax + smax) * batch;
+    const double obytes = (gemm_operand_bytes(smax, nrhs, mmax, cmake(1.0, 0.0), &rows) + 16.0 * smax * smax) * batch;
+    {
+        ExtArm arm(op, ext, flops, obytes, smax, nrhs, mmax + smax, batch, 1);
+        const dim3 grid(nrhs / 64, 1, batch);
+        if (mmax <= 48) ZG_LAUNCH(k_sep_bwd_small<12>, grid, smax, nrhs, mmax, Finv, F12, lda, sa, R);
+        else if (mmax <= 64) ZG_LAUNCH(k_sep_bwd_small<16>, grid, smax, nrhs, mmax, Finv, F12, lda, sa, R);
+        else ZG_LAUNCH(k_sep_bwd_small<24>, grid, smax, nrhs, mmax, Finv, F12, lda, sa, R);
+    }
+    if (e0) {
+        hipEventRecord(e1, st);
+        op->ev_pending_gemm.push_back(std::make_pair((int)op->ev_used, flops));
+        op->ev_pending_gemm_n.push_back(1);
+        op->ev_pending_gemm_bytes.push_back(obytes);
+        op->ev_pending_gemm_sol.push_back(gemm_sol_ms(flops, obytes));
+        op->ev_used += 2;
+    }
+    return true;
 }
 
 // dense helpers for other translation units (3-D multigrid: coarsest-level inverse and its application)

@@ -215,6 +215,7 @@ struct GroupTrace {
 int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, long long sa, const cplx *B, int ldb, long long sb,
          cplx beta, cplx *C, int ldc, long long sc, int batch, const GemmRows *rows = nullptr);
 extern int g_gemm_tile;         // >= 0: forces the tile configuration (helm_debug_zgemm_bench)
+bool gemm_sep_bwd_small(helm_op *op, int smax, int mmax, int nrhs, const cplx *Finv, const cplx *F12, int lda, long long sa, int batch, const GemmRows &rows);
 // ---- nd_gj.hip ----
 // in-place inverse of `batch` n x n blocks (row-major, leading dimension ld, batch stride `stride`); W: workspace with batch stride ws, at least n*n elements per matrix
 void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cplx *W, long long ws, int align = 1, int base = 0);

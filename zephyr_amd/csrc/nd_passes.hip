@@ -278,16 +278,14 @@ void backward_group_batched(helm_op *op, NdFactor *f, size_t gk, const SolveCtx 
     cplx *XS = c.arenaV + xs_off * nrhs;
     if (c.use_idx && g.mmax > 0 && g.mmax <= GB_KIDX) {
         // lower tree levels (almost all rows): every Xt row addressed through the row table -- no gather / store pass
-        if (gform && (c.Qt != c.Xt || !g.leaf) && nmax <= GB_KIDX) {
+        if (gform && c.Qt != c.Xt && nmax <= GB_KIDX) {
             // leaves: x_S = [F11^-1 | G] [y_S; x_B] in ONE product -- y_S rows from the right-hand sides, x_B rows from Xt; the result goes
             // straight to the Xt rows (no intermediate: 2 x 3.2 GB less per pass at 1024^2 x 256)
             GemmRows R; R.tabB = c.tab + g.roff; R.offB = 0; R.tabCo = c.tab + g.roff; R.offCo = 0; R.tab_stride = nmax;
-            // (small separator fronts, r5: y_S sits in the Xt rows that receive x_S -- one 16-row tile per front and column block, all rows read before any is stored)
-            R.Bx = c.Xt; R.Bx2 = g.leaf ? c.Qt : c.Xt; R.k2 = g.smax; R.Cox = c.Xt; R.ldx = nrhs;
+            R.Bx = c.Xt; R.Bx2 = c.Qt; R.k2 = g.smax; R.Cox = c.Xt; R.ldx = nrhs;
             // direct output: nothing on the GPU reads a leaf cell's x again but the residual check -- the rows go to the caller's array as u = conj(oscale x);
             // separator rows stay in Xt for the levels below and go to the caller's array beside it
-            if (c.Uout && g.leaf) { R.Cox = c.Uout; R.cj_out = 1; R.oscale = c.oscale; }
-            else if (c.Uout) { R.Cox2 = c.Uout; R.oscale = c.oscale; }
+            if (c.Uout) { R.Cox = c.Uout; R.cj_out = 1; R.oscale = c.oscale; }
             R.act_ro = g.leaf ? c.act : nullptr; R.nct = c.nct; R.first = g.first;
             gemm(op, g.smax, nrhs, nmax, one, Finv, nmax, s1, nullptr, 0, 0, zero, nullptr, 0, 0, g.cnt, &R);
             return;
@@ -299,6 +297,13 @@ void backward_group_batched(helm_op *op, NdFactor *f, size_t gk, const SolveCtx 
             R2.Bx = c.Xt; R2.Cox = c.Xt; R2.ldx = nrhs;
             gemm(op, g.smax, nrhs, g.mmax, one, F12, nmax, s1, nullptr, 0, 0, one, V, nrhs, (long long)g.smax * nrhs, g.cnt, &R2);
             return;
+        }
+        // small separator fronts (r5): both products in one launch, y_S -> x_S in place in Xt (k_sep_bwd_small)
+        if (!g.leaf && P.dof == 1 && g.smax <= 16) {
+            GemmRows R; R.tabB = c.tab + g.roff; R.offB = g.smax; R.tabCo = c.tab + g.roff; R.offCo = 0; R.tab_stride = nmax;
+            R.Bx = c.Xt; R.Cix = c.Xt; R.Cox = c.Xt; R.ldx = nrhs;
+            if (c.Uout) { R.Cox2 = c.Uout; R.oscale = c.oscale; }
+            if (gemm_sep_bwd_small(op, g.smax, g.mmax, nrhs, Finv, F12, nmax, s1, g.cnt, R)) return;
         }
         // T = y_S - F12 x_B and x_S = F11^-1 T
         GemmRows R1; R1.tabB = c.tab + g.roff; R1.offB = g.smax; R1.tabCi = c.tab + g.roff; R1.offCi = 0; R1.tab_stride = nmax;
