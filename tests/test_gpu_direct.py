@@ -629,8 +629,8 @@ def test_sparse_right_hand_sides_skip_nothing_that_matters(helm_lib, monkeypatch
 
 def test_short_product_kernels_and_listed_levels_change_no_bit(helm_lib, monkeypatch):
     """Round 5 (helm_tuning.nd_leaf_idle).  On sparse right-hand sides three things leave the tile kernel's slab pipeline: the leaf back substitution of
-    the (leaf, 64-column block) pairs without a right-hand side (k_leaf_bwd_idle), the one-product back substitution of the separator fronts of 8 and 16
-    unknowns (k_sep_bwd_small), and the decision which pairs of a separator level have work (k_fwd_flags + a product dealt from the list).  Same k groups,
+    the (leaf, 64-column block) pairs without a right-hand side (k_leaf_bwd_idle), the back substitution of the separator fronts of 8 and 16
+    unknowns in one launch (k_sep_bwd_small), and the decision which pairs of a separator level have work (k_fwd_flags + a product dealt from the list).  Same k groups,
     same order of the matrix instructions per accumulator: on a 256^2 grid (49-unknown leaves, levels of >= 256 fronts) with 128 right-hand sides -- point
     sources, an empty block of 64 columns' worth of zeros in the second half, a dense column -- the wavefields are bit for bit those of the library with the
     switch off, and those of the pass that computes every front (arena poisoned with NaNs)."""
