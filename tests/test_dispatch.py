@@ -257,3 +257,19 @@ def test_an_unstarted_result_superseded_by_a_later_call_refuses_to_start(monkeyp
     out = list(second)
     for a, b in zip(out, serial):
         assert np.array_equal(a, b)
+
+
+def test_a_prepare_step_that_breaks_outside_its_own_guard_does_not_hang_the_pipeline(monkeypatch):
+    """The prepare thread hands every item to the solve thread, whatever happened to it: an exception raised around `_run_prepare` (a broken subclass, an
+    instrumented method -- it did happen with a profiling wrapper) surfaces where the item's result is consumed instead of leaving the solve thread waiting
+    on an empty queue."""
+    from zephyr_amd import dispatch
+
+    def broken(item):
+        raise RuntimeError('prepare wrapper broke')
+    monkeypatch.setattr(dispatch.DevicePipeline, '_run_prepare', staticmethod(broken))
+    items = [dispatch.WorkItem((lambda prepared: 1), (lambda: None)) for _ in range(3)]
+    out = dispatch.pipelined(items, device=0, lookahead=1)
+    import pytest
+    with pytest.raises(RuntimeError):
+        next(out)

@@ -162,9 +162,12 @@ class DevicePipeline(object):
 
     def _prepare_loop(self, items, ready, gate=None):
         for item in items:
-            if gate is not None:
-                gate.acquire()          # released when the solve of the previous item starts
-            self._run_prepare(item)
+            try:
+                if gate is not None:
+                    gate.acquire()      # released when the solve of the previous item starts
+                self._run_prepare(item)
+            except BaseException as exc:    # (nothing above raises by design; but an item that never reaches the queue would leave the solve thread waiting for ever)
+                item._error = exc
             ready.put(item)             # blocks while `lookahead` prepared items are waiting
 
     def _solve_loop(self, n, ready, gate=None):
