@@ -634,6 +634,8 @@ def main():
     barrier()
     del stamps[:]
     del tl[:]
+    from zephyr_amd import _lib as _zl0
+    _zl0.runtime_stats(reset=True)       # what the timed region makes the HIP runtime create (allocations, events, first launches) is counted from here
     t0 = time.perf_counter()
     results = [None] * len(timed_items)
     if args.streams <= 1:
@@ -669,6 +671,7 @@ def main():
     agg = aggregate(results)
     barrier()
     elapsed = time.perf_counter() - t0
+    rt_timed = _zl0.runtime_stats()
     elapsed_local = elapsed
     item_done_ms = [round(1e3 * (x - t0), 2) for x in stamps]
     first_items = [(a, int(w_), round(1e3 * (t_ - t0), 2)) for a, w_, t_ in sorted(tl, key=lambda m: m[2])][:12]
@@ -827,13 +830,18 @@ def main():
                 'value': wavefields / elapsed_dense, 'ms_per_step': 1e3 * elapsed_dense / nsteps,
                 'what': 'the same K items (events off) with HELM_ND_SPARSE_RHS=0: the forward pass visits every front; `value` lets it skip the fronts '
                         'whose right-hand-side rows (81 nonzeros per Kaiser source at the surface) and whose children are all zero in a block of 64 columns'},
-            'config': {'workload': 'Eurus 2D isotropic %dx%d synthetic-Marmousi (seed 20240512, dx=%g m), 16 freqs 2-9.5 Hz x 256 Kaiser sources; '
+            # the driver's record keeps the first 24 scalar keys of `config` and 120 characters of a string: the flat keys are written at the end of main(),
+            # decisive ones first; prose and lists live in `detail`
+            'config': {'workload': ('Eurus 2D iso %dx%d synth-Marmousi dx=%gm, 16 freqs 2-9.5Hz x 256 src; step=assemble+factor 1 freq+solve %d src, relres<=%g'
+                                    % (n, n, dx, B, args.rtol))[:120]},
+            'detail': {'workload': 'Eurus 2D isotropic %dx%d synthetic-Marmousi (seed 20240512, dx=%g m), 16 freqs 2-9.5 Hz x 256 Kaiser sources; '
                                    'step = create + assemble 1 frequency + solve %d sources to true relres<=%g (method=%s: %s)' % (n, n, dx, B, args.rtol, args.method, how),
                        'buffers': ("node-major: right-hand sides and wavefields in the reference's own (N, nsrc) C-order arrays, resident in HBM" if node else
                                    'rhs-major: one right-hand side / wavefield per row, resident in HBM'),
                        'grid': [n, n], 'sources_per_step': B, 'work_items_in_flight': args.streams, 'freqs_hz_this_run': agg['freqs'], 'sharding': ('strong: the 16 work items of the job (one frequency x 256 sources each) round-robin over ranks; value = 4096 wavefields / slowest rank' if args.scaling == 'strong' else 'work items (freq, source batch) round-robin over ranks'),
                        'solves_or_iterations_per_rhs_mean': float(np.mean(iters)) if iters else None,
                        'solves_or_iterations_per_rhs_max': int(np.max(iters)) if iters else None,
+                       'runtime_objects_created_in_timed_region': rt_timed,
                        'device_ms_per_step': {'solve_call': agg['solve_ms'] / nsteps, 'of_which_factorisation': agg['factor_ms'] / nsteps,
                                               'note': 'pipelined: solve_call covers the triangular solves + residual checks of an item, the factorisation (of_which_factorisation: its span on its own '
                                                       'stream, beside the previous item) is no longer inside it' if args.pipeline else 'serial: the factorisation is inside solve_call'}},
@@ -888,15 +896,15 @@ def main():
         # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command in two separate
         # runs, tools/run_profiles_r3.sh; bench.py cannot run the profiler on itself) -- only when they were collected for this workload
         def pmc(name):
-            for rnd in ('r04', 'r03', 'r02'):
-                path = os.path.join(ROOT, 'profiles', '%s_%s.json' % (rnd, name))
-                if os.path.exists(path):
-                    try:
-                        d_ = json.load(open(path))
-                        if d_.get('batch') == B and d_.get('grid') == [n, n]:
-                            return d_, 'profiles/%s_%s.json' % (rnd, name)
-                    except Exception:
-                        pass
+            # the newest round's file first (profiles/rNN_<name>.json)
+            import glob
+            for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_%s.json' % name)), reverse=True):
+                try:
+                    d_ = json.load(open(path))
+                    if d_.get('batch') == B and d_.get('grid') == [n, n]:
+                        return d_, 'profiles/' + os.path.basename(path)
+                except Exception:
+                    pass
             return None, None
         try:
             if direct:
@@ -1014,46 +1022,64 @@ def main():
                     out['cpu_baseline_pool'] = cpu_baseline_pool(cfg, freqs)
                 except Exception as exc:
                     out['cpu_baseline_pool'] = 'failed: %s' % exc
-        # The driver's record keeps the SCALAR entries of `config` (strings, numbers) and only the names of every other key: round 4's nested
-        # `driver_visible` dict, the grid list and the per-step dict were dropped.  So every figure a reader of BENCH_rNN.json / SCALE_rNN.json needs is a
-        # flat scalar key of `config` here; lists and dicts live at the top level of the line.
+        # The driver's record keeps the first 24 SCALAR entries of `config` and 120 characters of a string (round 5's 40-odd keys lost every config-4 / config-5 /
+        # parity / multi-GPU figure): exactly 24 flat keys, decisive ones first; everything else is in `detail`, `config2/4/5`, `roofline`.
         try:
             cfgd = out['config']
-            for k in ('grid', 'freqs_hz_this_run', 'device_ms_per_step'):
-                out['detail_' + k] = cfgd.pop(k, None)
-            dms = out.get('detail_device_ms_per_step') or {}
+            det = out['detail']
+            dms = det.get('device_ms_per_step') or {}
             c2 = out.get('config2') if isinstance(out.get('config2'), dict) else {}
             c4d = c4 if isinstance(c4, dict) else {}
             c5 = out.get('config5') if isinstance(out.get('config5'), dict) else {}
             rl = out['roofline']
-            flat = {
+            gaps = np.diff(np.array([0.0] + item_done_ms)) if item_done_ms else np.zeros(1)
+            unprof = (out.get('unprofiled') or {}).get('value')
+            strong = (out.get('strong_scaling_job') or {}).get('value')
+            flat = [
+                ('unprofiled_wfs', unprof),
+                ('timed_max_item_gap_ms', float(gaps.max())), ('timed_p50_item_ms', float(np.median(gaps))),
+                ('timed_dev_allocs', rt_timed['dev_allocs']), ('timed_dev_alloc_mb', rt_timed['dev_alloc_bytes'] / 1e6),
+                ('timed_pinned_allocs', rt_timed['host_allocs']), ('timed_first_launches', rt_timed['first_launches']),
+                ('roofline_frac_serial', rl.get('frac')), ('two_roofs_frac', (rl.get('two_roofs') or {}).get('frac')),
+                ('stencil_frac', (out.get('stencil_roofline') or rl).get('frac')),
+                ('c4_dpred_s', c4d.get('dpred_seconds')), ('c4_jtvec_s', c4d.get('jtvec_seconds')), ('c4_gpu_ms', c4d.get('gpu_ms')),
+                ('c5_job_s', c5.get('job_seconds')),
+                ('c5_apply_frac_B16', next((a_.get('frac_of_peak') for a_ in (c5.get('apply') or []) if a_.get('B') == 16), None)),
+                ('parity_vs_lu_max_rel', out.get('parity_vs_lu_max_rel')),
+                ('cpu_baseline_wfs', out['cpu_baseline'].get('value') if isinstance(out.get('cpu_baseline'), dict) else None),
+                ('rccl_ranks_seen', ranks_seen), ('gradient_allreduce_ms', c4d.get('gradient_allreduce_ms_512')),
+                ('ms_per_step_slowest_rank', max(rank_ms)),
+                ('strong_job_wfs', strong), ('c2_wfs_device', c2.get('device_wfs')),
+                ('dense_rhs_wfs', (out.get('every_front_computed') or {}).get('value')),
+            ]
+            assert len(flat) + len(cfgd) <= 24
+            for k, v in flat:
+                cfgd[k] = float('%.6g' % v) if isinstance(v, float) else v
+            more = {
                 'grid_n': n, 'freqs_this_run': len(agg['freqs']),
+                'timed_dev_alloc_ms': rt_timed['dev_alloc_ms'], 'timed_first_launch_ms': rt_timed['first_launch_ms'],
+                'timed_events_created': rt_timed['events_created'], 'timed_streams_created': rt_timed['streams_created'],
+                'kernels_registered': rt_timed['kernels_registered'], 'kernels_resolved_by_warm': rt_timed['kernels_resolved'], 'warm_ms': rt_timed['warm_ms'],
                 'device_ms_solve_call': dms.get('solve_call'), 'device_ms_factorisation': dms.get('of_which_factorisation'),
-                'roofline_frac_serial': rl.get('frac'), 'in_pipeline_frac': (rl.get('in_pipeline') or {}).get('frac'),
-                'two_roofs_frac': (rl.get('two_roofs') or {}).get('frac'), 'gemm_avg_launch_us': rl.get('avg_launch_us'),
-                'stencil_frac': (out.get('stencil_roofline') or rl).get('frac'),
-                'unprofiled_wfs': (out.get('unprofiled') or {}).get('value'),
-                'dense_rhs_wfs': (out.get('every_front_computed') or {}).get('value'),
-                'support_declared_wfs': (out.get('support_declared') or {}).get('value'),
-                'strong_job_wfs': (out.get('strong_scaling_job') or {}).get('value'), 'strong_job_s': (out.get('strong_scaling_job') or {}).get('seconds'),
+                'in_pipeline_frac': (rl.get('in_pipeline') or {}).get('frac'), 'gemm_avg_launch_us': rl.get('avg_launch_us'),
+                'support_declared_wfs': (out.get('support_declared') or {}).get('value'), 'strong_job_s': (out.get('strong_scaling_job') or {}).get('seconds'),
                 'host_api_wfs': out['value_host_api'].get('value') if isinstance(out.get('value_host_api'), dict) else None,
-                'c2_wfs_device': c2.get('device_wfs'), 'c2_ms_per_item': c2.get('device_ms_per_item'), 'c2_wfs_host_api': c2.get('host_api_wfs'),
+                'c2_ms_per_item': c2.get('device_ms_per_item'), 'c2_wfs_host_api': c2.get('host_api_wfs'),
                 'c2_gemm_frac': c2.get('gemm_frac_serial'), 'c2_worst_relres': c2.get('worst_relres'),
-                'c4_dpred_s': c4d.get('dpred_seconds'), 'c4_jtvec_s': c4d.get('jtvec_seconds'),
                 'c4_allreduce_ms_512': c4d.get('gradient_allreduce_ms_512'), 'c4_allreduce_ms_1024': c4d.get('gradient_allreduce_ms_1024'),
-                'gradient_allreduce_ms': c4d.get('gradient_allreduce_ms_512'),
-                'c5_job_s': c5.get('job_seconds'), 'c5_rtol': c5.get('rtol'), 'c5_job_s_rtol1e10': c5.get('job_seconds_rtol1e10'),
-                'c5_apply_frac_B16': next((a_.get('frac_of_peak') for a_ in (c5.get('apply') or []) if a_.get('B') == 16), None),
+                'c5_rtol': c5.get('rtol'), 'c5_job_s_rtol1e10': c5.get('job_seconds_rtol1e10'),
                 'c5_apply_us_B16': next((a_.get('us') for a_ in (c5.get('apply') or []) if a_.get('B') == 16), None),
-                'parity_vs_lu_max_rel': out.get('parity_vs_lu_max_rel'),
-                'cpu_baseline_wfs': out['cpu_baseline'].get('value') if isinstance(out.get('cpu_baseline'), dict) else None,
-                'rccl_ranks_seen': ranks_seen, 'collective_backend': backend if world > 1 else 'none',
-                'ms_per_step_slowest_rank': max(rank_ms), 'ms_per_step_fastest_rank': min(rank_ms),
+                'collective_backend': backend if world > 1 else 'none', 'ms_per_step_fastest_rank': min(rank_ms),
+                # (N = 1) the weak-scaling headline and the whole 16-frequency job are the same pipeline over 20 and 16 items: they must agree
+                'weak_over_strong': (value / strong) if strong else None,
+                'weak_equals_strong_within_5pct': (abs(value / strong - 1.0) <= 0.05) if (strong and world == 1) else None,
+                'headline_over_unprofiled': (value / unprof) if unprof else None,
             }
             for r_, ms_ in enumerate(rank_ms):
-                flat['ms_per_step_rank%d' % r_] = ms_
-            for k, v in flat.items():
-                cfgd[k] = float('%.6g' % v) if isinstance(v, float) else v
+                more['ms_per_step_rank%d' % r_] = ms_
+            det['flat'] = {k: (float('%.6g' % v) if isinstance(v, float) else v) for k, v in more.items()}
+            if more['weak_equals_strong_within_5pct'] is False:
+                sys.stderr.write('bench.py: WARNING weak-scaling value %.0f and strong_job_wfs %.0f differ by more than 5 %%\n' % (value, strong))
         except Exception as exc:
             out['config']['flat_keys_error'] = str(exc)
         print(json.dumps(out), flush=True)

@@ -264,6 +264,24 @@ int helm_debug_ws_selftest(int ndev, int concurrent, long long bytes);
  * HELM_ALLOC_TRACE=1 prints): a job that booked its memory with helm_reserve must issue none. */
 int helm_debug_alloc_stats(int reset, long long *slow_calls, double *worst_ms);
 
+/* Resolve every kernel of the library on `device` now: the HIP runtime looks a kernel up in its code object and builds its dispatch record the first
+ * time it is launched on a device (1.8 ms of host time for the nine kernels of one tree level in a cold process), and a job meets some kernels only at
+ * some frequencies -- pivoted leaves, the pivoted-LU treatment of ill-conditioned fronts, refinement widths.  Nothing is launched.  Called by the
+ * library itself when the first operator of a device is created (HELM_WARM=0: not); returns the number of kernels the library holds (> 0) or
+ * HELM_ERR_DEVICE.  Counterpart of starting the reference's worker pool before the first product (distributors.py:80-96). */
+int helm_warm(int device);
+/* (diagnostic) what the library made the HIP runtime create since the last reset: device / pinned allocations that reached the driver (count, bytes,
+ * host milliseconds), events, streams, kernels launched for the first time in the process (count, host milliseconds of those launch calls); and, not
+ * reset, the kernels registered / resolved by helm_warm and its milliseconds.  A job whose memory was booked shows zeros across its timed region. */
+typedef struct helm_runtime_stats {
+    long long dev_allocs;  double dev_alloc_bytes;  double dev_alloc_ms;
+    long long host_allocs; double host_alloc_bytes; double host_alloc_ms;
+    long long events_created, streams_created;
+    long long first_launches; double first_launch_ms;
+    long long kernels_registered, kernels_resolved; double warm_ms;
+} helm_runtime_stats;
+int helm_debug_runtime_stats(int reset, helm_runtime_stats *out);
+
 /* --- tuning ------------------------------------------------------------------------------
  * The options of the library that are real options (round 5: the seventy-odd HELM_* environment switches of rounds 1-4 were the tuning
  * interface; the measured-and-rejected ones are gone, HISTORY.md has what they measured).  Every field can still be given through the

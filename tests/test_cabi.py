@@ -30,6 +30,25 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.SolveOpts) == 32
     assert ctypes.sizeof(_lib.SolveInfo) == 24
     assert ctypes.sizeof(_lib.Timing) == 104      # 11 + 2 (gemm_bytes, gemm_sol_ms) eight-byte fields
+    text = open(os.path.join(ROOT, 'include', 'helm.h')).read()
+    body = re.sub(r'/\*.*?\*/', '', text[text.index('typedef struct helm_runtime_stats {'):text.index('} helm_runtime_stats;')], flags=re.S)
+    names = [n.strip() for decl in re.findall(r'(?:long long|double)\s+([^;]+);', body) for n in decl.split(',')]
+    assert names == [n for n, _ in _lib.RuntimeStats._fields_] and ctypes.sizeof(_lib.RuntimeStats) == 8 * len(names)
+
+
+def test_every_kernel_registers_at_load(helm_lib):
+    """Every kernel instantiation with a launch site registers its host handle while the library is loaded (no GPU needed): helm_warm() resolves
+    that list on a device, so no kernel meets the runtime's lazy symbol lookup inside a solve."""
+    from zephyr_amd import _lib
+    st = _lib.runtime_stats()
+    assert st['kernels_registered'] >= 200
+    assert st['first_launches'] == 0 and st['dev_allocs'] == 0
+    src = os.path.join(ROOT, 'zephyr_amd', 'csrc')
+    for f in os.listdir(src):                       # no launch site bypasses the registry
+        if f.endswith(('.hip', '.hpp')):
+            text = open(os.path.join(src, f)).read()
+            stray = [l for l in text.splitlines() if re.search(r'\bhipLaunchKernelGGL\(|<<<', l) and 'define' not in l and not l.lstrip().startswith(('//', 'else hipLaunchKernelGGL', 'if (tl_ev0)'))]
+            assert not stray, (f, stray[:2])
 
 
 def test_tuning_struct_round_trip(helm_lib, monkeypatch):

@@ -158,3 +158,24 @@ def test_eight_logical_devices_book_their_memory_before_the_workers_start(helm_l
             assert worst.value < 20.0 and slow.value <= 8, 'job %d: %d allocator call(s) of more than 1 ms after the bookings (worst %.1f ms)' % (job, slow.value, worst.value)
         del mf.factors
     assert helm_lib.helm_debug_ws_slots(0, 1) >= 1          # device 0's own table holds the booked scratch
+
+
+def test_warm_resolves_every_kernel_and_a_second_job_creates_nothing(helm_lib):
+    """helm_warm (run by the library when the first operator of a device is created) resolves every registered kernel without launching one; after one
+    pass over a job, a second pass over OTHER frequencies of the same shape makes the HIP runtime create nothing -- no device or pinned allocation, no
+    stream -- and launches no kernel for the first time.  (The reference starts its worker pool before the first product: distributors.py:80-96.)"""
+    import zephyr_amd as za
+    from zephyr_amd import _lib
+    n = helm_lib.helm_warm(0)
+    st = _lib.runtime_stats()
+    assert n == st['kernels_registered'] >= 200 and st['kernels_resolved'] == st['kernels_registered']
+    sc, q = config(freqs=[3., 4.5, 6., 7.5])
+    for u in za.MultiFreq(dict(sc)) * q:
+        del u
+    _lib.runtime_stats(reset=True)
+    sc2 = dict(sc, freqs=[3.5, 5., 6.5, 8.])
+    for u in za.MultiFreq(sc2) * q:
+        del u
+    st = _lib.runtime_stats()
+    assert st['dev_allocs'] == 0 and st['host_allocs'] == 0 and st['streams_created'] == 0, st
+    assert st['first_launches'] == 0, st

@@ -55,6 +55,15 @@ class Tuning(ctypes.Structure):
                 ('mg3_bt_f32', ctypes.c_int), ('mg3_otf', ctypes.c_int), ('mg3_omega', ctypes.c_double)]
 
 
+class RuntimeStats(ctypes.Structure):
+    """helm_runtime_stats of include/helm.h: what the library made the HIP runtime create since the last reset."""
+    _fields_ = [('dev_allocs', ctypes.c_longlong), ('dev_alloc_bytes', ctypes.c_double), ('dev_alloc_ms', ctypes.c_double),
+                ('host_allocs', ctypes.c_longlong), ('host_alloc_bytes', ctypes.c_double), ('host_alloc_ms', ctypes.c_double),
+                ('events_created', ctypes.c_longlong), ('streams_created', ctypes.c_longlong),
+                ('first_launches', ctypes.c_longlong), ('first_launch_ms', ctypes.c_double),
+                ('kernels_registered', ctypes.c_longlong), ('kernels_resolved', ctypes.c_longlong), ('warm_ms', ctypes.c_double)]
+
+
 # every symbol include/helm.h declares, with its ctypes signature
 _c_dp = ctypes.POINTER(ctypes.c_double)
 _SIGNATURES = {
@@ -102,6 +111,8 @@ _SIGNATURES = {
     'helm_debug_plan_cache': (ctypes.c_int, [ctypes.c_int]),
     'helm_debug_ws_selftest': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_longlong]),
     'helm_debug_alloc_stats': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_double)]),
+    'helm_warm': (ctypes.c_int, [ctypes.c_int]),
+    'helm_debug_runtime_stats': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(RuntimeStats)]),
     'helm_rhs_from_coo_device': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong,
                                                 ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong]),
     'helm_sample_device': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p,
@@ -162,6 +173,13 @@ def tuning():
 def set_tuning(t=None):
     'replace the options for the process (None: defaults + environment again)'
     check(load().helm_set_tuning(ctypes.byref(t) if t is not None else None))
+
+
+def runtime_stats(reset=False):
+    'helm_debug_runtime_stats as a dict (device / pinned allocations, events, streams, first launches since the last reset)'
+    st = RuntimeStats()
+    check(load().helm_debug_runtime_stats(1 if reset else 0, ctypes.byref(st)))
+    return {k: getattr(st, k) for k, _ in RuntimeStats._fields_}
 
 
 def last_error(handle=None):

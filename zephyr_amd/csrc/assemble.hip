@@ -319,7 +319,7 @@ int helm_launch_assemble(helm_op *op, double freq_re, double freq_im, double tau
         P.fx = op->pml_scale * 3.0 * log(1.0 / 1e-3) / (2.0 * lx * lx * lx);
         P.fz = op->pml_scale * 3.0 * log(1.0 / 1e-3) / (2.0 * lz * lz * lz);
         P.fs0 = op->fs[0]; P.fs1 = op->fs[1]; P.fs2 = op->fs[2]; P.fs3 = op->fs[3];
-        hipLaunchKernelGGL(k_assemble_mz, dim3(blocks), dim3(threads), 0, op->stream, P, op->d_c, op->d_rho,
+        HELM_LAUNCH(k_assemble_mz, dim3(blocks), dim3(threads), 0, op->stream, P, op->d_c, op->d_rho,
                            d_prof, d_prof + nx, d_prof + 2 * nx, d_prof + 2 * nx + nz, op->d_C);
         HIP_TRY(op, hipGetLastError());
         HIP_TRY(op, hipStreamSynchronize(op->stream));
@@ -359,7 +359,7 @@ int helm_launch_assemble(helm_op *op, double freq_re, double freq_im, double tau
         EuParams P;
         P.nz = nz; P.nx = nx; P.dx = op->dx; P.dz = op->dz; P.om = om; P.aniso = op->aniso ? 1 : 0;
         P.nblk_out = op->block0_only ? 1 : (op->asm_nblk == 1 ? 1 : 4);
-        hipLaunchKernelGGL(k_assemble_eurus, dim3(blocks), dim3(threads), 0, op->stream, P, op->d_c, op->d_rho,
+        HELM_LAUNCH(k_assemble_eurus, dim3(blocks), dim3(threads), 0, op->stream, P, op->d_c, op->d_rho,
                            op->d_theta, op->d_eps, op->d_delta, d_xi, d_xi + nx + 2, op->d_C);
         HIP_TRY(op, hipGetLastError());
         HIP_TRY(op, hipStreamSynchronize(op->stream));

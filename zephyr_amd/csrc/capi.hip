@@ -31,6 +31,96 @@ void helm_set_error(helm_op *op, const char *msg) {
 extern "C" const char *helm_last_error(const helm_op *op) { return op ? op->err.c_str() : g_last_error.c_str(); }
 extern "C" const char *helm_version(void) { return "libhelm 0.1 (gfx950)"; }
 
+// ---- kernel registry and runtime-object bookkeeping (helm_internal.hpp) ---------------------------------------------------------------------
+// (function-local statics: kernels register during the static initialisation of whichever translation unit comes first)
+namespace {
+struct KernelRec { const void *fn; const char *pretty; std::atomic<bool> launched{false}; };
+struct KernelRegistry {
+    std::mutex mu;
+    std::vector<KernelRec *> recs;                 // records are never moved or freed: slots stay valid without the lock
+    std::atomic<KernelRec *> fast[2048];
+    std::atomic<int> n{0};
+};
+KernelRegistry &kreg() { static KernelRegistry *r = new KernelRegistry(); return *r; }
+struct RuntimeCounters {
+    std::atomic<long long> dev_allocs{0}, dev_alloc_bytes{0}, dev_alloc_us{0}, host_allocs{0}, host_alloc_bytes{0}, host_alloc_us{0},
+                           events{0}, streams{0}, first_launches{0}, first_launch_us{0}, resolved{0}, warm_us{0};
+};
+RuntimeCounters &rtc() { static RuntimeCounters *c = new RuntimeCounters(); return *c; }
+double wall_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}
+double HelmFirstLaunch::now_ms() { return wall_ms(); }
+int helm_kernel_register(const void *fn, const char *pretty) {
+    KernelRegistry &r = kreg();
+    std::lock_guard<std::mutex> lk(r.mu);
+    KernelRec *k = new KernelRec(); k->fn = fn; k->pretty = pretty;
+    r.recs.push_back(k);
+    const int slot = (int)r.recs.size() - 1;
+    if (slot < 2048) r.fast[slot].store(k);
+    r.n.store(slot + 1);
+    return slot;
+}
+bool helm_kernel_first_launch(int slot) {
+    if (slot < 0 || slot >= 2048) return false;
+    KernelRec *k = kreg().fast[slot].load(std::memory_order_relaxed);
+    if (!k || k->launched.load(std::memory_order_relaxed)) return false;
+    return !k->launched.exchange(true);
+}
+void helm_kernel_first_launch_done(int slot, double host_ms) {
+    (void)slot;
+    rtc().first_launches += 1; rtc().first_launch_us += (long long)(host_ms * 1e3);
+    static const bool tr = getenv("HELM_LAUNCH_TRACE") && atoi(getenv("HELM_LAUNCH_TRACE"));
+    if (tr) { KernelRec *k = kreg().fast[slot].load(); fprintf(stderr, "[helm first launch] %8.3f ms  %s\n", host_ms, k ? k->pretty : "?"); }
+}
+hipError_t helm_counted_malloc(void **p, size_t bytes) {
+    const double t0 = wall_ms();
+    const hipError_t e = (hipMalloc)(p, bytes);
+    rtc().dev_allocs += 1; rtc().dev_alloc_bytes += (long long)bytes; rtc().dev_alloc_us += (long long)((wall_ms() - t0) * 1e3);
+    return e;
+}
+hipError_t helm_counted_host_malloc(void **p, size_t bytes, unsigned flags) {
+    const double t0 = wall_ms();
+    const hipError_t e = (hipHostMalloc)(p, bytes, flags);
+    rtc().host_allocs += 1; rtc().host_alloc_bytes += (long long)bytes; rtc().host_alloc_us += (long long)((wall_ms() - t0) * 1e3);
+    return e;
+}
+hipError_t helm_counted_event_create(hipEvent_t *e, unsigned flags) { rtc().events += 1; return flags ? (hipEventCreateWithFlags)(e, flags) : (hipEventCreate)(e); }
+hipError_t helm_counted_stream_create(hipStream_t *s, unsigned flags, int prio, bool with_prio) {
+    rtc().streams += 1;
+    return with_prio ? (hipStreamCreateWithPriority)(s, flags, prio) : (hipStreamCreateWithFlags)(s, flags);
+}
+extern "C" int helm_debug_runtime_stats(int reset, helm_runtime_stats *out) {
+    RuntimeCounters &c = rtc();
+    if (out) {
+        out->dev_allocs = c.dev_allocs.load(); out->dev_alloc_bytes = (double)c.dev_alloc_bytes.load(); out->dev_alloc_ms = c.dev_alloc_us.load() * 1e-3;
+        out->host_allocs = c.host_allocs.load(); out->host_alloc_bytes = (double)c.host_alloc_bytes.load(); out->host_alloc_ms = c.host_alloc_us.load() * 1e-3;
+        out->events_created = c.events.load(); out->streams_created = c.streams.load();
+        out->first_launches = c.first_launches.load(); out->first_launch_ms = c.first_launch_us.load() * 1e-3;
+        out->kernels_registered = kreg().n.load(); out->kernels_resolved = c.resolved.load(); out->warm_ms = c.warm_us.load() * 1e-3;
+    }
+    if (reset) { c.dev_allocs = 0; c.dev_alloc_bytes = 0; c.dev_alloc_us = 0; c.host_allocs = 0; c.host_alloc_bytes = 0; c.host_alloc_us = 0;
+                 c.events = 0; c.streams = 0; c.first_launches = 0; c.first_launch_us = 0; }
+    return HELM_OK;
+}
+// Resolve every kernel of the library on `device` (code objects loaded, dispatch records built) without launching anything.  Idempotent; runs by itself
+// when the first operator of a device is created (HELM_WARM=0 leaves it to the caller).
+extern "C" int helm_warm(int device) {
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); helm_set_error(nullptr, "helm_warm: hipSetDevice failed"); return HELM_ERR_DEVICE; }
+    static std::mutex mu; static std::map<int, int> done;
+    std::lock_guard<std::mutex> lk(mu);
+    KernelRegistry &r = kreg();
+    const int n = std::min(r.n.load(), 2048);
+    int &upto = done[device];
+    const double t0 = wall_ms();
+    for (int i = upto; i < n; ++i) {
+        hipFuncAttributes at;
+        if (hipFuncGetAttributes(&at, r.fast[i].load()->fn) == hipSuccess) rtc().resolved += 1; else (void)hipGetLastError();
+    }
+    upto = n;
+    rtc().warm_us += (long long)((wall_ms() - t0) * 1e3);
+    return n;
+}
+
 // ---- tuning (include/helm.h: helm_tuning) ------------------------------------------------------------------------------------------------
 namespace {
 std::mutex g_tune_mu;
@@ -325,6 +415,12 @@ static helm_op *create_common(helm_op *op) {
     const int device = op->device;
     { std::lock_guard<std::mutex> lk(g_shared_ws.mu); g_live_handles += 1; }      // helm_destroy takes it back on every exit
     HIP_TRY_NULL(hipSetDevice(device));
+    {   // first operator of this device in the process: resolve the library's kernels now, not one by one inside the first solves of each kind
+        static std::mutex wmu; static std::map<int, bool> warmed;
+        bool need = false;
+        { std::lock_guard<std::mutex> lk(wmu); if (!warmed[device]) { warmed[device] = true; need = true; } }
+        if (need && tune_i("HELM_WARM", 1)) (void)helm_warm(device);
+    }
     op->stream = helm_stream_acquire(device, 0);
     if (!op->stream) { helm_destroy(op); helm_set_error(nullptr, "hipStreamCreate failed"); return nullptr; }
     op->own_stream = true;
@@ -1991,7 +2087,7 @@ extern "C" int helm_rhs_support_from_coo(helm_op *op, const void *d_row, const v
     if (!op || !d_bits || rows < 1 || nrhs < 1 || nrhs > 512 || nnz < 0 || (nnz > 0 && (!d_row || !d_col))) return HELM_ERR_ARG;
     HIP_TRY(op, hipSetDevice(op->device));
     HIP_TRY(op, hipMemsetAsync(d_bits, 0, (size_t)((rows + 3) / 4) * 4, op->stream));
-    if (nnz > 0) hipLaunchKernelGGL(k_support_from_coo, dim3((unsigned)std::min<long long>((nnz + 255) / 256, 4096)), dim3(256), 0, op->stream,
+    if (nnz > 0) HELM_LAUNCH(k_support_from_coo, dim3((unsigned)std::min<long long>((nnz + 255) / 256, 4096)), dim3(256), 0, op->stream,
                                     (const long long *)d_row, (const int *)d_col, nnz, rows, nrhs, (unsigned *)d_bits);
     HIP_TRY(op, hipGetLastError());
     HIP_TRY(op, hipStreamSynchronize(op->stream));

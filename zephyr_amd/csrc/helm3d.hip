@@ -347,14 +347,14 @@ int helm3d_launch_assemble(helm_op *op, double freq_re, double freq_im, double t
     if (over) P.dx = P.dy = P.dz = 1.0;
     P.om = cmake(om.real(), om.imag()); P.blend = 0.5;
     const int blocks = (int)((op->N + 255) / 256);
-    hipLaunchKernelGGL(k_assemble_3d, dim3(blocks), dim3(256), 0, op->stream, P, (const cplx *)op->d_c, (const double *)op->d_rho,
+    HELM_LAUNCH(k_assemble_3d, dim3(blocks), dim3(256), 0, op->stream, P, (const cplx *)op->d_c, (const double *)op->d_rho,
                        (const cplx *)d_L, (const cplx *)(d_L + 3 * (size_t)op->nx), (const cplx *)(d_L + 3 * (size_t)op->nx + 3 * (size_t)op->ny), op->d_C);
     HIP_TRY(op, hipGetLastError());
     // K and b for the on-the-fly apply (24 B per point; a handle that cannot have them simply keeps reading its planes)
     if (!op->d_K3) op->d_K3 = (cplx *)helm_pool_alloc(op->device, (size_t)op->N * sizeof(cplx));
     if (!op->d_b3) op->d_b3 = (double *)helm_pool_alloc(op->device, (size_t)op->N * sizeof(double));
     if (op->d_K3 && op->d_b3) {
-        hipLaunchKernelGGL(k_kb_3d, dim3((unsigned)std::min<long long>(blocks, 65535)), dim3(256), 0, op->stream, P, (const cplx *)op->d_c, (const double *)op->d_rho, op->d_K3, op->d_b3);
+        HELM_LAUNCH(k_kb_3d, dim3((unsigned)std::min<long long>(blocks, 65535)), dim3(256), 0, op->stream, P, (const cplx *)op->d_c, (const double *)op->d_rho, op->d_K3, op->d_b3);
         HIP_TRY(op, hipGetLastError());
         op->otf_idx2 = 1.0 / (P.dx * P.dx); op->otf_idy2 = 1.0 / (P.dy * P.dy); op->otf_idz2 = 1.0 / (P.dz * P.dz); op->otf_blend = P.blend;
         op->otf3 = true;
@@ -369,13 +369,13 @@ int helm3d_apply_num_blocks(const helm_op *op) {
 
 static void launch3_otf(hipStream_t st, dim3 grid, const Stencil3Params &q, int epi) {
     switch (epi) {
-    case EPI_NONE: hipLaunchKernelGGL((k_stencil3<false, EPI_NONE, true>), grid, dim3(256), 0, st, q); break;
-    case EPI_DOT_W: hipLaunchKernelGGL((k_stencil3<false, EPI_DOT_W, true>), grid, dim3(256), 0, st, q); break;
-    case EPI_DOT_XY: hipLaunchKernelGGL((k_stencil3<false, EPI_DOT_XY, true>), grid, dim3(256), 0, st, q); break;
-    case EPI_DOT_YY: hipLaunchKernelGGL((k_stencil3<false, EPI_DOT_YY, true>), grid, dim3(256), 0, st, q); break;
-    case EPI_RESID: hipLaunchKernelGGL((k_stencil3<false, EPI_RESID, true>), grid, dim3(256), 0, st, q); break;
-    case EPI_DOT_WY: hipLaunchKernelGGL((k_stencil3<false, EPI_DOT_WY, true>), grid, dim3(256), 0, st, q); break;
-    case EPI_JACOBI: hipLaunchKernelGGL((k_stencil3<false, EPI_JACOBI, true>), grid, dim3(256), 0, st, q); break;
+    case EPI_NONE: HELM_LAUNCH((k_stencil3<false, EPI_NONE, true>), grid, dim3(256), 0, st, q); break;
+    case EPI_DOT_W: HELM_LAUNCH((k_stencil3<false, EPI_DOT_W, true>), grid, dim3(256), 0, st, q); break;
+    case EPI_DOT_XY: HELM_LAUNCH((k_stencil3<false, EPI_DOT_XY, true>), grid, dim3(256), 0, st, q); break;
+    case EPI_DOT_YY: HELM_LAUNCH((k_stencil3<false, EPI_DOT_YY, true>), grid, dim3(256), 0, st, q); break;
+    case EPI_RESID: HELM_LAUNCH((k_stencil3<false, EPI_RESID, true>), grid, dim3(256), 0, st, q); break;
+    case EPI_DOT_WY: HELM_LAUNCH((k_stencil3<false, EPI_DOT_WY, true>), grid, dim3(256), 0, st, q); break;
+    case EPI_JACOBI: HELM_LAUNCH((k_stencil3<false, EPI_JACOBI, true>), grid, dim3(256), 0, st, q); break;
     default: break;
     }
 }
@@ -383,13 +383,13 @@ static void launch3_otf(hipStream_t st, dim3 grid, const Stencil3Params &q, int 
 template <bool SCALED>
 static void launch3_epi(hipStream_t st, dim3 grid, const Stencil3Params &q, int epi) {
     switch (epi) {
-    case EPI_NONE: hipLaunchKernelGGL((k_stencil3<SCALED, EPI_NONE>), grid, dim3(256), 0, st, q); break;
-    case EPI_DOT_W: hipLaunchKernelGGL((k_stencil3<SCALED, EPI_DOT_W>), grid, dim3(256), 0, st, q); break;
-    case EPI_DOT_XY: hipLaunchKernelGGL((k_stencil3<SCALED, EPI_DOT_XY>), grid, dim3(256), 0, st, q); break;
-    case EPI_DOT_YY: hipLaunchKernelGGL((k_stencil3<SCALED, EPI_DOT_YY>), grid, dim3(256), 0, st, q); break;
-    case EPI_RESID: hipLaunchKernelGGL((k_stencil3<SCALED, EPI_RESID>), grid, dim3(256), 0, st, q); break;
-    case EPI_DOT_WY: hipLaunchKernelGGL((k_stencil3<SCALED, EPI_DOT_WY>), grid, dim3(256), 0, st, q); break;
-    case EPI_JACOBI: hipLaunchKernelGGL((k_stencil3<SCALED, EPI_JACOBI>), grid, dim3(256), 0, st, q); break;
+    case EPI_NONE: HELM_LAUNCH((k_stencil3<SCALED, EPI_NONE>), grid, dim3(256), 0, st, q); break;
+    case EPI_DOT_W: HELM_LAUNCH((k_stencil3<SCALED, EPI_DOT_W>), grid, dim3(256), 0, st, q); break;
+    case EPI_DOT_XY: HELM_LAUNCH((k_stencil3<SCALED, EPI_DOT_XY>), grid, dim3(256), 0, st, q); break;
+    case EPI_DOT_YY: HELM_LAUNCH((k_stencil3<SCALED, EPI_DOT_YY>), grid, dim3(256), 0, st, q); break;
+    case EPI_RESID: HELM_LAUNCH((k_stencil3<SCALED, EPI_RESID>), grid, dim3(256), 0, st, q); break;
+    case EPI_DOT_WY: HELM_LAUNCH((k_stencil3<SCALED, EPI_DOT_WY>), grid, dim3(256), 0, st, q); break;
+    case EPI_JACOBI: HELM_LAUNCH((k_stencil3<SCALED, EPI_JACOBI>), grid, dim3(256), 0, st, q); break;
     default: break;
     }
 }

@@ -183,6 +183,44 @@ struct helm_op {
     HELM_FAIL(op, HELM_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); } } while (0)
 
 void helm_set_error(helm_op *op, const char *msg);
+
+// ---- kernel registry (capi.hip) -------------------------------------------------------------------
+// The HIP runtime resolves a kernel lazily: the first launch of a symbol on a device looks it up in the code object and builds its dispatch
+// record (tens to hundreds of microseconds of host time, 1.8 ms for the nine kernels of a tree level in a cold process).  A job meets some
+// instantiations only at some frequencies (pivoted leaves, the pivoted-LU treatment of ill-conditioned fronts, refinement widths), i.e. possibly
+// for the first time in the middle of a timed region.  Every kernel instantiation that has a launch site therefore registers its host handle when
+// the library is loaded (HelmKernelReg: a static data member per instantiation), helm_warm() resolves all of them on a device without launching
+// anything, and helm_debug_runtime_stats() counts the first launches that still happen (with their host time).
+int helm_kernel_register(const void *fn, const char *pretty);
+bool helm_kernel_first_launch(int slot);                  // true exactly once per slot
+void helm_kernel_first_launch_done(int slot, double host_ms);
+template <auto K> struct HelmKernelReg {
+    static const char *pretty() { return __PRETTY_FUNCTION__; }
+    static inline const int slot = helm_kernel_register((const void *)K, pretty());
+};
+struct HelmFirstLaunch {
+    int slot; bool first; double t0;
+    static double now_ms();
+    explicit HelmFirstLaunch(int s) : slot(s), first(helm_kernel_first_launch(s)), t0(first ? now_ms() : 0.0) {}
+    ~HelmFirstLaunch() { if (first) helm_kernel_first_launch_done(slot, now_ms() - t0); }
+};
+#define HELM_LAUNCH(KERNEL, ...) do { HelmFirstLaunch fl_(HelmKernelReg<(KERNEL)>::slot); hipLaunchKernelGGL(KERNEL, __VA_ARGS__); } while (0)
+
+// ---- runtime-object bookkeeping (capi.hip) ----------------------------------------------------------
+// Every call of the library that makes the HIP runtime create something -- device memory, pinned memory, an event, a stream -- goes through a
+// counting wrapper (the function-like macros below catch the calls of every translation unit; `(hipMalloc)(...)` is how the wrappers reach the
+// real entry points).  helm_debug_runtime_stats() reports the counts: a job whose pools were booked (helm_reserve, warm-up items) must show
+// zeros across its timed region.
+hipError_t helm_counted_malloc(void **p, size_t bytes);
+hipError_t helm_counted_host_malloc(void **p, size_t bytes, unsigned flags);
+hipError_t helm_counted_event_create(hipEvent_t *e, unsigned flags);
+hipError_t helm_counted_stream_create(hipStream_t *s, unsigned flags, int prio, bool with_prio);
+#define hipMalloc(P, B) helm_counted_malloc((void **)(P), (B))
+#define hipHostMalloc(P, B, F) helm_counted_host_malloc((void **)(P), (B), (F))
+#define hipEventCreate(E) helm_counted_event_create((E), 0u)
+#define hipEventCreateWithFlags(E, F) helm_counted_event_create((E), (F))
+#define hipStreamCreateWithFlags(S, F) helm_counted_stream_create((S), (F), 0, false)
+#define hipStreamCreateWithPriority(S, F, PR) helm_counted_stream_create((S), (F), (PR), true)
 helm_tuning helm_tuning_now();                            // the options in force (helm_set_tuning, else defaults + environment; include/helm.h)
 
 // Size-keyed cache of large device buffers (coefficient planes, factors, per-call temporaries): a job walks through many

@@ -696,13 +696,13 @@ int helm_vec_num_blocks(const helm_op *op) { return vec_blocks(op->Nv > 0 ? op->
 template <int P, bool SCALED, bool ADJ>
 static void launch_stencil_epi(hipStream_t st, dim3 grid, const StencilParams &q, int epi) {
     switch (epi) {
-    case EPI_NONE: hipLaunchKernelGGL((k_stencil_t<cplx, P, SCALED, ADJ, EPI_NONE>), grid, dim3(256), 0, st, q); break;
-    case EPI_DOT_W: hipLaunchKernelGGL((k_stencil_t<cplx, P, SCALED, ADJ, EPI_DOT_W>), grid, dim3(256), 0, st, q); break;
-    case EPI_DOT_XY: hipLaunchKernelGGL((k_stencil_t<cplx, P, SCALED, ADJ, EPI_DOT_XY>), grid, dim3(256), 0, st, q); break;
-    case EPI_DOT_YY: hipLaunchKernelGGL((k_stencil_t<cplx, P, SCALED, ADJ, EPI_DOT_YY>), grid, dim3(256), 0, st, q); break;
-    case EPI_RESID: hipLaunchKernelGGL((k_stencil_t<cplx, P, SCALED, ADJ, EPI_RESID>), grid, dim3(256), 0, st, q); break;
-    case EPI_JACOBI: hipLaunchKernelGGL((k_stencil_t<cplx, P, SCALED, ADJ, EPI_JACOBI>), grid, dim3(256), 0, st, q); break;
-    case EPI_DOT_WY: hipLaunchKernelGGL((k_stencil_t<cplx, P, SCALED, ADJ, EPI_DOT_WY>), grid, dim3(256), 0, st, q); break;
+    case EPI_NONE: HELM_LAUNCH((k_stencil_t<cplx, P, SCALED, ADJ, EPI_NONE>), grid, dim3(256), 0, st, q); break;
+    case EPI_DOT_W: HELM_LAUNCH((k_stencil_t<cplx, P, SCALED, ADJ, EPI_DOT_W>), grid, dim3(256), 0, st, q); break;
+    case EPI_DOT_XY: HELM_LAUNCH((k_stencil_t<cplx, P, SCALED, ADJ, EPI_DOT_XY>), grid, dim3(256), 0, st, q); break;
+    case EPI_DOT_YY: HELM_LAUNCH((k_stencil_t<cplx, P, SCALED, ADJ, EPI_DOT_YY>), grid, dim3(256), 0, st, q); break;
+    case EPI_RESID: HELM_LAUNCH((k_stencil_t<cplx, P, SCALED, ADJ, EPI_RESID>), grid, dim3(256), 0, st, q); break;
+    case EPI_JACOBI: HELM_LAUNCH((k_stencil_t<cplx, P, SCALED, ADJ, EPI_JACOBI>), grid, dim3(256), 0, st, q); break;
+    case EPI_DOT_WY: HELM_LAUNCH((k_stencil_t<cplx, P, SCALED, ADJ, EPI_DOT_WY>), grid, dim3(256), 0, st, q); break;
     }
 }
 
@@ -719,13 +719,13 @@ static int launch_apply_f32(helm_op *op, const ApplyArgs &a) {
     int split = 1;
     if (q.nblk < 1024) { split = (1024 + q.nblk - 1) / q.nblk; if (split > a.nrhs) split = a.nrhs; if (split < 1) split = 1; }
     dim3 grid(q.nblk, split);
-    if (a.xmode == 1 && a.epi == EPI_RESID) hipLaunchKernelGGL((k_stencil_t<cplxf, STENCIL_P, false, false, EPI_RESID, 1>), grid, dim3(256), 0, op->stream, q);
-    else if (a.xmode == 2 && a.epi == EPI_JACOBI) hipLaunchKernelGGL((k_stencil_t<cplxf, STENCIL_P, false, false, EPI_JACOBI, 2>), grid, dim3(256), 0, op->stream, q);
+    if (a.xmode == 1 && a.epi == EPI_RESID) HELM_LAUNCH((k_stencil_t<cplxf, STENCIL_P, false, false, EPI_RESID, 1>), grid, dim3(256), 0, op->stream, q);
+    else if (a.xmode == 2 && a.epi == EPI_JACOBI) HELM_LAUNCH((k_stencil_t<cplxf, STENCIL_P, false, false, EPI_JACOBI, 2>), grid, dim3(256), 0, op->stream, q);
     else if (a.xmode != 0) HELM_FAIL(op, HELM_ERR_ARG, "unsupported fused stencil mode");
     else switch (a.epi) {
-    case EPI_NONE: hipLaunchKernelGGL((k_stencil_t<cplxf, STENCIL_P, false, false, EPI_NONE>), grid, dim3(256), 0, op->stream, q); break;
-    case EPI_RESID: hipLaunchKernelGGL((k_stencil_t<cplxf, STENCIL_P, false, false, EPI_RESID>), grid, dim3(256), 0, op->stream, q); break;
-    case EPI_JACOBI: hipLaunchKernelGGL((k_stencil_t<cplxf, STENCIL_P, false, false, EPI_JACOBI>), grid, dim3(256), 0, op->stream, q); break;
+    case EPI_NONE: HELM_LAUNCH((k_stencil_t<cplxf, STENCIL_P, false, false, EPI_NONE>), grid, dim3(256), 0, op->stream, q); break;
+    case EPI_RESID: HELM_LAUNCH((k_stencil_t<cplxf, STENCIL_P, false, false, EPI_RESID>), grid, dim3(256), 0, op->stream, q); break;
+    case EPI_JACOBI: HELM_LAUNCH((k_stencil_t<cplxf, STENCIL_P, false, false, EPI_JACOBI>), grid, dim3(256), 0, op->stream, q); break;
     default: HELM_FAIL(op, HELM_ERR_ARG, "unsupported single-precision stencil epilogue");
     }
     HIP_TRY(op, hipGetLastError());
@@ -777,11 +777,11 @@ int helm_launch_apply(helm_op *op, const ApplyArgs &a) {
         } else e0 = nullptr;
     }
     if (a.xmode == 1 && a.epi == EPI_RESID && !a.scaled && !a.adjoint) {
-        hipLaunchKernelGGL((k_stencil_t<cplx, STENCIL_P, false, false, EPI_RESID, 1>), grid, dim3(256), 0, op->stream, q);
+        HELM_LAUNCH((k_stencil_t<cplx, STENCIL_P, false, false, EPI_RESID, 1>), grid, dim3(256), 0, op->stream, q);
     } else if (a.xmode == 2 && a.epi == EPI_JACOBI && !a.scaled && !a.adjoint) {
-        hipLaunchKernelGGL((k_stencil_t<cplx, STENCIL_P, false, false, EPI_JACOBI, 2>), grid, dim3(256), 0, op->stream, q);
+        HELM_LAUNCH((k_stencil_t<cplx, STENCIL_P, false, false, EPI_JACOBI, 2>), grid, dim3(256), 0, op->stream, q);
     } else if (a.xmode == 3 && a.epi == EPI_RESID && !a.scaled && !a.adjoint) {
-        hipLaunchKernelGGL((k_stencil_t<cplx, STENCIL_P, false, false, EPI_RESID, 3>), grid, dim3(256), 0, op->stream, q);
+        HELM_LAUNCH((k_stencil_t<cplx, STENCIL_P, false, false, EPI_RESID, 3>), grid, dim3(256), 0, op->stream, q);
     } else if (a.xmode != 0) {
         HELM_FAIL(op, HELM_ERR_ARG, "unsupported fused stencil mode");
     } else if (a.scaled) {
@@ -806,7 +806,7 @@ int helm_launch_apply(helm_op *op, const ApplyArgs &a) {
 
 int helm_launch_scale_planes(helm_op *op) {
     const int blocks = (int)((op->N + 255) / 256);
-    hipLaunchKernelGGL(k_scale_planes, dim3(blocks), dim3(256), 0, op->stream, op->d_C, op->d_Cs, op->d_dinv, op->N, op->nblocks, op->diag_floor, op->nplanes, op->centre);
+    HELM_LAUNCH(k_scale_planes, dim3(blocks), dim3(256), 0, op->stream, op->d_C, op->d_Cs, op->d_dinv, op->N, op->nblocks, op->diag_floor, op->nplanes, op->centre);
     HIP_TRY(op, hipGetLastError());
     return HELM_OK;
 }
@@ -814,7 +814,7 @@ int helm_launch_scale_planes(helm_op *op) {
 int helm_launch_prep_rhs(helm_op *op, const cplx *dRHS, long long rhs_ld, long long row_off, cplx premul,
                          const cplx *sub, cplx *out, int nrhs) {
     dim3 grid(vec_blocks(op->Nv), nrhs);
-    hipLaunchKernelGGL(k_prep_rhs, grid, dim3(256), 0, op->stream, dRHS, rhs_ld, row_off, premul, sub, (const cplx *)nullptr, out, op->Nv);
+    HELM_LAUNCH(k_prep_rhs, grid, dim3(256), 0, op->stream, dRHS, rhs_ld, row_off, premul, sub, (const cplx *)nullptr, out, op->Nv);
     HIP_TRY(op, hipGetLastError());
     return HELM_OK;
 }
@@ -822,7 +822,7 @@ int helm_launch_prep_rhs(helm_op *op, const cplx *dRHS, long long rhs_ld, long l
 // out = premul*rhs - sub and the partial sums of ||out||^2 (reduce with FIN_NORM over helm_vec_num_blocks partials)
 int helm_launch_prep_rhs_norm(helm_op *op, const cplx *dRHS, long long rhs_ld, long long row_off, cplx premul, const cplx *sub, cplx *out, int nrhs) {
     dim3 grid(vec_blocks(op->Nv), nrhs);
-    hipLaunchKernelGGL(k_prep_rhs_norm, grid, dim3(256), 0, op->stream, dRHS, rhs_ld, row_off, premul, sub, out, op->Nv, (double *)op->d_part, (int)grid.x);
+    HELM_LAUNCH(k_prep_rhs_norm, grid, dim3(256), 0, op->stream, dRHS, rhs_ld, row_off, premul, sub, out, op->Nv, (double *)op->d_part, (int)grid.x);
     HIP_TRY(op, hipGetLastError());
     return HELM_OK;
 }
@@ -832,11 +832,11 @@ int helm_launch_bicg_init(helm_op *op, int block, const cplx *dRHS, long long rh
                           VecPtrs w, int nrhs, double rtol) {
     // w.t temporarily receives bbar = dinv * (premul*rhs - sub); the caller copies/keeps it
     dim3 grid(vec_blocks(op->Nv), nrhs);
-    hipLaunchKernelGGL(k_prep_rhs, grid, dim3(256), 0, op->stream, dRHS, rhs_ld, (long long)0, premul, sub,
+    HELM_LAUNCH(k_prep_rhs, grid, dim3(256), 0, op->stream, dRHS, rhs_ld, (long long)0, premul, sub,
                        (const cplx *)(op->d_dinv + (long long)block * op->N), w.t, op->Nv);
-    hipLaunchKernelGGL(k_krylov_init, grid, dim3(256), 0, op->stream, (const cplx *)w.t, w, op->Nv, (double *)op->d_part, (int)grid.x);
+    HELM_LAUNCH(k_krylov_init, grid, dim3(256), 0, op->stream, (const cplx *)w.t, w, op->Nv, (double *)op->d_part, (int)grid.x);
     FinParams f; f.scal = op->d_scal; f.part = (const double *)op->d_part; f.nblk = grid.x; f.which = FIN_BICG_INIT; f.rtol = rtol; f.mask = nullptr; f.aux = nullptr;
-    hipLaunchKernelGGL(k_fin, dim3(nrhs), dim3(256), 0, op->stream, f);
+    HELM_LAUNCH(k_fin, dim3(nrhs), dim3(256), 0, op->stream, f);
     HIP_TRY(op, hipGetLastError());
     return HELM_OK;
 }
@@ -844,79 +844,79 @@ int helm_launch_bicg_init(helm_op *op, int block, const cplx *dRHS, long long rh
 // x = 0, r = r0 = bvec, p = v = 0 and the scalar records, for a system whose right-hand side is already formed
 int helm_launch_krylov_init(helm_op *op, const cplx *bvec, VecPtrs w, int nrhs, double rtol) {
     dim3 grid(vec_blocks(op->Nv), nrhs);
-    hipLaunchKernelGGL(k_krylov_init, grid, dim3(256), 0, op->stream, bvec, w, op->Nv, (double *)op->d_part, (int)grid.x);
+    HELM_LAUNCH(k_krylov_init, grid, dim3(256), 0, op->stream, bvec, w, op->Nv, (double *)op->d_part, (int)grid.x);
     FinParams f; f.scal = op->d_scal; f.part = (const double *)op->d_part; f.nblk = grid.x; f.which = FIN_BICG_INIT; f.rtol = rtol; f.mask = nullptr; f.aux = nullptr;
-    hipLaunchKernelGGL(k_fin, dim3(nrhs), dim3(256), 0, op->stream, f);
+    HELM_LAUNCH(k_fin, dim3(nrhs), dim3(256), 0, op->stream, f);
     HIP_TRY(op, hipGetLastError());
     return HELM_OK;
 }
 
 int helm_launch_bicg_p(helm_op *op, VecPtrs w, int nrhs) {
     dim3 grid(vec_blocks(op->Nv), nrhs);
-    hipLaunchKernelGGL(k_bicg_p, grid, dim3(256), 0, op->stream, w, op->Nv, (const RhsScal *)op->d_scal);
+    HELM_LAUNCH(k_bicg_p, grid, dim3(256), 0, op->stream, w, op->Nv, (const RhsScal *)op->d_scal);
     return HELM_OK;
 }
 int helm_launch_bicg_s(helm_op *op, VecPtrs w, int nrhs) {
     dim3 grid(vec_blocks(op->Nv), nrhs);
-    hipLaunchKernelGGL(k_bicg_s, grid, dim3(256), 0, op->stream, w, op->Nv, (const RhsScal *)op->d_scal);
+    HELM_LAUNCH(k_bicg_s, grid, dim3(256), 0, op->stream, w, op->Nv, (const RhsScal *)op->d_scal);
     return HELM_OK;
 }
 int helm_launch_bicg_xr(helm_op *op, VecPtrs w, const cplx *xp, const cplx *xs, int nrhs) {
     dim3 grid(vec_blocks(op->Nv), nrhs);
-    hipLaunchKernelGGL(k_bicg_xr, grid, dim3(256), 0, op->stream, w, xp, xs, op->Nv, (const RhsScal *)op->d_scal, (double *)op->d_part, (int)grid.x);
+    HELM_LAUNCH(k_bicg_xr, grid, dim3(256), 0, op->stream, w, xp, xs, op->Nv, (const RhsScal *)op->d_scal, (double *)op->d_part, (int)grid.x);
     return HELM_OK;
 }
 int helm_launch_cg_xr(helm_op *op, VecPtrs w, int nrhs) {
     dim3 grid(vec_blocks(op->Nv), nrhs);
-    hipLaunchKernelGGL(k_cg_xr, grid, dim3(256), 0, op->stream, w, op->Nv, (const RhsScal *)op->d_scal, (double *)op->d_part, (int)grid.x);
+    HELM_LAUNCH(k_cg_xr, grid, dim3(256), 0, op->stream, w, op->Nv, (const RhsScal *)op->d_scal, (double *)op->d_part, (int)grid.x);
     return HELM_OK;
 }
 int helm_launch_cg_p(helm_op *op, VecPtrs w, int nrhs, int first) {
     dim3 grid(vec_blocks(op->Nv), nrhs);
-    hipLaunchKernelGGL(k_cg_p, grid, dim3(256), 0, op->stream, w, op->Nv, (const RhsScal *)op->d_scal, first);
+    HELM_LAUNCH(k_cg_p, grid, dim3(256), 0, op->stream, w, op->Nv, (const RhsScal *)op->d_scal, first);
     return HELM_OK;
 }
 
 int helm_launch_fin(helm_op *op, int which, int nrhs, int nblk_part) {
     FinParams f; f.scal = op->d_scal; f.part = (const double *)op->d_part; f.nblk = nblk_part; f.which = which; f.rtol = 0.0; f.mask = nullptr; f.aux = nullptr;
-    hipLaunchKernelGGL(k_fin, dim3(nrhs), dim3(256), 0, op->stream, f);
+    HELM_LAUNCH(k_fin, dim3(nrhs), dim3(256), 0, op->stream, f);
     return HELM_OK;
 }
 
 int helm_launch_fin_ex(helm_op *op, int which, int nrhs, int nblk_part, const int *mask, double *aux) {
     FinParams f; f.scal = op->d_scal; f.part = (const double *)op->d_part; f.nblk = nblk_part; f.which = which; f.rtol = 0.0; f.mask = mask; f.aux = aux;
-    hipLaunchKernelGGL(k_fin, dim3(nrhs), dim3(256), 0, op->stream, f);
+    HELM_LAUNCH(k_fin, dim3(nrhs), dim3(256), 0, op->stream, f);
     return HELM_OK;
 }
 
 int helm_launch_restart_copy_mask(helm_op *op, VecPtrs w, int nrhs, const int *mask) {
     dim3 grid(vec_blocks(op->Nv), nrhs);
-    hipLaunchKernelGGL(k_restart_copy, grid, dim3(256), 0, op->stream, w, op->Nv, mask);
+    HELM_LAUNCH(k_restart_copy, grid, dim3(256), 0, op->stream, w, op->Nv, mask);
     return HELM_OK;
 }
 
 int helm_launch_norm2(helm_op *op, const cplx *a, int nrhs) {
     dim3 grid(vec_blocks(op->Nv), nrhs);
-    hipLaunchKernelGGL(k_norm2, grid, dim3(256), 0, op->stream, a, op->Nv, (double *)op->d_part, (int)grid.x);
+    HELM_LAUNCH(k_norm2, grid, dim3(256), 0, op->stream, a, op->Nv, (double *)op->d_part, (int)grid.x);
     return HELM_OK;
 }
 
 int helm_launch_finish(helm_op *op, const cplx *x, cplx *dU, long long u_ld, int nrhs, long long row_off) {
     dim3 grid(vec_blocks(op->Nv), nrhs);
-    hipLaunchKernelGGL(k_finish, grid, dim3(256), 0, op->stream, x, dU, u_ld, row_off, op->Nv);
+    HELM_LAUNCH(k_finish, grid, dim3(256), 0, op->stream, x, dU, u_ld, row_off, op->Nv);
     HIP_TRY(op, hipGetLastError());
     return HELM_OK;
 }
 
 int helm_launch_abs(helm_op *op, const cplx *in, cplx *out, long long n, double sign) {
-    hipLaunchKernelGGL(k_abs_cplx, dim3((unsigned)std::min<long long>((n + 255) / 256, 1 << 20)), dim3(256), 0, op->stream, in, out, n, sign);
+    HELM_LAUNCH(k_abs_cplx, dim3((unsigned)std::min<long long>((n + 255) / 256, 1 << 20)), dim3(256), 0, op->stream, in, out, n, sign);
     HIP_TRY(op, hipGetLastError());
     return HELM_OK;
 }
 
 int helm_launch_finish_ex(helm_op *op, const cplx *x, long long x_ld, long long x_off, cplx *dU, long long u_ld, long long row_off, int nrhs) {
     dim3 grid(vec_blocks(op->N), nrhs);
-    hipLaunchKernelGGL(k_finish_ex, grid, dim3(256), 0, op->stream, x, x_ld, x_off, dU, u_ld, row_off, op->N);
+    HELM_LAUNCH(k_finish_ex, grid, dim3(256), 0, op->stream, x, x_ld, x_off, dU, u_ld, row_off, op->N);
     HIP_TRY(op, hipGetLastError());
     return HELM_OK;
 }
@@ -924,7 +924,7 @@ int helm_launch_finish_ex(helm_op *op, const cplx *x, long long x_ld, long long 
 int helm_launch_prep_rhs_ex(helm_op *op, const cplx *dRHS, long long rhs_ld, long long row_off, cplx premul, const cplx *scale,
                             cplx *out, long long out_ld, long long out_off, int nrhs) {
     dim3 grid(vec_blocks(op->N), nrhs);
-    hipLaunchKernelGGL(k_prep_rhs_ex, grid, dim3(256), 0, op->stream, dRHS, rhs_ld, row_off, premul, scale, out, out_ld, out_off, op->N);
+    HELM_LAUNCH(k_prep_rhs_ex, grid, dim3(256), 0, op->stream, dRHS, rhs_ld, row_off, premul, scale, out, out_ld, out_off, op->N);
     HIP_TRY(op, hipGetLastError());
     return HELM_OK;
 }
@@ -932,7 +932,7 @@ int helm_launch_prep_rhs_ex(helm_op *op, const cplx *dRHS, long long rhs_ld, lon
 int helm_launch_rowscaled_system(helm_op *op) {
     if (!op->d_S) HIP_TRY(op, hipMalloc(&op->d_S, (size_t)36 * op->N * sizeof(cplx)));
     if (!op->d_rs) HIP_TRY(op, hipMalloc(&op->d_rs, (size_t)2 * op->N * sizeof(double)));
-    hipLaunchKernelGGL(k_rowscale_system, dim3((unsigned)((op->N + 255) / 256)), dim3(256), 0, op->stream, (const cplx *)op->d_C, op->d_S, op->d_rs, op->N);
+    HELM_LAUNCH(k_rowscale_system, dim3((unsigned)((op->N + 255) / 256)), dim3(256), 0, op->stream, (const cplx *)op->d_C, op->d_S, op->d_rs, op->N);
     HIP_TRY(op, hipGetLastError());
     return HELM_OK;
 }
@@ -940,7 +940,7 @@ int helm_launch_rowscaled_system(helm_op *op) {
 int helm_launch_prep_rhs_rs(helm_op *op, const cplx *dRHS, long long rhs_ld, long long row_off, cplx premul, const double *rs,
                             cplx *out, long long out_ld, long long out_off, int nrhs) {
     dim3 grid(vec_blocks(op->N), nrhs);
-    hipLaunchKernelGGL(k_prep_rhs_rs, grid, dim3(256), 0, op->stream, dRHS, rhs_ld, row_off, premul, rs, out, out_ld, out_off, op->N);
+    HELM_LAUNCH(k_prep_rhs_rs, grid, dim3(256), 0, op->stream, dRHS, rhs_ld, row_off, premul, rs, out, out_ld, out_off, op->N);
     HIP_TRY(op, hipGetLastError());
     return HELM_OK;
 }
@@ -954,7 +954,7 @@ __global__ __launch_bounds__(256) void k_rowscale_inplace(cplx *v, const double 
     }
 }
 int helm_launch_rowscale_inplace(helm_op *op, cplx *v, const double *rs, long long NV, int nrhs) {
-    hipLaunchKernelGGL(k_rowscale_inplace, dim3(vec_blocks(NV), nrhs), dim3(256), 0, op->stream, v, rs, NV);
+    HELM_LAUNCH(k_rowscale_inplace, dim3(vec_blocks(NV), nrhs), dim3(256), 0, op->stream, v, rs, NV);
     HIP_TRY(op, hipGetLastError());
     return HELM_OK;
 }
@@ -969,7 +969,7 @@ __global__ __launch_bounds__(256) void k_rhs_from_coo(const long long *__restric
 }
 int helm_launch_rhs_from_coo(helm_op *op, const long long *row, const int *col, const cplx *val, long long nnz, cplx *R, int nrhs, long long rows, int node_major) {
     HIP_TRY(op, hipMemsetAsync(R, 0, (size_t)nrhs * rows * sizeof(cplx), op->stream));
-    if (nnz > 0) hipLaunchKernelGGL(k_rhs_from_coo, dim3((unsigned)std::min<long long>((nnz + 255) / 256, 65535)), dim3(256), 0, op->stream, row, col, val, nnz, R, rows, nrhs, node_major);
+    if (nnz > 0) HELM_LAUNCH(k_rhs_from_coo, dim3((unsigned)std::min<long long>((nnz + 255) / 256, 65535)), dim3(256), 0, op->stream, row, col, val, nnz, R, rows, nrhs, node_major);
     HIP_TRY(op, hipGetLastError());
     return HELM_OK;
 }
@@ -986,7 +986,7 @@ __global__ __launch_bounds__(256) void k_sample(const cplx *__restrict__ U, int 
 }
 int helm_launch_sample(helm_op *op, const cplx *U, int nsrc, long long ld, const long long *rowptr, const long long *col, const cplx *val, int nrec, cplx *out) {
     const long long tot = (long long)nrec * nsrc;
-    hipLaunchKernelGGL(k_sample, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, op->stream, U, nsrc, ld, rowptr, col, val, nrec, out);
+    HELM_LAUNCH(k_sample, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, op->stream, U, nsrc, ld, rowptr, col, val, nrec, out);
     HIP_TRY(op, hipGetLastError());
     return HELM_OK;
 }
@@ -997,18 +997,18 @@ __global__ __launch_bounds__(256) void k_gardner_rho(const cplx *__restrict__ c,
         rho[i] = 310.0 * pow(c[i].x, 0.25);
 }
 int helm_launch_gardner_rho(helm_op *op) {
-    hipLaunchKernelGGL(k_gardner_rho, dim3(vec_blocks(op->N)), dim3(256), 0, op->stream, (const cplx *)op->d_c, op->d_rho, op->N);
+    HELM_LAUNCH(k_gardner_rho, dim3(vec_blocks(op->N)), dim3(256), 0, op->stream, (const cplx *)op->d_c, op->d_rho, op->N);
     HIP_TRY(op, hipGetLastError());
     return HELM_OK;
 }
 
 int helm_launch_zero(helm_op *op, cplx *p, long long n) {
-    hipLaunchKernelGGL(k_zero, dim3(vec_blocks(n)), dim3(256), 0, op->stream, p, n);
+    HELM_LAUNCH(k_zero, dim3(vec_blocks(n)), dim3(256), 0, op->stream, p, n);
     return HELM_OK;
 }
 
 int helm_launch_imaging(helm_op *op, const cplx *uf, const cplx *ub, int nsrc, const cplx *scaler, cplx *g) {
-    hipLaunchKernelGGL(k_imaging, dim3(vec_blocks(op->N)), dim3(256), 0, op->stream, uf, ub, nsrc, scaler, g, op->N);
+    HELM_LAUNCH(k_imaging, dim3(vec_blocks(op->N)), dim3(256), 0, op->stream, uf, ub, nsrc, scaler, g, op->N);
     HIP_TRY(op, hipGetLastError());
     return HELM_OK;
 }

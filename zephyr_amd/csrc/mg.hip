@@ -397,8 +397,8 @@ int setup_typed(helm_op *op, MgPrecond *P) {
         if (F32) {
             MG_HIP(hipMalloc(&L.C, (size_t)9 * N * sizeof(V))); MG_HIP(hipMalloc(&L.dinv, (size_t)N * sizeof(V)));
             L.own_planes = true;
-            hipLaunchKernelGGL((k_convert<V, cplx>), dim3(vblocks(9 * N)), dim3(256), 0, st, (const cplx *)L.op->d_C, (V *)L.C, 9 * N);
-            hipLaunchKernelGGL((k_convert<V, cplx>), dim3(vblocks(N)), dim3(256), 0, st, (const cplx *)L.op->d_dinv, (V *)L.dinv, N);
+            HELM_LAUNCH((k_convert<V, cplx>), dim3(vblocks(9 * N)), dim3(256), 0, st, (const cplx *)L.op->d_C, (V *)L.C, 9 * N);
+            HELM_LAUNCH((k_convert<V, cplx>), dim3(vblocks(N)), dim3(256), 0, st, (const cplx *)L.op->d_dinv, (V *)L.dinv, N);
         } else { L.C = L.op->d_C; L.dinv = L.op->d_dinv; }
         const size_t bytes = (size_t)batch * N * sizeof(V);
         if (l > 0 || F32) { MG_HIP(hipMalloc(&L.u, bytes)); MG_HIP(hipMalloc(&L.f, bytes)); }
@@ -437,9 +437,9 @@ int setup_typed(helm_op *op, MgPrecond *P) {
         P->sC = P->sop->d_C;
         const size_t zl = (size_t)2 * W * op->nz, xl = (size_t)2 * W * (op->nx - 2 * W);
         for (int k = 0; k < 3; ++k) { MG_HIP(hipMalloc(&P->zl[k], zl * sizeof(cplx))); MG_HIP(hipMalloc(&P->xl[k], xl * sizeof(cplx))); }
-        hipLaunchKernelGGL(k_line_factor, dim3((2 * W + 63) / 64), dim3(64), 0, st, (const cplx *)P->sop->d_C, op->nz, op->nx, W, 1,
+        HELM_LAUNCH(k_line_factor, dim3((2 * W + 63) / 64), dim3(64), 0, st, (const cplx *)P->sop->d_C, op->nz, op->nx, W, 1,
                            (cplx *)P->zl[0], (cplx *)P->zl[1], (cplx *)P->zl[2]);
-        hipLaunchKernelGGL(k_line_factor, dim3((2 * W + 63) / 64), dim3(64), 0, st, (const cplx *)P->sop->d_C, op->nz, op->nx, W, 0,
+        HELM_LAUNCH(k_line_factor, dim3((2 * W + 63) / 64), dim3(64), 0, st, (const cplx *)P->sop->d_C, op->nz, op->nx, W, 0,
                            (cplx *)P->xl[0], (cplx *)P->xl[1], (cplx *)P->xl[2]);
         MG_HIP(hipMalloc(&P->strip_r, (size_t)batch * N * sizeof(cplx)));
         MG_HIP(hipMemsetAsync(P->strip_r, 0, (size_t)batch * N * sizeof(cplx), st));
@@ -547,7 +547,7 @@ int vcycle(helm_op *op, MgPrecond *P, int l, const V *f, V *u_out, int nrhs, con
     hipStream_t st = op->stream;
     if (l == (int)P->lv.size() - 1) {
         dim3 grid((P->nc + 255) / 256, nrhs);
-        hipLaunchKernelGGL((k_coarse_dense<V>), grid, dim3(256), (size_t)P->nc * sizeof(V), st, (const V *)P->d_cinvT, f, u_out, P->nc, scal);
+        HELM_LAUNCH((k_coarse_dense<V>), grid, dim3(256), (size_t)P->nc * sizeof(V), st, (const V *)P->d_cinvT, f, u_out, P->nc, scal);
         return HELM_OK;
     }
     // Jacobi sweeps ping-pong between two buffers; start so that the last sweep lands in u_out
@@ -560,7 +560,7 @@ int vcycle(helm_op *op, MgPrecond *P, int l, const V *f, V *u_out, int nrhs, con
         rc = stencil_level<V>(op, lo, L.C, (const V *)nullptr, (V *)L.r, f, nrhs, EPI_RESID, scal, L.dinv, P->omega_j, nullptr, 0, 1, u);
         if (rc) return rc;
     } else {
-        hipLaunchKernelGGL((k_jac0<V>), vg, dim3(256), 0, st, (const V *)L.dinv, f, u, N, P->omega_j, scal);
+        HELM_LAUNCH((k_jac0<V>), vg, dim3(256), 0, st, (const V *)L.dinv, f, u, N, P->omega_j, scal);
         for (int k = 0; k < P->nu1 - 1; ++k) {
             rc = stencil_level<V>(op, lo, L.C, u, alt, f, nrhs, EPI_JACOBI, scal, L.dinv, P->omega_j);
             if (rc) return rc;
@@ -571,7 +571,7 @@ int vcycle(helm_op *op, MgPrecond *P, int l, const V *f, V *u_out, int nrhs, con
     }
     MgLevel &C = P->lv[l + 1];
     dim3 cg(vblocks(C.op->N), nrhs);
-    hipLaunchKernelGGL((k_restrict<V>), cg, dim3(256), 0, st, (const V *)L.r, (V *)C.f, lo->nz, lo->nx, C.op->nz, C.op->nx, scal);
+    HELM_LAUNCH((k_restrict<V>), cg, dim3(256), 0, st, (const V *)L.r, (V *)C.f, lo->nz, lo->nx, C.op->nz, C.op->nx, scal);
     rc = vcycle<V>(op, P, l + 1, (const V *)C.f, (V *)C.u, nrhs, scal, fmode);
     if (rc) return rc;
     if (fmode && l < P->fdepth && l + 1 < (int)P->lv.size() - 1) {
@@ -580,7 +580,7 @@ int vcycle(helm_op *op, MgPrecond *P, int l, const V *f, V *u_out, int nrhs, con
         if (rc) return rc;
         rc = vcycle<V>(op, P, l + 1, (const V *)C.g, (V *)C.f2, nrhs, scal, false);
         if (rc) return rc;
-        hipLaunchKernelGGL((k_axpy1<V>), cg, dim3(256), 0, st, (const V *)C.f2, (V *)C.u, C.op->N, scal);
+        HELM_LAUNCH((k_axpy1<V>), cg, dim3(256), 0, st, (const V *)C.f2, (V *)C.u, C.op->N, scal);
     }
     int k0 = 0;
     if (P->fuse && P->nu2 >= 1) {
@@ -590,7 +590,7 @@ int vcycle(helm_op *op, MgPrecond *P, int l, const V *f, V *u_out, int nrhs, con
         std::swap(u, alt);
         k0 = 1;
     } else {
-        hipLaunchKernelGGL((k_prolong_add<V>), vg, dim3(256), 0, st, (const V *)C.u, u, lo->nz, lo->nx, C.op->nz, C.op->nx, scal);
+        HELM_LAUNCH((k_prolong_add<V>), vg, dim3(256), 0, st, (const V *)C.u, u, lo->nz, lo->nx, C.op->nz, C.op->nx, scal);
     }
     for (int k = k0; k < P->nu2; ++k) {
         rc = stencil_level<V>(op, lo, L.C, u, alt, f, nrhs, EPI_JACOBI, scal, L.dinv, P->omega_j);
@@ -610,10 +610,10 @@ int apply_typed(helm_op *op, MgPrecond *P, const cplx *in, cplx *out, int nrhs, 
     dim3 vg(vblocks(N), nrhs);
     int rc;
     if (F32) {      // cycle in single precision between two conversions
-        hipLaunchKernelGGL((k_convert_rhs<V, cplx>), vg, dim3(256), 0, st, in, (V *)L0.f, N, scal);
+        HELM_LAUNCH((k_convert_rhs<V, cplx>), vg, dim3(256), 0, st, in, (V *)L0.f, N, scal);
         rc = vcycle<V>(op, P, 0, (const V *)L0.f, (V *)L0.u, nrhs, scal, P->fdepth > 0);
         if (rc) return rc;
-        hipLaunchKernelGGL((k_convert_rhs<cplx, V>), vg, dim3(256), 0, st, (const V *)L0.u, out, N, scal);
+        HELM_LAUNCH((k_convert_rhs<cplx, V>), vg, dim3(256), 0, st, (const V *)L0.u, out, N, scal);
     } else {
         rc = vcycle<V>(op, P, 0, (const V *)in, (V *)out, nrhs, scal, P->fdepth > 0);
         if (rc) return rc;
@@ -626,7 +626,7 @@ int apply_typed(helm_op *op, MgPrecond *P, const cplx *in, cplx *out, int nrhs, 
         dim3 lg(4 * W, nrhs);
         LineFactors<cplx> zf = {(const cplx *)P->zl[0], (const cplx *)P->zl[1], (const cplx *)P->zl[2]};
         LineFactors<cplx> xf = {(const cplx *)P->xl[0], (const cplx *)P->xl[1], (const cplx *)P->xl[2]};
-        hipLaunchKernelGGL((k_line_solve<cplx>), lg, dim3(64), 0, st, op->nz, op->nx, W, zf, xf, (const cplx *)P->strip_r, out, P->wstrip, scal);
+        HELM_LAUNCH((k_line_solve<cplx>), lg, dim3(64), 0, st, op->nz, op->nx, W, zf, xf, (const cplx *)P->strip_r, out, P->wstrip, scal);
     }
     HIP_TRY(op, hipGetLastError());
     return HELM_OK;

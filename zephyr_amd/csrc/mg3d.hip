@@ -181,16 +181,16 @@ int cycle(helm_op *op, Mg3Precond *P, size_t l, int nrhs, cplx *final_out = null
         return nd_dense_gemm(op, nrhs, P->nc, P->nc, cmake(1, 0), L.f, P->nc, P->cinvT, P->nc, cmake(0, 0), L.u, P->nc);
     }
     Mg3Level &C = P->lv[l + 1];
-    hipLaunchKernelGGL(k3_jac0, vgrid(L.N, nrhs), dim3(256), 0, st, L.f, L.op->d_dinv, L.u, L.N, P->omega_j);
+    HELM_LAUNCH(k3_jac0, vgrid(L.N, nrhs), dim3(256), 0, st, L.f, L.op->d_dinv, L.u, L.N, P->omega_j);
     int rc;
     for (int s = 1; s < P->nu1; ++s) {
         rc = level_apply(op, L, L.u, L.t, L.f, nrhs, EPI_JACOBI, P->omega_j); if (rc) return rc;
         std::swap(L.u, L.t);
     }
     rc = level_apply(op, L, L.u, L.r, L.f, nrhs, EPI_RESID, 0.0); if (rc) return rc;
-    hipLaunchKernelGGL(k3_restrict, vgrid(C.N, nrhs), dim3(256), 0, st, L.r, C.f, L.nz, L.ny, L.nx, C.nz, C.ny, C.nx);
+    HELM_LAUNCH(k3_restrict, vgrid(C.N, nrhs), dim3(256), 0, st, L.r, C.f, L.nz, L.ny, L.nx, C.nz, C.ny, C.nx);
     rc = cycle(op, P, l + 1, nrhs); if (rc) return rc;
-    hipLaunchKernelGGL(k3_prolong_add, vgrid(L.N, nrhs), dim3(256), 0, st, C.u, L.u, L.nz, L.ny, L.nx, C.nz, C.ny, C.nx);
+    HELM_LAUNCH(k3_prolong_add, vgrid(L.N, nrhs), dim3(256), 0, st, C.u, L.u, L.nz, L.ny, L.nx, C.nz, C.ny, C.nx);
     for (int s = 0; s < P->nu2; ++s) {
         if (final_out && s == P->nu2 - 1) return level_apply(op, L, L.u, final_out, L.f, nrhs, EPI_JACOBI, P->omega_j);
         rc = level_apply(op, L, L.u, L.t, L.f, nrhs, EPI_JACOBI, P->omega_j); if (rc) return rc;
@@ -746,7 +746,7 @@ int bt_setup(helm_op *op, Bt3 &B, const Mg3Level &L, int batch) {
     auto finish = [&](int chain, cplx *Tk, int k) -> int {
         const int rc = nd_dense_inverse(ctx[chain], Tk, B.m, W[chain]);
         if (rc) { helm_set_error(op, helm_last_error(ctx[chain])); return rc; }
-        if (B.f32) hipLaunchKernelGGL(k_bt_to_f32, dim3(4096), dim3(256), 0, sts[chain], (const cplx *)Tk, B.Tinv32 + (long long)k * B.m * B.ld32, B.m, B.ld32);
+        if (B.f32) HELM_LAUNCH(k_bt_to_f32, dim3(4096), dim3(256), 0, sts[chain], (const cplx *)Tk, B.Tinv32 + (long long)k * B.m * B.ld32, B.m, B.ld32);
         return HELM_OK;
     };
     int rc = HELM_OK;
@@ -756,13 +756,13 @@ int bt_setup(helm_op *op, Bt3 &B, const Mg3Level &L, int batch) {
         if (step < nl) {
             const int k = step;
             cplx *Tk = slot(0, step, k);
-            hipLaunchKernelGGL(k_bt_schur_t, dim3(sg), dim3(256), 0, sts[0], planes, g, k, lastL, (const cplx *)nullptr, Tk);
+            HELM_LAUNCH(k_bt_schur_t, dim3(sg), dim3(256), 0, sts[0], planes, g, k, lastL, (const cplx *)nullptr, Tk);
             rc = finish(0, Tk, k); lastL = Tk;
         }
         if (step < nr && !rc) {
             const int k = B.np - 1 - step;
             cplx *Tk = slot(1, step, k);
-            hipLaunchKernelGGL(k_bt_schur_t, dim3(sg), dim3(256), 0, sts[1], planes, g, k, (const cplx *)nullptr, lastR, Tk);
+            HELM_LAUNCH(k_bt_schur_t, dim3(sg), dim3(256), 0, sts[1], planes, g, k, (const cplx *)nullptr, lastR, Tk);
             rc = finish(1, Tk, k); lastR = Tk;
         }
     }
@@ -770,7 +770,7 @@ int bt_setup(helm_op *op, Bt3 &B, const Mg3Level &L, int batch) {
         hipEventRecord(B.ev[1], sts[1]);
         hipStreamWaitEvent(sts[0], B.ev[1], 0);
         cplx *Tk = slot(0, nl, B.mid);
-        hipLaunchKernelGGL(k_bt_schur_t, dim3(sg), dim3(256), 0, sts[0], planes, g, B.mid, lastL, lastR, Tk);
+        HELM_LAUNCH(k_bt_schur_t, dim3(sg), dim3(256), 0, sts[0], planes, g, B.mid, lastL, lastR, Tk);
         rc = finish(0, Tk, B.mid);
     }
     hipStreamSynchronize(sts[1]);
@@ -872,26 +872,26 @@ int bt_solve(helm_op *op, Bt3 &B, const Mg3Level &L, const cplx *f, cplx *u, int
         hipStream_t st = sts[chain];
         cplx *Zk = B.Z + k * pz;
         if (B.f32) {
-            hipLaunchKernelGGL(k_bt_apply32<16>, dim3((B.m + 127) / 128, B.ksplit), dim3(256), 0, st, (const cplx *)B.Y[chain], B.mpad,
+            HELM_LAUNCH(k_bt_apply32<16>, dim3((B.m + 127) / 128, B.ksplit), dim3(256), 0, st, (const cplx *)B.Y[chain], B.mpad,
                                (const float2 *)(B.Tinv32 + (long long)k * B.m * B.ld32), B.m, B.ld32, B.kc, nrhs, B.parts[chain]);
-            hipLaunchKernelGGL(k_bt_reduce, dim3(redg), dim3(256), 0, st, (const cplx *)B.parts[chain], B.nparts, pz, Zk, sub);
+            HELM_LAUNCH(k_bt_reduce, dim3(redg), dim3(256), 0, st, (const cplx *)B.parts[chain], B.nparts, pz, Zk, sub);
             return HELM_OK;
         }
         const cplx *Tk = B.Tinv + (long long)k * B.mpad * B.m;
         if (B.own) {
-            hipLaunchKernelGGL(k_bt_apply<16>, dim3((B.m + 127) / 128, B.ksplit), dim3(256), 0, st, (const cplx *)B.Y[chain], B.mpad, Tk, B.m, B.kc, nrhs, B.parts[chain]);
-            hipLaunchKernelGGL(k_bt_reduce, dim3(redg), dim3(256), 0, st, (const cplx *)B.parts[chain], B.nparts, pz, Zk, sub);
+            HELM_LAUNCH(k_bt_apply<16>, dim3((B.m + 127) / 128, B.ksplit), dim3(256), 0, st, (const cplx *)B.Y[chain], B.mpad, Tk, B.m, B.kc, nrhs, B.parts[chain]);
+            HELM_LAUNCH(k_bt_reduce, dim3(redg), dim3(256), 0, st, (const cplx *)B.parts[chain], B.nparts, pz, Zk, sub);
             return HELM_OK;
         }
         // generic batched GEMM (more than 16 right-hand sides): it launches on the handle's own stream, so this path keeps to one chain order
         const int rc = nd_dense_gemm_batched(chain ? B.aux : op, nrhs, B.m, B.kc, cmake(1, 0), B.Y[chain], B.mpad, B.kc, Tk, B.m, (long long)B.kc * B.m, cmake(0, 0),
                                              B.parts[chain], B.m, pz, B.ksplit);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_bt_reduce, dim3(redg), dim3(256), 0, st, (const cplx *)B.parts[chain], B.ksplit, pz, Zk, sub);
+        HELM_LAUNCH(k_bt_reduce, dim3(redg), dim3(256), 0, st, (const cplx *)B.parts[chain], B.ksplit, pz, Zk, sub);
         return HELM_OK;
     };
     auto rhs = [&](int chain, int k, const cplx *fk, const cplx *Zm, const cplx *Zp) {
-        hipLaunchKernelGGL(k_bt_rhs, rg, dim3(256), 0, sts[chain], planes, g, k, fk, Zm, Zp, B.Y[chain], B.mpad);
+        HELM_LAUNCH(k_bt_rhs, rg, dim3(256), 0, sts[chain], planes, g, k, fk, Zm, Zp, B.Y[chain], B.mpad);
     };
     const int nl = B.mid, nr = B.np - 1 - B.mid;
     int rc = HELM_OK;
@@ -913,7 +913,7 @@ int bt_solve(helm_op *op, Bt3 &B, const Mg3Level &L, const cplx *f, cplx *u, int
     }
     hipEventRecord(B.ev[1], sts[1]);
     hipStreamWaitEvent(sts[0], B.ev[1], 0);
-    hipLaunchKernelGGL(k_bt_scatter, dim3((unsigned)std::min<long long>(((long long)B.np * B.m + 255) / 256, 4096), nrhs), dim3(256), 0, sts[0],
+    HELM_LAUNCH(k_bt_scatter, dim3((unsigned)std::min<long long>(((long long)B.np * B.m + 255) / 256, 4096), nrhs), dim3(256), 0, sts[0],
                        (const cplx *)B.Z, g, nrhs, u);
     return HELM_OK;
 }
@@ -936,14 +936,14 @@ int cycle_keep(helm_op *op, Mg3Precond *P, size_t l, int nrhs, cplx *final_out =
         a.scal = nullptr; a.part = (double *)op->d_part; a.dinv = dl1; a.omega_j = w; a.profile = 0;
         return helm_launch_apply(L.op, a);
     };
-    hipLaunchKernelGGL(k3_jac0, vgrid(L.N, nrhs), dim3(256), 0, st, L.f, dl1, L.u, L.N, w);
+    HELM_LAUNCH(k3_jac0, vgrid(L.N, nrhs), dim3(256), 0, st, L.f, dl1, L.u, L.N, w);
     int rc;
     for (int s = 1; s < P->nu1; ++s) { rc = smooth(L.u, L.t); if (rc) return rc; std::swap(L.u, L.t); }
     rc = level_apply(op, L, L.u, L.r, L.f, nrhs, EPI_RESID, 0.0); if (rc) return rc;
-    hipLaunchKernelGGL(k3_restrict_t, vgrid(C.N, nrhs), dim3(256), 0, st, (const cplx *)L.r, C.f, L.ny, L.nx, C.nz, C.ny, C.nx, L.N,
+    HELM_LAUNCH(k3_restrict_t, vgrid(C.N, nrhs), dim3(256), 0, st, (const cplx *)L.r, C.f, L.ny, L.nx, C.nz, C.ny, C.nx, L.N,
                        (const RTab *)K->rt[0][l], (const RTab *)K->rt[1][l], (const RTab *)K->rt[2][l]);
     rc = cycle_keep(op, P, l + 1, nrhs); if (rc) return rc;
-    hipLaunchKernelGGL(k3_prolong_add_t, vgrid(L.N, nrhs), dim3(256), 0, st, (const cplx *)C.u, L.u, L.nz, L.ny, L.nx, C.ny, C.nx, C.N,
+    HELM_LAUNCH(k3_prolong_add_t, vgrid(L.N, nrhs), dim3(256), 0, st, (const cplx *)C.u, L.u, L.nz, L.ny, L.nx, C.ny, C.nx, C.N,
                        (const PTab *)K->pt[0][l], (const PTab *)K->pt[1][l], (const PTab *)K->pt[2][l]);
     for (int s = 0; s < P->nu2; ++s) {
         if (final_out && s == P->nu2 - 1) return smooth(L.u, final_out);
@@ -1059,7 +1059,7 @@ double inverse_seconds_class(helm_op *op, int m) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (A && W && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
             for (int rep = 0; rep < 2; ++rep) {                       // the second run is the timed one
-                hipLaunchKernelGGL(k3_cal_fill, dim3(1024), dim3(256), 0, op->stream, A, mc);
+                HELM_LAUNCH(k3_cal_fill, dim3(1024), dim3(256), 0, op->stream, A, mc);
                 hipEventRecord(e0, op->stream);
                 nd_dense_inverse(op, A, mc, W);
                 hipEventRecord(e1, op->stream);
@@ -1203,7 +1203,7 @@ int setup_keep(helm_op *op, Mg3Precond *P, int batch, int ncoarsen, double tauM)
                 hipMemcpyAsync(dk + off, kept[a].data(), kept[a].size() * sizeof(int), hipMemcpyHostToDevice, op->stream);
                 dka[a] = dk + off; off += kept[a].size();
             }
-            hipLaunchKernelGGL(k3_inject_model, dim3((unsigned)std::min<long long>((Lr.N + 255) / 256, 65535)), dim3(256), 0, op->stream, (const cplx *)Lf.op->d_c,
+            HELM_LAUNCH(k3_inject_model, dim3((unsigned)std::min<long long>((Lr.N + 255) / 256, 65535)), dim3(256), 0, op->stream, (const cplx *)Lf.op->d_c,
                                (const double *)Lf.op->d_rho, Lf.ny, Lf.nx, dka[0], dka[1], dka[2], Lr.nz, Lr.ny, Lr.nx, Lr.op->d_c, Lr.op->d_rho);
             hipStreamSynchronize(op->stream);                    // (kept[] is overwritten below; the table buffer goes back to the pool)
             helm_pool_free(op->device, dk, kb);
@@ -1216,7 +1216,7 @@ int setup_keep(helm_op *op, Mg3Precond *P, int batch, int ncoarsen, double tauM)
         cplx *dl1 = (cplx *)helm_pool_alloc(op->device, (size_t)Lr.N * sizeof(cplx));
         if (!dl1) HELM_FAIL(op, HELM_ERR_DEVICE, "3-D multigrid: level vectors do not fit");
         K->dl1.push_back(dl1); K->dl1_bytes.push_back((size_t)Lr.N * sizeof(cplx));
-        hipLaunchKernelGGL(k3_l1_dinv, dim3((unsigned)std::min<long long>((Lr.N + 255) / 256, 65535)), dim3(256), 0, op->stream, (const cplx *)Lr.op->d_C, dl1, Lr.N, K->omega_l1);
+        HELM_LAUNCH(k3_l1_dinv, dim3((unsigned)std::min<long long>((Lr.N + 255) / 256, 65535)), dim3(256), 0, op->stream, (const cplx *)Lr.op->d_C, dl1, Lr.N, K->omega_l1);
         // next level
         Ax3 cx[3];
         for (int a = 0; a < 3; ++a) {
@@ -1233,7 +1233,7 @@ int setup_keep(helm_op *op, Mg3Precond *P, int batch, int ncoarsen, double tauM)
         const Mg3Level &Lf = P->lv[ncoarsen - 1]; Mg3Level &Lc = P->lv[ncoarsen];
         const int t = ncoarsen - 1;
         Lc.op->otf3 = false;            // (the coarse level's planes are the Galerkin product from here on, not what its c, rho and factor tables would rebuild)
-        hipLaunchKernelGGL(k3_galerkin, dim3((unsigned)((Lc.N + 255) / 256)), dim3(256), 0, op->stream, (const cplx *)Lf.op->d_C, Lf.nz, Lf.ny, Lf.nx,
+        HELM_LAUNCH(k3_galerkin, dim3((unsigned)((Lc.N + 255) / 256)), dim3(256), 0, op->stream, (const cplx *)Lf.op->d_C, Lf.nz, Lf.ny, Lf.nx,
                            Lc.op->d_C, Lc.nz, Lc.ny, Lc.nx, (const RTab *)K->rt[0][t], (const RTab *)K->rt[1][t], (const RTab *)K->rt[2][t],
                            (const PTab *)K->pt[0][t], (const PTab *)K->pt[1][t], (const PTab *)K->pt[2][t]);
         HIP_TRY(op, hipGetLastError());
@@ -1289,7 +1289,7 @@ int mg3_setup(helm_op *op, int batch) {
         unsigned long long hmin = ~0ULL;
         if (!dmin) HELM_FAIL(op, HELM_ERR_DEVICE, "3-D multigrid: scratch allocation failed");
         hipMemcpyAsync(dmin, &hmin, sizeof(hmin), hipMemcpyHostToDevice, op->stream);
-        hipLaunchKernelGGL(k3_min_re, dim3(2048), dim3(256), 0, op->stream, (const cplx *)op->d_c, op->N, dmin);
+        HELM_LAUNCH(k3_min_re, dim3(2048), dim3(256), 0, op->stream, (const cplx *)op->d_c, op->N, dmin);
         hipMemcpyAsync(&hmin, dmin, sizeof(hmin), hipMemcpyDeviceToHost, op->stream);
         HIP_TRY(op, hipStreamSynchronize(op->stream));
         helm_pool_free(op->device, dmin, 64);
@@ -1416,9 +1416,9 @@ int mg3_setup(helm_op *op, int batch) {
         hipFree(A); hipFree(W); return fail(HELM_ERR_DEVICE, "3-D multigrid: coarsest inverse does not fit");
     }
     hipMemsetAsync(A, 0, mb, op->stream);
-    hipLaunchKernelGGL(k3_dense, dim3((unsigned)((Lc.N + 255) / 256)), dim3(256), 0, op->stream, (const cplx *)Lc.op->d_C, A, Lc.nz, Lc.ny, Lc.nx);
+    HELM_LAUNCH(k3_dense, dim3((unsigned)((Lc.N + 255) / 256)), dim3(256), 0, op->stream, (const cplx *)Lc.op->d_C, A, Lc.nz, Lc.ny, Lc.nx);
     rc = nd_dense_inverse(op, A, P->nc, W);
-    if (!rc) hipLaunchKernelGGL(k3_transpose_sq, dim3(4096), dim3(256), 0, op->stream, (const cplx *)A, P->cinvT, P->nc);
+    if (!rc) HELM_LAUNCH(k3_transpose_sq, dim3(4096), dim3(256), 0, op->stream, (const cplx *)A, P->cinvT, P->nc);
     hipStreamSynchronize(op->stream);
     hipFree(A); hipFree(W);
     if (rc) return fail(rc, "3-D multigrid: coarsest inverse failed");

@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void k_lu_solve(const cplx *__restrict__ LU, i
 }  // namespace
 
 void launch_lu_solve(hipStream_t st, const cplx *LU, int ld, int n, const int *piv, cplx *B, int ldb, int ncols) {
-    hipLaunchKernelGGL(k_lu_solve, dim3((ncols + 15) / 16), dim3(256), 0, st, LU, ld, n, piv, B, ldb, ncols);
+    HELM_LAUNCH(k_lu_solve, dim3((ncols + 15) / 16), dim3(256), 0, st, LU, ld, n, piv, B, ldb, ncols);
 }
 
 // ---- factorisation ---------------------------------------------------------------------------------------------
@@ -517,7 +517,7 @@ int flag_group(helm_op *op, NdFactor *f, size_t gi) {
     if (!slot) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: no pinned buffer for the list of ill-conditioned fronts");
     int *d_list = (int *)(f->d_est + 2 * (size_t)g.cnt);
     HIP_TRY(op, hipMemsetAsync(d_list, 0, sizeof(int), st));
-    hipLaunchKernelGGL(k_front_flag, dim3((g.cnt + 255) / 256), dim3(256), 0, st, (const double *)f->d_est, (const double *)(f->d_est + g.cnt), g.cnt, 1.0, thr, d_list, ND_STABLE_CAP);
+    HELM_LAUNCH(k_front_flag, dim3((g.cnt + 255) / 256), dim3(256), 0, st, (const double *)f->d_est, (const double *)(f->d_est + g.cnt), g.cnt, 1.0, thr, d_list, ND_STABLE_CAP);
     HIP_TRY(op, hipMemcpyAsync(slot->host, d_list, (ND_STABLE_CAP + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(op, hipEventRecord(slot->ev, st));
     return HELM_OK;
@@ -574,15 +574,15 @@ int stabilise_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *wor
         const long long foff = n.foff;
         n.finv_off = 0; n.f12_off = g.smax;                                       // [F11 | F12] rows go to S.lu, [F21 | F22] back to the arena
         const int rb = std::max(std::min(nmax, 4), (nmax + 2047) / 2048);
-        hipLaunchKernelGGL(k_nd_build_front, dim3((nmax + rb - 1) / rb, 1), dim3(256), (size_t)nmax * sizeof(int2), st, f->pd->d_nodes, 0, arenaF, S.lu, planes, P.nz, P.nx, rb,
+        HELM_LAUNCH(k_nd_build_front, dim3((nmax + rb - 1) / rb, 1), dim3(256), (size_t)nmax * sizeof(int2), st, f->pd->d_nodes, 0, arenaF, S.lu, planes, P.nz, P.nx, rb,
                            0, 1, n);                                                 // (the redirected node travels as a launch argument: no copy, no host wait)
         cplx *F21 = arenaF + foff, *F22 = arenaF + foff + g.smax;
         HIP_TRY(op, hipMemcpy2DAsync(S.f21, (size_t)g.smax * sizeof(cplx), F21, (size_t)nmax * sizeof(cplx), (size_t)g.smax * sizeof(cplx), (size_t)g.mmax, hipMemcpyDeviceToDevice, st));
-        if (g.smax <= 64) hipLaunchKernelGGL(k_lu_factor64, dim3(1), dim3(256), 0, st, S.lu, nmax, g.smax, S.piv);
-        else hipLaunchKernelGGL(k_lu_factor, dim3(1), dim3(256), 0, st, S.lu, nmax, g.smax, S.piv);
+        if (g.smax <= 64) HELM_LAUNCH(k_lu_factor64, dim3(1), dim3(256), 0, st, S.lu, nmax, g.smax, S.piv);
+        else HELM_LAUNCH(k_lu_factor, dim3(1), dim3(256), 0, st, S.lu, nmax, g.smax, S.piv);
         // Schur complement through the same factors: F22 -= F21 (F11^-1 F12)
         HIP_TRY(op, hipMemcpy2DAsync(work, (size_t)g.mmax * sizeof(cplx), S.lu + g.smax, (size_t)nmax * sizeof(cplx), (size_t)g.mmax * sizeof(cplx), (size_t)g.smax, hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(k_lu_solve, dim3((g.mmax + 15) / 16), dim3(256), 0, st, (const cplx *)S.lu, nmax, g.smax, (const int *)S.piv, work, g.mmax, g.mmax);
+        HELM_LAUNCH(k_lu_solve, dim3((g.mmax + 15) / 16), dim3(256), 0, st, (const cplx *)S.lu, nmax, g.smax, (const int *)S.piv, work, g.mmax, g.mmax);
         gemm(op, g.mmax, g.mmax, g.smax, mone, S.f21, g.smax, 0, work, g.mmax, 0, one, F22, nmax, 0, 1, nullptr);
         if (getenv("HELM_ND_DEBUG") && atoi(getenv("HELM_ND_DEBUG")) >= 3) {      // reproducibility probe: checksums of every piece of this front's re-elimination
             auto sum2d = [&](const void *src, size_t pitch, size_t wbytes, size_t rows_) {
@@ -654,7 +654,7 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
         const int rb = std::max(std::min(nmax, 4), (nmax + want - 1) / want);
         for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
             const int nb = std::min(65535, g.cnt - j0);
-            hipLaunchKernelGGL(k_nd_build_front, dim3((nmax + rb - 1) / rb, nb), dim3(256), (size_t)nmax * sizeof(int2), st, d_nodes, g.first + j0, arenaF, f->d_fac, planes,
+            HELM_LAUNCH(k_nd_build_front, dim3((nmax + rb - 1) / rb, nb), dim3(256), (size_t)nmax * sizeof(int2), st, d_nodes, g.first + j0, arenaF, f->d_fac, planes,
                                P.nz, P.nx, rb, schur_gather ? 1 : 0, 0, NdDev());
         }
     } else {
@@ -662,7 +662,7 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
         HIP_TRY(op, hipMemsetAsync(Finv, 0, (size_t)g.cnt * s1 * sizeof(cplx), st));
         for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
             const int nb = std::min(65535, g.cnt - j0);
-            hipLaunchKernelGGL(k_nd_assemble, dim3((nmax + 255) / 256, nb), dim3(256), 0, st, d_nodes, g.first + j0, arenaF, f->d_fac, planes, P.nz, P.nx);
+            HELM_LAUNCH(k_nd_assemble, dim3((nmax + 255) / 256, nb), dim3(256), 0, st, d_nodes, g.first + j0, arenaF, f->d_fac, planes, P.nz, P.nx);
         }
         if (!g.leaf) {
             // children's ring sizes are bounded by this group's front size
@@ -674,7 +674,7 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
                     const long long total = (long long)nmax * nmax;
                     const int chunk = (int)std::max<long long>(4096, std::min<long long>(total, std::max<long long>(16LL * nmax, total / std::max(1, 2048 / nb))));
                     const int gx = (int)std::max<long long>(1, std::min<long long>((total + chunk - 1) / chunk, 65535));
-                    hipLaunchKernelGGL(k_nd_extend_add, dim3(gx, nb), dim3(256), shm, st, d_nodes, g.first + j0, slot, arenaF, f->d_fac, P.nz, P.nx, chunk);
+                    HELM_LAUNCH(k_nd_extend_add, dim3(gx, nb), dim3(256), shm, st, d_nodes, g.first + j0, slot, arenaF, f->d_fac, P.nz, P.nx, chunk);
                 }
         }
     }
@@ -686,11 +686,11 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
     const bool watch = stable_enabled(P) && !g.leaf && g.mmax > 0 && g.smax <= std::min(stable_smax, LUS_NMAX) && ensure_est(op, f, std::min(stable_smax, LUS_NMAX)) == HELM_OK;
     double *est_rows = watch ? f->d_est + est_rows_off(P) : nullptr;
     if (watch) for (int j0 = 0; j0 < g.cnt; j0 += 65535)
-        hipLaunchKernelGGL(k_front_cond<0>, dim3(std::min(65535, g.cnt - j0)), dim3(256), 0, st, Finv + (long long)j0 * s1, nmax, s1, d_nodes + g.first + j0, f->d_est + j0,
+        HELM_LAUNCH(k_front_cond<0>, dim3(std::min(65535, g.cnt - j0)), dim3(256), 0, st, Finv + (long long)j0 * s1, nmax, s1, d_nodes + g.first + j0, f->d_est + j0,
                            est_rows + (long long)j0 * g.smax, g.smax);
     invert(op, Finv, nmax, s1, g.smax, g.cnt, work, s11, P.dof, 0);      // F11 -> F11^-1 where it stays
     if (watch) for (int j0 = 0; j0 < g.cnt; j0 += 65535)
-        hipLaunchKernelGGL(k_front_cond<1>, dim3(std::min(65535, g.cnt - j0)), dim3(256), 0, st, Finv + (long long)j0 * s1, nmax, s1, d_nodes + g.first + j0, f->d_est + g.cnt + j0,
+        HELM_LAUNCH(k_front_cond<1>, dim3(std::min(65535, g.cnt - j0)), dim3(256), 0, st, Finv + (long long)j0 * s1, nmax, s1, d_nodes + g.first + j0, f->d_est + g.cnt + j0,
                            est_rows + (long long)j0 * g.smax, g.smax);
     if (watch) { const int rcf = flag_group(op, f, gi); if (rcf) return rcf; }      // (the list travels while the products below run)
     if (g.mmax > 0) {

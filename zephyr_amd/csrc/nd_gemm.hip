@@ -346,7 +346,7 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
             if (op->sk_buf) {
                 GemmRows R; R.dense = 1; R.ksplit = ks; R.kc = kc; R.pstride = per;
                 launch_mfma<4, 1, 2, 1, 8>(st, 0, batch * ks, M, Nn, K, cmake(1, 0), A, lda, sa, B, ldb, sb, cmake(0, 0), op->sk_buf, Nn, (long long)M * Nn, R);
-                hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)std::min<long long>((per + 255) / 256, 4096)), dim3(256), 0, st, (const cplx *)op->sk_buf, ks, per, M, Nn, alpha, beta,
+                HELM_LAUNCH(k_splitk_reduce, dim3((unsigned)std::min<long long>((per + 255) / 256, 4096)), dim3(256), 0, st, (const cplx *)op->sk_buf, ks, per, M, Nn, alpha, beta,
                                    C, ldc, sc, per);
                 split_done = true;
             }

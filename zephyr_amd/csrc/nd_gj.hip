@@ -683,7 +683,7 @@ void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cp
             cplx *Pb = gj_pbuf(op, batch);
             if (Pb) {
                 const long long sp = 2LL * PNB * PNB;
-                hipLaunchKernelGGL(k_gj_pivot, dim3(batch), dim3(256), 0, st, M, ld, stride, n, 0, std::min(PNB, n), (const cplx *)nullptr, (const cplx *)nullptr, ws, Pb, sp);
+                HELM_LAUNCH(k_gj_pivot, dim3(batch), dim3(256), 0, st, M, ld, stride, n, 0, std::min(PNB, n), (const cplx *)nullptr, (const cplx *)nullptr, ws, Pb, sp);
                 const bool ext = op && op->profiling && tune.prof_ext != 0;
                 int step = 0;
                 for (int k0 = 0; k0 < n; k0 += PNB, ++step) {
@@ -703,7 +703,7 @@ void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cp
                     const dim3 grid((n + 31) / 32, (n + 63) / 64, batch + a.nsw);
                     ZG_LAUNCH(k_gj_step, grid, a);
                 }
-                if (step & 1) hipLaunchKernelGGL(k_copy_blocks, dim3((unsigned)std::min<long long>(((long long)n * n + 255) / 256, 1024), batch), dim3(256), 0, st, (const cplx *)W, n, ws, M, ld, stride, n);
+                if (step & 1) HELM_LAUNCH(k_copy_blocks, dim3((unsigned)std::min<long long>(((long long)n * n + 255) / 256, 1024), batch), dim3(256), 0, st, (const cplx *)W, n, ws, M, ld, stride, n);
                 return;
             }
         }
@@ -711,10 +711,10 @@ void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cp
         // z-slice of the update's grid: that slice must have a workgroup for each).  The dense plane inverses of the 3-D coarse solve, n = 3713: -7 %.
         if (n >= 512 && (long long)((n + 63) / 64) * ((n + 31) / 32) >= batch && (long long)2 * PNB * n + PNB * PNB <= ws) {
             cplx *Pb = W + (long long)2 * PNB * n;
-            hipLaunchKernelGGL(k_gj_pivot, dim3(batch), dim3(256), 0, st, M, ld, stride, n, 0, std::min(PNB, n), Wc, Wr, ws, Pb, ws);
+            HELM_LAUNCH(k_gj_pivot, dim3(batch), dim3(256), 0, st, M, ld, stride, n, 0, std::min(PNB, n), Wc, Wr, ws, Pb, ws);
             for (int k0 = 0; k0 < n; k0 += PNB) {
                 const int nb = std::min(PNB, n - k0);
-                hipLaunchKernelGGL(k_gj_slices, dim3((n + 63) / 64, batch), dim3(256), 0, st, M, ld, stride, n, k0, nb, Wc, Wr, ws, Pb, ws);
+                HELM_LAUNCH(k_gj_slices, dim3((n + 63) / 64, batch), dim3(256), 0, st, M, ld, stride, n, k0, nb, Wc, Wr, ws, Pb, ws);
                 GemmRows R; R.dense = 1; R.zr0 = k0; R.zr1 = k0 + nb; R.zc0 = k0; R.zc1 = k0 + nb;
                 GjPivotArgs pv;
                 if (k0 + PNB < n) {                                      // the sweep of the next pivot block rides along; the update leaves that block alone
@@ -732,7 +732,7 @@ void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cp
             const int nb = std::min(PNB, n - k0);
             for (int b0 = 0; b0 < batch; b0 += 65535) {
                 const int nbt = std::min(65535, batch - b0);
-                hipLaunchKernelGGL(k_gj_panel, dim3((n + 63) / 64, nbt), dim3(256), 0, st, M + b0 * stride, ld, stride, n, k0, nb, Wc + b0 * ws, Wr + b0 * ws, ws);
+                HELM_LAUNCH(k_gj_panel, dim3((n + 63) / 64, nbt), dim3(256), 0, st, M + b0 * stride, ld, stride, n, k0, nb, Wc + b0 * ws, Wr + b0 * ws, ws);
             }
             GemmRows R; R.dense = 1; R.zr0 = k0; R.zr1 = k0 + nb; R.zc0 = k0; R.zc1 = k0 + nb;
             gemm(op, n, n, nb, cmake(-1, 0), Wc, PNB, ws, Wr, n, ws, cmake(1, 0), M, ld, stride, batch, &R);
@@ -742,9 +742,9 @@ void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cp
     if (n <= gj_base) {
         for (int b0 = 0; b0 < batch; b0 += 1 << 20) {
             const int nb = std::min(1 << 20, batch - b0);
-            if (n <= 32 && batch >= 2048) hipLaunchKernelGGL(k_gj32w_inverse, dim3((nb + 3) / 4), dim3(256), 0, st, M + b0 * stride, ld, stride, n, nb);
-            else if (n <= 32) hipLaunchKernelGGL(k_gj32_inverse, dim3(nb), dim3(256), 0, st, M + b0 * stride, ld, stride, n);
-            else hipLaunchKernelGGL(k_gj_inverse<64>, dim3(nb), dim3(256), 0, st, M + b0 * stride, ld, stride, n);
+            if (n <= 32 && batch >= 2048) HELM_LAUNCH(k_gj32w_inverse, dim3((nb + 3) / 4), dim3(256), 0, st, M + b0 * stride, ld, stride, n, nb);
+            else if (n <= 32) HELM_LAUNCH(k_gj32_inverse, dim3(nb), dim3(256), 0, st, M + b0 * stride, ld, stride, n);
+            else HELM_LAUNCH(k_gj_inverse<64>, dim3(nb), dim3(256), 0, st, M + b0 * stride, ld, stride, n);
         }
         return;
     }

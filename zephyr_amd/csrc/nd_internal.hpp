@@ -77,7 +77,8 @@ struct GemmRows {
 // Per-launch timing without extra packets: when gemm() has armed a pair of events, the dispatch itself carries them
 // (hipExtLaunchKernelGGL: start / stop timestamps of that kernel), instead of two hipEventRecord markers around it.
 extern thread_local hipEvent_t tl_ev0, tl_ev1;
-#define ZG_LAUNCH(KERNEL, GRID, ...) do { if (tl_ev0) hipExtLaunchKernelGGL(KERNEL, GRID, dim3(256), 0, st, tl_ev0, tl_ev1, 0, __VA_ARGS__); \
+#define ZG_LAUNCH(KERNEL, GRID, ...) do { HelmFirstLaunch fl_(HelmKernelReg<(KERNEL)>::slot); \
+                                          if (tl_ev0) hipExtLaunchKernelGGL(KERNEL, GRID, dim3(256), 0, st, tl_ev0, tl_ev1, 0, __VA_ARGS__); \
                                           else hipLaunchKernelGGL(KERNEL, GRID, dim3(256), 0, st, __VA_ARGS__); } while (0)
 
 // What one GEMM launch has to move at the very least -- every operand once: A (M x K), B (K x N), C written (and read when beta != 0) -- and the

@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void k_leaf_factor_pivoted(const NdDev *nodes,
 }  // namespace
 
 void launch_leaf_factor(hipStream_t st, int smax, int nb, const NdDev *d_nodes, int first, cplx *arenaF, cplx *fac, cplx *g21b, const cplx *planes, int nz, int nx, int *flags, int dbg) {
-    if (smax <= 49) hipLaunchKernelGGL(k_leaf_factor<49>, dim3(nb), dim3(128), 0, st, d_nodes, first, arenaF, fac, g21b, planes, nz, nx, flags, dbg);
-    else hipLaunchKernelGGL(k_leaf_factor<64>, dim3(nb), dim3(128), 0, st, d_nodes, first, arenaF, fac, g21b, planes, nz, nx, flags, dbg);
-    hipLaunchKernelGGL(k_leaf_factor_pivoted, dim3(nb), dim3(256), 0, st, d_nodes, first, arenaF, fac, g21b, planes, nz, nx, (const int *)flags);
+    if (smax <= 49) HELM_LAUNCH(k_leaf_factor<49>, dim3(nb), dim3(128), 0, st, d_nodes, first, arenaF, fac, g21b, planes, nz, nx, flags, dbg);
+    else HELM_LAUNCH(k_leaf_factor<64>, dim3(nb), dim3(128), 0, st, d_nodes, first, arenaF, fac, g21b, planes, nz, nx, flags, dbg);
+    HELM_LAUNCH(k_leaf_factor_pivoted, dim3(nb), dim3(256), 0, st, d_nodes, first, arenaF, fac, g21b, planes, nz, nx, (const int *)flags);
 }

@@ -153,7 +153,7 @@ void forward_stable(helm_op *op, NdFactor *f, size_t gi, const SolveCtx &c) {
         cplx *V = c.arenaV + n.voff * nrhs;
         // the front vector gathered again: separator rows q_S + the children's rows (written to Xt as y_S for the back substitution), ring rows
         // the children's rows; then z = F11^-1 y_S through the LU and V_B -= F21 z
-        hipLaunchKernelGGL(k_nd_fwd_rows, c.rgrid(nmax), c.rb, 0, op->stream, c.tab + n.roff, V, c.arenaV, c.Qt, c.Xt, (long long)nmax, nrhs, g.leaf ? 0 : 1,
+        HELM_LAUNCH(k_nd_fwd_rows, c.rgrid(nmax), c.rb, 0, op->stream, c.tab + n.roff, V, c.arenaV, c.Qt, c.Xt, (long long)nmax, nrhs, g.leaf ? 0 : 1,
                            (const int *)c.act, c.nct, (const NdDev *)f->pd->d_nodes, S.node, nmax);
         if (c.act) hipMemsetAsync(c.act + (long long)S.node * c.nct, 1, (size_t)c.nct * sizeof(int), op->stream);      // (every row of this front has been written)
         launch_lu_solve(op->stream, S.lu, nmax, S.smax, S.piv, V, nrhs, nrhs);
@@ -185,7 +185,7 @@ void forward_group_batched(helm_op *op, NdFactor *f, size_t gi, const SolveCtx &
         if (R.act && !R.hint && c.flist && g.smax <= 64 && c.Qt != c.Xt && helm_tuning_now().nd_leaf_idle != 0) {
             for (int j0 = 0; j0 < g.cnt; j0 += 32768) {
                 const int nbj = std::min(32768, g.cnt - j0), pairs = nbj * c.nct;
-                hipLaunchKernelGGL((k_fwd_flags<32, 2>), dim3((pairs + 1) / 2), dim3(256), 0, op->stream, c.tab + g.roff + (long long)j0 * nmax, nmax, g.smax,
+                HELM_LAUNCH((k_fwd_flags<32, 2>), dim3((pairs + 1) / 2), dim3(256), 0, op->stream, c.tab + g.roff + (long long)j0 * nmax, nmax, g.smax,
                                    (const NdDev *)f->pd->d_nodes, g.first + j0, nbj, c.nct, c.act, c.Qt, c.Xt, nrhs, nrhs, c.fcount + gi, c.flist, 1);
             }
             R.hint = 1;
@@ -205,7 +205,7 @@ void forward_group_batched(helm_op *op, NdFactor *f, size_t gi, const SolveCtx &
         R.act = c.act; R.nct = c.nct; R.first = g.first; R.nodes = f->pd->d_nodes;
         if (c.act && c.flist && g.cnt <= 65535 && g.smax <= 128 && helm_tuning_now().nd_leaf_idle != 0) {      // who has work: decided before the launch, which is dealt from the list
             const int pairs = g.cnt * c.nct;
-#define FWD_FLAGS(NR_, WPP_) hipLaunchKernelGGL((k_fwd_flags<NR_, WPP_>), dim3((pairs + 4 / WPP_ - 1) / (4 / WPP_)), dim3(256), 0, op->stream, c.tab + g.roff, nmax, g.smax, \
+#define FWD_FLAGS(NR_, WPP_) HELM_LAUNCH((k_fwd_flags<NR_, WPP_>), dim3((pairs + 4 / WPP_ - 1) / (4 / WPP_)), dim3(256), 0, op->stream, c.tab + g.roff, nmax, g.smax, \
                                                 (const NdDev *)f->pd->d_nodes, g.first, g.cnt, c.nct, c.act, c.Qt, c.Xt, nrhs, nrhs, c.fcount + gi, c.flist, 0)
             if (g.smax <= 8) FWD_FLAGS(8, 1); else if (g.smax <= 16) FWD_FLAGS(16, 1); else if (g.smax <= 32) FWD_FLAGS(16, 2); else if (g.smax <= 64) FWD_FLAGS(16, 4);
             else FWD_FLAGS(32, 4);
@@ -218,7 +218,7 @@ void forward_group_batched(helm_op *op, NdFactor *f, size_t gi, const SolveCtx &
         if (c.act && !R.act) hipMemsetAsync(c.act + (long long)g.first * c.nct, 1, (size_t)g.cnt * c.nct * sizeof(int), op->stream);
         return;
     }
-    hipLaunchKernelGGL(k_nd_fwd_rows, c.rgrid(rows), c.rb, 0, op->stream, c.tab + g.roff, V, c.arenaV, c.Qt, c.Xt, rows, nrhs, g.leaf ? 0 : 1,
+    HELM_LAUNCH(k_nd_fwd_rows, c.rgrid(rows), c.rb, 0, op->stream, c.tab + g.roff, V, c.arenaV, c.Qt, c.Xt, rows, nrhs, g.leaf ? 0 : 1,
                        (const int *)c.act, c.nct, (const NdDev *)f->pd->d_nodes, g.first, nmax);
     if (c.act) hipMemsetAsync(c.act + (long long)g.first * c.nct, 1, (size_t)g.cnt * c.nct * sizeof(int), op->stream);      // (these fronts write every row)
     if (g.mmax > 0)     // outgoing ring part: V_B -= G21 V_S
@@ -244,11 +244,11 @@ int backward_stable(helm_op *op, NdFactor *f, size_t gk, const SolveCtx &c, bool
                 if (!S.vs) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: scratch for an ill-conditioned front failed");
                 S.vs_elems = need;
             }
-            hipLaunchKernelGGL(k_nd_bwd_gather, c.rgrid(nmax), c.rb, 0, op->stream, c.tab + n.roff, S.vs, g.leaf ? c.Qt : (const cplx *)c.Xt, (const cplx *)c.Xt, (long long)nmax, nrhs);
+            HELM_LAUNCH(k_nd_bwd_gather, c.rgrid(nmax), c.rb, 0, op->stream, c.tab + n.roff, S.vs, g.leaf ? c.Qt : (const cplx *)c.Xt, (const cplx *)c.Xt, (long long)nmax, nrhs);
         } else {
             if (S.mmax > 0) gemm(op, S.smax, nrhs, S.mmax, mone, S.lu + S.smax, nmax, 0, S.vs + (long long)S.smax * nrhs, nrhs, 0, one, S.vs, nrhs, 0, 1);
             launch_lu_solve(op->stream, S.lu, nmax, S.smax, S.piv, S.vs, nrhs, nrhs);
-            hipLaunchKernelGGL(k_nd_bwd_store, c.rgrid(S.smax), c.rb, 0, op->stream, c.tab + n.roff, (const cplx *)S.vs, c.Xt, (long long)S.smax, S.smax, nmax, nrhs, c.Uout, c.oscale);
+            HELM_LAUNCH(k_nd_bwd_store, c.rgrid(S.smax), c.rb, 0, op->stream, c.tab + n.roff, (const cplx *)S.vs, c.Xt, (long long)S.smax, S.smax, nmax, nrhs, c.Uout, c.oscale);
         }
     }
     return HELM_OK;
@@ -314,7 +314,7 @@ void backward_group_batched(helm_op *op, NdFactor *f, size_t gk, const SolveCtx 
         gemm(op, g.smax, nrhs, g.smax, one, Finv, nmax, s1, V, nrhs, (long long)g.smax * nrhs, zero, nullptr, 0, 0, g.cnt, &R2);
         return;
     }
-    hipLaunchKernelGGL(k_nd_bwd_gather, c.rgrid(rows), c.rb, 0, op->stream, c.tab + g.roff, V, g.leaf ? c.Qt : c.Xt, c.Xt, rows, nrhs);
+    HELM_LAUNCH(k_nd_bwd_gather, c.rgrid(rows), c.rb, 0, op->stream, c.tab + g.roff, V, g.leaf ? c.Qt : c.Xt, c.Xt, rows, nrhs);
     if (gform) {            // the gathered front vector is [y_S; x_B]: one dense product with [F11^-1 | G]
         gemm(op, g.smax, nrhs, nmax, one, Finv, nmax, s1, V, nrhs, (long long)nmax * nrhs, zero, XS, nrhs, (long long)g.smax * nrhs, g.cnt);
     } else {
@@ -324,7 +324,7 @@ void backward_group_batched(helm_op *op, NdFactor *f, size_t gk, const SolveCtx 
         gemm(op, g.smax, nrhs, g.smax, one, Finv, nmax, s1, V, nrhs, (long long)nmax * nrhs, zero, XS, nrhs, (long long)g.smax * nrhs, g.cnt);
     }
     const long long srows = (long long)g.cnt * g.smax;
-    hipLaunchKernelGGL(k_nd_bwd_store, c.rgrid(srows), c.rb, 0, op->stream, c.tab + g.roff, XS, c.Xt, srows, g.smax, nmax, nrhs, c.Uout, c.oscale);
+    HELM_LAUNCH(k_nd_bwd_store, c.rgrid(srows), c.rb, 0, op->stream, c.tab + g.roff, XS, c.Xt, srows, g.smax, nmax, nrhs, c.Uout, c.oscale);
 }
 
 }  // namespace
@@ -404,13 +404,13 @@ static void arm_sparse_rhs(helm_op *op, NdFactor *f, SolveCtx &c, hipStream_t st
     // 3.2 of the 4.3 GB of a 1024^2 x 256 batch.  Only for the pass whose right-hand sides are the caller's own array (refinement passes solve for residuals).
     if (op->rhs_bits && c.Qt == op->rhs_bits_q && c.nrhs == op->rhs_bits_nrhs && nct <= 8 && f->pd->d_cellnode && op->rhs_bits_rows == (long long)f->pd->plan.nz * f->pd->plan.nx) {
         const long long N = op->rhs_bits_rows;
-        hipLaunchKernelGGL(k_nd_support_act, dim3((unsigned)std::min<long long>((N + 255) / 256, 4096)), dim3(256), 0, st, op->rhs_bits, (const int *)f->pd->d_cellnode, f->d_act, nct, N);
+        HELM_LAUNCH(k_nd_support_act, dim3((unsigned)std::min<long long>((N + 255) / 256, 4096)), dim3(256), 0, st, op->rhs_bits, (const int *)f->pd->d_cellnode, f->d_act, nct, N);
         c.act_hint = 1;
         if (getenv("HELM_ND_SUPPORT_CHECK") && atoi(getenv("HELM_ND_SUPPORT_CHECK"))) {
             int *d_bad = (int *)helm_pool_alloc(op->device, sizeof(int));
             if (d_bad) {
                 hipMemsetAsync(d_bad, 0, sizeof(int), st);
-                hipLaunchKernelGGL(k_nd_support_check, dim3(4096), dim3(256), 0, st, op->rhs_bits, c.Qt, c.nrhs, c.nrhs, N, d_bad);
+                HELM_LAUNCH(k_nd_support_check, dim3(4096), dim3(256), 0, st, op->rhs_bits, c.Qt, c.nrhs, c.nrhs, N, d_bad);
                 int bad = 0;
                 hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st);
                 hipStreamSynchronize(st);
@@ -432,7 +432,7 @@ const unsigned char *nd_rhs_mask(helm_op *op, NdFactor *f) {
         if (!f->d_qmask) return nullptr;
         f->qmask_elems = (size_t)N;
     }
-    hipLaunchKernelGGL(k_nd_qmask, dim3((unsigned)std::min<long long>((N + 255) / 256, 4096)), dim3(256), 0, op->stream, (const int *)f->pd->d_cellnode, (const int *)f->d_act, f->act_nct, N, f->d_qmask);
+    HELM_LAUNCH(k_nd_qmask, dim3((unsigned)std::min<long long>((N + 255) / 256, 4096)), dim3(256), 0, op->stream, (const int *)f->pd->d_cellnode, (const int *)f->d_act, f->act_nct, N, f->d_qmask);
     return f->d_qmask;
 }
 

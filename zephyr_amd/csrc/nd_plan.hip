@@ -221,7 +221,7 @@ int nd_get_plan_dims(helm_op *op, int pnz, int pnx, int leaf, int dof, std::shar
         const int nmax = g.smax + g.mmax;
         for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
             const int nb = std::min(65535, g.cnt - j0);
-            hipLaunchKernelGGL(k_nd_build_tab, dim3((nmax + 255) / 256, nb), dim3(256), 0, op->stream, pd->d_nodes, g.first + j0, pd->d_tab, P.nz, P.nx);
+            HELM_LAUNCH(k_nd_build_tab, dim3((nmax + 255) / 256, nb), dim3(256), 0, op->stream, pd->d_nodes, g.first + j0, pd->d_tab, P.nz, P.nx);
         }
     }
     if (dof == 1) {                                      // which leaf eliminates a cell (the residual's q mask on sparse right-hand sides)
@@ -232,7 +232,7 @@ int nd_get_plan_dims(helm_op *op, int pnz, int pnx, int leaf, int dof, std::shar
                 const NdGroup &g = P.groups[gi];
                 if (!g.leaf) continue;
                 const long long rows = (long long)g.cnt * (g.smax + g.mmax);
-                hipLaunchKernelGGL(k_nd_cellnode, dim3((unsigned)std::min<long long>((rows + 255) / 256, 65535)), dim3(256), 0, op->stream,
+                HELM_LAUNCH(k_nd_cellnode, dim3((unsigned)std::min<long long>((rows + 255) / 256, 65535)), dim3(256), 0, op->stream,
                                    (const int4 *)(pd->d_tab + g.roff), rows, g.smax + g.mmax, g.first, pd->d_cellnode);
             }
         }

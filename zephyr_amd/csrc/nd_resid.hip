@@ -308,13 +308,13 @@ __global__ void k_axpy_one(cplx *y, const cplx *x, long long n, int conj) {
 void launch_transpose(hipStream_t st, const cplx *in, long long rows, long long cols, cplx *out, int swap, int conj) {
     // (the long dimension rides on gridDim.x: swap = 1 means `cols` is the long one's partner, see k_transpose)
     const dim3 grid = swap ? dim3((unsigned)((rows + 31) / 32), (unsigned)((cols + 31) / 32)) : dim3((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
-    hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, st, in, rows, cols, out, swap, conj);
+    HELM_LAUNCH(k_transpose, grid, dim3(256), 0, st, in, rows, cols, out, swap, conj);
 }
 
 int nd_prep_transpose_norm(helm_op *op, const cplx *rhs, long long rhs_ld, long long row_off, cplx premul, const cplx *sub, cplx *Qt, long long N, int nrhs,
                            double *part, int nblk_cap, int *nblk_out) {
     const int nblk = (int)std::max<long long>(1, std::min<long long>((N + 31) / 32, std::min(nblk_cap, 1024)));
-    hipLaunchKernelGGL(k_prep_transpose_norm, dim3(nblk, (nrhs + 31) / 32), dim3(256), 0, op->stream, rhs, rhs_ld, row_off, premul, sub, Qt, N, nrhs, part, nblk);
+    HELM_LAUNCH(k_prep_transpose_norm, dim3(nblk, (nrhs + 31) / 32), dim3(256), 0, op->stream, rhs, rhs_ld, row_off, premul, sub, Qt, N, nrhs, part, nblk);
     *nblk_out = nblk;
     return check_kernels(op, "right-hand-side transpose");
 }
@@ -346,12 +346,12 @@ int nd_resid_nm(helm_op *op, const cplx *planes, const cplx *Xin, int ldin, cplx
     for (int c0 = 0; c0 < ncol; c0 += 256) {          // more than 256 columns: one launch per 256 (partials of later chunks follow the first)
         const int nc = std::min(256, ncol - c0);
         if (ly == 1)        // full-width batches: four waves share a tile, its coefficients staged in LDS; the wavefield (read by nobody on the GPU) stored nontemporally
-            hipLaunchKernelGGL((k_resid_nm_lds<4, 1>), dim3(nblk), dim3(256, 1), 0, op->stream, planes, op->nz, op->nx, Xin + c0, ldin, Q + (qmap ? 0 : c0), ldq,
+            HELM_LAUNCH((k_resid_nm_lds<4, 1>), dim3(nblk), dim3(256, 1), 0, op->stream, planes, op->nz, op->nx, Xin + c0, ldin, Q + (qmap ? 0 : c0), ldq,
                                qmap ? qmap + c0 : nullptr, nc, store, Rout ? Rout + (qmap ? 0 : c0) : nullptr, part + (long long)c0 * 4 * nblk, nblk, ntiles,
                                qnorm, Uout ? Uout + c0 : nullptr, ldu, oscale, c0 == 0 ? qmask : nullptr, xin_is_u);
         else if (xin_is_u) HELM_FAIL(op, HELM_ERR_STATE, "node-major residual: direct output needs the full-width kernel");
         else
-            hipLaunchKernelGGL(k_resid_nm<4>, dim3(nblk), dim3(lx, ly), 0, op->stream, planes, op->nz, op->nx, Xin + c0, ldin, Q + (qmap ? 0 : c0), ldq,
+            HELM_LAUNCH(k_resid_nm<4>, dim3(nblk), dim3(lx, ly), 0, op->stream, planes, op->nz, op->nx, Xin + c0, ldin, Q + (qmap ? 0 : c0), ldq,
                                qmap ? qmap + c0 : nullptr, nc, store, Rout ? Rout + (qmap ? 0 : c0) : nullptr, part + (long long)c0 * 4 * nblk, nblk, seg, ntiles,
                                qnorm, Uout ? Uout + c0 : nullptr, ldu, oscale);
     }
@@ -371,17 +371,17 @@ int nd_resid_nm(helm_op *op, const cplx *planes, const cplx *Xin, int ldin, cplx
 int nd_recover_x(helm_op *op, const cplx *U, cplx *Xt, long long elems, cplx oscale) {
     const double d = oscale.x * oscale.x + oscale.y * oscale.y;
     const cplx inv = cmake(oscale.x / d, -oscale.y / d);
-    hipLaunchKernelGGL(k_recover_x, dim3((unsigned)std::min<long long>((elems + 255) / 256, 65535)), dim3(256), 0, op->stream, U, Xt, elems, inv);
+    HELM_LAUNCH(k_recover_x, dim3((unsigned)std::min<long long>((elems + 255) / 256, 65535)), dim3(256), 0, op->stream, U, Xt, elems, inv);
     return check_kernels(op, "recovering x from the wavefield array");
 }
 
 int nd_scatter_add_cols(helm_op *op, cplx *Xt, int ldq, const int *d_cols, int k, const cplx *Dp, long long N) {
-    hipLaunchKernelGGL(k_scatter_add_cols, dim3((unsigned)std::min<long long>((N * k + 255) / 256, 1 << 20)), dim3(256), 0, op->stream, Xt, ldq, d_cols, k, Dp, N);
+    HELM_LAUNCH(k_scatter_add_cols, dim3((unsigned)std::min<long long>((N * k + 255) / 256, 1 << 20)), dim3(256), 0, op->stream, Xt, ldq, d_cols, k, Dp, N);
     return check_kernels(op, "column scatter");
 }
 
 int nd_pack_cols(helm_op *op, const cplx *Qt, int ldq, const int *d_cols, int k, cplx *Rp, long long N) {
-    hipLaunchKernelGGL(k_pack_cols, dim3((unsigned)std::min<long long>((N * k + 255) / 256, 1 << 20)), dim3(256), 0, op->stream, Qt, ldq, d_cols, k, Rp, N);
+    HELM_LAUNCH(k_pack_cols, dim3((unsigned)std::min<long long>((N * k + 255) / 256, 1 << 20)), dim3(256), 0, op->stream, Qt, ldq, d_cols, k, Rp, N);
     return check_kernels(op, "column packing");
 }
 
@@ -389,18 +389,18 @@ int nd_pack_cols(helm_op *op, const cplx *Qt, int ldq, const int *d_cols, int k,
 int nd_transpose(helm_op *op, const cplx *in, long long rows, long long cols, cplx *out) {
     const bool swap = rows > cols;            // the long dimension rides on gridDim.x
     dim3 grid = swap ? dim3((unsigned)((rows + 31) / 32), (unsigned)((cols + 31) / 32)) : dim3((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
-    hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, op->stream, in, rows, cols, out, swap ? 1 : 0, 0);
+    HELM_LAUNCH(k_transpose, grid, dim3(256), 0, op->stream, in, rows, cols, out, swap ? 1 : 0, 0);
     return check_kernels(op, "transpose");
 }
 
 // Xt (cells x nrhs) -> U (nrhs x N), conjugated on request
 int nd_transpose_out(helm_op *op, const cplx *Xt, long long N, int nrhs, cplx *U, int conj) {
-    hipLaunchKernelGGL(k_transpose, dim3((unsigned)((N + 31) / 32), (nrhs + 31) / 32), dim3(256), 0, op->stream, Xt, N, (long long)nrhs, U, 1, conj);
+    HELM_LAUNCH(k_transpose, dim3((unsigned)((N + 31) / 32), (nrhs + 31) / 32), dim3(256), 0, op->stream, Xt, N, (long long)nrhs, U, 1, conj);
     return check_kernels(op, "transpose out");
 }
 
 int nd_axpy_one(helm_op *op, cplx *y, const cplx *x, long long n, int conj) {
-    hipLaunchKernelGGL(k_axpy_one, dim3((unsigned)std::min<long long>((n + 255) / 256, 65535)), dim3(256), 0, op->stream, y, x, n, conj);
+    HELM_LAUNCH(k_axpy_one, dim3((unsigned)std::min<long long>((n + 255) / 256, 65535)), dim3(256), 0, op->stream, y, x, n, conj);
     return HELM_OK;
 }
 
