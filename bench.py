@@ -584,14 +584,16 @@ def main():
 
     nsolvers = max(1, int(os.environ.get('HELM_BENCH_SOLVERS', '1')))       # solve threads of the device pipeline (each writes its own wavefield array)
     u_bufs = {}
+    import threading
+    u_lock = threading.Lock()
 
     def solve_item(w, op, ubuf=None):
         if ubuf is None and nsolvers > 1:
-            import threading
             key = threading.get_ident()
-            if key not in u_bufs:
-                u_bufs[key] = d_u if not u_bufs else torch.empty_like(d_u)
-            ubuf = u_bufs[key]
+            with u_lock:                 # (two solve threads must not both take d_u)
+                if key not in u_bufs:
+                    u_bufs[key] = d_u if not u_bufs else torch.empty_like(d_u)
+                ubuf = u_bufs[key]
         ubuf = d_u if ubuf is None else ubuf
         fi, bi = work_item(w, nb)
         tl.append(('solve starts', w, time.perf_counter()))
@@ -631,6 +633,12 @@ def main():
     nsteps = max(1, len(timed_items)) if args.scaling == 'strong' else args.steps
     run_items(warm_items, True)          # (events on, like the timed region: the per-process event pool comes into being here, not inside it)
 
+    # the interpreter's cyclic collector: everything alive now (torch, scipy, the model, the source matrices: ~10^6 objects) moves to the permanent generation,
+    # so that a full collection triggered inside a timed region walks the job's own few objects, not the process (50-100 ms with torch imported).  The
+    # collector stays ON; long-running dispatch loops do the same after their set-up (gc.freeze is the documented tool for it).
+    import gc
+    gc.collect()
+    gc.freeze()
     barrier()
     del stamps[:]
     del tl[:]

@@ -150,7 +150,8 @@ int helm_apply_device(helm_op *op, int block, int adjoint, const void *dX, void 
 /* --- solve ---------------------------------------------------------------------------- */
 /* U[r] = conj( A^-1 (premul * RHS[r]) ).  rows = N, or 2N for Eurus stacked right-hand sides
  * (eurus.py:512-533: N-row input is zero-padded and the result clipped to N rows; 2N-row input
- * returns 2N rows).  info: nrhs entries or NULL.  opts NULL = defaults. */
+ * returns 2N rows).  info: nrhs entries or NULL.  opts NULL = defaults.  RHS and U may be the same buffer (in place) or disjoint; they
+ * must not overlap partially. */
 int helm_solve(helm_op *op, const double *RHS, double *U, int nrhs, long long rows,
                double premul_re, double premul_im,
                const helm_solve_opts *opts, helm_solve_info *info);
@@ -285,8 +286,10 @@ int helm_debug_runtime_stats(int reset, helm_runtime_stats *out);
 /* --- tuning ------------------------------------------------------------------------------
  * The options of the library that are real options (round 5: the seventy-odd HELM_* environment switches of rounds 1-4 were the tuning
  * interface; the measured-and-rejected ones are gone, HISTORY.md has what they measured).  Every field can still be given through the
- * environment variable named beside it -- read when it is used, so a test may flip one between two calls -- and helm_set_tuning
- * replaces the lot for the process (NULL: back to defaults + environment).  Process-wide, like the reference's module-level defaults
+ * environment variable named beside it -- looked at when an API call that starts work is entered (create, assemble, prefactor, solve, apply,
+ * get_tuning), by the calling thread and nowhere below it, so a test may flip one BETWEEN two calls, never during one -- and helm_set_tuning
+ * replaces the lot for the process (NULL: back to defaults + environment).  Values are clamped to the ranges the code can run with whichever
+ * way they arrive (nd_leaf >= 2, nd_plans >= 1, nd_ws_gb > 0, nd_stable_safety >= 1, ws_slots 1..4, pf_prio -1/0/1, mg3_omega in (0, 2]).  Process-wide, like the reference's module-level defaults
  * (distributors.py:28-34); not per handle.  Diagnostics that change no result and no speed stay environment-only: HELM_ND_TRACE,
  * HELM_ND_DEBUG, HELM_GEMM_LOG, HELM_MG3_TRACE, HELM_ALLOC_TRACE, and the test hooks behind HELM_TESTING=1 (HELM_ND_POISON,
  * HELM_ND_SUPPORT_CHECK, HELM_LEAF_DBG, HELM_ND_INJECT_*). */

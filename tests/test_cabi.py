@@ -77,6 +77,13 @@ def test_tuning_struct_round_trip(helm_lib, monkeypatch):
     assert u.nd_leaf == 5 and u.nd_sparse_rhs == 0 and u.mg3_omega == 0.7
     _lib.set_tuning(None)
     assert _lib.tuning().nd_leaf == 7
+    # a C caller that zero-initialises the structure and sets one field gets the same limits the environment path applies
+    z = _lib.Tuning()
+    z.nd_sparse_rhs = 1
+    _lib.set_tuning(z)
+    u = _lib.tuning()
+    assert (u.nd_leaf, u.nd_plans, u.ws_slots, u.pf_prio) == (2, 1, 1, 0) and u.nd_ws_gb == 32.0 and u.nd_stable_safety == 1.0 and u.mg3_omega == 0.9
+    _lib.set_tuning(None)
 
 
 def test_code_object_is_gfx950():

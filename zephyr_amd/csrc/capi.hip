@@ -129,32 +129,42 @@ helm_tuning g_tune_user;
 int tune_i(const char *name, int d) { const char *v = getenv(name); return v ? atoi(v) : d; }
 double tune_d(const char *name, double d) { const char *v = getenv(name); return v ? atof(v) : d; }
 }
-helm_tuning helm_tuning_now() {
-    {
-        std::lock_guard<std::mutex> lk(g_tune_mu);
-        if (g_tune_set) return g_tune_user;
-    }
+// the limits every source of the options goes through (environment, helm_set_tuning): values outside them would switch a path off by accident
+// (nd_plans = 0, nd_ws_gb = 0: batch forced to 1) rather than by intent
+static void tuning_clamp(helm_tuning &t) {
+    t.nd_leaf = std::max(2, t.nd_leaf);
+    if (!(t.nd_ws_gb > 0)) t.nd_ws_gb = 32.0;
+    t.nd_stable_safety = std::max(1.0, t.nd_stable_safety);
+    if (!(t.nd_stable_thr >= 0)) t.nd_stable_thr = 0.0;
+    t.nd_fused_leaf_min = std::max(1, t.nd_fused_leaf_min);
+    t.nd_gjstep_min = std::max(64, t.nd_gjstep_min);
+    t.nd_plans = std::max(1, t.nd_plans);
+    t.ws_slots = std::min(4, std::max(1, t.ws_slots));
+    t.pf_prio = t.pf_prio > 0 ? 1 : (t.pf_prio < 0 ? -1 : 0);
+    if (!(t.mg3_omega > 0) || t.mg3_omega > 2.0) t.mg3_omega = 0.9;
+}
+static helm_tuning tuning_from_env() {
     helm_tuning t;
-    t.nd_leaf = std::max(2, tune_i("HELM_ND_LEAF", 8));
+    t.nd_leaf = tune_i("HELM_ND_LEAF", 8);
     t.nd_ws_gb = tune_d("HELM_ND_WS_GB", 32.0);
     t.nd_sparse_rhs = tune_i("HELM_ND_SPARSE_RHS", 1);
     t.nd_stable = tune_i("HELM_ND_STABLE", 1);
     t.nd_stable_thr = tune_d("HELM_ND_STABLE_THR", 0.0);
-    t.nd_stable_safety = std::max(1.0, tune_d("HELM_ND_STABLE_SAFETY", 8.0));
+    t.nd_stable_safety = tune_d("HELM_ND_STABLE_SAFETY", 8.0);
     t.nd_fused_leaf = tune_i("HELM_ND_FUSEDLEAF", 1);
     t.nd_fused_leaf_min = tune_i("HELM_ND_FUSEDLEAF_MIN", 2048);
     t.nd_gjstep = tune_i("HELM_ND_GJSTEP", 1);
     t.nd_gjstep_min = tune_i("HELM_ND_GJSTEP_MIN", 128);
     t.nd_overlap = tune_i("HELM_ND_OVERLAP_NM", 1);
     t.nd_xcd_map = tune_i("HELM_ND_XCDMAP", 2);
-    t.nd_plans = std::max(1, tune_i("HELM_ND_PLANS", 6));
+    t.nd_plans = tune_i("HELM_ND_PLANS", 6);
     t.nd_direct_out = tune_i("HELM_ND_DIRECT_OUT", 1);
     t.nd_leaf_idle = tune_i("HELM_ND_LEAF_IDLE", 1);
     t.auto_direct = tune_i("HELM_AUTO_DIRECT", 1);
     t.auto_mg3 = tune_i("HELM_AUTO_MG3", 1);
     t.prof_ext = tune_i("HELM_PROF_EXT", 1);
     t.ws_slots = tune_i("HELM_WS_SLOTS", 3);
-    { const int p = tune_i("HELM_PF_PRIO", 1); t.pf_prio = p > 0 ? 1 : (p < 0 ? -1 : 0); }
+    t.pf_prio = tune_i("HELM_PF_PRIO", 1);
     t.mg3_keep = tune_i("HELM_MG3_KEEP", 1);
     t.mg3_keep_levels = tune_i("HELM_MG3_KEEP_LEVELS", -1);
     t.mg3_galerkin = tune_i("HELM_MG3_GALERKIN", 1);
@@ -162,12 +172,41 @@ helm_tuning helm_tuning_now() {
     t.mg3_bt_f32 = tune_i("HELM_MG3_BT_F32", 1);
     t.mg3_otf = tune_i("HELM_MG3_OTF", 1);
     t.mg3_omega = tune_d("HELM_MG3_OMEGA", 0.9);
+    tuning_clamp(t);
     return t;
 }
-extern "C" int helm_get_tuning(helm_tuning *out) { if (!out) return HELM_ERR_ARG; *out = helm_tuning_now(); return HELM_OK; }
+// The options in force.  helm_set_tuning's structure wins; otherwise defaults + environment, re-read when the HELM_* entries of the environment have changed
+// (a test may flip a variable between two calls): the passes ask once per tree level from worker threads, and 27 getenv calls each time raced against exactly
+// that setenv.  The environment is compared by a fingerprint of its HELM_* entries, at API entry only (helm_tuning_refresh).
+extern char **environ;
+static unsigned long long env_fingerprint() {
+    unsigned long long h = 1469598103934665603ull;
+    for (char **e = environ; e && *e; ++e) {
+        const char *s = *e;
+        if (s[0] != 'H' || s[1] != 'E' || s[2] != 'L' || s[3] != 'M' || s[4] != '_') continue;
+        for (; *s; ++s) { h ^= (unsigned char)*s; h *= 1099511628211ull; }
+        h ^= 0xff; h *= 1099511628211ull;
+    }
+    return h;
+}
+static bool g_tune_have = false; static unsigned long long g_tune_fp = 0; static helm_tuning g_tune_cached;
+// called at the entry of the API calls that start work (create, assemble, prefactor, solve, apply, get_tuning): the environment is looked at THERE, by the
+// calling thread, and nowhere below -- a caller that changes a HELM_* variable does so between two calls, as the header says
+void helm_tuning_refresh() {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    const unsigned long long now = env_fingerprint();
+    if (!g_tune_have || now != g_tune_fp) { g_tune_cached = tuning_from_env(); g_tune_fp = now; g_tune_have = true; }
+}
+helm_tuning helm_tuning_now() {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    if (g_tune_set) return g_tune_user;
+    if (!g_tune_have) { g_tune_cached = tuning_from_env(); g_tune_fp = env_fingerprint(); g_tune_have = true; }
+    return g_tune_cached;
+}
+extern "C" int helm_get_tuning(helm_tuning *out) { if (!out) return HELM_ERR_ARG; helm_tuning_refresh(); *out = helm_tuning_now(); return HELM_OK; }
 extern "C" int helm_set_tuning(const helm_tuning *t) {
     std::lock_guard<std::mutex> lk(g_tune_mu);
-    if (t) { g_tune_user = *t; g_tune_set = true; } else g_tune_set = false;
+    if (t) { g_tune_user = *t; tuning_clamp(g_tune_user); g_tune_set = true; } else g_tune_set = false;
     return HELM_OK;
 }
 
@@ -335,12 +374,14 @@ size_t helm_pool_idle_bytes(int device) {
     auto it = g_pool.held.find(device);
     return it == g_pool.held.end() ? 0 : it->second;
 }
+static void pool_forget(void *p);       // (g_pool.mu held) the buffer has gone back to the driver
 // give this device's idle buffers back to the driver (the current device must be `device`)
 static void pool_flush_device(int device) {
     std::lock_guard<std::mutex> lk(g_pool.mu);
     AllocTrace trf("pool flush", g_pool.held[device]);
     for (auto it = g_pool.idle.lower_bound(std::make_pair(device, (size_t)0)); it != g_pool.idle.end() && it->first.first == device; ) {
         hipFree(it->second);
+        pool_forget(it->second);
         it = g_pool.idle.erase(it);
     }
     g_pool.held[device] = 0;
@@ -356,27 +397,51 @@ hipError_t helm_malloc_retry(int device, void **p, size_t bytes) {
     if (e != hipSuccess) { (void)hipGetLastError(); *p = nullptr; }
     return e;
 }
+// r6: a request is served by the smallest idle buffer of the device whose capacity is at least the request and at most twice it (+ 1 MB; from 64 MB up: at most
+// one size class more, so that the GB-sized factor and wavefield buffers do not take each other's places): the pool used to be
+// keyed by the exact size, and sizes that follow the operator -- how many ill-conditioned fronts a frequency has, how many right-hand sides take a
+// refinement pass -- missed it at every new frequency: 12 hipMalloc calls inside the timed region of the bench job after a five-item warm-up.  New buffers are
+// allocated in size classes (steps of 1/8 of the power of two below, at least 4 KB), and the pool remembers every buffer's capacity, so a buffer
+// goes back under what it can hold, not under what it was asked for.
+static std::map<void *, size_t> g_pool_capacity;        // every live buffer that came out of helm_pool_alloc: what it can hold (guarded by g_pool.mu)
+static void pool_forget(void *p) { g_pool_capacity.erase(p); }
+static size_t pool_size_class(size_t bytes) {
+    if (bytes <= 4096) return 4096;
+    int top = 63 - __builtin_clzll((unsigned long long)(bytes - 1));      // bytes - 1 in [2^top, 2^(top+1))
+    const int sh = top - 3;
+    return (((bytes - 1) >> sh) + 1) << sh;
+}
 void *helm_pool_alloc(int device, size_t bytes) {
+    if (bytes == 0) bytes = 1;
     {
         std::lock_guard<std::mutex> lk(g_pool.mu);
-        auto it = g_pool.idle.find(std::make_pair(device, bytes));
-        if (it != g_pool.idle.end()) { void *p = it->second; g_pool.idle.erase(it); g_pool.held[device] -= bytes; return p; }
+        auto it = g_pool.idle.lower_bound(std::make_pair(device, bytes));
+        if (it != g_pool.idle.end() && it->first.first == device && it->first.second <= (bytes < ((size_t)64 << 20) ? 2 * bytes + ((size_t)1 << 20) : bytes + bytes / 8)) {
+            void *p = it->second; g_pool.held[device] -= it->first.second; g_pool.idle.erase(it); return p;
+        }
     }
     void *p = nullptr;
-    AllocTrace tr("pool hipMalloc", bytes);
-    if (helm_malloc_retry(device, &p, bytes) != hipSuccess) return nullptr;
+    const size_t cap = pool_size_class(bytes);
+    AllocTrace tr("pool hipMalloc", cap);
+    if (helm_malloc_retry(device, &p, cap) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    g_pool_capacity[p] = cap;
     return p;
 }
 void helm_pool_free(int device, void *p, size_t bytes) {
     if (!p) return;
     {
         std::lock_guard<std::mutex> lk(g_pool.mu);
+        auto ic = g_pool_capacity.find(p);
+        if (ic != g_pool_capacity.end()) bytes = ic->second;            // (a buffer that did not come from the pool is taken in under the size the caller states)
+        else g_pool_capacity[p] = bytes;
         const size_t cap = pool_cap_bytes(device);
         size_t &held = g_pool.held[device];
         if (bytes >= kPoolMinBytes && (held + bytes <= cap || bytes < ((size_t)1 << 20))) {
             g_pool.idle.insert(std::make_pair(std::make_pair(device, bytes), p)); held += bytes;
             return;
         }
+        g_pool_capacity.erase(p);
     }
     AllocTrace tr("pool hipFree", bytes);
     hipFree(p);
@@ -389,6 +454,7 @@ static int pf_prio() { return helm_tuning_now().pf_prio; }
 static helm_op *create_common(helm_op *op);
 
 extern "C" helm_op *helm_create3d(int device, int nz, int ny, int nx, double dx, double dy, double dz, int nPML) {
+    helm_tuning_refresh();
     if (nz < 3 || ny < 3 || nx < 3) { helm_set_error(nullptr, "nz, ny and nx must be >= 3"); return nullptr; }
     if (!(dx > 0) || !(dy > 0) || !(dz > 0)) { helm_set_error(nullptr, "grid spacings must be positive"); return nullptr; }
     helm_op *op = new helm_op();
@@ -399,6 +465,7 @@ extern "C" helm_op *helm_create3d(int device, int nz, int ny, int nx, double dx,
 }
 
 extern "C" helm_op *helm_create(int device, int variant, int nz, int nx, double dx, double dz, int nPML, const int *freeSurf) {
+    helm_tuning_refresh();
     if (nz < 3 || nx < 3) { helm_set_error(nullptr, "nz and nx must be >= 3"); return nullptr; }
     if (variant != HELM_MINIZEPHYR && variant != HELM_EURUS) { helm_set_error(nullptr, "unknown variant"); return nullptr; }
     if (!(dx > 0) || !(dz > 0)) { helm_set_error(nullptr, "dx and dz must be positive"); return nullptr; }
@@ -488,7 +555,7 @@ extern "C" int helm_trim(void) {
                 w.ptr = nullptr; w.bytes = 0;
             }
         std::lock_guard<std::mutex> lp(g_pool.mu);
-        for (auto &kv : g_pool.idle) { hipSetDevice(kv.first.first); hipFree(kv.second); }
+        for (auto &kv : g_pool.idle) { hipSetDevice(kv.first.first); hipFree(kv.second); pool_forget(kv.second); }
         g_pool.idle.clear(); g_pool.held.clear();
     }
     (void)hipSetDevice(cur);
@@ -600,6 +667,7 @@ int helm_ensure_host_model(helm_op *op) {
 }
 
 extern "C" int helm_assemble(helm_op *op, double freq_re, double freq_im, double tau, double ky, double cPML) {
+    helm_tuning_refresh();
     if (!op) return HELM_ERR_ARG;
     if (!op->has_model) HELM_FAIL(op, HELM_ERR_STATE, "helm_set_model must be called before helm_assemble");
     HIP_TRY(op, hipSetDevice(op->device));
@@ -724,6 +792,7 @@ static void timing_collect(helm_op *op) {
 
 // ---- apply -----------------------------------------------------------------------------------
 extern "C" int helm_apply_device(helm_op *op, int block, int adjoint, const void *dX, void *dY, int nrhs) {
+    helm_tuning_refresh();
     if (!op || !dX || !dY || nrhs < 1 || block < 0 || block >= op->nblocks) return HELM_ERR_ARG;
     if (!op->assembled) HELM_FAIL(op, HELM_ERR_STATE, "operator not assembled");
     HIP_TRY(op, hipSetDevice(op->device));
@@ -1194,7 +1263,9 @@ int solve_block_direct(helm_op *op, int block, const cplx *dRHS, long long rhs_l
         // direct output (helm_tuning.nd_direct_out; full-width batches, whose residual kernel can read the caller's array): the back substitution writes
         // u = conj(premul x) into dUconj itself and the residual launch below stores nothing -- x_in_u until a refinement pass needs x back in Xt
         NdDirectOut dout;
-        bool x_in_u = native_nm && n > 128 && helm_tuning_now().nd_direct_out != 0;
+        // (not when the caller solves in place, dU == dRHS: the back substitution would overwrite q before the residual launch has read it -- that call takes the
+        // path of the narrow batches, where the residual launch reads q[cell] and writes u[cell] in the same thread)
+        bool x_in_u = native_nm && n > 128 && helm_tuning_now().nd_direct_out != 0 && (const void *)Qt != (const void *)dUconj;
         if (x_in_u) { dout.U = dUconj; dout.oscale = premul; }
         if (factor_pending) {
             float fms = 0.f;
@@ -1796,6 +1867,7 @@ extern "C" int helm_set_tolerance_hint(helm_op *op, double rtol) {
 }
 
 extern "C" int helm_prefactor_n(helm_op *op, int nrhs) {
+    helm_tuning_refresh();
     if (!op) return HELM_ERR_ARG;
     if (!op->assembled) HELM_FAIL(op, HELM_ERR_STATE, "operator not assembled");
     if (op->ny > 0) return prefactor3d(op, nrhs);
@@ -1803,6 +1875,7 @@ extern "C" int helm_prefactor_n(helm_op *op, int nrhs) {
 }
 
 extern "C" int helm_prefactor(helm_op *op) {
+    helm_tuning_refresh();
     if (!op) return HELM_ERR_ARG;
     if (!op->assembled) HELM_FAIL(op, HELM_ERR_STATE, "operator not assembled");
     // a hint: only the single-block 2-D systems the direct path of HELM_AUTO / HELM_DIRECT factors once per frequency
@@ -1845,6 +1918,7 @@ extern "C" int helm_prefactor(helm_op *op) {
 // kernels and copies in flight was measured at 0.7-1.5 s (HELM_ALLOC_TRACE=1), so a dispatcher that knows how many workers it is
 // about to start on a GPU asks once, before they run.  A hint: errors other than bad arguments are swallowed.
 extern "C" int helm_reserve(helm_op *op, int nrhs, long long rows, int concurrent) {
+    helm_tuning_refresh();
     if (!op || nrhs < 1 || rows < 1 || concurrent < 1) return HELM_ERR_ARG;
     if (hipSetDevice(op->device) != hipSuccess) { (void)hipGetLastError(); return HELM_OK; }
     if (concurrent > 64) concurrent = 64;
@@ -1892,6 +1966,7 @@ extern "C" int helm_reserve(helm_op *op, int nrhs, long long rows, int concurren
 
 extern "C" int helm_solve_device(helm_op *op, const void *dRHS, void *dU, int nrhs, long long rows,
                                  double premul_re, double premul_im, const helm_solve_opts *opts, helm_solve_info *info) {
+    helm_tuning_refresh();
     if (!op) return HELM_ERR_ARG;
     // a declared support (helm_set_rhs_support) belongs to THIS call's right-hand sides and to no later one -- whichever way the call ends, the
     // early returns below included (the bits usually live in a buffer the caller recycles as soon as this returns)
@@ -2026,6 +2101,7 @@ extern "C" int helm_solve_device(helm_op *op, const void *dRHS, void *dU, int nr
 
 extern "C" int helm_solve(helm_op *op, const double *RHS, double *U, int nrhs, long long rows,
                           double premul_re, double premul_im, const helm_solve_opts *opts, helm_solve_info *info) {
+    helm_tuning_refresh();
     if (!op || !RHS || !U || nrhs < 1) return HELM_ERR_ARG;
     HIP_TRY(op, hipSetDevice(op->device));
     const size_t bytes = (size_t)nrhs * rows * sizeof(cplx);
@@ -2104,6 +2180,7 @@ extern "C" void helm_host_free(void *p, size_t bytes) { helm_hostpool_free(p, by
 // makes that copy run at the PCIe rate).  Layout of U and of the implied dense right-hand sides per opts->flags.
 extern "C" int helm_solve_coo(helm_op *op, const long long *row, const int *col, const double *val, long long nnz, double *U, int nrhs, long long rows,
                               double premul_re, double premul_im, const helm_solve_opts *opts, helm_solve_info *info) {
+    helm_tuning_refresh();
     if (!op || !U || nrhs < 1 || rows < 1 || nnz < 0 || (nnz > 0 && (!row || !col || !val))) return HELM_ERR_ARG;
     HIP_TRY(op, hipSetDevice(op->device));
     const size_t bytes = (size_t)nrhs * rows * sizeof(cplx);

@@ -73,6 +73,7 @@ struct NdFactor {
     unsigned char *d_qmask = nullptr; size_t qmask_elems = 0;  // per grid cell: bit b set when the right-hand sides may be nonzero there in block b of 64 columns
     int *d_act = nullptr; size_t act_elems = 0;              // forward pass on sparse right-hand sides: per front and block of 64 columns, were its outgoing rows computed?
     int *d_leafflag = nullptr; size_t leafflag_elems = 0;     // per leaf of a group: 1 when the fused leaf kernel met a small pivot (the leaf is then re-done with pivoting)
+    struct FlagSlot *flag_slot = nullptr; double flag_thr = 0; // pinned buffer + event the list of a group's ill-conditioned fronts is travelling through (flag_group -> stabilise_group), and the threshold it was made with
 };
 
 // local index of unknown (cell (z, x), component comp) in the front: [0, s) separator, [s, s+m) ring; -1 when the cell

@@ -222,6 +222,7 @@ hipError_t helm_counted_stream_create(hipStream_t *s, unsigned flags, int prio, 
 #define hipStreamCreateWithFlags(S, F) helm_counted_stream_create((S), (F), 0, false)
 #define hipStreamCreateWithPriority(S, F, PR) helm_counted_stream_create((S), (F), (PR), true)
 helm_tuning helm_tuning_now();                            // the options in force (helm_set_tuning, else defaults + environment; include/helm.h)
+void helm_tuning_refresh();                               // look at the environment again (API entry points call this; nothing below them does)
 
 // Size-keyed cache of large device buffers (coefficient planes, factors, per-call temporaries): a job walks through many
 // operators of identical shape, and hipMalloc/hipFree of GB-sized buffers cost milliseconds each.  helm_trim() empties it.

@@ -24,6 +24,7 @@
 // All dense arithmetic is fp64 complex on the matrix cores (v_mfma_f64_16x16x4_f64, nd_gemm_body.hpp).
 #include "nd_internal.hpp"
 #include <map>
+#include <mutex>
 #include <cstring>
 
 // ---- kernels ---------------------------------------------------------------------------------------------------
@@ -428,9 +429,32 @@ static void stable_free(NdFactor *f) {
     f->stable.clear();
 }
 
+// r6: the slots live in a process-wide free list per device (they used to be thread_local: every fresh prepare thread of the dispatcher paid a hipHostMalloc
+// on its first factorisation's critical path and never gave the page or the event back); a factorisation holds one between flag_group and stabilise_group.
+struct FlagSlot { int *host = nullptr; hipEvent_t ev = nullptr; int device = 0; };
+namespace { std::mutex g_flag_mu; std::map<int, std::vector<FlagSlot *>> g_flag_idle; }
+FlagSlot *flag_slot_acquire(int device) {
+    {
+        std::lock_guard<std::mutex> lk(g_flag_mu);
+        std::vector<FlagSlot *> &idle = g_flag_idle[device];
+        if (!idle.empty()) { FlagSlot *s = idle.back(); idle.pop_back(); return s; }
+    }
+    FlagSlot *s = new FlagSlot(); s->device = device;
+    s->host = (int *)helm_hostpool_alloc((ND_STABLE_CAP + 1) * sizeof(int));
+    if (!s->host) { delete s; return nullptr; }
+    if (hipEventCreateWithFlags(&s->ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); helm_hostpool_free(s->host, (ND_STABLE_CAP + 1) * sizeof(int)); delete s; return nullptr; }
+    return s;
+}
+void flag_slot_release(FlagSlot *s) {
+    if (!s) return;
+    std::lock_guard<std::mutex> lk(g_flag_mu);
+    g_flag_idle[s->device].push_back(s);
+}
+
 void nd_free(NdFactor *f) {
     if (!f) return;
     stable_free(f);
+    if (f->flag_slot) { (void)hipEventSynchronize(f->flag_slot->ev); flag_slot_release(f->flag_slot); f->flag_slot = nullptr; }
     if (f->d_est) helm_pool_free(f->pd ? f->pd->device : 0, f->d_est, f->est_elems * sizeof(double));
     if (f->d_leafflag) helm_pool_free(f->pd ? f->pd->device : 0, f->d_leafflag, f->leafflag_elems * sizeof(int));
     if (f->d_act) helm_pool_free(f->pd ? f->pd->device : 0, f->d_act, f->act_elems * sizeof(int));
@@ -487,17 +511,6 @@ int ensure_est(helm_op *op, NdFactor *f, int stable_smax) {
 // EVENT only -- the list is on the host while the products still run, and with nothing flagged (the usual case) the next group is enqueued without the
 // stream ever running dry.  (Rounds 3-4: hipStreamSynchronize after the products, once per watched group -- the factorisation stream idled for a host
 // round trip 11 times per operator, and in the pipelined job the factorisation span is what a step waits for.)
-struct FlagSlot { int *host = nullptr; hipEvent_t ev = nullptr; };
-FlagSlot *flag_slot(int device) {
-    thread_local std::map<int, FlagSlot> slots;
-    FlagSlot &s = slots[device];
-    if (!s.host) {
-        if (hipHostMalloc((void **)&s.host, (ND_STABLE_CAP + 1) * sizeof(int), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); s.host = nullptr; return nullptr; }
-        if (hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); hipHostFree(s.host); s.host = nullptr; return nullptr; }
-    }
-    return &s;
-}
-
 // after the inversion of group gi: flag its ill-conditioned fronts and start the list on its way to the host
 int flag_group(helm_op *op, NdFactor *f, size_t gi) {
     const NdPlan &P = f->pd->plan;
@@ -513,8 +526,10 @@ int flag_group(helm_op *op, NdFactor *f, size_t gi) {
     const double safety = tune.nd_stable_safety;
     const double rt = op->rtol_hint > 0 ? op->rtol_hint : 1e-10;
     const double thr = tune.nd_stable_thr > 0 ? tune.nd_stable_thr : std::min(1e9, std::max(2e3, rt / (safety * 1.1102230246251565e-16)));
-    FlagSlot *slot = flag_slot(op->device);
+    if (!f->flag_slot) f->flag_slot = flag_slot_acquire(op->device);
+    FlagSlot *slot = f->flag_slot;
     if (!slot) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: no pinned buffer for the list of ill-conditioned fronts");
+    f->flag_thr = thr;
     int *d_list = (int *)(f->d_est + 2 * (size_t)g.cnt);
     HIP_TRY(op, hipMemsetAsync(d_list, 0, sizeof(int), st));
     HELM_LAUNCH(k_front_flag, dim3((g.cnt + 255) / 256), dim3(256), 0, st, (const double *)f->d_est, (const double *)(f->d_est + g.cnt), g.cnt, 1.0, thr, d_list, ND_STABLE_CAP);
@@ -529,26 +544,33 @@ int stabilise_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *wor
     const NdGroup &g = P.groups[gi];
     hipStream_t st = op->stream;
     const int nmax = g.smax + g.mmax;
-    FlagSlot *slot = flag_slot(op->device);
-    if (!slot) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: no pinned buffer for the list of ill-conditioned fronts");
-    HIP_TRY(op, hipEventSynchronize(slot->ev));
+    FlagSlot *slot = f->flag_slot;
+    if (!slot) HELM_FAIL(op, HELM_ERR_STATE, "direct solver: stabilise_group without flag_group");
     int h_list[ND_STABLE_CAP + 1];
-    memcpy(h_list, slot->host, sizeof(h_list));
+    {
+        const hipError_t es = hipEventSynchronize(slot->ev);
+        memcpy(h_list, slot->host, sizeof(h_list));
+        f->flag_slot = nullptr; flag_slot_release(slot);        // (the list is on the host: the slot goes back before anything below can fail)
+        if (es != hipSuccess) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: waiting for the list of ill-conditioned fronts failed: %s", hipGetErrorString(es));
+    }
     const int nflag = std::max(0, std::min(h_list[0], ND_STABLE_CAP));
     if (h_list[0] > ND_STABLE_CAP) {
         // more flagged fronts than are treated per group: which of them made it into the list is up to the order the atomics ran in, and the factors would
-        // differ from one factorisation of the same operator to the next.  Take the worst ND_STABLE_CAP by estimate instead (ties: lower position).
-        std::vector<double> est((size_t)g.cnt);
+        // differ from one factorisation of the same operator to the next.  Take the worst ND_STABLE_CAP of the FLAGGED fronts by the estimate the flag was
+        // made from, a[j] * b[j] = ||F11|| ||F11^-1|| (ties: lower position).
+        std::vector<double> est(2 * (size_t)g.cnt);
         HIP_TRY(op, hipStreamSynchronize(st));
-        HIP_TRY(op, hipMemcpy(est.data(), f->d_est + g.cnt, est.size() * sizeof(double), hipMemcpyDeviceToHost));
-        std::vector<int> order((size_t)g.cnt);
-        for (int j = 0; j < g.cnt; ++j) order[j] = j;
-        auto worse = [&](int a, int b) {
-            const double ea = est[a] == est[a] ? est[a] : HUGE_VAL, eb = est[b] == est[b] ? est[b] : HUGE_VAL;      // (NaN: worst)
-            return ea != eb ? ea > eb : a < b;
-        };
-        std::partial_sort(order.begin(), order.begin() + nflag, order.end(), worse);
-        for (int q = 0; q < nflag; ++q) h_list[1 + q] = order[q];
+        HIP_TRY(op, hipMemcpy(est.data(), f->d_est, est.size() * sizeof(double), hipMemcpyDeviceToHost));
+        const double thr = f->flag_thr;
+        std::vector<std::pair<double, int>> cand;
+        for (int j = 0; j < g.cnt; ++j) {
+            const double e = est[j] * est[(size_t)g.cnt + j];
+            if (!(e <= thr)) cand.push_back(std::make_pair(e == e ? e : HUGE_VAL, j));                          // (the kernel's own test; NaN: worst)
+        }
+        auto worse = [](const std::pair<double, int> &a, const std::pair<double, int> &b) { return a.first != b.first ? a.first > b.first : a.second < b.second; };
+        const int take = std::min<int>(nflag, (int)cand.size());
+        std::partial_sort(cand.begin(), cand.begin() + take, cand.end(), worse);
+        for (int q = 0; q < take; ++q) h_list[1 + q] = cand[q].second;
     }
     std::sort(h_list + 1, h_list + 1 + nflag);                                   // (the atomics hand the slots out in no particular order)
     if (getenv("HELM_ND_DEBUG") && atoi(getenv("HELM_ND_DEBUG")) >= 2) {

@@ -467,6 +467,7 @@ int nd_dense_gemm_batched(helm_op *op, int M, int Nn, int K, cplx alpha, const c
     return check_kernels(op, "dense GEMM");
 }
 extern "C" int helm_debug_zgemm(int device, int M, int Nn, int K, const double *alpha, const double *A, const double *B, const double *beta, double *C, int batch) {
+    helm_tuning_refresh();
     if (hipSetDevice(device) != hipSuccess) return HELM_ERR_DEVICE;
     cplx *dA, *dB, *dC;
     const size_t na = (size_t)batch * M * K, nb = (size_t)batch * K * Nn, nc = (size_t)batch * M * Nn;
@@ -486,6 +487,7 @@ extern "C" int helm_debug_zgemm(int device, int M, int Nn, int K, const double *
 // times `reps` launches of one strided-batched GEMM shape on random operands; variant < 16: the tile gemm() would choose, 16 (t + 1) + anything: tile
 // configuration t forced (choose_tile); returns the average milliseconds per launch in *ms
 extern "C" int helm_debug_zgemm_bench(int device, int M, int Nn, int K, int batch, int variant, int reps, double *ms_out) {
+    helm_tuning_refresh();
     if (hipSetDevice(device) != hipSuccess) return HELM_ERR_DEVICE;
     cplx *dA, *dB, *dC;
     const size_t na = (size_t)batch * M * K, nb = (size_t)batch * K * Nn, nc = (size_t)batch * M * Nn;

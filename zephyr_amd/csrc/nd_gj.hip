@@ -777,6 +777,7 @@ int nd_dense_inverse(helm_op *op, cplx *M, int n, cplx *W) {
 }
 
 extern "C" int helm_debug_inverse(int device, int n, double *A, int batch) {
+    helm_tuning_refresh();
     if (hipSetDevice(device) != hipSuccess) return HELM_ERR_DEVICE;
     cplx *dA, *dW;
     const size_t na = (size_t)batch * n * n;
@@ -792,6 +793,7 @@ extern "C" int helm_debug_inverse(int device, int n, double *A, int batch) {
 // times `reps` in-place inversions of one n x n matrix (the caller's A, uploaded once; an inverse of an inverse is as good a test
 // matrix as the original) with the 2 x 2 block recursion applied from `recurse_n` unknowns up (0: the default policy)
 extern "C" int helm_debug_inverse_bench(int device, int n, const double *A, int reps, int recurse_n, double *ms_out) {
+    helm_tuning_refresh();
     if (hipSetDevice(device) != hipSuccess) return HELM_ERR_DEVICE;
     cplx *dA, *dW;
     const size_t na = (size_t)n * n;

@@ -260,6 +260,7 @@ extern "C" int helm_debug_plan_cache(int device) {
 
 // ---- diagnostics exported through the C ABI (host side of the plan; dense kernels on small inputs) ---------------------
 extern "C" int helm_direct_plan(int nz, int nx, int leaf, int *out, int cap) {
+    helm_tuning_refresh();
     NdPlan P;
     nd_build_plan(P, nz, nx, leaf);
     const int nn = (int)P.nodes.size();
@@ -276,6 +277,7 @@ extern "C" int helm_direct_plan(int nz, int nx, int leaf, int *out, int cap) {
 // cells (z * nx + x) of the front of node `node` in local order; returns s + m, or a negative value when the
 // inverse map nd_local disagrees with nd_cell (self-check of the closed-form index maps)
 extern "C" int helm_direct_plan_front(int nz, int nx, int leaf, int node, long long *cells, int cap) {
+    helm_tuning_refresh();
     NdPlan P;
     nd_build_plan(P, nz, nx, leaf);
     if (node < 0 || node >= (int)P.nodes.size()) return HELM_ERR_ARG;

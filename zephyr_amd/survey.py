@@ -139,14 +139,15 @@ class HelmBaseSurvey(BaseSCCache):
         """back-sources qb[f][:, s] = R_s^T resid[:, s, f] (survey.py:171-188).  With a fixed receiver array every source shares one R, and the nsrc
         sparse products per frequency of the reference collapse into one, R^T (resid[:, :, f]) -- the same columns, built in one call."""
         if self.mode == 'fixed':
-            # R^T is N x nrec with a patch of cells per receiver: only the rows some receiver touches are nonzero.  One dense product on those rows
-            # per frequency, handed back as a CSR matrix built from its arrays (sorted rows, every column present): no sparse-sparse product, no sort.
+            # R^T is N x nrec with a patch of cells per receiver: only the rows some receiver touches are nonzero.  One sparse x dense product on those
+            # rows per frequency (R^T restricted to them stays CSR: ~81 entries per receiver whatever nrec is -- densified it would be O(nrec^2)),
+            # handed back as a CSR matrix built from its arrays (sorted rows, every column present): no sparse-sparse product, no sort.
             cache = self.__dict__.setdefault('_vecCache', {})
             if 'RtRows' not in cache:
                 Rt = sp.csr_matrix(self.rVec(0).T)
                 Rt.sum_duplicates()
                 rows = np.flatnonzero(np.diff(Rt.indptr))
-                cache['RtRows'] = (rows, Rt[rows, :].toarray(), Rt.shape[0])
+                cache['RtRows'] = (rows, sp.csr_matrix(Rt[rows, :]), Rt.shape[0])
             rows, Rsub, N = cache['RtRows']
             ns = resid.shape[1]
             indptr = np.zeros(N + 1, dtype=np.int64)
@@ -155,7 +156,7 @@ class HelmBaseSurvey(BaseSCCache):
             indices = np.tile(np.arange(ns, dtype=np.int32), rows.size)
             out = []
             for ifreq in range(self.nfreq):
-                block = Rsub @ np.ascontiguousarray(resid[:, :, ifreq])                  # (rows, nsrc) dense
+                block = np.asarray(Rsub @ np.ascontiguousarray(resid[:, :, ifreq]))      # sparse (rows, nrec) x dense (nrec, nsrc) -> dense (rows, nsrc)
                 m = sp.csr_matrix((block.ravel(), indices, indptr), shape=(N, ns))
                 m.has_sorted_indices = True
                 out.append(m)
