@@ -643,6 +643,8 @@ def main():
     del stamps[:]
     del tl[:]
     from zephyr_amd import _lib as _zl0
+    if os.environ.get('HELM_ALLOC_TRACE'):
+        sys.stderr.write('[bench] timed region starts\n'); sys.stderr.flush()
     _zl0.runtime_stats(reset=True)       # what the timed region makes the HIP runtime create (allocations, events, first launches) is counted from here
     t0 = time.perf_counter()
     results = [None] * len(timed_items)
@@ -680,6 +682,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     rt_timed = _zl0.runtime_stats()
+    if os.environ.get('HELM_ALLOC_TRACE'):
+        sys.stderr.write('[bench] timed region ends\n'); sys.stderr.flush()
     elapsed_local = elapsed
     item_done_ms = [round(1e3 * (x - t0), 2) for x in stamps]
     first_items = [(a, int(w_), round(1e3 * (t_ - t0), 2)) for a, w_, t_ in sorted(tl, key=lambda m: m[2])][:12]

@@ -280,8 +280,14 @@ typedef struct helm_runtime_stats {
     long long events_created, streams_created;
     long long first_launches; double first_launch_ms;
     long long kernels_registered, kernels_resolved; double warm_ms;
+    long long dev_frees; double dev_free_ms;          /* hipFree calls (each waits for every stream of the device) */
+    long long sync_calls; double sync_ms;             /* host-side waits of the library (stream / event / device synchronisations, blocking copies) */
+    long long slow_syncs; double worst_sync_ms;       /* those of at least 10 ms (HELM_SYNC_TRACE=<ms> names their call sites on stderr) */
 } helm_runtime_stats;
 int helm_debug_runtime_stats(int reset, helm_runtime_stats *out);
+/* (diagnostic) start != 0: a thread of the library starts reading the clock in a loop; start == 0: it stops, and the longest interval between two of its readings
+ * (and how many exceeded 5 ms) come back.  A stall every thread of the process sits through shows here; a stall of the GPU or of the HIP runtime does not. */
+int helm_debug_stall_watch(int start, double *worst_gap_ms, long long *gaps_over_5ms);
 
 /* --- tuning ------------------------------------------------------------------------------
  * The options of the library that are real options (round 5: the seventy-odd HELM_* environment switches of rounds 1-4 were the tuning
@@ -324,6 +330,9 @@ typedef struct helm_tuning {
     int    mg3_bt_f32;         /* HELM_MG3_BT_F32        1     single-precision plane inverses of the block-tridiagonal coarse solve */
     int    mg3_otf;            /* HELM_MG3_OTF           1     27-point apply rebuilds its coefficients from c, rho and the PML profiles (1: from 4 right-hand sides per workgroup up, 2: always) */
     double mg3_omega;          /* HELM_MG3_OMEGA         0.9   Jacobi damping of the smoother */
+    /* host-side waits */
+    double sync_spin_ms;       /* HELM_SYNC_SPIN_MS      20    a wait of the library polls for this long before it blocks on the runtime's interrupt (0: blocks at once); a thread asleep there is
+                                                               sometimes woken 50-80 ms late on this platform, and the kernels a wait sits behind take 0.03-3 ms */
 } helm_tuning;
 int helm_get_tuning(helm_tuning *out);          /* the values in force now (environment applied) */
 int helm_set_tuning(const helm_tuning *t);      /* NULL: defaults + environment again */

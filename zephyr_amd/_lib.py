@@ -52,7 +52,7 @@ class Tuning(ctypes.Structure):
                 ('nd_xcd_map', ctypes.c_int), ('nd_plans', ctypes.c_int), ('nd_direct_out', ctypes.c_int), ('nd_leaf_idle', ctypes.c_int), ('auto_direct', ctypes.c_int),
                 ('auto_mg3', ctypes.c_int), ('prof_ext', ctypes.c_int), ('ws_slots', ctypes.c_int), ('pf_prio', ctypes.c_int),
                 ('mg3_keep', ctypes.c_int), ('mg3_keep_levels', ctypes.c_int), ('mg3_galerkin', ctypes.c_int), ('mg3_depth_model', ctypes.c_int),
-                ('mg3_bt_f32', ctypes.c_int), ('mg3_otf', ctypes.c_int), ('mg3_omega', ctypes.c_double)]
+                ('mg3_bt_f32', ctypes.c_int), ('mg3_otf', ctypes.c_int), ('mg3_omega', ctypes.c_double), ('sync_spin_ms', ctypes.c_double)]
 
 
 class RuntimeStats(ctypes.Structure):
@@ -61,7 +61,9 @@ class RuntimeStats(ctypes.Structure):
                 ('host_allocs', ctypes.c_longlong), ('host_alloc_bytes', ctypes.c_double), ('host_alloc_ms', ctypes.c_double),
                 ('events_created', ctypes.c_longlong), ('streams_created', ctypes.c_longlong),
                 ('first_launches', ctypes.c_longlong), ('first_launch_ms', ctypes.c_double),
-                ('kernels_registered', ctypes.c_longlong), ('kernels_resolved', ctypes.c_longlong), ('warm_ms', ctypes.c_double)]
+                ('kernels_registered', ctypes.c_longlong), ('kernels_resolved', ctypes.c_longlong), ('warm_ms', ctypes.c_double),
+                ('dev_frees', ctypes.c_longlong), ('dev_free_ms', ctypes.c_double),
+                ('sync_calls', ctypes.c_longlong), ('sync_ms', ctypes.c_double), ('slow_syncs', ctypes.c_longlong), ('worst_sync_ms', ctypes.c_double)]
 
 
 # every symbol include/helm.h declares, with its ctypes signature
@@ -113,6 +115,7 @@ _SIGNATURES = {
     'helm_debug_alloc_stats': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_double)]),
     'helm_warm': (ctypes.c_int, [ctypes.c_int]),
     'helm_debug_runtime_stats': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(RuntimeStats)]),
+    'helm_debug_stall_watch': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]),
     'helm_rhs_from_coo_device': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong,
                                                 ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong]),
     'helm_sample_device': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p,
@@ -239,6 +242,36 @@ def pinned_reserve(shape, count, dtype=np.complex128):
     n = len(held)
     del held
     return n
+
+
+def to_device(arr, dev, dtype=None):
+    """numpy array -> torch tensor on `dev` without handing pageable memory to the HIP runtime: arrays above 64 KB go through a pinned buffer of the
+    library (a copy straight from pageable memory makes the runtime register the caller's pages, and when numpy frees them -- or the host kernel moves
+    them -- the driver takes every queue of the process off the GPU for 60-80 ms while it revalidates the registration; include/helm.h, helm_set_model)."""
+    import torch
+    a = np.ascontiguousarray(arr, dtype=dtype)
+    if a.nbytes <= (64 << 10):
+        return torch.from_numpy(a).to(dev)
+    p = pinned_empty(a.shape, a.dtype)
+    np.copyto(p, a)
+    t = torch.from_numpy(p).to(dev, non_blocking=True)
+    wait_torch_stream(dev)                # (the copy has completed: the pinned buffer goes back to the pool)
+    del p
+    return t
+
+
+def wait_torch_stream(dev, spin_ms=None):
+    """torch.cuda.current_stream(dev).synchronize() that polls before it blocks (helm_tuning.sync_spin_ms): a thread asleep in the runtime's blocking wait is
+    sometimes woken 50-80 ms late on this platform (include/helm.h, sync_spin_ms)."""
+    import time
+    import torch
+    st = torch.cuda.current_stream(dev)
+    budget = (tuning().sync_spin_ms if spin_ms is None else spin_ms) * 1e-3
+    t0 = time.perf_counter()
+    while budget > 0 and not st.query():
+        if time.perf_counter() - t0 > budget:
+            break
+    st.synchronize()
 
 
 def ptr(arr):

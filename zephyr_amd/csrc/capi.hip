@@ -8,6 +8,7 @@
 #include <atomic>
 #include <unistd.h>
 #include <mutex>
+#include <thread>
 #include <map>
 #include <cstring>
 #include <algorithm>
@@ -43,6 +44,7 @@ struct KernelRegistry {
 };
 KernelRegistry &kreg() { static KernelRegistry *r = new KernelRegistry(); return *r; }
 struct RuntimeCounters {
+    std::atomic<long long> dev_frees{0}, dev_free_us{0}, sync_calls{0}, sync_us{0}, slow_syncs{0}, worst_sync_us{0};
     std::atomic<long long> dev_allocs{0}, dev_alloc_bytes{0}, dev_alloc_us{0}, host_allocs{0}, host_alloc_bytes{0}, host_alloc_us{0},
                            events{0}, streams{0}, first_launches{0}, first_launch_us{0}, resolved{0}, warm_us{0};
 };
@@ -75,7 +77,76 @@ void helm_kernel_first_launch_done(int slot, double host_ms) {
 hipError_t helm_counted_malloc(void **p, size_t bytes) {
     const double t0 = wall_ms();
     const hipError_t e = (hipMalloc)(p, bytes);
+    static const int tr = getenv("HELM_ALLOC_TRACE") ? atoi(getenv("HELM_ALLOC_TRACE")) : 0;
+    if (tr >= 2) fprintf(stderr, "[helm alloc] hipMalloc %12zu B  %8.3f ms\n", bytes, wall_ms() - t0);
     rtc().dev_allocs += 1; rtc().dev_alloc_bytes += (long long)bytes; rtc().dev_alloc_us += (long long)((wall_ms() - t0) * 1e3);
+    return e;
+}
+namespace {
+struct SyncTimer {
+    const char *what, *file; int line; double t0;
+    SyncTimer(const char *w, const char *f, int l) : what(w), file(f), line(l), t0(wall_ms()) {}
+    ~SyncTimer() {
+        const double ms = wall_ms() - t0;
+        rtc().sync_calls += 1; rtc().sync_us += (long long)(ms * 1e3);
+        if (ms >= 10.0) { rtc().slow_syncs += 1; long long us = (long long)(ms * 1e3), prev = rtc().worst_sync_us.load(); while (us > prev && !rtc().worst_sync_us.compare_exchange_weak(prev, us)) {} }
+        static const double thr = getenv("HELM_SYNC_TRACE") ? atof(getenv("HELM_SYNC_TRACE")) : 0.0;
+        if (thr > 0 && ms >= thr) { const char *b = strrchr(file, '/'); fprintf(stderr, "[helm sync] %-22s %9.3f ms  %s:%d\n", what, ms, b ? b + 1 : file, line); }
+    }
+};
+}
+// Waits spin before they block (helm_tuning.sync_spin_ms, default 20 ms): the blocking waits of the runtime sleep on an interrupt, and on this platform a thread
+// that sleeps there is sometimes woken 50-80 ms late -- both pipeline threads at once, about once per 100-150 ms of a job of small kernels (round 6: the
+// config-4 gradient step lost 60-80 of its 110-140 ms to ONE such wake-up per dpred / Jtvec; with any thread of the process spinning it never happened).
+// The kernels a wait of this library sits behind take 0.03-3 ms, so the poll is where the wait ends; what outlasts the budget blocks as before.
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+}
+static double sync_spin_budget_ms() { return helm_tuning_now().sync_spin_ms; }
+hipError_t helm_timed_stream_sync(hipStream_t s, const char *file, int line) {
+    SyncTimer t("hipStreamSynchronize", file, line);
+    const double budget = sync_spin_budget_ms();
+    if (budget > 0) {
+        const double t0 = wall_ms();
+        for (;;) {
+            const hipError_t q = hipStreamQuery(s);
+            if (q == hipSuccess) return hipSuccess;
+            if (q != hipErrorNotReady) { (void)hipGetLastError(); break; }
+            (void)hipGetLastError();
+            if (wall_ms() - t0 > budget) break;
+            for (int i = 0; i < 64; ++i) cpu_relax();
+        }
+    }
+    return (hipStreamSynchronize)(s);
+}
+hipError_t helm_timed_event_sync(hipEvent_t e, const char *file, int line) {
+    SyncTimer t("hipEventSynchronize", file, line);
+    const double budget = sync_spin_budget_ms();
+    if (budget > 0) {
+        const double t0 = wall_ms();
+        for (;;) {
+            const hipError_t q = hipEventQuery(e);
+            if (q == hipSuccess) return hipSuccess;
+            if (q != hipErrorNotReady) { (void)hipGetLastError(); break; }
+            (void)hipGetLastError();
+            if (wall_ms() - t0 > budget) break;
+            for (int i = 0; i < 64; ++i) cpu_relax();
+        }
+    }
+    return (hipEventSynchronize)(e);
+}
+hipError_t helm_timed_device_sync(const char *file, int line) { SyncTimer t("hipDeviceSynchronize", file, line); return (hipDeviceSynchronize)(); }
+hipError_t helm_timed_memcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, const char *file, int line) { SyncTimer t("hipMemcpy", file, line); return (hipMemcpy)(dst, src, bytes, kind); }
+hipError_t helm_counted_free(void *p) {
+    if (!p) return hipSuccess;
+    const double t0 = wall_ms();
+    const hipError_t e = (hipFree)(p);                 // (waits for every stream of the device)
+    const double ms = wall_ms() - t0;
+    rtc().dev_frees += 1; rtc().dev_free_us += (long long)(ms * 1e3);
+    static const int tr = getenv("HELM_ALLOC_TRACE") ? atoi(getenv("HELM_ALLOC_TRACE")) : 0;
+    if (tr >= 2) fprintf(stderr, "[helm alloc] hipFree   %p  %8.3f ms\n", p, ms);
     return e;
 }
 hipError_t helm_counted_host_malloc(void **p, size_t bytes, unsigned flags) {
@@ -97,9 +168,37 @@ extern "C" int helm_debug_runtime_stats(int reset, helm_runtime_stats *out) {
         out->events_created = c.events.load(); out->streams_created = c.streams.load();
         out->first_launches = c.first_launches.load(); out->first_launch_ms = c.first_launch_us.load() * 1e-3;
         out->kernels_registered = kreg().n.load(); out->kernels_resolved = c.resolved.load(); out->warm_ms = c.warm_us.load() * 1e-3;
+        out->dev_frees = c.dev_frees.load(); out->dev_free_ms = c.dev_free_us.load() * 1e-3;
+        out->sync_calls = c.sync_calls.load(); out->sync_ms = c.sync_us.load() * 1e-3; out->slow_syncs = c.slow_syncs.load(); out->worst_sync_ms = c.worst_sync_us.load() * 1e-3;
     }
     if (reset) { c.dev_allocs = 0; c.dev_alloc_bytes = 0; c.dev_alloc_us = 0; c.host_allocs = 0; c.host_alloc_bytes = 0; c.host_alloc_us = 0;
-                 c.events = 0; c.streams = 0; c.first_launches = 0; c.first_launch_us = 0; }
+                 c.events = 0; c.streams = 0; c.first_launches = 0; c.first_launch_us = 0; c.dev_frees = 0; c.dev_free_us = 0; c.sync_calls = 0; c.sync_us = 0; c.slow_syncs = 0; c.worst_sync_us = 0; }
+    return HELM_OK;
+}
+// (diagnostic) a thread of the library that does nothing but read the clock: the longest interval between two readings while it ran.  Tells a stall of the
+// PROCESS (every thread stops: the watcher sees it too) from a stall of the GPU or of the runtime (the watcher keeps running).
+namespace { std::atomic<bool> g_watch_on{false}; std::atomic<long long> g_watch_worst_us{0}, g_watch_gaps{0}; std::thread *g_watch_thread = nullptr; }
+extern "C" int helm_debug_stall_watch(int start, double *worst_gap_ms, long long *gaps_over_5ms) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (start) {
+        if (g_watch_thread) return HELM_OK;
+        g_watch_worst_us = 0; g_watch_gaps = 0; g_watch_on = true;
+        g_watch_thread = new std::thread([] {
+            double last = wall_ms();
+            while (g_watch_on.load(std::memory_order_relaxed)) {
+                const double now = wall_ms(), gap = now - last;
+                last = now;
+                if (gap > 5.0) g_watch_gaps += 1;
+                long long us = (long long)(gap * 1e3), prev = g_watch_worst_us.load();
+                while (us > prev && !g_watch_worst_us.compare_exchange_weak(prev, us)) {}
+            }
+        });
+        return HELM_OK;
+    }
+    if (g_watch_thread) { g_watch_on = false; g_watch_thread->join(); delete g_watch_thread; g_watch_thread = nullptr; }
+    if (worst_gap_ms) *worst_gap_ms = g_watch_worst_us.load() * 1e-3;
+    if (gaps_over_5ms) *gaps_over_5ms = g_watch_gaps.load();
     return HELM_OK;
 }
 // Resolve every kernel of the library on `device` (code objects loaded, dispatch records built) without launching anything.  Idempotent; runs by itself
@@ -142,6 +241,8 @@ static void tuning_clamp(helm_tuning &t) {
     t.ws_slots = std::min(4, std::max(1, t.ws_slots));
     t.pf_prio = t.pf_prio > 0 ? 1 : (t.pf_prio < 0 ? -1 : 0);
     if (!(t.mg3_omega > 0) || t.mg3_omega > 2.0) t.mg3_omega = 0.9;
+    if (!(t.sync_spin_ms >= 0)) t.sync_spin_ms = 0.0;
+    t.sync_spin_ms = std::min(t.sync_spin_ms, 60000.0);
 }
 static helm_tuning tuning_from_env() {
     helm_tuning t;
@@ -172,6 +273,7 @@ static helm_tuning tuning_from_env() {
     t.mg3_bt_f32 = tune_i("HELM_MG3_BT_F32", 1);
     t.mg3_otf = tune_i("HELM_MG3_OTF", 1);
     t.mg3_omega = tune_d("HELM_MG3_OMEGA", 0.9);
+    t.sync_spin_ms = tune_d("HELM_SYNC_SPIN_MS", 20.0);
     tuning_clamp(t);
     return t;
 }
@@ -339,6 +441,7 @@ void helm_hostpool_free(void *p, size_t bytes) {
 }
 // pinned host memory the library holds idle goes back to the system
 extern "C" int helm_host_trim(void) {
+    helm_tuning_refresh();
     std::lock_guard<std::mutex> lk(g_hostpool.mu);
     for (auto &kv : g_hostpool.idle) hipHostFree(kv.second);
     g_hostpool.idle.clear(); g_hostpool.held = 0;
@@ -508,7 +611,7 @@ extern "C" void helm_destroy(helm_op *op) {
     helm_pf_retire(op);
     if (op->stream) hipStreamSynchronize(op->stream);
     helm_pool_free(op->device, op->d_c, (size_t)op->N * sizeof(cplx)); helm_pool_free(op->device, op->d_rho, (size_t)op->N * sizeof(double));
-    hipFree(op->d_theta); hipFree(op->d_eps); hipFree(op->d_delta);
+    helm_pool_free(op->device, op->d_theta, (size_t)op->N * sizeof(double)); helm_pool_free(op->device, op->d_eps, (size_t)op->N * sizeof(double)); helm_pool_free(op->device, op->d_delta, (size_t)op->N * sizeof(double));
     helm_pool_free(op->device, op->d_K3, (size_t)op->N * sizeof(cplx)); helm_pool_free(op->device, op->d_b3, (size_t)op->N * sizeof(double));
     helm_pool_free(op->device, op->d_L3, op->l3_elems * sizeof(cplx));
     {
@@ -543,6 +646,7 @@ extern "C" void helm_destroy(helm_op *op) {
 // Release what the library caches between calls (the shared scratch of the direct path).  The scratch is kept across
 // handles on purpose -- allocating tens of GB costs far more than a solve -- so a host that wants the memory back says so.
 extern "C" int helm_trim(void) {
+    helm_tuning_refresh();
     int cur = 0;
     (void)hipGetDevice(&cur);
     {
@@ -564,6 +668,7 @@ extern "C" int helm_trim(void) {
 
 // (tests) how many scratch slots of `device` hold a buffer of at least `bytes`; -1: the number of slots per device
 extern "C" int helm_debug_ws_slots(int device, long long bytes) {
+    helm_tuning_refresh();
     if (device < 0) return shared_ws_slots();
     std::lock_guard<std::mutex> lk(g_shared_ws.mu);
     auto it = g_shared_ws.dev.find(device);
@@ -574,6 +679,7 @@ extern "C" int helm_debug_ws_slots(int device, long long bytes) {
 }
 
 extern "C" int helm_set_stream(helm_op *op, void *hip_stream) {
+    helm_tuning_refresh();
     if (!op) return HELM_ERR_ARG;
     HIP_TRY(op, hipSetDevice(op->device));
     helm_pf_retire(op);
@@ -587,30 +693,60 @@ extern "C" int helm_set_stream(helm_op *op, void *hip_stream) {
     return HELM_OK;
 }
 
-extern "C" int helm_set_profiling(helm_op *op, int on) { if (!op) return HELM_ERR_ARG; op->profiling = on != 0; return HELM_OK; }
+extern "C" int helm_set_profiling(helm_op *op, int on) {
+    helm_tuning_refresh(); if (!op) return HELM_ERR_ARG; op->profiling = on != 0; return HELM_OK; }
 extern "C" int helm_last_timing(const helm_op *op, helm_timing *out) { if (!op || !out) return HELM_ERR_ARG; *out = op->timing; return HELM_OK; }
 extern "C" int helm_num_blocks(const helm_op *op) { return op ? op->nblocks : HELM_ERR_ARG; }
 extern "C" long long helm_num_points(const helm_op *op) { return op ? op->N : HELM_ERR_ARG; }
 
+// Host array -> device through a pinned buffer of the library (recycled by size): the caller's pages are never handed to the runtime.  A copy of a few MB
+// straight from pageable memory makes the runtime pin the caller's pages in place (a user-pointer registration), and when those pages go away or move
+// afterwards -- numpy frees the temporary, the host kernel migrates or compacts the page -- the driver takes EVERY queue of the process off the GPU until the
+// registration has been revalidated: 60-80 ms with nothing running, once per dpred / Jtvec of the config-4 job (round 6: found with HELM_SYNC_TRACE, any
+// host-side wait of either thread could be the one that sat through it).  Chunked, two buffers: the memcpy of chunk k+1 runs beside the DMA of chunk k.
+static int upload_staged(helm_op *op, void *dst, const void *src, size_t bytes) {
+    const size_t chunk = (size_t)4 << 20;
+    char *buf[2] = {(char *)helm_hostpool_alloc(chunk), (char *)helm_hostpool_alloc(chunk)};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int rc = HELM_OK;
+    if (!buf[0] || !buf[1] || hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) != hipSuccess) rc = HELM_ERR_DEVICE;
+    bool used[2] = {false, false};
+    for (size_t off = 0, k = 0; off < bytes && rc == HELM_OK; off += chunk, ++k) {
+        const int b = (int)(k & 1);
+        const size_t n = std::min(chunk, bytes - off);
+        if (used[b] && hipEventSynchronize(ev[b]) != hipSuccess) { rc = HELM_ERR_DEVICE; break; }
+        memcpy(buf[b], (const char *)src + off, n);
+        if (hipMemcpyAsync((char *)dst + off, buf[b], n, hipMemcpyHostToDevice, op->stream) != hipSuccess || hipEventRecord(ev[b], op->stream) != hipSuccess) { rc = HELM_ERR_DEVICE; break; }
+        used[b] = true;
+    }
+    for (int b = 0; b < 2; ++b) {
+        if (used[b]) (void)hipEventSynchronize(ev[b]);
+        if (ev[b]) hipEventDestroy(ev[b]);
+        helm_hostpool_free(buf[b], chunk);
+    }
+    if (rc) (void)hipGetLastError();
+    return rc;
+}
+
 extern "C" int helm_set_model(helm_op *op, const double *c, const double *rho, const double *theta, const double *eps, const double *delta) {
+    helm_tuning_refresh();
     if (!op || !c) return HELM_ERR_ARG;
     HIP_TRY(op, hipSetDevice(op->device));
     const size_t N = (size_t)op->N;
-    HIP_TRY(op, hipMemcpyAsync(op->d_c, c, N * sizeof(cplx), hipMemcpyHostToDevice, op->stream));
+    if (upload_staged(op, op->d_c, c, N * sizeof(cplx))) HELM_FAIL(op, HELM_ERR_DEVICE, "model upload failed");
     if (!rho) {   // Gardner default 310 * Re(c)^0.25  (discretization.py:70), evaluated on the device
         const int rcg = helm_launch_gardner_rho(op);
         if (rcg) return rcg;
     } else {
-        HIP_TRY(op, hipMemcpyAsync(op->d_rho, rho, N * sizeof(double), hipMemcpyHostToDevice, op->stream));
+        if (upload_staged(op, op->d_rho, rho, N * sizeof(double))) HELM_FAIL(op, HELM_ERR_DEVICE, "model upload failed");
     }
     op->aniso = false;
     bool m3zero = true;
     if (op->variant == HELM_EURUS) {
         auto up = [&](double *&dst, const double *src) -> int {
-            if (!src) { if (dst) { hipFree(dst); dst = nullptr; } return 0; }
-            if (!dst) { if (hipMalloc(&dst, N * sizeof(double)) != hipSuccess) return -1; }
-            if (hipMemcpyAsync(dst, src, N * sizeof(double), hipMemcpyHostToDevice, op->stream) != hipSuccess) return -1;
-            return 0;
+            if (!src) { if (dst) { helm_pool_free(op->device, dst, N * sizeof(double)); dst = nullptr; } return 0; }
+            if (!dst) { dst = (double *)helm_pool_alloc(op->device, N * sizeof(double)); if (!dst) return -1; }
+            return upload_staged(op, dst, src, N * sizeof(double)) ? -1 : 0;
         };
         if (up(op->d_theta, theta) || up(op->d_eps, eps) || up(op->d_delta, delta)) HELM_FAIL(op, HELM_ERR_DEVICE, "anisotropy upload failed");
         op->aniso = theta || eps || delta;
@@ -710,6 +846,7 @@ int helm_ensure_scaled(helm_op *op) {
 }
 
 extern "C" int helm_get_diagonals(helm_op *op, double *out) {
+    helm_tuning_refresh();
     if (!op || !out) return HELM_ERR_ARG;
     if (!op->assembled) HELM_FAIL(op, HELM_ERR_STATE, "operator not assembled");
     HIP_TRY(op, hipSetDevice(op->device));
@@ -809,6 +946,7 @@ extern "C" int helm_apply_device(helm_op *op, int block, int adjoint, const void
 }
 
 extern "C" int helm_apply(helm_op *op, int block, int adjoint, const double *X, double *Y, int nrhs) {
+    helm_tuning_refresh();
     if (!op || !X || !Y || nrhs < 1) return HELM_ERR_ARG;
     HIP_TRY(op, hipSetDevice(op->device));
     const size_t bytes = (size_t)nrhs * op->N * sizeof(cplx);
@@ -1103,6 +1241,7 @@ static int g_selftest_allocs = 0;
 static void *ws_host_alloc(int, size_t bytes) { g_selftest_allocs += 1; return malloc(bytes); }
 static void ws_host_free(int, void *p) { free(p); }
 extern "C" int helm_debug_ws_selftest(int ndev, int concurrent, long long bytes) {
+    helm_tuning_refresh();
     if (ndev < 1 || concurrent < 1 || bytes < 1) return HELM_ERR_ARG;
     SharedWs T;
     int rc = 0;
@@ -1861,6 +2000,7 @@ static int prefactor3d(helm_op *op, int nrhs) {
 // ill-conditioned fronts get the pivoted-LU treatment follows from it (direct.hip, stabilise_group).  Every solve records its own rtol as well,
 // so a factorisation that happens inside a solve needs no hint.
 extern "C" int helm_set_tolerance_hint(helm_op *op, double rtol) {
+    helm_tuning_refresh();
     if (!op || !(rtol > 0)) return HELM_ERR_ARG;
     op->rtol_hint = rtol; op->rtol_hint_set = true;
     return HELM_OK;
@@ -2117,6 +2257,7 @@ extern "C" int helm_solve(helm_op *op, const double *RHS, double *U, int nrhs, l
 }
 
 extern "C" int helm_rhs_from_coo_device(helm_op *op, const void *d_row, const void *d_col, const void *d_val, long long nnz, void *dR, int nrhs, long long rows) {
+    helm_tuning_refresh();
     if (!op || !dR || nrhs < 1 || rows < 1 || nnz < 0 || (nnz > 0 && (!d_row || !d_col || !d_val))) return HELM_ERR_ARG;
     HIP_TRY(op, hipSetDevice(op->device));
     int rc = helm_launch_rhs_from_coo(op, (const long long *)d_row, (const int *)d_col, (const cplx *)d_val, nnz, (cplx *)dR, nrhs, rows);
@@ -2126,6 +2267,7 @@ extern "C" int helm_rhs_from_coo_device(helm_op *op, const void *d_row, const vo
 }
 
 extern "C" int helm_rhs_from_coo_device_layout(helm_op *op, const void *d_row, const void *d_col, const void *d_val, long long nnz, void *dR, int nrhs, long long rows, int flags) {
+    helm_tuning_refresh();
     if (!op || !dR || nrhs < 1 || rows < 1 || nnz < 0 || (nnz > 0 && (!d_row || !d_col || !d_val))) return HELM_ERR_ARG;
     HIP_TRY(op, hipSetDevice(op->device));
     int rc = helm_launch_rhs_from_coo(op, (const long long *)d_row, (const int *)d_col, (const cplx *)d_val, nnz, (cplx *)dR, nrhs, rows, (flags & HELM_RHS_NODE_MAJOR) ? 1 : 0);
@@ -2141,6 +2283,7 @@ extern "C" int helm_rhs_from_coo_device_layout(helm_op *op, const void *d_row, c
 // sets the leaf flags of its forward pass from the bits instead of reading every right-hand-side row to look for nonzeros (3.2 of 4.3 GB at 1024^2 x 256).
 // HELM_ND_SUPPORT_CHECK=1 verifies the guarantee (one pass over q) and fails the solve if it does not hold.
 extern "C" int helm_set_rhs_support(helm_op *op, const void *d_bits, long long rows, int nrhs) {
+    helm_tuning_refresh();
     if (!op) return HELM_ERR_ARG;
     if (!d_bits) { op->rhs_bits = nullptr; op->rhs_bits_q = nullptr; return HELM_OK; }
     if (rows < 1 || nrhs < 1 || nrhs > 512) HELM_FAIL(op, HELM_ERR_ARG, "helm_set_rhs_support: rows >= 1 and 1 <= nrhs <= 512");
@@ -2160,6 +2303,7 @@ __global__ __launch_bounds__(256) void k_support_from_coo(const long long *row, 
 // bits (rows bytes, rounded up to a multiple of 4, on the device) from the triplets of a sparse right-hand-side matrix (device arrays as for
 // helm_rhs_from_coo_device_layout): what helm_set_rhs_support takes
 extern "C" int helm_rhs_support_from_coo(helm_op *op, const void *d_row, const void *d_col, long long nnz, void *d_bits, long long rows, int nrhs) {
+    helm_tuning_refresh();
     if (!op || !d_bits || rows < 1 || nrhs < 1 || nrhs > 512 || nnz < 0 || (nnz > 0 && (!d_row || !d_col))) return HELM_ERR_ARG;
     HIP_TRY(op, hipSetDevice(op->device));
     HIP_TRY(op, hipMemsetAsync(d_bits, 0, (size_t)((rows + 3) / 4) * 4, op->stream));
@@ -2218,6 +2362,7 @@ extern "C" int helm_solve_coo(helm_op *op, const long long *row, const int *col,
 }
 
 extern "C" int helm_sample_device(helm_op *op, const void *dU, int nsrc, long long ld, const void *d_rowptr, const void *d_col, const void *d_val, int nrec, void *d_out) {
+    helm_tuning_refresh();
     if (!op || !dU || !d_rowptr || !d_col || !d_val || !d_out || nsrc < 1 || nrec < 1) return HELM_ERR_ARG;
     HIP_TRY(op, hipSetDevice(op->device));
     int rc = helm_launch_sample(op, (const cplx *)dU, nsrc, ld, (const long long *)d_rowptr, (const long long *)d_col, (const cplx *)d_val, nrec, (cplx *)d_out);
@@ -2227,6 +2372,7 @@ extern "C" int helm_sample_device(helm_op *op, const void *dU, int nsrc, long lo
 }
 
 extern "C" int helm_imaging_accumulate_device(helm_op *op, const void *dUF, const void *dUB, int nsrc, const void *dScaler, void *dG) {
+    helm_tuning_refresh();
     if (!op || !dUF || !dUB || !dScaler || !dG || nsrc < 1) return HELM_ERR_ARG;
     HIP_TRY(op, hipSetDevice(op->device));
     int rc = helm_launch_imaging(op, (const cplx *)dUF, (const cplx *)dUB, nsrc, (const cplx *)dScaler, (cplx *)dG);

@@ -212,10 +212,22 @@ struct HelmFirstLaunch {
 // real entry points).  helm_debug_runtime_stats() reports the counts: a job whose pools were booked (helm_reserve, warm-up items) must show
 // zeros across its timed region.
 hipError_t helm_counted_malloc(void **p, size_t bytes);
+hipError_t helm_counted_free(void *p);
 hipError_t helm_counted_host_malloc(void **p, size_t bytes, unsigned flags);
 hipError_t helm_counted_event_create(hipEvent_t *e, unsigned flags);
 hipError_t helm_counted_stream_create(hipStream_t *s, unsigned flags, int prio, bool with_prio);
+// host-side waits: how long the calling thread sat in each (HELM_SYNC_TRACE=<ms>: waits longer than that are reported on stderr with their call site;
+// helm_debug_runtime_stats counts those of at least 10 ms -- a wait that long on a GPU whose kernels take 0.03-3 ms is a stall, not work)
+hipError_t helm_timed_stream_sync(hipStream_t s, const char *file, int line);
+hipError_t helm_timed_event_sync(hipEvent_t e, const char *file, int line);
+hipError_t helm_timed_device_sync(const char *file, int line);
+hipError_t helm_timed_memcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, const char *file, int line);
+#define hipStreamSynchronize(S) helm_timed_stream_sync((S), __FILE__, __LINE__)
+#define hipEventSynchronize(E) helm_timed_event_sync((E), __FILE__, __LINE__)
+#define hipDeviceSynchronize() helm_timed_device_sync(__FILE__, __LINE__)
+#define hipMemcpy(D, S, B, K) helm_timed_memcpy((D), (S), (B), (K), __FILE__, __LINE__)
 #define hipMalloc(P, B) helm_counted_malloc((void **)(P), (B))
+#define hipFree(P) helm_counted_free((void *)(P))
 #define hipHostMalloc(P, B, F) helm_counted_host_malloc((void **)(P), (B), (F))
 #define hipEventCreate(E) helm_counted_event_create((E), 0u)
 #define hipEventCreateWithFlags(E, F) helm_counted_event_create((E), (F))

@@ -171,6 +171,15 @@ __global__ __launch_bounds__(256) void k_nd_build_front(const NdDev *nodes, int 
     // keeps every load behind the previous store, and a wave that took one entry per lane at a time paid a full memory round trip per row of a small
     // front (14 in a row at the 8192-front level: ~100 us for 110 MB) or per 64 columns of a large one.  Small fronts: four rows at once; others: four
     // column blocks of one row.
+    if (skip22 & 2) {       // (diagnostic, HELM_ND_BUILD1=1: round 4's loop, one entry per lane at a time -- the A/B of the gather-four form below)
+        skip22 &= 1;
+        for (int r = r0 + ty; r < r1; r += 4) {
+            const int2 ia = finfo[r];
+            const int cend = (skip22 && r >= n.smax) ? n.smax : nmax;
+            for (int c = tx; c < cend; c += 64) *front_entry(n, arenaF, fac, r, c) = value(r, c, ia, finfo[c]);
+        }
+        return;
+    }
     if (nmax <= 64) {
         for (int rq = r0 + ty; rq < r1; rq += 16) {
             cplx v[4]; int2 ia[4];
@@ -674,10 +683,11 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
         // rows per workgroup: whole fronts while there are thousands of them, a few rows each for the handful of big ones at the top
         const int want = std::max(1, 2048 / g.cnt);
         const int rb = std::max(std::min(nmax, 4), (nmax + want - 1) / want);
+        static const int build1 = (getenv("HELM_ND_BUILD1") && atoi(getenv("HELM_ND_BUILD1"))) ? 2 : 0;      // (diagnostic: round 4's gather loop)
         for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
             const int nb = std::min(65535, g.cnt - j0);
             HELM_LAUNCH(k_nd_build_front, dim3((nmax + rb - 1) / rb, nb), dim3(256), (size_t)nmax * sizeof(int2), st, d_nodes, g.first + j0, arenaF, f->d_fac, planes,
-                               P.nz, P.nx, rb, schur_gather ? 1 : 0, 0, NdDev());
+                               P.nz, P.nx, rb, (schur_gather ? 1 : 0) | build1, 0, NdDev());
         }
     } else {
         if (fs > 0) HIP_TRY(op, hipMemsetAsync(F, 0, (size_t)g.cnt * fs * sizeof(cplx), st));

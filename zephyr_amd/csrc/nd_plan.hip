@@ -253,6 +253,7 @@ int nd_get_plan_dims(helm_op *op, int pnz, int pnx, int leaf, int dof, std::shar
 
 // (tests) number of plans the cache holds for `device`
 extern "C" int helm_debug_plan_cache(int device) {
+    helm_tuning_refresh();
     std::lock_guard<std::mutex> lk(g_plan_mu);
     auto it = g_plans.find(device);
     return it == g_plans.end() ? 0 : (int)it->second.size();

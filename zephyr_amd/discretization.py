@@ -303,10 +303,10 @@ class BaseDiscretization(BaseModelDependent):
                 coo.sum_duplicates()
             r_, c_, v_, shape, nnz = coo.row, coo.col, coo.data, coo.shape, int(coo.nnz)
         dev = torch.device('cuda', self.device)
-        row = torch.from_numpy(np.ascontiguousarray(r_, dtype=np.int64)).to(dev)
-        col = torch.from_numpy(np.ascontiguousarray(c_, dtype=np.int32)).to(dev)
-        val = torch.from_numpy(np.ascontiguousarray(v_, dtype=np.complex128)).to(dev)
-        torch.cuda.current_stream(dev).synchronize()        # (the copies of THIS thread: a device-wide synchronisation would wait for the other workers' kernels too)
+        row = _lib.to_device(r_, dev, np.int64)
+        col = _lib.to_device(c_, dev, np.int32)
+        val = _lib.to_device(v_, dev, np.complex128)
+        _lib.wait_torch_stream(dev)                         # (the copies of THIS thread: a device-wide synchronisation would wait for the other workers' kernels too)
         _lib.check(lib.helm_rhs_from_coo_device_layout(self.handle, ctypes.c_void_p(row.data_ptr()), ctypes.c_void_p(col.data_ptr()),
                                                        ctypes.c_void_p(val.data_ptr()), nnz, ctypes.c_void_p(d_rhs), int(shape[1]),
                                                        int(shape[0]), _lib.HELM_RHS_NODE_MAJOR if layout == 'node' else 0), self.handle)
@@ -319,8 +319,8 @@ class BaseDiscretization(BaseModelDependent):
         lib = _lib.load()
         coo = sp.coo_matrix(q)
         dev = torch.device('cuda', self.device)
-        row = torch.from_numpy(np.ascontiguousarray(coo.row, dtype=np.int64)).to(dev)
-        col = torch.from_numpy(np.ascontiguousarray(coo.col, dtype=np.int32)).to(dev)
+        row = _lib.to_device(coo.row, dev, np.int64)
+        col = _lib.to_device(coo.col, dev, np.int32)
         bits = torch.zeros(((int(coo.shape[0]) + 3) // 4) * 4, dtype=torch.uint8, device=dev)
         torch.cuda.synchronize(dev)
         _lib.check(lib.helm_rhs_support_from_coo(self.handle, ctypes.c_void_p(row.data_ptr()), ctypes.c_void_p(col.data_ptr()), int(coo.nnz),

@@ -22,6 +22,7 @@ from .distributors import MultiFreq, ViscoMultiFreq
 from .survey import HelmBaseSurvey, Helm2DSurvey, Helm25DSurvey
 from . import parallel
 from . import dispatch
+from . import _lib
 
 EPS = 1e-15
 
@@ -309,8 +310,8 @@ class HelmBaseProblem(BaseModelDependent, BaseSCCache):
                 parts.append((coo.row, coo.col + off, coo.data))
             trip = (np.concatenate([p_[0] for p_ in parts]), np.concatenate([p_[1] for p_ in parts]), np.concatenate([p_[2] for p_ in parts]), (N, 2 * k))
             op.rhsFromSparseDevice(trip, R.data_ptr())      # sparse triplets up, dense on the device
-            scaler = torch.from_numpy(np.ascontiguousarray(self.gradientScaler(ifreq) * scale * scale)).to(dev)
-            torch.cuda.current_stream(dev).synchronize()
+            scaler = _lib.to_device(self.gradientScaler(ifreq) * scale * scale, dev, np.complex128)
+            _lib.wait_torch_stream(dev)
             op.solveDevice(R.data_ptr(), U.data_ptr(), 2 * k, N)
             op.imagingAccumulateDevice(U.data_ptr(), U.data_ptr() + k * N * 16, k, scaler.data_ptr(), state['G'].data_ptr())
             return None
@@ -348,9 +349,7 @@ class HelmBaseProblem(BaseModelDependent, BaseSCCache):
             state = wstate.setdefault(('buffers', op.device), {})
             k = c1 - c0
             if 'csr' not in state:
-                state['csr'] = (torch.from_numpy(np.ascontiguousarray(Rm.indptr, dtype=np.int64)).to(dev),
-                                torch.from_numpy(np.ascontiguousarray(Rm.indices, dtype=np.int64)).to(dev),
-                                torch.from_numpy(np.ascontiguousarray(Rm.data, dtype=np.complex128)).to(dev), nrec)
+                state['csr'] = (_lib.to_device(Rm.indptr, dev, np.int64), _lib.to_device(Rm.indices, dev, np.int64), _lib.to_device(Rm.data, dev, np.complex128), nrec)
             if state.get('cap', 0) < k:
                 state['R'] = torch.empty((k, N), dtype=torch.complex128, device=dev)
                 state['U'] = torch.empty((k, N), dtype=torch.complex128, device=dev)
