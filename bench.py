@@ -18,6 +18,14 @@ import os
 import sys
 import time
 
+# BLAS / OpenMP pools of ONE thread for this process, set before numpy loads its BLAS: the job's host side needs four or five threads (main, prepare, solve, the
+# runtime's own), and a threaded BLAS call anywhere near a timed region leaves 64 OpenBLAS workers spinning for ~100 ms -- under the GPU boxes' container CPU
+# quota (cgroup cpu.max = 16 CPUs per 100 ms, while os.cpu_count() says 256) that exhausts the period's budget in 25 ms and the scheduler freezes every thread of
+# the process, the ones feeding the GPU included, for the remaining 75 ms (round 6: found in config 4, whose updateModel compared two models with np.linalg.norm).
+# The CPU-baseline legs are single-thread by definition (`cores`: 1) or run their own processes (cpu_baseline_pool).
+for _k in ('OPENBLAS_NUM_THREADS', 'OMP_NUM_THREADS', 'MKL_NUM_THREADS'):
+    os.environ.setdefault(_k, '1')
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -27,6 +35,32 @@ if ROOT not in sys.path:
 NFREQ, NSRC = 16, 256
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 F64_PEAK_TFLOPS = 78.6    # MI355X fp64 dense peak, vector FMA = MFMA f64 rate (AMD spec)
+
+
+def cgroup_cpu():
+    """CPU quota (cores) and throttling counters of this process's cgroup: (quota_cores or None, throttled periods, throttled microseconds).  cgroup v2 (cpu.max,
+    cpu.stat) or v1 (cpu.cfs_quota_us, cpu.stat); zeros where unreadable."""
+    quota, nthr, usec = None, 0, 0
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        quota = None if q == 'max' else float(q) / float(per)
+        stat = open('/sys/fs/cgroup/cpu.stat').read()
+    except Exception:
+        try:
+            q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read()); per = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            quota = None if q <= 0 else q / per
+            stat = open('/sys/fs/cgroup/cpu/cpu.stat').read()
+        except Exception:
+            stat = ''
+    for line in stat.splitlines():
+        k, _, v = line.partition(' ')
+        if k == 'nr_throttled':
+            nthr = int(v)
+        elif k == 'throttled_usec':
+            usec = int(v)
+        elif k == 'throttled_time':          # v1: nanoseconds
+            usec = int(v) // 1000
+    return quota, nthr, usec
 
 
 def build_config(n, dx):
@@ -77,8 +111,8 @@ def cpu_baseline(cfg, freqs, q_host, sample_rhs=8):
                 system='M1-only (isotropic-equivalent N x N block; the reference factors the 2N x 2N system, see cpu_baseline_2n)',
                 freq_hz=f, assemble_s=t1 - t0, factor_s=t2 - t1, per_rhs_s=t_rhs, sample_rhs=sample_rhs,
                 sample='1 of 16 freqs (%.2f Hz) of the 1024^2 job: numpy assembly %.1fs + SciPy SuperLU factor %.1fs + %d back-substitutions %.3fs each, '
-                       'extrapolated to 256 sources/frequency; single thread; host has %d logical CPUs'
-                       % (f, t1 - t0, t2 - t1, sample_rhs, t_rhs, os.cpu_count())), u
+                       'extrapolated to 256 sources/frequency; single thread; host has %d logical CPUs, container CPU quota %s'
+                       % (f, t1 - t0, t2 - t1, sample_rhs, t_rhs, os.cpu_count(), cgroup_cpu()[0])), u
 
 
 def cpu_baseline_2n(n=512, dx=10.0, f=6.0, sample_rhs=4):
@@ -417,21 +451,46 @@ def config4_leg(local, world, rank, dist, backend):
     # receiver matrices are built once, each model gets its own operators and factorisations
     prob, surv = pair(ctrue)
     dobs = surv.dpred()                                        # (also the warm-up of the pools for the timed calls below)
-    mcur = ccur.ravel()
-    sync(); t0 = time.perf_counter()
+    mcur, mtrue = ccur.ravel(), ctrue.ravel()
     dcur = surv.dpred(mcur)
-    sync(); t_fwd = slowest(time.perf_counter() - t0)
     resid = dcur - dobs
     g0 = prob.Jtvec(mcur, resid)                               # (first call: the 2 x 64-column buffers come into being)
-    prob.updateModel(ctrue.ravel())                            # a model change in between: the timed call rebuilds its operators like an inversion step does
-    sync(); t0 = time.perf_counter()
-    g = prob.Jtvec(mcur, resid)
-    sync(); t_grad = slowest(time.perf_counter() - t0)
+
+    def device_ms():
+        'sum over the model\'s eight operators of the device spans of their last factorisation and solve call (HIP events on their own streams)'
+        tot = 0.0
+        for op in prob.system.subProblems:
+            if op.factors:
+                t = op.lastTiming()
+                tot += t['solve_ms'] + t['factor_ms']
+        return tot
+    # five repetitions of each call, every one on a model that differs from the one before it (an inversion step: the call builds, assembles and factors its
+    # eight operators); the figure quoted is the median, the spread (max - min) / median beside it
+    reps = 5
+    t_fwd, t_grad, gpu_fwd, gpu_grad, cg0 = [], [], [], [], cgroup_cpu()
+    g = g0
+    for _ in range(reps):
+        prob.updateModel(mtrue)
+        sync(); t0 = time.perf_counter()
+        surv.dpred(mcur)
+        sync(); t_fwd.append(slowest(time.perf_counter() - t0)); gpu_fwd.append(device_ms())
+        prob.updateModel(mtrue)
+        sync(); t0 = time.perf_counter()
+        g = prob.Jtvec(mcur, resid)
+        sync(); t_grad.append(slowest(time.perf_counter() - t0)); gpu_grad.append(device_ms())
+    cg1 = cgroup_cpu()
     del prob.factors
+    med = lambda v: float(np.median(v))
+    spread = lambda v: float((max(v) - min(v)) / np.median(v))
     out = {'workload': 'FWI gradient step on 512x512 (true: synthetic Marmousi slice, current: its 25-pt box smooth), 8 freqs 3-10 Hz x 64 sources, 128 receivers at z=20 m; '
                        'dpred(m) + Jtvec(m, v) (mux form, device imaging), each including the construction, assembly and factorisation of the 8 operators of the model handed in; '
-                       'frequencies sharded over %d rank(s), one all-reduce of the gradient' % world,
-           'dpred_seconds': t_fwd, 'jtvec_seconds': t_grad, 'wavefields_per_s_forward': nf * ns / t_fwd, 'wavefields_per_s_gradient': 2 * nf * ns / t_grad,
+                       'frequencies sharded over %d rank(s), one all-reduce of the gradient; median of %d repetitions' % (world, reps),
+           'dpred_seconds': med(t_fwd), 'jtvec_seconds': med(t_grad), 'dpred_seconds_all': t_fwd, 'jtvec_seconds_all': t_grad,
+           'dpred_spread': spread(t_fwd), 'jtvec_spread': spread(t_grad),
+           'gpu_ms_dpred': med(gpu_fwd), 'gpu_ms_jtvec': med(gpu_grad), 'gpu_ms': med(gpu_fwd) + med(gpu_grad),
+           'gpu_ms_what': 'sum over the eight operators of a call of the device spans (HIP events) of factorisation and solve; the two run on different streams and overlap between operators',
+           'cpu_throttled_ms': (cg1[2] - cg0[2]) / 1e3,
+           'wavefields_per_s_forward': nf * ns / med(t_fwd), 'wavefields_per_s_gradient': 2 * nf * ns / med(t_grad),
            'gradient_norm': float(np.linalg.norm(g)), 'gradient_repeatable_rel': float(np.linalg.norm(g - g0) / max(np.linalg.norm(g), 1e-300)),
            'residual_norm': float(np.linalg.norm(resid))}
     # the collective on its own: N x 16 B complex128 at 512^2 and 1024^2, in place on the device (what _JtvecDevice issues once per gradient)
@@ -645,6 +704,7 @@ def main():
     from zephyr_amd import _lib as _zl0
     if os.environ.get('HELM_ALLOC_TRACE'):
         sys.stderr.write('[bench] timed region starts\n'); sys.stderr.flush()
+    cg0 = cgroup_cpu()
     _zl0.runtime_stats(reset=True)       # what the timed region makes the HIP runtime create (allocations, events, first launches) is counted from here
     t0 = time.perf_counter()
     results = [None] * len(timed_items)
@@ -682,6 +742,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     rt_timed = _zl0.runtime_stats()
+    cg1 = cgroup_cpu()
+    rt_timed['cpu_quota_cores'] = cg1[0]
+    rt_timed['cpu_throttled_periods'] = cg1[1] - cg0[1]
+    rt_timed['cpu_throttled_ms'] = (cg1[2] - cg0[2]) / 1e3
     if os.environ.get('HELM_ALLOC_TRACE'):
         sys.stderr.write('[bench] timed region ends\n'); sys.stderr.flush()
     elapsed_local = elapsed
@@ -1050,8 +1114,8 @@ def main():
             flat = [
                 ('unprofiled_wfs', unprof),
                 ('timed_max_item_gap_ms', float(gaps.max())), ('timed_p50_item_ms', float(np.median(gaps))),
-                ('timed_dev_allocs', rt_timed['dev_allocs']), ('timed_dev_alloc_mb', rt_timed['dev_alloc_bytes'] / 1e6),
-                ('timed_pinned_allocs', rt_timed['host_allocs']), ('timed_first_launches', rt_timed['first_launches']),
+                ('timed_cpu_throttled_ms', rt_timed['cpu_throttled_ms']), ('cpu_quota_cores', rt_timed['cpu_quota_cores']),
+                ('timed_dev_allocs', rt_timed['dev_allocs']), ('timed_first_launches', rt_timed['first_launches']),
                 ('roofline_frac_serial', rl.get('frac')), ('two_roofs_frac', (rl.get('two_roofs') or {}).get('frac')),
                 ('stencil_frac', (out.get('stencil_roofline') or rl).get('frac')),
                 ('c4_dpred_s', c4d.get('dpred_seconds')), ('c4_jtvec_s', c4d.get('jtvec_seconds')), ('c4_gpu_ms', c4d.get('gpu_ms')),
@@ -1069,7 +1133,9 @@ def main():
                 cfgd[k] = float('%.6g' % v) if isinstance(v, float) else v
             more = {
                 'grid_n': n, 'freqs_this_run': len(agg['freqs']),
-                'timed_dev_alloc_ms': rt_timed['dev_alloc_ms'], 'timed_first_launch_ms': rt_timed['first_launch_ms'],
+                'timed_dev_alloc_ms': rt_timed['dev_alloc_ms'], 'timed_first_launch_ms': rt_timed['first_launch_ms'], 'timed_dev_alloc_mb': rt_timed['dev_alloc_bytes'] / 1e6,
+                'timed_pinned_allocs': rt_timed['host_allocs'], 'timed_cpu_throttled_periods': rt_timed['cpu_throttled_periods'],
+                'timed_slow_syncs': rt_timed['slow_syncs'], 'timed_worst_sync_ms': rt_timed['worst_sync_ms'],
                 'timed_events_created': rt_timed['events_created'], 'timed_streams_created': rt_timed['streams_created'],
                 'kernels_registered': rt_timed['kernels_registered'], 'kernels_resolved_by_warm': rt_timed['kernels_resolved'], 'warm_ms': rt_timed['warm_ms'],
                 'device_ms_solve_call': dms.get('solve_call'), 'device_ms_factorisation': dms.get('of_which_factorisation'),

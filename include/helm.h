@@ -331,8 +331,9 @@ typedef struct helm_tuning {
     int    mg3_otf;            /* HELM_MG3_OTF           1     27-point apply rebuilds its coefficients from c, rho and the PML profiles (1: from 4 right-hand sides per workgroup up, 2: always) */
     double mg3_omega;          /* HELM_MG3_OMEGA         0.9   Jacobi damping of the smoother */
     /* host-side waits */
-    double sync_spin_ms;       /* HELM_SYNC_SPIN_MS      20    a wait of the library polls for this long before it blocks on the runtime's interrupt (0: blocks at once); a thread asleep there is
-                                                               sometimes woken 50-80 ms late on this platform, and the kernels a wait sits behind take 0.03-3 ms */
+    double sync_spin_ms;       /* HELM_SYNC_SPIN_MS      0     a wait of the library polls for this long before it blocks on the runtime's interrupt (saves the 20-50 us wake-up of each
+                                                               wait; costs a CPU per waiting thread -- leave it off under a container CPU quota, where a spinning thread spends the budget the
+                                                               launching threads need) */
 } helm_tuning;
 int helm_get_tuning(helm_tuning *out);          /* the values in force now (environment applied) */
 int helm_set_tuning(const helm_tuning *t);      /* NULL: defaults + environment again */

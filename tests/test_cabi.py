@@ -65,7 +65,7 @@ def test_tuning_struct_round_trip(helm_lib, monkeypatch):
             monkeypatch.delenv(k)
     t = _lib.tuning()
     assert (t.nd_leaf, t.nd_ws_gb, t.nd_sparse_rhs, t.nd_gjstep_min, t.nd_plans, t.ws_slots, t.mg3_keep_levels) == (8, 32.0, 1, 128, 6, 3, -1)
-    assert t.mg3_omega == 0.9 and t.nd_stable_safety == 8.0 and t.sync_spin_ms == 20.0      # first and last doubles: the layouts agree end to end
+    assert t.mg3_omega == 0.9 and t.nd_stable_safety == 8.0 and t.sync_spin_ms == 0.0      # first and last doubles: the layouts agree end to end
     monkeypatch.setenv('HELM_ND_LEAF', '6')
     monkeypatch.setenv('HELM_MG3_OMEGA', '0.7')
     t = _lib.tuning()

@@ -273,3 +273,22 @@ def test_a_prepare_step_that_breaks_outside_its_own_guard_does_not_hang_the_pipe
     import pytest
     with pytest.raises(RuntimeError):
         next(out)
+
+
+def test_blas_pools_are_single_threaded_while_a_pipeline_runs_and_restored_after():
+    """A threaded BLAS call beside a running pipeline leaves its workers spinning, and under a container CPU quota the scheduler then freezes the whole
+    process (problem.py, _norm2): the dispatcher holds the pools to one thread from start() until its last thread has finished, then gives the caller's
+    limits back."""
+    tpc = pytest.importorskip('threadpoolctl')
+    from zephyr_amd import dispatch
+
+    def blas_threads():
+        return [p['num_threads'] for p in tpc.threadpool_info() if p.get('user_api') == 'blas']
+    before = blas_threads()
+    if not before or max(before) < 2:
+        pytest.skip('no multi-threaded BLAS pool in this process')
+    seen = []
+    items = [dispatch.WorkItem((lambda _p: seen.append(blas_threads())), None) for _ in range(3)]
+    assert list(dispatch.pipelined(items, device=0, lookahead=1)) == [None] * 3
+    assert all(v == [1] * len(v) for v in seen), seen
+    assert blas_threads() == before

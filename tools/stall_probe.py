@@ -24,7 +24,15 @@ big = np.random.default_rng(0).standard_normal(N * 2).view(np.complex128)       
 small = np.arange(1000, dtype=np.int64)
 
 
+KEPT = []
+
+
 def job(mode):
+    if 'keep' in mode:                     # config 4 keeps a model's eight operators (factors resident) until the next model arrives, then drops them all at once
+        for o in KEPT:
+            del o.factors
+        del KEPT[:]
+
     def prep(f):
         op = za.Eurus(dict(cfg, freq=float(f), rtol=1e-10, batch=ns, device=0))
         op.prefactor()
@@ -48,12 +56,16 @@ def job(mode):
             x = d_u[:2, :128].cpu().numpy()
         if 'newmodel' in mode:
             pass
-        del op.factors
+        if 'keep' in mode:
+            KEPT.append(op)
+        else:
+            del op.factors
         return 0
     items = [dispatch.WorkItem(solve, (lambda f=f: prep(f))) for f in freqs]
     return list(dispatch.pipelined(items, device=0, lookahead=1))
 
 
+IDLE = float(os.environ.get('PROBE_IDLE_MS', '0')) * 1e-3       # host-only pause before every job: does a GPU that has been idle stall when work comes back?
 for mode in (sys.argv[2:] or ['plain', 'tsync', 'h2d_small', 'h2d_big', 'h2d_big_staged', 'empty', 'fromcoo', 'd2h', 'fromcoo+d2h+tsync']):
     job(mode)
     torch.cuda.synchronize()
@@ -62,6 +74,7 @@ for mode in (sys.argv[2:] or ['plain', 'tsync', 'h2d_small', 'h2d_big', 'h2d_big
     _lib.load().helm_debug_stall_watch(1, None, None)
     for _ in range(reps):
         _lib.runtime_stats(reset=True)
+        if IDLE > 0: time.sleep(IDLE)
         t0 = time.perf_counter()
         job(mode)
         torch.cuda.synchronize()

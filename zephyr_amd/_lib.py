@@ -245,24 +245,13 @@ def pinned_reserve(shape, count, dtype=np.complex128):
 
 
 def to_device(arr, dev, dtype=None):
-    """numpy array -> torch tensor on `dev` without handing pageable memory to the HIP runtime: arrays above 64 KB go through a pinned buffer of the
-    library (a copy straight from pageable memory makes the runtime register the caller's pages, and when numpy frees them -- or the host kernel moves
-    them -- the driver takes every queue of the process off the GPU for 60-80 ms while it revalidates the registration; include/helm.h, helm_set_model)."""
+    'numpy array -> torch tensor on `dev` (contiguous, cast to dtype if given)'
     import torch
-    a = np.ascontiguousarray(arr, dtype=dtype)
-    if a.nbytes <= (64 << 10):
-        return torch.from_numpy(a).to(dev)
-    p = pinned_empty(a.shape, a.dtype)
-    np.copyto(p, a)
-    t = torch.from_numpy(p).to(dev, non_blocking=True)
-    wait_torch_stream(dev)                # (the copy has completed: the pinned buffer goes back to the pool)
-    del p
-    return t
+    return torch.from_numpy(np.ascontiguousarray(arr, dtype=dtype)).to(dev)
 
 
 def wait_torch_stream(dev, spin_ms=None):
-    """torch.cuda.current_stream(dev).synchronize() that polls before it blocks (helm_tuning.sync_spin_ms): a thread asleep in the runtime's blocking wait is
-    sometimes woken 50-80 ms late on this platform (include/helm.h, sync_spin_ms)."""
+    """torch.cuda.current_stream(dev).synchronize(), polling first when helm_tuning.sync_spin_ms says so (default: it does not; include/helm.h)."""
     import time
     import torch
     st = torch.cuda.current_stream(dev)

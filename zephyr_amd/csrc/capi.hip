@@ -95,10 +95,10 @@ struct SyncTimer {
     }
 };
 }
-// Waits spin before they block (helm_tuning.sync_spin_ms, default 20 ms): the blocking waits of the runtime sleep on an interrupt, and on this platform a thread
-// that sleeps there is sometimes woken 50-80 ms late -- both pipeline threads at once, about once per 100-150 ms of a job of small kernels (round 6: the
-// config-4 gradient step lost 60-80 of its 110-140 ms to ONE such wake-up per dpred / Jtvec; with any thread of the process spinning it never happened).
-// The kernels a wait of this library sits behind take 0.03-3 ms, so the poll is where the wait ends; what outlasts the budget blocks as before.
+// A wait may poll before it blocks (helm_tuning.sync_spin_ms, default 0 = block at once).  Round 6 built this while hunting 60-80 ms stalls of the config-4
+// gradient step in the belief that threads asleep on the runtime's interrupt were woken late; the stalls were the container's CPU quota freezing the process
+// (zephyr_amd/problem.py, _norm2), which a polling thread makes worse, not better: under a quota every spinning thread is budget the launching threads
+// do not have.  Kept as an option for hosts without one (the poll saves the 20-50 us wake-up of each of the ~30 waits of a work item).
 static inline void cpu_relax() {
 #if defined(__x86_64__) || defined(__i386__)
     __builtin_ia32_pause();
@@ -273,7 +273,7 @@ static helm_tuning tuning_from_env() {
     t.mg3_bt_f32 = tune_i("HELM_MG3_BT_F32", 1);
     t.mg3_otf = tune_i("HELM_MG3_OTF", 1);
     t.mg3_omega = tune_d("HELM_MG3_OMEGA", 0.9);
-    t.sync_spin_ms = tune_d("HELM_SYNC_SPIN_MS", 20.0);
+    t.sync_spin_ms = tune_d("HELM_SYNC_SPIN_MS", 0.0);
     tuning_clamp(t);
     return t;
 }
@@ -518,8 +518,11 @@ void *helm_pool_alloc(int device, size_t bytes) {
     if (bytes == 0) bytes = 1;
     {
         std::lock_guard<std::mutex> lk(g_pool.mu);
-        auto it = g_pool.idle.lower_bound(std::make_pair(device, bytes));
-        if (it != g_pool.idle.end() && it->first.first == device && it->first.second <= (bytes < ((size_t)64 << 20) ? 2 * bytes + ((size_t)1 << 20) : bytes + bytes / 8)) {
+        // from 64 MB up: a buffer of the request's own size class only (the GB-sized factor, scratch and wavefield buffers must not take each other's places: a
+        // request that finds its class taken by a neighbour allocates, and a 4-GB hipMalloc inside a job is what the pool exists to prevent)
+        const bool big = bytes >= ((size_t)64 << 20);
+        auto it = big ? g_pool.idle.find(std::make_pair(device, pool_size_class(bytes))) : g_pool.idle.lower_bound(std::make_pair(device, bytes));
+        if (it != g_pool.idle.end() && it->first.first == device && (big || it->first.second <= 2 * bytes + ((size_t)1 << 20))) {
             void *p = it->second; g_pool.held[device] -= it->first.second; g_pool.idle.erase(it); return p;
         }
     }
@@ -699,46 +702,17 @@ extern "C" int helm_last_timing(const helm_op *op, helm_timing *out) { if (!op |
 extern "C" int helm_num_blocks(const helm_op *op) { return op ? op->nblocks : HELM_ERR_ARG; }
 extern "C" long long helm_num_points(const helm_op *op) { return op ? op->N : HELM_ERR_ARG; }
 
-// Host array -> device through a pinned buffer of the library (recycled by size): the caller's pages are never handed to the runtime.  A copy of a few MB
-// straight from pageable memory makes the runtime pin the caller's pages in place (a user-pointer registration), and when those pages go away or move
-// afterwards -- numpy frees the temporary, the host kernel migrates or compacts the page -- the driver takes EVERY queue of the process off the GPU until the
-// registration has been revalidated: 60-80 ms with nothing running, once per dpred / Jtvec of the config-4 job (round 6: found with HELM_SYNC_TRACE, any
-// host-side wait of either thread could be the one that sat through it).  Chunked, two buffers: the memcpy of chunk k+1 runs beside the DMA of chunk k.
-static int upload_staged(helm_op *op, void *dst, const void *src, size_t bytes) {
-    const size_t chunk = (size_t)4 << 20;
-    char *buf[2] = {(char *)helm_hostpool_alloc(chunk), (char *)helm_hostpool_alloc(chunk)};
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    int rc = HELM_OK;
-    if (!buf[0] || !buf[1] || hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) != hipSuccess) rc = HELM_ERR_DEVICE;
-    bool used[2] = {false, false};
-    for (size_t off = 0, k = 0; off < bytes && rc == HELM_OK; off += chunk, ++k) {
-        const int b = (int)(k & 1);
-        const size_t n = std::min(chunk, bytes - off);
-        if (used[b] && hipEventSynchronize(ev[b]) != hipSuccess) { rc = HELM_ERR_DEVICE; break; }
-        memcpy(buf[b], (const char *)src + off, n);
-        if (hipMemcpyAsync((char *)dst + off, buf[b], n, hipMemcpyHostToDevice, op->stream) != hipSuccess || hipEventRecord(ev[b], op->stream) != hipSuccess) { rc = HELM_ERR_DEVICE; break; }
-        used[b] = true;
-    }
-    for (int b = 0; b < 2; ++b) {
-        if (used[b]) (void)hipEventSynchronize(ev[b]);
-        if (ev[b]) hipEventDestroy(ev[b]);
-        helm_hostpool_free(buf[b], chunk);
-    }
-    if (rc) (void)hipGetLastError();
-    return rc;
-}
-
 extern "C" int helm_set_model(helm_op *op, const double *c, const double *rho, const double *theta, const double *eps, const double *delta) {
     helm_tuning_refresh();
     if (!op || !c) return HELM_ERR_ARG;
     HIP_TRY(op, hipSetDevice(op->device));
     const size_t N = (size_t)op->N;
-    if (upload_staged(op, op->d_c, c, N * sizeof(cplx))) HELM_FAIL(op, HELM_ERR_DEVICE, "model upload failed");
+    HIP_TRY(op, hipMemcpyAsync(op->d_c, c, N * sizeof(cplx), hipMemcpyHostToDevice, op->stream));
     if (!rho) {   // Gardner default 310 * Re(c)^0.25  (discretization.py:70), evaluated on the device
         const int rcg = helm_launch_gardner_rho(op);
         if (rcg) return rcg;
     } else {
-        if (upload_staged(op, op->d_rho, rho, N * sizeof(double))) HELM_FAIL(op, HELM_ERR_DEVICE, "model upload failed");
+        HIP_TRY(op, hipMemcpyAsync(op->d_rho, rho, N * sizeof(double), hipMemcpyHostToDevice, op->stream));
     }
     op->aniso = false;
     bool m3zero = true;
@@ -746,7 +720,7 @@ extern "C" int helm_set_model(helm_op *op, const double *c, const double *rho, c
         auto up = [&](double *&dst, const double *src) -> int {
             if (!src) { if (dst) { helm_pool_free(op->device, dst, N * sizeof(double)); dst = nullptr; } return 0; }
             if (!dst) { dst = (double *)helm_pool_alloc(op->device, N * sizeof(double)); if (!dst) return -1; }
-            return upload_staged(op, dst, src, N * sizeof(double)) ? -1 : 0;
+            return hipMemcpyAsync(dst, src, N * sizeof(double), hipMemcpyHostToDevice, op->stream) != hipSuccess ? -1 : 0;
         };
         if (up(op->d_theta, theta) || up(op->d_eps, eps) || up(op->d_delta, delta)) HELM_FAIL(op, HELM_ERR_DEVICE, "anisotropy upload failed");
         op->aniso = theta || eps || delta;

@@ -75,6 +75,39 @@ class Throttle(object):
         self._closed = True
 
 
+class _QuietBlas(object):
+    """While a pipeline runs, BLAS / OpenMP pools of the process are held to one thread (threadpoolctl, when it is installed): a threaded BLAS call made from
+    a work item -- or by the caller while it consumes results -- leaves its workers spinning for ~100 ms, and under a container CPU quota that freezes every thread
+    of the process, the ones feeding the GPU included, for most of a scheduler period (zephyr_amd/problem.py, _norm2).  Nested use counts; the limits the caller
+    had come back when the last pipeline has joined.  Nothing here can stop workers that were already spinning when the pipeline started: set
+    OPENBLAS_NUM_THREADS / OMP_NUM_THREADS for the process where a quota is in force."""
+    _lock = threading.Lock()
+    _depth = 0
+    _limiter = None
+
+    @classmethod
+    def enter(cls):
+        with cls._lock:
+            cls._depth += 1
+            if cls._depth == 1 and os.environ.get('HELM_QUIET_BLAS', '1') != '0':
+                try:
+                    from threadpoolctl import threadpool_limits
+                    cls._limiter = threadpool_limits(limits=1)
+                except Exception:
+                    cls._limiter = None
+
+    @classmethod
+    def leave(cls):
+        with cls._lock:
+            cls._depth = max(0, cls._depth - 1)
+            if cls._depth == 0 and cls._limiter is not None:
+                try:
+                    cls._limiter.restore_original_limits()
+                except Exception:
+                    pass
+                cls._limiter = None
+
+
 class WorkItem(object):
     """prepare() runs on the device's prepare thread (may be None), solve(prepared) on its solve thread;
     `future` receives solve's return value or the first exception of either step."""
@@ -107,26 +140,42 @@ class DevicePipeline(object):
         if not items:
             return
         if self.lookahead == 0:
-            t = threading.Thread(target=self._serial, args=(items,), name='helm-dev%d' % self.device)
-            t.daemon = True
-            t.start()
-            self._threads = [t]
+            self._launch([threading.Thread(target=self._guard(self._serial), args=(items,), name='helm-dev%d' % self.device)])
             return
         ready = queue.Queue(maxsize=max(self.lookahead, self.solvers))
         # strict: item k+1 is prepared while item k is being solved and not before (a queue of one lets the prepare thread start on item k+2
         # as soon as item k+1 waits in it) -- for operators whose preparation is heavy on the GPU and in memory (3-D preconditioners)
         gate = threading.Semaphore(1) if self.strict else None
-        tp = threading.Thread(target=self._prepare_loop, args=(items, ready, gate), name='helm-prep%d' % self.device)
+        tp = threading.Thread(target=self._guard(self._prepare_loop), args=(items, ready, gate), name='helm-prep%d' % self.device)
         if self.solvers == 1:
-            tss = [threading.Thread(target=self._solve_loop, args=(len(items), ready, gate), name='helm-solve%d' % self.device)]
+            tss = [threading.Thread(target=self._guard(self._solve_loop), args=(len(items), ready, gate), name='helm-solve%d' % self.device)]
         else:
             left = [len(items)]
             lock = threading.Lock()
-            tss = [threading.Thread(target=self._solve_shared, args=(left, lock, ready), name='helm-solve%d.%d' % (self.device, k)) for k in range(self.solvers)]
-        for t in [tp] + tss:
+            tss = [threading.Thread(target=self._guard(self._solve_shared), args=(left, lock, ready), name='helm-solve%d.%d' % (self.device, k)) for k in range(self.solvers)]
+        self._launch([tp] + tss)
+
+    def _launch(self, threads):
+        'start the pipeline\'s threads; the process-wide BLAS limit (_QuietBlas) is held from now until the LAST of them has finished its items'
+        self._alive = len(threads)
+        self._alive_lock = threading.Lock()
+        _QuietBlas.enter()
+        for t in threads:
             t.daemon = True
             t.start()
-        self._threads = [tp] + tss
+        self._threads = threads
+
+    def _guard(self, fn):
+        def run(*args):
+            try:
+                fn(*args)
+            finally:
+                with self._alive_lock:
+                    self._alive -= 1
+                    last = self._alive == 0
+                if last:
+                    _QuietBlas.leave()
+        return run
 
     def join(self):
         for t in self._threads:

@@ -27,6 +27,15 @@ from . import _lib
 EPS = 1e-15
 
 
+def _norm2(d):
+    """||d||_2 without BLAS.  np.linalg.norm hands a vector of this size to a threaded dot product, and OpenBLAS's workers (64 of them on a large host) then
+    spin for ~100 ms waiting for more work: under a container CPU quota (cgroup cpu.max, 16 CPUs on the GPU boxes of this project) that burns the period's
+    budget in 25 ms and the scheduler freezes EVERY thread of the process -- the ones feeding the GPU included -- for the remaining 75 ms.  Round 6: this one
+    call cost dpred / Jtvec 60-80 of their 110-140 ms (problem.py:51-66 compares the models the same way)."""
+    d = np.asarray(d)
+    return float(np.sqrt(np.add.reduce(np.square(d.real)) + (np.add.reduce(np.square(d.imag)) if np.iscomplexobj(d) else 0.0)))
+
+
 class HelmBaseProblem(BaseModelDependent, BaseSCCache):
 
     initMap = {
@@ -65,7 +74,7 @@ class HelmBaseProblem(BaseModelDependent, BaseSCCache):
         elif isinstance(m, (np.ndarray, np.inexact, complex, float)):
             m = np.asarray(m)
             old = np.asarray(self.systemConfig.get(loneKey, 0.))
-            if old.size != m.size or not np.linalg.norm(m.ravel() - old.ravel()) < EPS:
+            if old.size != m.size or not _norm2(m.ravel() - old.ravel()) < EPS:
                 self.systemConfig[loneKey] = m
                 self.clearCache()
         else:
