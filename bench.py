@@ -1115,7 +1115,7 @@ def main():
                 ('unprofiled_wfs', unprof),
                 ('timed_max_item_gap_ms', float(gaps.max())), ('timed_p50_item_ms', float(np.median(gaps))),
                 ('timed_cpu_throttled_ms', rt_timed['cpu_throttled_ms']), ('cpu_quota_cores', rt_timed['cpu_quota_cores']),
-                ('timed_dev_allocs', rt_timed['dev_allocs']), ('timed_first_launches', rt_timed['first_launches']),
+                ('timed_dev_allocs', rt_timed['dev_allocs']), ('timed_dev_alloc_ms', rt_timed['dev_alloc_ms']), ('timed_first_launches', rt_timed['first_launches']),
                 ('roofline_frac_serial', rl.get('frac')), ('two_roofs_frac', (rl.get('two_roofs') or {}).get('frac')),
                 ('stencil_frac', (out.get('stencil_roofline') or rl).get('frac')),
                 ('c4_dpred_s', c4d.get('dpred_seconds')), ('c4_jtvec_s', c4d.get('jtvec_seconds')), ('c4_gpu_ms', c4d.get('gpu_ms')),
@@ -1126,14 +1126,14 @@ def main():
                 ('rccl_ranks_seen', ranks_seen), ('gradient_allreduce_ms', c4d.get('gradient_allreduce_ms_512')),
                 ('ms_per_step_slowest_rank', max(rank_ms)),
                 ('strong_job_wfs', strong), ('c2_wfs_device', c2.get('device_wfs')),
-                ('dense_rhs_wfs', (out.get('every_front_computed') or {}).get('value')),
             ]
             assert len(flat) + len(cfgd) <= 24
             for k, v in flat:
                 cfgd[k] = float('%.6g' % v) if isinstance(v, float) else v
             more = {
                 'grid_n': n, 'freqs_this_run': len(agg['freqs']),
-                'timed_dev_alloc_ms': rt_timed['dev_alloc_ms'], 'timed_first_launch_ms': rt_timed['first_launch_ms'], 'timed_dev_alloc_mb': rt_timed['dev_alloc_bytes'] / 1e6,
+                'dense_rhs_wfs': (out.get('every_front_computed') or {}).get('value'),
+                'timed_first_launch_ms': rt_timed['first_launch_ms'], 'timed_dev_alloc_mb': rt_timed['dev_alloc_bytes'] / 1e6,
                 'timed_pinned_allocs': rt_timed['host_allocs'], 'timed_cpu_throttled_periods': rt_timed['cpu_throttled_periods'],
                 'timed_slow_syncs': rt_timed['slow_syncs'], 'timed_worst_sync_ms': rt_timed['worst_sync_ms'],
                 'timed_events_created': rt_timed['events_created'], 'timed_streams_created': rt_timed['streams_created'],

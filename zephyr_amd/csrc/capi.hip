@@ -201,6 +201,7 @@ extern "C" int helm_debug_stall_watch(int start, double *worst_gap_ms, long long
     if (gaps_over_5ms) *gaps_over_5ms = g_watch_gaps.load();
     return HELM_OK;
 }
+void helm_pool_slab_reserve(int device);
 // Resolve every kernel of the library on `device` (code objects loaded, dispatch records built) without launching anything.  Idempotent; runs by itself
 // when the first operator of a device is created (HELM_WARM=0 leaves it to the caller).
 extern "C" int helm_warm(int device) {
@@ -216,6 +217,7 @@ extern "C" int helm_warm(int device) {
         if (hipFuncGetAttributes(&at, r.fast[i].load()->fn) == hipSuccess) rtc().resolved += 1; else (void)hipGetLastError();
     }
     upto = n;
+    helm_pool_slab_reserve(device);
     rtc().warm_us += (long long)((wall_ms() - t0) * 1e3);
     return n;
 }
@@ -478,16 +480,19 @@ size_t helm_pool_idle_bytes(int device) {
     return it == g_pool.held.end() ? 0 : it->second;
 }
 static void pool_forget(void *p);       // (g_pool.mu held) the buffer has gone back to the driver
+static std::map<void *, bool> g_carved;  // blocks that are pieces of a slab (see slab_carve; guarded by g_pool.mu)
 // give this device's idle buffers back to the driver (the current device must be `device`)
 static void pool_flush_device(int device) {
     std::lock_guard<std::mutex> lk(g_pool.mu);
     AllocTrace trf("pool flush", g_pool.held[device]);
+    size_t kept = 0;
     for (auto it = g_pool.idle.lower_bound(std::make_pair(device, (size_t)0)); it != g_pool.idle.end() && it->first.first == device; ) {
+        if (g_carved.count(it->second)) { kept += it->first.second; ++it; continue; }       // (a piece of a slab: stays idle)
         hipFree(it->second);
         pool_forget(it->second);
         it = g_pool.idle.erase(it);
     }
-    g_pool.held[device] = 0;
+    g_pool.held[device] = kept;
 }
 // hipMalloc that, under memory pressure, empties the device's idle pool and tries once more -- for every allocation of the library that does
 // not go through the size-keyed pool itself (scratch slots, temporaries of the host-buffer entry points, plans)
@@ -508,6 +513,43 @@ hipError_t helm_malloc_retry(int device, void **p, size_t bytes) {
 // goes back under what it can hold, not under what it was asked for.
 static std::map<void *, size_t> g_pool_capacity;        // every live buffer that came out of helm_pool_alloc: what it can hold (guarded by g_pool.mu)
 static void pool_forget(void *p) { g_pool_capacity.erase(p); }
+// Small buffers (size class up to 16 MB: per-operator flags, estimates, split-K partials, the pivoted-LU storage of ill-conditioned fronts ...) come out of
+// slabs of 512 MB, one hipMalloc each, carved by a bump pointer and recycled through the idle table like every other buffer.  Their sizes follow the operator
+// -- how many fronts a frequency has flagged, which products split their inner dimension -- so a job met half a dozen new ones per pass over its frequencies
+// however long the warm-up (round 6: 6 hipMalloc calls, 16 MB, in the timed region of every bench run).  A carved block is never handed back to the driver by
+// itself; slabs live as long as the process (helm_trim keeps them: 512 MB each, a handful at most).
+static const size_t kSlabBytes = (size_t)512 << 20, kSlabMaxBlock = (size_t)16 << 20;
+struct Slab { char *base = nullptr; size_t used = 0; };
+static std::map<int, std::vector<Slab>> g_slabs;                   // guarded by g_pool.mu
+static bool slab_add(int device) {                                 // (g_pool.mu NOT held: the driver call may take milliseconds)
+    void *b = nullptr;
+    AllocTrace tr("pool slab", kSlabBytes);
+    if (helm_malloc_retry(device, &b, kSlabBytes) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    Slab sl; sl.base = (char *)b;
+    g_slabs[device].push_back(sl);
+    return true;
+}
+static void *slab_carve(int device, size_t cap) {
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        {
+            std::lock_guard<std::mutex> lk(g_pool.mu);
+            std::vector<Slab> &v = g_slabs[device];
+            if (!v.empty()) {
+                Slab &sl = v.back();
+                const size_t off = (sl.used + 255) & ~(size_t)255;
+                if (off + cap <= kSlabBytes) { sl.used = off + cap; void *p = sl.base + off; g_pool_capacity[p] = cap; g_carved[p] = true; return p; }
+            }
+        }
+        if (!slab_add(device)) return nullptr;
+    }
+    return nullptr;
+}
+// the first slab of a device, brought into being by helm_warm (i.e. when the first operator of the device is created), not by whichever solve first misses the pool
+static void slab_reserve(int device) {
+    { std::lock_guard<std::mutex> lk(g_pool.mu); if (!g_slabs[device].empty()) return; }
+    (void)slab_add(device);
+}
 static size_t pool_size_class(size_t bytes) {
     if (bytes <= 4096) return 4096;
     int top = 63 - __builtin_clzll((unsigned long long)(bytes - 1));      // bytes - 1 in [2^top, 2^(top+1))
@@ -518,22 +560,33 @@ void *helm_pool_alloc(int device, size_t bytes) {
     if (bytes == 0) bytes = 1;
     {
         std::lock_guard<std::mutex> lk(g_pool.mu);
-        // from 64 MB up: a buffer of the request's own size class only (the GB-sized factor, scratch and wavefield buffers must not take each other's places: a
-        // request that finds its class taken by a neighbour allocates, and a 4-GB hipMalloc inside a job is what the pool exists to prevent)
-        const bool big = bytes >= ((size_t)64 << 20);
-        auto it = big ? g_pool.idle.find(std::make_pair(device, pool_size_class(bytes))) : g_pool.idle.lower_bound(std::make_pair(device, bytes));
-        if (it != g_pool.idle.end() && it->first.first == device && (big || it->first.second <= 2 * bytes + ((size_t)1 << 20))) {
+        // from 64 MB up a buffer of the request's own size class is preferred (the GB-sized factor, scratch and wavefield buffers keep to their own kind);
+        // failing that -- and for small requests from the start -- the smallest idle buffer that holds the request and is at most twice its size (+ 1 MB).
+        // (Measured, round 6: with the own-class rule alone the bench job allocated 5.2 GB inside its timed region in every run -- 0.6 ms on one box, 122 ms
+        // on another, which is the kind of stall that cost round 5's driver run a fifth of its headline; with the fall-back: nothing above 8 MB.)
+        auto it = g_pool.idle.end();
+        if (bytes >= ((size_t)64 << 20)) it = g_pool.idle.find(std::make_pair(device, pool_size_class(bytes)));
+        if (it == g_pool.idle.end()) {
+            it = g_pool.idle.lower_bound(std::make_pair(device, bytes));
+            if (it != g_pool.idle.end() && (it->first.first != device || it->first.second > 2 * bytes + ((size_t)1 << 20))) it = g_pool.idle.end();
+        }
+        if (it != g_pool.idle.end()) {
             void *p = it->second; g_pool.held[device] -= it->first.second; g_pool.idle.erase(it); return p;
         }
     }
     void *p = nullptr;
     const size_t cap = pool_size_class(bytes);
+    if (cap <= kSlabMaxBlock) {                 // small buffers are carved out of a slab: no driver call however many new sizes a frequency brings
+        p = slab_carve(device, cap);
+        if (p) return p;
+    }
     AllocTrace tr("pool hipMalloc", cap);
     if (helm_malloc_retry(device, &p, cap) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lk(g_pool.mu);
     g_pool_capacity[p] = cap;
     return p;
 }
+void helm_pool_slab_reserve(int device) { slab_reserve(device); }
 void helm_pool_free(int device, void *p, size_t bytes) {
     if (!p) return;
     {
@@ -543,7 +596,7 @@ void helm_pool_free(int device, void *p, size_t bytes) {
         else g_pool_capacity[p] = bytes;
         const size_t cap = pool_cap_bytes(device);
         size_t &held = g_pool.held[device];
-        if (bytes >= kPoolMinBytes && (held + bytes <= cap || bytes < ((size_t)1 << 20))) {
+        if (g_carved.count(p) || (bytes >= kPoolMinBytes && (held + bytes <= cap || bytes < ((size_t)1 << 20)))) {
             g_pool.idle.insert(std::make_pair(std::make_pair(device, bytes), p)); held += bytes;
             return;
         }
@@ -662,8 +715,13 @@ extern "C" int helm_trim(void) {
                 w.ptr = nullptr; w.bytes = 0;
             }
         std::lock_guard<std::mutex> lp(g_pool.mu);
-        for (auto &kv : g_pool.idle) { hipSetDevice(kv.first.first); hipFree(kv.second); pool_forget(kv.second); }
-        g_pool.idle.clear(); g_pool.held.clear();
+        std::map<int, size_t> kept;
+        for (auto it = g_pool.idle.begin(); it != g_pool.idle.end(); ) {
+            if (g_carved.count(it->second)) { kept[it->first.first] += it->first.second; ++it; continue; }       // (pieces of a slab stay idle: slabs live as long as the process)
+            hipSetDevice(it->first.first); hipFree(it->second); pool_forget(it->second);
+            it = g_pool.idle.erase(it);
+        }
+        g_pool.held = kept;
     }
     (void)hipSetDevice(cur);
     return helm_host_trim();
