@@ -61,6 +61,6 @@ def test_bench_gpus_2_runs_two_ranks(helm_lib):
     assert cfg['c4_dpred_s'] > 0 and cfg['c4_jtvec_s'] > 0 and cfg['gradient_allreduce_ms'] > 0 and more['c4_allreduce_ms_1024'] > 0
     assert cfg['strong_job_wfs'] > 0
     # the timed region created nothing: pools, events, pinned records and every kernel's dispatch record exist before it starts
-    for k in ('timed_max_item_gap_ms', 'timed_p50_item_ms', 'timed_dev_allocs', 'timed_pinned_allocs', 'timed_first_launches'):
+    for k in ('timed_max_item_gap_ms', 'timed_p50_item_ms', 'timed_dev_allocs', 'timed_dev_alloc_ms', 'timed_cpu_throttled_ms', 'cpu_quota_cores', 'timed_first_launches'):
         assert k in cfg
     assert rec['config4']['gradient_repeatable_rel'] <= 1e-12
