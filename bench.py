@@ -563,6 +563,9 @@ def main():
     ap.add_argument('--config5-rtol', type=float, default=1e-8)
     ap.add_argument('--no-config2', action='store_true', help='skip the config-2 leg (512^2, 8 freqs x 64 sources; ~10 s)')
     ap.add_argument('--no-config4', action='store_true', help='skip the config-4 leg (FWI gradient step at 512^2; ~15 s)')
+    ap.add_argument('--group', type=int, default=int(os.environ.get('HELM_BENCH_GROUP', '2')),
+                    help='work items whose factorisations the device pipeline enqueues together (helm_prefactor_many: the fronts of `group` frequencies in the same '
+                         'batched launches; 1: every frequency factored by itself, rounds 1-5)')
     ap.add_argument('--streams', type=int, default=1, help='work items in flight per GPU (host threads, one operator handle / HIP stream each)')
     args = ap.parse_args()
 
@@ -636,8 +639,9 @@ def main():
         sc.update(freq=float(freqs[fi]), rtol=args.rtol, maxit=400000, method=args.method, batch=B, device=local)
         op = Eurus(sc)
         op.setProfiling(profile and os.environ.get('HELM_BENCH_NOPROFILE', '0') != '1')
-        if args.pipeline:
+        if args.pipeline and args.group <= 1:
             op.prefactor()               # launches only: the factorisation runs beside the solves of the previous item
+        # (--group G > 1: the dispatcher calls prefactor_many on G prepared operators at once, zephyr_amd.dispatch)
         tl.append(('prepare done', w, time.perf_counter()))
         return op
 
@@ -673,8 +677,9 @@ def main():
             return [run_item(w, profile) for w in ws]
         from zephyr_amd import dispatch
         items = [dispatch.WorkItem((lambda op, w=w: solve_item(w, op)), (lambda w=w: prepare_item(w, profile))) for w in ws]
+        from zephyr_amd import prefactor_many
         return list(dispatch.pipelined(items, device=local, lookahead=int(os.environ.get('HELM_BENCH_LOOKAHEAD', '1')), strict=os.environ.get('HELM_BENCH_STRICT', '0') == '1',
-                                       solvers=nsolvers))
+                                       solvers=nsolvers, group=args.group, group_prepare=prefactor_many if args.group > 1 else None))
 
     def barrier():
         torch.cuda.synchronize()
@@ -893,8 +898,12 @@ def main():
             'ms_per_step': 1e3 * elapsed / nsteps, 'higher_is_better': True, 'scaling': args.scaling,
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'timed_region': 'K work items through the device pipeline with per-launch HIP events on; `unprofiled` repeats the same K items with the events off',
-            'pipeline': ('device pipeline of zephyr_amd.dispatch (MultiFreq parallel mode): item k+1 is created, assembled and its factorisation enqueued '
+            'pipeline': (('device pipeline of zephyr_amd.dispatch (MultiFreq parallel mode): items k+1 .. k+%d are created and assembled, their factorisations enqueued TOGETHER '
+                          '(helm_prefactor_many: the fronts of %d frequencies in the same batched launches, high-priority stream) while the items before them are being solved'
+                          % (args.group, args.group)) if args.pipeline and args.group > 1 else
+                         'device pipeline of zephyr_amd.dispatch (MultiFreq parallel mode): item k+1 is created, assembled and its factorisation enqueued '
                          '(helm_prefactor, high-priority stream) while item k is being solved' if args.pipeline else 'off: items strictly one after the other'),
+            'factorisations_per_launch_set': args.group if args.pipeline else 1,
             'item_done_ms': item_done_ms, 'first_items_timeline_ms': first_items,
             'unprofiled': None if elapsed_plain is None else {'value': wavefields / elapsed_plain, 'ms_per_step': 1e3 * elapsed_plain / nsteps},
             'strong_scaling_job': strong_job,

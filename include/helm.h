@@ -181,6 +181,13 @@ int helm_prefactor(helm_op *op);
  * factorisation of its directly solved level are built NOW, in the calling thread (hundreds of ms): a dispatcher's prepare thread calls this
  * for frequency k+1 while another handle iterates on frequency k.  A hint like helm_prefactor. */
 int helm_prefactor_n(helm_op *op, int nrhs);
+/* helm_prefactor for n operators of the same grid on one GPU at once (2-D; n <= 4): their factorisations are enqueued TOGETHER -- the elimination tree depends
+ * on the grid alone, so the fronts of n frequencies ride in the same strided batches, batch index = front x frequency.  The top of the tree is a chain of small
+ * dependent launches that leaves most of the chip idle (88 block steps of ~30 us at 1024^2, gather-bound levels of 8-16 unknowns, products over one to four
+ * fronts); that chain is now walked once per set.  Each operator's factors come out bit for bit what helm_prefactor would have made of them and are solved with
+ * as usual, one operator at a time; the launches go to the high-priority stream of ops[0].  A hint: operators that do not qualify (3-D, coupled TTI, factors
+ * already there, different grids) are prefactored one by one.  The reference overlaps frequencies with a process pool (distributors.py:161-168). */
+int helm_prefactor_many(helm_op **ops, int n);
 /* The relative tolerance the solves on this operator will ask for, told before its factors are built (helm_prefactor takes no options):
  * fronts whose condition estimate exceeds rtol / (8 eps) are re-eliminated with a pivoted LU so that one pass meets rtol.  Default 1e-10;
  * a solve that builds the factors itself uses its own opts->rtol.  Counterpart of the `Solver` the reference receives through its
@@ -315,6 +322,7 @@ typedef struct helm_tuning {
     int    nd_xcd_map;         /* HELM_ND_XCDMAP         2     workgroup ids regrouped so that a front's tiles share an XCD (0 off, 1 column tiles only) */
     int    nd_plans;           /* HELM_ND_PLANS          6     elimination-tree plans cached per device */
     int    nd_direct_out;      /* HELM_ND_DIRECT_OUT     1     back substitution writes the caller's wavefield array itself (node-major calls) */
+    int    nd_many;            /* HELM_ND_MANY           1     helm_prefactor_many factors its operators in the same launches (0: one after the other) */
     int    nd_leaf_idle;       /* HELM_ND_LEAF_IDLE      1     sparse right-hand sides: idle leaf blocks and small separator fronts of the back substitution go to kernels that issue all their loads at once; the forward pass deals its separator levels from lists of active (front, block) pairs */
     /* dispatch / memory */
     int    auto_direct;        /* HELM_AUTO_DIRECT       1     HELM_AUTO takes the direct path in 2-D */

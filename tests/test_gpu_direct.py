@@ -662,3 +662,53 @@ def test_short_product_kernels_and_listed_levels_change_no_bit(helm_lib, monkeyp
     assert np.array_equal(out['11'], out['01'])
     assert np.array_equal(out['11'], out['10'])
     assert not np.any(out['11'][:, 100])
+
+
+@pytest.mark.parametrize('Disc,nf', [('Eurus', 2), ('Eurus', 3), ('MiniZephyr', 4)])
+def test_operators_factored_in_the_same_launches_match_one_at_a_time_bit_for_bit(helm_lib, Disc, nf):
+    """helm_prefactor_many: the fronts of nf frequencies ride in the same strided batches (batch index = front x frequency, factors interleaved in one buffer).
+    Every choice that depends on the batch size is made as for one frequency, so each operator's wavefields must equal those of the one-at-a-time
+    factorisation in every bit -- and so must a second solve on the same factors and a solve after one of the set's operators has been destroyed.
+    Counterpart: the reference factors one frequency per pool worker (zephyr/backend/distributors.py:161-168, discretization.py:78-103)."""
+    import zephyr_amd as za
+    from zephyr_amd.models import marmousi_like
+    n = 200
+    c = marmousi_like(n, n, 12.)
+    cls = getattr(za, Disc)
+    freqs = [4.0, 6.5, 9.0, 11.0][:nf]
+    locs = np.stack([np.linspace(300., 2000., 70), np.full(70, 24.)], axis=1)
+    base = dict(nx=n, nz=n, dx=12., dz=12., c=c, nPML=10, rtol=1e-10, method='direct')
+    q = za.SparseKaiserSource(base)(locs)
+    single = []
+    for f in freqs:
+        op = cls(dict(base, freq=f))
+        op.prefactor()
+        single.append(np.array(op * q))
+        del op.factors
+    ops = [cls(dict(base, freq=f)) for f in freqs]
+    za.prefactor_many(ops)
+    together = [np.array(op * q) for op in ops]
+    for a, b, op in zip(single, together, ops):
+        assert np.array_equal(a, b)
+        assert all(i['status'] == 0 and i['relres'] <= 1e-10 for i in op.lastInfo)
+    del ops[0].factors                                  # the shared buffer lives on for the others
+    for a, op in zip(single[1:], ops[1:]):
+        assert np.array_equal(a, np.array(op * q))
+
+
+def test_prefactor_many_falls_back_for_operators_it_cannot_take_together(helm_lib):
+    'different grids, a coupled TTI operator, an operator that already has factors: prefactored one by one, results as always'
+    import zephyr_amd as za
+    from zephyr_amd.models import marmousi_like
+    q1 = za.SimpleSource(dict(nx=96, nz=96, dx=10., dz=10.))(np.array([[400., 300.]]))
+    q2 = za.SimpleSource(dict(nx=80, nz=112, dx=10., dz=10.))(np.array([[400., 300.]]))
+    a = za.Eurus(dict(nx=96, nz=96, dx=10., dz=10., c=marmousi_like(96, 96, 10.), freq=8., rtol=1e-10, method='direct'))
+    b = za.Eurus(dict(nx=80, nz=112, dx=10., dz=10., c=marmousi_like(112, 80, 10.), freq=8., rtol=1e-10, method='direct'))
+    ua, ub = np.array(a * q1), np.array(b * q2)
+    del a.factors, b.factors
+    a2 = za.Eurus(dict(nx=96, nz=96, dx=10., dz=10., c=marmousi_like(96, 96, 10.), freq=8., rtol=1e-10, method='direct'))
+    b2 = za.Eurus(dict(nx=80, nz=112, dx=10., dz=10., c=marmousi_like(112, 80, 10.), freq=8., rtol=1e-10, method='direct'))
+    za.prefactor_many([a2, b2])
+    assert np.array_equal(ua, np.array(a2 * q1)) and np.array_equal(ub, np.array(b2 * q2))
+    za.prefactor_many([a2, b2])                          # factors are there: a no-op
+    assert np.array_equal(ua, np.array(a2 * q1))

@@ -6,7 +6,7 @@ Host classes mirror zephyr.backend; all assembly and solves run in libhelm (HIP,
 from .analytical import AnalyticalHelmholtz
 from .base import BaseModelDependent, BaseAnisotropic
 from .config import AttributeMapper, BaseSCCache, SCFilter
-from .discretization import BaseDiscretization, DiscretizationWrapper
+from .discretization import BaseDiscretization, DiscretizationWrapper, prefactor_many
 from .distributors import BaseDist, BaseMPDist, MultiFreq, SerialMultiFreq, ViscoMultiFreq
 from .eurus import Eurus, EurusHD
 from .helm3d import Helm3D
@@ -22,7 +22,7 @@ def trim():
 
 __all__ = [
     'AnalyticalHelmholtz', 'BaseModelDependent', 'BaseAnisotropic', 'AttributeMapper', 'BaseSCCache', 'SCFilter',
-    'BaseDiscretization', 'DiscretizationWrapper', 'BaseDist', 'BaseMPDist', 'MultiFreq', 'SerialMultiFreq',
+    'BaseDiscretization', 'DiscretizationWrapper', 'prefactor_many', 'BaseDist', 'BaseMPDist', 'MultiFreq', 'SerialMultiFreq',
     'ViscoMultiFreq', 'Eurus', 'EurusHD', 'Helm3D', 'MiniZephyr', 'MiniZephyrHD', 'MiniZephyr25D', 'FakeSource', 'SimpleSource',
     'StackedSimpleSource', 'SparseKaiserSource', 'KaiserSource', 'AnisotropicKaiserSource', 'trim',
 ]

@@ -49,7 +49,7 @@ class Tuning(ctypes.Structure):
     _fields_ = [('nd_leaf', ctypes.c_int), ('nd_ws_gb', ctypes.c_double), ('nd_sparse_rhs', ctypes.c_int), ('nd_stable', ctypes.c_int),
                 ('nd_stable_thr', ctypes.c_double), ('nd_stable_safety', ctypes.c_double), ('nd_fused_leaf', ctypes.c_int),
                 ('nd_fused_leaf_min', ctypes.c_int), ('nd_gjstep', ctypes.c_int), ('nd_gjstep_min', ctypes.c_int), ('nd_overlap', ctypes.c_int),
-                ('nd_xcd_map', ctypes.c_int), ('nd_plans', ctypes.c_int), ('nd_direct_out', ctypes.c_int), ('nd_leaf_idle', ctypes.c_int), ('auto_direct', ctypes.c_int),
+                ('nd_xcd_map', ctypes.c_int), ('nd_plans', ctypes.c_int), ('nd_direct_out', ctypes.c_int), ('nd_many', ctypes.c_int), ('nd_leaf_idle', ctypes.c_int), ('auto_direct', ctypes.c_int),
                 ('auto_mg3', ctypes.c_int), ('prof_ext', ctypes.c_int), ('ws_slots', ctypes.c_int), ('pf_prio', ctypes.c_int),
                 ('mg3_keep', ctypes.c_int), ('mg3_keep_levels', ctypes.c_int), ('mg3_galerkin', ctypes.c_int), ('mg3_depth_model', ctypes.c_int),
                 ('mg3_bt_f32', ctypes.c_int), ('mg3_otf', ctypes.c_int), ('mg3_omega', ctypes.c_double), ('sync_spin_ms', ctypes.c_double)]
@@ -99,6 +99,7 @@ _SIGNATURES = {
                                                        ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_int]),
     'helm_prefactor': (ctypes.c_int, [ctypes.c_void_p]),
     'helm_prefactor_n': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    'helm_prefactor_many': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]),
     'helm_reserve': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_int]),
     'helm_set_tolerance_hint': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double]),
     'helm_last_timing': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Timing)]),

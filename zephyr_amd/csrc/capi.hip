@@ -263,6 +263,7 @@ static helm_tuning tuning_from_env() {
     t.nd_plans = tune_i("HELM_ND_PLANS", 6);
     t.nd_direct_out = tune_i("HELM_ND_DIRECT_OUT", 1);
     t.nd_leaf_idle = tune_i("HELM_ND_LEAF_IDLE", 1);
+    t.nd_many = tune_i("HELM_ND_MANY", 1);
     t.auto_direct = tune_i("HELM_AUTO_DIRECT", 1);
     t.auto_mg3 = tune_i("HELM_AUTO_MG3", 1);
     t.prof_ext = tune_i("HELM_PROF_EXT", 1);
@@ -1994,9 +1995,10 @@ void helm_pf_retire(helm_op *op) {
     hipSetDevice(op->device);
     if (op->pf_done) hipEventSynchronize(op->pf_done);
     float ms = 0.f;
-    if (op->pf_t0 && op->pf_t1 && hipEventElapsedTime(&ms, op->pf_t0, op->pf_t1) == hipSuccess) op->timing.factor_ms += ms;
-    helm_pool_free(op->device, op->pf_ws, op->pf_ws_bytes);
-    op->pf_ws = nullptr; op->pf_ws_bytes = 0;
+    if (op->pf_t0 && op->pf_t1 && hipEventElapsedTime(&ms, op->pf_t0, op->pf_t1) == hipSuccess) op->timing.factor_ms += ms / std::max(1, op->pf_share);
+    if (op->pf_ws_shared) op->pf_ws_shared.reset();            // (scratch of a set factored together: goes back to the pool with the last of its operators)
+    else helm_pool_free(op->device, op->pf_ws, op->pf_ws_bytes);
+    op->pf_ws = nullptr; op->pf_ws_bytes = 0; op->pf_share = 1;
     op->pf_pending = false;
 }
 
@@ -2035,6 +2037,69 @@ extern "C" int helm_set_tolerance_hint(helm_op *op, double rtol) {
     helm_tuning_refresh();
     if (!op || !(rtol > 0)) return HELM_ERR_ARG;
     op->rtol_hint = rtol; op->rtol_hint_set = true;
+    return HELM_OK;
+}
+
+// The factorisations of n operators in the same launches (include/helm.h).  The elimination tree is geometry only, so the fronts of n frequencies ride in one
+// strided batch each: the latency-bound chain at the top of the tree (88 block steps of ~30 us, the gather-bound small separator levels, products of one to
+// four fronts that fill a quarter of the chip) is paid once per set instead of once per frequency.  Operators that do not qualify for the direct path's
+// prefactorisation, or that differ in grid / device, are prefactored one by one (the call is a hint, like helm_prefactor).
+extern "C" int helm_prefactor_many(helm_op **ops, int n) {
+    helm_tuning_refresh();
+    if (!ops || n < 1) return HELM_ERR_ARG;
+    for (int k = 0; k < n; ++k) if (!ops[k]) return HELM_ERR_ARG;
+    auto qualifies = [&](helm_op *op) {
+        return op->assembled && op->ny == 0 && !op->direct_failed && !op->direct[0] && !op->pf_pending && !(op->variant == HELM_EURUS && !op->block_zero[2]) &&
+               helm_tuning_now().auto_direct != 0 && !testing_hook("HELM_ND_INJECT_FAILURE");
+    };
+    bool together = n >= 2 && n <= ND_NF_MAX && helm_tuning_now().nd_many != 0;
+    for (int k = 0; k < n && together; ++k) {
+        helm_op *op = ops[k];
+        if (!qualifies(op) || op->device != ops[0]->device || op->nz != ops[0]->nz || op->nx != ops[0]->nx || op->variant != ops[0]->variant) together = false;
+        for (int j = 0; j < k; ++j) if (ops[j] == op) together = false;
+    }
+    if (!together) {
+        for (int k = 0; k < n; ++k) { const int rc = helm_prefactor(ops[k]); if (rc) return rc; }
+        return HELM_OK;
+    }
+    helm_op *op0 = ops[0];
+    HIP_TRY(op0, hipSetDevice(op0->device));
+    if (!op0->fstream) {
+        op0->fstream_prio = pf_prio();
+        op0->fstream = helm_stream_acquire(op0->device, op0->fstream_prio);
+        if (!op0->fstream) HELM_FAIL(op0, HELM_ERR_DEVICE, "hipStreamCreate failed");
+    }
+    for (int k = 0; k < n; ++k) {
+        helm_op *op = ops[k];
+        if (!op->pf_done) HIP_TRY(op, hipEventCreateWithFlags(&op->pf_done, hipEventDisableTiming));
+        if (!op->pf_t0) HIP_TRY(op, hipEventCreate(&op->pf_t0));
+        if (!op->pf_t1) HIP_TRY(op, hipEventCreate(&op->pf_t1));
+    }
+    NdFactor *fs[ND_NF_MAX] = {nullptr, nullptr, nullptr, nullptr};
+    auto drop = [&]() { for (int k = 0; k < n; ++k) { nd_free(fs[k]); fs[k] = nullptr; } };
+    for (int k = 0; k < n; ++k) {
+        fs[k] = new NdFactor();
+        const int rc = nd_get_plan(ops[k], helm_tuning_now().nd_leaf, 1, &fs[k]->pd);
+        if (rc) { drop(); return rc; }
+    }
+    const size_t wsb = (size_t)n * (size_t)nd_factor_ws_elems(fs[0]->pd->plan) * sizeof(cplx);
+    void *ws = helm_pool_alloc(op0->device, wsb);
+    if (!ws) { drop(); HELM_FAIL(op0, HELM_ERR_DEVICE, "direct solver: cannot allocate %.1f GB of factorisation scratch", wsb / 1e9); }
+    const int dev = op0->device;
+    std::shared_ptr<void> holder(ws, [dev, wsb](void *p) { helm_pool_free(dev, p, wsb); });
+    { op0->ev_used = 0; op0->ev_pending.clear(); op0->ev_pending_gemm.clear(); op0->ev_pending_gemm_n.clear(); op0->ev_pending_gemm_bytes.clear(); op0->ev_pending_gemm_sol.clear(); op0->ev_pending_gemm_shape.clear(); }
+    hipStream_t main = op0->stream;
+    op0->stream = op0->fstream;                  // (the assembled planes of every operator are complete: helm_assemble synchronises)
+    for (int k = 0; k < n; ++k) hipEventRecord(ops[k]->pf_t0, op0->fstream);
+    const int rc = nd_factor_enqueue_many(op0, n, ops, fs, (cplx *)ws);
+    for (int k = 0; k < n; ++k) { hipEventRecord(ops[k]->pf_t1, op0->fstream); hipEventRecord(ops[k]->pf_done, op0->fstream); }
+    op0->stream = main;
+    if (rc) { hipStreamSynchronize(op0->fstream); drop(); return rc; }
+    for (int k = 0; k < n; ++k) {
+        helm_op *op = ops[k];
+        op->direct[0] = fs[k];
+        op->pf_ws = nullptr; op->pf_ws_bytes = 0; op->pf_ws_shared = holder; op->pf_share = n; op->pf_pending = true;
+    }
     return HELM_OK;
 }
 

@@ -62,8 +62,20 @@ struct NdStable {
     cplx *vs = nullptr; size_t vs_elems = 0;     // back-substitution scratch [smax + mmax][nrhs], grown on demand
 };
 
+// Several frequencies of one grid factored by the same launches (helm_prefactor_many; nd_factor.hip): their factors live interleaved in ONE buffer, a front's
+// slot of `slot` elements at offset `off` of the single layout at  nf * off + kf * slot  (batch index of the factorisation's launches = front * nf + frequency).
+#define ND_NF_MAX 4
+struct NdPlanesSet { const cplx *p[ND_NF_MAX]; };       // coefficient planes of the nf operators (a kernel argument)
+struct NdFacShared {                                     // what the NdFactors of a set share: released when the last of them goes
+    int device = 0;
+    cplx *d_fac = nullptr; size_t fac_bytes = 0;
+    double *d_est = nullptr; size_t est_elems = 0;
+    ~NdFacShared();
+};
 struct NdFactor {
     std::shared_ptr<NdPlanDev> pd;
+    int nf = 1, kf = 0;                                  // this factor is frequency kf of a set of nf (1, 0: on its own)
+    std::shared_ptr<NdFacShared> shared;                 // (nf > 1) owner of d_fac / d_est
     cplx *d_fac = nullptr;
     int block = 0;
     double flops = 0;
@@ -75,6 +87,10 @@ struct NdFactor {
     int *d_leafflag = nullptr; size_t leafflag_elems = 0;     // per leaf of a group: 1 when the fused leaf kernel met a small pivot (the leaf is then re-done with pivoting)
     struct FlagSlot *flag_slot = nullptr; double flag_thr = 0; // pinned buffer + event the list of a group's ill-conditioned fronts is travelling through (flag_group -> stabilise_group), and the threshold it was made with
 };
+
+// where a group's array of the single layout (offset `off`, `slot` elements per front) lies for this factor, and the stride between its fronts
+inline cplx *nd_fac_at(const NdFactor *f, long long off, long long slot) { return f->d_fac + (long long)f->nf * off + (long long)f->kf * slot; }
+inline long long nd_fac_stride(const NdFactor *f, long long slot) { return (long long)f->nf * slot; }
 
 // local index of unknown (cell (z, x), component comp) in the front: [0, s) separator, [s, s+m) ring; -1 when the cell
 // is not in the front.  Unknown = cell index * dof + comp within each part.
@@ -123,6 +139,9 @@ int nd_get_plan(helm_op *op, int leaf, int dof, std::shared_ptr<NdPlanDev> *out)
 int nd_get_plan_dims(helm_op *op, int nz, int nx, int leaf, int dof, std::shared_ptr<NdPlanDev> *out);
 int nd_factor(helm_op *op, int block, NdFactor *f, cplx *ws, const cplx *planes = nullptr);    // f->pd must be set; dof 2: block ignored, all four Eurus blocks
 int nd_factor_enqueue(helm_op *op, int block, NdFactor *f, cplx *ws, const cplx *planes = nullptr);    // the same without the final synchronisation: launches only
+// nf operators of one grid (block 0 each, one unknown per cell) factored by the same launches on op's stream: fs[k] (pd set, nothing else) receives frequency k's
+// factors, ws: nf * nd_factor_ws_elems(plan) elements of scratch.  Every factor comes out bit for bit what nd_factor_enqueue would have made of it.
+int nd_factor_enqueue_many(helm_op *op, int nf, helm_op *const *ops, NdFactor *const *fs, cplx *ws);
 void nd_free(NdFactor *f);
 long long nd_solve_ws_elems(const NdPlan &P, int nrhs);
 int nd_solve(helm_op *op, NdFactor *f, const cplx *Xin, cplx *Xout, int nrhs, cplx *ws, int conj_out = 0);   // conj_out: Xout = conj(x)

@@ -34,11 +34,18 @@ namespace {
 // storage (rows of smax + mmax; F11 is inverted in place, F12 is kept -- for leaves it becomes -F11^-1 F12 after the Schur complement, so
 // that the back substitution of a leaf is ONE product [F11^-1 | -F11^-1 F12] [y_S; x_B]), [F21 | F22] in the scratch arena (F21 feeds G21, F22 becomes the Schur
 // complement the parent picks up).  (r, c): padded front coordinates.
-__device__ __forceinline__ cplx *front_entry(const NdDev &n, cplx *arenaF, cplx *fac, int r, int c) {
+// Several frequencies in the same launches (NdFactor::nf > 1, helm_prefactor_many): the plan is geometry only, so the fronts of nf operators ride in one
+// strided batch, batch index = front * nf + frequency.  Every array of the single layout becomes nf interleaved copies of itself -- a front's slot of
+// `slot` elements at offset `off` moves to  nf * off + kf * slot  -- so the batched products and inversions see one uniform stride (their kernels do not
+// change at all) and the passes of frequency kf see theirs with stride nf * slot.  nf = 1, kf = 0 is the layout of rounds 1-5, bit for bit.
+__device__ __forceinline__ long long mf_off(long long off, long long slot, int nf, int kf) { return (long long)nf * off + (long long)kf * slot; }
+__device__ __forceinline__ cplx *front_entry(const NdDev &n, cplx *arenaF, cplx *fac, int r, int c, int nf = 1, int kf = 0, int fac_private = 0) {
+    const int nmax = n.smax + n.mmax;
     if (r < n.smax) {
-        return fac + n.finv_off + (long long)r * (n.smax + n.mmax) + c;        // [F11 | F12] share their rows
+        // [F11 | F12] share their rows (fac_private: a buffer of this front alone -- the pivoted-LU storage of an ill-conditioned front)
+        return fac + (fac_private ? n.finv_off : mf_off(n.finv_off, (long long)n.smax * nmax, nf, kf)) + (long long)r * nmax + c;
     }
-    return arenaF + n.foff + (long long)(r - n.smax) * (n.smax + n.mmax) + c;
+    return arenaF + mf_off(n.foff, (long long)n.mmax * nmax, nf, kf) + (long long)(r - n.smax) * nmax + c;
 }
 
 __global__ __launch_bounds__(256) void k_nd_assemble(const NdDev *nodes, int first, cplx *arenaF, cplx *fac, const cplx *planes, int nz, int nx) {
@@ -105,10 +112,13 @@ __global__ __launch_bounds__(256) void k_nd_extend_add(const NdDev *nodes, int f
 // every other padded slot.  The inverse maps are the same closed-form nd_cell / nd_local; a workgroup tabulates them for the
 // front's rows once in LDS and then streams `rb` rows.  Traffic per level: children's F22 read once, the fronts written once
 // (the scatter form read-modify-wrote the parents twice on top of the memsets).
-__global__ __launch_bounds__(256) void k_nd_build_front(const NdDev *nodes, int first, cplx *arenaF, cplx *fac, const cplx *planes, int nz, int nx, int rb,
-                                                        int skip22, int use_ovr, NdDev ovr) {
+__global__ __launch_bounds__(256) void k_nd_build_front(const NdDev *nodes, int first, cplx *arenaF, cplx *fac, NdPlanesSet pset, int nz, int nx, int rb,
+                                                        int skip22, int use_ovr, NdDev ovr, int nf, int kfix) {
     extern __shared__ int2 finfo[];        // per padded row: x = z | x << 16 (-1: padding), y = (k0 + 1) | (k1 + 1) << 14 | comp << 28
-    const NdDev n = use_ovr ? ovr : nodes[first + blockIdx.y];   // (ovr, a launch argument: one front rebuilt with its [F11 | F12] rows redirected, see NdStable)
+    // (nf > 1: batch index = front * nf + frequency; kfix >= 0: one frequency's front alone, the re-elimination of an ill-conditioned one)
+    const int kf = kfix >= 0 ? kfix : (int)(blockIdx.y % nf);
+    const cplx *planes = pset.p[kf];
+    const NdDev n = use_ovr ? ovr : nodes[first + (kfix >= 0 ? blockIdx.y : blockIdx.y / nf)];   // (ovr, a launch argument: one front rebuilt with its [F11 | F12] rows redirected, see NdStable)
     const int nmax = n.smax + n.mmax;
     const int r0 = blockIdx.x * rb;
     if (r0 >= nmax) return;
@@ -135,8 +145,9 @@ __global__ __launch_bounds__(256) void k_nd_build_front(const NdDev *nodes, int 
     }
     __syncthreads();
     const long long N = (long long)nz * nx;
-    const cplx *S0 = h0 ? arenaF + c0.foff + c0.smax : nullptr, *S1 = h1 ? arenaF + c1.foff + c1.smax : nullptr;
     const int ld0 = c0.smax + c0.mmax, ld1 = c1.smax + c1.mmax;
+    const cplx *S0 = h0 ? arenaF + mf_off(c0.foff, (long long)c0.mmax * ld0, nf, kf) + c0.smax : nullptr;
+    const cplx *S1 = h1 ? arenaF + mf_off(c1.foff, (long long)c1.mmax * ld1, nf, kf) + c1.smax : nullptr;
     const int r1 = r0 + rb < nmax ? r0 + rb : nmax;
     const int tx = tid & 63, ty = tid >> 6;
     const bool colmode = n.dof > 2;
@@ -166,57 +177,15 @@ __global__ __launch_bounds__(256) void k_nd_build_front(const NdDev *nodes, int 
         return v;
     };
     // skip22: the ring x ring block (the sum of the children's Schur complements, most of a front below the tree top) is not
-    // materialised -- the Schur-complement product gathers it itself (k_zgemm3<.., 4, ..>) and writes S where F22 would have been
-    // Four entries per lane are gathered before any of them is stored (round 5): the children's blocks and the front live in one arena, so the compiler
-    // keeps every load behind the previous store, and a wave that took one entry per lane at a time paid a full memory round trip per row of a small
-    // front (14 in a row at the 8192-front level: ~100 us for 110 MB) or per 64 columns of a large one.  Small fronts: four rows at once; others: four
-    // column blocks of one row.
-    if (skip22 & 2) {       // (diagnostic, HELM_ND_BUILD1=1: round 4's loop, one entry per lane at a time -- the A/B of the gather-four form below)
-        skip22 &= 1;
-        for (int r = r0 + ty; r < r1; r += 4) {
-            const int2 ia = finfo[r];
-            const int cend = (skip22 && r >= n.smax) ? n.smax : nmax;
-            for (int c = tx; c < cend; c += 64) *front_entry(n, arenaF, fac, r, c) = value(r, c, ia, finfo[c]);
-        }
-        return;
-    }
-    if (nmax <= 64) {
-        for (int rq = r0 + ty; rq < r1; rq += 16) {
-            cplx v[4]; int2 ia[4];
-            const int c = tx;
-            const int2 ib = c < nmax ? finfo[c] : make_int2(-1, 0);
-            #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int r = rq + 4 * k;
-                ia[k] = r < r1 ? finfo[r] : make_int2(-1, 0);
-                const int cend = (skip22 && r >= n.smax) ? n.smax : nmax;
-                v[k] = (r < r1 && c < cend) ? value(r, c, ia[k], ib) : cmake(0.0, 0.0);
-            }
-            #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int r = rq + 4 * k;
-                const int cend = (skip22 && r >= n.smax) ? n.smax : nmax;
-                if (r < r1 && c < cend) *front_entry(n, arenaF, fac, r, c) = v[k];
-            }
-        }
-        return;
-    }
+    // materialised -- the Schur-complement product gathers it itself (k_zgemm3<.., 4, ..>) and writes S where F22 would have been.
+    // One entry per lane at a time, 40 registers: eight waves per SIMD cover the gathers' latency.  (Round 5 gathered four entries per lane before storing any
+    // -- "the compiler keeps every load behind the previous store" -- and measured 0.02-0.03 ms per level in its favour on single levels; the restructured kernel
+    // took 154 registers, three waves per SIMD, and the profile of a whole work item says 1.53 -> 2.04 ms: round 6 ran round 4's tree beside this one on
+    // the same box, tools/bisect_build_front.sh, and put the loop back.)
     for (int r = r0 + ty; r < r1; r += 4) {
         const int2 ia = finfo[r];
         const int cend = (skip22 && r >= n.smax) ? n.smax : nmax;
-        for (int cq = tx; cq < cend; cq += 256) {
-            cplx v[4];
-            #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int c = cq + 64 * k;
-                v[k] = c < cend ? value(r, c, ia, finfo[c < nmax ? c : 0]) : cmake(0.0, 0.0);
-            }
-            #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int c = cq + 64 * k;
-                if (c < cend) *front_entry(n, arenaF, fac, r, c) = v[k];
-            }
-        }
+        for (int c = tx; c < cend; c += 64) *front_entry(n, arenaF, fac, r, c, nf, kf, use_ovr) = value(r, c, ia, finfo[c]);
     }
 }
 
@@ -236,13 +205,13 @@ __global__ __launch_bounds__(256) void k_nd_build_front(const NdDev *nodes, int 
 // (The max-entry norm was tried first in round 3: for a near-singular front F11^-1 ~ u v^T / sigma with u, v spread over all unknowns, and max |entry|
 // underestimates the norm by the front's size.  Over the front's own s x s unknowns: the identity that pads a smaller front is not part of it.)
 template <int AFTER>
-__global__ __launch_bounds__(256) void k_front_cond(const cplx *M0, int ld, long long stride, const NdDev *nodes, double *out, double *rows, int smax) {
+__global__ __launch_bounds__(256) void k_front_cond(const cplx *M0, int ld, long long stride, const NdDev *nodes, double *out, double *rows, int smax, int nf) {
     __shared__ double red[4];
     __shared__ double dsh[LUS_NMAX];
     __shared__ unsigned char lone[LUS_NMAX];
     const cplx *M = M0 + (long long)blockIdx.x * stride;
     double *w = rows + (long long)blockIdx.x * smax;
-    const int n = nodes[blockIdx.x].s;
+    const int n = nodes[blockIdx.x / nf].s;              // (nf > 1: batch index = front * nf + frequency)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double best = 0.0;
     for (int i = wv; i < n; i += 4) {                      // a wave per row: coalesced along the row
@@ -272,9 +241,10 @@ __global__ __launch_bounds__(256) void k_front_cond(const cplx *M0, int ld, long
     if (threadIdx.x == 0) out[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
 }
 // list[0] = number of fronts with  scale * a[j] * b[j] > thr  (capped), list[1..] = their positions in the group, worst first is not needed
-__global__ void k_front_flag(const double *a, const double *b, int cnt, double scale, double thr, int *list, int cap) {
+// (nf, kf: the estimates of nf interleaved frequencies lie at j * nf + kf; the list holds front positions j)
+__global__ void k_front_flag(const double *a, const double *b, int cnt, double scale, double thr, int *list, int cap, int nf, int kf) {
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += gridDim.x * blockDim.x)
-        if (!(scale * a[j] * b[j] <= thr)) {                                                               // (NaN counts as flagged)
+        if (!(scale * a[(long long)j * nf + kf] * b[(long long)j * nf + kf] <= thr)) {                   // (NaN counts as flagged)
             const int slot = atomicAdd(list, 1);
             if (slot < cap) list[1 + slot] = j;
         }
@@ -464,12 +434,16 @@ void nd_free(NdFactor *f) {
     if (!f) return;
     stable_free(f);
     if (f->flag_slot) { (void)hipEventSynchronize(f->flag_slot->ev); flag_slot_release(f->flag_slot); f->flag_slot = nullptr; }
-    if (f->d_est) helm_pool_free(f->pd ? f->pd->device : 0, f->d_est, f->est_elems * sizeof(double));
+    if (f->d_est && !f->shared) helm_pool_free(f->pd ? f->pd->device : 0, f->d_est, f->est_elems * sizeof(double));
     if (f->d_leafflag) helm_pool_free(f->pd ? f->pd->device : 0, f->d_leafflag, f->leafflag_elems * sizeof(int));
     if (f->d_act) helm_pool_free(f->pd ? f->pd->device : 0, f->d_act, f->act_elems * sizeof(int));
     if (f->d_qmask) helm_pool_free(f->pd ? f->pd->device : 0, f->d_qmask, f->qmask_elems);
-    if (f->d_fac) helm_pool_free(f->pd ? f->pd->device : 0, f->d_fac, (size_t)f->pd->plan.fac_elems * sizeof(cplx));
-    delete f;
+    if (f->d_fac && !f->shared) helm_pool_free(f->pd ? f->pd->device : 0, f->d_fac, (size_t)f->pd->plan.fac_elems * sizeof(cplx));
+    delete f;                      // (a factor of a set: the shared buffers go with the last of them, ~NdFacShared)
+}
+NdFacShared::~NdFacShared() {
+    if (d_fac) helm_pool_free(device, d_fac, fac_bytes);
+    if (d_est) helm_pool_free(device, d_est, est_elems * sizeof(double));
 }
 
 // Fronts that keep G = -F11^-1 F12 where F12 was, so that their back substitution is ONE product [F11^-1 | G] [y_S; x_B]: the leaves.
@@ -496,18 +470,31 @@ bool stable_enabled(const NdPlan &P) {
     // coupled system's rhs-major path have overwritten by then
     return helm_tuning_now().nd_stable != 0 && P.dof == 1;
 }
-// d_est: [a: cnt][b: cnt][flag list: ND_STABLE_CAP + 1 ints] of the group at hand, and from est_rows_off on the row sums of its pivot blocks (cnt x smax)
-size_t est_rows_off(const NdPlan &P) {
+// d_est of a set of nf frequencies (nf = 1: a factor on its own): [a: nf cnt][b: nf cnt] of the group at hand, entry front * nf + frequency; from
+// est_list_off on nf flag lists of ND_STABLE_CAP + 1 ints; from est_rows_off on the row sums of its pivot blocks (nf cnt x smax, same order)
+const size_t kEstList = (ND_STABLE_CAP + 2) / 2 + 2;            // doubles per flag list
+size_t est_list_off(const NdPlan &P, int nf) {
     int maxcnt = 1;
     for (const NdGroup &g : P.groups) maxcnt = std::max(maxcnt, g.cnt);
-    return 2 * (size_t)maxcnt + (ND_STABLE_CAP + 2) / 2 + 8;
+    return 2 * (size_t)nf * maxcnt;
 }
+size_t est_rows_off(const NdPlan &P, int nf) { return est_list_off(P, nf) + (size_t)nf * kEstList + 8; }
+// (the estimates belong to the set: frequency 0's factor holds the pointer for all of them, NdFacShared owns the buffer when nf > 1)
 int ensure_est(helm_op *op, NdFactor *f, int stable_smax) {
     const NdPlan &P = f->pd->plan;
+    const int nf = f->nf;
     size_t rows = 0;
     for (const NdGroup &g : P.groups) if (!g.leaf && g.mmax > 0 && g.smax <= stable_smax) rows = std::max(rows, (size_t)g.cnt * g.smax);
-    const size_t need = est_rows_off(P) + rows;
+    const size_t need = est_rows_off(P, nf) + (size_t)nf * rows;
     if (f->est_elems >= need) return HELM_OK;
+    if (f->shared) {
+        if (f->shared->d_est) { hipStreamSynchronize(op->stream); helm_pool_free(op->device, f->shared->d_est, f->shared->est_elems * sizeof(double)); f->shared->d_est = nullptr; f->shared->est_elems = 0; }
+        f->shared->d_est = (double *)helm_pool_alloc(op->device, need * sizeof(double));
+        if (!f->shared->d_est) return HELM_ERR_DEVICE;
+        f->shared->est_elems = need;
+        f->d_est = f->shared->d_est; f->est_elems = need;
+        return HELM_OK;
+    }
     if (f->d_est) { hipStreamSynchronize(op->stream); helm_pool_free(op->device, f->d_est, f->est_elems * sizeof(double)); f->d_est = nullptr; f->est_elems = 0; }
     f->d_est = (double *)helm_pool_alloc(op->device, need * sizeof(double));
     if (!f->d_est) return HELM_ERR_DEVICE;
@@ -521,7 +508,8 @@ int ensure_est(helm_op *op, NdFactor *f, int stable_smax) {
 // stream ever running dry.  (Rounds 3-4: hipStreamSynchronize after the products, once per watched group -- the factorisation stream idled for a host
 // round trip 11 times per operator, and in the pipelined job the factorisation span is what a step waits for.)
 // after the inversion of group gi: flag its ill-conditioned fronts and start the list on its way to the host
-int flag_group(helm_op *op, NdFactor *f, size_t gi) {
+// (f: the factor of frequency f->kf of a set of f->nf; est: the SET's estimates, ensure_est; rt: the tolerance that frequency's factors are built for)
+int flag_group(helm_op *op, NdFactor *f, size_t gi, double *est, double rt_hint) {
     const NdPlan &P = f->pd->plan;
     const NdGroup &g = P.groups[gi];
     hipStream_t st = op->stream;
@@ -533,26 +521,29 @@ int flag_group(helm_op *op, NdFactor *f, size_t gi) {
     // affair and leaves the rest to the refinement pass, which always exists).  HELM_ND_STABLE_THR overrides with a fixed number.
     const helm_tuning tune = helm_tuning_now();
     const double safety = tune.nd_stable_safety;
-    const double rt = op->rtol_hint > 0 ? op->rtol_hint : 1e-10;
+    const double rt = rt_hint > 0 ? rt_hint : 1e-10;
     const double thr = tune.nd_stable_thr > 0 ? tune.nd_stable_thr : std::min(1e9, std::max(2e3, rt / (safety * 1.1102230246251565e-16)));
     if (!f->flag_slot) f->flag_slot = flag_slot_acquire(op->device);
     FlagSlot *slot = f->flag_slot;
     if (!slot) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: no pinned buffer for the list of ill-conditioned fronts");
     f->flag_thr = thr;
-    int *d_list = (int *)(f->d_est + 2 * (size_t)g.cnt);
+    int *d_list = (int *)(est + est_list_off(P, f->nf) + (size_t)f->kf * kEstList);
     HIP_TRY(op, hipMemsetAsync(d_list, 0, sizeof(int), st));
-    HELM_LAUNCH(k_front_flag, dim3((g.cnt + 255) / 256), dim3(256), 0, st, (const double *)f->d_est, (const double *)(f->d_est + g.cnt), g.cnt, 1.0, thr, d_list, ND_STABLE_CAP);
+    HELM_LAUNCH(k_front_flag, dim3((g.cnt + 255) / 256), dim3(256), 0, st, (const double *)est, (const double *)(est + (size_t)f->nf * g.cnt), g.cnt, 1.0, thr, d_list, ND_STABLE_CAP,
+                f->nf, f->kf);
     HIP_TRY(op, hipMemcpyAsync(slot->host, d_list, (ND_STABLE_CAP + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(op, hipEventRecord(slot->ev, st));
     return HELM_OK;
 }
 
 // after the batched elimination of group gi (whose list flag_group has requested): eliminate each of its ill-conditioned fronts again
-int stabilise_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, const cplx *planes) {
+// (f: frequency f->kf of a set of f->nf; arenaF / work: the set's scratch; est: the set's estimates)
+int stabilise_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, const cplx *planes, const double *est) {
     const NdPlan &P = f->pd->plan;
     const NdGroup &g = P.groups[gi];
     hipStream_t st = op->stream;
     const int nmax = g.smax + g.mmax;
+    const int nf = f->nf, kf = f->kf;
     FlagSlot *slot = f->flag_slot;
     if (!slot) HELM_FAIL(op, HELM_ERR_STATE, "direct solver: stabilise_group without flag_group");
     int h_list[ND_STABLE_CAP + 1];
@@ -567,13 +558,13 @@ int stabilise_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *wor
         // more flagged fronts than are treated per group: which of them made it into the list is up to the order the atomics ran in, and the factors would
         // differ from one factorisation of the same operator to the next.  Take the worst ND_STABLE_CAP of the FLAGGED fronts by the estimate the flag was
         // made from, a[j] * b[j] = ||F11|| ||F11^-1|| (ties: lower position).
-        std::vector<double> est(2 * (size_t)g.cnt);
+        std::vector<double> eh(2 * (size_t)nf * g.cnt);
         HIP_TRY(op, hipStreamSynchronize(st));
-        HIP_TRY(op, hipMemcpy(est.data(), f->d_est, est.size() * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(op, hipMemcpy(eh.data(), est, eh.size() * sizeof(double), hipMemcpyDeviceToHost));
         const double thr = f->flag_thr;
         std::vector<std::pair<double, int>> cand;
         for (int j = 0; j < g.cnt; ++j) {
-            const double e = est[j] * est[(size_t)g.cnt + j];
+            const double e = eh[(size_t)j * nf + kf] * eh[(size_t)nf * g.cnt + (size_t)j * nf + kf];
             if (!(e <= thr)) cand.push_back(std::make_pair(e == e ? e : HUGE_VAL, j));                          // (the kernel's own test; NaN: worst)
         }
         auto worse = [](const std::pair<double, int> &a, const std::pair<double, int> &b) { return a.first != b.first ? a.first > b.first : a.second < b.second; };
@@ -583,12 +574,12 @@ int stabilise_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *wor
     }
     std::sort(h_list + 1, h_list + 1 + nflag);                                   // (the atomics hand the slots out in no particular order)
     if (getenv("HELM_ND_DEBUG") && atoi(getenv("HELM_ND_DEBUG")) >= 2) {
-        std::vector<double> h(2 * (size_t)g.cnt);
+        std::vector<double> h(2 * (size_t)nf * g.cnt);
         hipStreamSynchronize(st);
-        hipMemcpy(h.data(), f->d_est, h.size() * sizeof(double), hipMemcpyDeviceToHost);
+        hipMemcpy(h.data(), est, h.size() * sizeof(double), hipMemcpyDeviceToHost);
         double worst = 0; int wj = 0;
-        for (int j = 0; j < g.cnt; ++j) { const double e = h[j] * h[g.cnt + j]; if (!(e <= worst)) { worst = e; wj = j; } }
-        fprintf(stderr, "[helm direct] level %d s %d cnt %d: estimate of front 0 = %.3e * %.3e; worst %.3e at %d; flagged %d\n", g.level, g.smax, g.cnt, h[0], h[g.cnt], worst, wj, h_list[0]);
+        for (int j = 0; j < g.cnt; ++j) { const double e = h[(size_t)j * nf + kf] * h[(size_t)nf * g.cnt + (size_t)j * nf + kf]; if (!(e <= worst)) { worst = e; wj = j; } }
+        fprintf(stderr, "[helm direct] level %d s %d cnt %d (frequency %d of %d): estimate of front 0 = %.3e * %.3e; worst %.3e at %d; flagged %d\n", g.level, g.smax, g.cnt, kf, nf, h[kf], h[(size_t)nf * g.cnt + kf], worst, wj, h_list[0]);
     }
     if ((long long)g.smax * g.mmax > P.work_elems) return HELM_OK;               // (no room for the s x m solve: leave the group as it is)
     const cplx one = cmake(1, 0), mone = cmake(-1, 0);
@@ -602,11 +593,12 @@ int stabilise_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *wor
         f->stable.push_back(S);                                                   // (owned by the factor from here on: freed by nd_free on every path)
         if (!S.lu || !S.f21 || !S.piv) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: allocation for an ill-conditioned front failed");
         NdDev n = P.nodes[S.node];
-        const long long foff = n.foff;
+        const long long foff = (long long)nf * n.foff + (long long)kf * g.mmax * nmax;       // this frequency's [F21 | F22] of the front in the set's arena
         n.finv_off = 0; n.f12_off = g.smax;                                       // [F11 | F12] rows go to S.lu, [F21 | F22] back to the arena
         const int rb = std::max(std::min(nmax, 4), (nmax + 2047) / 2048);
-        HELM_LAUNCH(k_nd_build_front, dim3((nmax + rb - 1) / rb, 1), dim3(256), (size_t)nmax * sizeof(int2), st, f->pd->d_nodes, 0, arenaF, S.lu, planes, P.nz, P.nx, rb,
-                           0, 1, n);                                                 // (the redirected node travels as a launch argument: no copy, no host wait)
+        NdPlanesSet ps; for (int q2 = 0; q2 < ND_NF_MAX; ++q2) ps.p[q2] = planes;
+        HELM_LAUNCH(k_nd_build_front, dim3((nmax + rb - 1) / rb, 1), dim3(256), (size_t)nmax * sizeof(int2), st, f->pd->d_nodes, 0, arenaF, S.lu, ps, P.nz, P.nx, rb,
+                           0, 1, n, nf, kf);                                         // (the redirected node travels as a launch argument: no copy, no host wait)
         cplx *F21 = arenaF + foff, *F22 = arenaF + foff + g.smax;
         HIP_TRY(op, hipMemcpy2DAsync(S.f21, (size_t)g.smax * sizeof(cplx), F21, (size_t)nmax * sizeof(cplx), (size_t)g.smax * sizeof(cplx), (size_t)g.mmax, hipMemcpyDeviceToDevice, st));
         if (g.smax <= 64) HELM_LAUNCH(k_lu_factor64, dim3(1), dim3(256), 0, st, S.lu, nmax, g.smax, S.piv);
@@ -638,18 +630,25 @@ int stabilise_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *wor
 
 }  // namespace
 
-// factorisation of one group (tree level x kind) on op->stream
-int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, const cplx *planes) {
-    const NdPlan &P = f->pd->plan;
-    const NdDev *d_nodes = f->pd->d_nodes;
+// factorisation of one group (tree level x kind) on op->stream, for the nf frequencies of a set at once (nf = 1: the factorisation of rounds 1-5).
+// S.f[k] / S.planes[k] / S.rtol[k]: factor, coefficient planes and tolerance of frequency k; arenaF / work: scratch of nf times the single size.
+// Every strided batch below is nf times as long, batch index = front * nf + frequency (direct.hpp); the leaf level, which fills the chip by itself, and the
+// re-elimination of ill-conditioned fronts go frequency by frequency.
+int factor_group_set(helm_op *op, const FacSet &S, size_t gi, cplx *arenaF, cplx *work) {
+    NdFactor *f0 = S.f[0];
+    const int nf = S.nf;
+    const NdPlan &P = f0->pd->plan;
+    const NdDev *d_nodes = f0->pd->d_nodes;
     hipStream_t st = op->stream;
     const cplx one = cmake(1, 0), mone = cmake(-1, 0), zero = cmake(0, 0);
     const NdGroup &g = P.groups[gi];
     const int nmax = g.smax + g.mmax;
     const long long fs = (long long)g.mmax * nmax;              // scratch per front: [F21 | F22]
     const long long s11 = (long long)g.smax * g.smax, s12 = (long long)g.smax * g.mmax, s1 = (long long)g.smax * nmax;   // s1: stride of [F11 | F12]
-    cplx *F = arenaF + g.foff;
-    cplx *Finv = f->d_fac + g.finv, *G21 = f->d_fac + g.g21, *F12 = f->d_fac + g.f12;
+    const int nbatch = nf * g.cnt;                              // fronts x frequencies
+    cplx *F = arenaF + (long long)nf * g.foff;
+    cplx *Finv = f0->d_fac + (long long)nf * g.finv, *G21 = f0->d_fac + (long long)nf * g.g21, *F12 = Finv + g.smax;
+    NfDivScope nfdiv(nf);                                       // tile shapes / kernel variants are chosen as for ONE frequency: bit for bit the one-at-a-time factors
     // leaves of one unknown per cell and at most 8 x 8 cells: the whole leaf level in one kernel (k_leaf_factor; HELM_ND_FUSEDLEAF=0: the batched path)
     const helm_tuning tune = helm_tuning_now();
     const int fused_leaf = tune.nd_fused_leaf;
@@ -657,21 +656,24 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
     // leaves in flight hide and a few hundred do not: the handful of larger leaves of a level stay on the batched path, HELM_ND_FUSEDLEAF_MIN)
     const int fused_leaf_min = tune.nd_fused_leaf_min;
     if (fused_leaf && g.leaf && g.cnt >= fused_leaf_min && P.dof == 1 && P.leaf <= 8 && g.smax <= 64 && g.mmax > 0 && g.mmax <= LEAF_MP) {
-        if (f->leafflag_elems < (size_t)g.cnt) {
-            if (f->d_leafflag) { hipStreamSynchronize(st); helm_pool_free(op->device, f->d_leafflag, f->leafflag_elems * sizeof(int)); f->d_leafflag = nullptr; f->leafflag_elems = 0; }
-            int maxcnt = g.cnt;
-            for (const NdGroup &q : P.groups) if (q.leaf) maxcnt = std::max(maxcnt, q.cnt);
-            f->d_leafflag = (int *)helm_pool_alloc(op->device, (size_t)maxcnt * sizeof(int));
-            if (!f->d_leafflag) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: allocation of the leaf flags failed");
-            f->leafflag_elems = (size_t)maxcnt;
-        }
         const int leaf_dbg = getenv("HELM_LEAF_DBG") ? atoi(getenv("HELM_LEAF_DBG")) : 0;       // (timing experiments: 1 no LU, 2 no substitution, 4 no G21 / S; test: 8 every leaf re-done by the pivoted kernel)
-        for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
-            const int nb = std::min(65535, g.cnt - j0);
-            cplx *g21b = G21 + (long long)j0 * g.mmax * g.smax;
-            launch_leaf_factor(st, g.smax, nb, d_nodes, g.first + j0, arenaF, f->d_fac, g21b, planes, P.nz, P.nx, f->d_leafflag + j0, leaf_dbg);
+        for (int k = 0; k < nf; ++k) {
+            NdFactor *f = S.f[k];
+            if (f->leafflag_elems < (size_t)g.cnt) {
+                if (f->d_leafflag) { hipStreamSynchronize(st); helm_pool_free(op->device, f->d_leafflag, f->leafflag_elems * sizeof(int)); f->d_leafflag = nullptr; f->leafflag_elems = 0; }
+                int maxcnt = g.cnt;
+                for (const NdGroup &q : P.groups) if (q.leaf) maxcnt = std::max(maxcnt, q.cnt);
+                f->d_leafflag = (int *)helm_pool_alloc(op->device, (size_t)maxcnt * sizeof(int));
+                if (!f->d_leafflag) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: allocation of the leaf flags failed");
+                f->leafflag_elems = (size_t)maxcnt;
+            }
+            for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
+                const int nb = std::min(65535, g.cnt - j0);
+                cplx *g21b = G21 + (long long)j0 * nf * g.mmax * g.smax;
+                launch_leaf_factor(st, g.smax, nb, d_nodes, g.first + j0, arenaF, f0->d_fac, g21b, S.planes[k], P.nz, P.nx, f->d_leafflag + j0, leaf_dbg, nf, k);
+            }
+            f->flops += (double)g.cnt * 8.0 * (2.0 * LEAF_BW * g.smax * (g.smax + g.mmax) + 3.0 * g.mmax * (g.smax + g.mmax));
         }
-        f->flops += (double)g.cnt * 8.0 * (2.0 * LEAF_BW * g.smax * (g.smax + g.mmax) + 3.0 * g.mmax * (g.smax + g.mmax));
         return HELM_OK;
     }
     // the ring x ring block of a non-leaf front stays unbuilt: its Schur-complement product gathers the children's contributions itself
@@ -683,18 +685,21 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
         // rows per workgroup: whole fronts while there are thousands of them, a few rows each for the handful of big ones at the top
         const int want = std::max(1, 2048 / g.cnt);
         const int rb = std::max(std::min(nmax, 4), (nmax + want - 1) / want);
-        static const int build1 = (getenv("HELM_ND_BUILD1") && atoi(getenv("HELM_ND_BUILD1"))) ? 2 : 0;      // (diagnostic: round 4's gather loop)
-        for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
-            const int nb = std::min(65535, g.cnt - j0);
-            HELM_LAUNCH(k_nd_build_front, dim3((nmax + rb - 1) / rb, nb), dim3(256), (size_t)nmax * sizeof(int2), st, d_nodes, g.first + j0, arenaF, f->d_fac, planes,
-                               P.nz, P.nx, rb, (schur_gather ? 1 : 0) | build1, 0, NdDev());
+        NdPlanesSet ps; for (int k = 0; k < ND_NF_MAX; ++k) ps.p[k] = S.planes[k < nf ? k : 0];
+        const int chunk = 65535 / nf;                             // fronts per launch (grid y = fronts x frequencies)
+        for (int j0 = 0; j0 < g.cnt; j0 += chunk) {
+            const int nb = std::min(chunk, g.cnt - j0);
+            HELM_LAUNCH(k_nd_build_front, dim3((nmax + rb - 1) / rb, nb * nf), dim3(256), (size_t)nmax * sizeof(int2), st, d_nodes, g.first + j0, arenaF, f0->d_fac, ps,
+                               P.nz, P.nx, rb, schur_gather ? 1 : 0, 0, NdDev(), nf, -1);
         }
     } else {
+        if (nf != 1) HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "direct solver: fronts of %d unknowns take the unfused build, which factors one frequency at a time", nmax);
+        const cplx *planes = S.planes[0];
         if (fs > 0) HIP_TRY(op, hipMemsetAsync(F, 0, (size_t)g.cnt * fs * sizeof(cplx), st));
         HIP_TRY(op, hipMemsetAsync(Finv, 0, (size_t)g.cnt * s1 * sizeof(cplx), st));
         for (int j0 = 0; j0 < g.cnt; j0 += 65535) {
             const int nb = std::min(65535, g.cnt - j0);
-            HELM_LAUNCH(k_nd_assemble, dim3((nmax + 255) / 256, nb), dim3(256), 0, st, d_nodes, g.first + j0, arenaF, f->d_fac, planes, P.nz, P.nx);
+            HELM_LAUNCH(k_nd_assemble, dim3((nmax + 255) / 256, nb), dim3(256), 0, st, d_nodes, g.first + j0, arenaF, f0->d_fac, planes, P.nz, P.nx);
         }
         if (!g.leaf) {
             // children's ring sizes are bounded by this group's front size
@@ -706,7 +711,7 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
                     const long long total = (long long)nmax * nmax;
                     const int chunk = (int)std::max<long long>(4096, std::min<long long>(total, std::max<long long>(16LL * nmax, total / std::max(1, 2048 / nb))));
                     const int gx = (int)std::max<long long>(1, std::min<long long>((total + chunk - 1) / chunk, 65535));
-                    HELM_LAUNCH(k_nd_extend_add, dim3(gx, nb), dim3(256), shm, st, d_nodes, g.first + j0, slot, arenaF, f->d_fac, P.nz, P.nx, chunk);
+                    HELM_LAUNCH(k_nd_extend_add, dim3(gx, nb), dim3(256), shm, st, d_nodes, g.first + j0, slot, arenaF, f0->d_fac, P.nz, P.nx, chunk);
                 }
         }
     }
@@ -715,39 +720,47 @@ int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, 
     const int stable_smax = 128;      // larger fronts are left alone: the one-workgroup LU would cost more than the refinement pass it saves, none that large has been seen ill-conditioned
     // (leaves are not watched: 20-40 typically, below 6e3 in every operator examined, and their level is the one where two more passes over
     // every front cost something)
-    const bool watch = stable_enabled(P) && !g.leaf && g.mmax > 0 && g.smax <= std::min(stable_smax, LUS_NMAX) && ensure_est(op, f, std::min(stable_smax, LUS_NMAX)) == HELM_OK;
-    double *est_rows = watch ? f->d_est + est_rows_off(P) : nullptr;
-    if (watch) for (int j0 = 0; j0 < g.cnt; j0 += 65535)
-        HELM_LAUNCH(k_front_cond<0>, dim3(std::min(65535, g.cnt - j0)), dim3(256), 0, st, Finv + (long long)j0 * s1, nmax, s1, d_nodes + g.first + j0, f->d_est + j0,
-                           est_rows + (long long)j0 * g.smax, g.smax);
-    invert(op, Finv, nmax, s1, g.smax, g.cnt, work, s11, P.dof, 0);      // F11 -> F11^-1 where it stays
-    if (watch) for (int j0 = 0; j0 < g.cnt; j0 += 65535)
-        HELM_LAUNCH(k_front_cond<1>, dim3(std::min(65535, g.cnt - j0)), dim3(256), 0, st, Finv + (long long)j0 * s1, nmax, s1, d_nodes + g.first + j0, f->d_est + g.cnt + j0,
-                           est_rows + (long long)j0 * g.smax, g.smax);
-    if (watch) { const int rcf = flag_group(op, f, gi); if (rcf) return rcf; }      // (the list travels while the products below run)
+    const bool watch = stable_enabled(P) && !g.leaf && g.mmax > 0 && g.smax <= std::min(stable_smax, LUS_NMAX) && ensure_est(op, f0, std::min(stable_smax, LUS_NMAX)) == HELM_OK;
+    double *est = watch ? f0->d_est : nullptr;
+    double *est_rows = watch ? est + est_rows_off(P, nf) : nullptr;
+    if (watch) for (int b0 = 0; b0 < nbatch; b0 += 65535 / nf * nf)
+        HELM_LAUNCH(k_front_cond<0>, dim3(std::min(65535 / nf * nf, nbatch - b0)), dim3(256), 0, st, Finv + (long long)b0 * s1, nmax, s1, d_nodes + g.first + b0 / nf, est + b0,
+                           est_rows + (long long)b0 * g.smax, g.smax, nf);
+    invert(op, Finv, nmax, s1, g.smax, nbatch, work, s11, P.dof, 0);      // F11 -> F11^-1 where it stays
+    if (watch) for (int b0 = 0; b0 < nbatch; b0 += 65535 / nf * nf)
+        HELM_LAUNCH(k_front_cond<1>, dim3(std::min(65535 / nf * nf, nbatch - b0)), dim3(256), 0, st, Finv + (long long)b0 * s1, nmax, s1, d_nodes + g.first + b0 / nf, est + nbatch + b0,
+                           est_rows + (long long)b0 * g.smax, g.smax, nf);
+    if (watch) for (int k = 0; k < nf; ++k) { const int rcf = flag_group(op, S.f[k], gi, est, S.rtol[k]); if (rcf) return rcf; }      // (the lists travel while the products below run)
     if (g.mmax > 0) {
         // G21 = F21 F11^-1 ; F22 -= G21 F12
-        gemm(op, g.mmax, g.smax, g.smax, one, F, nmax, fs, Finv, nmax, s1, zero, G21, g.smax, (long long)g.mmax * g.smax, g.cnt);
+        gemm(op, g.mmax, g.smax, g.smax, one, F, nmax, fs, Finv, nmax, s1, zero, G21, g.smax, (long long)g.mmax * g.smax, nbatch);
         if (schur_gather) {
-            GemmRows R; R.schur4 = 1; R.nodes = d_nodes; R.first = g.first; R.arenaS = arenaF; R.tabCi = f->pd->d_tab + g.roff; R.tab_stride = nmax;
-            gemm(op, g.mmax, g.mmax, g.smax, mone, G21, g.smax, (long long)g.mmax * g.smax, F12, nmax, s1, zero, F + g.smax, nmax, fs, g.cnt, &R);
+            GemmRows R; R.schur4 = 1; R.nodes = d_nodes; R.first = g.first; R.arenaS = arenaF; R.tabCi = f0->pd->d_tab + g.roff; R.tab_stride = nmax; R.nf = nf;
+            gemm(op, g.mmax, g.mmax, g.smax, mone, G21, g.smax, (long long)g.mmax * g.smax, F12, nmax, s1, zero, F + g.smax, nmax, fs, nbatch, &R);
         } else
-        gemm(op, g.mmax, g.mmax, g.smax, mone, G21, g.smax, (long long)g.mmax * g.smax, F12, nmax, s1, one, F + g.smax, nmax, fs, g.cnt);
+        gemm(op, g.mmax, g.mmax, g.smax, mone, G21, g.smax, (long long)g.mmax * g.smax, F12, nmax, s1, one, F + g.smax, nmax, fs, nbatch);
         if (merged_group(P, g)) {
             // leaves (and small separator fronts): F12 <- -F11^-1 F12, in place where a front is one 64-row tile (GemmRows::tm64), else through the inversion workspace
             if (g.smax <= 64) {
                 GemmRows R; R.dense = 1; R.tm64 = 1;
-                gemm(op, g.smax, g.mmax, g.smax, mone, Finv, nmax, s1, F12, nmax, s1, zero, F12, nmax, s1, g.cnt, &R);
+                gemm(op, g.smax, g.mmax, g.smax, mone, Finv, nmax, s1, F12, nmax, s1, zero, F12, nmax, s1, nbatch, &R);
             } else {
-                gemm(op, g.smax, g.mmax, g.smax, mone, Finv, nmax, s1, F12, nmax, s1, zero, work, g.mmax, s12, g.cnt);
+                gemm(op, g.smax, g.mmax, g.smax, mone, Finv, nmax, s1, F12, nmax, s1, zero, work, g.mmax, s12, nbatch);
                 HIP_TRY(op, hipMemcpy2DAsync(F12, (size_t)nmax * sizeof(cplx), work, (size_t)g.mmax * sizeof(cplx), (size_t)g.mmax * sizeof(cplx),
-                                             (size_t)g.cnt * g.smax, hipMemcpyDeviceToDevice, st));
+                                             (size_t)nbatch * g.smax, hipMemcpyDeviceToDevice, st));
             }
         }
     }
-    f->flops += (double)g.cnt * 8.0 * (2.0 * g.smax * g.smax * g.smax + (double)g.smax * g.smax * g.mmax + (double)g.smax * g.mmax * g.mmax);
-    if (watch) return stabilise_group(op, f, gi, arenaF, work, planes);
+    for (int k = 0; k < nf; ++k)
+        S.f[k]->flops += (double)g.cnt * 8.0 * (2.0 * g.smax * g.smax * g.smax + (double)g.smax * g.smax * g.mmax + (double)g.smax * g.mmax * g.mmax);
+    if (watch) for (int k = 0; k < nf; ++k) { const int rcs = stabilise_group(op, S.f[k], gi, arenaF, work, S.planes[k], est); if (rcs) return rcs; }
     return HELM_OK;
+}
+
+// factorisation of one group for a factor on its own
+int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, const cplx *planes) {
+    FacSet S; S.nf = 1; S.f[0] = f; S.planes[0] = planes; S.rtol[0] = op->rtol_hint;
+    return factor_group_set(op, S, gi, arenaF, work);
 }
 
 int factor_prologue(helm_op *op, int block, NdFactor *f, const cplx *planes_in, const cplx **planes) {
@@ -790,5 +803,32 @@ int nd_factor_enqueue(helm_op *op, int block, NdFactor *f, cplx *ws, const cplx 
         rc = factor_group(op, f, gi, ws, ws + 2 * P.fregion, planes);
         if (rc) return rc;
     }
+    return check_kernels(op, "factorisation kernels");
+}
+
+// The factorisations of nf operators of one grid in the same launches on op's stream (helm_prefactor_many).  fs[k]: pd set, nothing else; afterwards each is a
+// factor like any other (its passes address the interleaved storage through nd_fac_at / nd_fac_stride) and the shared buffer goes when the last of them is freed.
+int nd_factor_enqueue_many(helm_op *op, int nf, helm_op *const *ops, NdFactor *const *fs, cplx *ws) {
+    if (nf < 1 || nf > ND_NF_MAX) HELM_FAIL(op, HELM_ERR_ARG, "direct solver: %d frequencies in one factorisation (1 .. %d)", nf, ND_NF_MAX);
+    const NdPlan &P = fs[0]->pd->plan;
+    if (P.dof != 1) HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "direct solver: the coupled system is factored one frequency at a time");
+    std::shared_ptr<NdFacShared> sh = std::make_shared<NdFacShared>();
+    sh->device = op->device;
+    sh->fac_bytes = (size_t)nf * (size_t)P.fac_elems * sizeof(cplx);
+    sh->d_fac = (cplx *)helm_pool_alloc(op->device, sh->fac_bytes);
+    if (!sh->d_fac) HELM_FAIL(op, HELM_ERR_DEVICE, "direct solver: cannot allocate %.1f GB for the factors of %d frequencies", sh->fac_bytes * 1e-9, nf);
+    FacSet S; S.nf = nf;
+    for (int k = 0; k < nf; ++k) {
+        NdFactor *f = fs[k];
+        if (f->pd.get() != fs[0]->pd.get()) HELM_FAIL(op, HELM_ERR_ARG, "direct solver: the operators of one factorisation must share their grid");
+        f->nf = nf; f->kf = k; f->shared = sh; f->d_fac = sh->d_fac; f->block = 0; f->flops = 0;
+        S.f[k] = f; S.planes[k] = ops[k]->d_C; S.rtol[k] = ops[k]->rtol_hint;
+    }
+    cplx *arenaF = ws, *work = ws + (long long)nf * 2 * P.fregion;
+    for (size_t gi = 0; gi < P.groups.size(); ++gi) {
+        const int rc = factor_group_set(op, S, gi, arenaF, work);
+        if (rc) return rc;
+    }
+    for (int k = 1; k < nf; ++k) { fs[k]->d_est = nullptr; fs[k]->est_elems = 0; }      // (the estimates hang off frequency 0's factor and the shared record)
     return check_kernels(op, "factorisation kernels");
 }

@@ -3,6 +3,7 @@
 #include "nd_gemm_body.hpp"
 
 thread_local hipEvent_t tl_ev0 = nullptr, tl_ev1 = nullptr;
+thread_local int tl_nf_div = 1;
 int g_gemm_tile = -1;           // >= 0: forces the tile configuration (helm_debug_zgemm_bench)
 
 namespace {
@@ -331,8 +332,9 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
     // partial product to the handle's scratch and a small launch adds them up (with alpha / beta applied there).
     // (measured on the 47 x 79 x 79 level: fewer than 96 tiles / 192 workgroups -> 5.8 ms per coarse solve, 300 / 768 -> 5.0, more changes nothing)
     bool split_done = false;
-    if (op && !rows && !ext && Nn <= 16 && K >= 1024 && batch <= 64) {
-        const long long tiles = (long long)batch * ((M + 127) / 128);
+    const int dbatch = std::max(1, batch / tl_nf_div);        // the batch the choices below are made for (one frequency's share of a multi-frequency launch)
+    if (op && !rows && !ext && Nn <= 16 && K >= 1024 && dbatch <= 64) {
+        const long long tiles = (long long)dbatch * ((M + 127) / 128);
         if (tiles < 300) {
             const int ks = (int)std::min<long long>(16, std::max<long long>(2, 768 / tiles));
             const int kc = (((K + ks - 1) / ks) + 7) & ~7;
@@ -353,7 +355,7 @@ int gemm(helm_op *op, int M, int Nn, int K, cplx alpha, const cplx *A, int lda, 
         }
     }
     bool latency_mode = false;
-    const int vsel = choose_tile(M, Nn, K, batch, rows, &latency_mode);
+    const int vsel = choose_tile(M, Nn, K, dbatch, rows, &latency_mode);
     const int idxmode = rows && rows->schur4 ? 4 : (rows && !rows->dense ? (rows->fwd3 ? 2 : 1) : 0);
     const int xcd_map = helm_tuning_now().nd_xcd_map;
     for (int b0 = 0; b0 < batch && !split_done; b0 += 65535) {

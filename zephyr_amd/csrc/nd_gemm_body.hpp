@@ -74,7 +74,7 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
     const int m0 = byi * TM, n0 = bxi * TN;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave / WN, wn = wave % WN, lr = lane & 15, lq = lane >> 4;
-    const long long trow = IDX ? (long long)(R.z0 + bzi) * R.tab_stride : 0;
+    const long long trow = IDX ? (long long)(IDX == 4 ? (R.z0 + bzi) / R.nf : R.z0 + bzi) * R.tab_stride : 0;
     const bool idxB = IDX == 1 && R.tabB != nullptr;
     if (idxB) {
         for (int k = tid; k < K; k += 256) kidx[k] = R.tabB[trow + R.offB + k].x;
@@ -142,10 +142,11 @@ __device__ __forceinline__ void zgemm3_body(int M, int Nn, int K, cplx alpha, co
     const cplx *S0 = nullptr, *S1 = nullptr;
     int ld0 = 0, ld1 = 0;
     if (IDX == 4) {
-        const NdDev nd = R.nodes[R.first + R.z0 + bzi];
+        const int bg = R.z0 + bzi, kf = bg % R.nf;                 // (R.nf > 1: batch index = front * nf + frequency)
+        const NdDev nd = R.nodes[R.first + bg / R.nf];
         int base0 = 0, base1 = 0;
-        if (nd.kid[0] >= 0) { const NdDev c0 = R.nodes[nd.kid[0]]; S0 = R.arenaS + c0.foff + c0.smax; ld0 = c0.smax + c0.mmax; base0 = (int)(c0.voff + c0.smax); }
-        if (nd.kid[1] >= 0) { const NdDev c1 = R.nodes[nd.kid[1]]; S1 = R.arenaS + c1.foff + c1.smax; ld1 = c1.smax + c1.mmax; base1 = (int)(c1.voff + c1.smax); }
+        if (nd.kid[0] >= 0) { const NdDev c0 = R.nodes[nd.kid[0]]; ld0 = c0.smax + c0.mmax; S0 = R.arenaS + (long long)R.nf * c0.foff + (long long)kf * c0.mmax * ld0 + c0.smax; base0 = (int)(c0.voff + c0.smax); }
+        if (nd.kid[1] >= 0) { const NdDev c1 = R.nodes[nd.kid[1]]; ld1 = c1.smax + c1.mmax; S1 = R.arenaS + (long long)R.nf * c1.foff + (long long)kf * c1.mmax * ld1 + c1.smax; base1 = (int)(c1.voff + c1.smax); }
         for (int t = tid; t < TM + TN; t += 256) {
             const int q = t < TM ? m0 + t : n0 + (t - TM);
             int2 e = make_int2(-1, -1);

@@ -675,10 +675,11 @@ void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cp
     const int gj_base = base ? base : (align == 2 ? 64 : 32);
     const int recurse_min = g_recurse_min > 0 ? g_recurse_min : 3000;
     const bool recurse = align == 1 && n >= recurse_min && (long long)n * n <= ws;
-    if (!recurse && batch <= 1024 && n > gj_base && gj_base == 32 && (long long)2 * PNB * n <= ws) {
+    const int dbatch = std::max(1, batch / tl_nf_div);            // the batch the choices are made for (one frequency's share of a multi-frequency launch)
+    if (!recurse && dbatch <= 1024 && n > gj_base && gj_base == 32 && (long long)2 * PNB * n <= ws) {
         cplx *Wc = W, *Wr = W + (long long)PNB * n;
         const helm_tuning tune = helm_tuning_now();
-        if (tune.nd_gjstep && n >= tune.nd_gjstep_min && n <= 1536 && (long long)n * n <= ws && batch <= 32768) {
+        if (tune.nd_gjstep && n >= tune.nd_gjstep_min && n <= 1536 && (long long)n * n <= ws && dbatch <= 32768 && batch <= 32768) {
             // one launch per block step: the second copy of the matrix lives in W, the two P buffers in the handle's scratch
             cplx *Pb = gj_pbuf(op, batch);
             if (Pb) {
@@ -742,7 +743,7 @@ void invert(helm_op *op, cplx *M, int ld, long long stride, int n, int batch, cp
     if (n <= gj_base) {
         for (int b0 = 0; b0 < batch; b0 += 1 << 20) {
             const int nb = std::min(1 << 20, batch - b0);
-            if (n <= 32 && batch >= 2048) HELM_LAUNCH(k_gj32w_inverse, dim3((nb + 3) / 4), dim3(256), 0, st, M + b0 * stride, ld, stride, n, nb);
+            if (n <= 32 && dbatch >= 2048) HELM_LAUNCH(k_gj32w_inverse, dim3((nb + 3) / 4), dim3(256), 0, st, M + b0 * stride, ld, stride, n, nb);
             else if (n <= 32) HELM_LAUNCH(k_gj32_inverse, dim3(nb), dim3(256), 0, st, M + b0 * stride, ld, stride, n);
             else HELM_LAUNCH(k_gj_inverse<64>, dim3(nb), dim3(256), 0, st, M + b0 * stride, ld, stride, n);
         }

@@ -34,6 +34,7 @@ struct GemmRows {
     int schur4 = 0;
     const NdDev *nodes = nullptr; int first = 0;
     const cplx *arenaS = nullptr;
+    int nf = 1;                 // (schur4) batch index = front * nf + frequency: tables and node records go by the front, the children's blocks lie interleaved (direct.hpp)
     // forward pass on sparse right-hand sides (sources of a survey touch a handful of cells): act[front * nct + column / 64] != 0 when that front's
     // outgoing rows were computed for that block of 64 columns -- a front whose own right-hand-side rows and whose children's rows are all zero
     // there has nothing to add, writes zeros for its y_S rows and leaves its ring rows unwritten (its parent reads the flag, not the rows)
@@ -77,6 +78,10 @@ struct GemmRows {
 // Per-launch timing without extra packets: when gemm() has armed a pair of events, the dispatch itself carries them
 // (hipExtLaunchKernelGGL: start / stop timestamps of that kernel), instead of two hipEventRecord markers around it.
 extern thread_local hipEvent_t tl_ev0, tl_ev1;
+// While a set of nf frequencies is being factored the batches are nf times as long, and everything that CHOOSES by batch size -- tile shape, split of the inner
+// dimension, which small-inverse kernel -- must choose as for one frequency: the factors have to come out bit for bit those of the one-at-a-time path.
+extern thread_local int tl_nf_div;
+struct NfDivScope { int prev; explicit NfDivScope(int nf) : prev(tl_nf_div) { tl_nf_div = nf < 1 ? 1 : nf; } ~NfDivScope() { tl_nf_div = prev; } };
 #define ZG_LAUNCH(KERNEL, GRID, ...) do { HelmFirstLaunch fl_(HelmKernelReg<(KERNEL)>::slot); \
                                           if (tl_ev0) hipExtLaunchKernelGGL(KERNEL, GRID, dim3(256), 0, st, tl_ev0, tl_ev1, 0, __VA_ARGS__); \
                                           else hipLaunchKernelGGL(KERNEL, GRID, dim3(256), 0, st, __VA_ARGS__); } while (0)
@@ -226,8 +231,10 @@ void launch_zgemm3_la(hipStream_t st, bool latency_tile, int nb, int M, int Nn, 
                       cplx beta, cplx *C, int ldc, long long sc, const GemmRows &R, const GjPivotArgs &pv);
 // ---- nd_leaf.hip ----
 // the leaf level of the factorisation in one kernel (+ the pivoted re-elimination of the leaves it flags)
-void launch_leaf_factor(hipStream_t st, int smax, int nb, const NdDev *d_nodes, int first, cplx *arenaF, cplx *fac, cplx *g21b, const cplx *planes, int nz, int nx, int *flags, int dbg);
+void launch_leaf_factor(hipStream_t st, int smax, int nb, const NdDev *d_nodes, int first, cplx *arenaF, cplx *fac, cplx *g21b, const cplx *planes, int nz, int nx, int *flags, int dbg,
+                        int nf = 1, int kf = 0);
 // ---- nd_factor.hip ----
+struct FacSet { int nf = 1; NdFactor *f[ND_NF_MAX] = {nullptr, nullptr, nullptr, nullptr}; const cplx *planes[ND_NF_MAX] = {nullptr, nullptr, nullptr, nullptr}; double rtol[ND_NF_MAX] = {0, 0, 0, 0}; };
 int factor_prologue(helm_op *op, int block, NdFactor *f, const cplx *planes_in, const cplx **planes);
 int factor_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *work, const cplx *planes);     // factorisation of one group (tree level x kind) on op->stream
 bool merged_group(const NdPlan &P, const NdGroup &g);      // fronts that keep G = -F11^-1 F12 where F12 was (one-product back substitution): the leaves

@@ -83,7 +83,8 @@ __device__ __forceinline__ void leaf_fill(const NdDev &n, const cplx *planes, in
 }
 
 template <int SP>
-__global__ __launch_bounds__(128, 4) void k_leaf_factor(const NdDev *nodes, int first, cplx *arenaF, cplx *fac, cplx *g21base, const cplx *planes, int nz, int nx, int *flags, int dbg) {
+__global__ __launch_bounds__(128, 4) void k_leaf_factor(const NdDev *nodes, int first, cplx *arenaF, cplx *fac, cplx *g21base, const cplx *planes, int nz, int nx, int *flags, int dbg,
+                                                        int nf, int kf) {
     __shared__ cplx band[SP * LEAF_NB];
     __shared__ LeafTabs T;
     __shared__ float rowmax[SP];
@@ -130,7 +131,8 @@ __global__ __launch_bounds__(128, 4) void k_leaf_factor(const NdDev *nodes, int 
     const bool active = c < SP + mmax;
     const int gc = c < SP ? c : smax + (c - SP);                             // column in the [F11^-1 | G] rows of smax + mmax
     const bool stored = active && (c < SP ? c < smax : true);
-    cplx *Fcol = fac + n.finv_off + gc;
+    // (nf, kf: frequency kf of nf factored together -- this front's slots lie at nf * offset + kf * slot, direct.hpp; 1, 0: on its own)
+    cplx *Fcol = fac + (long long)nf * n.finv_off + (long long)kf * smax * nmax + gc;
     // right-hand side of this column: e_c, or -F12[:, c - SP] (three entries at most)
     int ra0 = -1, ra1 = -1, ra2 = -1;
     cplx rv0 = cmake(0.0, 0.0), rv1 = rv0, rv2 = rv0;
@@ -192,8 +194,8 @@ __global__ __launch_bounds__(128, 4) void k_leaf_factor(const NdDev *nodes, int 
     __syncthreads();                                                         // (every column of this leaf is in place: the other wave's too)
     // G21 = F21 F11^-1 (columns c < smax) and S = F21 G (columns SP .. SP + mmax): three-term sums over rows of [F11^-1 | G] read back
     if (active && !(dbg & 4)) {
-        cplx *G21 = g21base + (long long)blockIdx.x * mmax * smax;
-        cplx *S = arenaF + n.foff + smax;
+        cplx *G21 = g21base + ((long long)blockIdx.x * nf + kf) * mmax * smax;
+        cplx *S = arenaF + (long long)nf * n.foff + (long long)kf * mmax * nmax + smax;
         for (int r = 0; r < mmax; ++r) {
             cplx acc = cmake(0.0, 0.0);
             if (r < n.m && stored) {
@@ -211,7 +213,8 @@ __global__ __launch_bounds__(128, 4) void k_leaf_factor(const NdDev *nodes, int 
 
 
 // a flagged leaf once more, with row pivoting: dense Gauss-Jordan of F11 in LDS, then the same three sparse products
-__global__ __launch_bounds__(256) void k_leaf_factor_pivoted(const NdDev *nodes, int first, cplx *arenaF, cplx *fac, cplx *g21base, const cplx *planes, int nz, int nx, const int *flags) {
+__global__ __launch_bounds__(256) void k_leaf_factor_pivoted(const NdDev *nodes, int first, cplx *arenaF, cplx *fac, cplx *g21base, const cplx *planes, int nz, int nx, const int *flags,
+                                                             int nf, int kf) {
     if (!flags[blockIdx.x]) return;
     __shared__ cplx a[GJ_MAX][GJ_MAX + 1];
     __shared__ cplx fcol[GJ_MAX];
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(256) void k_leaf_factor_pivoted(const NdDev *nodes,
     }
     __syncthreads();
     gj_lds<GJ_MAX>(a, fcol, piv, smax, tid, 256);                         // a = F11^-1 (identity on the padding)
-    cplx *Frow = fac + n.finv_off;
+    cplx *Frow = fac + (long long)nf * n.finv_off + (long long)kf * smax * nmax;
     for (int e = tid; e < smax * nmax; e += 256) {
         const int i = e / nmax, cc = e % nmax;
         cplx v;
@@ -259,8 +262,8 @@ __global__ __launch_bounds__(256) void k_leaf_factor_pivoted(const NdDev *nodes,
         }
         Frow[(long long)i * nmax + cc] = v;
     }
-    cplx *G21 = g21base + (long long)blockIdx.x * mmax * smax;
-    cplx *S = arenaF + n.foff + smax;
+    cplx *G21 = g21base + ((long long)blockIdx.x * nf + kf) * mmax * smax;
+    cplx *S = arenaF + (long long)nf * n.foff + (long long)kf * mmax * nmax + smax;
     for (int e = tid; e < mmax * nmax; e += 256) {
         const int r = e / nmax, cc = e % nmax;
         cplx v = cmake(0.0, 0.0);
@@ -284,8 +287,10 @@ __global__ __launch_bounds__(256) void k_leaf_factor_pivoted(const NdDev *nodes,
 
 }  // namespace
 
-void launch_leaf_factor(hipStream_t st, int smax, int nb, const NdDev *d_nodes, int first, cplx *arenaF, cplx *fac, cplx *g21b, const cplx *planes, int nz, int nx, int *flags, int dbg) {
-    if (smax <= 49) HELM_LAUNCH(k_leaf_factor<49>, dim3(nb), dim3(128), 0, st, d_nodes, first, arenaF, fac, g21b, planes, nz, nx, flags, dbg);
-    else HELM_LAUNCH(k_leaf_factor<64>, dim3(nb), dim3(128), 0, st, d_nodes, first, arenaF, fac, g21b, planes, nz, nx, flags, dbg);
-    HELM_LAUNCH(k_leaf_factor_pivoted, dim3(nb), dim3(256), 0, st, d_nodes, first, arenaF, fac, g21b, planes, nz, nx, (const int *)flags);
+// (nf, kf: frequency kf of a set of nf -- fac / arenaF / g21b are the SET's bases, the kernels place this frequency's slots among the interleaved ones)
+void launch_leaf_factor(hipStream_t st, int smax, int nb, const NdDev *d_nodes, int first, cplx *arenaF, cplx *fac, cplx *g21b, const cplx *planes, int nz, int nx, int *flags, int dbg,
+                        int nf, int kf) {
+    if (smax <= 49) HELM_LAUNCH(k_leaf_factor<49>, dim3(nb), dim3(128), 0, st, d_nodes, first, arenaF, fac, g21b, planes, nz, nx, flags, dbg, nf, kf);
+    else HELM_LAUNCH(k_leaf_factor<64>, dim3(nb), dim3(128), 0, st, d_nodes, first, arenaF, fac, g21b, planes, nz, nx, flags, dbg, nf, kf);
+    HELM_LAUNCH(k_leaf_factor_pivoted, dim3(nb), dim3(256), 0, st, d_nodes, first, arenaF, fac, g21b, planes, nz, nx, (const int *)flags, nf, kf);
 }

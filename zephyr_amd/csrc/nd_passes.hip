@@ -190,7 +190,7 @@ void forward_group_batched(helm_op *op, NdFactor *f, size_t gi, const SolveCtx &
             }
             R.hint = 1;
         }
-        gemm(op, g.mmax, nrhs, g.smax, mone, f->d_fac + g.g21, g.smax, (long long)g.mmax * g.smax, nullptr, 0, 0, zero,
+        gemm(op, g.mmax, nrhs, g.smax, mone, nd_fac_at(f, g.g21, (long long)g.mmax * g.smax), g.smax, nd_fac_stride(f, (long long)g.mmax * g.smax), nullptr, 0, 0, zero,
              V + (long long)g.smax * nrhs, nrhs, (long long)nmax * nrhs, g.cnt, &R);
         if (c.act && !R.act) hipMemsetAsync(c.act + (long long)g.first * c.nct, 1, (size_t)g.cnt * c.nct * sizeof(int), op->stream);
         return;
@@ -213,7 +213,7 @@ void forward_group_batched(helm_op *op, NdFactor *f, size_t gi, const SolveCtx &
             R.list = c.flist; R.lcount = c.fcount + gi;
         }
         { const NdDev &n0 = P.nodes[g.first]; R.child_rows = (n0.kid[0] >= 0 ? P.nodes[n0.kid[0]].mmax : 0) + (n0.kid[1] >= 0 ? P.nodes[n0.kid[1]].mmax : 0); }
-        gemm(op, g.mmax, nrhs, g.smax, mone, f->d_fac + g.g21, g.smax, (long long)g.mmax * g.smax, nullptr, 0, 0, one,
+        gemm(op, g.mmax, nrhs, g.smax, mone, nd_fac_at(f, g.g21, (long long)g.mmax * g.smax), g.smax, nd_fac_stride(f, (long long)g.mmax * g.smax), nullptr, 0, 0, one,
              V + (long long)g.smax * nrhs, nrhs, (long long)nmax * nrhs, g.cnt, &R);
         if (c.act && !R.act) hipMemsetAsync(c.act + (long long)g.first * c.nct, 1, (size_t)g.cnt * c.nct * sizeof(int), op->stream);
         return;
@@ -222,7 +222,7 @@ void forward_group_batched(helm_op *op, NdFactor *f, size_t gi, const SolveCtx &
                        (const int *)c.act, c.nct, (const NdDev *)f->pd->d_nodes, g.first, nmax);
     if (c.act) hipMemsetAsync(c.act + (long long)g.first * c.nct, 1, (size_t)g.cnt * c.nct * sizeof(int), op->stream);      // (these fronts write every row)
     if (g.mmax > 0)     // outgoing ring part: V_B -= G21 V_S
-        gemm(op, g.mmax, nrhs, g.smax, mone, f->d_fac + g.g21, g.smax, (long long)g.mmax * g.smax, V, nrhs, (long long)nmax * nrhs, one,
+        gemm(op, g.mmax, nrhs, g.smax, mone, nd_fac_at(f, g.g21, (long long)g.mmax * g.smax), g.smax, nd_fac_stride(f, (long long)g.mmax * g.smax), V, nrhs, (long long)nmax * nrhs, one,
              V + (long long)g.smax * nrhs, nrhs, (long long)nmax * nrhs, g.cnt);
 }
 
@@ -268,8 +268,8 @@ void backward_group_batched(helm_op *op, NdFactor *f, size_t gk, const SolveCtx 
     const NdGroup &g = P.groups[gk];
     const int nmax = g.smax + g.mmax, nrhs = c.nrhs;
     const long long rows = (long long)g.cnt * nmax;
-    const long long s1 = (long long)g.smax * nmax;                 // stride of a front's [F11^-1 | F12] rows
-    const cplx *Finv = f->d_fac + g.finv, *F12 = f->d_fac + g.f12;
+    const long long s1 = nd_fac_stride(f, (long long)g.smax * nmax);      // stride of a front's [F11^-1 | F12] rows (nf times the slot for a factor of a set, direct.hpp)
+    const cplx *Finv = nd_fac_at(f, g.finv, (long long)g.smax * nmax), *F12 = Finv + g.smax;
     // leaves hold G = -F11^-1 F12 in place of F12: x_S = F11^-1 y_S + G x_B
     const bool gform = merged_group(P, g);
     cplx *V = c.arenaV + g.voff * nrhs;

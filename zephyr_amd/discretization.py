@@ -375,6 +375,27 @@ class BaseDiscretization(BaseModelDependent):
         return self * value
 
 
+def prefactor_many(ops):
+    """Start the factorisations the next solves on `ops` need in the SAME launches and return at once (helm_prefactor_many): operators of one grid on one GPU,
+    at most four; the latency-bound top of the elimination tree is then walked once for all of them.  Every operator's factors are bit for bit what
+    `op.prefactor()` would have made; operators the library cannot take together are prefactored one by one.  The reference's dispatcher overlaps
+    frequencies with a process pool (distributors.py:161-168) -- `zephyr_amd.dispatch` groups its prepare step around this call."""
+    ops = [op for op in ops if op is not None]
+    if not ops:
+        return
+    direct = [op for op in ops if str(op.method).lower() in ('auto', 'direct') and hasattr(op, 'handle')]
+    for op in ops:
+        if op not in direct and hasattr(op, 'prefactor'):
+            op.prefactor()
+    lib = _lib.load()
+    for i in range(0, len(direct), 4):
+        part = direct[i:i + 4]
+        for op in part:
+            lib.helm_set_tolerance_hint(op.handle, float(op.rtol))       # the factors are conditioned for the tolerance the solves will ask for
+        hs = (ctypes.c_void_p * len(part))(*[op.handle for op in part])
+        _lib.check(lib.helm_prefactor_many(hs, len(part)), part[0].handle)
+
+
 class DiscretizationWrapper(BaseSCCache):
     """Composite of sub-problems built from per-sub-problem config updates (discretization.py:109-169)."""
 

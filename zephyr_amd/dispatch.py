@@ -125,10 +125,15 @@ class WorkItem(object):
 class DevicePipeline(object):
     """Two threads for one GPU: items are prepared up to `lookahead` ahead of the one being solved."""
 
-    def __init__(self, device, lookahead=1, strict=False, solvers=1):
+    def __init__(self, device, lookahead=1, strict=False, solvers=1, group=1, group_prepare=None):
         self.device = device
         self.lookahead = max(0, int(lookahead))
         self.strict = bool(strict)
+        # group > 1: the prepare thread takes its items `group` at a time -- every item's own prepare() first (build, assemble), then ONE call
+        # group_prepare([prepared objects]) for the lot (discretization.prefactor_many: their factorisations in the same launches), then they are handed to the
+        # solve thread one by one.  The items' own prepare() must then leave the factorisation to group_prepare.
+        self.group = 1 if self.strict else max(1, int(group))
+        self.group_prepare = group_prepare if self.group > 1 else None
         # solvers > 1: that many solve threads take the prepared items in turn, so that the launches of item k+1's solve are already queued while the
         # host still waits for the residual norms of item k (every solve ends with a read-back the host has to look at).  The items of one pipeline
         # must then not share buffers they write (each solve thread's items run one after the other, those of different threads side by side).
@@ -142,7 +147,7 @@ class DevicePipeline(object):
         if self.lookahead == 0:
             self._launch([threading.Thread(target=self._guard(self._serial), args=(items,), name='helm-dev%d' % self.device)])
             return
-        ready = queue.Queue(maxsize=max(self.lookahead, self.solvers))
+        ready = queue.Queue(maxsize=max(self.lookahead * self.group, self.solvers))
         # strict: item k+1 is prepared while item k is being solved and not before (a queue of one lets the prepare thread start on item k+2
         # as soon as item k+1 waits in it) -- for operators whose preparation is heavy on the GPU and in memory (3-D preconditioners)
         gate = threading.Semaphore(1) if self.strict else None
@@ -210,6 +215,22 @@ class DevicePipeline(object):
             self._run_solve(item)
 
     def _prepare_loop(self, items, ready, gate=None):
+        if self.group > 1:
+            for i in range(0, len(items), self.group):
+                part = items[i:i + self.group]
+                try:
+                    for item in part:
+                        self._run_prepare(item)
+                    good = [item for item in part if item._error is None]
+                    if self.group_prepare is not None and good:
+                        self.group_prepare([item._prepared for item in good])
+                except BaseException as exc:        # (an exception of the group's step belongs to every item of the group)
+                    for item in part:
+                        if item._error is None:
+                            item._error = exc
+                for item in part:
+                    ready.put(item)
+            return
         for item in items:
             try:
                 if gate is not None:
@@ -251,11 +272,11 @@ def dispatch(workers, lookahead=1, strict=False):
     return pipes
 
 
-def pipelined(items, device=0, lookahead=1, strict=False, solvers=1):
+def pipelined(items, device=0, lookahead=1, strict=False, solvers=1, group=1, group_prepare=None):
     """Run `items` on one device with prepare-ahead and yield their results in order (exceptions surface where the
-    failing item's result is consumed)."""
+    failing item's result is consumed).  group / group_prepare: see DevicePipeline."""
     items = list(items)
-    pipe = DevicePipeline(device, lookahead, strict, solvers)
+    pipe = DevicePipeline(device, lookahead, strict, solvers, group, group_prepare)
     pipe.start(items)
     try:
         for item in items:
