@@ -179,3 +179,31 @@ def test_warm_resolves_every_kernel_and_a_second_job_creates_nothing(helm_lib):
     st = _lib.runtime_stats()
     assert st['dev_allocs'] == 0 and st['host_allocs'] == 0 and st['streams_created'] == 0, st
     assert st['first_launches'] == 0, st
+
+
+def test_job_over_eight_logical_devices_matches_the_serial_job_checksum_for_checksum(helm_lib, monkeypatch):
+    """The 16-frequency job dealt over eight workers (HELM_DEVICES = 0 x 8: the in-process counterpart of the reference's pool, distributors.py:161-173, on the
+    one GPU of this box) returns, frequency by frequency, exactly the wavefields of the serial dispatch: same order, same bits.  1024^2 with the bench model
+    when HELM_TEST_FULL=1 (tests/test_gpu_fullsize.py covers that size against the LU), 256^2 otherwise."""
+    import hashlib
+    import zephyr_amd as za
+    from zephyr_amd.models import marmousi_like
+    n = 1024 if os.environ.get('HELM_TEST_FULL') == '1' else 256
+    dx = 9.0 if n == 1024 else 12.0
+    nsrc = 16
+    sc = dict(nx=n, nz=n, dx=dx, dz=dx, c=marmousi_like(n, n, dx), nPML=10, freqs=[float(f) for f in np.linspace(2.0, 9.5, 16)], Disc=za.Eurus, rtol=1e-10)
+    locs = np.stack([np.linspace(0.1 * n * dx, 0.9 * n * dx, nsrc), np.full(nsrc, 2 * dx)], axis=1)
+    q = za.SparseKaiserSource(sc)(locs)
+
+    def sums(cfg):
+        out = []
+        mf = za.MultiFreq(cfg)
+        for u in mf * q:
+            out.append(hashlib.sha256(np.ascontiguousarray(u).tobytes()).hexdigest())
+            del u
+        del mf.factors
+        return out
+    serial = sums(dict(sc, parallel=False))
+    monkeypatch.setenv('HELM_DEVICES', '0,0,0,0,0,0,0,0')
+    par = sums(sc)
+    assert len(par) == 16 and par == serial

@@ -7,7 +7,7 @@ REPS=${2:-3}
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 for i in $(seq 1 $REPS); do
-  HELM_LAUNCH_TRACE=1 HELM_ALLOC_TRACE=2 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-config5 --no-config2 --no-config4 --no-host-api > $OUT/run$i.json 2> $OUT/run$i.err
+  HELM_LAUNCH_TRACE=1 HELM_ALLOC_TRACE=2 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-config5 --no-config2 --no-config4 --no-host-api ${BENCH_EXTRA:-} > $OUT/run$i.json 2> $OUT/run$i.err
   python3 - $OUT/run$i.json <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

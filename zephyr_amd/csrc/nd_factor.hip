@@ -799,10 +799,13 @@ int nd_factor_enqueue(helm_op *op, int block, NdFactor *f, cplx *ws, const cplx 
     const cplx *planes = nullptr;
     int rc = factor_prologue(op, block, f, planes_in, &planes);
     if (rc) return rc;
+    GroupTrace tr(op->stream, "factor");
     for (size_t gi = 0; gi < P.groups.size(); ++gi) {
         rc = factor_group(op, f, gi, ws, ws + 2 * P.fregion, planes);
         if (rc) return rc;
+        tr.mark();
     }
+    tr.report(P, false);
     return check_kernels(op, "factorisation kernels");
 }
 
@@ -825,10 +828,13 @@ int nd_factor_enqueue_many(helm_op *op, int nf, helm_op *const *ops, NdFactor *c
         S.f[k] = f; S.planes[k] = ops[k]->d_C; S.rtol[k] = ops[k]->rtol_hint;
     }
     cplx *arenaF = ws, *work = ws + (long long)nf * 2 * P.fregion;
+    GroupTrace tr(op->stream, nf == 2 ? "factor x2" : (nf == 3 ? "factor x3" : "factor x4"));      // (HELM_ND_TRACE=1: per-level device time, and a wait at the end)
     for (size_t gi = 0; gi < P.groups.size(); ++gi) {
         const int rc = factor_group_set(op, S, gi, arenaF, work);
         if (rc) return rc;
+        tr.mark();
     }
+    tr.report(P, false);
     for (int k = 1; k < nf; ++k) { fs[k]->d_est = nullptr; fs[k]->est_elems = 0; }      // (the estimates hang off frequency 0's factor and the shared record)
     return check_kernels(op, "factorisation kernels");
 }

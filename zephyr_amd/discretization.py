@@ -383,7 +383,7 @@ def prefactor_many(ops):
     ops = [op for op in ops if op is not None]
     if not ops:
         return
-    direct = [op for op in ops if str(op.method).lower() in ('auto', 'direct') and hasattr(op, 'handle')]
+    direct = [op for op in ops if getattr(type(op), 'VARIANT', None) in (_lib.HELM_MINIZEPHYR, _lib.HELM_EURUS) and str(getattr(op, 'method', '')).lower() in ('auto', 'direct')]
     for op in ops:
         if op not in direct and hasattr(op, 'prefactor'):
             op.prefactor()

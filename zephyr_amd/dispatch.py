@@ -258,7 +258,7 @@ class DevicePipeline(object):
             self._run_solve(ready.get())
 
 
-def dispatch(workers, lookahead=1, strict=False):
+def dispatch(workers, lookahead=1, strict=False, group=1, group_prepare=None):
     """Start one DevicePipeline per worker.  workers: [(device, [WorkItem, ...]), ...] (each list in the order it should run;
     the same device may appear twice: two pipelines then share that GPU).  Returns the pipelines (join() them, or just wait on
     the items' futures)."""
@@ -266,7 +266,7 @@ def dispatch(workers, lookahead=1, strict=False):
         workers = list(workers.items())
     pipes = []
     for dev, items in workers:
-        p = DevicePipeline(dev, lookahead, strict)
+        p = DevicePipeline(dev, lookahead, strict, 1, group, group_prepare)
         p.start(items)
         pipes.append(p)
     return pipes

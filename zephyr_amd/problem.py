@@ -155,11 +155,19 @@ class HelmBaseProblem(BaseModelDependent, BaseSCCache):
         worker, for its device buffers), the factorisation of the worker's next item started ahead of time."""
         states = [dict(device=d) for d in devs]
         queues = [[] for _ in devs]
+        # the factorisations of a worker's next two operators are enqueued together (discretization.prefactor_many: the fronts of both frequencies in the same
+        # batched launches); an item's own prepare step then only builds and assembles its operator
+        from .discretization import prefactor_many
+        group = 2 if all(getattr(type(op), 'VARIANT', None) in (_lib.HELM_MINIZEPHYR, _lib.HELM_EURUS) for _, op, _, _, _ in items) else 1      # (2-D operators: what helm_prefactor_many takes)
         for w, op, ifreq, c0, c1 in items:
             def solve(_p, w=w, op=op, ifreq=ifreq, c0=c0, c1=c1):
                 return fn(states[w], op, ifreq, c0, c1)
-            queues[w].append(dispatch.WorkItem(solve, op.prefactor if hasattr(op, 'prefactor') else None))
-        pipes = dispatch.dispatch(list(zip(devs, queues)), lookahead=1)
+            if group > 1:
+                prep = (lambda op=op: (op.handle, op)[1])
+            else:
+                prep = op.prefactor if hasattr(op, 'prefactor') else None
+            queues[w].append(dispatch.WorkItem(solve, prep))
+        pipes = dispatch.dispatch(list(zip(devs, queues)), lookahead=1, group=group, group_prepare=prefactor_many if group > 1 else None)
         try:
             out = [it.future.result() for q in queues for it in q]
         finally:
