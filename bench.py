@@ -63,6 +63,15 @@ def cgroup_cpu():
     return quota, nthr, usec
 
 
+def memtrace(what):
+    'HELM_BENCH_MEMTRACE=1: free device memory (hipMemGetInfo) at the phases of the run, on stderr'
+    if os.environ.get('HELM_BENCH_MEMTRACE'):
+        import torch
+        free, tot = torch.cuda.mem_get_info()
+        sys.stderr.write('[bench mem] %-34s free %6.1f of %6.1f GB\n' % (what, free / 1e9, tot / 1e9))
+        sys.stderr.flush()
+
+
 def build_config(n, dx):
     from zephyr_amd.models import marmousi_like
     # complex128 once, here: the discretisation classes cast `c` to complex128 at construction (discretization.py:23-31), which for a
@@ -746,6 +755,7 @@ def main():
     agg = aggregate(results)
     barrier()
     elapsed = time.perf_counter() - t0
+    memtrace('after the timed region')
     rt_timed = _zl0.runtime_stats()
     cg1 = cgroup_cpu()
     rt_timed['cpu_quota_cores'] = cg1[0]
@@ -825,6 +835,7 @@ def main():
         tj = max_over_ranks(time.perf_counter() - t1)
         strong_job = {'wavefields': NFREQ * nb * B, 'seconds': tj, 'value': NFREQ * nb * B / tj, 'unit': 'wavefields/s',
                       'what': 'the whole 16-frequency job (every frequency x %d sources), its work items round-robin over the %d rank(s); max over ranks' % (B * nb, world)}
+    memtrace('after the extra passes')
     wavefields = (NFREQ * nb * B) if args.scaling == 'strong' else world * args.steps * B
     value = wavefields / elapsed
 
@@ -1023,6 +1034,9 @@ def main():
                 from zephyr_amd import MultiFreq
                 del d_u
                 torch.cuda.empty_cache()
+                from zephyr_amd import _lib as _zl1
+                _zl1.load().helm_trim()          # (every leg starts from empty pools and warms its own: what the passes above left idle -- tens of GB -- goes back to the device)
+                memtrace('before the host-API leg')
                 best = None
                 for wpd in (1, 3):
                     os.environ['HELM_WORKERS_PER_DEVICE'] = str(wpd)
@@ -1058,6 +1072,12 @@ def main():
                 out['value_host_api'] = best
             except Exception as exc:
                 out['value_host_api'] = 'failed: %s' % exc
+            try:
+                from zephyr_amd import _lib as _zl2
+                _zl2.load().helm_trim(); _zl2.load().helm_host_trim()
+            except Exception:
+                pass
+            memtrace('after the host-API leg')
             d_u = torch.empty((N, B) if node else (B, N), dtype=torch.complex128, device=dev)
         out['config4'] = c4
         if world == 1 and not args.no_config2 and direct:

@@ -360,7 +360,7 @@ int helm_events_grow(helm_op *op, int n) {
 // (small buffers too: hipFree waits for every stream of the device, which would stall a host thread that prepares the next operator
 // while another one is solving -- the per-operator scratch of a few KB goes through the pool like the GB-sized buffers)
 static const size_t kPoolMinBytes = (size_t)64;
-// What the pool may hold idle: three quarters of the device's memory (HELM_POOL_GB overrides; buffers below 1 MB are always kept: their hipFree
+// What the pool may hold idle: half of the device's memory (HELM_POOL_GB overrides; buffers below 1 MB are always kept: their hipFree
 // would be a device synchronisation for nothing).  A 16-frequency job at 1024^2 hands back ~70 GB of
 // factors when its operators go; with a 64-GB cap the overflow went to hipFree and the next job's hipMalloc calls -- issued while other
 // threads had kernels and copies in flight -- took 1.2-1.5 s EACH (HELM_ALLOC_TRACE=1 shows them).
@@ -372,7 +372,7 @@ static size_t pool_cap_bytes(int device) {          // (call with g_pool.mu held
     if (const char *e = getenv("HELM_POOL_GB")) cap = (size_t)(atof(e) * 1e9);
     else {
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess) cap = prop.totalGlobalMem / 4 * 3;     // (in use + idle here cannot exceed the device: a failed hipMalloc empties the pool and retries)
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) cap = prop.totalGlobalMem / 2;     // (r6: half, not three quarters -- the caller's own allocator (torch) lives on the same device and cannot make this pool give anything back)
         else (void)hipGetLastError();
     }
     caps[device] = cap;
@@ -565,12 +565,17 @@ void *helm_pool_alloc(int device, size_t bytes) {
         // failing that -- and for small requests from the start -- the smallest idle buffer that holds the request and is at most twice its size (+ 1 MB).
         // (Measured, round 6: with the own-class rule alone the bench job allocated 5.2 GB inside its timed region in every run -- 0.6 ms on one box, 122 ms
         // on another, which is the kind of stall that cost round 5's driver run a fifth of its headline; with the fall-back: nothing above 8 MB.)
+        static const double slack = getenv("HELM_POOL_SLACK") ? std::max(1.0, atof(getenv("HELM_POOL_SLACK"))) : 2.0;      // (diagnostic: 1 = a request's own size class only)
+        static const int ptrace = getenv("HELM_ALLOC_TRACE") ? atoi(getenv("HELM_ALLOC_TRACE")) : 0;
         auto it = g_pool.idle.end();
         if (bytes >= ((size_t)64 << 20)) it = g_pool.idle.find(std::make_pair(device, pool_size_class(bytes)));
         if (it == g_pool.idle.end()) {
             it = g_pool.idle.lower_bound(std::make_pair(device, bytes));
-            if (it != g_pool.idle.end() && (it->first.first != device || it->first.second > 2 * bytes + ((size_t)1 << 20))) it = g_pool.idle.end();
+            if (it != g_pool.idle.end() && (it->first.first != device || (double)it->first.second > slack * (double)bytes + (double)((size_t)1 << 20))) it = g_pool.idle.end();
         }
+        if (ptrace >= 3 && bytes >= ((size_t)64 << 20))
+            fprintf(stderr, "[helm pool] request %9.1f MB (class %9.1f MB): %s %9.1f MB\n", bytes / 1e6, pool_size_class(bytes) / 1e6, it != g_pool.idle.end() ? "served by an idle buffer of" : "MISS, allocating",
+                    (it != g_pool.idle.end() ? it->first.second : pool_size_class(bytes)) / 1e6);
         if (it != g_pool.idle.end()) {
             void *p = it->second; g_pool.held[device] -= it->first.second; g_pool.idle.erase(it); return p;
         }
