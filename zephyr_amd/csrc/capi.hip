@@ -340,6 +340,7 @@ struct SharedWs { std::mutex mu; std::map<int, WsDevice> dev; };
 static SharedWs g_shared_ws;
 static int shared_ws_slots() { const int n = helm_tuning_now().ws_slots; return n < 1 ? 1 : (n > WS_SLOTS_MAX ? WS_SLOTS_MAX : n); }
 static int g_live_handles = 0;     // guarded by g_shared_ws.mu
+static std::map<int, int> g_live_per_device;      // guarded by g_shared_ws.mu
 
 // idle device buffers by (device, size); `held` and the cap are per device (r4: one sum over all GPUs hit a single device's cap with the second GPU's buffers)
 struct DevPool { std::mutex mu; std::multimap<std::pair<int, size_t>, void *> idle; std::map<int, size_t> held; };
@@ -482,6 +483,8 @@ size_t helm_pool_idle_bytes(int device) {
 }
 static void pool_forget(void *p);       // (g_pool.mu held) the buffer has gone back to the driver
 static std::map<void *, bool> g_carved;  // blocks that are pieces of a slab (see slab_carve; guarded by g_pool.mu)
+struct PoolClassStat { int in_use = 0, high = 0, total = 0; };
+static std::map<std::pair<int, size_t>, PoolClassStat> g_pool_stats;         // (device, capacity) of big buffers; guarded by g_pool.mu        // (see pool_top_up)
 // give this device's idle buffers back to the driver (the current device must be `device`)
 static void pool_flush_device(int device) {
     std::lock_guard<std::mutex> lk(g_pool.mu);
@@ -494,6 +497,7 @@ static void pool_flush_device(int device) {
         it = g_pool.idle.erase(it);
     }
     g_pool.held[device] = kept;
+    for (auto is = g_pool_stats.begin(); is != g_pool_stats.end(); ) { if (is->first.first == device) { is->second.total = is->second.in_use; is->second.high = is->second.in_use; } ++is; }
 }
 // hipMalloc that, under memory pressure, empties the device's idle pool and tries once more -- for every allocation of the library that does
 // not go through the size-keyed pool itself (scratch slots, temporaries of the host-buffer entry points, plans)
@@ -513,7 +517,16 @@ hipError_t helm_malloc_retry(int device, void **p, size_t bytes) {
 // allocated in size classes (steps of 1/8 of the power of two below, at least 4 KB), and the pool remembers every buffer's capacity, so a buffer
 // goes back under what it can hold, not under what it was asked for.
 static std::map<void *, size_t> g_pool_capacity;        // every live buffer that came out of helm_pool_alloc: what it can hold (guarded by g_pool.mu)
-static void pool_forget(void *p) { g_pool_capacity.erase(p); }
+// One spare beyond the high-water mark (big buffers, 64 MB .. 16 GB): the pool of a class holds what the busiest moment so far needed, and a pipelined job's busiest
+// moment is a matter of thread timing -- a job that got by with three factor buffers in its first five items asked for a fourth in its next twenty (round 6: 3 to 5 GB
+// of hipMalloc inside the bench's timed region in one run of three; 0.6 ms on one box, 122 ms on another = the stall that cost round 5's driver run a fifth of its
+// headline).  When the last operator of a device is destroyed -- every buffer idle, nobody waiting -- each such class is topped up to high-water + 1.
+static const size_t kSpareMin = (size_t)64 << 20, kSpareMax = (size_t)16 << 30;
+static void pool_forget(void *p) {
+    auto it = g_pool_capacity.find(p);
+    if (it == g_pool_capacity.end()) return;
+    g_pool_capacity.erase(it);
+}
 // Small buffers (size class up to 16 MB: per-operator flags, estimates, split-K partials, the pivoted-LU storage of ill-conditioned fronts ...) come out of
 // slabs of 512 MB, one hipMalloc each, carved by a bump pointer and recycled through the idle table like every other buffer.  Their sizes follow the operator
 // -- how many fronts a frequency has flagged, which products split their inner dimension -- so a job met half a dozen new ones per pass over its frequencies
@@ -577,7 +590,9 @@ void *helm_pool_alloc(int device, size_t bytes) {
             fprintf(stderr, "[helm pool] request %9.1f MB (class %9.1f MB): %s %9.1f MB\n", bytes / 1e6, pool_size_class(bytes) / 1e6, it != g_pool.idle.end() ? "served by an idle buffer of" : "MISS, allocating",
                     (it != g_pool.idle.end() ? it->first.second : pool_size_class(bytes)) / 1e6);
         if (it != g_pool.idle.end()) {
-            void *p = it->second; g_pool.held[device] -= it->first.second; g_pool.idle.erase(it); return p;
+            void *p = it->second; g_pool.held[device] -= it->first.second;
+            if (it->first.second >= kSpareMin) { PoolClassStat &cs = g_pool_stats[std::make_pair(device, it->first.second)]; cs.in_use += 1; cs.high = std::max(cs.high, cs.in_use); }
+            g_pool.idle.erase(it); return p;
         }
     }
     void *p = nullptr;
@@ -590,7 +605,31 @@ void *helm_pool_alloc(int device, size_t bytes) {
     if (helm_malloc_retry(device, &p, cap) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lk(g_pool.mu);
     g_pool_capacity[p] = cap;
+    if (cap >= kSpareMin) { PoolClassStat &cs = g_pool_stats[std::make_pair(device, cap)]; cs.total += 1; cs.in_use += 1; cs.high = std::max(cs.high, cs.in_use); }
     return p;
+}
+// (see PoolClassStat) called with no operator of the device alive
+static void pool_top_up(int device) {
+    std::vector<size_t> want;
+    {
+        std::lock_guard<std::mutex> lk(g_pool.mu);
+        const size_t cap = pool_cap_bytes(device);
+        size_t held = g_pool.held[device];
+        for (auto &kv : g_pool_stats) {
+            if (kv.first.first != device || kv.first.second > kSpareMax) continue;
+            PoolClassStat &cs = kv.second;
+            for (int k = cs.total; k < cs.high + 1 && cs.high > 0; ++k) { if (held + kv.first.second > cap) break; want.push_back(kv.first.second); held += kv.first.second; }
+        }
+    }
+    for (size_t bytes : want) {
+        void *p = nullptr;
+        AllocTrace tr("pool spare", bytes);
+        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; }        // (a spare is a convenience: no flush-and-retry for it)
+        std::lock_guard<std::mutex> lk(g_pool.mu);
+        g_pool_capacity[p] = bytes;
+        g_pool_stats[std::make_pair(device, bytes)].total += 1;
+        g_pool.idle.insert(std::make_pair(std::make_pair(device, bytes), p)); g_pool.held[device] += bytes;
+    }
 }
 void helm_pool_slab_reserve(int device) { slab_reserve(device); }
 void helm_pool_free(int device, void *p, size_t bytes) {
@@ -600,6 +639,7 @@ void helm_pool_free(int device, void *p, size_t bytes) {
         auto ic = g_pool_capacity.find(p);
         if (ic != g_pool_capacity.end()) bytes = ic->second;            // (a buffer that did not come from the pool is taken in under the size the caller states)
         else g_pool_capacity[p] = bytes;
+        if (bytes >= kSpareMin) { auto is = g_pool_stats.find(std::make_pair(device, bytes)); if (is != g_pool_stats.end() && is->second.in_use > 0) is->second.in_use -= 1; }
         const size_t cap = pool_cap_bytes(device);
         size_t &held = g_pool.held[device];
         if (g_carved.count(p) || (bytes >= kPoolMinBytes && (held + bytes <= cap || bytes < ((size_t)1 << 20)))) {
@@ -607,6 +647,7 @@ void helm_pool_free(int device, void *p, size_t bytes) {
             return;
         }
         g_pool_capacity.erase(p);
+        if (bytes >= kSpareMin) { auto is = g_pool_stats.find(std::make_pair(device, bytes)); if (is != g_pool_stats.end() && is->second.total > 0) is->second.total -= 1; }
     }
     AllocTrace tr("pool hipFree", bytes);
     hipFree(p);
@@ -645,7 +686,7 @@ extern "C" helm_op *helm_create(int device, int variant, int nz, int nx, double 
 
 static helm_op *create_common(helm_op *op) {
     const int device = op->device;
-    { std::lock_guard<std::mutex> lk(g_shared_ws.mu); g_live_handles += 1; }      // helm_destroy takes it back on every exit
+    { std::lock_guard<std::mutex> lk(g_shared_ws.mu); g_live_handles += 1; g_live_per_device[device] += 1; }      // helm_destroy takes it back on every exit
     HIP_TRY_NULL(hipSetDevice(device));
     {   // first operator of this device in the process: resolve the library's kernels now, not one by one inside the first solves of each kind
         static std::mutex wmu; static std::map<int, bool> warmed;
@@ -700,9 +741,17 @@ extern "C" void helm_destroy(helm_op *op) {
     }
     if (op->side_stream) helm_stream_release(op->device, -1, op->side_stream);
     if (op->own_stream && op->stream) helm_stream_release(op->device, 0, op->stream);
+    const int device = op->device;
     delete op;
-    std::lock_guard<std::mutex> lk(g_shared_ws.mu);
-    g_live_handles -= 1;
+    bool last = false;
+    {
+        std::lock_guard<std::mutex> lk(g_shared_ws.mu);
+        g_live_handles -= 1;
+        int &n = g_live_per_device[device];
+        if (n > 0) n -= 1;
+        last = n == 0;
+    }
+    if (last && tune_i("HELM_POOL_SPARE", 1)) pool_top_up(device);      // (nobody is waiting for this thread now: the spares of the big size classes, see PoolClassStat)
 }
 
 // Release what the library caches between calls (the shared scratch of the direct path).  The scratch is kept across
@@ -728,6 +777,7 @@ extern "C" int helm_trim(void) {
             it = g_pool.idle.erase(it);
         }
         g_pool.held = kept;
+        for (auto &kv : g_pool_stats) { kv.second.total = kv.second.in_use; kv.second.high = kv.second.in_use; }
     }
     (void)hipSetDevice(cur);
     return helm_host_trim();
