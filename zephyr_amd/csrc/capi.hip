@@ -517,10 +517,13 @@ hipError_t helm_malloc_retry(int device, void **p, size_t bytes) {
 // allocated in size classes (steps of 1/8 of the power of two below, at least 4 KB), and the pool remembers every buffer's capacity, so a buffer
 // goes back under what it can hold, not under what it was asked for.
 static std::map<void *, size_t> g_pool_capacity;        // every live buffer that came out of helm_pool_alloc: what it can hold (guarded by g_pool.mu)
-// One spare beyond the high-water mark (big buffers, 64 MB .. 16 GB): the pool of a class holds what the busiest moment so far needed, and a pipelined job's busiest
+// Spares beyond the high-water mark (big buffers, 64 MB .. 16 GB): the pool of a class holds what the busiest moment so far needed, and a pipelined job's busiest
 // moment is a matter of thread timing -- a job that got by with three factor buffers in its first five items asked for a fourth in its next twenty (round 6: 3 to 5 GB
 // of hipMalloc inside the bench's timed region in one run of three; 0.6 ms on one box, 122 ms on another = the stall that cost round 5's driver run a fifth of its
-// headline).  When the last operator of a device is destroyed -- every buffer idle, nobody waiting -- each such class is topped up to high-water + 1.
+// headline; with pairs of operators factored together a five-item warm-up sees one or two sets of pair buffers alive and the job needs three).  When the last
+// operator of a device is destroyed -- every buffer idle, nobody waiting -- each such class whose busiest moment used EVERY buffer it had is topped up to
+// high-water + HELM_POOL_SPARE (default 2); a class that kept one unused has its headroom and is left alone (so a job's last destroy adds nothing once the
+// pool has settled: a top-up is a hipMalloc too, and the end of one timed pass is the eve of the next).
 static const size_t kSpareMin = (size_t)64 << 20, kSpareMax = (size_t)16 << 30;
 static void pool_forget(void *p) {
     auto it = g_pool_capacity.find(p);
@@ -609,7 +612,7 @@ void *helm_pool_alloc(int device, size_t bytes) {
     return p;
 }
 // (see PoolClassStat) called with no operator of the device alive
-static void pool_top_up(int device) {
+static void pool_top_up(int device, int spare) {
     std::vector<size_t> want;
     {
         std::lock_guard<std::mutex> lk(g_pool.mu);
@@ -618,7 +621,8 @@ static void pool_top_up(int device) {
         for (auto &kv : g_pool_stats) {
             if (kv.first.first != device || kv.first.second > kSpareMax) continue;
             PoolClassStat &cs = kv.second;
-            for (int k = cs.total; k < cs.high + 1 && cs.high > 0; ++k) { if (held + kv.first.second > cap) break; want.push_back(kv.first.second); held += kv.first.second; }
+            if (cs.high < cs.total) continue;                      // the busiest moment left a buffer of this class unused: enough headroom
+            for (int k = cs.total; k < cs.high + spare && cs.high > 0; ++k) { if (held + kv.first.second > cap) break; want.push_back(kv.first.second); held += kv.first.second; }
         }
     }
     for (size_t bytes : want) {
@@ -751,7 +755,7 @@ extern "C" void helm_destroy(helm_op *op) {
         if (n > 0) n -= 1;
         last = n == 0;
     }
-    if (last && tune_i("HELM_POOL_SPARE", 1)) pool_top_up(device);      // (nobody is waiting for this thread now: the spares of the big size classes, see PoolClassStat)
+    { const int spare = tune_i("HELM_POOL_SPARE", 2); if (last && spare > 0) pool_top_up(device, spare); }      // (nobody is waiting for this thread now: the spares of the big size classes, see PoolClassStat)
 }
 
 // Release what the library caches between calls (the shared scratch of the direct path).  The scratch is kept across
