@@ -292,3 +292,48 @@ def test_blas_pools_are_single_threaded_while_a_pipeline_runs_and_restored_after
     assert list(dispatch.pipelined(items, device=0, lookahead=1)) == [None] * 3
     assert all(v == [1] * len(v) for v in seen), seen
     assert blas_threads() == before
+
+
+def test_grouped_prepare_takes_items_in_sets_and_an_error_of_the_set_reaches_each_of_its_items():
+    """group > 1: every item's own prepare() runs, then ONE group_prepare() for the set (discretization.prefactor_many: the factorisations of the set's operators
+    in the same launches); the first item goes alone so that the solve thread starts early; results keep their order; an exception of the set's step surfaces
+    at every item of that set and at no other.  (The reference hands its pool one sub-problem at a time: distributors.py:161-168.)"""
+    from zephyr_amd import dispatch
+    seen = []
+    items = [dispatch.WorkItem((lambda p: 10 * p), (lambda k=k: k)) for k in range(7)]
+    assert list(dispatch.pipelined(items, device=0, lookahead=1, group=2, group_prepare=lambda ps: seen.append(list(ps)))) == [0, 10, 20, 30, 40, 50, 60]
+    assert seen == [[0], [1, 2], [3, 4], [5, 6]]
+
+    def boom(ps):
+        if 3 in ps:
+            raise RuntimeError('set with item 3 failed')
+    items = [dispatch.WorkItem((lambda p: p), (lambda k=k: k)) for k in range(6)]
+    futs = [it.future for it in items]
+    pipe = dispatch.DevicePipeline(0, 1, False, 1, 2, boom)
+    pipe.start(items)
+    got = []
+    for f in futs:
+        try:
+            got.append(f.result())
+        except RuntimeError as exc:
+            got.append(str(exc))
+    pipe.join()
+    assert got == [0, 1, 2, 'set with item 3 failed', 'set with item 3 failed', 5]          # sets: [0], [1, 2], [3, 4], [5]
+    # an item whose own prepare fails is left out of the set's step and fails alone
+    def prep(k):
+        if k == 2:
+            raise ValueError('item 2')
+        return k
+    sets = []
+    items = [dispatch.WorkItem((lambda p: p), (lambda k=k: prep(k))) for k in range(5)]
+    futs = [it.future for it in items]
+    pipe = dispatch.DevicePipeline(0, 1, False, 1, 2, lambda ps: sets.append(list(ps)))
+    pipe.start(items)
+    res = []
+    for f in futs:
+        try:
+            res.append(f.result())
+        except ValueError as exc:
+            res.append(str(exc))
+    pipe.join()
+    assert res == [0, 1, 'item 2', 3, 4] and sets == [[0], [1], [3, 4]]
