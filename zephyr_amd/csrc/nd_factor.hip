@@ -112,13 +112,19 @@ __global__ __launch_bounds__(256) void k_nd_extend_add(const NdDev *nodes, int f
 // every other padded slot.  The inverse maps are the same closed-form nd_cell / nd_local; a workgroup tabulates them for the
 // front's rows once in LDS and then streams `rb` rows.  Traffic per level: children's F22 read once, the fronts written once
 // (the scatter form read-modify-wrote the parents twice on top of the memsets).
+// (OVR: the front's record is the launch argument `ovr`, not nodes[...] -- one front rebuilt with its [F11 | F12] rows redirected, see NdStable.  A template, not a
+// run-time choice: `use_ovr ? ovr : nodes[i]` made the compiler keep the 100-byte record in vector registers -- 154 instead of 40, three waves per SIMD instead of
+// eight, and the kernel of every level 30-50 % slower: 1.53 -> 2.04 ms per work item between rounds 4 and 5, found in round 6 with round 4's tree beside this one.)
+template <bool OVR>
 __global__ __launch_bounds__(256) void k_nd_build_front(const NdDev *nodes, int first, cplx *arenaF, cplx *fac, NdPlanesSet pset, int nz, int nx, int rb,
-                                                        int skip22, int use_ovr, NdDev ovr, int nf, int kfix) {
+                                                        int skip22, NdDev ovr, int nf, int kfix) {
+    constexpr int use_ovr = OVR ? 1 : 0;
     extern __shared__ int2 finfo[];        // per padded row: x = z | x << 16 (-1: padding), y = (k0 + 1) | (k1 + 1) << 14 | comp << 28
     // (nf > 1: batch index = front * nf + frequency; kfix >= 0: one frequency's front alone, the re-elimination of an ill-conditioned one)
     const int kf = kfix >= 0 ? kfix : (int)(blockIdx.y % nf);
     const cplx *planes = pset.p[kf];
-    const NdDev n = use_ovr ? ovr : nodes[first + (kfix >= 0 ? blockIdx.y : blockIdx.y / nf)];   // (ovr, a launch argument: one front rebuilt with its [F11 | F12] rows redirected, see NdStable)
+    NdDev n;
+    if (OVR) n = ovr; else n = nodes[first + (kfix >= 0 ? blockIdx.y : blockIdx.y / nf)];
     const int nmax = n.smax + n.mmax;
     const int r0 = blockIdx.x * rb;
     if (r0 >= nmax) return;
@@ -178,10 +184,8 @@ __global__ __launch_bounds__(256) void k_nd_build_front(const NdDev *nodes, int 
     };
     // skip22: the ring x ring block (the sum of the children's Schur complements, most of a front below the tree top) is not
     // materialised -- the Schur-complement product gathers it itself (k_zgemm3<.., 4, ..>) and writes S where F22 would have been.
-    // One entry per lane at a time, 40 registers: eight waves per SIMD cover the gathers' latency.  (Round 5 gathered four entries per lane before storing any
-    // -- "the compiler keeps every load behind the previous store" -- and measured 0.02-0.03 ms per level in its favour on single levels; the restructured kernel
-    // took 154 registers, three waves per SIMD, and the profile of a whole work item says 1.53 -> 2.04 ms: round 6 ran round 4's tree beside this one on
-    // the same box, tools/bisect_build_front.sh, and put the loop back.)
+    // One entry per lane at a time, 40 registers: eight waves per SIMD cover the gathers' latency.  (Round 5 also gathered four entries per lane before storing
+    // any; beside the register blow-up described at the top of the kernel that form measured 2 % ahead of this loop, A/B in one binary -- not worth a second path.)
     for (int r = r0 + ty; r < r1; r += 4) {
         const int2 ia = finfo[r];
         const int cend = (skip22 && r >= n.smax) ? n.smax : nmax;
@@ -597,8 +601,8 @@ int stabilise_group(helm_op *op, NdFactor *f, size_t gi, cplx *arenaF, cplx *wor
         n.finv_off = 0; n.f12_off = g.smax;                                       // [F11 | F12] rows go to S.lu, [F21 | F22] back to the arena
         const int rb = std::max(std::min(nmax, 4), (nmax + 2047) / 2048);
         NdPlanesSet ps; for (int q2 = 0; q2 < ND_NF_MAX; ++q2) ps.p[q2] = planes;
-        HELM_LAUNCH(k_nd_build_front, dim3((nmax + rb - 1) / rb, 1), dim3(256), (size_t)nmax * sizeof(int2), st, f->pd->d_nodes, 0, arenaF, S.lu, ps, P.nz, P.nx, rb,
-                           0, 1, n, nf, kf);                                         // (the redirected node travels as a launch argument: no copy, no host wait)
+        HELM_LAUNCH(k_nd_build_front<true>, dim3((nmax + rb - 1) / rb, 1), dim3(256), (size_t)nmax * sizeof(int2), st, f->pd->d_nodes, 0, arenaF, S.lu, ps, P.nz, P.nx, rb,
+                           0, n, nf, kf);                                         // (the redirected node travels as a launch argument: no copy, no host wait)
         cplx *F21 = arenaF + foff, *F22 = arenaF + foff + g.smax;
         HIP_TRY(op, hipMemcpy2DAsync(S.f21, (size_t)g.smax * sizeof(cplx), F21, (size_t)nmax * sizeof(cplx), (size_t)g.smax * sizeof(cplx), (size_t)g.mmax, hipMemcpyDeviceToDevice, st));
         if (g.smax <= 64) HELM_LAUNCH(k_lu_factor64, dim3(1), dim3(256), 0, st, S.lu, nmax, g.smax, S.piv);
@@ -689,8 +693,8 @@ int factor_group_set(helm_op *op, const FacSet &S, size_t gi, cplx *arenaF, cplx
         const int chunk = 65535 / nf;                             // fronts per launch (grid y = fronts x frequencies)
         for (int j0 = 0; j0 < g.cnt; j0 += chunk) {
             const int nb = std::min(chunk, g.cnt - j0);
-            HELM_LAUNCH(k_nd_build_front, dim3((nmax + rb - 1) / rb, nb * nf), dim3(256), (size_t)nmax * sizeof(int2), st, d_nodes, g.first + j0, arenaF, f0->d_fac, ps,
-                               P.nz, P.nx, rb, schur_gather ? 1 : 0, 0, NdDev(), nf, -1);
+            HELM_LAUNCH(k_nd_build_front<false>, dim3((nmax + rb - 1) / rb, nb * nf), dim3(256), (size_t)nmax * sizeof(int2), st, d_nodes, g.first + j0, arenaF, f0->d_fac, ps,
+                               P.nz, P.nx, rb, schur_gather ? 1 : 0, NdDev(), nf, -1);
         }
     } else {
         if (nf != 1) HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "direct solver: fronts of %d unknowns take the unfused build, which factors one frequency at a time", nmax);
