@@ -760,10 +760,12 @@ extern "C" void helm_destroy(helm_op *op) {
 
 // Release what the library caches between calls (the shared scratch of the direct path).  The scratch is kept across
 // handles on purpose -- allocating tens of GB costs far more than a solve -- so a host that wants the memory back says so.
+static void scratch_sweep_all_wait();        // (scratch of enqueued factorisations: waits for them and hands it back)
 extern "C" int helm_trim(void) {
     helm_tuning_refresh();
     int cur = 0;
     (void)hipGetDevice(&cur);
+    scratch_sweep_all_wait();
     {
         std::lock_guard<std::mutex> lk(g_shared_ws.mu);
         for (auto &kv : g_shared_ws.dev) for (int i = 0; i < WS_SLOTS_MAX; ++i) if (kv.second.slot[i].busy) return HELM_ERR_STATE;
@@ -2049,16 +2051,59 @@ int solve_block(helm_op *op, int block, const cplx *dRHS, long long rhs_ld, long
 }  // namespace
 
 // A factorisation started by helm_prefactor is complete (or abandoned): wait for it, book its time, give its scratch back.
+// Scratch of a factorisation that helm_prefactor[_many] has enqueued goes back to the pool when the factorisation has FINISHED on the GPU, not when its operator
+// is first solved with: a set is factored long before its turn in the pipeline comes, and held until then the scratch of four sets (4 GB each at 1024^2 x 2) was
+// alive at once.  An event recorded behind the factorisation; every later prefactor / retire on the device looks which ones have completed.
+namespace {
+struct PendingScratch { int device; hipEvent_t ev; void *ws; size_t bytes; };
+std::mutex g_ps_mu;
+std::vector<PendingScratch> g_pending_scratch;
+}
+static void scratch_sweep(int device, bool wait) {
+    std::vector<PendingScratch> done;
+    {
+        std::lock_guard<std::mutex> lk(g_ps_mu);
+        for (size_t i = 0; i < g_pending_scratch.size(); ) {
+            PendingScratch &ps = g_pending_scratch[i];
+            bool fin = false;
+            if (ps.device == device) {
+                if (wait) { (void)hipEventSynchronize(ps.ev); fin = true; }
+                else { const hipError_t q = hipEventQuery(ps.ev); if (q == hipSuccess) fin = true; else (void)hipGetLastError(); }
+            }
+            if (fin) { done.push_back(ps); g_pending_scratch.erase(g_pending_scratch.begin() + i); } else ++i;
+        }
+    }
+    for (PendingScratch &ps : done) { hipEventDestroy(ps.ev); helm_pool_free(ps.device, ps.ws, ps.bytes); }
+}
+static void scratch_sweep_all_wait() {
+    std::vector<int> devs;
+    { std::lock_guard<std::mutex> lk(g_ps_mu); for (const PendingScratch &ps : g_pending_scratch) devs.push_back(ps.device); }
+    for (int d : devs) { hipSetDevice(d); scratch_sweep(d, true); }
+}
+// ws is handed over: released behind everything enqueued on `st` so far (at once if no event can be had)
+static void scratch_defer(int device, hipStream_t st, void *ws, size_t bytes) {
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, st) != hipSuccess) {
+        (void)hipGetLastError();
+        if (ev) hipEventDestroy(ev);
+        hipStreamSynchronize(st);
+        helm_pool_free(device, ws, bytes);
+        return;
+    }
+    std::lock_guard<std::mutex> lk(g_ps_mu);
+    g_pending_scratch.push_back(PendingScratch{device, ev, ws, bytes});
+}
+
 void helm_pf_retire(helm_op *op) {
     if (!op || !op->pf_pending) return;
     hipSetDevice(op->device);
     if (op->pf_done) hipEventSynchronize(op->pf_done);
     float ms = 0.f;
     if (op->pf_t0 && op->pf_t1 && hipEventElapsedTime(&ms, op->pf_t0, op->pf_t1) == hipSuccess) op->timing.factor_ms += ms / std::max(1, op->pf_share);
-    if (op->pf_ws_shared) op->pf_ws_shared.reset();            // (scratch of a set factored together: goes back to the pool with the last of its operators)
-    else helm_pool_free(op->device, op->pf_ws, op->pf_ws_bytes);
+    if (op->pf_ws) helm_pool_free(op->device, op->pf_ws, op->pf_ws_bytes);
     op->pf_ws = nullptr; op->pf_ws_bytes = 0; op->pf_share = 1;
     op->pf_pending = false;
+    scratch_sweep(op->device, false);          // (this operator's factorisation has finished: its set's scratch, and any older one's, goes back now)
 }
 
 // 3-D: what the next solve would build first -- the multigrid hierarchy with its directly solved level (hundreds of ms of GPU work and host logic,
@@ -2144,8 +2189,7 @@ extern "C" int helm_prefactor_many(helm_op **ops, int n) {
     const size_t wsb = (size_t)n * (size_t)nd_factor_ws_elems(fs[0]->pd->plan) * sizeof(cplx);
     void *ws = helm_pool_alloc(op0->device, wsb);
     if (!ws) { drop(); HELM_FAIL(op0, HELM_ERR_DEVICE, "direct solver: cannot allocate %.1f GB of factorisation scratch", wsb / 1e9); }
-    const int dev = op0->device;
-    std::shared_ptr<void> holder(ws, [dev, wsb](void *p) { helm_pool_free(dev, p, wsb); });
+    scratch_sweep(op0->device, false);           // (scratch of earlier sets whose factorisations have finished)
     { op0->ev_used = 0; op0->ev_pending.clear(); op0->ev_pending_gemm.clear(); op0->ev_pending_gemm_n.clear(); op0->ev_pending_gemm_bytes.clear(); op0->ev_pending_gemm_sol.clear(); op0->ev_pending_gemm_shape.clear(); }
     hipStream_t main = op0->stream;
     op0->stream = op0->fstream;                  // (the assembled planes of every operator are complete: helm_assemble synchronises)
@@ -2153,11 +2197,12 @@ extern "C" int helm_prefactor_many(helm_op **ops, int n) {
     const int rc = nd_factor_enqueue_many(op0, n, ops, fs, (cplx *)ws);
     for (int k = 0; k < n; ++k) { hipEventRecord(ops[k]->pf_t1, op0->fstream); hipEventRecord(ops[k]->pf_done, op0->fstream); }
     op0->stream = main;
-    if (rc) { hipStreamSynchronize(op0->fstream); drop(); return rc; }
+    if (rc) { hipStreamSynchronize(op0->fstream); helm_pool_free(op0->device, ws, wsb); drop(); return rc; }
+    scratch_defer(op0->device, op0->fstream, ws, wsb);
     for (int k = 0; k < n; ++k) {
         helm_op *op = ops[k];
         op->direct[0] = fs[k];
-        op->pf_ws = nullptr; op->pf_ws_bytes = 0; op->pf_ws_shared = holder; op->pf_share = n; op->pf_pending = true;
+        op->pf_ws = nullptr; op->pf_ws_bytes = 0; op->pf_share = n; op->pf_pending = true;
     }
     return HELM_OK;
 }
@@ -2204,7 +2249,8 @@ extern "C" int helm_prefactor(helm_op *op) {
     op->stream = main;
     if (rc) { hipStreamSynchronize(op->fstream); helm_pool_free(op->device, ws, wsb); nd_free(f); return rc; }
     op->direct[0] = f;
-    op->pf_ws = ws; op->pf_ws_bytes = wsb; op->pf_pending = true;
+    scratch_defer(op->device, op->fstream, ws, wsb);
+    op->pf_ws = nullptr; op->pf_ws_bytes = 0; op->pf_pending = true;
     return HELM_OK;
 }
 

@@ -116,7 +116,6 @@ struct helm_op {
     bool pf_pending = false;
     hipEvent_t pf_done = nullptr, pf_t0 = nullptr, pf_t1 = nullptr;
     void *pf_ws = nullptr; size_t pf_ws_bytes = 0;
-    std::shared_ptr<void> pf_ws_shared;    // helm_prefactor_many: the scratch of a set of operators factored by the same launches (back to the pool with the last of them)
     int pf_share = 1;                      // operators whose factorisations share the span pf_t0 .. pf_t1
 
     // model
