@@ -1022,9 +1022,11 @@ def main():
                 if pz:
                     out['roofline']['traffic'] = pz['traffic_bytes_per_launch']
                     out['roofline']['traffic_source'] = src_z + ' (HBM bytes per GEMM launch, FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes)'
-                    try:      # the same figure per work item against the operand bytes the library books for the launches of this run's serial pass
+                    try:      # the same per WORK ITEM (the PMC run's own item count: one residual launch each) against the operand bytes the library books per item here
                         tr = out['roofline']
-                        per_item = pz['traffic_bytes_per_launch'] * tr['launches_timed'] / float(args.steps) / 1e9
+                        pr0, _ = pmc('pmc_traffic_resid_nm')
+                        items_pmc = float(pr0['launches_fetch_pass']) if pr0 and pr0.get('launches_fetch_pass') else 2.0
+                        per_item = pz['traffic_bytes_per_launch'] * pz['launches_fetch_pass'] / items_pmc / 1e9
                         tr['traffic_GB_per_item'] = per_item
                         tr['traffic_over_operand_bytes'] = per_item / tr['two_roofs']['operand_GB_per_item']
                     except Exception:

@@ -337,6 +337,7 @@ typedef struct helm_tuning {
     int    mg3_depth_model;    /* HELM_MG3_DEPTH_MODEL   1     trade set-up seconds against booked iteration counts */
     int    mg3_bt_f32;         /* HELM_MG3_BT_F32        1     single-precision plane inverses of the block-tridiagonal coarse solve */
     int    mg3_otf;            /* HELM_MG3_OTF           1     27-point apply rebuilds its coefficients from c, rho and the PML profiles (1: from 4 right-hand sides per workgroup up, 2: always) */
+    int    mg3_f32;            /* HELM_MG3_F32           1     the layer-preserving cycle keeps the work vectors of its finest level in complex64 (input, result and every coarser level stay complex128) */
     double mg3_omega;          /* HELM_MG3_OMEGA         0.9   Jacobi damping of the smoother */
     /* host-side waits */
     double sync_spin_ms;       /* HELM_SYNC_SPIN_MS      0     a wait of the library polls for this long before it blocks on the runtime's interrupt (saves the 20-50 us wake-up of each

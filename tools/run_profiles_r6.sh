@@ -20,15 +20,16 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_serial_sparse
 HELM_ND_SPARSE_RHS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_sets -o s -- python3 $B --steps 8 --warmup 4 > $OUT/bench_sets_under_rocprof.json 2> $OUT/stats_sets.err
 export HELM_ND_SPARSE_RHS=0
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-config5 --no-config2 --no-config4 --no-host-api --no-pipeline --no-plain-pass > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err
+  # (two work items, their factorisations in one set of launches like the timed region's; the timed region and the roofline pass each run them once)
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 0 --no-cpu --no-config5 --no-config2 --no-config4 --no-host-api --no-plain-pass > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err
 done
 unset HELM_ND_SPARSE_RHS
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc3d_$C -- python3 $GRAFT_REPO_ROOT/tools/apply3d_micro.py 16 4 > $OUT/pmc3d_$C.json 2> $OUT/pmc3d_$C.err
 done
 cd $GRAFT_REPO_ROOT
-python3 tools/pmc_reduce.py --fetch $OUT/pmc_FETCH_SIZE --write $OUT/pmc_WRITE_SIZE --kernel k_zgemm3,k_gj_step --out $OUT/pmc_traffic_zgemm.json --note "all k_zgemm3 and k_gj_step dispatches of one work item (factorisation + solve passes), serial, every front computed (HELM_ND_SPARSE_RHS=0)" > /dev/null
-python3 tools/pmc_reduce.py --fetch $OUT/pmc_FETCH_SIZE --write $OUT/pmc_WRITE_SIZE --kernel k_resid_nm --out $OUT/pmc_traffic_resid.json --note "node-major residual launches of one work item (direct output: the launch reads the caller's wavefield array and stores nothing), q read everywhere (HELM_ND_SPARSE_RHS=0)" > /dev/null
+python3 tools/pmc_reduce.py --fetch $OUT/pmc_FETCH_SIZE --write $OUT/pmc_WRITE_SIZE --kernel k_zgemm3,k_gj_step --out $OUT/pmc_traffic_zgemm.json --note "all k_zgemm3 and k_gj_step dispatches of four work items (two in the timed region, two in the roofline pass; factorisations in sets of two + solve passes), every front computed (HELM_ND_SPARSE_RHS=0)" > /dev/null
+python3 tools/pmc_reduce.py --fetch $OUT/pmc_FETCH_SIZE --write $OUT/pmc_WRITE_SIZE --kernel k_resid_nm --out $OUT/pmc_traffic_resid.json --note "node-major residual launches of four work items (direct output: the launch reads the caller's wavefield array and stores nothing), q read everywhere (HELM_ND_SPARSE_RHS=0)" > /dev/null
 python3 tools/pmc_reduce.py --fetch $OUT/pmc_FETCH_SIZE --write $OUT/pmc_WRITE_SIZE --kernel k_stencil_t --out $OUT/pmc_traffic_stencil_micro.json --note "rhs-major stencil apply launches of the in-bench microbenchmark (B = 1, 8, 32, 64; 6 launches each)" > /dev/null
 python3 tools/pmc_reduce.py --fetch $OUT/pmc3d_FETCH_SIZE --write $OUT/pmc3d_WRITE_SIZE --kernel k_stencil3 --grid 256 --batch 16 --out $OUT/pmc_traffic_stencil3.json --note "27-point apply, 256 x 256 x 128, B = 16, coefficients on the fly (tools/apply3d_micro.py 16 4: 4 launches); algorithmic bytes by SURVEY 8(d): N (32 B + 432) = 7.92 GB" > /dev/null
 find $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc3d_FETCH_SIZE $OUT/pmc3d_WRITE_SIZE -name "*.csv" -size +2M -delete

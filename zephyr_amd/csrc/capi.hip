@@ -275,6 +275,7 @@ static helm_tuning tuning_from_env() {
     t.mg3_depth_model = tune_i("HELM_MG3_DEPTH_MODEL", 1);
     t.mg3_bt_f32 = tune_i("HELM_MG3_BT_F32", 1);
     t.mg3_otf = tune_i("HELM_MG3_OTF", 1);
+    t.mg3_f32 = tune_i("HELM_MG3_F32", 1);
     t.mg3_omega = tune_d("HELM_MG3_OMEGA", 0.9);
     t.sync_spin_ms = tune_d("HELM_SYNC_SPIN_MS", 0.0);
     tuning_clamp(t);

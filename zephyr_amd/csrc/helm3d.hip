@@ -99,9 +99,9 @@ __global__ __launch_bounds__(256) void k_kb_3d(Asm3Params P, const cplx *__restr
 // ---- batched 27-point apply -----------------------------------------------------------------------
 struct Stencil3Params {
     const cplx *planes;      // 27 planes, stride N
-    const cplx *X;
-    cplx *Y;
-    const cplx *W;
+    const void *X;           // complex128, or complex64 in the mixed-precision instantiations (the vectors of the multigrid cycle's finest level, mg3d.hip)
+    void *Y;
+    const void *W;
     long long ld, N;
     int nz, ny, nx, nrhs, ntx, nty, nblk;
     int zfast;               // tile order: 1 = z fastest (workgroups that run together share their z-halo planes in the XCD's L2)
@@ -134,13 +134,20 @@ constexpr int T3X = 64, T3Y = 4;
 // 3 x 3 x 3 neighbourhood -- staged through the tile's own LDS buffers, 24 B per point with halo -- and the three 1-D factor tables: the same expressions in
 // the same order as k_assemble_3d, so the apply is bit for bit the stored-plane apply.  Amortised over the right-hand sides of the launch (helm3d_launch_apply
 // takes this path from 4 right-hand sides up); the coarse levels that carry a Galerkin operator keep their stored planes.
-template <bool SCALED, int EPI, bool OTF = false>
+// TX / TW / TY (round 6): element types of X, W and Y -- cplx, or cplxf for vectors the multigrid cycle keeps in single precision.  The arithmetic is fp64 either
+// way (converted on the way out of LDS); what halves is the staging of the 3 x 396-element tiles per 256 outputs, which is what bounds this kernel, and the
+// HBM bytes of the vectors.
+__device__ __forceinline__ cplx cvt64(cplx a) { return a; }
+__device__ __forceinline__ cplx cvt64(cplxf a) { return to_f64(a); }
+template <bool SCALED, int EPI, bool OTF = false, class TX = cplx, class TW = cplx, class TY = cplx>
 __global__ __launch_bounds__(256) void k_stencil3(Stencil3Params q) {
     constexpr int LW = T3X + 2, LH = T3Y + 2;          // one staged plane: LH rows of LW
     constexpr int PLANE = LW * LH;                      // 396 elements
     constexpr int NEL = 3 * PLANE;                      // three z-planes
     constexpr int NLOAD = (NEL + 255) / 256;            // elements staged per thread
-    __shared__ __attribute__((aligned(16))) cplx tile[2][NEL];
+    constexpr size_t TILEB = 2 * (size_t)NEL * sizeof(TX), OTFB = OTF ? (size_t)NEL * (sizeof(cplx) + sizeof(double)) : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TILEB > OTFB ? TILEB : OTFB];
+    TX *const tile0 = reinterpret_cast<TX *>(smem);     // tile[buf] = tile0 + buf * NEL
     __shared__ double red[16];
 
     const int tid = threadIdx.x, lane = tid & 63, wy = tid >> 6;
@@ -168,8 +175,8 @@ __global__ __launch_bounds__(256) void k_stencil3(Stencil3Params q) {
         }
     } else {
         // K of the three planes with halo into tile[0], b into tile[1] (as doubles), then every thread reads its 27 neighbours
-        cplx *Kt = &tile[0][0];
-        double *bt = reinterpret_cast<double *>(&tile[1][0]);
+        cplx *Kt = reinterpret_cast<cplx *>(smem);
+        double *bt = reinterpret_cast<double *>(smem + (size_t)NEL * sizeof(cplx));
         for (int e = tid; e < NEL; e += 256) {
             const int p = e / PLANE, rem = e - p * PLANE, r = rem / LW, cc = rem - r * LW;
             const int gz = iz - 1 + p, gy = y0 - 1 + r, gx = x0 - 1 + cc;
@@ -207,13 +214,13 @@ __global__ __launch_bounds__(256) void k_stencil3(Stencil3Params q) {
     }
 
     // staging map: element e of the 3-plane tile -> (plane p, tile row r, tile column cc)
-    cplx pre[NLOAD];
+    TX pre[NLOAD];
     auto prefetch = [&](int b) {
-        const cplx *Xb = q.X + (long long)b * q.ld;
+        const TX *Xb = static_cast<const TX *>(q.X) + (long long)b * q.ld;
 #pragma unroll
         for (int l = 0; l < NLOAD; ++l) {
             const int e = tid + 256 * l;
-            cplx v = cmake(0.0, 0.0);
+            TX v = vzero<TX>();
             if (e < NEL) {
                 const int p = e / PLANE, rem = e - p * PLANE, r = rem / LW, cc = rem - r * LW;
                 const int gz = iz - 1 + p, gy = y0 - 1 + r, gx = x0 - 1 + cc;
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(256) void k_stencil3(Stencil3Params q) {
 #pragma unroll
         for (int l = 0; l < NLOAD; ++l) {
             const int e = tid + 256 * l;
-            if (e < NEL) tile[buf][e] = pre[l];
+            if (e < NEL) tile0[buf * NEL + e] = pre[l];
         }
     };
 
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(256) void k_stencil3(Stencil3Params q) {
         __syncthreads();
 
         cplx acc = cmake(0.0, 0.0), xc = cmake(0.0, 0.0);
-        const cplx *tb = &tile[buf][wy * LW + lane];
+        const TX *tb = tile0 + buf * NEL + wy * LW + lane;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
 #pragma unroll
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(256) void k_stencil3(Stencil3Params q) {
 #pragma unroll
                 for (int cc = 0; cc < 3; ++cc) {
                     const int k = 9 * p + 3 * r + cc;
-                    const cplx xv = tb[p * PLANE + r * LW + cc];
+                    const cplx xv = cvt64(tb[p * PLANE + r * LW + cc]);
                     if (SCALED && k == 13) { acc.x += xv.x; acc.y += xv.y; }
                     else cfma(acc, cf[k], xv);
                     if (k == 13) xc = xv;
@@ -262,13 +269,14 @@ __global__ __launch_bounds__(256) void k_stencil3(Stencil3Params q) {
         if (ok) {
             cplx y = acc;
             const long long g = (long long)b * q.ld + idx;
-            if (EPI == EPI_RESID) { const cplx w = q.W[g]; y = csub(w, y); dsum[0] += cabs2(y); }
-            else if (EPI == EPI_DOT_W) { const cplx w = q.W[g]; dsum[0] += w.x * y.x + w.y * y.y; dsum[1] += w.x * y.y - w.y * y.x; }
+            const TW *Wp = static_cast<const TW *>(q.W);
+            if (EPI == EPI_RESID) { const cplx w = cvt64(Wp[g]); y = csub(w, y); dsum[0] += cabs2(y); }
+            else if (EPI == EPI_DOT_W) { const cplx w = cvt64(Wp[g]); dsum[0] += w.x * y.x + w.y * y.y; dsum[1] += w.x * y.y - w.y * y.x; }
             else if (EPI == EPI_DOT_XY) { dsum[0] += y.x * xc.x + y.y * xc.y; dsum[1] += y.x * xc.y - y.y * xc.x; dsum[2] += cabs2(y); }
             else if (EPI == EPI_DOT_YY) { dsum[0] += cabs2(y); }
-            else if (EPI == EPI_DOT_WY) { const cplx w = q.W[g]; dsum[0] += y.x * w.x + y.y * w.y; dsum[1] += y.x * w.y - y.y * w.x; dsum[2] += cabs2(y); }
-            else if (EPI == EPI_JACOBI) { const cplx res = csub(q.W[g], y); y = xc; cfma(y, cscale(q.dinv[idx], q.omega_j), res); }
-            q.Y[g] = y;
+            else if (EPI == EPI_DOT_WY) { const cplx w = cvt64(Wp[g]); dsum[0] += y.x * w.x + y.y * w.y; dsum[1] += y.x * w.y - y.y * w.x; dsum[2] += cabs2(y); }
+            else if (EPI == EPI_JACOBI) { const cplx res = csub(cvt64(Wp[g]), y); y = xc; cfma(y, cscale(q.dinv[idx], q.omega_j), res); }
+            static_cast<TY *>(q.Y)[g] = vfrom<TY>(y);
         }
         if (EPI != EPI_NONE && EPI != EPI_JACOBI) {
             const int wave = tid >> 6;
@@ -394,6 +402,16 @@ static void launch3_epi(hipStream_t st, dim3 grid, const Stencil3Params &q, int 
     }
 }
 
+// mixed precision (ApplyArgs::x32 / y32): X in complex64, W in complex128, Y in complex64 or complex128 -- the sweeps and the residual of the multigrid cycle's
+// finest level (mg3d.hip); unscaled planes only
+template <bool OTF>
+static bool launch3_mixed(hipStream_t st, dim3 grid, const Stencil3Params &q, int epi, int y32) {
+    if (epi == EPI_RESID && y32) { HELM_LAUNCH((k_stencil3<false, EPI_RESID, OTF, cplxf, cplx, cplxf>), grid, dim3(256), 0, st, q); return true; }
+    if (epi == EPI_JACOBI && y32) { HELM_LAUNCH((k_stencil3<false, EPI_JACOBI, OTF, cplxf, cplx, cplxf>), grid, dim3(256), 0, st, q); return true; }
+    if (epi == EPI_JACOBI && !y32) { HELM_LAUNCH((k_stencil3<false, EPI_JACOBI, OTF, cplxf, cplx, cplx>), grid, dim3(256), 0, st, q); return true; }
+    return false;
+}
+
 int helm3d_launch_apply(helm_op *op, const ApplyArgs &a, hipEvent_t e0, hipEvent_t e1) {
     if (a.adjoint) HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "adjoint apply is not available for the 3-D operator");
     Stencil3Params q;
@@ -415,7 +433,11 @@ int helm3d_launch_apply(helm_op *op, const ApplyArgs &a, hipEvent_t e0, hipEvent
     q.idx2 = op->otf_idx2; q.idy2 = op->otf_idy2; q.idz2 = op->otf_idz2; q.blend = op->otf_blend;
     q.npart = helm3d_apply_num_blocks(op);
     if (e0) hipEventRecord(e0, op->stream);
-    if (otf) launch3_otf(op->stream, grid, q, a.epi);
+    if (a.x32) {
+        if (a.scaled || a.w32 || !(otf ? launch3_mixed<true>(op->stream, grid, q, a.epi, a.y32) : launch3_mixed<false>(op->stream, grid, q, a.epi, a.y32)))
+            HELM_FAIL(op, HELM_ERR_UNSUPPORTED, "3-D apply: this combination of vector precisions has no kernel (X complex64 with W complex128: residual and Jacobi sweep only)");
+    }
+    else if (otf) launch3_otf(op->stream, grid, q, a.epi);
     else if (a.scaled) launch3_epi<true>(op->stream, grid, q, a.epi);
     else launch3_epi<false>(op->stream, grid, q, a.epi);
     if (e1) hipEventRecord(e1, op->stream);

@@ -305,6 +305,7 @@ struct ApplyArgs {
     int f32 = 0;                    // 1: planes / X / Y / W / dinv are single-precision complex (multigrid levels);
                                     //    only EPI_NONE / EPI_RESID / EPI_JACOBI, unscaled, forward
     int profile = 1;                // count this launch in the roofline timing of the handle that owns the solve
+    int x32 = 0, w32 = 0, y32 = 0;  // (3-D) X / W / Y hold complex64 (the multigrid cycle's finest-level vectors, mg3d.hip); the arithmetic stays fp64
 };
 int helm_launch_apply(helm_op *op, const ApplyArgs &a);
 

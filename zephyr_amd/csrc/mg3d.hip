@@ -35,6 +35,7 @@ struct Mg3Precond {
     int nc = 0, batch = 0;
     double omega_j = 0.8, beta = 0.6, cpml_m = 30.0;
     int nu1 = 1, nu2 = 1, min_n = 8;
+    bool fine32 = false;          // (layer-preserving cycle) the finest level's work vectors u, t, r hold complex64 -- see cycle_keep
 };
 
 // ---- what the layer-preserving cycle has actually needed: iterations per right-hand side, by class -----------------------------------------
@@ -94,11 +95,14 @@ void level_vectors_free(helm_op *op, Mg3Level &L) {
 double envd(const char *n, double d) { const char *v = getenv(n); return v ? atof(v) : d; }
 int envi(const char *n, int d) { const char *v = getenv(n); return v ? atoi(v) : d; }
 
-__global__ void k3_jac0(const cplx *__restrict__ f, const cplx *__restrict__ dinv, cplx *__restrict__ u, long long N, double w) {
-    const cplx *fb = f + (long long)blockIdx.y * N; cplx *ub = u + (long long)blockIdx.y * N;
+template <class TU>
+__global__ void k3_jac0(const cplx *__restrict__ f, const cplx *__restrict__ dinv, TU *__restrict__ u, long long N, double w) {
+    const cplx *fb = f + (long long)blockIdx.y * N; TU *ub = u + (long long)blockIdx.y * N;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x)
-        ub[i] = cmul(cscale(dinv[i], w), fb[i]);
+        ub[i] = vfrom<TU>(cmul(cscale(dinv[i], w), fb[i]));
 }
+__device__ __forceinline__ cplx mg_cvt64(cplx a) { return a; }
+__device__ __forceinline__ cplx mg_cvt64(cplxf a) { return to_f64(a); }
 
 // coarse = R fine, R = P^T / 8 (full weighting; weights 1, 1/2, 1/4, 1/8 by distance class, fine points outside the grid skipped)
 __global__ void k3_restrict(const cplx *__restrict__ fine, cplx *__restrict__ coarse, int nz, int ny, int nx, int nzc, int nyc, int nxc) {
@@ -181,7 +185,7 @@ int cycle(helm_op *op, Mg3Precond *P, size_t l, int nrhs, cplx *final_out = null
         return nd_dense_gemm(op, nrhs, P->nc, P->nc, cmake(1, 0), L.f, P->nc, P->cinvT, P->nc, cmake(0, 0), L.u, P->nc);
     }
     Mg3Level &C = P->lv[l + 1];
-    HELM_LAUNCH(k3_jac0, vgrid(L.N, nrhs), dim3(256), 0, st, L.f, L.op->d_dinv, L.u, L.N, P->omega_j);
+    HELM_LAUNCH(k3_jac0<cplx>, vgrid(L.N, nrhs), dim3(256), 0, st, (const cplx *)L.f, (const cplx *)L.op->d_dinv, L.u, L.N, P->omega_j);
     int rc;
     for (int s = 1; s < P->nu1; ++s) {
         rc = level_apply(op, L, L.u, L.t, L.f, nrhs, EPI_JACOBI, P->omega_j); if (rc) return rc;
@@ -335,10 +339,12 @@ __global__ void k3_l1_dinv(const cplx *__restrict__ planes, cplx *__restrict__ d
     }
 }
 
-__global__ void k3_restrict_t(const cplx *__restrict__ fine, cplx *__restrict__ coarse, int ny, int nx, int nzc, int nyc, int nxc, long long Nf,
+// (TF: element type of the fine vector -- complex64 for the finest level of a cycle that keeps its work vectors in single precision)
+template <class TF>
+__global__ void k3_restrict_t(const TF *__restrict__ fine, cplx *__restrict__ coarse, int ny, int nx, int nzc, int nyc, int nxc, long long Nf,
                               const RTab *__restrict__ tz, const RTab *__restrict__ ty, const RTab *__restrict__ tx) {
     const long long Nc = (long long)nzc * nyc * nxc;
-    const cplx *fb = fine + (long long)blockIdx.y * Nf; cplx *cb = coarse + (long long)blockIdx.y * Nc;
+    const TF *fb = fine + (long long)blockIdx.y * Nf; cplx *cb = coarse + (long long)blockIdx.y * Nc;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < Nc; i += (long long)gridDim.x * blockDim.x) {
         const int X = (int)(i % nxc), Y = (int)((i / nxc) % nyc), Z = (int)(i / ((long long)nxc * nyc));
         const RTab rz = tz[Z], ry = ty[Y], rx = tx[X];
@@ -347,9 +353,9 @@ __global__ void k3_restrict_t(const cplx *__restrict__ fine, cplx *__restrict__ 
         for (int a = 0; a < 3; ++a) { if (wz[a] == 0.0) continue;
             for (int b = 0; b < 3; ++b) { if (wy[b] == 0.0) continue;
                 const double wab = wz[a] * wy[b];
-                const cplx *row = fb + ((long long)(rz.f + a - 1) * ny + (ry.f + b - 1)) * nx + rx.f;
+                const TF *row = fb + ((long long)(rz.f + a - 1) * ny + (ry.f + b - 1)) * nx + rx.f;
                 for (int c = 0; c < 3; ++c) { if (wx[c] == 0.0) continue;
-                    const cplx v = row[c - 1];
+                    const cplx v = mg_cvt64(row[c - 1]);
                     const double w = wab * wx[c];
                     acc.x += w * v.x; acc.y += w * v.y;
                 } } }
@@ -357,10 +363,11 @@ __global__ void k3_restrict_t(const cplx *__restrict__ fine, cplx *__restrict__ 
     }
 }
 
-__global__ void k3_prolong_add_t(const cplx *__restrict__ coarse, cplx *__restrict__ fine, int nz, int ny, int nx, int nyc, int nxc, long long Nc,
+template <class TF>
+__global__ void k3_prolong_add_t(const cplx *__restrict__ coarse, TF *__restrict__ fine, int nz, int ny, int nx, int nyc, int nxc, long long Nc,
                                  const PTab *__restrict__ tz, const PTab *__restrict__ ty, const PTab *__restrict__ tx) {
     const long long Nf = (long long)nz * ny * nx;
-    cplx *fb = fine + (long long)blockIdx.y * Nf; const cplx *cb = coarse + (long long)blockIdx.y * Nc;
+    TF *fb = fine + (long long)blockIdx.y * Nf; const cplx *cb = coarse + (long long)blockIdx.y * Nc;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < Nf; i += (long long)gridDim.x * blockDim.x) {
         const int x = (int)(i % nx), y = (int)((i / nx) % ny), z = (int)(i / ((long long)nx * ny));
         const PTab pz = tz[z], py = ty[y], px = tx[x];
@@ -374,7 +381,7 @@ __global__ void k3_prolong_add_t(const cplx *__restrict__ coarse, cplx *__restri
                     const double w = wz[a] * wy[b] * wx[c];
                     acc.x += w * v.x; acc.y += w * v.y;
                 } } }
-        fb[i] = cadd(fb[i], acc);
+        fb[i] = vfrom<TF>(cadd(mg_cvt64(fb[i]), acc));
     }
 }
 
@@ -930,20 +937,37 @@ int cycle_keep(helm_op *op, Mg3Precond *P, size_t l, int nrhs, cplx *final_out =
     Mg3Level &C = P->lv[l + 1];
     const cplx *dl1 = K->dl1[l];
     const double w = K->omega_l1;
+    // f32 (round 6, helm_tuning.mg3_f32): the work vectors u, t, r of the FINEST level hold complex64 -- the cycle is a preconditioner, its input and its result
+    // stay complex128 (the outer BiCGSTAB recurrences, the operator applies that form its residuals and the convergence check are untouched), and single precision
+    // in between costs the Krylov method nothing it can see (iteration counts in the tests).  What it buys: half the bytes of every vector the sweeps, the residual
+    // and the transfers of that level move, and half the staging of the 27-point kernel's tiles, which is what bounds it.
+    const bool f32 = l == 0 && P->fine32 && final_out != nullptr && P->nu2 >= 1;
     auto smooth = [&](const cplx *x, cplx *y) -> int {
         ApplyArgs a;
         a.planes = L.op->d_C; a.X = x; a.Y = y; a.W = L.f; a.ld = L.N; a.nrhs = nrhs; a.epi = EPI_JACOBI; a.scaled = 0; a.adjoint = 0;
         a.scal = nullptr; a.part = (double *)op->d_part; a.dinv = dl1; a.omega_j = w; a.profile = 0;
+        if (f32) { a.x32 = 1; a.y32 = (y == final_out) ? 0 : 1; }
         return helm_launch_apply(L.op, a);
     };
-    HELM_LAUNCH(k3_jac0, vgrid(L.N, nrhs), dim3(256), 0, st, L.f, dl1, L.u, L.N, w);
+    if (f32) HELM_LAUNCH(k3_jac0<cplxf>, vgrid(L.N, nrhs), dim3(256), 0, st, (const cplx *)L.f, dl1, (cplxf *)L.u, L.N, w);
+    else HELM_LAUNCH(k3_jac0<cplx>, vgrid(L.N, nrhs), dim3(256), 0, st, (const cplx *)L.f, dl1, L.u, L.N, w);
     int rc;
     for (int s = 1; s < P->nu1; ++s) { rc = smooth(L.u, L.t); if (rc) return rc; std::swap(L.u, L.t); }
-    rc = level_apply(op, L, L.u, L.r, L.f, nrhs, EPI_RESID, 0.0); if (rc) return rc;
-    HELM_LAUNCH(k3_restrict_t, vgrid(C.N, nrhs), dim3(256), 0, st, (const cplx *)L.r, C.f, L.ny, L.nx, C.nz, C.ny, C.nx, L.N,
+    if (f32) {
+        ApplyArgs a;
+        a.planes = L.op->d_C; a.X = L.u; a.Y = L.r; a.W = L.f; a.ld = L.N; a.nrhs = nrhs; a.epi = EPI_RESID; a.scaled = 0; a.adjoint = 0;
+        a.scal = nullptr; a.part = (double *)op->d_part; a.dinv = L.op->d_dinv; a.omega_j = 0.0; a.profile = 0; a.x32 = 1; a.y32 = 1;
+        rc = helm_launch_apply(L.op, a);
+    } else rc = level_apply(op, L, L.u, L.r, L.f, nrhs, EPI_RESID, 0.0);
+    if (rc) return rc;
+    if (f32) HELM_LAUNCH(k3_restrict_t<cplxf>, vgrid(C.N, nrhs), dim3(256), 0, st, (const cplxf *)L.r, C.f, L.ny, L.nx, C.nz, C.ny, C.nx, L.N,
+                         (const RTab *)K->rt[0][l], (const RTab *)K->rt[1][l], (const RTab *)K->rt[2][l]);
+    else HELM_LAUNCH(k3_restrict_t<cplx>, vgrid(C.N, nrhs), dim3(256), 0, st, (const cplx *)L.r, C.f, L.ny, L.nx, C.nz, C.ny, C.nx, L.N,
                        (const RTab *)K->rt[0][l], (const RTab *)K->rt[1][l], (const RTab *)K->rt[2][l]);
     rc = cycle_keep(op, P, l + 1, nrhs); if (rc) return rc;
-    HELM_LAUNCH(k3_prolong_add_t, vgrid(L.N, nrhs), dim3(256), 0, st, (const cplx *)C.u, L.u, L.nz, L.ny, L.nx, C.ny, C.nx, C.N,
+    if (f32) HELM_LAUNCH(k3_prolong_add_t<cplxf>, vgrid(L.N, nrhs), dim3(256), 0, st, (const cplx *)C.u, (cplxf *)L.u, L.nz, L.ny, L.nx, C.ny, C.nx, C.N,
+                         (const PTab *)K->pt[0][l], (const PTab *)K->pt[1][l], (const PTab *)K->pt[2][l]);
+    else HELM_LAUNCH(k3_prolong_add_t<cplx>, vgrid(L.N, nrhs), dim3(256), 0, st, (const cplx *)C.u, L.u, L.nz, L.ny, L.nx, C.ny, C.nx, C.N,
                        (const PTab *)K->pt[0][l], (const PTab *)K->pt[1][l], (const PTab *)K->pt[2][l]);
     for (int s = 0; s < P->nu2; ++s) {
         if (final_out && s == P->nu2 - 1) return smooth(L.u, final_out);
@@ -1155,6 +1179,7 @@ int setup_keep(helm_op *op, Mg3Precond *P, int batch, int ncoarsen, double tauM)
     };
     Mg3Keep *K = new Mg3Keep();
     P->keep = K;
+    P->fine32 = helm_tuning_now().mg3_f32 != 0;
     K->omega_l1 = 1.6;
     K->device = op->device;
     std::complex<double> om(2.0 * M_PI * op->a_freq_re, 2.0 * M_PI * op->a_freq_im);
