@@ -134,13 +134,14 @@ constexpr int T3X = 64, T3Y = 4;
 // 3 x 3 x 3 neighbourhood -- staged through the tile's own LDS buffers, 24 B per point with halo -- and the three 1-D factor tables: the same expressions in
 // the same order as k_assemble_3d, so the apply is bit for bit the stored-plane apply.  Amortised over the right-hand sides of the launch (helm3d_launch_apply
 // takes this path from 4 right-hand sides up); the coarse levels that carry a Galerkin operator keep their stored planes.
-// TX / TW / TY (round 6): element types of X, W and Y -- cplx, or cplxf for vectors the multigrid cycle keeps in single precision.  The arithmetic is fp64 either
-// way (converted on the way out of LDS); what halves is the staging of the 3 x 396-element tiles per 256 outputs, which is what bounds this kernel, and the
-// HBM bytes of the vectors.
+// TX / TW / TY (round 6): element types of X, W and Y -- cplx, or cplxf for vectors the multigrid cycle keeps in single precision.  With X in complex64 the 27
+// multiply-adds run in single precision too (coefficients built in fp64, rounded once per thread; the residual / sweep epilogue in fp64): a first version that
+// converted every staged value to fp64 on its way out of LDS was 8 % SLOWER than the all-fp64 kernel -- 54 conversions per output on top of 108 fp64
+// multiply-adds -- where this one halves the tile staging, the coefficient registers (108 -> 54) and the multiply-add cost.
 __device__ __forceinline__ cplx cvt64(cplx a) { return a; }
 __device__ __forceinline__ cplx cvt64(cplxf a) { return to_f64(a); }
-template <bool SCALED, int EPI, bool OTF = false, class TX = cplx, class TW = cplx, class TY = cplx>
-__global__ __launch_bounds__(256) void k_stencil3(Stencil3Params q) {
+template <bool SCALED, int EPI, bool OTF, class TX, class TW, class TY>
+__device__ __forceinline__ void stencil3_body(const Stencil3Params &q) {
     constexpr int LW = T3X + 2, LH = T3Y + 2;          // one staged plane: LH rows of LW
     constexpr int PLANE = LW * LH;                      // 396 elements
     constexpr int NEL = 3 * PLANE;                      // three z-planes
@@ -166,12 +167,13 @@ __global__ __launch_bounds__(256) void k_stencil3(Stencil3Params q) {
     const bool ok = col < nx && row < ny;
     const long long idx = ((long long)iz * ny + row) * nx + col;
 
-    cplx cf[27];
+    using TA = TX;                                       // the type the stencil sum is formed in: that of the staged values
+    TA cf[27];
     if (!OTF) {
 #pragma unroll
         for (int k = 0; k < 27; ++k) {
-            if (SCALED && k == 13) cf[k] = cmake(1.0, 0.0);
-            else cf[k] = ok ? q.planes[(long long)k * N + idx] : cmake(0.0, 0.0);
+            if (SCALED && k == 13) cf[k] = vone<TA>();
+            else cf[k] = ok ? vfrom<TA>(q.planes[(long long)k * N + idx]) : vzero<TA>();
         }
     } else {
         // K of the three planes with halo into tile[0], b into tile[1] (as doubles), then every thread reads its 27 neighbours
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(256) void k_stencil3(Stencil3Params q) {
                         const int e = p * PLANE + (wy + r) * LW + lane + cc;
                         out = coeff3(cc - 1, r - 1, p - 1, lxv[cc], lyv[r], lzv[p], q.idx2, q.idy2, q.idz2, b0, bt[e], Kt[e], q.blend);
                     }
-                    cf[k] = out;
+                    cf[k] = vfrom<TA>(out);
                 }
         __syncthreads();                                            // the tile buffers go back to the right-hand sides
     }
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(256) void k_stencil3(Stencil3Params q) {
         if (bn < q.nrhs) prefetch(bn);
         __syncthreads();
 
-        cplx acc = cmake(0.0, 0.0), xc = cmake(0.0, 0.0);
+        TA acc = vzero<TA>(), xc0 = vzero<TA>();
         const TX *tb = tile0 + buf * NEL + wy * LW + lane;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
@@ -259,15 +261,16 @@ __global__ __launch_bounds__(256) void k_stencil3(Stencil3Params q) {
 #pragma unroll
                 for (int cc = 0; cc < 3; ++cc) {
                     const int k = 9 * p + 3 * r + cc;
-                    const cplx xv = cvt64(tb[p * PLANE + r * LW + cc]);
+                    const TA xv = tb[p * PLANE + r * LW + cc];
                     if (SCALED && k == 13) { acc.x += xv.x; acc.y += xv.y; }
                     else cfma(acc, cf[k], xv);
-                    if (k == 13) xc = xv;
+                    if (k == 13) xc0 = xv;
                 }
         }
         double dsum[4] = {0.0, 0.0, 0.0, 0.0};
         if (ok) {
-            cplx y = acc;
+            cplx y = cvt64(acc);
+            const cplx xc = cvt64(xc0);
             const long long g = (long long)b * q.ld + idx;
             const TW *Wp = static_cast<const TW *>(q.W);
             if (EPI == EPI_RESID) { const cplx w = cvt64(Wp[g]); y = csub(w, y); dsum[0] += cabs2(y); }
@@ -298,6 +301,13 @@ __global__ __launch_bounds__(256) void k_stencil3(Stencil3Params q) {
         b = bn;
     }
 }
+
+template <bool SCALED, int EPI, bool OTF = false, class TX = cplx, class TW = cplx, class TY = cplx>
+__global__ __launch_bounds__(256) void k_stencil3(Stencil3Params q) { stencil3_body<SCALED, EPI, OTF, TX, TW, TY>(q); }
+// the single-precision instantiations (X complex64, W complex128).  (Bounded to three waves per SIMD -- __launch_bounds__(256, 3) -- the coefficient build spills
+// 68-100 bytes per lane and config 5 loses the 0.02 s per frequency these kernels gain; left to the register allocator: 156-210 registers.)
+template <int EPI, bool OTF, class TY>
+__global__ __launch_bounds__(256) void k_stencil3_lp(Stencil3Params q) { stencil3_body<false, EPI, OTF, cplxf, cplx, TY>(q); }
 
 // (Round 5 measured a lane-shifted form of this kernel -- a thread reads only the nine values of its own x column from LDS and forms three partial sums, two
 // of which cross to the neighbour lanes as v_mov_b32_dpp wave_shl / wave_shr values; lanes 0 and 63 as halo lanes, 62 outputs per wave -- 9 LDS reads per output
@@ -406,9 +416,9 @@ static void launch3_epi(hipStream_t st, dim3 grid, const Stencil3Params &q, int 
 // finest level (mg3d.hip); unscaled planes only
 template <bool OTF>
 static bool launch3_mixed(hipStream_t st, dim3 grid, const Stencil3Params &q, int epi, int y32) {
-    if (epi == EPI_RESID && y32) { HELM_LAUNCH((k_stencil3<false, EPI_RESID, OTF, cplxf, cplx, cplxf>), grid, dim3(256), 0, st, q); return true; }
-    if (epi == EPI_JACOBI && y32) { HELM_LAUNCH((k_stencil3<false, EPI_JACOBI, OTF, cplxf, cplx, cplxf>), grid, dim3(256), 0, st, q); return true; }
-    if (epi == EPI_JACOBI && !y32) { HELM_LAUNCH((k_stencil3<false, EPI_JACOBI, OTF, cplxf, cplx, cplx>), grid, dim3(256), 0, st, q); return true; }
+    if (epi == EPI_RESID && y32) { HELM_LAUNCH((k_stencil3_lp<EPI_RESID, OTF, cplxf>), grid, dim3(256), 0, st, q); return true; }
+    if (epi == EPI_JACOBI && y32) { HELM_LAUNCH((k_stencil3_lp<EPI_JACOBI, OTF, cplxf>), grid, dim3(256), 0, st, q); return true; }
+    if (epi == EPI_JACOBI && !y32) { HELM_LAUNCH((k_stencil3_lp<EPI_JACOBI, OTF, cplx>), grid, dim3(256), 0, st, q); return true; }
     return false;
 }
 
