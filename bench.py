@@ -586,6 +586,12 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
+    # N rank processes on one node share the container's CPU quota: a rank of this job keeps ~2.5 CPUs busy (two threads that wait for the GPU in the runtime's
+    # spinning wait).  Where the quota does not cover that, the library's waits sleep between polls instead (helm_tuning.sync_sleep_us): exhausting the quota would
+    # freeze every thread of every rank for the rest of each 100-ms scheduler period.
+    quota_cores = cgroup_cpu()[0]
+    if quota_cores is not None and quota_cores / max(1, world) < 3.0 and 'HELM_SYNC_SLEEP_US' not in os.environ:
+        os.environ['HELM_SYNC_SLEEP_US'] = '40'
     import torch
     import torch.distributed as dist
     backend = os.environ.get('HELM_BENCH_BACKEND', 'nccl')      # 'gloo' only for single-GPU dry runs of the N>1 logic
@@ -719,6 +725,7 @@ def main():
     if os.environ.get('HELM_ALLOC_TRACE'):
         sys.stderr.write('[bench] timed region starts\n'); sys.stderr.flush()
     cg0 = cgroup_cpu()
+    cpu0 = time.process_time()
     _zl0.runtime_stats(reset=True)       # what the timed region makes the HIP runtime create (allocations, events, first launches) is counted from here
     t0 = time.perf_counter()
     results = [None] * len(timed_items)
@@ -758,6 +765,7 @@ def main():
     memtrace('after the timed region')
     rt_timed = _zl0.runtime_stats()
     cg1 = cgroup_cpu()
+    rt_timed['cpu_cores_used'] = (time.process_time() - cpu0) / max(elapsed, 1e-9)      # CPU seconds of this process (all threads) per second of the timed region
     rt_timed['cpu_quota_cores'] = cg1[0]
     rt_timed['cpu_throttled_periods'] = cg1[1] - cg0[1]
     rt_timed['cpu_throttled_ms'] = (cg1[2] - cg0[2]) / 1e3
@@ -1179,7 +1187,7 @@ def main():
                 'grid_n': n, 'freqs_this_run': len(agg['freqs']),
                 'dense_rhs_wfs': (out.get('every_front_computed') or {}).get('value'),
                 'timed_first_launch_ms': rt_timed['first_launch_ms'], 'timed_dev_alloc_mb': rt_timed['dev_alloc_bytes'] / 1e6,
-                'timed_pinned_allocs': rt_timed['host_allocs'], 'timed_cpu_throttled_periods': rt_timed['cpu_throttled_periods'],
+                'timed_pinned_allocs': rt_timed['host_allocs'], 'timed_cpu_throttled_periods': rt_timed['cpu_throttled_periods'], 'timed_cpu_cores_used': rt_timed['cpu_cores_used'], 'wait_sleep_us': int(os.environ.get('HELM_SYNC_SLEEP_US', '0') or 0),
                 'timed_slow_syncs': rt_timed['slow_syncs'], 'timed_worst_sync_ms': rt_timed['worst_sync_ms'],
                 'timed_events_created': rt_timed['events_created'], 'timed_streams_created': rt_timed['streams_created'],
                 'kernels_registered': rt_timed['kernels_registered'], 'kernels_resolved_by_warm': rt_timed['kernels_resolved'], 'warm_ms': rt_timed['warm_ms'],

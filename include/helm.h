@@ -343,6 +343,8 @@ typedef struct helm_tuning {
     double sync_spin_ms;       /* HELM_SYNC_SPIN_MS      0     a wait of the library polls for this long before it blocks on the runtime's interrupt (saves the 20-50 us wake-up of each
                                                                wait; costs a CPU per waiting thread -- leave it off under a container CPU quota, where a spinning thread spends the budget the
                                                                launching threads need) */
+    int    sync_sleep_us;      /* HELM_SYNC_SLEEP_US     0     > 0: a wait of the library polls with a sleep of this many microseconds between two looks instead of the runtime's wait, which keeps a
+                                                               CPU busy while it lasts (2.5 CPUs per process in the pipelined bench job): for several processes under a container CPU quota */
 } helm_tuning;
 int helm_get_tuning(helm_tuning *out);          /* the values in force now (environment applied) */
 int helm_set_tuning(const helm_tuning *t);      /* NULL: defaults + environment again */

@@ -52,7 +52,7 @@ class Tuning(ctypes.Structure):
                 ('nd_xcd_map', ctypes.c_int), ('nd_plans', ctypes.c_int), ('nd_direct_out', ctypes.c_int), ('nd_many', ctypes.c_int), ('nd_leaf_idle', ctypes.c_int), ('auto_direct', ctypes.c_int),
                 ('auto_mg3', ctypes.c_int), ('prof_ext', ctypes.c_int), ('ws_slots', ctypes.c_int), ('pf_prio', ctypes.c_int),
                 ('mg3_keep', ctypes.c_int), ('mg3_keep_levels', ctypes.c_int), ('mg3_galerkin', ctypes.c_int), ('mg3_depth_model', ctypes.c_int),
-                ('mg3_bt_f32', ctypes.c_int), ('mg3_otf', ctypes.c_int), ('mg3_f32', ctypes.c_int), ('mg3_omega', ctypes.c_double), ('sync_spin_ms', ctypes.c_double)]
+                ('mg3_bt_f32', ctypes.c_int), ('mg3_otf', ctypes.c_int), ('mg3_f32', ctypes.c_int), ('mg3_omega', ctypes.c_double), ('sync_spin_ms', ctypes.c_double), ('sync_sleep_us', ctypes.c_int)]
 
 
 class RuntimeStats(ctypes.Structure):

@@ -7,6 +7,7 @@
 #include <chrono>
 #include <atomic>
 #include <unistd.h>
+#include <time.h>
 #include <mutex>
 #include <thread>
 #include <map>
@@ -105,8 +106,23 @@ static inline void cpu_relax() {
 #endif
 }
 static double sync_spin_budget_ms() { return helm_tuning_now().sync_spin_ms; }
+// helm_tuning.sync_sleep_us > 0: a wait polls with a sleep of that many microseconds between two looks instead of the runtime's own wait, which keeps a CPU busy
+// for as long as it lasts -- 2.5 CPUs per process in the pipelined bench job (two threads that are nearly always waiting for the GPU).  For N processes on a node
+// whose container grants fewer CPUs than 2.5 N (round 6: 16 for the one-GPU boxes): exhausting the quota freezes every thread of every process for the rest of
+// the scheduler period (profiles/r06_cpu_quota_stall.txt).  Costs the sleep's granularity per wait (~50 us, ~30 waits per work item).
+static bool sleep_wait(hipStream_t s, hipEvent_t e, int sleep_us) {
+    struct timespec ts; ts.tv_sec = 0; ts.tv_nsec = (long)sleep_us * 1000L;
+    for (;;) {
+        const hipError_t q = e ? hipEventQuery(e) : hipStreamQuery(s);
+        if (q == hipSuccess) return true;
+        (void)hipGetLastError();
+        if (q != hipErrorNotReady) return false;
+        nanosleep(&ts, nullptr);
+    }
+}
 hipError_t helm_timed_stream_sync(hipStream_t s, const char *file, int line) {
     SyncTimer t("hipStreamSynchronize", file, line);
+    { const int su = helm_tuning_now().sync_sleep_us; if (su > 0 && sleep_wait(s, nullptr, su)) return hipSuccess; }
     const double budget = sync_spin_budget_ms();
     if (budget > 0) {
         const double t0 = wall_ms();
@@ -123,6 +139,7 @@ hipError_t helm_timed_stream_sync(hipStream_t s, const char *file, int line) {
 }
 hipError_t helm_timed_event_sync(hipEvent_t e, const char *file, int line) {
     SyncTimer t("hipEventSynchronize", file, line);
+    { const int su = helm_tuning_now().sync_sleep_us; if (su > 0 && sleep_wait(nullptr, e, su)) return hipSuccess; }
     const double budget = sync_spin_budget_ms();
     if (budget > 0) {
         const double t0 = wall_ms();
@@ -245,6 +262,7 @@ static void tuning_clamp(helm_tuning &t) {
     if (!(t.mg3_omega > 0) || t.mg3_omega > 2.0) t.mg3_omega = 0.9;
     if (!(t.sync_spin_ms >= 0)) t.sync_spin_ms = 0.0;
     t.sync_spin_ms = std::min(t.sync_spin_ms, 60000.0);
+    t.sync_sleep_us = std::min(100000, std::max(0, t.sync_sleep_us));
 }
 static helm_tuning tuning_from_env() {
     helm_tuning t;
@@ -278,6 +296,7 @@ static helm_tuning tuning_from_env() {
     t.mg3_f32 = tune_i("HELM_MG3_F32", 1);
     t.mg3_omega = tune_d("HELM_MG3_OMEGA", 0.9);
     t.sync_spin_ms = tune_d("HELM_SYNC_SPIN_MS", 0.0);
+    t.sync_sleep_us = tune_i("HELM_SYNC_SLEEP_US", 0);
     tuning_clamp(t);
     return t;
 }
