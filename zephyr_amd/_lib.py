@@ -108,6 +108,7 @@ _SIGNATURES = {
                                                       ctypes.c_void_p, ctypes.c_void_p]),
     'helm_get_tuning': (ctypes.c_int, [ctypes.POINTER(Tuning)]),
     'helm_set_tuning': (ctypes.c_int, [ctypes.POINTER(Tuning)]),
+    'helm_pool_spares': (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     'helm_trim': (ctypes.c_int, []),
     'helm_host_trim': (ctypes.c_int, []),
     'helm_debug_ws_slots': (ctypes.c_int, [ctypes.c_int, ctypes.c_longlong]),

@@ -775,12 +775,23 @@ extern "C" void helm_destroy(helm_op *op) {
         if (n > 0) n -= 1;
         last = n == 0;
     }
-    { const int spare = tune_i("HELM_POOL_SPARE", 2); if (last && spare > 0) pool_top_up(device, spare); }      // (nobody is waiting for this thread now: the spares of the big size classes, see PoolClassStat)
+    // (auto: the spares of the big size classes are topped up here, when nobody is waiting for this thread -- HELM_POOL_SPARE_AUTO=0 leaves it to helm_pool_spares,
+    // for callers that time the region this destroy ends)
+    { const int spare = tune_i("HELM_POOL_SPARE", 2); if (last && spare > 0 && tune_i("HELM_POOL_SPARE_AUTO", 1)) pool_top_up(device, spare); }
 }
 
 // Release what the library caches between calls (the shared scratch of the direct path).  The scratch is kept across
 // handles on purpose -- allocating tens of GB costs far more than a solve -- so a host that wants the memory back says so.
 static void scratch_sweep_all_wait();        // (scratch of enqueued factorisations: waits for them and hands it back)
+static void scratch_sweep_fwd(int device);   // (the same for what has finished on one device, without waiting)
+extern "C" int helm_pool_spares(int device, int spare) {
+    helm_tuning_refresh();
+    if (spare < 0) return HELM_ERR_ARG;
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); helm_set_error(nullptr, "helm_pool_spares: hipSetDevice failed"); return HELM_ERR_DEVICE; }
+    scratch_sweep_fwd(device);
+    if (spare > 0) pool_top_up(device, spare);
+    return HELM_OK;
+}
 extern "C" int helm_trim(void) {
     helm_tuning_refresh();
     int cur = 0;
@@ -2095,6 +2106,7 @@ static void scratch_sweep(int device, bool wait) {
     }
     for (PendingScratch &ps : done) { hipEventDestroy(ps.ev); helm_pool_free(ps.device, ps.ws, ps.bytes); }
 }
+static void scratch_sweep_fwd(int device) { scratch_sweep(device, false); }
 static void scratch_sweep_all_wait() {
     std::vector<int> devs;
     { std::lock_guard<std::mutex> lk(g_ps_mu); for (const PendingScratch &ps : g_pending_scratch) devs.push_back(ps.device); }
