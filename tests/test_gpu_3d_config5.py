@@ -184,7 +184,8 @@ def test_prefactor_builds_the_3d_preconditioner_ahead_of_the_solve(helm_lib, mon
     import zephyr_amd as za
     cfg, q, ref = small_lu
     monkeypatch.setenv('HELM_MG3_KEEP', '2')
-    a = za.Helm3D(cfg)
+    monkeypatch.setenv('HELM_MG3_DEPTH_MODEL', '0')                  # the cost model weighs TIMED set-ups against iterations: on this small grid the two builds below may come out
+    a = za.Helm3D(cfg)                                               # on different sides of it (seen once in a full-suite run: 17 against 10 iterations); its own tests are above
     ua = a * q
     ia = [i['iterations'] for i in a.lastInfo]
     del a.factors
