@@ -468,28 +468,40 @@ def config4_leg(local, world, rank, dist, backend):
     resid = dcur - dobs
     g0 = prob.Jtvec(mcur, resid)                               # (first call: the 2 x 64-column buffers come into being)
 
+    per_op = []
+
     def device_ms():
         'sum over the model\'s eight operators of the device spans of their last factorisation and solve call (HIP events on their own streams)'
         tot = 0.0
+        per_op.append([])
         for op in prob.system.subProblems:
             if op.factors:
                 t = op.lastTiming()
                 tot += t['solve_ms'] + t['factor_ms']
+                per_op[-1].append((round(t['factor_ms'], 2), round(t['solve_ms'], 2)))
         return tot
     # five repetitions of each call, every one on a model that differs from the one before it (an inversion step: the call builds, assembles and factors its
     # eight operators); the figure quoted is the median, the spread (max - min) / median beside it
     reps = 5
     t_fwd, t_grad, gpu_fwd, gpu_grad, cg0 = [], [], [], [], cgroup_cpu()
+    rt_fwd, rt_grad = [], []                                   # what each timed call made the HIP runtime and the interpreter's collector do (diagnostics)
+    import gc
+
+    def rt_of(c0):
+        r = _lib.runtime_stats()
+        return {'dev_allocs': r['dev_allocs'], 'dev_alloc_ms': round(r['dev_alloc_ms'], 3), 'dev_frees': r['dev_frees'], 'pinned_allocs': r['host_allocs'],
+                'first_launches': r['first_launches'], 'slow_syncs': r['slow_syncs'], 'worst_sync_ms': round(r['worst_sync_ms'], 3),
+                'gc_collections': [a['collections'] - b for a, b in zip(gc.get_stats(), c0)]}
     g = g0
     for _ in range(reps):
         prob.updateModel(mtrue)
-        sync(); t0 = time.perf_counter()
+        sync(); _lib.runtime_stats(reset=True); c0 = [a['collections'] for a in gc.get_stats()]; t0 = time.perf_counter()
         surv.dpred(mcur)
-        sync(); t_fwd.append(slowest(time.perf_counter() - t0)); gpu_fwd.append(device_ms())
+        sync(); t_fwd.append(slowest(time.perf_counter() - t0)); gpu_fwd.append(device_ms()); rt_fwd.append(rt_of(c0))
         prob.updateModel(mtrue)
-        sync(); t0 = time.perf_counter()
+        sync(); _lib.runtime_stats(reset=True); c0 = [a['collections'] for a in gc.get_stats()]; t0 = time.perf_counter()
         g = prob.Jtvec(mcur, resid)
-        sync(); t_grad.append(slowest(time.perf_counter() - t0)); gpu_grad.append(device_ms())
+        sync(); t_grad.append(slowest(time.perf_counter() - t0)); gpu_grad.append(device_ms()); rt_grad.append(rt_of(c0))
     cg1 = cgroup_cpu()
     del prob.factors
     med = lambda v: float(np.median(v))
@@ -497,9 +509,9 @@ def config4_leg(local, world, rank, dist, backend):
     out = {'workload': 'FWI gradient step on 512x512 (true: synthetic Marmousi slice, current: its 25-pt box smooth), 8 freqs 3-10 Hz x 64 sources, 128 receivers at z=20 m; '
                        'dpred(m) + Jtvec(m, v) (mux form, device imaging), each including the construction, assembly and factorisation of the 8 operators of the model handed in; '
                        'frequencies sharded over %d rank(s), one all-reduce of the gradient; median of %d repetitions' % (world, reps),
-           'dpred_seconds': med(t_fwd), 'jtvec_seconds': med(t_grad), 'dpred_seconds_all': t_fwd, 'jtvec_seconds_all': t_grad,
+           'dpred_seconds': med(t_fwd), 'jtvec_seconds': med(t_grad), 'dpred_seconds_all': t_fwd, 'jtvec_seconds_all': t_grad, 'dpred_runtime_all': rt_fwd, 'jtvec_runtime_all': rt_grad,
            'dpred_spread': spread(t_fwd), 'jtvec_spread': spread(t_grad),
-           'gpu_ms_dpred': med(gpu_fwd), 'gpu_ms_jtvec': med(gpu_grad), 'gpu_ms': med(gpu_fwd) + med(gpu_grad),
+           'gpu_ms_dpred_all': gpu_fwd, 'gpu_ms_jtvec_all': gpu_grad, 'gpu_ms_per_operator_factor_solve': per_op[-2 * reps:], 'gpu_ms_dpred': med(gpu_fwd), 'gpu_ms_jtvec': med(gpu_grad), 'gpu_ms': med(gpu_fwd) + med(gpu_grad),
            'gpu_ms_what': 'sum over the eight operators of a call of the device spans (HIP events) of factorisation and solve; the two run on different streams and overlap between operators',
            'cpu_throttled_ms': (cg1[2] - cg0[2]) / 1e3,
            'wavefields_per_s_forward': nf * ns / med(t_fwd), 'wavefields_per_s_gradient': 2 * nf * ns / med(t_grad),
