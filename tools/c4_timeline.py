@@ -102,10 +102,11 @@ ncalls = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 import gc; gc.collect(); gc.freeze()
 for c in range(ncalls):
     p.updateModel(mtrue)
-    torch.cuda.synchronize(); del LOG[:]; del ITEMS[:]
+    torch.cuda.synchronize(); del LOG[:]; del ITEMS[:]; _lib.runtime_stats(reset=True)
     T0[0] = t0 = time.perf_counter()
     sv.dpred(mcur)
-    torch.cuda.synchronize(); t1 = time.perf_counter()
+    torch.cuda.synchronize(); t1 = time.perf_counter(); rs = _lib.runtime_stats()
+    print('    runtime objects created in the call: streams %d, events %d, device allocations %d, pinned %d' % (rs['streams_created'], rs['events_created'], rs['dev_allocs'], rs['host_allocs']))
     print('--- dpred call %d: %.1f ms   (starts at CLOCK_MONOTONIC %d ns)' % (c, 1e3 * (t1 - t0), int(t0 * 1e9)))
     for a, b, th, what in sorted(LOG):
         print('   %7.2f .. %7.2f  (%6.2f)  %-12s %s' % (a, b, b - a, th, what))
