@@ -28,6 +28,10 @@ for _k in ('OPENBLAS_NUM_THREADS', 'OMP_NUM_THREADS', 'MKL_NUM_THREADS'):
 # the library's pool tops its spares up by itself when a device's last operator is destroyed -- which is how every pass of this file ENDS, inside its timing
 # window; here the top-ups are asked for between the passes instead (barrier(), helm_pool_spares)
 os.environ.setdefault('HELM_POOL_SPARE_AUTO', '0')
+# items the device pipeline's prepare thread may be ahead of its solve thread.  Round 6, four fresh processes each (profiles/r06_lookahead.txt): 1 -> 14 747 - 15 087
+# wavefields/s, 2 -> 15 356 - 15 545, 3 -> 15 141 - 15 314: with one item of slack a late hand-over between the two threads leaves the factorisation stream empty for
+# part of a set; with two the next set is always enqueued.  (The pool keeps three spares per size class for the extra operators alive.)
+LOOKAHEAD = int(os.environ.get('HELM_BENCH_LOOKAHEAD', '2'))
 
 import numpy as np
 
@@ -711,7 +715,7 @@ def main():
         npipes = max(1, int(os.environ.get('HELM_BENCH_PIPES', '1')))
 
         def one_pipe(its):
-            return list(dispatch.pipelined(its, device=local, lookahead=int(os.environ.get('HELM_BENCH_LOOKAHEAD', '1')), strict=os.environ.get('HELM_BENCH_STRICT', '0') == '1',
+            return list(dispatch.pipelined(its, device=local, lookahead=LOOKAHEAD, strict=os.environ.get('HELM_BENCH_STRICT', '0') == '1',
                                            solvers=nsolvers, group=args.group, group_prepare=prefactor_many if args.group > 1 else None))
         if npipes <= 1:
             return one_pipe(items)
@@ -735,7 +739,7 @@ def main():
         if spares:                       # (the barrier that OPENS a pass: the pool's spares are topped up here, between passes, never inside one)
             try:
                 from zephyr_amd import _lib as _zlb
-                _zlb.load().helm_pool_spares(local, int(os.environ.get('HELM_POOL_SPARE', '2')))
+                _zlb.load().helm_pool_spares(local, int(os.environ.get('HELM_POOL_SPARE', '3')))
             except Exception:
                 pass
         torch.cuda.synchronize()
