@@ -84,6 +84,7 @@ class _QuietBlas(object):
     _lock = threading.Lock()
     _depth = 0
     _limiter = None
+    _controller = None
 
     @classmethod
     def enter(cls):
@@ -91,8 +92,10 @@ class _QuietBlas(object):
             cls._depth += 1
             if cls._depth == 1 and os.environ.get('HELM_QUIET_BLAS', '1') != '0':
                 try:
-                    from threadpoolctl import threadpool_limits
-                    cls._limiter = threadpool_limits(limits=1)
+                    if cls._controller is None:        # (looking the process's BLAS / OpenMP libraries up costs 0.5 ms with torch loaded; the limit itself 0.03)
+                        from threadpoolctl import ThreadpoolController
+                        cls._controller = ThreadpoolController()
+                    cls._limiter = cls._controller.limit(limits=1)
                 except Exception:
                     cls._limiter = None
 
