@@ -247,9 +247,35 @@ def pinned_reserve(shape, count, dtype=np.complex128):
 
 
 def to_device(arr, dev, dtype=None):
-    'numpy array -> torch tensor on `dev` (contiguous, cast to dtype if given)'
+    """numpy array -> torch tensor on `dev` (contiguous, cast to dtype if given), staged through a pinned buffer of the library.
+
+    Never hand the caller's pageable array to the runtime: for a copy of more than a few hundred KB HIP pins the caller's pages in place (a user-pointer
+    registration), and when that memory goes back to the system afterwards -- numpy frees a temporary of a few MB with munmap -- the kernel driver takes EVERY
+    queue of the process off the GPU until the registration has been dealt with: 15-20 ms in which nothing of this process runs, charged to whatever is
+    submitted next (round 6: config 4's dpred(m), profiles/r06_config4_dpred_spread.txt; with glibc told never to unmap, all of them were gone)."""
     import torch
-    return torch.from_numpy(np.ascontiguousarray(arr, dtype=dtype)).to(dev)
+    a = np.ascontiguousarray(arr, dtype=dtype)
+    if a.nbytes < (64 << 10):                       # (small copies go through the runtime's own staging buffer: nothing is registered)
+        return torch.from_numpy(a).to(dev)
+    host = pinned_empty(a.shape, a.dtype)
+    host[...] = a
+    return torch.from_numpy(host).to(dev)           # (synchronous: the pinned block goes back to the library's pool when `host` does)
+
+
+_TORCH_NP = {'torch.complex128': np.complex128, 'torch.complex64': np.complex64, 'torch.float64': np.float64, 'torch.float32': np.float32,
+             'torch.int64': np.int64, 'torch.int32': np.int32, 'torch.uint8': np.uint8}
+
+
+def from_device(t):
+    """torch tensor on a GPU -> numpy array, through a pinned buffer of the library (see to_device: a device-to-host copy into pageable memory registers the
+    destination's pages the same way).  The array returned is ordinary memory the runtime has never seen."""
+    import torch
+    t = t.contiguous()
+    if t.numel() * t.element_size() < (64 << 10):
+        return t.cpu().numpy()
+    host = pinned_empty(tuple(t.shape), _TORCH_NP[str(t.dtype)])
+    torch.from_numpy(host).copy_(t)
+    return np.array(host)
 
 
 def wait_torch_stream(dev, spin_ms=None):

@@ -853,17 +853,91 @@ extern "C" int helm_last_timing(const helm_op *op, helm_timing *out) { if (!op |
 extern "C" int helm_num_blocks(const helm_op *op) { return op ? op->nblocks : HELM_ERR_ARG; }
 extern "C" long long helm_num_points(const helm_op *op) { return op ? op->N : HELM_ERR_ARG; }
 
+// Host array -> device through pinned buffers of the library (two chunks of 4 MB from the host pool: the memcpy of chunk k+1 runs beside the DMA of chunk k); the
+// caller's pages are never handed to the runtime.  A copy of a few MB straight from pageable memory makes HIP pin the caller's pages in place (a user-pointer
+// registration); when those pages go back to the system afterwards -- numpy frees an array of that size with munmap -- the kernel driver takes EVERY queue of the
+// process off the GPU while it deals with the registration: 15-20 ms in which nothing of this process runs, charged to whatever is submitted next (round 6:
+// one dpred(m) of config 4 in three took 55-65 ms instead of 39; with glibc told never to unmap, none did -- profiles/r06_config4_dpred_spread.txt).
+namespace {
+std::mutex g_upload_mu;
+std::map<int, std::vector<hipEvent_t>> g_upload_events;              // per device, recycled (an event per chunk buffer of an upload in flight)
+}
+// is this host address memory the runtime already knows as pinned (hipHostMalloc / hipHostRegister, the library's own host pool included)?
+static bool host_ptr_is_pinned(const void *p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+// One direction of a staged copy: `up` host -> device, else device -> host; returns when the data is where it was asked to be.
+static int copy_staged(helm_op *op, void *dst, const void *src, size_t bytes, bool up) {
+    const size_t chunk = (size_t)4 << 20;
+    if (bytes == 0) return HELM_OK;
+    if (host_ptr_is_pinned(up ? src : dst)) {                     // nothing to protect: the runtime moves it straight
+        if (hipMemcpyAsync(dst, src, bytes, up ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, op->stream) != hipSuccess || hipStreamSynchronize(op->stream) != hipSuccess) {
+            (void)hipGetLastError(); helm_set_error(op, "host / device copy failed"); return HELM_ERR_DEVICE;
+        }
+        return HELM_OK;
+    }
+    const int nbuf = bytes > chunk ? 2 : 1;
+    char *buf[2] = {(char *)helm_hostpool_alloc(chunk), nbuf > 1 ? (char *)helm_hostpool_alloc(chunk) : nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    {
+        std::lock_guard<std::mutex> lk(g_upload_mu);
+        std::vector<hipEvent_t> &v = g_upload_events[op->device];
+        for (int b = 0; b < nbuf; ++b) if (!v.empty()) { ev[b] = v.back(); v.pop_back(); }
+    }
+    int rc = HELM_OK;
+    for (int b = 0; b < nbuf; ++b) {
+        if (!buf[b]) rc = HELM_ERR_DEVICE;
+        if (!ev[b] && hipEventCreateWithFlags(&ev[b], hipEventDisableTiming) != hipSuccess) { ev[b] = nullptr; rc = HELM_ERR_DEVICE; }
+    }
+    bool used[2] = {false, false};
+    size_t pend_off[2] = {0, 0}, pend_n[2] = {0, 0};             // (down: the chunk that sits in buf[b] and still has to reach the caller's array)
+    for (size_t off = 0, k = 0; off < bytes && rc == HELM_OK; off += chunk, ++k) {
+        const int b = (int)(k % nbuf);
+        const size_t n = std::min(chunk, bytes - off);
+        if (used[b]) {
+            if (hipEventSynchronize(ev[b]) != hipSuccess) { rc = HELM_ERR_DEVICE; break; }
+            if (!up) memcpy((char *)dst + pend_off[b], buf[b], pend_n[b]);
+        }
+        if (up) memcpy(buf[b], (const char *)src + off, n);
+        const hipError_t e = up ? hipMemcpyAsync((char *)dst + off, buf[b], n, hipMemcpyHostToDevice, op->stream)
+                                : hipMemcpyAsync(buf[b], (const char *)src + off, n, hipMemcpyDeviceToHost, op->stream);
+        if (e != hipSuccess || hipEventRecord(ev[b], op->stream) != hipSuccess) { rc = HELM_ERR_DEVICE; break; }
+        used[b] = true; pend_off[b] = off; pend_n[b] = n;
+    }
+    // (the chunks still in flight, oldest first)
+    const size_t nchunks = (bytes + chunk - 1) / chunk;
+    for (int q = 0; q < nbuf; ++q) {
+        const int b = (int)((nchunks + q) % nbuf);
+        if (used[b]) {
+            if (hipEventSynchronize(ev[b]) != hipSuccess) rc = HELM_ERR_DEVICE;
+            else if (!up && rc == HELM_OK) memcpy((char *)dst + pend_off[b], buf[b], pend_n[b]);
+            used[b] = false;
+        }
+    }
+    for (int b = 0; b < nbuf; ++b) if (buf[b]) helm_hostpool_free(buf[b], chunk);
+    {
+        std::lock_guard<std::mutex> lk(g_upload_mu);
+        for (int b = 0; b < nbuf; ++b) if (ev[b]) g_upload_events[op->device].push_back(ev[b]);
+    }
+    if (rc) { (void)hipGetLastError(); helm_set_error(op, "host / device copy failed"); }
+    return rc;
+}
+int helm_upload_staged(helm_op *op, void *dst, const void *src, size_t bytes) { return copy_staged(op, dst, src, bytes, true); }
+int helm_download_staged(helm_op *op, void *dst, const void *src, size_t bytes) { return copy_staged(op, dst, src, bytes, false); }
+
 extern "C" int helm_set_model(helm_op *op, const double *c, const double *rho, const double *theta, const double *eps, const double *delta) {
     helm_tuning_refresh();
     if (!op || !c) return HELM_ERR_ARG;
     HIP_TRY(op, hipSetDevice(op->device));
     const size_t N = (size_t)op->N;
-    HIP_TRY(op, hipMemcpyAsync(op->d_c, c, N * sizeof(cplx), hipMemcpyHostToDevice, op->stream));
+    if (helm_upload_staged(op, op->d_c, c, N * sizeof(cplx))) return HELM_ERR_DEVICE;
     if (!rho) {   // Gardner default 310 * Re(c)^0.25  (discretization.py:70), evaluated on the device
         const int rcg = helm_launch_gardner_rho(op);
         if (rcg) return rcg;
     } else {
-        HIP_TRY(op, hipMemcpyAsync(op->d_rho, rho, N * sizeof(double), hipMemcpyHostToDevice, op->stream));
+        if (helm_upload_staged(op, op->d_rho, rho, N * sizeof(double))) return HELM_ERR_DEVICE;
     }
     op->aniso = false;
     bool m3zero = true;
@@ -871,7 +945,7 @@ extern "C" int helm_set_model(helm_op *op, const double *c, const double *rho, c
         auto up = [&](double *&dst, const double *src) -> int {
             if (!src) { if (dst) { helm_pool_free(op->device, dst, N * sizeof(double)); dst = nullptr; } return 0; }
             if (!dst) { dst = (double *)helm_pool_alloc(op->device, N * sizeof(double)); if (!dst) return -1; }
-            return hipMemcpyAsync(dst, src, N * sizeof(double), hipMemcpyHostToDevice, op->stream) != hipSuccess ? -1 : 0;
+            return helm_upload_staged(op, dst, src, N * sizeof(double)) ? -1 : 0;
         };
         if (up(op->d_theta, theta) || up(op->d_eps, eps) || up(op->d_delta, delta)) HELM_FAIL(op, HELM_ERR_DEVICE, "anisotropy upload failed");
         op->aniso = theta || eps || delta;
@@ -976,7 +1050,7 @@ extern "C" int helm_get_diagonals(helm_op *op, double *out) {
     if (!op->assembled) HELM_FAIL(op, HELM_ERR_STATE, "operator not assembled");
     HIP_TRY(op, hipSetDevice(op->device));
     { const int rcb = helm_need_all_blocks(op); if (rcb) return rcb; }
-    HIP_TRY(op, hipMemcpy(out, op->d_C, (size_t)op->nblocks * op->nplanes * op->N * sizeof(cplx), hipMemcpyDeviceToHost));
+    if (helm_download_staged(op, out, op->d_C, (size_t)op->nblocks * op->nplanes * op->N * sizeof(cplx))) return HELM_ERR_DEVICE;
     return HELM_OK;
 }
 
@@ -1079,9 +1153,9 @@ extern "C" int helm_apply(helm_op *op, int block, int adjoint, const double *X, 
     HIP_TRY(op, hipMalloc(&dX, bytes));
     if (hipMalloc(&dY, bytes) != hipSuccess) { hipFree(dX); HELM_FAIL(op, HELM_ERR_DEVICE, "hipMalloc failed"); }
     int rc = HELM_OK;
-    if (hipMemcpy(dX, X, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = HELM_ERR_DEVICE;
+    if (helm_upload_staged(op, dX, X, bytes)) rc = HELM_ERR_DEVICE;
     if (!rc) rc = helm_apply_device(op, block, adjoint, dX, dY, nrhs);
-    if (!rc && hipMemcpy(Y, dY, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = HELM_ERR_DEVICE;
+    if (!rc && helm_download_staged(op, Y, dY, bytes)) rc = HELM_ERR_DEVICE;
     hipFree(dX); hipFree(dY);
     return rc;
 }
@@ -2482,9 +2556,9 @@ extern "C" int helm_solve(helm_op *op, const double *RHS, double *U, int nrhs, l
     void *dR = helm_pool_alloc(op->device, bytes), *dU = helm_pool_alloc(op->device, bytes);
     if (!dR || !dU) { helm_pool_free(op->device, dR, bytes); helm_pool_free(op->device, dU, bytes); HELM_FAIL(op, HELM_ERR_DEVICE, "hipMalloc failed"); }
     int rc = HELM_OK;
-    if (hipMemcpy(dR, RHS, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = HELM_ERR_DEVICE;
+    if (helm_upload_staged(op, dR, RHS, bytes)) rc = HELM_ERR_DEVICE;
     if (!rc) rc = helm_solve_device(op, dR, dU, nrhs, rows, premul_re, premul_im, opts, info);
-    if (rc >= 0 && hipMemcpy(U, dU, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = HELM_ERR_DEVICE;
+    if (rc >= 0 && helm_download_staged(op, U, dU, bytes)) rc = HELM_ERR_DEVICE;
     hipStreamSynchronize(op->stream);
     helm_pool_free(op->device, dR, bytes); helm_pool_free(op->device, dU, bytes);
     return rc;
@@ -2578,9 +2652,8 @@ extern "C" int helm_solve_coo(helm_op *op, const long long *row, const int *col,
             release();
             HELM_FAIL(op, HELM_ERR_ARG, "sparse right-hand side: entry %lld addresses (row %lld, column %d) outside the %lld x %d right-hand-side matrix", k, row[k], col[k], rows, nrhs);
         }
-    if (nnz > 0 && (hipMemcpyAsync(d_row, row, nnz * sizeof(long long), hipMemcpyHostToDevice, op->stream) != hipSuccess ||
-                    hipMemcpyAsync(d_val, val, nnz * sizeof(cplx), hipMemcpyHostToDevice, op->stream) != hipSuccess ||
-                    hipMemcpyAsync(d_col, col, nnz * sizeof(int), hipMemcpyHostToDevice, op->stream) != hipSuccess)) rc = HELM_ERR_DEVICE;
+    if (nnz > 0 && (helm_upload_staged(op, d_row, row, nnz * sizeof(long long)) || helm_upload_staged(op, d_val, val, nnz * sizeof(cplx)) ||
+                    helm_upload_staged(op, d_col, col, nnz * sizeof(int)))) rc = HELM_ERR_DEVICE;
     const int flags = opts ? opts->flags : 0;
     if (!rc) rc = helm_launch_rhs_from_coo(op, d_row, d_col, d_val, nnz, (cplx *)dR, nrhs, rows, (flags & HELM_RHS_NODE_MAJOR) ? 1 : 0);
     if (!rc && hipStreamSynchronize(op->stream) != hipSuccess) rc = HELM_ERR_DEVICE;
@@ -2590,7 +2663,7 @@ extern "C" int helm_solve_coo(helm_op *op, const long long *row, const int *col,
         (void)helm_set_rhs_support(op, dBits, rows, nrhs);
     if (!rc) rc = helm_solve_device(op, dR, dU, nrhs, rows, premul_re, premul_im, opts, info);
     (void)helm_set_rhs_support(op, nullptr, 0, 0);          // (the bits live in dT, which goes back to the pool below: never leave a pointer to them behind)
-    if (rc >= 0 && hipMemcpy(U, dU, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = HELM_ERR_DEVICE;
+    if (rc >= 0 && helm_download_staged(op, U, dU, bytes)) rc = HELM_ERR_DEVICE;
     release();
     return rc;
 }

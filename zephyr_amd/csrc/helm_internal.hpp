@@ -245,6 +245,8 @@ void helm_pool_free(int device, void *p, size_t bytes);   // the buffer must no 
 size_t helm_pool_idle_bytes(int device);                  // what the pool holds idle on that device (not in hipMemGetInfo's free figure)
 hipError_t helm_malloc_retry(int device, void **p, size_t bytes);   // hipMalloc; on failure the device's idle pool is emptied and the call repeated
 void *helm_hostpool_alloc(size_t bytes);                  // pinned host memory, recycled by size
+int helm_download_staged(helm_op *op, void *dst, const void *src, size_t bytes);    // device -> caller's host array, the same way
+int helm_upload_staged(helm_op *op, void *dst, const void *src, size_t bytes);      // caller's host array -> device on op->stream through the library's pinned chunks (capi.hip); returns when the copy is done
 void helm_hostpool_free(void *p, size_t bytes);
 hipStream_t helm_stream_acquire(int device, int prio);    // prio 0 normal, 1 highest, -1 lowest; recycled across handles
 void helm_stream_release(int device, int prio, hipStream_t s);

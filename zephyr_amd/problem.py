@@ -339,11 +339,11 @@ class HelmBaseProblem(BaseModelDependent, BaseSCCache):
             if self._sharded:
                 parallel.allreduce_sum_device(G)
             torch.cuda.synchronize(G.device)
-            return G.cpu().numpy()
+            return _lib.from_device(G)
         g = np.zeros(N, dtype=np.complex128)
         for G in parts:                                   # per-GPU partial gradients: 16 B per grid point each
             torch.cuda.synchronize(G.device)
-            g += G.cpu().numpy()
+            g += _lib.from_device(G)
         return parallel.allreduce_sum(g) if self._sharded else g
 
     def _dpredDevice(self, owned):
@@ -378,7 +378,7 @@ class HelmBaseProblem(BaseModelDependent, BaseSCCache):
             op.rhsFromSparseDevice(sp.csc_matrix(q)[:, c0:c1], R.data_ptr())
             op.solveDevice(R.data_ptr(), U.data_ptr(), k, N)
             op.sampleDevice(U.data_ptr(), k, state['csr'], out.data_ptr())      # (returns when the samples are there: helm_sample_device waits for its own stream)
-            data[:, c0:c1, ifreq] = scale * out.cpu().numpy()          # (disjoint slices per item: no two workers write the same entries)
+            data[:, c0:c1, ifreq] = scale * _lib.from_device(out)          # (disjoint slices per item: no two workers write the same entries)
             return None
         self._runOnDevices(devs, items, one)
         return data
