@@ -164,7 +164,11 @@ int helm_solve_device(helm_op *op, const void *dRHS, void *dU, int nrhs, long lo
  * Here only the triplets cross PCIe; U (host, nrhs*rows complex128, layout per opts->flags) receives the wavefields. */
 int helm_solve_coo(helm_op *op, const long long *row, const int *col, const double *val, long long nnz, double *U, int nrhs,
                    long long rows, double premul_re, double premul_im, const helm_solve_opts *opts, helm_solve_info *info);
-/* Pinned host memory for result arrays (device-to-host copies into it run at the PCIe rate); recycled by size. */
+/* Pinned host memory for result arrays (device-to-host copies into it run at the PCIe rate); recycled by size.
+ * Host arrays in general (r6): every entry point above that takes one (helm_set_model, helm_apply, helm_solve, helm_solve_coo, helm_get_diagonals) moves it through
+ * pinned 4-MB chunks of the library unless the array is pinned memory itself (this call, hipHostMalloc, hipHostRegister) -- then it is copied straight, which is
+ * what a caller with GBs of wavefields wants.  The caller's pageable pages are never registered with the runtime: memory registered that way and later unmapped
+ * (free() of a large array) makes the kernel driver evict every queue of the process for 15-20 ms (profiles/r06_config4_dpred_spread.txt). */
 void *helm_host_alloc(size_t bytes);
 void helm_host_free(void *p, size_t bytes);
 
