@@ -469,6 +469,9 @@ def config4_leg(local, world, rank, dist, backend):
         return float(t.item())
     # ONE problem / survey pair, the model handed in like an inversion does it (`dpred(m)`, `Jtvec(m, v)`: problem.py:51-66 updateModel): the survey's source and
     # receiver matrices are built once, each model gets its own operators and factorisations
+    import gc
+    gc.collect()                                               # (arrays of the legs before this one that only the collector can free go now, not inside a timed call:
+                                                               #  unmapping host memory the runtime has registered stalls the process's queues)
     prob, surv = pair(ctrue)
     dobs = surv.dpred()                                        # (also the warm-up of the pools for the timed calls below)
     mcur, mtrue = ccur.ravel(), ctrue.ravel()
@@ -493,7 +496,6 @@ def config4_leg(local, world, rank, dist, backend):
     reps = 5
     t_fwd, t_grad, gpu_fwd, gpu_grad, cg0 = [], [], [], [], cgroup_cpu()
     rt_fwd, rt_grad = [], []                                   # what each timed call made the HIP runtime and the interpreter's collector do (diagnostics)
-    import gc
 
     def rt_of(c0):
         r = _lib.runtime_stats()

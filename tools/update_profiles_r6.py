@@ -92,7 +92,7 @@ if os.path.exists(os.path.join(S, 'bench3d_under_rocprof.txt')):
 # headline reproducibility: the driver's command in fresh processes on fresh leases
 runs = []
 for tag, path in [('this lease, first GPU process of the box (all legs)', os.path.join(S, 'bench_driver.json'))] + [('this lease, fresh process %d' % i, os.path.join(S, 'headline_%d.json' % i)) for i in (1, 2, 3)] + \
-        [('other lease: ' + os.path.relpath(p, ROOT), p) for p in OTHER]:
+        [('separate gpurun call: ' + os.path.relpath(p, ROOT), p) for p in OTHER]:
     if os.path.exists(path) and open(path).read().strip():
         try:
             r = last_json(path)
@@ -158,7 +158,7 @@ findings of the round (written from the `gpurun` outputs of the day, commands in
 
 ## Is the headline reproducible?  (`r06_headline_repro.json`)
 
-The driver's command in fresh processes, on this lease and on other leases of the day: **min {rep['min']:.0f} / median {rep['median']:.0f} / max {rep['max']:.0f} wavefields/s**
+The driver's command in fresh processes, on this lease and in separate gpurun calls of the day: **min {rep['min']:.0f} / median {rep['median']:.0f} / max {rep['max']:.0f} wavefields/s**
 over {rep['n']} runs (max / min = {rep['spread_max_over_min']:.3f}).  Round 5's driver run measured 10 914 for a command that gave 13 950-14 630 here.
 
 | run | wavefields/s | ms per step | `unprofiled_wfs` | longest item gap, ms | device allocations in the timed region | cgroup throttling in the timed region, ms |
