@@ -209,6 +209,7 @@ def test_single_precision_work_vectors_cost_the_krylov_method_nothing(helm_lib, 
     import zephyr_amd as za
     cfg, q, ref = small_lu
     monkeypatch.setenv('HELM_MG3_KEEP', '2')
+    monkeypatch.setenv('HELM_MG3_DEPTH_MODEL', '0')                  # (both builds on the same hierarchy: the cost model's verdict depends on timed set-ups)
     its = {}
     for f32 in ('1', '0'):
         monkeypatch.setenv('HELM_MG3_F32', f32)

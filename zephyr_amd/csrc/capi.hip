@@ -858,6 +858,30 @@ extern "C" long long helm_num_points(const helm_op *op) { return op ? op->N : HE
 // registration); when those pages go back to the system afterwards -- numpy frees an array of that size with munmap -- the kernel driver takes EVERY queue of the
 // process off the GPU while it deals with the registration: 15-20 ms in which nothing of this process runs, charged to whatever is submitted next (round 6:
 // one dpred(m) of config 4 in three took 55-65 ms instead of 39; with glibc told never to unmap, none did -- profiles/r06_config4_dpred_spread.txt).
+// The few small kernels of an operator's set-up (default density, assembly) go to a stream of another priority class than the operator's own for the duration of
+// the call.  Streams of one priority class share a handful of hardware queues, each of them in order: on the operator's normal-priority stream an 8-us kernel of
+// the NEXT operator's set-up sat behind whatever solve had been queued on the same hardware queue -- helm_set_model / helm_assemble took 10-20 ms of the
+// pipeline's prepare thread in every other set (tools/pipeline_timeline.py: the call ended when the other thread's helm_solve_device did).  The low class is
+// used by nothing else on the 2-D path.  Top-level operators only: a multigrid level's operator shares its parent's stream and must stay in its order.
+namespace {
+struct SetupStream {
+    helm_op *op; hipStream_t keep, tmp = nullptr; int prio;
+    explicit SetupStream(helm_op *o) : op(o), keep(o->stream) {
+        static const int pr = getenv("HELM_SETUP_PRIO") ? atoi(getenv("HELM_SETUP_PRIO")) : -1;
+        prio = pr;
+        if (pr == 0 || !o->own_stream || o->block0_only || !keep) return;
+        if (hipStreamSynchronize(keep) != hipSuccess) { (void)hipGetLastError(); return; }        // (nothing of this operator is in flight when its model or frequency changes)
+        tmp = helm_stream_acquire(o->device, prio);
+        if (tmp) o->stream = tmp;
+    }
+    ~SetupStream() {
+        if (!tmp) return;
+        (void)hipStreamSynchronize(tmp);
+        op->stream = keep;
+        helm_stream_release(op->device, prio, tmp);
+    }
+};
+}
 namespace {
 std::mutex g_upload_mu;
 std::map<int, std::vector<hipEvent_t>> g_upload_events;              // per device, recycled (an event per chunk buffer of an upload in flight)
@@ -872,8 +896,18 @@ static bool host_ptr_is_pinned(const void *p) {
 static int copy_staged(helm_op *op, void *dst, const void *src, size_t bytes, bool up) {
     const size_t chunk = (size_t)4 << 20;
     if (bytes == 0) return HELM_OK;
+    // The copies run on a stream of another priority class (xs; the low one, which the 2-D path uses for nothing else), not on the operator's: the copy of a chunk is a small kernel (or an SDMA packet behind one), and
+    // on the operator's normal-priority stream it waited its turn behind the solve kernels of other operators -- a 24-MB model took 10 ms of the pipeline's prepare
+    // thread in every other set (tools/pipeline_timeline.py).  The call returns when the data has arrived, so nothing the operator's stream gets afterwards can
+    // overtake it; what that stream has queued BEFORE the call is waited for first (a download reads what those launches produce).
+    hipStream_t ops = op->stream;
+    if (hipStreamSynchronize(ops) != hipSuccess) { (void)hipGetLastError(); helm_set_error(op, "host / device copy failed"); return HELM_ERR_DEVICE; }
+    static const int xprio = getenv("HELM_XFER_PRIO") ? atoi(getenv("HELM_XFER_PRIO")) : -1;
+    hipStream_t xs = helm_stream_acquire(op->device, xprio);
+    if (!xs) { helm_set_error(op, "host / device copy: no stream"); return HELM_ERR_DEVICE; }
+    struct XsGuard { int dev, prio; hipStream_t s; ~XsGuard() { helm_stream_release(dev, prio, s); } } xs_guard{op->device, xprio, xs};
     if (host_ptr_is_pinned(up ? src : dst)) {                     // nothing to protect: the runtime moves it straight
-        if (hipMemcpyAsync(dst, src, bytes, up ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, op->stream) != hipSuccess || hipStreamSynchronize(op->stream) != hipSuccess) {
+        if (hipMemcpyAsync(dst, src, bytes, up ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, xs) != hipSuccess || hipStreamSynchronize(xs) != hipSuccess) {
             (void)hipGetLastError(); helm_set_error(op, "host / device copy failed"); return HELM_ERR_DEVICE;
         }
         return HELM_OK;
@@ -901,9 +935,9 @@ static int copy_staged(helm_op *op, void *dst, const void *src, size_t bytes, bo
             if (!up) memcpy((char *)dst + pend_off[b], buf[b], pend_n[b]);
         }
         if (up) memcpy(buf[b], (const char *)src + off, n);
-        const hipError_t e = up ? hipMemcpyAsync((char *)dst + off, buf[b], n, hipMemcpyHostToDevice, op->stream)
-                                : hipMemcpyAsync(buf[b], (const char *)src + off, n, hipMemcpyDeviceToHost, op->stream);
-        if (e != hipSuccess || hipEventRecord(ev[b], op->stream) != hipSuccess) { rc = HELM_ERR_DEVICE; break; }
+        const hipError_t e = up ? hipMemcpyAsync((char *)dst + off, buf[b], n, hipMemcpyHostToDevice, xs)
+                                : hipMemcpyAsync(buf[b], (const char *)src + off, n, hipMemcpyDeviceToHost, xs);
+        if (e != hipSuccess || hipEventRecord(ev[b], xs) != hipSuccess) { rc = HELM_ERR_DEVICE; break; }
         used[b] = true; pend_off[b] = off; pend_n[b] = n;
     }
     // (the chunks still in flight, oldest first)
@@ -932,6 +966,7 @@ extern "C" int helm_set_model(helm_op *op, const double *c, const double *rho, c
     if (!op || !c) return HELM_ERR_ARG;
     HIP_TRY(op, hipSetDevice(op->device));
     const size_t N = (size_t)op->N;
+    SetupStream setup_stream(op);
     if (helm_upload_staged(op, op->d_c, c, N * sizeof(cplx))) return HELM_ERR_DEVICE;
     if (!rho) {   // Gardner default 310 * Re(c)^0.25  (discretization.py:70), evaluated on the device
         const int rcg = helm_launch_gardner_rho(op);
@@ -1011,6 +1046,7 @@ extern "C" int helm_assemble(helm_op *op, double freq_re, double freq_im, double
     // quarters of the 604 MB the assembly writes at 1024^2 -- are built when something asks for them (helm_need_all_blocks: a stacked 2N right-hand side,
     // helm_get_diagonals, an apply of another block, the scaled planes of the Krylov paths)
     op->asm_nblk = (op->variant == HELM_EURUS && op->block_zero[2] && !op->block0_only && helm_tuning_now().auto_direct != 0) ? 1 : 4;
+    SetupStream setup_stream(op);
     int rc = op->ny > 0 ? helm3d_launch_assemble(op, freq_re, freq_im, tau, cPML) : helm_launch_assemble(op, freq_re, freq_im, tau, ky, cPML);
     if (rc) return rc;
     op->scaled_ok = false;

@@ -119,6 +119,32 @@ __global__ __launch_bounds__(256) void k_fwd_flags(const int4 *__restrict__ tab,
     for (int i = 0; i < NR; ++i) if (rows[i] >= 0) Xt[(long long)rows[i] * ldx + col] = cmake(0.0, 0.0);      // y_S = 0 where the back substitution will look for it
 }
 
+// The leaves' flags (no declared support): one workgroup per leaf, wave w looks at the column blocks w, w + 4, ... -- the four waves of a workgroup read the 4 KB of
+// a right-hand-side row side by side (k_fwd_flags<32, 2> gave a pair of waves 1 KB of it each: 736 us for the 3.2 GB of leaf rows of the 1024^2 x 256 job, 0.54 of
+// the HBM rate).  Rows in passes of NR, every load of a pass in flight at once.  Same decisions, same flags.
+template <int NR>
+__global__ __launch_bounds__(256) void k_leaf_flags(const int4 *__restrict__ tab, int nmax, int smax, int first, int nct, int *__restrict__ act,
+                                                    const cplx *__restrict__ Q, int ldx, int nrhs) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x;
+    const int4 *t = tab + (long long)j * nmax;
+    for (int b = wave; b < nct; b += 4) {
+        const int col = 64 * b + lane;
+        int nz = 0;
+        for (int r0 = 0; r0 < smax; r0 += NR) {
+            int rows[NR];
+            #pragma unroll
+            for (int i = 0; i < NR; ++i) { const int r = r0 + i; const int4 e = r < smax ? t[r] : make_int4(-1, -1, -1, 0); rows[i] = (e.w && col < nrhs) ? e.x : -1; }
+            cplx v[NR];
+            #pragma unroll
+            for (int i = 0; i < NR; ++i) v[i] = *(rows[i] >= 0 ? Q + (long long)rows[i] * ldx + col : g_fwd_zero);
+            #pragma unroll
+            for (int i = 0; i < NR; ++i) nz |= (v[i].x != 0.0 || v[i].y != 0.0) ? 1 : 0;
+        }
+        if (__any(nz) && lane == 0) act[(long long)(first + j) * nct + b] = 1;
+    }
+}
+
 struct SolveCtx {
     const int4 *tab; cplx *Xt, *arenaV; int nrhs; dim3 rb; int use_idx;
     const cplx *Qt;       // node-major right-hand sides (read only); == Xt for an in-place solve
@@ -179,15 +205,12 @@ void forward_group_batched(helm_op *op, NdFactor *f, size_t gi, const SolveCtx &
         // leaves have no children: the outgoing ring part is -G21 x_S with x_S read straight from Xt
         GemmRows R; R.tabB = c.tab + g.roff; R.offB = 0; R.tab_stride = nmax; R.Bx = c.Qt; R.ldx = nrhs;
         R.act = c.act; R.nct = c.nct; R.first = g.first; R.hint = R.act ? c.act_hint : 0;
-        // r5: without a declared support the leaves' flags are found by k_fwd_flags (a wave pair per leaf and block of 64 columns, every load in flight at
+        // r5: without a declared support the leaves' flags are found by a scan of their own (every load of a pass in flight at
         // once) and the product then behaves as with a declared one: a workgroup whose flags are down leaves on one load.  (It used to find out itself:
         // 753 us for the 3.2 GB of leaf rows, 54 % of the HBM rate, from workgroups of 134 registers per lane.)
         if (R.act && !R.hint && c.flist && g.smax <= 64 && c.Qt != c.Xt && helm_tuning_now().nd_leaf_idle != 0) {
-            for (int j0 = 0; j0 < g.cnt; j0 += 32768) {
-                const int nbj = std::min(32768, g.cnt - j0), pairs = nbj * c.nct;
-                HELM_LAUNCH((k_fwd_flags<32, 2>), dim3((pairs + 1) / 2), dim3(256), 0, op->stream, c.tab + g.roff + (long long)j0 * nmax, nmax, g.smax,
-                                   (const NdDev *)f->pd->d_nodes, g.first + j0, nbj, c.nct, c.act, c.Qt, c.Xt, nrhs, nrhs, c.fcount + gi, c.flist, 1);
-            }
+            // (r6: one workgroup per leaf -- k_leaf_flags: 734 -> 561 us on the 1024^2 x 256 job, 0.54 -> 0.71 of the HBM rate)
+            HELM_LAUNCH((k_leaf_flags<25>), dim3(g.cnt), dim3(256), 0, op->stream, c.tab + g.roff, nmax, g.smax, g.first, c.nct, c.act, c.Qt, nrhs, nrhs);
             R.hint = 1;
         }
         gemm(op, g.mmax, nrhs, g.smax, mone, nd_fac_at(f, g.g21, (long long)g.mmax * g.smax), g.smax, nd_fac_stride(f, (long long)g.mmax * g.smax), nullptr, 0, 0, zero,
