@@ -28,9 +28,9 @@ for _k in ('OPENBLAS_NUM_THREADS', 'OMP_NUM_THREADS', 'MKL_NUM_THREADS'):
 # the library's pool tops its spares up by itself when a device's last operator is destroyed -- which is how every pass of this file ENDS, inside its timing
 # window; here the top-ups are asked for between the passes instead (barrier(), helm_pool_spares)
 os.environ.setdefault('HELM_POOL_SPARE_AUTO', '0')
-# items the device pipeline's prepare thread may be ahead of its solve thread.  Round 6, four fresh processes each (profiles/r06_lookahead.txt): 1 -> 14 747 - 15 087
-# wavefields/s, 2 -> 15 356 - 15 545, 3 -> 15 141 - 15 314: with one item of slack a late hand-over between the two threads leaves the factorisation stream empty for
-# part of a set; with two the next set is always enqueued.  (The pool keeps three spares per size class for the extra operators alive.)
+# items the device pipeline's prepare thread may be ahead of its solve thread (profiles/r06_lookahead.txt).  Two absorbed the prepare thread's 10-20 ms waits
+# behind another operator's solve while those existed (1 -> 14 747 - 15 087 wavefields/s, 2 -> 15 356 - 15 545); since the set-up kernels run on a hardware
+# queue of their own, 1, 2 and 3 give the same 15 500 - 15 800.  Two stays: slack against a late hand-over costs one more operator alive (three pool spares).
 LOOKAHEAD = int(os.environ.get('HELM_BENCH_LOOKAHEAD', '2'))
 
 import numpy as np
