@@ -38,6 +38,8 @@ class ConfigMeta(type):
 def cast_value(cast, value):
     if cast is None or value is None:
         return value
+    if cast in (np.complex128, np.float64) and isinstance(value, np.ndarray) and value.ndim > 0 and not value.flags.writeable and value.dtype == np.dtype(cast):
+        return value                     # (a read-only array of the right type is somebody's private copy already: discretization._spConfigs)
     try:
         return cast(value)
     except TypeError:
