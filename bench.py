@@ -620,11 +620,20 @@ def main():
     import torch
     import torch.distributed as dist
     backend = os.environ.get('HELM_BENCH_BACKEND', 'nccl')      # 'gloo' only for single-GPU dry runs of the N>1 logic
+    ndev = max(1, torch.cuda.device_count())               # (counting devices does not initialise the GPU)
+    if world > 1 and backend == 'nccl' and int(os.environ.get('LOCAL_WORLD_SIZE', world)) > ndev:
+        # more ranks than GPUs on this node (a dry run of the N > 1 logic on a one-GPU box): RCCL refuses two ranks on one device
+        sys.stderr.write('[bench] %d ranks on %d GPU(s): collectives through gloo (RCCL wants one device per rank)\n' % (world, ndev))
+        backend = 'gloo'
+    local = local % ndev
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group(backend, rank=rank, world_size=world)
-    local = local % max(1, torch.cuda.device_count())
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device('cuda', local))      # (the rank's own GPU, said explicitly)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
