@@ -132,6 +132,37 @@ def test_operator_times_sparse_and_dense_rhs(helm_lib):
         za.MiniZephyr(cfg) * sp.csr_matrix(qs)[:-1]
 
 
+def test_host_arrays_go_through_pinned_chunks_or_straight(helm_lib):
+    """Round 6: a host array that crosses the C ABI (helm_apply, helm_get_diagonals, helm_set_model) is copied through the library's pinned 4-MB chunks unless
+    it is pinned memory already (helm_host_alloc), which goes straight -- the caller's pageable pages are never registered with the runtime (include/helm.h).
+    Both ways move the same bytes: sizes that end inside a chunk, on a chunk boundary and below one chunk, up and down, against the oracle's matrix."""
+    import zephyr_amd as za
+    from zephyr_amd import _lib
+    cfg = model(300, 273)
+    op = za.MiniZephyr(cfg)
+    N = cfg['nz'] * cfg['nx']
+    planes = op.diagonals()[0]
+    rng = np.random.default_rng(8)
+    for nrhs in (1, 3, 7):                                     # 1.3 MB (one chunk, partly filled), 3.9 MB, 9.2 MB (three chunks, the last one partial)
+        x = rng.standard_normal((N, nrhs)) + 1j * rng.standard_normal((N, nrhs))
+        y_pageable = op.applyForward(x)
+        xp = _lib.pinned_empty((nrhs, N)); xp[...] = x.T
+        yp = _lib.pinned_empty((nrhs, N))
+        _lib.check(helm_lib.helm_apply(op.handle, 0, 0, _lib.ptr(xp), _lib.ptr(yp), nrhs), op.handle)
+        assert np.array_equal(y_pageable, yp.T)
+        assert nrm(y_pageable, ho.stencil_apply(planes, x)) <= 1e-12
+    cfgb = model(512, 512)
+    opb = za.MiniZephyr(cfgb)
+    xb = rng.standard_normal((512 * 512, 2)) + 1j * rng.standard_normal((512 * 512, 2))       # 8 MB: two full chunks, nothing left over
+    yb = opb.applyForward(xb)
+    xp = _lib.pinned_empty((2, 512 * 512)); xp[...] = xb.T
+    yp = _lib.pinned_empty((2, 512 * 512))
+    _lib.check(helm_lib.helm_apply(opb.handle, 0, 0, _lib.ptr(xp), _lib.ptr(yp), 2), opb.handle)
+    assert np.array_equal(yb, yp.T)
+    d1, d2 = opb.diagonals(), opb.diagonals()                  # 37.7 MB down through the chunks, twice
+    assert np.array_equal(d1, d2) and np.all(np.isfinite(d1.view(float)))
+
+
 @pytest.mark.parametrize('cls_name,premul', [('Eurus', None), ('MiniZephyr', None), ('Eurus', 0.3 - 1.7j), ('MiniZephyrHD', None), ('MiniZephyr', 0.3 - 1.7j)])
 def test_direct_output_writes_the_wavefields_of_the_two_step_path(helm_lib, monkeypatch, cls_name, premul):
     """Round 5 (helm_tuning.nd_direct_out): for a full-width node-major batch the back substitution writes u = conj(premul x) into the caller's array
