@@ -183,6 +183,31 @@ def test_visco_multifreq_velocity_and_result():
     assert np.linalg.norm(np.stack(list(vm * g['q'])) - g['visco']) / np.linalg.norm(g['visco']) < 1e-10
 
 
+def test_sub_problems_share_one_private_copy_of_the_model():
+    """Round 6: a dispatcher makes ONE complex128 copy of the velocity model for all its sub-problems (read-only; config.cast_value hands a read-only array of the
+    right type on as it is) -- the reference casts per sub-problem (discretization.py:24-31 through galoshes' initMap).  The caller's array is not aliased: changing it
+    afterwards changes nothing a sub-problem holds; a per-frequency model (ViscoMultiFreq) is cast per sub-problem as before."""
+    g = load('g4_multifreq.npz')
+    nz, nx = g['c'].shape
+    c = np.array(g['c'], dtype=np.float64)
+    sc = dict(nx=nx, nz=nz, dx=10., dz=10., c=c, rho=g['rho'], nPML=6, freqs=list(g['freqs']), Disc=za.MiniZephyr)
+    mf = za.MultiFreq(sc)
+    subs = mf.subProblems
+    assert all(s.c is subs[0].c for s in subs) and subs[0].c.dtype == np.complex128 and not subs[0].c.flags.writeable
+    assert not np.shares_memory(subs[0].c, c)
+    before = subs[0].c.copy()
+    c += 1.0
+    assert np.array_equal(subs[0].c, before)
+    vm = za.ViscoMultiFreq(dict(sc, Q=g['Q'], freqBase=10.))
+    vs = vm.subProblems
+    assert vs[0].c is not vs[1].c
+    w = np.ones((nz, nx), dtype=np.complex128)
+    w.setflags(write=False)
+    assert config.cast_value(np.complex128, w) is w                          # (as numpy's own cast does for an array of that type)
+    f = np.ones((nz, nx)); f.setflags(write=False)
+    assert config.cast_value(np.complex128, f) is not f and config.cast_value(np.complex128, f).dtype == np.complex128
+
+
 def test_wrapper_factors_flag():
     sc = dict(nx=30, nz=20, c=2500., freqs=[5., 6.], Disc=za.MiniZephyr)
     mf = za.MultiFreq(sc)
